@@ -1,0 +1,63 @@
+"""pytest configuration: registers the `gpu` marker, puts the repo root and the product
+package directory (`ac-solver_amd/`, which holds the drop-in `ac_solver` package) on sys.path,
+and offers fixture loaders for tests/golden/."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "ac-solver_amd")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (PKG, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_json(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def load_npz(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.fixture(scope="session")
+def golden_json():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = load_json(name)
+        return cache[name]
+
+    return get
+
+
+@pytest.fixture(scope="session")
+def golden_npz():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = load_npz(name)
+        return cache[name]
+
+    return get
+
+
+def ms_pool_generator_order(ms_pool_json):
+    """The 1190 Miller-Schupp presentations, n outer / lenw inner."""
+    pool = []
+    for n in range(1, 8):
+        d = ms_pool_json["by_n"][str(n)]
+        for w in range(1, 8):
+            pool += d[str(w)]
+    return pool

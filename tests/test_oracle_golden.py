@@ -1,0 +1,134 @@
+"""Pins the CPU oracle (oracle/ac_oracle.c) against golden vectors produced by the Python
+reference (oracle/tools/make_golden.py) and against the data the reference's own tests hold.
+CPU only."""
+import numpy as np
+import pytest
+
+from conftest import ms_pool_generator_order
+from oracle import ac_oracle as O
+
+EXC = {1: AssertionError, 2: IndexError, 3: ValueError}
+
+
+def test_simplify_relator_reference_table(golden_json):
+    for r in golden_json("unit_tables.json")["simplify_relator"]:
+        out, n = O.simplify_relator(np.array(r["relator"]), r["L"], cyclical=r["cyclical"], padded=r["padded"])
+        assert out.tolist() == r["out"] and n == r["length"], r
+
+
+def test_simplify_relator_fuzz(golden_json):
+    for r in golden_json("simplify_fuzz.json"):
+        if r["err"]:
+            with pytest.raises(EXC[r["err"]]):
+                O.simplify_relator(np.array(r["relator"]), r["L"], cyclical=r["cyclical"], padded=r["padded"])
+        else:
+            out, n = O.simplify_relator(np.array(r["relator"]), r["L"], cyclical=r["cyclical"], padded=r["padded"])
+            assert out.tolist() == r["out"] and n == r["length"], r
+
+
+def test_validity_and_triviality_tables(golden_json):
+    t = golden_json("unit_tables.json")
+    for r in t["is_array_valid_presentation"]:
+        assert O.is_array_valid_presentation(r["array"]) == r["valid"], r
+    for r in t["is_presentation_trivial"]:
+        assert O.is_presentation_trivial(r["array"]) == r["trivial"], r
+
+
+def test_simplify_presentation_table(golden_json):
+    for r in golden_json("unit_tables.json")["simplify_presentation"]:
+        out, lens = O.simplify_presentation(r["presentation"], r["L"], r["lengths"])
+        assert out.tolist() == r["out"] and lens == r["out_lengths"]
+
+
+@pytest.mark.parametrize("name", ["concatenate_relators", "conjugate"])
+def test_move_tables(golden_json, name):
+    fn = getattr(O, name)
+    for r in golden_json("unit_tables.json")[name]:
+        out, lens = fn(r["presentation"], r["L"], r["i"], r["j"], r["sign"], r["lengths"])
+        assert out.tolist() == r["out"] and lens == r["out_lengths"], r
+
+
+def test_raw_moves_fuzz(golden_json):
+    for r in golden_json("moves_raw_fuzz.json"):
+        fn = O.concatenate_relators if r["fn"] == "cat" else O.conjugate
+        if r["err"]:
+            with pytest.raises(EXC[r["err"]]):
+                fn(r["p"], r["L"], r["i"], r["j"], r["sign"], r["lengths"])
+        else:
+            out, lens = fn(r["p"], r["L"], r["i"], r["j"], r["sign"], r["lengths"])
+            assert out.tolist() == r["out"] and lens == r["out_lengths"], r
+
+
+def test_acmove_table(golden_json):
+    for r in golden_json("unit_tables.json")["ACMove"]:
+        out, lens = O.ACMove(r["move"], r["presentation"], r["L"], [4, 4], cyclical=r["cyclical"])
+        assert out.tolist() == r["out"] and lens == r["out_lengths"]
+
+
+@pytest.mark.parametrize("L", [2, 3, 4, 5, 7, 12, 25, 36])
+def test_acmove_fuzz(golden_npz, L):
+    z = golden_npz("acmove_fuzz.npz")
+    st, mv, cy = z[f"L{L}_state"], z[f"L{L}_move"], z[f"L{L}_cyclical"]
+    for c in (0, 1):
+        m = cy == c
+        out, lens, err = O.move_batch(st[m], mv[m], L, cyclical=bool(c))
+        assert np.array_equal(err, z[f"L{L}_err"][m])
+        assert np.array_equal(out, z[f"L{L}_out"][m])
+        assert np.array_equal(lens, z[f"L{L}_lens"][m])
+
+
+def test_stable_ak3_notebook_sequence(golden_json):
+    g = golden_json("stable_ak3.json")
+    L = g["L"]
+    state = np.array(g["relator1"] + [0] * (L - len(g["relator1"])) + g["relator2"] + [0] * (L - len(g["relator2"])), dtype=np.int8)
+    lens = None
+    for m in g["sequence_one_based"]:
+        state, lens = O.ACMove(m - 1, state, L, lens, cyclical=False)
+    assert state.tolist() == g["end_state"] and lens == g["end_lengths"]
+
+
+def test_env_trajectories(golden_npz):
+    z = golden_npz("env_traj.npz")
+    T, N = z["tape"].shape
+    states = z["init"].copy()
+    counts = np.zeros(N, np.int32)
+    horizon = int(z["horizon"])
+    t_prev = 0
+    rew, done, trunc = [], [], []
+    for t in (0, 1, 7, 31, 127):
+        r, d, tr, err = O.env_rollout(states, counts, horizon, np.ascontiguousarray(z["tape"][t_prev:t + 1]))
+        assert not err.any()
+        assert np.array_equal(states, z[f"state_t{t}"]), t
+        rew.append(r), done.append(d), trunc.append(tr)
+        t_prev = t + 1
+    assert np.array_equal(np.concatenate(rew), z["reward"])
+    assert np.array_equal(np.concatenate(done), z["done"])
+    assert np.array_equal(np.concatenate(trunc), z["truncated"])
+
+
+def test_env_episodes(golden_json):
+    for ep in golden_json("env_episodes.json")["episodes"]:
+        s = np.array(ep["initial_state"], dtype=np.int8)[None].copy()
+        c = np.zeros(1, np.int32)
+        for st in ep["steps"]:
+            r, d, tr, err = O.env_rollout(s, c, ep["horizon"], np.array([[st["action"]]], dtype=np.uint8))
+            assert s[0].tolist() == st["state"]
+            assert (int(r[0, 0]), bool(d[0, 0]), bool(tr[0, 0])) == (st["reward"], st["done"], st["truncated"]), (ep["name"], st)
+
+
+def test_search_golden(golden_json):
+    for r in golden_json("search.json"):
+        fn = O.bfs if r["algo"] == "bfs" else O.greedy_search
+        ok, path = fn(r["presentation"], r["budget"], cyclically_reduce_after_moves=r["cyclical"])
+        want = [tuple(x) for x in r["path"]] if r["path"] is not None else None
+        assert ok == r["solved"] and path == want, (r["tag"], r["algo"], r["budget"])
+
+
+def test_greedy_paths_file_all_533(golden_json):
+    """data/greedy_search_paths.txt (budget 1e6): every path is reproduced exactly."""
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    g = golden_json("greedy_paths_1e6.json")
+    assert len(g["rows"]) == 533
+    for row in g["rows"]:
+        ok, path = O.greedy_search(pool[row["pool_index"]], g["budget"])
+        assert ok and path == [tuple(x) for x in row["path"]], row["pool_index"]
