@@ -1,0 +1,128 @@
+"""ctypes binding of libacx.so (include/acx.h) -- the only way the Python surface reaches the
+HIP kernels.  There is no CPU fallback: if the library is missing the import fails loudly, and
+if no GPU is visible every compute call raises `AcxError`.
+
+Reference-side note: the reference is pure Python, so this module is exactly the
+stub a maintainer of shehper/AC-Solver would add to route ac_solver/envs and ac_solver/search
+through the accelerator.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("ACX_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libacx.so"))
+
+# return codes / flags (mirror include/acx.h)
+OK, E_INVAL, E_NODEVICE, E_NOMEM, E_ROWERR, E_CAPACITY = 0, -1, -2, -3, -4, -5
+F_CYCLICAL, F_NO_SIMPLIFY, F_NO_MOVE, F_BYTES = 1, 2, 4, 8
+U8, I32, I64, I8, F32 = 0, 1, 2, 3, 4
+ENV_RECORD_ACTIONS = 1
+SEARCH_BFS, SEARCH_GREEDY = 0, 1
+ERR_ASSERT, ERR_INDEX, ERR_VALUE, ERR_UNPACKABLE = 1, 2, 3, 250
+
+
+class AcxError(RuntimeError):
+    pass
+
+
+class SearchStats(C.Structure):
+    _fields_ = [("nodes", C.c_int64), ("expanded", C.c_int64), ("children", C.c_int64), ("levels", C.c_int64),
+                ("min_len", C.c_int32), ("seconds", C.c_double)]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build the HIP extension first (python __graft_entry__.py, or "
+        "make -C ac-solver_amd/csrc).  ac_solver has no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+_i8p, _u8p, _i32p, _i64p, _f32p = (C.POINTER(t) for t in (C.c_int8, C.c_uint8, C.c_int32, C.c_int64, C.c_float))
+_vp = C.c_void_p
+
+SIGNATURES = {
+    "acx_version": (C.c_int, []),
+    "acx_last_error": (C.c_char_p, []),
+    "acx_device_count": (C.c_int, []),
+    "acx_move_batch_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "acx_move_batch": (C.c_int, [_i8p, _u8p, C.c_int64, C.c_int, C.c_int, _i8p, _i32p, _u8p, _i32p]),
+    "acx_simplify_relators": (C.c_int, [_i8p, C.c_int64, C.c_int, C.c_int, _i8p, _i32p, _u8p]),
+    "acx_env_create": (_vp, [C.c_int64, C.c_int, C.c_int64, C.c_int]),
+    "acx_env_destroy": (None, [_vp]),
+    "acx_env_set_initial": (C.c_int, [_vp, _i8p, _i64p, C.c_int64]),
+    "acx_env_reset": (C.c_int, [_vp, _i8p, _i64p, C.c_int64]),
+    "acx_env_step": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_float, C.c_float, _vp, _vp, _vp, C.c_int, _vp]),
+    "acx_env_step_host": (C.c_int, [_vp, _i64p, _i8p, _f32p, _u8p, _u8p, _i8p, C.c_int]),
+    "acx_env_rollout": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_float, C.c_float, _vp, _vp, C.c_int, _vp]),
+    "acx_env_observe": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "acx_env_get": (C.c_int, [_vp, _i64p, C.c_int64, _i8p, _i32p, _i32p]),
+    "acx_env_get_actions": (C.c_int, [_vp, C.c_int64, C.c_int, _i32p, C.c_int64, _i64p]),
+    "acx_env_get_errors": (C.c_int, [_vp, _u8p, C.c_int]),
+    "acx_env_max_reward": (C.c_int64, [_vp]),
+    "acx_search": (C.c_int, [C.c_int, _i8p, C.c_int, C.c_int64, C.c_int, _i32p, _i32p, _i32p, C.c_int64, _i64p, C.POINTER(SearchStats)]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here means the library is stale: rebuild it
+    _fn.restype, _fn.argtypes = _res, _args
+
+
+def last_error():
+    return (lib.acx_last_error() or b"").decode()
+
+
+def check(rc, what="acx"):
+    if rc != OK:
+        raise AcxError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def device_count():
+    return lib.acx_device_count()
+
+
+def require_device():
+    if device_count() < 1:
+        raise AcxError("no MI355X / HIP device visible: ac_solver runs its moves, environment and searches "
+                       "in HIP kernels and has no CPU fallback")
+
+
+def ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def as_i8_rows(a, what="presentation"):
+    """-> C-contiguous int8 copy; values must be representable (letters are small integers)"""
+    arr = np.asarray(a)
+    if arr.dtype != np.int8:
+        if arr.size and (arr.min() < -127 or arr.max() > 127):
+            raise ValueError(f"{what}: letters must fit in int8")
+        arr = arr.astype(np.int8)
+    return np.ascontiguousarray(arr)
+
+
+def move_rows(rows, actions, L, flags):
+    """Byte-exact / packed batched ACMove on host arrays. -> (out, lens, err, fit)"""
+    require_device()
+    rows = as_i8_rows(rows)
+    n = rows.shape[0]
+    out = np.empty_like(rows)
+    lens = np.empty((n, 2), np.int32)
+    err = np.empty(n, np.uint8)
+    fit = np.empty(n, np.int32)
+    act = None if actions is None else np.ascontiguousarray(actions, np.uint8)
+    check(lib.acx_move_batch(ptr(rows, C.c_int8), None if act is None else ptr(act, C.c_uint8), n, L, flags, ptr(out, C.c_int8),
+                             ptr(lens, C.c_int32), ptr(err, C.c_uint8), ptr(fit, C.c_int32) if flags & F_BYTES else None), "acx_move_batch")
+    return out, lens, err, fit
+
+
+def simplify_rows(rows, cyclical):
+    require_device()
+    rows = as_i8_rows(rows, "relator")
+    n, width = rows.shape
+    out = np.empty_like(rows)
+    lens = np.empty((n, 2), np.int32)
+    err = np.empty(n, np.uint8)
+    check(lib.acx_simplify_relators(ptr(rows, C.c_int8), n, width, int(bool(cyclical)), ptr(out, C.c_int8), ptr(lens, C.c_int32),
+                                    ptr(err, C.c_uint8)), "acx_simplify_relators")
+    return out, lens, err

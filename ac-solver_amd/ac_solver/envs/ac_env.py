@@ -1,0 +1,136 @@
+"""Andrews-Curtis environment for balanced presentations with two generators -- drop-in for
+ac_solver/envs/ac_env.py (`ACEnvConfig`, `ACEnv`).
+
+`ACEnv` keeps the reference's gymnasium surface (attributes, return conventions, exceptions) but
+its state lives on the GPU: every `step` is one launch of libacx's environment kernel (the same
+kernel that advances 65 536 environments at a time in `ACVecEnv`), every `reset` one upload.
+"""
+from dataclasses import dataclass, field
+from typing import Union
+import ctypes as C
+
+import numpy as np
+
+from ac_solver import _acx
+from ac_solver._gym import Box, Discrete, Env
+from ac_solver.envs.utils import is_array_valid_presentation
+
+
+@dataclass
+class ACEnvConfig:
+    """Reference: ac_env.py:14-53.  Default state is the trivial presentation <x, y>."""
+
+    initial_state: Union[np.ndarray, list] = field(default_factory=lambda: np.array([1, 0, 2, 0]))
+    horizon_length: any = 1000
+    use_supermoves: any = False
+
+    def __post_init__(self):
+        if isinstance(self.initial_state, list):
+            self.initial_state = np.array(self.initial_state)
+        if not isinstance(self.initial_state, np.ndarray):
+            raise TypeError("initial_state must be a numpy array")
+        if self.initial_state.ndim != 1:
+            raise ValueError("initial_state must be a 1-dimensional array")
+        if len(self.initial_state) % 2 != 0:
+            raise ValueError("initial state must have even length")
+        if not is_array_valid_presentation(self.initial_state):
+            raise ValueError("initial state must be a valid presentation")
+
+    @property
+    def max_relator_length(self):
+        return len(self.initial_state) // 2
+
+    @classmethod
+    def from_dict(cls, config_dict):
+        defaults = cls()
+        return cls(
+            initial_state=np.array(config_dict.get("initial_state", defaults.initial_state)),
+            horizon_length=config_dict.get("horizon_length", defaults.horizon_length),
+            use_supermoves=config_dict.get("use_supermoves", defaults.use_supermoves),
+        )
+
+
+class _Handle:
+    """Owns one acx_env; frees it with the Python object."""
+
+    def __init__(self, n, L, horizon, flags):
+        _acx.require_device()
+        self.ptr = _acx.lib.acx_env_create(n, L, int(horizon), flags)
+        if not self.ptr:
+            raise _acx.AcxError(f"acx_env_create failed: {_acx.last_error()}")
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            _acx.lib.acx_env_destroy(self.ptr)
+            self.ptr = None
+
+
+class ACEnv(Env):
+    """Reference: ac_env.py:56-134.  reward = max_reward * done - total_length * (1 - done);
+    done <=> total length 2; truncated <=> count_steps >= horizon_length; no self-reset."""
+
+    def __init__(self, config: ACEnvConfig = None):
+        config = ACEnvConfig() if config is None else config
+        self.n_gen = 2
+        self.max_relator_length = config.max_relator_length
+        self.initial_state = config.initial_state
+        self.horizon_length = config.horizon_length
+        if config.use_supermoves:
+            raise NotImplementedError("ACEnv with supermoves is not yet implemented in this library.")
+        L = self.max_relator_length
+        if L > 64:
+            raise ValueError("ACEnv supports max_relator_length <= 64 on the device")
+        if np.any(np.abs(self.initial_state) > self.n_gen):
+            raise ValueError("ACEnv is a two-generator environment: letters must be in {+-1, +-2}")
+
+        self.observation_space = Box(np.full(2 * L, -self.n_gen, dtype=np.int8), np.full(2 * L, self.n_gen, dtype=np.int8), dtype=np.int8)
+        self.action_space = Discrete(12)
+        self.max_reward = self.horizon_length * L * self.n_gen
+
+        self._dtype = self.initial_state.dtype
+        self._h = _Handle(1, L, self.horizon_length, 0)
+        row = _acx.as_i8_rows(self.initial_state.reshape(1, -1))
+        _acx.check(_acx.lib.acx_env_set_initial(self._h.ptr, _acx.ptr(row, C.c_int8), None, 1), "acx_env_set_initial")
+        self.state = np.copy(self.initial_state)
+        self.count_steps = 0
+        self.lengths = [int(np.count_nonzero(self.state[:L])), int(np.count_nonzero(self.state[L:]))]
+        self.actions = []
+
+    def step(self, action):
+        self.actions += [action]
+        L = self.max_relator_length
+        assert action in range(0, 12), f"Expect n to be in range 0-11 (both inclusive); got {action}"
+        act = np.array([int(action)], dtype=np.int64)
+        obs = np.empty((1, 2 * L), np.int8)
+        rew = np.empty(1, np.float32)
+        done = np.empty(1, np.uint8)
+        trunc = np.empty(1, np.uint8)
+        _acx.check(_acx.lib.acx_env_step_host(self._h.ptr, _acx.ptr(act, C.c_int64), _acx.ptr(obs, C.c_int8), _acx.ptr(rew, C.c_float),
+                                              _acx.ptr(done, C.c_uint8), _acx.ptr(trunc, C.c_uint8), None, 0), "acx_env_step_host")
+        err = np.empty(1, np.uint8)
+        _acx.check(_acx.lib.acx_env_get_errors(self._h.ptr, _acx.ptr(err, C.c_uint8), 1))
+        if err[0]:
+            # the reference's ACMove raised before state/lengths/count_steps were touched (ac_env.py:97);
+            # the kernel left the device state and counter untouched as well
+            raise (IndexError if err[0] == _acx.ERR_INDEX else AssertionError)(
+                f"move {action} empties a relator of {self.state}: not a valid presentation")
+        self.state = obs[0].astype(self._dtype)
+        self.lengths = [int(np.count_nonzero(obs[0, :L])), int(np.count_nonzero(obs[0, L:]))]
+        self.count_steps += 1
+        is_done = bool(done[0])
+        reward = int(rew[0])
+        return self.state, reward, is_done, bool(trunc[0]), ({"actions": self.actions.copy()} if is_done else {})
+
+    def reset(self, *, seed=None, options=None):
+        L = self.max_relator_length
+        start = options["starting_state"] if options and "starting_state" in options else self.initial_state
+        self.state = np.copy(start)
+        row = _acx.as_i8_rows(np.asarray(self.state).reshape(1, -1))
+        _acx.check(_acx.lib.acx_env_reset(self._h.ptr, _acx.ptr(row, C.c_int8), None, 1), "acx_env_reset")
+        self.lengths = [int(np.count_nonzero(self.state[:L])), int(np.count_nonzero(self.state[L:]))]
+        self.count_steps = 0
+        self.actions = []
+        return self.state, {}
+
+    def render(self):
+        pass

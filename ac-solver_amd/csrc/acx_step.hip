@@ -1,0 +1,738 @@
+// acx_step.hip -- AC moves and the vectorised ACEnv on gfx950: kernels + their C-ABI entry points.
+//
+// Kernels (one presentation per lane, 64-lane waves, 256-thread workgroups):
+//   k_move_bytes     byte-exact ACMove on raw int8 rows (any letters / invalid rows)   ac_moves.py:159
+//   k_simplify_rows  simplify_relator on raw rows                                      utils.py:175
+//   k_move_packed    ACMove on packed words; rows staged through LDS for 16-B coalesced global I/O
+//   k_env_step       ACEnv.step for n resident envs; obs (int8 / f32) staged through LDS     ac_env.py:95
+//   k_env_rollout    T fused ACEnv.step from an action tape, state resident in registers
+//   k_env_load / k_env_observe / k_env_gather   reset / observation plumbing               ac_env.py:115
+//
+// Roofline: HBM (integer byte shuffling, no MFMA).  Algorithmic bytes per env step: 4L + 7
+// (state in + out, action, f32 reward, done, truncated) -- see DESIGN.md.
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "acx_bytes.h"
+#include "acx_common.h"
+#include "acx_word.h"
+
+namespace acx {
+
+// ---------------------------------------------------------------- host helpers (shared) -------
+char* last_error_buf() {
+    static thread_local char buf[512] = "";
+    return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+bool have_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        fail(ACX_E_NODEVICE, "no HIP device visible: libacx has no CPU fallback");
+        return false;
+    }
+    return true;
+}
+
+int Scratch::ensure(size_t bytes) {
+    if (bytes <= cap) return ACX_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 4;
+    if (hipMalloc(&p, want) != hipSuccess) return fail(ACX_E_NOMEM, "hipMalloc(%zu) failed", want);
+    cap = want;
+    return ACX_OK;
+}
+Scratch::~Scratch() {}  // freed with the context at process exit
+Scratch& scratch(int slot) {
+    static thread_local Scratch s[4];
+    return s[slot & 3];
+}
+
+// ---------------------------------------------------------------- device helpers --------------
+__device__ __forceinline__ int load_action(const void* p, int dtype, int64_t k) {
+    switch (dtype) {
+        case ACX_U8: return ((const uint8_t*)p)[k];
+        case ACX_I32: return ((const int32_t*)p)[k];
+        case ACX_I64: return (int)((const int64_t*)p)[k];
+        default: return ((const int8_t*)p)[k];
+    }
+}
+
+// Per-wave cooperative copy of `nbytes` contiguous bytes, 16 B per lane per trip when both sides
+// are 16-B aligned (`vec`), byte-wise for the ragged tail / unaligned callers.
+__device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, int nbytes, int lane, bool vec) {
+    int o = lane * 16;
+    if (vec) {
+        for (; o + 16 <= nbytes; o += 64 * 16) *(uint4*)(dst + o) = *(const uint4*)(src + o);
+        if (o < nbytes)
+            for (int b = o; b < nbytes && b < o + 16; b++) dst[b] = src[b];
+    } else {
+        for (int b = lane; b < nbytes; b += 64) dst[b] = src[b];
+    }
+}
+
+__device__ __forceinline__ float clip_reward(float r, float lo, float hi) {
+    return lo < hi ? fminf(fmaxf(r, lo), hi) : r;
+}
+
+// ---------------------------------------------------------------- byte-exact kernels ----------
+template <int MAXL>
+__global__ void __launch_bounds__(64) k_move_bytes(const int8_t* __restrict__ in, const void* __restrict__ act, int adt, int64_t n,
+                                                   int L, int flags, int8_t* __restrict__ out, int32_t* __restrict__ len,
+                                                   uint8_t* __restrict__ err, int32_t* __restrict__ fit) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int8_t row[2 * MAXL], res[2 * MAXL], w1[MAXL], w2[MAXL];
+    for (int k = 0; k < 2 * L; k++) row[k] = in[r * 2 * L + k];
+    const int a = (flags & ACX_F_NO_MOVE) ? 0 : load_action(act, adt, r);
+    int lens[2] = {0, 0}, f = -1, e;
+    if (a < 0 || a >= 12) e = ACX_ERR_ASSERT;  // ac_moves.py:188-190
+    else e = move_bytes(row, L, a, flags, res, lens, &f, w1, w2);
+    if (e != ACX_ERR_NONE) {  // the reference raised: pass the row through
+        int ext;
+        for (int k = 0; k < 2 * L; k++) res[k] = row[k];
+        lens[0] = take_nonzero(row, L, w1, &ext);
+        lens[1] = take_nonzero(row + L, L, w1, &ext);
+        f = -1;
+    }
+    for (int k = 0; k < 2 * L; k++) out[r * 2 * L + k] = res[k];
+    len[2 * r] = lens[0];
+    len[2 * r + 1] = lens[1];
+    err[r] = (uint8_t)e;
+    if (fit) fit[r] = f;
+}
+
+template <int MAXW>
+__global__ void __launch_bounds__(64) k_simplify_rows(const int8_t* __restrict__ in, int64_t n, int width, int cyclical,
+                                                      int8_t* __restrict__ out, int32_t* __restrict__ len, uint8_t* __restrict__ err) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int8_t row[MAXW], res[MAXW];
+    for (int k = 0; k < width; k++) row[k] = in[r * width + k];
+    int nz;
+    const int nn = simplify_row(row, width, cyclical != 0, res, &nz);
+    for (int k = 0; k < width; k++) out[r * width + k] = nn < 0 ? row[k] : res[k];
+    len[2 * r] = nn < 0 ? nz : nn;
+    len[2 * r + 1] = nz;
+    err[r] = nn < 0 ? (uint8_t)(-nn) : 0;
+}
+
+// ---------------------------------------------------------------- packed stateless kernel -----
+// One wave = 64 rows = one contiguous 128*L byte tile, moved global <-> LDS with 16-B lanes; each
+// lane then packs / unpacks its own row inside LDS.
+template <typename W>
+__global__ void __launch_bounds__(256) k_move_packed(const int8_t* __restrict__ in, const void* __restrict__ act, int adt, int64_t n,
+                                                     int L, int cyclical, int8_t* __restrict__ out, int32_t* __restrict__ len,
+                                                     uint8_t* __restrict__ err, int vec) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int RB = 2 * L;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    const int rows = (int)(n - row0 < 64 ? (n - row0 < 0 ? 0 : n - row0) : 64);
+    uint8_t* tile = lds + wave * 64 * RB;
+    if (rows > 0) wave_copy(tile, (const uint8_t*)in + row0 * RB, rows * RB, lane, vec != 0);
+    __syncthreads();
+    if (lane < rows) {
+        const int64_t r = row0 + lane;
+        int8_t* my = (int8_t*)tile + lane * RB;
+        Pres<W> s;
+        bool ok = pack_relator<W>(my, L, s.w0, s.n0);
+        ok = pack_relator<W>(my + L, L, s.w1, s.n1) && ok;
+        const int a = load_action(act, adt, r);
+        int e;
+        if (!ok) {
+            e = ACX_ERR_UNPACKABLE;
+            s.n0 = s.n1 = 0;
+            for (int k = 0; k < L; k++) {
+                s.n0 += my[k] != 0;
+                s.n1 += my[L + k] != 0;
+            }
+        } else if (a < 0 || a >= 12) {
+            e = ACX_ERR_ASSERT;
+        } else {
+            e = apply_move<W>(s, a, L, cyclical != 0);
+            if (e == ACX_ERR_NONE) {
+                unpack_relator<W>(s.w0, s.n0, L, my);
+                unpack_relator<W>(s.w1, s.n1, L, my + L);
+            }
+        }
+        len[2 * r] = s.n0;
+        len[2 * r + 1] = s.n1;
+        err[r] = (uint8_t)e;
+    }
+    __syncthreads();
+    if (rows > 0) wave_copy((uint8_t*)out + row0 * RB, tile, rows * RB, lane, vec != 0);
+}
+
+// ---------------------------------------------------------------- vectorised env --------------
+template <typename W> struct EnvDev {
+    W* w0;        // [n] relator 0, current state
+    W* w1;        // [n] relator 1
+    uint16_t* ln; // [n] n0 | n1 << 8
+    int32_t* cnt; // [n] count_steps (ac_env.py:104)
+    uint8_t* err; // [n] sticky error byte
+    W* iw0;       // initial state (ACEnvConfig.initial_state)
+    W* iw1;
+    uint16_t* iln;
+    uint8_t* hist;     // [H, n] action history ring (row = count_steps % H), or NULL
+    int32_t* last_len; // [n] length of the episode that last finished (for final_info["actions"])
+    int64_t n;
+    int32_t L, H;
+    int64_t horizon;
+    float max_reward;
+};
+
+template <typename W> __device__ __forceinline__ void env_load(const EnvDev<W>& e, int64_t i, Pres<W>& s) {
+    s.w0 = e.w0[i];
+    s.w1 = e.w1[i];
+    const uint16_t l = e.ln[i];
+    s.n0 = l & 0xff;
+    s.n1 = l >> 8;
+}
+template <typename W> __device__ __forceinline__ void env_store(const EnvDev<W>& e, int64_t i, const Pres<W>& s) {
+    e.w0[i] = s.w0;
+    e.w1[i] = s.w1;
+    e.ln[i] = (uint16_t)(s.n0 | (s.n1 << 8));
+}
+
+// One env transition (ac_env.py:95-113) incl. the optional gymnasium-style autoreset.
+// `fin` receives the terminal state when the env finished and was reset.
+template <typename W>
+__device__ __forceinline__ void env_transition(const EnvDev<W>& e, int64_t i, Pres<W>& s, int32_t& cnt, int a, bool autoreset,
+                                               float clip_lo, float clip_hi, float& reward, int& done, int& trunc, bool& was_reset,
+                                               Pres<W>& fin) {
+    if (e.hist) e.hist[(int64_t)(cnt % e.H) * e.n + i] = (uint8_t)a;  // self.actions += [action], :96
+    const int er = (a < 0 || a >= 12) ? (int)ACX_ERR_ASSERT : apply_move<W>(s, a, e.L, true);  // cyclical=True, :97
+    if (er) e.err[i] = (uint8_t)er;
+    const int tot = s.n0 + s.n1;
+    done = tot == 2;                                                              // :101
+    reward = clip_reward(done ? e.max_reward : -(float)tot, clip_lo, clip_hi);    // :102 (+ TransformReward clip)
+    if (!er) cnt += 1;  // :104 (when the reference's ACMove raises, step() aborts before the counter moves)
+    trunc = cnt >= e.horizon;                                                     // :105
+    was_reset = autoreset && (done || trunc);
+    if (was_reset) {  // SyncVectorEnv autoreset: ACEnv.reset() -> initial_state, :115-131
+        fin = s;
+        e.last_len[i] = cnt;
+        s.w0 = e.iw0[i];
+        s.w1 = e.iw1[i];
+        const uint16_t l = e.iln[i];
+        s.n0 = l & 0xff;
+        s.n1 = l >> 8;
+        cnt = 0;
+    }
+}
+
+template <typename W, typename OBS> __device__ __forceinline__ void write_obs_row(OBS* row, const Pres<W>& s, int L) {
+    for (int k = 0; k < L; k++) {
+        row[k] = k < s.n0 ? (OBS)letter_of_code(get<W>(s.w0, k)) : (OBS)0;
+        row[L + k] = k < s.n1 ? (OBS)letter_of_code(get<W>(s.w1, k)) : (OBS)0;
+    }
+}
+
+template <typename W, typename OBS>
+__global__ void __launch_bounds__(256) k_env_step(EnvDev<W> e, const void* __restrict__ act, int adt, OBS* __restrict__ obs,
+                                                  float* __restrict__ rew, float clip_lo, float clip_hi, uint8_t* __restrict__ done,
+                                                  uint8_t* __restrict__ trunc, OBS* __restrict__ final_obs, int autoreset, int vec) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int RB = 2 * e.L * (int)sizeof(OBS);
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    const int rows = (int)(e.n - row0 < 64 ? (e.n - row0 < 0 ? 0 : e.n - row0) : 64);
+    uint8_t* tile = lds + wave * 64 * RB;
+    OBS* my = (OBS*)(tile + lane * RB);
+    Pres<W> s, fin;
+    bool was_reset = false;
+    if (lane < rows) {
+        const int64_t i = row0 + lane;
+        env_load<W>(e, i, s);
+        int32_t cnt = e.cnt[i];
+        float r;
+        int d, t;
+        env_transition<W>(e, i, s, cnt, load_action(act, adt, i), autoreset != 0, clip_lo, clip_hi, r, d, t, was_reset, fin);
+        env_store<W>(e, i, s);
+        e.cnt[i] = cnt;
+        if (rew) rew[i] = r;
+        if (done) done[i] = (uint8_t)d;
+        if (trunc) trunc[i] = (uint8_t)t;
+        if (obs) write_obs_row<W, OBS>(my, s, e.L);
+    }
+    if (obs) {
+        __syncthreads();
+        if (rows > 0) wave_copy((uint8_t*)obs + row0 * RB, tile, rows * RB, lane, vec != 0);
+    }
+    if (final_obs) {  // terminal observation of envs that were just reset, current observation otherwise
+        __syncthreads();
+        if (lane < rows) write_obs_row<W, OBS>(my, was_reset ? fin : s, e.L);
+        __syncthreads();
+        if (rows > 0) wave_copy((uint8_t*)final_obs + row0 * RB, tile, rows * RB, lane, vec != 0);
+    }
+}
+
+template <typename W>
+__global__ void __launch_bounds__(256) k_env_rollout(EnvDev<W> e, const uint8_t* __restrict__ tape, int64_t T, float* __restrict__ rew,
+                                                     float clip_lo, float clip_hi, uint8_t* __restrict__ done,
+                                                     uint8_t* __restrict__ trunc, int autoreset) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= e.n) return;
+    Pres<W> s, fin;
+    env_load<W>(e, i, s);
+    int32_t cnt = e.cnt[i];
+    for (int64_t t = 0; t < T; t++) {
+        float r;
+        int d, tr;
+        bool was_reset;
+        env_transition<W>(e, i, s, cnt, tape[t * e.n + i], autoreset != 0, clip_lo, clip_hi, r, d, tr, was_reset, fin);
+        if (rew) rew[t * e.n + i] = r;
+        if (done) done[t * e.n + i] = (uint8_t)d;
+        if (trunc) trunc[t * e.n + i] = (uint8_t)tr;
+    }
+    env_store<W>(e, i, s);
+    e.cnt[i] = cnt;
+}
+
+template <typename W, typename OBS>
+__global__ void __launch_bounds__(256) k_env_observe(EnvDev<W> e, OBS* __restrict__ obs, int vec) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int RB = 2 * e.L * (int)sizeof(OBS);
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    const int rows = (int)(e.n - row0 < 64 ? (e.n - row0 < 0 ? 0 : e.n - row0) : 64);
+    uint8_t* tile = lds + wave * 64 * RB;
+    if (lane < rows) {
+        Pres<W> s;
+        env_load<W>(e, row0 + lane, s);
+        write_obs_row<W, OBS>((OBS*)(tile + lane * RB), s, e.L);
+    }
+    __syncthreads();
+    if (rows > 0) wave_copy((uint8_t*)obs + row0 * RB, tile, rows * RB, lane, vec != 0);
+}
+
+// rows [m, 2L] int8 (device staging) -> packed state of envs idx[k] (or env k when idx == NULL).
+// to_initial: also overwrite the stored initial state.  rows == NULL: reset to the initial state.
+template <typename W>
+__global__ void k_env_load(EnvDev<W> e, const int8_t* __restrict__ rows, const int64_t* __restrict__ idx, int64_t m, int to_initial,
+                           uint8_t* __restrict__ rowerr) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const int64_t i = idx ? idx[k] : k;
+    Pres<W> s;
+    if (rows) {
+        const int8_t* r = rows + k * 2 * e.L;
+        bool ok = pack_relator<W>(r, e.L, s.w0, s.n0);
+        ok = pack_relator<W>(r + e.L, e.L, s.w1, s.n1) && ok;
+        if (to_initial) ok = ok && s.n0 > 0 && s.n1 > 0;  // ACEnvConfig validates; reset(options=) does not
+        rowerr[k] = ok ? 0 : (uint8_t)ACX_ERR_UNPACKABLE;
+        if (!ok) return;
+        if (to_initial) {
+            e.iw0[i] = s.w0;
+            e.iw1[i] = s.w1;
+            e.iln[i] = (uint16_t)(s.n0 | (s.n1 << 8));
+        }
+    } else {
+        s.w0 = e.iw0[i];
+        s.w1 = e.iw1[i];
+        const uint16_t l = e.iln[i];
+        s.n0 = l & 0xff;
+        s.n1 = l >> 8;
+        rowerr[k] = 0;
+    }
+    env_store<W>(e, i, s);
+    e.cnt[i] = 0;
+    e.err[i] = 0;
+    e.last_len[i] = 0;
+}
+
+template <typename W>
+__global__ void k_env_gather(EnvDev<W> e, const int64_t* __restrict__ idx, int64_t m, int8_t* __restrict__ rows, int32_t* __restrict__ len,
+                             int32_t* __restrict__ cnt) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const int64_t i = idx ? idx[k] : k;
+    Pres<W> s;
+    env_load<W>(e, i, s);
+    unpack_relator<W>(s.w0, s.n0, e.L, rows + k * 2 * e.L);
+    unpack_relator<W>(s.w1, s.n1, e.L, rows + k * 2 * e.L + e.L);
+    len[2 * k] = s.n0;
+    len[2 * k + 1] = s.n1;
+    cnt[k] = e.cnt[i];
+}
+
+}  // namespace acx
+
+// =================================================================== C ABI ======================
+using namespace acx;
+
+struct acx_env {
+    int64_t n;
+    int L, H, flags, device;
+    int64_t horizon;
+    bool wide;     // W = u128
+    void* arena;   // one allocation holding all device arrays
+    EnvDev<uint64_t> d64;
+    EnvDev<u128> d128;
+};
+
+extern "C" {
+
+int acx_version(void) { return ACX_VERSION; }
+const char* acx_last_error(void) { return last_error_buf(); }
+int acx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+int acx_move_batch_device(const int8_t* d_in, const void* d_action, int action_dtype, int64_t n, int L, int flags, int8_t* d_out,
+                          int32_t* d_len, uint8_t* d_err, int32_t* d_fit, void* stream) {
+    if (!have_device()) return ACX_E_NODEVICE;
+    if (n < 0 || L < 1 || !d_in || !d_out || !d_len || !d_err) return fail(ACX_E_INVAL, "acx_move_batch_device: bad argument");
+    if (!d_action && !(flags & ACX_F_NO_MOVE)) return fail(ACX_E_INVAL, "acx_move_batch_device: actions required");
+    if (action_dtype < ACX_U8 || action_dtype > ACX_I8) return fail(ACX_E_INVAL, "acx_move_batch_device: bad action dtype");
+    if (n == 0) return ACX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (flags & ACX_F_BYTES) {
+        if (L > kMaxBytesL) return fail(ACX_E_INVAL, "byte path handles L <= %d, got %d", kMaxBytesL, L);
+        const unsigned grid = (unsigned)ceil_div<int64_t>(n, 64);
+        if (L <= 32)
+            hipLaunchKernelGGL(k_move_bytes<32>, dim3(grid), dim3(64), 0, st, d_in, d_action, action_dtype, n, L, flags, d_out, d_len, d_err, d_fit);
+        else
+            hipLaunchKernelGGL(k_move_bytes<kMaxBytesL>, dim3(grid), dim3(64), 0, st, d_in, d_action, action_dtype, n, L, flags, d_out, d_len, d_err, d_fit);
+    } else {
+        if (flags & (ACX_F_NO_SIMPLIFY | ACX_F_NO_MOVE)) return fail(ACX_E_INVAL, "ACX_F_NO_SIMPLIFY / ACX_F_NO_MOVE need ACX_F_BYTES");
+        if (L > 64) return fail(ACX_E_INVAL, "packed path handles L <= 64, got %d (use ACX_F_BYTES)", L);
+        const unsigned grid = (unsigned)ceil_div<int64_t>(n, 256);
+        const size_t lds = (size_t)4 * 64 * 2 * L;
+        const int vec = aligned16(d_in) && aligned16(d_out);
+        if (L <= 32)
+            hipLaunchKernelGGL(k_move_packed<uint64_t>, dim3(grid), dim3(256), lds, st, d_in, d_action, action_dtype, n, L, flags & ACX_F_CYCLICAL, d_out, d_len, d_err, vec);
+        else
+            hipLaunchKernelGGL(k_move_packed<u128>, dim3(grid), dim3(256), lds, st, d_in, d_action, action_dtype, n, L, flags & ACX_F_CYCLICAL, d_out, d_len, d_err, vec);
+    }
+    ACX_HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
+int acx_move_batch(const int8_t* h_in, const uint8_t* h_action, int64_t n, int L, int flags, int8_t* h_out, int32_t* h_len,
+                   uint8_t* h_err, int32_t* h_fit) {
+    if (!have_device()) return ACX_E_NODEVICE;
+    if (n < 0 || L < 1 || !h_in || !h_out || !h_len || !h_err) return fail(ACX_E_INVAL, "acx_move_batch: bad argument");
+    if (n == 0) return ACX_OK;
+    const size_t row = (size_t)2 * L, a16 = 256;
+    auto up = [&](size_t b) { return (b + a16 - 1) / a16 * a16; };
+    const size_t o_in = 0, o_act = o_in + up(n * row), o_out = o_act + up(n), o_len = o_out + up(n * row), o_err = o_len + up(n * 8),
+                 o_fit = o_err + up(n), total = o_fit + up(n * 4);
+    Scratch& s = scratch(0);
+    int rc = s.ensure(total);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)s.p;
+    ACX_HIP_TRY(hipMemcpy(b + o_in, h_in, n * row, hipMemcpyHostToDevice));
+    if (h_action) ACX_HIP_TRY(hipMemcpy(b + o_act, h_action, n, hipMemcpyHostToDevice));
+    rc = acx_move_batch_device((const int8_t*)(b + o_in), h_action ? b + o_act : nullptr, ACX_U8, n, L, flags, (int8_t*)(b + o_out),
+                               (int32_t*)(b + o_len), b + o_err, h_fit ? (int32_t*)(b + o_fit) : nullptr, nullptr);
+    if (rc) return rc;
+    ACX_HIP_TRY(hipDeviceSynchronize());
+    ACX_HIP_TRY(hipMemcpy(h_out, b + o_out, n * row, hipMemcpyDeviceToHost));
+    ACX_HIP_TRY(hipMemcpy(h_len, b + o_len, n * 8, hipMemcpyDeviceToHost));
+    ACX_HIP_TRY(hipMemcpy(h_err, b + o_err, n, hipMemcpyDeviceToHost));
+    if (h_fit) ACX_HIP_TRY(hipMemcpy(h_fit, b + o_fit, n * 4, hipMemcpyDeviceToHost));
+    return ACX_OK;
+}
+
+int acx_simplify_relators(const int8_t* h_in, int64_t n, int width, int cyclical, int8_t* h_out, int32_t* h_len, uint8_t* h_err) {
+    if (!have_device()) return ACX_E_NODEVICE;
+    if (n < 0 || width < 0 || width > 256 || !h_out || !h_len || !h_err) return fail(ACX_E_INVAL, "acx_simplify_relators: bad argument (width <= 256)");
+    if (n == 0) return ACX_OK;
+    if (width == 0) {  // np.array([]) -> ([], 0)
+        for (int64_t k = 0; k < n; k++) h_len[2 * k] = h_len[2 * k + 1] = 0, h_err[k] = 0;
+        return ACX_OK;
+    }
+    const size_t a16 = 256;
+    auto up = [&](size_t b) { return (b + a16 - 1) / a16 * a16; };
+    const size_t o_in = 0, o_out = up(n * width), o_len = o_out + up(n * width), o_err = o_len + up(n * 8), total = o_err + up(n);
+    Scratch& s = scratch(0);
+    int rc = s.ensure(total);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)s.p;
+    ACX_HIP_TRY(hipMemcpy(b + o_in, h_in, n * width, hipMemcpyHostToDevice));
+    const unsigned grid = (unsigned)ceil_div<int64_t>(n, 64);
+    if (width <= 64)
+        hipLaunchKernelGGL(k_simplify_rows<64>, dim3(grid), dim3(64), 0, nullptr, (const int8_t*)(b + o_in), n, width, cyclical, (int8_t*)(b + o_out), (int32_t*)(b + o_len), b + o_err);
+    else
+        hipLaunchKernelGGL(k_simplify_rows<256>, dim3(grid), dim3(64), 0, nullptr, (const int8_t*)(b + o_in), n, width, cyclical, (int8_t*)(b + o_out), (int32_t*)(b + o_len), b + o_err);
+    ACX_HIP_TRY(hipGetLastError());
+    ACX_HIP_TRY(hipDeviceSynchronize());
+    ACX_HIP_TRY(hipMemcpy(h_out, b + o_out, n * width, hipMemcpyDeviceToHost));
+    ACX_HIP_TRY(hipMemcpy(h_len, b + o_len, n * 8, hipMemcpyDeviceToHost));
+    ACX_HIP_TRY(hipMemcpy(h_err, b + o_err, n, hipMemcpyDeviceToHost));
+    return ACX_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------- env ---
+template <typename W> static void carve(EnvDev<W>& d, uint8_t* base, int64_t n, int L, int H, int64_t horizon, bool hist, size_t* total) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        uint8_t* p = base ? base + o : nullptr;
+        o += (bytes + 255) / 256 * 256;
+        return p;
+    };
+    d.w0 = (W*)take(n * sizeof(W));
+    d.w1 = (W*)take(n * sizeof(W));
+    d.iw0 = (W*)take(n * sizeof(W));
+    d.iw1 = (W*)take(n * sizeof(W));
+    d.ln = (uint16_t*)take(n * 2);
+    d.iln = (uint16_t*)take(n * 2);
+    d.cnt = (int32_t*)take(n * 4);
+    d.last_len = (int32_t*)take(n * 4);
+    d.err = (uint8_t*)take(n);
+    d.hist = hist ? (uint8_t*)take((size_t)H * n) : nullptr;
+    d.n = n;
+    d.L = L;
+    d.H = H;
+    d.horizon = horizon;
+    d.max_reward = (float)(horizon * L * 2);
+    *total = o;
+}
+
+extern "C" {
+
+acx_env* acx_env_create(int64_t n, int L, int64_t horizon, int flags) {
+    if (!have_device()) return nullptr;
+    if (n < 1 || L < 1 || L > 64 || horizon < 1) {
+        fail(ACX_E_INVAL, "acx_env_create: need n >= 1, 1 <= L <= 64, horizon >= 1");
+        return nullptr;
+    }
+    acx_env* e = new (std::nothrow) acx_env();
+    if (!e) return nullptr;
+    e->n = n;
+    e->L = L;
+    e->horizon = horizon;
+    e->flags = flags;
+    e->wide = L > 32;
+    e->H = (int)(horizon < (1 << 20) ? horizon : (1 << 20));
+    (void)hipGetDevice(&e->device);
+    size_t total = 0;
+    const bool hist = (flags & ACX_ENV_RECORD_ACTIONS) != 0;
+    if (e->wide) carve<u128>(e->d128, nullptr, n, L, e->H, horizon, hist, &total);
+    else carve<uint64_t>(e->d64, nullptr, n, L, e->H, horizon, hist, &total);
+    if (hipMalloc(&e->arena, total) != hipSuccess) {
+        fail(ACX_E_NOMEM, "acx_env_create: hipMalloc(%zu) failed", total);
+        delete e;
+        return nullptr;
+    }
+    (void)hipMemset(e->arena, 0, total);
+    if (e->wide) carve<u128>(e->d128, (uint8_t*)e->arena, n, L, e->H, horizon, hist, &total);
+    else carve<uint64_t>(e->d64, (uint8_t*)e->arena, n, L, e->H, horizon, hist, &total);
+    // default ACEnvConfig.initial_state is the trivial presentation <x, y> (ac_env.py:16-18)
+    std::vector<int8_t> init((size_t)n * 2 * L, 0);
+    for (int64_t i = 0; i < n; i++) {
+        init[i * 2 * L] = 1;
+        init[i * 2 * L + L] = 2;
+    }
+    if (acx_env_set_initial(e, init.data(), nullptr, n) != ACX_OK) {
+        acx_env_destroy(e);
+        return nullptr;
+    }
+    return e;
+}
+
+void acx_env_destroy(acx_env* e) {
+    if (!e) return;
+    if (e->arena) (void)hipFree(e->arena);
+    delete e;
+}
+
+int64_t acx_env_max_reward(const acx_env* e) { return e ? e->horizon * e->L * 2 : 0; }
+
+static int env_load_rows(acx_env* e, const int8_t* h_states, const int64_t* h_idx, int64_t m, int to_initial) {
+    if (!e || m < 0 || (h_idx == nullptr && m != e->n && m != 0)) return fail(ACX_E_INVAL, "env reset: idx == NULL needs n_idx == n");
+    if (m == 0) return ACX_OK;
+    if (h_idx)
+        for (int64_t k = 0; k < m; k++)
+            if (h_idx[k] < 0 || h_idx[k] >= e->n) return fail(ACX_E_INVAL, "env reset: index %lld out of range", (long long)h_idx[k]);
+    const size_t row = (size_t)2 * e->L;
+    auto up = [&](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t o_rows = 0, o_idx = up(m * row), o_err = o_idx + up(m * 8), total = o_err + up(m);
+    Scratch& s = scratch(1);
+    int rc = s.ensure(total);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)s.p;
+    if (h_states) ACX_HIP_TRY(hipMemcpy(b + o_rows, h_states, m * row, hipMemcpyHostToDevice));
+    if (h_idx) ACX_HIP_TRY(hipMemcpy(b + o_idx, h_idx, m * 8, hipMemcpyHostToDevice));
+    const unsigned grid = (unsigned)ceil_div<int64_t>(m, 256);
+    const int8_t* rows = h_states ? (const int8_t*)(b + o_rows) : nullptr;
+    const int64_t* idx = h_idx ? (const int64_t*)(b + o_idx) : nullptr;
+    if (e->wide) hipLaunchKernelGGL(k_env_load<u128>, dim3(grid), dim3(256), 0, nullptr, e->d128, rows, idx, m, to_initial, b + o_err);
+    else hipLaunchKernelGGL(k_env_load<uint64_t>, dim3(grid), dim3(256), 0, nullptr, e->d64, rows, idx, m, to_initial, b + o_err);
+    ACX_HIP_TRY(hipGetLastError());
+    std::vector<uint8_t> err((size_t)m);
+    ACX_HIP_TRY(hipMemcpy(err.data(), b + o_err, m, hipMemcpyDeviceToHost));
+    for (int64_t k = 0; k < m; k++)
+        if (err[k]) return fail(ACX_E_ROWERR, "row %lld is not a valid presentation over {+-1,+-2} (ACEnvConfig raises ValueError)", (long long)k);
+    return ACX_OK;
+}
+
+int acx_env_set_initial(acx_env* e, const int8_t* h_states, const int64_t* h_idx, int64_t n_idx) {
+    if (!h_states) return fail(ACX_E_INVAL, "acx_env_set_initial: states required");
+    return env_load_rows(e, h_states, h_idx, n_idx, 1);
+}
+
+int acx_env_reset(acx_env* e, const int8_t* h_states, const int64_t* h_idx, int64_t n_idx) {
+    return env_load_rows(e, h_states, h_idx, n_idx, 0);
+}
+
+int acx_env_step(acx_env* e, const void* d_actions, int action_dtype, void* d_obs, int obs_dtype, float* d_reward, float clip_lo,
+                 float clip_hi, uint8_t* d_done, uint8_t* d_trunc, void* d_final_obs, int autoreset, void* stream) {
+    if (!e || !d_actions) return fail(ACX_E_INVAL, "acx_env_step: env and actions required");
+    if (action_dtype < ACX_U8 || action_dtype > ACX_I8) return fail(ACX_E_INVAL, "acx_env_step: bad action dtype");
+    if (obs_dtype != ACX_I8 && obs_dtype != ACX_F32) return fail(ACX_E_INVAL, "acx_env_step: obs dtype must be ACX_I8 or ACX_F32");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)ceil_div<int64_t>(e->n, 256);
+    const bool f32 = obs_dtype == ACX_F32;
+    const size_t lds = (d_obs || d_final_obs) ? (size_t)4 * 64 * 2 * e->L * (f32 ? 4 : 1) : 0;
+    const int vec = aligned16(d_obs) && aligned16(d_final_obs);
+#define ACX_LAUNCH_STEP(W, OBS, dev)                                                                                                  \
+    hipLaunchKernelGGL((k_env_step<W, OBS>), dim3(grid), dim3(256), lds, st, dev, d_actions, action_dtype, (OBS*)d_obs, d_reward, clip_lo, \
+                       clip_hi, d_done, d_trunc, (OBS*)d_final_obs, autoreset, vec)
+    if (e->wide) {
+        if (f32) ACX_LAUNCH_STEP(u128, float, e->d128);
+        else ACX_LAUNCH_STEP(u128, int8_t, e->d128);
+    } else {
+        if (f32) ACX_LAUNCH_STEP(uint64_t, float, e->d64);
+        else ACX_LAUNCH_STEP(uint64_t, int8_t, e->d64);
+    }
+#undef ACX_LAUNCH_STEP
+    ACX_HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
+int acx_env_step_host(acx_env* e, const int64_t* h_actions, int8_t* h_obs, float* h_reward, uint8_t* h_done, uint8_t* h_trunc,
+                      int8_t* h_final_obs, int autoreset) {
+    if (!e || !h_actions) return fail(ACX_E_INVAL, "acx_env_step_host: env and actions required");
+    const int64_t n = e->n;
+    const size_t row = (size_t)2 * e->L;
+    auto up = [&](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t o_act = 0, o_obs = up(n * 8), o_fin = o_obs + up(n * row), o_rew = o_fin + up(n * row), o_done = o_rew + up(n * 4),
+                 o_trunc = o_done + up(n), total = o_trunc + up(n);
+    Scratch& s = scratch(2);
+    int rc = s.ensure(total);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)s.p;
+    ACX_HIP_TRY(hipMemcpy(b + o_act, h_actions, n * 8, hipMemcpyHostToDevice));
+    rc = acx_env_step(e, b + o_act, ACX_I64, b + o_obs, ACX_I8, (float*)(b + o_rew), 0.f, 0.f, b + o_done, b + o_trunc,
+                      h_final_obs ? b + o_fin : nullptr, autoreset, nullptr);
+    if (rc) return rc;
+    ACX_HIP_TRY(hipDeviceSynchronize());
+    if (h_obs) ACX_HIP_TRY(hipMemcpy(h_obs, b + o_obs, n * row, hipMemcpyDeviceToHost));
+    if (h_final_obs) ACX_HIP_TRY(hipMemcpy(h_final_obs, b + o_fin, n * row, hipMemcpyDeviceToHost));
+    if (h_reward) ACX_HIP_TRY(hipMemcpy(h_reward, b + o_rew, n * 4, hipMemcpyDeviceToHost));
+    if (h_done) ACX_HIP_TRY(hipMemcpy(h_done, b + o_done, n, hipMemcpyDeviceToHost));
+    if (h_trunc) ACX_HIP_TRY(hipMemcpy(h_trunc, b + o_trunc, n, hipMemcpyDeviceToHost));
+    return ACX_OK;
+}
+
+int acx_env_rollout(acx_env* e, const uint8_t* d_tape, int64_t T, float* d_reward, float clip_lo, float clip_hi, uint8_t* d_done,
+                    uint8_t* d_trunc, int autoreset, void* stream) {
+    if (!e || !d_tape || T < 0) return fail(ACX_E_INVAL, "acx_env_rollout: bad argument");
+    if (T == 0) return ACX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)ceil_div<int64_t>(e->n, 256);
+    if (e->wide) hipLaunchKernelGGL(k_env_rollout<u128>, dim3(grid), dim3(256), 0, st, e->d128, d_tape, T, d_reward, clip_lo, clip_hi, d_done, d_trunc, autoreset);
+    else hipLaunchKernelGGL(k_env_rollout<uint64_t>, dim3(grid), dim3(256), 0, st, e->d64, d_tape, T, d_reward, clip_lo, clip_hi, d_done, d_trunc, autoreset);
+    ACX_HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
+int acx_env_observe(acx_env* e, void* d_obs, int obs_dtype, void* stream) {
+    if (!e || !d_obs) return fail(ACX_E_INVAL, "acx_env_observe: bad argument");
+    if (obs_dtype != ACX_I8 && obs_dtype != ACX_F32) return fail(ACX_E_INVAL, "acx_env_observe: obs dtype must be ACX_I8 or ACX_F32");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)ceil_div<int64_t>(e->n, 256);
+    const bool f32 = obs_dtype == ACX_F32;
+    const size_t lds = (size_t)4 * 64 * 2 * e->L * (f32 ? 4 : 1);
+    const int vec = aligned16(d_obs);
+    if (e->wide) {
+        if (f32) hipLaunchKernelGGL((k_env_observe<u128, float>), dim3(grid), dim3(256), lds, st, e->d128, (float*)d_obs, vec);
+        else hipLaunchKernelGGL((k_env_observe<u128, int8_t>), dim3(grid), dim3(256), lds, st, e->d128, (int8_t*)d_obs, vec);
+    } else {
+        if (f32) hipLaunchKernelGGL((k_env_observe<uint64_t, float>), dim3(grid), dim3(256), lds, st, e->d64, (float*)d_obs, vec);
+        else hipLaunchKernelGGL((k_env_observe<uint64_t, int8_t>), dim3(grid), dim3(256), lds, st, e->d64, (int8_t*)d_obs, vec);
+    }
+    ACX_HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
+int acx_env_get(acx_env* e, const int64_t* h_idx, int64_t m, int8_t* h_state, int32_t* h_len, int32_t* h_count) {
+    if (!e || m < 0 || (!h_idx && m != e->n)) return fail(ACX_E_INVAL, "acx_env_get: bad argument");
+    if (m == 0) return ACX_OK;
+    if (h_idx)
+        for (int64_t k = 0; k < m; k++)
+            if (h_idx[k] < 0 || h_idx[k] >= e->n) return fail(ACX_E_INVAL, "acx_env_get: index out of range");
+    const size_t row = (size_t)2 * e->L;
+    auto up = [&](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t o_rows = 0, o_idx = up(m * row), o_len = o_idx + up(m * 8), o_cnt = o_len + up(m * 8), total = o_cnt + up(m * 4);
+    Scratch& s = scratch(1);
+    int rc = s.ensure(total);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)s.p;
+    if (h_idx) ACX_HIP_TRY(hipMemcpy(b + o_idx, h_idx, m * 8, hipMemcpyHostToDevice));
+    ACX_HIP_TRY(hipDeviceSynchronize());  // steps may be in flight on other streams
+    const unsigned grid = (unsigned)ceil_div<int64_t>(m, 256);
+    const int64_t* idx = h_idx ? (const int64_t*)(b + o_idx) : nullptr;
+    if (e->wide) hipLaunchKernelGGL(k_env_gather<u128>, dim3(grid), dim3(256), 0, nullptr, e->d128, idx, m, (int8_t*)(b + o_rows), (int32_t*)(b + o_len), (int32_t*)(b + o_cnt));
+    else hipLaunchKernelGGL(k_env_gather<uint64_t>, dim3(grid), dim3(256), 0, nullptr, e->d64, idx, m, (int8_t*)(b + o_rows), (int32_t*)(b + o_len), (int32_t*)(b + o_cnt));
+    ACX_HIP_TRY(hipGetLastError());
+    if (h_state) ACX_HIP_TRY(hipMemcpy(h_state, b + o_rows, m * row, hipMemcpyDeviceToHost));
+    if (h_len) ACX_HIP_TRY(hipMemcpy(h_len, b + o_len, m * 8, hipMemcpyDeviceToHost));
+    if (h_count) ACX_HIP_TRY(hipMemcpy(h_count, b + o_cnt, m * 4, hipMemcpyDeviceToHost));
+    return ACX_OK;
+}
+
+int acx_env_get_actions(acx_env* e, int64_t i, int which, int32_t* h_out, int64_t cap, int64_t* n_out) {
+    if (!e || i < 0 || i >= e->n || !n_out) return fail(ACX_E_INVAL, "acx_env_get_actions: bad argument");
+    if (!(e->flags & ACX_ENV_RECORD_ACTIONS)) return fail(ACX_E_INVAL, "env was created without ACX_ENV_RECORD_ACTIONS");
+    ACX_HIP_TRY(hipDeviceSynchronize());
+    const uint8_t* hist = e->wide ? e->d128.hist : e->d64.hist;
+    const int32_t* src = which ? (e->wide ? e->d128.last_len : e->d64.last_len) : (e->wide ? e->d128.cnt : e->d64.cnt);
+    int32_t cnt = 0;
+    ACX_HIP_TRY(hipMemcpy(&cnt, src + i, 4, hipMemcpyDeviceToHost));
+    *n_out = cnt;
+    if (cnt > e->H) return fail(ACX_E_CAPACITY, "episode has %d steps but the history ring keeps %d", cnt, e->H);
+    if (cnt > cap) return fail(ACX_E_CAPACITY, "actions buffer too small: need %d", cnt);
+    if (cnt == 0) return ACX_OK;
+    std::vector<uint8_t> col((size_t)cnt);
+    // strided column read: row t of the ring, column i
+    ACX_HIP_TRY(hipMemcpy2D(col.data(), 1, hist + i, (size_t)e->n, 1, (size_t)cnt, hipMemcpyDeviceToHost));
+    for (int32_t t = 0; t < cnt; t++) h_out[t] = col[t];
+    return ACX_OK;
+}
+
+int acx_env_get_errors(acx_env* e, uint8_t* h_err, int clear) {
+    if (!e || !h_err) return fail(ACX_E_INVAL, "acx_env_get_errors: bad argument");
+    ACX_HIP_TRY(hipDeviceSynchronize());
+    uint8_t* d = e->wide ? e->d128.err : e->d64.err;
+    ACX_HIP_TRY(hipMemcpy(h_err, d, e->n, hipMemcpyDeviceToHost));
+    if (clear) ACX_HIP_TRY(hipMemset(d, 0, e->n));
+    return ACX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+// acx_word.h -- packed-word arithmetic for two-generator Andrews-Curtis presentations.
+//
+// A relator over {x, x^-1, y, y^-1} is held as (w, n): letter k occupies bits [2k, 2k+1] of w,
+// n is the length, bits above 2n are zero.  The 2-bit code is ORDER PRESERVING on the int8 letters
+// of the reference (-2 -> 0, -1 -> 1, +1 -> 2, +2 -> 3) so that inverse(letter) = code ^ 3 and
+// tuple comparison of int8 states can be done on codes.  W = uint64_t carries L <= 32 letters,
+// W = unsigned __int128 carries L <= 64.
+//
+// With this layout the reference's word operations become a handful of shifts and masks:
+//   inverse word        reverse the 2-bit groups, complement              (ac_moves.py:41-48)
+//   junction cancel     ctz(inv(w1) ^ w2) / 2                             (ac_moves.py:56-60)
+//   concatenation       w1 | (w2 >> 2acc) << 2(n1-acc)                    (ac_moves.py:62-74)
+//   conjugation         compare first / last code with g                  (ac_moves.py:119-154)
+//   "is freely reduced" any 2-bit field of w ^ (w >> 2) equal to 3        (utils.py:208-217)
+//   cyclic reduction    ctz(w ^ inv(w)) / 2 letters off both ends         (utils.py:220-229)
+//
+// Everything here is __host__ __device__ so that tests/hostshim can run the very same code on the
+// CPU against the oracle (test infrastructure); the product only ever runs it inside HIP kernels.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define ACX_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define ACX_HD inline
+#endif
+
+namespace acx {
+
+typedef unsigned __int128 u128;
+
+enum : int {
+    ACX_ERR_NONE = 0,
+    ACX_ERR_ASSERT = 1,      // the reference raises AssertionError (invalid presentation after the move)
+    ACX_ERR_INDEX = 2,       // the reference raises IndexError (conjugating an empty relator)
+    ACX_ERR_VALUE = 3,       // the reference raises ValueError (np.pad with a negative width)
+    ACX_ERR_UNPACKABLE = 250 // row is not a valid {0,+-1,+-2} presentation: use the byte path
+};
+
+ACX_HD int code_of_letter(int a) { return a < 0 ? a + 2 : a + 1; }   // a in {-2,-1,1,2}
+ACX_HD int letter_of_code(int c) { return c < 2 ? c - 2 : c - 1; }
+
+// ---- width-specific primitives -------------------------------------------------------------
+template <typename W> struct wtraits;
+
+template <> struct wtraits<uint64_t> {
+    static constexpr int kBits = 64;
+    static constexpr int kMaxLetters = 32;
+    static ACX_HD int ctz(uint64_t w) { return __builtin_ctzll(w); }  // w != 0
+    static ACX_HD uint64_t rev2(uint64_t w) {                         // reverse the 32 two-bit groups
+        uint64_t r = __builtin_bitreverse64(w);
+        return ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+    }
+    static ACX_HD uint64_t lo_ones() { return 0x5555555555555555ull; }
+};
+
+template <> struct wtraits<u128> {
+    static constexpr int kBits = 128;
+    static constexpr int kMaxLetters = 64;
+    static ACX_HD int ctz(u128 w) {
+        uint64_t lo = (uint64_t)w;
+        return lo ? __builtin_ctzll(lo) : 64 + __builtin_ctzll((uint64_t)(w >> 64));
+    }
+    static ACX_HD u128 rev2(u128 w) {
+        return ((u128)wtraits<uint64_t>::rev2((uint64_t)w) << 64) | wtraits<uint64_t>::rev2((uint64_t)(w >> 64));
+    }
+    static ACX_HD u128 lo_ones() { return ((u128)0x5555555555555555ull << 64) | 0x5555555555555555ull; }
+};
+
+// shifts by a letter count that may reach the full width
+template <typename W> ACX_HD W shl(W w, int letters) { return 2 * letters >= wtraits<W>::kBits ? (W)0 : (W)(w << (2 * letters)); }
+template <typename W> ACX_HD W shr(W w, int letters) { return 2 * letters >= wtraits<W>::kBits ? (W)0 : (W)(w >> (2 * letters)); }
+template <typename W> ACX_HD W mask(int letters) { return (W)(shl<W>((W)1, letters) - 1); }  // letters == max -> 0 - 1 = all ones
+template <typename W> ACX_HD int get(W w, int k) { return (int)((uint32_t)shr<W>(w, k) & 3u); }
+
+// inverse word: reversed and letter-wise inverted (code ^ 3)
+template <typename W> ACX_HD W inv(W w, int n) {
+    if (n == 0) return (W)0;
+    W r = wtraits<W>::rev2(w) >> (wtraits<W>::kBits - 2 * n);
+    return r ^ mask<W>(n);
+}
+
+// number of leading letters on which a and b agree, capped at `cap`
+template <typename W> ACX_HD int common_prefix(W a, W b, int cap) {
+    W t = a ^ b;
+    int cp = t ? (wtraits<W>::ctz(t) >> 1) : wtraits<W>::kMaxLetters;
+    return cp < cap ? cp : cap;
+}
+
+// true when some adjacent pair of the n-letter word is mutually inverse
+template <typename W> ACX_HD bool has_inverse_pair(W w, int n) {
+    if (n < 2) return false;
+    W t = w ^ (w >> 2);  // field k = code[k] ^ code[k+1]; inverse pair <=> field == 3
+    return (t & (t >> 1) & wtraits<W>::lo_ones() & mask<W>(n - 1)) != 0;
+}
+
+// free reduction (utils.py:208-217): stack pass; the freely reduced form is unique, so this equals
+// the reference's delete-and-step-back loop
+template <typename W> ACX_HD void free_reduce(W& w, int& n) {
+    if (!has_inverse_pair<W>(w, n)) return;
+    W o = 0;
+    int on = 0;
+    for (int k = 0; k < n; k++) {
+        int c = get<W>(w, k);
+        if (on > 0 && get<W>(o, on - 1) == (c ^ 3)) {
+            on--;
+            o &= mask<W>(on);
+        } else {
+            o |= shl<W>((W)c, on);
+            on++;
+        }
+    }
+    w = o;
+    n = on;
+}
+
+// cyclic reduction of a freely reduced word (utils.py:220-229)
+template <typename W> ACX_HD void cyclic_reduce(W& w, int& n) {
+    if (n < 2) return;
+    W t = w ^ inv<W>(w, n);  // non-zero for a reduced non-empty word (w == w^-1 only for the empty word)
+    if (!t) return;
+    int p = wtraits<W>::ctz(t) >> 1;  // < n/2: a reduced word cannot match through its middle
+    if (2 * p >= n) return;           // unreachable for reduced words; keeps shifts defined
+    w = shr<W>(w, p) & mask<W>(n - 2 * p);
+    n -= 2 * p;
+}
+
+// A packed presentation.  Plain scalar fields (no arrays): runtime-indexed members would be spilled
+// to scratch / LDS by hipcc.
+template <typename W> struct Pres {
+    W w0, w1;
+    int n0, n1;
+};
+
+// r1 r2^{+-1} with junction cancellation (ac_moves.py:4-76): (w1,n1) is r_i, (w2,n2) is r_j.
+// Returns false when the product does not fit (outputs untouched).
+template <typename W> ACX_HD bool concat_words(W w1, int n1, W w2, int n2, bool negate, int L, W& out, int& nout) {
+    if (negate) w2 = inv<W>(w2, n2);
+    const int acc = common_prefix<W>(inv<W>(w1, n1), w2, n1 < n2 ? n1 : n2);
+    const int nn = n1 + n2 - 2 * acc;
+    if (nn > L) return false;
+    out = (w1 & mask<W>(n1 - acc)) | shl<W>(shr<W>(w2, acc), n1 - acc);
+    nout = nn;
+    return true;
+}
+
+// g r g^-1 with end cancellation (ac_moves.py:79-156); gc is the code of g; n >= 1
+template <typename W> ACX_HD bool conjugate_word(W w, int n, int gc, int L, W& out, int& nout) {
+    const int sc = get<W>(w, 0) == (gc ^ 3);
+    const int ec = get<W>(w, n - 1) == gc;
+    const int nn = n + 2 - 2 * (sc + ec);
+    if (nn > L) return false;
+    const int nb = n - sc - ec;  // letters of r that survive
+    W r = shr<W>(w, sc) & mask<W>(nb);
+    if (!sc) r = (r << 2) | (W)gc;
+    if (!ec) r |= shl<W>((W)(gc ^ 3), nn - 1);
+    out = r;
+    nout = nn;
+    return true;
+}
+
+// ACMove (ac_moves.py:159-231) on a packed presentation (zero-padded words over {+-1,+-2}; a relator
+// may be empty, as the reference's own outputs can be when the input was not freely reduced).
+// Returns ACX_ERR_NONE, ACX_ERR_INDEX (conjugating an empty relator, ac_moves.py:119) or
+// ACX_ERR_ASSERT (a relator is empty after the move: the validity assert of simplify_presentation,
+// utils.py:261-263); on error the state is left unchanged.
+template <typename W> ACX_HD int apply_move(Pres<W>& s, int a, int L, bool cyclical) {
+    const int m = a + 1;
+    const bool i1 = (m & 1) != 0;  // ac_moves.py:192-206: odd ids touch r_1
+    const int i = i1 ? 1 : 0;
+    W wi = i1 ? s.w1 : s.w0, wj = i1 ? s.w0 : s.w1;
+    int ni = i1 ? s.n1 : s.n0, nj = i1 ? s.n0 : s.n1;
+    if (a < 4) {
+        concat_words<W>(wi, ni, wj, nj, (((m - i) >> 1) & 1) != 0, L, wi, ni);
+    } else {
+        if (ni == 0) return ACX_ERR_INDEX;
+        const int jp = ((m - i) >> 1) & 1;
+        const int sp = ((m - i - 2 * jp) >> 2) & 1;
+        conjugate_word<W>(wi, ni, sp ? 1 - jp : 2 + jp, L, wi, ni);  // g = -(jp+1) -> code 1-jp ; +(jp+1) -> 2+jp
+    }
+    if (ni == 0 || nj == 0) return ACX_ERR_ASSERT;
+    // simplify_presentation, utils.py:267-278 (both relators, also the untouched one)
+    free_reduce<W>(wi, ni);
+    free_reduce<W>(wj, nj);
+    if (cyclical) {
+        cyclic_reduce<W>(wi, ni);
+        cyclic_reduce<W>(wj, nj);
+    }
+    s.w0 = i1 ? wj : wi;
+    s.w1 = i1 ? wi : wj;
+    s.n0 = i1 ? nj : ni;
+    s.n1 = i1 ? ni : nj;
+    return ACX_ERR_NONE;
+}
+
+// ---- int8 row <-> packed ------------------------------------------------------------------------
+// Pack one relator from L int8 letters.  Returns false if the row is not a right-padded word over
+// {+-1, +-2} (interior zero or foreign letter).
+template <typename W> ACX_HD bool pack_relator(const int8_t* r, int L, W& w, int& n) {
+    W o = 0;
+    int len = 0;
+    bool ok = true, ended = false;
+    for (int k = 0; k < L; k++) {
+        int a = r[k];
+        if (a == 0) {
+            ended = true;
+        } else {
+            ok = ok && !ended && a >= -2 && a <= 2;
+            o |= shl<W>((W)(code_of_letter(a) & 3), len);
+            len++;
+        }
+    }
+    w = o;
+    n = len;
+    return ok;
+}
+
+template <typename W> ACX_HD void unpack_relator(W w, int n, int L, int8_t* r) {
+    for (int k = 0; k < L; k++) r[k] = k < n ? (int8_t)letter_of_code(get<W>(w, k)) : (int8_t)0;
+}
+
+// 8 letters starting at letter `k0` as 8 int8 in one u64 (little endian), zero beyond n.
+template <typename W> ACX_HD uint64_t unpack8(W w, int n, int k0) {
+    uint64_t x = (uint64_t)shr<W>(w, k0) & 0xFFFFull;               // 8 codes
+    x = (x | (x << 24)) & 0x000000FF000000FFull;
+    x = (x | (x << 12)) & 0x000F000F000F000Full;
+    x = (x | (x << 6)) & 0x0303030303030303ull;                     // one code per byte
+    uint64_t hi = (x >> 1) & 0x0101010101010101ull;                 // code >= 2
+    x = ((x + hi + 0x7E7E7E7E7E7E7E7Eull) ^ 0x8080808080808080ull); // code -> letter: {0,1,2,3} -> {-2,-1,1,2}
+    int cnt = n - k0;
+    uint64_t m = cnt >= 8 ? ~0ull : (cnt <= 0 ? 0ull : ((1ull << (8 * cnt)) - 1));
+    return x & m;
+}
+
+// Signed-tuple order of two packed presentations as the reference's Python tuples compare them
+// (greedy.py:104-113: zeros pad each half, -2 < -1 < 0 < 1 < 2).  Returns <0, 0, >0.
+template <typename W> ACX_HD int compare_relator(W a, int na, W b, int nb) {
+    W t = a ^ b;
+    int m = na < nb ? na : nb;
+    int cp = t ? (wtraits<W>::ctz(t) >> 1) : wtraits<W>::kMaxLetters;
+    if (cp < m) return get<W>(a, cp) < get<W>(b, cp) ? -1 : 1;
+    if (na == nb) return 0;
+    // the shorter word is a prefix of the longer: compare its padding 0 with the longer word's next letter
+    if (na < nb) return get<W>(b, na) >= 2 ? -1 : 1;  // 0 < positive letter
+    return get<W>(a, nb) >= 2 ? 1 : -1;
+}
+
+template <typename W> ACX_HD int compare_pres(const Pres<W>& a, const Pres<W>& b) {
+    int c = compare_relator<W>(a.w0, a.n0, b.w0, b.n0);
+    return c ? c : compare_relator<W>(a.w1, a.n1, b.w1, b.n1);
+}
+
+}  // namespace acx

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the AC hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 65 536 batched ACEnv.step per GPU, Miller-Schupp initial states
+(pool of 1190 presentations, env e starts from pool[e mod 1190]) re-embedded at max_relator_length = 25,
+uniform random actions from a pre-generated device tape, horizon 1000, gymnasium-style autoreset.
+A "step" is ONE launch of the env kernel over the whole batch: it reads the packed state + the action
+and writes the new state, the int8 observation [N, 50], the f32 reward and the done / truncated flags
+into row t of PPO-style rollout buffers that are already resident in HBM.
+
+One process per GPU (torch.distributed / RCCL only for the barrier and the MAX over ranks: the
+environments are independent, so there is no data-path collective -> "scaling": "weak").
+Rank 0 prints ONE JSON line.  `roofline` prices the env kernel against HBM with the ALGORITHMIC bytes
+of one step (4L + 7 = 107 B at L = 25); `cpu_baseline` times the CPU oracle (plain C port
+of the reference's algorithm, oracle/ac_oracle.c) on one host core on a bounded sample of the same
+workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "ac-solver_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+L = 25
+N_ENVS = 65536
+HORIZON = 1000
+ALGO_BYTES_PER_STEP = 4 * L + 7  # state in + out (2 x 2L), action 1, reward f32 4, done 1, truncated 1
+HBM_PEAK_GBS = 8000.0            # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+
+def ms_pool_at_L(L):
+    """The 1190 Miller-Schupp presentations (n = 1..7, max_w_len = 7, generator order) at width L."""
+    from ac_solver.search.miller_schupp.miller_schupp import generate_miller_schupp_presentations
+
+    pool = []
+    for n in range(1, 8):
+        d = generate_miller_schupp_presentations(n, 7)
+        for w in range(1, 8):
+            for p in d[w]:
+                p = np.asarray(p, np.int8)
+                half = len(p) // 2
+                row = np.zeros(2 * L, np.int8)
+                for h in (0, 1):
+                    word = p[h * half:(h + 1) * half]
+                    word = word[word != 0]
+                    row[h * L:h * L + len(word)] = word
+                pool.append(row)
+    return np.stack(pool)
+
+
+def cpu_baseline(states, seed, budget_s=12.0):
+    """Oracle ACEnv.step (1 thread) on a bounded sample of the same workload: 4096-env slices x 64 steps."""
+    from oracle import ac_oracle as O
+
+    rng = np.random.default_rng(seed)
+    n = 4096
+    st = np.ascontiguousarray(states[:n]).copy()
+    cnt = np.zeros(n, np.int32)
+    steps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        tape = rng.integers(0, 12, size=(64, n), dtype=np.uint8)
+        O.env_rollout(st, cnt, HORIZON, tape, want_outputs=True)
+        done = cnt >= HORIZON
+        if done.any():  # keep the sample in the same regime as the GPU run (autoreset at the horizon)
+            st[done] = states[:n][done]
+            cnt[done] = 0
+        steps += 64 * n
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} ACEnv.step calls ({n} envs, MS initial states, L={L}) by oracle/ac_oracle.c in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, default=N_ENVS, help="envs per GPU (default: BASELINE config 2)")
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
+                    help="graph: the K launches are captured once into a hipGraph and replayed; eager: K host launches")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-search", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the AC hot path only exists as HIP kernels (no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from ac_solver import _acx
+    from ac_solver.envs.vec_env import ACVecEnv
+
+    K, W, N = args.steps, args.warmup, args.envs
+    pool = ms_pool_at_L(L)
+    states = pool[(np.arange(N) + rank * N) % len(pool)]
+    env = ACVecEnv(states, horizon_length=HORIZON, obs_dtype="int8", record_actions=False, final_info=False)
+    dev = env.device
+    T = K + W
+    tape = torch.as_tensor(np.random.default_rng(rank).integers(0, 12, size=(T, N), dtype=np.uint8), device=dev)
+    # PPO-style rollout buffers, resident in HBM before the timed region
+    obs = torch.empty((K, N, 2 * L), dtype=torch.int8, device=dev)
+    rew = torch.empty((K, N), dtype=torch.float32, device=dev)
+    done = torch.empty((K, N), dtype=torch.bool, device=dev)
+    trunc = torch.empty((K, N), dtype=torch.bool, device=dev)
+
+    def launch(t, slot):
+        _acx.check(_acx.lib.acx_env_step(env._h.ptr, tape[t].data_ptr(), _acx.U8, obs[slot].data_ptr(), _acx.I8, rew[slot].data_ptr(), 0.0, 0.0,
+                                         done[slot].data_ptr(), trunc[slot].data_ptr(), None, 1, env._stream()), "acx_env_step")
+
+    env.reset()
+    for t in range(W):  # untimed warm-up steps
+        launch(t, t % K)
+    torch.cuda.synchronize()
+
+    mode = args.mode
+    graph = None
+    if mode == "graph":
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):  # capturing does not execute: the env stays in its post-warm-up state
+                for k in range(K):
+                    launch(W + k, k)
+        except Exception as e:  # pragma: no cover
+            print(f"[bench] graph capture failed ({e}); falling back to eager launches", file=sys.stderr)
+            graph, mode = None, "eager"
+    torch.cuda.synchronize()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    if graph is not None:
+        graph.replay()
+    else:
+        for k in range(K):
+            launch(W + k, k)
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream: K back-to-back env kernels
+
+    tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall, dev_ms = float(tmax[0]), float(tmax[1])
+
+    # sanity: the timed steps really ran (count_steps advanced, rewards written)
+    assert int(env.get_counts().max()) > 0 and bool(torch.isfinite(rew).all()) and bool((rew != 0).all())
+
+    if rank == 0:
+        total_steps = N * K * world
+        launch_s = dev_ms * 1e-3 / K
+        achieved = ALGO_BYTES_PER_STEP * N / launch_s / 1e9
+        out = {
+            "metric": "AC env-steps/sec at max_relator_len=25",
+            "value": total_steps / wall,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": wall * 1e3 / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int8 letters packed 2 bit/letter in u64",
+            "data": "synthetic",
+            "config": {"workload": f"{N} batched ACEnv.step per GPU, Miller-Schupp initial states, max_relator_len={L}, horizon {HORIZON}, "
+                                   "random action tape, int8 obs + f32 reward + done/truncated into HBM rollout buffers",
+                       "envs_per_gpu": N, "max_relator_length": L, "launch": mode, "parallelism": f"dp{world} (independent envs, no collective)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_env_step<u64,int8>", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * N,
+                         "avg_launch_us": launch_s * 1e6},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(states, 0)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

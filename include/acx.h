@@ -1,0 +1,143 @@
+/*
+ * acx.h -- C ABI of libacx.so: the MI355X (gfx950) Andrews-Curtis environment step and search
+ * frontier.  This is the drop-in boundary for the hot path of shehper/AC-Solver.
+ *
+ * The reference is pure Python and has no FFI; its boundary is the Python surface
+ *     ac_solver/envs/ac_moves.py:159   ACMove            (+ :4 concatenate_relators, :79 conjugate)
+ *     ac_solver/envs/utils.py:175,243  simplify_relator / simplify_presentation
+ *     ac_solver/envs/ac_env.py:95,115  ACEnv.step / ACEnv.reset
+ *     ac_solver/search/breadth_first.py:15  bfs
+ *     ac_solver/search/greedy.py:15         greedy_search
+ * Each entry point below names the reference function it replaces.  The ctypes binding a maintainer
+ * would add is ac-solver_amd/ac_solver/_acx.py.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every buffer
+ *   - every function returns 0 on success, a negative ACX_E_* code on failure, and
+ *     acx_last_error() then returns a thread-local message
+ *   - pointers named d_* are device pointers on the current device (torch `tensor.data_ptr()`),
+ *     h_* are host pointers; `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream) or NULL
+ *   - a presentation is 2L int8: two relators, letters in {+-1, +-2}, left aligned, zero padded
+ *     (ac_solver/envs/utils.py:4-8); rows of a batch are contiguous: [n, 2L]
+ *   - per-row error bytes: 0 ok, 1 the reference raises AssertionError, 2 IndexError, 3 ValueError,
+ *     250 row is not a packable presentation (use ACX_F_BYTES)
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with ACX_E_NODEVICE
+ */
+#ifndef ACX_H
+#define ACX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACX_VERSION 100
+
+/* return codes */
+#define ACX_OK 0
+#define ACX_E_INVAL (-1)    /* bad argument */
+#define ACX_E_NODEVICE (-2) /* no HIP device / HIP runtime error */
+#define ACX_E_NOMEM (-3)
+#define ACX_E_ROWERR (-4)   /* some row hit a reference exception: inspect the err bytes */
+#define ACX_E_CAPACITY (-5) /* a caller-provided output buffer is too small */
+
+/* move flags */
+#define ACX_F_CYCLICAL 1    /* ACMove(cyclical=True) */
+#define ACX_F_NO_SIMPLIFY 2 /* concatenate_relators / conjugate only (ACX_F_BYTES only) */
+#define ACX_F_NO_MOVE 4     /* simplify_presentation only (ACX_F_BYTES only) */
+#define ACX_F_BYTES 8       /* byte-exact kernel: any int8 letters, invalid rows, L <= 128 */
+
+/* dtypes of action / observation buffers */
+#define ACX_U8 0
+#define ACX_I32 1
+#define ACX_I64 2
+#define ACX_I8 3
+#define ACX_F32 4
+
+int acx_version(void);
+const char *acx_last_error(void);
+int acx_device_count(void); /* 0 when no GPU is visible; never fails */
+
+/* ---- stateless batched moves --------------------------------------------------------------
+ * Replaces ACMove (ac_moves.py:159-231) applied row-wise: out[k] = ACMove(action[k], in[k], L,
+ * cyclical).  d_len [n,2] int32 receives the relator lengths, d_err [n] the per-row error byte
+ * (rows in error are copied through unchanged).  d_fit (nullable, ACX_F_BYTES only) [n] int32
+ * receives the new length of the touched relator or -1 when the move did not fit.
+ * Without ACX_F_BYTES the packed kernel runs (L <= 64, valid {+-1,+-2} rows). */
+int acx_move_batch_device(const int8_t *d_in, const void *d_action, int action_dtype, int64_t n, int L, int flags,
+                          int8_t *d_out, int32_t *d_len, uint8_t *d_err, int32_t *d_fit, void *stream);
+/* host-buffer convenience around the same kernels (staging through a cached device buffer) */
+int acx_move_batch(const int8_t *h_in, const uint8_t *h_action, int64_t n, int L, int flags, int8_t *h_out,
+                   int32_t *h_len, uint8_t *h_err, int32_t *h_fit);
+/* Replaces simplify_relator (utils.py:175-240) on n rows of `width` int8: h_out [n,width] gets the
+ * reduced word left aligned, h_len [n,2] = (reduced length, letters on entry), h_err as above. */
+int acx_simplify_relators(const int8_t *h_in, int64_t n, int width, int cyclical, int8_t *h_out, int32_t *h_len,
+                          uint8_t *h_err);
+
+/* ---- vectorised environment ---------------------------------------------------------------
+ * n independent ACEnv instances (ac_env.py:56-134) resident on one device in packed form.
+ * A handle is bound to the device current at creation and is not thread safe. */
+typedef struct acx_env acx_env;
+
+#define ACX_ENV_RECORD_ACTIONS 1 /* keep the per-episode action history (info["actions"], ac_env.py:96,112) */
+
+acx_env *acx_env_create(int64_t n, int L, int64_t horizon, int flags);
+void acx_env_destroy(acx_env *env);
+/* ACEnvConfig.initial_state for the envs idx[0..n_idx) (NULL = all, rows in env order); also resets them.
+ * Rows must be valid presentations (ACEnvConfig.__post_init__, ac_env.py:22-35): else ACX_E_ROWERR. */
+int acx_env_set_initial(acx_env *env, const int8_t *h_states, const int64_t *h_idx, int64_t n_idx);
+/* ACEnv.reset (ac_env.py:115-131): h_states NULL -> back to the initial state, else
+ * options={"starting_state": row}.  Zeroes count_steps and the action history of those envs. */
+int acx_env_reset(acx_env *env, const int8_t *h_states, const int64_t *h_idx, int64_t n_idx);
+/* ACEnv.step for all n envs (ac_env.py:95-113).  d_obs [n,2L] (ACX_I8 or ACX_F32) receives the state
+ * after the step -- after the autoreset when `autoreset` and the env finished, in which case
+ * d_final_obs (nullable, same dtype) holds the terminal observation.  d_reward [n] f32 =
+ * max_reward*done - total_length*(1-done), clipped to [clip_lo, clip_hi] when clip_lo < clip_hi.
+ * d_done / d_trunc [n] u8.  Any pointer may be NULL to skip that output. */
+int acx_env_step(acx_env *env, const void *d_actions, int action_dtype, void *d_obs, int obs_dtype, float *d_reward,
+                 float clip_lo, float clip_hi, uint8_t *d_done, uint8_t *d_trunc, void *d_final_obs, int autoreset,
+                 void *stream);
+/* Same step with host buffers (single-env Python surface): h_actions [n] int64, h_obs / h_final_obs
+ * [n,2L] int8, h_reward [n] f32 (unclipped), h_done / h_trunc [n] u8.  Synchronous. */
+int acx_env_step_host(acx_env *env, const int64_t *h_actions, int8_t *h_obs, float *h_reward, uint8_t *h_done,
+                      uint8_t *h_trunc, int8_t *h_final_obs, int autoreset);
+/* T fused steps from an action tape d_tape [T,n] u8 with the state resident in registers;
+ * d_reward / d_done / d_trunc are [T,n] (nullable).  Same semantics as T calls of acx_env_step. */
+int acx_env_rollout(acx_env *env, const uint8_t *d_tape, int64_t T, float *d_reward, float clip_lo, float clip_hi,
+                    uint8_t *d_done, uint8_t *d_trunc, int autoreset, void *stream);
+/* current observation of all envs, [n,2L] ACX_I8 / ACX_F32, device buffer */
+int acx_env_observe(acx_env *env, void *d_obs, int obs_dtype, void *stream);
+/* host copies for the single-env Python surface: state [n_idx,2L] i8, lengths [n_idx,2] i32,
+ * count_steps [n_idx] i32 */
+int acx_env_get(acx_env *env, const int64_t *h_idx, int64_t n_idx, int8_t *h_state, int32_t *h_len, int32_t *h_count);
+/* info["actions"] of env i (needs ACX_ENV_RECORD_ACTIONS): which = 0 the actions since its last reset,
+ * which = 1 the actions of the episode that the last step's autoreset just ended (final_info). */
+int acx_env_get_actions(acx_env *env, int64_t i, int which, int32_t *h_out, int64_t cap, int64_t *n_out);
+/* sticky per-env error bytes (a move hit the reference's AssertionError / IndexError: that env's state and
+ * step counter were left untouched, as when the reference's step() raises); h_err [n]; clear != 0 zeroes them */
+int acx_env_get_errors(acx_env *env, uint8_t *h_err, int clear);
+int64_t acx_env_max_reward(const acx_env *env); /* horizon * L * 2, ac_env.py:80 */
+
+/* ---- search ---------------------------------------------------------------------------------
+ * Replaces bfs (breadth_first.py:15-97) and greedy_search (greedy.py:15-121): same visiting order,
+ * same (solved, path) result.  path_* receive (action, total_length) pairs starting with (-1, len0);
+ * *path_n == 0 encodes the reference's `None`. */
+typedef struct {
+    int64_t nodes;     /* len(tree_nodes) at exit */
+    int64_t expanded;  /* parents expanded */
+    int64_t children;  /* ACMove evaluations */
+    int64_t levels;    /* BFS levels / greedy batches processed */
+    int32_t min_len;   /* smallest total length generated */
+    double seconds;    /* device time of the search loop */
+} acx_search_stats;
+
+#define ACX_SEARCH_BFS 0
+#define ACX_SEARCH_GREEDY 1
+
+int acx_search(int kind, const int8_t *h_presentation, int L, int64_t max_nodes, int cyclical, int32_t *solved,
+               int32_t *path_action, int32_t *path_len, int64_t path_cap, int64_t *path_n, acx_search_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACX_H */

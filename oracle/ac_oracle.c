@@ -258,7 +258,7 @@ int ac_env_rollout(int8_t *state, int32_t *count, int64_t n, int L, int64_t hori
             int tot = lens[0] + lens[1];
             int d = (tot == 2);                                            /* :101 */
             if (reward) reward[t * n + k] = d ? max_reward : -tot;         /* :102 */
-            count[k] += 1;                                                 /* :104 */
+            if (rc == AC_OK) count[k] += 1;                                /* :104; when ACMove raises, step() never gets here */
             if (done) done[t * n + k] = (uint8_t)d;
             if (trunc) trunc[t * n + k] = (uint8_t)(count[k] >= horizon);  /* :105 */
         }

@@ -4,7 +4,7 @@ CPU only."""
 import numpy as np
 import pytest
 
-from conftest import ms_pool_generator_order
+from tests.conftest import ms_pool_generator_order
 from oracle import ac_oracle as O
 
 EXC = {1: AssertionError, 2: IndexError, 3: ValueError}
