@@ -37,6 +37,33 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not found: build the HIP extension first (python __graft_entry__.py, or "
         "make -C ac-solver_amd/csrc).  ac_solver has no CPU fallback.")
 
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7).
+    If libacx.so were loaded first it would pull in the system copy, and a later `import torch` would load
+    the bundled one as a SECOND runtime (its NEEDED entry is the bare file name, which does not match the
+    loaded SONAME) -- the GPU then disappears for torch.  So when torch is installed but not yet imported,
+    load its runtime first; libacx's NEEDED libamdhip64.so.7 then binds to it."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
+_preload_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 _i8p, _u8p, _i32p, _i64p, _f32p = (C.POINTER(t) for t in (C.c_int8, C.c_uint8, C.c_int32, C.c_int64, C.c_float))

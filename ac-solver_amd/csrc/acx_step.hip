@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) k_move_packed(const int8_t* __restrict__ 
         } else if (a < 0 || a >= 12) {
             e = ACX_ERR_ASSERT;
         } else {
-            e = apply_move<W>(s, a, L, cyclical != 0);
+            e = apply_move<W, true>(s, a, L, cyclical != 0);
             if (e == ACX_ERR_NONE) {
                 unpack_relator<W>(s.w0, s.n0, L, my);
                 unpack_relator<W>(s.w1, s.n1, L, my + L);
@@ -178,15 +178,16 @@ __global__ void __launch_bounds__(256) k_move_packed(const int8_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------- vectorised env --------------
+// Resident state, structure of arrays (8-byte lanes -> 512-B coalesced wave accesses):
+//   w0[n], w1[n]   packed relators
+//   meta[n]        n0 | n1 << 8 | sticky_err << 16 | count_steps << 32
 template <typename W> struct EnvDev {
-    W* w0;        // [n] relator 0, current state
-    W* w1;        // [n] relator 1
-    uint16_t* ln; // [n] n0 | n1 << 8
-    int32_t* cnt; // [n] count_steps (ac_env.py:104)
-    uint8_t* err; // [n] sticky error byte
-    W* iw0;       // initial state (ACEnvConfig.initial_state)
+    W* w0;
+    W* w1;
+    uint64_t* meta;
+    W* iw0;  // ACEnvConfig.initial_state, packed
     W* iw1;
-    uint16_t* iln;
+    uint64_t* imeta;   // n0 | n1 << 8 of the initial state
     uint8_t* hist;     // [H, n] action history ring (row = count_steps % H), or NULL
     int32_t* last_len; // [n] length of the episode that last finished (for final_info["actions"])
     int64_t n;
@@ -195,54 +196,76 @@ template <typename W> struct EnvDev {
     float max_reward;
 };
 
-template <typename W> __device__ __forceinline__ void env_load(const EnvDev<W>& e, int64_t i, Pres<W>& s) {
-    s.w0 = e.w0[i];
-    s.w1 = e.w1[i];
-    const uint16_t l = e.ln[i];
-    s.n0 = l & 0xff;
-    s.n1 = l >> 8;
+template <typename W> struct EnvLane {
+    Pres<W> s;
+    int32_t cnt;
+    uint32_t err;
+};
+
+template <typename W> __device__ __forceinline__ void env_load(const EnvDev<W>& e, int64_t i, EnvLane<W>& v) {
+    v.s.w0 = e.w0[i];
+    v.s.w1 = e.w1[i];
+    const uint64_t m = e.meta[i];
+    v.s.n0 = (int)(m & 0xff);
+    v.s.n1 = (int)((m >> 8) & 0xff);
+    v.err = (uint32_t)((m >> 16) & 0xff);
+    v.cnt = (int32_t)(m >> 32);
 }
-template <typename W> __device__ __forceinline__ void env_store(const EnvDev<W>& e, int64_t i, const Pres<W>& s) {
-    e.w0[i] = s.w0;
-    e.w1[i] = s.w1;
-    e.ln[i] = (uint16_t)(s.n0 | (s.n1 << 8));
+template <typename W> __device__ __forceinline__ void env_store(const EnvDev<W>& e, int64_t i, const EnvLane<W>& v) {
+    e.w0[i] = v.s.w0;
+    e.w1[i] = v.s.w1;
+    e.meta[i] = (uint64_t)v.s.n0 | ((uint64_t)v.s.n1 << 8) | ((uint64_t)v.err << 16) | ((uint64_t)(uint32_t)v.cnt << 32);
 }
 
 // One env transition (ac_env.py:95-113) incl. the optional gymnasium-style autoreset.
 // `fin` receives the terminal state when the env finished and was reset.
-template <typename W>
-__device__ __forceinline__ void env_transition(const EnvDev<W>& e, int64_t i, Pres<W>& s, int32_t& cnt, int a, bool autoreset,
-                                               float clip_lo, float clip_hi, float& reward, int& done, int& trunc, bool& was_reset,
-                                               Pres<W>& fin) {
-    if (e.hist) e.hist[(int64_t)(cnt % e.H) * e.n + i] = (uint8_t)a;  // self.actions += [action], :96
-    const int er = (a < 0 || a >= 12) ? (int)ACX_ERR_ASSERT : apply_move<W>(s, a, e.L, true);  // cyclical=True, :97
-    if (er) e.err[i] = (uint8_t)er;
-    const int tot = s.n0 + s.n1;
-    done = tot == 2;                                                              // :101
-    reward = clip_reward(done ? e.max_reward : -(float)tot, clip_lo, clip_hi);    // :102 (+ TransformReward clip)
-    if (!er) cnt += 1;  // :104 (when the reference's ACMove raises, step() aborts before the counter moves)
-    trunc = cnt >= e.horizon;                                                     // :105
+template <typename W, bool SAFE>
+__device__ __forceinline__ void env_transition(const EnvDev<W>& e, int64_t i, EnvLane<W>& v, int a, bool autoreset, float clip_lo,
+                                               float clip_hi, float& reward, int& done, int& trunc, bool& was_reset, Pres<W>& fin) {
+    if (e.hist) e.hist[(int64_t)(v.cnt % e.H) * e.n + i] = (uint8_t)a;  // self.actions += [action], :96
+    const int er = (a < 0 || a >= 12) ? (int)ACX_ERR_ASSERT : apply_move<W, SAFE>(v.s, a, e.L, true);  // cyclical=True, :97
+    v.err = er ? (uint32_t)er : v.err;
+    const int tot = v.s.n0 + v.s.n1;
+    done = tot == 2;                                                            // :101
+    reward = clip_reward(done ? e.max_reward : -(float)tot, clip_lo, clip_hi);  // :102 (+ TransformReward clip)
+    v.cnt += er ? 0 : 1;  // :104 (when the reference's ACMove raises, step() aborts before the counter moves)
+    trunc = v.cnt >= e.horizon;                                                 // :105
     was_reset = autoreset && (done || trunc);
     if (was_reset) {  // SyncVectorEnv autoreset: ACEnv.reset() -> initial_state, :115-131
-        fin = s;
-        e.last_len[i] = cnt;
-        s.w0 = e.iw0[i];
-        s.w1 = e.iw1[i];
-        const uint16_t l = e.iln[i];
-        s.n0 = l & 0xff;
-        s.n1 = l >> 8;
-        cnt = 0;
+        fin = v.s;
+        e.last_len[i] = v.cnt;
+        v.s.w0 = e.iw0[i];
+        v.s.w1 = e.iw1[i];
+        const uint64_t m = e.imeta[i];
+        v.s.n0 = (int)(m & 0xff);
+        v.s.n1 = (int)((m >> 8) & 0xff);
+        v.cnt = 0;
     }
 }
 
-template <typename W, typename OBS> __device__ __forceinline__ void write_obs_row(OBS* row, const Pres<W>& s, int L) {
-    for (int k = 0; k < L; k++) {
-        row[k] = k < s.n0 ? (OBS)letter_of_code(get<W>(s.w0, k)) : (OBS)0;
-        row[L + k] = k < s.n1 ? (OBS)letter_of_code(get<W>(s.w1, k)) : (OBS)0;
+// the lane's observation row (2L entries) into its LDS slot, 8 letters per unpack
+template <typename W> __device__ __forceinline__ void write_obs_row(int8_t* row, const Pres<W>& s, int L) {
+    uint16_t* r16 = (uint16_t*)row;  // rows are 2L bytes apart: 2-byte aligned
+    for (int p = 0; p < 2 * L; p += 8) {
+        const uint64_t x = row8<W>(s.w0, s.n0, s.w1, s.n1, L, p);
+        const int valid = 2 * L - p < 8 ? 2 * L - p : 8;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (2 * q < valid) r16[(p >> 1) + q] = (uint16_t)(x >> (16 * q));
+    }
+}
+template <typename W> __device__ __forceinline__ void write_obs_row(float* row, const Pres<W>& s, int L) {
+    float2* r2 = (float2*)row;  // rows are 8L bytes apart: 8-byte aligned
+    for (int p = 0; p < 2 * L; p += 8) {
+        const uint64_t x = row8<W>(s.w0, s.n0, s.w1, s.n1, L, p);
+        const int valid = 2 * L - p < 8 ? 2 * L - p : 8;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (2 * q < valid) r2[(p >> 1) + q] = make_float2((float)(int8_t)(x >> (16 * q)), (float)(int8_t)(x >> (16 * q + 8)));
     }
 }
 
-template <typename W, typename OBS>
+template <typename W, bool SAFE, typename OBS>
 __global__ void __launch_bounds__(256) k_env_step(EnvDev<W> e, const void* __restrict__ act, int adt, OBS* __restrict__ obs,
                                                   float* __restrict__ rew, float clip_lo, float clip_hi, uint8_t* __restrict__ done,
                                                   uint8_t* __restrict__ trunc, OBS* __restrict__ final_obs, int autoreset, int vec) {
@@ -253,21 +276,20 @@ __global__ void __launch_bounds__(256) k_env_step(EnvDev<W> e, const void* __res
     const int rows = (int)(e.n - row0 < 64 ? (e.n - row0 < 0 ? 0 : e.n - row0) : 64);
     uint8_t* tile = lds + wave * 64 * RB;
     OBS* my = (OBS*)(tile + lane * RB);
-    Pres<W> s, fin;
+    EnvLane<W> v;
+    Pres<W> fin;
     bool was_reset = false;
     if (lane < rows) {
         const int64_t i = row0 + lane;
-        env_load<W>(e, i, s);
-        int32_t cnt = e.cnt[i];
+        env_load<W>(e, i, v);
         float r;
         int d, t;
-        env_transition<W>(e, i, s, cnt, load_action(act, adt, i), autoreset != 0, clip_lo, clip_hi, r, d, t, was_reset, fin);
-        env_store<W>(e, i, s);
-        e.cnt[i] = cnt;
+        env_transition<W, SAFE>(e, i, v, load_action(act, adt, i), autoreset != 0, clip_lo, clip_hi, r, d, t, was_reset, fin);
+        env_store<W>(e, i, v);
         if (rew) rew[i] = r;
         if (done) done[i] = (uint8_t)d;
         if (trunc) trunc[i] = (uint8_t)t;
-        if (obs) write_obs_row<W, OBS>(my, s, e.L);
+        if (obs) write_obs_row<W>(my, v.s, e.L);
     }
     if (obs) {
         __syncthreads();
@@ -275,32 +297,31 @@ __global__ void __launch_bounds__(256) k_env_step(EnvDev<W> e, const void* __res
     }
     if (final_obs) {  // terminal observation of envs that were just reset, current observation otherwise
         __syncthreads();
-        if (lane < rows) write_obs_row<W, OBS>(my, was_reset ? fin : s, e.L);
+        if (lane < rows) write_obs_row<W>(my, was_reset ? fin : v.s, e.L);
         __syncthreads();
         if (rows > 0) wave_copy((uint8_t*)final_obs + row0 * RB, tile, rows * RB, lane, vec != 0);
     }
 }
 
-template <typename W>
+template <typename W, bool SAFE>
 __global__ void __launch_bounds__(256) k_env_rollout(EnvDev<W> e, const uint8_t* __restrict__ tape, int64_t T, float* __restrict__ rew,
                                                      float clip_lo, float clip_hi, uint8_t* __restrict__ done,
                                                      uint8_t* __restrict__ trunc, int autoreset) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= e.n) return;
-    Pres<W> s, fin;
-    env_load<W>(e, i, s);
-    int32_t cnt = e.cnt[i];
+    EnvLane<W> v;
+    Pres<W> fin;
+    env_load<W>(e, i, v);
     for (int64_t t = 0; t < T; t++) {
         float r;
         int d, tr;
         bool was_reset;
-        env_transition<W>(e, i, s, cnt, tape[t * e.n + i], autoreset != 0, clip_lo, clip_hi, r, d, tr, was_reset, fin);
+        env_transition<W, SAFE>(e, i, v, tape[t * e.n + i], autoreset != 0, clip_lo, clip_hi, r, d, tr, was_reset, fin);
         if (rew) rew[t * e.n + i] = r;
         if (done) done[t * e.n + i] = (uint8_t)d;
         if (trunc) trunc[t * e.n + i] = (uint8_t)tr;
     }
-    env_store<W>(e, i, s);
-    e.cnt[i] = cnt;
+    env_store<W>(e, i, v);
 }
 
 template <typename W, typename OBS>
@@ -312,9 +333,9 @@ __global__ void __launch_bounds__(256) k_env_observe(EnvDev<W> e, OBS* __restric
     const int rows = (int)(e.n - row0 < 64 ? (e.n - row0 < 0 ? 0 : e.n - row0) : 64);
     uint8_t* tile = lds + wave * 64 * RB;
     if (lane < rows) {
-        Pres<W> s;
-        env_load<W>(e, row0 + lane, s);
-        write_obs_row<W, OBS>((OBS*)(tile + lane * RB), s, e.L);
+        EnvLane<W> v;
+        env_load<W>(e, row0 + lane, v);
+        write_obs_row<W>((OBS*)(tile + lane * RB), v.s, e.L);
     }
     __syncthreads();
     if (rows > 0) wave_copy((uint8_t*)obs + row0 * RB, tile, rows * RB, lane, vec != 0);
@@ -328,46 +349,55 @@ __global__ void k_env_load(EnvDev<W> e, const int8_t* __restrict__ rows, const i
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
     const int64_t i = idx ? idx[k] : k;
-    Pres<W> s;
+    EnvLane<W> v;
     if (rows) {
         const int8_t* r = rows + k * 2 * e.L;
-        bool ok = pack_relator<W>(r, e.L, s.w0, s.n0);
-        ok = pack_relator<W>(r + e.L, e.L, s.w1, s.n1) && ok;
-        if (to_initial) ok = ok && s.n0 > 0 && s.n1 > 0;  // ACEnvConfig validates; reset(options=) does not
+        bool ok = pack_relator<W>(r, e.L, v.s.w0, v.s.n0);
+        ok = pack_relator<W>(r + e.L, e.L, v.s.w1, v.s.n1) && ok;
+        if (to_initial) ok = ok && v.s.n0 > 0 && v.s.n1 > 0;  // ACEnvConfig validates; reset(options=) does not
         rowerr[k] = ok ? 0 : (uint8_t)ACX_ERR_UNPACKABLE;
         if (!ok) return;
         if (to_initial) {
-            e.iw0[i] = s.w0;
-            e.iw1[i] = s.w1;
-            e.iln[i] = (uint16_t)(s.n0 | (s.n1 << 8));
+            e.iw0[i] = v.s.w0;
+            e.iw1[i] = v.s.w1;
+            e.imeta[i] = (uint64_t)v.s.n0 | ((uint64_t)v.s.n1 << 8);
         }
     } else {
-        s.w0 = e.iw0[i];
-        s.w1 = e.iw1[i];
-        const uint16_t l = e.iln[i];
-        s.n0 = l & 0xff;
-        s.n1 = l >> 8;
+        v.s.w0 = e.iw0[i];
+        v.s.w1 = e.iw1[i];
+        const uint64_t mm = e.imeta[i];
+        v.s.n0 = (int)(mm & 0xff);
+        v.s.n1 = (int)((mm >> 8) & 0xff);
         rowerr[k] = 0;
     }
-    env_store<W>(e, i, s);
-    e.cnt[i] = 0;
-    e.err[i] = 0;
+    v.cnt = 0;
+    v.err = 0;
+    env_store<W>(e, i, v);
     e.last_len[i] = 0;
 }
 
 template <typename W>
 __global__ void k_env_gather(EnvDev<W> e, const int64_t* __restrict__ idx, int64_t m, int8_t* __restrict__ rows, int32_t* __restrict__ len,
-                             int32_t* __restrict__ cnt) {
+                             int32_t* __restrict__ cnt, uint8_t* __restrict__ err, int clear_err) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
     const int64_t i = idx ? idx[k] : k;
-    Pres<W> s;
-    env_load<W>(e, i, s);
-    unpack_relator<W>(s.w0, s.n0, e.L, rows + k * 2 * e.L);
-    unpack_relator<W>(s.w1, s.n1, e.L, rows + k * 2 * e.L + e.L);
-    len[2 * k] = s.n0;
-    len[2 * k + 1] = s.n1;
-    cnt[k] = e.cnt[i];
+    EnvLane<W> v;
+    env_load<W>(e, i, v);
+    if (rows) {
+        unpack_relator<W>(v.s.w0, v.s.n0, e.L, rows + k * 2 * e.L);
+        unpack_relator<W>(v.s.w1, v.s.n1, e.L, rows + k * 2 * e.L + e.L);
+    }
+    if (len) {
+        len[2 * k] = v.s.n0;
+        len[2 * k + 1] = v.s.n1;
+    }
+    if (cnt) cnt[k] = v.cnt;
+    if (err) err[k] = (uint8_t)v.err;
+    if (clear_err && v.err) {
+        v.err = 0;
+        env_store<W>(e, i, v);
+    }
 }
 
 }  // namespace acx
@@ -380,6 +410,7 @@ struct acx_env {
     int L, H, flags, device;
     int64_t horizon;
     bool wide;     // W = u128
+    bool safe;     // L equals the word capacity: shifts may reach the full width
     void* arena;   // one allocation holding all device arrays
     EnvDev<uint64_t> d64;
     EnvDev<u128> d128;
@@ -499,11 +530,9 @@ template <typename W> static void carve(EnvDev<W>& d, uint8_t* base, int64_t n, 
     d.w1 = (W*)take(n * sizeof(W));
     d.iw0 = (W*)take(n * sizeof(W));
     d.iw1 = (W*)take(n * sizeof(W));
-    d.ln = (uint16_t*)take(n * 2);
-    d.iln = (uint16_t*)take(n * 2);
-    d.cnt = (int32_t*)take(n * 4);
+    d.meta = (uint64_t*)take(n * 8);
+    d.imeta = (uint64_t*)take(n * 8);
     d.last_len = (int32_t*)take(n * 4);
-    d.err = (uint8_t*)take(n);
     d.hist = hist ? (uint8_t*)take((size_t)H * n) : nullptr;
     d.n = n;
     d.L = L;
@@ -512,6 +541,22 @@ template <typename W> static void carve(EnvDev<W>& d, uint8_t* base, int64_t n, 
     d.max_reward = (float)(horizon * L * 2);
     *total = o;
 }
+
+// launch helper: picks the (word width, safe-shift) instantiation of a kernel template
+#define ACX_ENV_DISPATCH(e, ...)                                          \
+    do {                                                                  \
+        if ((e)->wide) {                                                  \
+            typedef u128 W;                                               \
+            auto& dev = (e)->d128;                                        \
+            if ((e)->safe) { constexpr bool SAFE = true; (void)SAFE; __VA_ARGS__; }   \
+            else { constexpr bool SAFE = false; (void)SAFE; __VA_ARGS__; }            \
+        } else {                                                          \
+            typedef uint64_t W;                                           \
+            auto& dev = (e)->d64;                                         \
+            if ((e)->safe) { constexpr bool SAFE = true; (void)SAFE; __VA_ARGS__; }   \
+            else { constexpr bool SAFE = false; (void)SAFE; __VA_ARGS__; }            \
+        }                                                                 \
+    } while (0)
 
 extern "C" {
 
@@ -528,6 +573,7 @@ acx_env* acx_env_create(int64_t n, int L, int64_t horizon, int flags) {
     e->horizon = horizon;
     e->flags = flags;
     e->wide = L > 32;
+    e->safe = (L == 32 || L == 64);
     e->H = (int)(horizon < (1 << 20) ? horizon : (1 << 20));
     (void)hipGetDevice(&e->device);
     size_t total = 0;
@@ -581,8 +627,7 @@ static int env_load_rows(acx_env* e, const int8_t* h_states, const int64_t* h_id
     const unsigned grid = (unsigned)ceil_div<int64_t>(m, 256);
     const int8_t* rows = h_states ? (const int8_t*)(b + o_rows) : nullptr;
     const int64_t* idx = h_idx ? (const int64_t*)(b + o_idx) : nullptr;
-    if (e->wide) hipLaunchKernelGGL(k_env_load<u128>, dim3(grid), dim3(256), 0, nullptr, e->d128, rows, idx, m, to_initial, b + o_err);
-    else hipLaunchKernelGGL(k_env_load<uint64_t>, dim3(grid), dim3(256), 0, nullptr, e->d64, rows, idx, m, to_initial, b + o_err);
+    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL(k_env_load<W>, dim3(grid), dim3(256), 0, nullptr, dev, rows, idx, m, to_initial, b + o_err));
     ACX_HIP_TRY(hipGetLastError());
     std::vector<uint8_t> err((size_t)m);
     ACX_HIP_TRY(hipMemcpy(err.data(), b + o_err, m, hipMemcpyDeviceToHost));
@@ -610,17 +655,12 @@ int acx_env_step(acx_env* e, const void* d_actions, int action_dtype, void* d_ob
     const bool f32 = obs_dtype == ACX_F32;
     const size_t lds = (d_obs || d_final_obs) ? (size_t)4 * 64 * 2 * e->L * (f32 ? 4 : 1) : 0;
     const int vec = aligned16(d_obs) && aligned16(d_final_obs);
-#define ACX_LAUNCH_STEP(W, OBS, dev)                                                                                                  \
-    hipLaunchKernelGGL((k_env_step<W, OBS>), dim3(grid), dim3(256), lds, st, dev, d_actions, action_dtype, (OBS*)d_obs, d_reward, clip_lo, \
-                       clip_hi, d_done, d_trunc, (OBS*)d_final_obs, autoreset, vec)
-    if (e->wide) {
-        if (f32) ACX_LAUNCH_STEP(u128, float, e->d128);
-        else ACX_LAUNCH_STEP(u128, int8_t, e->d128);
-    } else {
-        if (f32) ACX_LAUNCH_STEP(uint64_t, float, e->d64);
-        else ACX_LAUNCH_STEP(uint64_t, int8_t, e->d64);
-    }
-#undef ACX_LAUNCH_STEP
+    if (f32)
+        ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_step<W, SAFE, float>), dim3(grid), dim3(256), lds, st, dev, d_actions, action_dtype, (float*)d_obs,
+                                                d_reward, clip_lo, clip_hi, d_done, d_trunc, (float*)d_final_obs, autoreset, vec));
+    else
+        ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_step<W, SAFE, int8_t>), dim3(grid), dim3(256), lds, st, dev, d_actions, action_dtype, (int8_t*)d_obs,
+                                                d_reward, clip_lo, clip_hi, d_done, d_trunc, (int8_t*)d_final_obs, autoreset, vec));
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
@@ -656,8 +696,8 @@ int acx_env_rollout(acx_env* e, const uint8_t* d_tape, int64_t T, float* d_rewar
     if (T == 0) return ACX_OK;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div<int64_t>(e->n, 256);
-    if (e->wide) hipLaunchKernelGGL(k_env_rollout<u128>, dim3(grid), dim3(256), 0, st, e->d128, d_tape, T, d_reward, clip_lo, clip_hi, d_done, d_trunc, autoreset);
-    else hipLaunchKernelGGL(k_env_rollout<uint64_t>, dim3(grid), dim3(256), 0, st, e->d64, d_tape, T, d_reward, clip_lo, clip_hi, d_done, d_trunc, autoreset);
+    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_rollout<W, SAFE>), dim3(grid), dim3(256), 0, st, dev, d_tape, T, d_reward, clip_lo, clip_hi, d_done, d_trunc,
+                                            autoreset));
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
@@ -670,13 +710,8 @@ int acx_env_observe(acx_env* e, void* d_obs, int obs_dtype, void* stream) {
     const bool f32 = obs_dtype == ACX_F32;
     const size_t lds = (size_t)4 * 64 * 2 * e->L * (f32 ? 4 : 1);
     const int vec = aligned16(d_obs);
-    if (e->wide) {
-        if (f32) hipLaunchKernelGGL((k_env_observe<u128, float>), dim3(grid), dim3(256), lds, st, e->d128, (float*)d_obs, vec);
-        else hipLaunchKernelGGL((k_env_observe<u128, int8_t>), dim3(grid), dim3(256), lds, st, e->d128, (int8_t*)d_obs, vec);
-    } else {
-        if (f32) hipLaunchKernelGGL((k_env_observe<uint64_t, float>), dim3(grid), dim3(256), lds, st, e->d64, (float*)d_obs, vec);
-        else hipLaunchKernelGGL((k_env_observe<uint64_t, int8_t>), dim3(grid), dim3(256), lds, st, e->d64, (int8_t*)d_obs, vec);
-    }
+    if (f32) ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_observe<W, float>), dim3(grid), dim3(256), lds, st, dev, (float*)d_obs, vec));
+    else ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_observe<W, int8_t>), dim3(grid), dim3(256), lds, st, dev, (int8_t*)d_obs, vec));
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
@@ -698,8 +733,8 @@ int acx_env_get(acx_env* e, const int64_t* h_idx, int64_t m, int8_t* h_state, in
     ACX_HIP_TRY(hipDeviceSynchronize());  // steps may be in flight on other streams
     const unsigned grid = (unsigned)ceil_div<int64_t>(m, 256);
     const int64_t* idx = h_idx ? (const int64_t*)(b + o_idx) : nullptr;
-    if (e->wide) hipLaunchKernelGGL(k_env_gather<u128>, dim3(grid), dim3(256), 0, nullptr, e->d128, idx, m, (int8_t*)(b + o_rows), (int32_t*)(b + o_len), (int32_t*)(b + o_cnt));
-    else hipLaunchKernelGGL(k_env_gather<uint64_t>, dim3(grid), dim3(256), 0, nullptr, e->d64, idx, m, (int8_t*)(b + o_rows), (int32_t*)(b + o_len), (int32_t*)(b + o_cnt));
+    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL(k_env_gather<W>, dim3(grid), dim3(256), 0, nullptr, dev, idx, m, (int8_t*)(b + o_rows), (int32_t*)(b + o_len),
+                                                        (int32_t*)(b + o_cnt), (uint8_t*)nullptr, 0));
     ACX_HIP_TRY(hipGetLastError());
     if (h_state) ACX_HIP_TRY(hipMemcpy(h_state, b + o_rows, m * row, hipMemcpyDeviceToHost));
     if (h_len) ACX_HIP_TRY(hipMemcpy(h_len, b + o_len, m * 8, hipMemcpyDeviceToHost));
@@ -712,9 +747,14 @@ int acx_env_get_actions(acx_env* e, int64_t i, int which, int32_t* h_out, int64_
     if (!(e->flags & ACX_ENV_RECORD_ACTIONS)) return fail(ACX_E_INVAL, "env was created without ACX_ENV_RECORD_ACTIONS");
     ACX_HIP_TRY(hipDeviceSynchronize());
     const uint8_t* hist = e->wide ? e->d128.hist : e->d64.hist;
-    const int32_t* src = which ? (e->wide ? e->d128.last_len : e->d64.last_len) : (e->wide ? e->d128.cnt : e->d64.cnt);
     int32_t cnt = 0;
-    ACX_HIP_TRY(hipMemcpy(&cnt, src + i, 4, hipMemcpyDeviceToHost));
+    if (which) {
+        ACX_HIP_TRY(hipMemcpy(&cnt, (e->wide ? e->d128.last_len : e->d64.last_len) + i, 4, hipMemcpyDeviceToHost));
+    } else {
+        uint64_t m = 0;
+        ACX_HIP_TRY(hipMemcpy(&m, (e->wide ? e->d128.meta : e->d64.meta) + i, 8, hipMemcpyDeviceToHost));
+        cnt = (int32_t)(m >> 32);
+    }
     *n_out = cnt;
     if (cnt > e->H) return fail(ACX_E_CAPACITY, "episode has %d steps but the history ring keeps %d", cnt, e->H);
     if (cnt > cap) return fail(ACX_E_CAPACITY, "actions buffer too small: need %d", cnt);
@@ -728,10 +768,15 @@ int acx_env_get_actions(acx_env* e, int64_t i, int which, int32_t* h_out, int64_
 
 int acx_env_get_errors(acx_env* e, uint8_t* h_err, int clear) {
     if (!e || !h_err) return fail(ACX_E_INVAL, "acx_env_get_errors: bad argument");
+    Scratch& s = scratch(1);
+    int rc = s.ensure((size_t)e->n);
+    if (rc) return rc;
     ACX_HIP_TRY(hipDeviceSynchronize());
-    uint8_t* d = e->wide ? e->d128.err : e->d64.err;
-    ACX_HIP_TRY(hipMemcpy(h_err, d, e->n, hipMemcpyDeviceToHost));
-    if (clear) ACX_HIP_TRY(hipMemset(d, 0, e->n));
+    const unsigned grid = (unsigned)ceil_div<int64_t>(e->n, 256);
+    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL(k_env_gather<W>, dim3(grid), dim3(256), 0, nullptr, dev, (const int64_t*)nullptr, e->n, (int8_t*)nullptr,
+                                                        (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)s.p, clear));
+    ACX_HIP_TRY(hipGetLastError());
+    ACX_HIP_TRY(hipMemcpy(h_err, s.p, e->n, hipMemcpyDeviceToHost));
     return ACX_OK;
 }
 

@@ -67,17 +67,25 @@ template <> struct wtraits<u128> {
     static ACX_HD u128 lo_ones() { return ((u128)0x5555555555555555ull << 64) | 0x5555555555555555ull; }
 };
 
-// shifts by a letter count that may reach the full width
-template <typename W> ACX_HD W shl(W w, int letters) { return 2 * letters >= wtraits<W>::kBits ? (W)0 : (W)(w << (2 * letters)); }
-template <typename W> ACX_HD W shr(W w, int letters) { return 2 * letters >= wtraits<W>::kBits ? (W)0 : (W)(w >> (2 * letters)); }
-template <typename W> ACX_HD W mask(int letters) { return (W)(shl<W>((W)1, letters) - 1); }  // letters == max -> 0 - 1 = all ones
-template <typename W> ACX_HD int get(W w, int k) { return (int)((uint32_t)shr<W>(w, k) & 3u); }
+// Shifts by a letter count.  SAFE = true tolerates counts that reach the full width (needed only when
+// max_relator_length equals the word capacity, 32 or 64); SAFE = false is the plain hardware shift.
+template <typename W, bool SAFE = true> ACX_HD W shl(W w, int letters) {
+    if (SAFE) return 2 * letters >= wtraits<W>::kBits ? (W)0 : (W)(w << (2 * letters));
+    return (W)(w << (2 * letters));
+}
+template <typename W, bool SAFE = true> ACX_HD W shr(W w, int letters) {
+    if (SAFE) return 2 * letters >= wtraits<W>::kBits ? (W)0 : (W)(w >> (2 * letters));
+    return (W)(w >> (2 * letters));
+}
+template <typename W, bool SAFE = true> ACX_HD W mask(int letters) { return (W)(shl<W, SAFE>((W)1, letters) - 1); }  // letters == capacity -> all ones
+template <typename W, bool SAFE = true> ACX_HD int get(W w, int k) { return (int)((uint32_t)shr<W, SAFE>(w, k) & 3u); }
 
 // inverse word: reversed and letter-wise inverted (code ^ 3)
-template <typename W> ACX_HD W inv(W w, int n) {
-    if (n == 0) return (W)0;
-    W r = wtraits<W>::rev2(w) >> (wtraits<W>::kBits - 2 * n);
-    return r ^ mask<W>(n);
+template <typename W, bool SAFE = true> ACX_HD W inv(W w, int n) {
+    // n == 0: the word is 0 and so is its reversal; the shift count is clamped to stay defined
+    const int sh = wtraits<W>::kBits - 2 * n;
+    W r = wtraits<W>::rev2(w) >> (sh >= wtraits<W>::kBits ? wtraits<W>::kBits - 2 : sh);
+    return n == 0 ? (W)0 : (W)(r ^ mask<W, SAFE>(n));
 }
 
 // number of leading letters on which a and b agree, capped at `cap`
@@ -88,25 +96,25 @@ template <typename W> ACX_HD int common_prefix(W a, W b, int cap) {
 }
 
 // true when some adjacent pair of the n-letter word is mutually inverse
-template <typename W> ACX_HD bool has_inverse_pair(W w, int n) {
-    if (n < 2) return false;
+template <typename W, bool SAFE = true> ACX_HD bool has_inverse_pair(W w, int n) {
     W t = w ^ (w >> 2);  // field k = code[k] ^ code[k+1]; inverse pair <=> field == 3
-    return (t & (t >> 1) & wtraits<W>::lo_ones() & mask<W>(n - 1)) != 0;
+    return n >= 2 && (t & (t >> 1) & wtraits<W>::lo_ones() & mask<W, SAFE>(n - 1)) != 0;
 }
 
 // free reduction (utils.py:208-217): stack pass; the freely reduced form is unique, so this equals
-// the reference's delete-and-step-back loop
-template <typename W> ACX_HD void free_reduce(W& w, int& n) {
-    if (!has_inverse_pair<W>(w, n)) return;
+// the reference's delete-and-step-back loop.  States produced by ACMove are already reduced, so the
+// loop only runs for unreduced initial states.
+template <typename W, bool SAFE = true> ACX_HD void free_reduce(W& w, int& n) {
+    if (!has_inverse_pair<W, SAFE>(w, n)) return;
     W o = 0;
     int on = 0;
     for (int k = 0; k < n; k++) {
-        int c = get<W>(w, k);
-        if (on > 0 && get<W>(o, on - 1) == (c ^ 3)) {
+        int c = get<W, SAFE>(w, k);
+        if (on > 0 && get<W, SAFE>(o, on - 1) == (c ^ 3)) {
             on--;
-            o &= mask<W>(on);
+            o &= mask<W, SAFE>(on);
         } else {
-            o |= shl<W>((W)c, on);
+            o |= shl<W, SAFE>((W)c, on);
             on++;
         }
     }
@@ -114,14 +122,13 @@ template <typename W> ACX_HD void free_reduce(W& w, int& n) {
     n = on;
 }
 
-// cyclic reduction of a freely reduced word (utils.py:220-229)
-template <typename W> ACX_HD void cyclic_reduce(W& w, int& n) {
-    if (n < 2) return;
-    W t = w ^ inv<W>(w, n);  // non-zero for a reduced non-empty word (w == w^-1 only for the empty word)
-    if (!t) return;
-    int p = wtraits<W>::ctz(t) >> 1;  // < n/2: a reduced word cannot match through its middle
-    if (2 * p >= n) return;           // unreachable for reduced words; keeps shifts defined
-    w = shr<W>(w, p) & mask<W>(n - 2 * p);
+// cyclic reduction of a freely reduced word (utils.py:220-229), branch free: p letters leave each end,
+// p = common prefix of w and w^-1, which for a reduced word stops before the middle
+template <typename W, bool SAFE = true> ACX_HD void cyclic_reduce(W& w, int& n) {
+    const W t = w ^ inv<W, SAFE>(w, n);  // non-zero for a reduced non-empty word
+    int p = t ? (wtraits<W>::ctz(t) >> 1) : 0;
+    p = 2 * p < n ? p : 0;  // unreachable for reduced words; keeps the shifts defined
+    w = shr<W, SAFE>(w, p) & mask<W, SAFE>(n - 2 * p);
     n -= 2 * p;
 }
 
@@ -134,29 +141,31 @@ template <typename W> struct Pres {
 
 // r1 r2^{+-1} with junction cancellation (ac_moves.py:4-76): (w1,n1) is r_i, (w2,n2) is r_j.
 // Returns false when the product does not fit (outputs untouched).
-template <typename W> ACX_HD bool concat_words(W w1, int n1, W w2, int n2, bool negate, int L, W& out, int& nout) {
-    if (negate) w2 = inv<W>(w2, n2);
-    const int acc = common_prefix<W>(inv<W>(w1, n1), w2, n1 < n2 ? n1 : n2);
+template <typename W, bool SAFE = true> ACX_HD bool concat_words(W w1, int n1, W w2, int n2, bool negate, int L, W& out, int& nout) {
+    const W w2i = inv<W, SAFE>(w2, n2);
+    w2 = negate ? w2i : w2;
+    const int acc = common_prefix<W>(inv<W, SAFE>(w1, n1), w2, n1 < n2 ? n1 : n2);
     const int nn = n1 + n2 - 2 * acc;
-    if (nn > L) return false;
-    out = (w1 & mask<W>(n1 - acc)) | shl<W>(shr<W>(w2, acc), n1 - acc);
-    nout = nn;
-    return true;
+    const bool fits = nn <= L;
+    const W r = (w1 & mask<W, SAFE>(n1 - acc)) | shl<W, SAFE>(shr<W, SAFE>(w2, acc), n1 - acc);
+    out = fits ? r : out;
+    nout = fits ? nn : nout;
+    return fits;
 }
 
 // g r g^-1 with end cancellation (ac_moves.py:79-156); gc is the code of g; n >= 1
-template <typename W> ACX_HD bool conjugate_word(W w, int n, int gc, int L, W& out, int& nout) {
-    const int sc = get<W>(w, 0) == (gc ^ 3);
-    const int ec = get<W>(w, n - 1) == gc;
+template <typename W, bool SAFE = true> ACX_HD bool conjugate_word(W w, int n, int gc, int L, W& out, int& nout) {
+    const int sc = get<W, SAFE>(w, 0) == (gc ^ 3);
+    const int ec = get<W, SAFE>(w, n - 1) == gc;
     const int nn = n + 2 - 2 * (sc + ec);
-    if (nn > L) return false;
+    const bool fits = nn <= L;
     const int nb = n - sc - ec;  // letters of r that survive
-    W r = shr<W>(w, sc) & mask<W>(nb);
-    if (!sc) r = (r << 2) | (W)gc;
-    if (!ec) r |= shl<W>((W)(gc ^ 3), nn - 1);
-    out = r;
-    nout = nn;
-    return true;
+    W r = shr<W, SAFE>(w, sc) & mask<W, SAFE>(nb);
+    r = sc ? r : (W)((r << 2) | (W)gc);
+    r |= ec ? (W)0 : shl<W, SAFE>((W)(gc ^ 3), fits ? nn - 1 : 0);
+    out = fits ? r : out;
+    nout = fits ? nn : nout;
+    return fits;
 }
 
 // ACMove (ac_moves.py:159-231) on a packed presentation (zero-padded words over {+-1,+-2}; a relator
@@ -164,27 +173,27 @@ template <typename W> ACX_HD bool conjugate_word(W w, int n, int gc, int L, W& o
 // Returns ACX_ERR_NONE, ACX_ERR_INDEX (conjugating an empty relator, ac_moves.py:119) or
 // ACX_ERR_ASSERT (a relator is empty after the move: the validity assert of simplify_presentation,
 // utils.py:261-263); on error the state is left unchanged.
-template <typename W> ACX_HD int apply_move(Pres<W>& s, int a, int L, bool cyclical) {
+template <typename W, bool SAFE = true> ACX_HD int apply_move(Pres<W>& s, int a, int L, bool cyclical) {
     const int m = a + 1;
     const bool i1 = (m & 1) != 0;  // ac_moves.py:192-206: odd ids touch r_1
     const int i = i1 ? 1 : 0;
     W wi = i1 ? s.w1 : s.w0, wj = i1 ? s.w0 : s.w1;
     int ni = i1 ? s.n1 : s.n0, nj = i1 ? s.n0 : s.n1;
     if (a < 4) {
-        concat_words<W>(wi, ni, wj, nj, (((m - i) >> 1) & 1) != 0, L, wi, ni);
+        concat_words<W, SAFE>(wi, ni, wj, nj, (((m - i) >> 1) & 1) != 0, L, wi, ni);
     } else {
         if (ni == 0) return ACX_ERR_INDEX;
         const int jp = ((m - i) >> 1) & 1;
         const int sp = ((m - i - 2 * jp) >> 2) & 1;
-        conjugate_word<W>(wi, ni, sp ? 1 - jp : 2 + jp, L, wi, ni);  // g = -(jp+1) -> code 1-jp ; +(jp+1) -> 2+jp
+        conjugate_word<W, SAFE>(wi, ni, sp ? 1 - jp : 2 + jp, L, wi, ni);  // g = -(jp+1) -> code 1-jp ; +(jp+1) -> 2+jp
     }
     if (ni == 0 || nj == 0) return ACX_ERR_ASSERT;
     // simplify_presentation, utils.py:267-278 (both relators, also the untouched one)
-    free_reduce<W>(wi, ni);
-    free_reduce<W>(wj, nj);
+    free_reduce<W, SAFE>(wi, ni);
+    free_reduce<W, SAFE>(wj, nj);
     if (cyclical) {
-        cyclic_reduce<W>(wi, ni);
-        cyclic_reduce<W>(wj, nj);
+        cyclic_reduce<W, SAFE>(wi, ni);
+        cyclic_reduce<W, SAFE>(wj, nj);
     }
     s.w0 = i1 ? wj : wi;
     s.w1 = i1 ? wi : wj;
@@ -219,17 +228,28 @@ template <typename W> ACX_HD void unpack_relator(W w, int n, int L, int8_t* r) {
     for (int k = 0; k < L; k++) r[k] = k < n ? (int8_t)letter_of_code(get<W>(w, k)) : (int8_t)0;
 }
 
-// 8 letters starting at letter `k0` as 8 int8 in one u64 (little endian), zero beyond n.
+// 8 letters starting at letter `k0` (< capacity) as 8 int8 in one u64 (little endian), zero beyond n.
 template <typename W> ACX_HD uint64_t unpack8(W w, int n, int k0) {
-    uint64_t x = (uint64_t)shr<W>(w, k0) & 0xFFFFull;               // 8 codes
+    uint64_t x = (uint64_t)(w >> (2 * k0)) & 0xFFFFull;             // 8 codes
     x = (x | (x << 24)) & 0x000000FF000000FFull;
     x = (x | (x << 12)) & 0x000F000F000F000Full;
     x = (x | (x << 6)) & 0x0303030303030303ull;                     // one code per byte
     uint64_t hi = (x >> 1) & 0x0101010101010101ull;                 // code >= 2
     x = ((x + hi + 0x7E7E7E7E7E7E7E7Eull) ^ 0x8080808080808080ull); // code -> letter: {0,1,2,3} -> {-2,-1,1,2}
     int cnt = n - k0;
-    uint64_t m = cnt >= 8 ? ~0ull : (cnt <= 0 ? 0ull : ((1ull << (8 * cnt)) - 1));
+    cnt = cnt < 0 ? 0 : (cnt > 8 ? 8 : cnt);
+    uint64_t m = cnt >= 8 ? ~0ull : ((1ull << (8 * cnt)) - 1);
     return x & m;
+}
+
+// 8 consecutive entries of the 2L-entry int8 row (r0 padded to L, then r1 padded to L) starting at
+// position p; entries past the row read as 0.  The branches depend only on p and L (wave uniform).
+template <typename W> ACX_HD uint64_t row8(W w0, int n0, W w1, int n1, int L, int p) {
+    if (p >= L) return p - L < L ? unpack8<W>(w1, n1, p - L) : 0ull;
+    uint64_t x = unpack8<W>(w0, n0, p);
+    const int cnt = L - p;
+    if (cnt < 8) x |= unpack8<W>(w1, n1, 0) << (8 * cnt);
+    return x;
 }
 
 // Signed-tuple order of two packed presentations as the reference's Python tuples compare them
