@@ -1,9 +1,702 @@
-// acx_search.hip -- device BFS / greedy frontier (placeholder until the frontier kernels land).
+// acx_search.hip -- device-resident BFS / greedy frontier over the AC graph (single GPU).
+//
+// Replaces bfs (ac_solver/search/breadth_first.py:15-97) and greedy_search (search/greedy.py:15-121)
+// with the SAME visiting order and therefore the same (solved, path) result:
+//
+//   * a search advances in BATCHES of parents that the reference would pop consecutively
+//       bfs     a slice of the current FIFO level (node ids are FIFO order)
+//       greedy  a prefix of the heap's minimal (total length, depth) bucket, in signed state order
+//   * every (parent, action) pair of the batch is one lane of k_expand: tag = 12 * parent_pos + action is
+//     exactly the order in which the reference generates children
+//   * duplicates are resolved to the MINIMUM tag (the reference's "first discoverer wins",
+//     breadth_first.py:87-89): the open-addressed table stores node ids; a candidate claims an empty slot
+//     with a 32-bit CAS on a provisional id (2^31 + tag) and equal keys fold with atomicMin, the full
+//     key of the occupant is always compared (exact set, no fingerprints)
+//   * winners are numbered by an exclusive scan in tag order, which reproduces the reference's insertion
+//     order; the per-parent budget test (breadth_first.py:91-95) becomes "first parent whose cumulative
+//     winner count reaches the budget"; the solved test (:84-85) "minimum tag with total length 2"
+//   * greedy additionally stops a batch right after the first parent that inserts a NEW child shorter than
+//     the bucket (that child is the heap's next minimum); later parents stay queued
+//
+// Keys: a relator word and its length share one machine word (length in the top 6 bits):
+// W = u64 for L <= 29, u128 for L <= 61.  Roofline: HBM (random table probes); see DESIGN.md.
+#include <string.h>
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <stdlib.h>
+
+#include <algorithm>
+#include <map>
+#include <vector>
+
 #include "acx_common.h"
+#include "acx_word.h"
+
+namespace acx {
+
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kProv = 0x80000000u;  // provisional id = kProv | tag (candidate of the running batch)
+constexpr uint64_t kNoTag = ~0ull;
+
+template <typename W> struct keyops {
+    static constexpr int kShift = wtraits<W>::kBits - 6;
+    static ACX_HD W make(W w, int n) { return w | ((W)n << kShift); }
+    static ACX_HD int len(W k) { return (int)(uint32_t)(k >> kShift); }
+    static ACX_HD W word(W k) { return k & (((W)1 << kShift) - 1); }
+};
+
+ACX_HD uint64_t mix64(uint64_t x) {
+    x ^= x >> 32;
+    x *= 0xd6e8feb86659fd93ull;
+    x ^= x >> 32;
+    x *= 0xd6e8feb86659fd93ull;
+    x ^= x >> 32;
+    return x;
+}
+ACX_HD uint64_t fold(uint64_t k) { return k; }
+ACX_HD uint64_t fold(u128 k) { return (uint64_t)k ^ ((uint64_t)(k >> 64) * 0x9e3779b97f4a7c15ull); }
+template <typename W> ACX_HD uint64_t hash_key(W k0, W k1) { return mix64(fold(k0) * 0x9e3779b97f4a7c15ull + mix64(fold(k1))); }
+
+template <typename W> struct SearchDev {
+    // node arena (committed nodes, id order == the reference's insertion order)
+    W* k0;
+    W* k1;
+    uint32_t* parent;
+    uint8_t* act;
+    uint8_t* tlen;
+    uint32_t* depth;
+    // visited table: node id / provisional id / kEmpty
+    uint32_t* slots;
+    uint32_t smask;
+    // batch-local table (greedy) for the in-batch dedup
+    uint32_t* bslots;
+    uint32_t bmask;
+    // candidates of the running batch, indexed by tag
+    W* ck0;
+    W* ck1;
+    uint8_t* clen;
+    uint32_t* cslot;
+    uint32_t* cflag;  // 1 = winner / new
+    uint32_t* cpos;   // exclusive scan of cflag
+    uint8_t* cknown;  // greedy: already in the visited table
+    // device scalars
+    unsigned long long* solved_tag;   // min tag with total length 2
+    unsigned long long* shorter_tag;  // greedy: min tag of a NEW child shorter than the bucket
+    unsigned long long* rank_tag;     // tag of the r-th winner (budget crossing)
+    uint32_t* err;
+    uint32_t* min_len;
+    int32_t L;
+    int32_t cyclical;
+};
+
+template <typename W> __device__ __forceinline__ void key_to_pres(W k0, W k1, Pres<W>& s) {
+    s.w0 = keyops<W>::word(k0);
+    s.n0 = keyops<W>::len(k0);
+    s.w1 = keyops<W>::word(k1);
+    s.n1 = keyops<W>::len(k1);
+}
+
+// one lane per (parent, action): tag t = 12 * p + a
+template <typename W>
+__global__ void __launch_bounds__(256) k_expand(SearchDev<W> d, const uint32_t* __restrict__ plist, uint32_t pbegin, uint32_t np) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t tl = 0xFFFFFFFFu;
+    if (t < 12u * np) {
+        const uint32_t p = t / 12u, a = t - 12u * p;
+        const uint32_t pid = plist ? plist[p] : pbegin + p;
+        Pres<W> s;
+        key_to_pres<W>(d.k0[pid], d.k1[pid], s);
+        const int e = apply_move<W, true>(s, (int)a, d.L, d.cyclical != 0);
+        if (e) atomicOr(d.err, (uint32_t)e);  // the reference's ACMove raises: the whole search raises
+        d.ck0[t] = keyops<W>::make(s.w0, s.n0);
+        d.ck1[t] = keyops<W>::make(s.w1, s.n1);
+        tl = (uint32_t)(s.n0 + s.n1);
+        d.clen[t] = (uint8_t)tl;
+        if (tl == 2) atomicMin(d.solved_tag, (unsigned long long)t);  // breadth_first.py:84 / greedy.py:91
+    }
+    // wave-level min before the atomic keeps contention low (all 64 lanes take part)
+    uint32_t m = tl;
+    for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m != 0xFFFFFFFFu) atomicMin(d.min_len, m);
+}
+
+template <typename W> __device__ __forceinline__ bool key_equals(const SearchDev<W>& d, uint32_t id, W k0, W k1) {
+    if (id & kProv) {
+        const uint32_t t = id & ~kProv;
+        return d.ck0[t] == k0 && d.ck1[t] == k1;
+    }
+    return d.k0[id] == k0 && d.k1[id] == k1;
+}
+
+// Insert candidate t into `slots` with min-tag resolution among equal keys.  cslot[t] = slot holding the key.
+// Occupants may be committed node ids (always win) or provisional ids of this batch.
+template <typename W>
+__global__ void __launch_bounds__(256) k_insert(SearchDev<W> d, uint32_t* __restrict__ slots, uint32_t mask, uint32_t m, int skip_known) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    if (skip_known && d.cknown[t]) {
+        d.cslot[t] = kEmpty;
+        return;
+    }
+    const W k0 = d.ck0[t], k1 = d.ck1[t];
+    const uint32_t me = kProv | t;
+    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & mask;
+    for (;;) {
+        uint32_t v = slots[h];
+        if (v == kEmpty) {
+            v = atomicCAS(&slots[h], kEmpty, me);
+            if (v == kEmpty) break;  // claimed
+        }
+        if (key_equals<W>(d, v, k0, k1)) {
+            if ((v & kProv) && v > me) atomicMin(&slots[h], me);
+            break;
+        }
+        h = (h + 1) & mask;
+    }
+    d.cslot[t] = h;
+}
+
+// read-only membership test against the visited table (greedy: speculative batches must not touch it)
+template <typename W> __global__ void __launch_bounds__(256) k_lookup(SearchDev<W> d, uint32_t m) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const W k0 = d.ck0[t], k1 = d.ck1[t];
+    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.smask;
+    uint8_t known = 0;
+    for (;;) {
+        const uint32_t v = d.slots[h];
+        if (v == kEmpty) break;
+        if (key_equals<W>(d, v, k0, k1)) {
+            known = 1;
+            break;
+        }
+        h = (h + 1) & d.smask;
+    }
+    d.cknown[t] = known;
+}
+
+// cflag[t] = 1 iff candidate t is the first discoverer of a state not seen before
+template <typename W>
+__global__ void __launch_bounds__(256) k_mark(SearchDev<W> d, const uint32_t* __restrict__ slots, uint32_t m, int bucket_len) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const uint32_t s = d.cslot[t];
+    const uint32_t win = (s != kEmpty && slots[s] == (kProv | t)) ? 1u : 0u;
+    d.cflag[t] = win;
+    if (win && bucket_len >= 0 && (int)d.clen[t] < bucket_len) atomicMin(d.shorter_tag, (unsigned long long)t);
+}
+
+// tag of the winner with 1-based rank r (exists and is unique)
+template <typename W> __global__ void __launch_bounds__(256) k_find_rank(SearchDev<W> d, uint32_t m, uint32_t r) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    if (d.cflag[t] && d.cpos[t] + 1 == r) *d.rank_tag = t;
+}
+
+// Winners below `cutoff` become nodes base + cpos[t].  BFS: their table slot (already claimed in the visited
+// table) is rewritten to the final id.  Greedy: the key is inserted into the visited table now (it is known
+// to be absent and the committed keys are pairwise distinct, so a plain CAS claim is enough).
+template <typename W>
+__global__ void __launch_bounds__(256) k_commit(SearchDev<W> d, const uint32_t* __restrict__ plist, uint32_t pbegin, uint32_t cutoff, uint32_t base,
+                                                int insert_now) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cutoff || !d.cflag[t]) return;
+    const uint32_t id = base + d.cpos[t];
+    const uint32_t p = t / 12u;
+    const uint32_t pid = plist ? plist[p] : pbegin + p;
+    const W k0 = d.ck0[t], k1 = d.ck1[t];
+    d.k0[id] = k0;
+    d.k1[id] = k1;
+    d.parent[id] = pid;
+    d.act[id] = (uint8_t)(t - 12u * p);
+    d.tlen[id] = d.clen[t];
+    d.depth[id] = d.depth[pid] + 1;
+    if (insert_now) {
+        uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.smask;
+        while (atomicCAS(&d.slots[h], kEmpty, id) != kEmpty) h = (h + 1) & d.smask;
+    } else {
+        d.slots[d.cslot[t]] = id;
+    }
+}
+
+// root node: id 0
+template <typename W> __global__ void k_root(SearchDev<W> d, W k0, W k1, uint32_t tl) {
+    d.k0[0] = k0;
+    d.k1[0] = k1;
+    d.parent[0] = kEmpty;
+    d.act[0] = 0xff;
+    d.tlen[0] = (uint8_t)tl;
+    d.depth[0] = 0;
+    d.slots[(uint32_t)hash_key<W>(k0, k1) & d.smask] = 0;
+}
+
+// path of node `id` from the root, written root first: out_act / out_len [depth + 1]
+template <typename W> __global__ void k_path(SearchDev<W> d, uint32_t id, int32_t* out_act, int32_t* out_len, int64_t cap) {
+    const uint32_t dep = d.depth[id];
+    for (uint32_t v = id, k = dep;; k--) {
+        if ((int64_t)k < cap) {
+            out_act[k] = d.act[v] == 0xff ? -1 : (int32_t)d.act[v];
+            out_len[k] = d.tlen[v];
+        }
+        if (k == 0) break;
+        v = d.parent[v];
+    }
+}
+
+// Order a heap bucket by the signed state tuple (greedy.py:104-113 heap key, third field): rank sort.
+// Thread i counts the bucket entries that sort before its own; states inside a bucket are pairwise
+// distinct (they passed the visited set), so ranks are a permutation.  Keys are staged through LDS in
+// tiles of 256 so that every comparison reads one broadcast LDS row.  O(n^2), buckets are small.
+template <typename W>
+__global__ void __launch_bounds__(256) k_rank_sort(SearchDev<W> d, const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+    __shared__ W t0[256];
+    __shared__ W t1[256];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t mine = i < n ? in[i] : 0;
+    Pres<W> me;
+    key_to_pres<W>(d.k0[mine], d.k1[mine], me);
+    uint32_t rank = 0;
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t j = base + threadIdx.x;
+        if (j < n) {
+            const uint32_t id = in[j];
+            t0[threadIdx.x] = d.k0[id];
+            t1[threadIdx.x] = d.k1[id];
+        }
+        __syncthreads();
+        const uint32_t cnt = n - base < 256 ? n - base : 256;
+        for (uint32_t q = 0; q < cnt; q++) {
+            Pres<W> o;
+            key_to_pres<W>(t0[q], t1[q], o);
+            rank += compare_pres<W>(o, me) < 0 ? 1u : 0u;
+        }
+        __syncthreads();
+    }
+    if (i < n) out[rank] = mine;
+}
+
+// ---------------------------------------------------------------------------------------- host ---
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t b) {
+        bytes = b ? b : 1;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            p = nullptr;
+            return fail(ACX_E_NOMEM, "hipMalloc(%zu) failed", bytes);
+        }
+        return ACX_OK;
+    }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+struct Scalars {
+    unsigned long long solved_tag, shorter_tag, rank_tag;
+    uint32_t err, min_len;
+};
+
+template <typename W> struct Searcher {
+    SearchDev<W> d;
+    DevBuf arena_nodes, arena_cand, arena_tab, arena_btab, arena_scal, arena_tmp, arena_list, arena_path;
+    size_t tmp_bytes = 0;
+    uint64_t cap_nodes = 0, cap_cand = 0, n_slots = 0, n_bslots = 0;
+    hipStream_t st = nullptr;
+
+    int init(int L, int cyclical, int64_t max_nodes, uint32_t batch_parents, bool greedy) {
+        memset(&d, 0, sizeof(d));
+        d.L = L;
+        d.cyclical = cyclical;
+        cap_nodes = (uint64_t)max_nodes + 64;
+        cap_cand = 12ull * batch_parents;
+        n_slots = 1024;
+        while (n_slots < 2 * (cap_nodes + cap_cand)) n_slots <<= 1;
+        if (n_slots > (1ull << 31)) return fail(ACX_E_INVAL, "acx_search: budget too large for 32-bit node ids");
+        n_bslots = 1024;
+        while (greedy && n_bslots < 2 * cap_cand) n_bslots <<= 1;
+        size_t o = 0;
+        auto take = [&](uint8_t* base, size_t bytes) {
+            uint8_t* p = base ? base + o : nullptr;
+            o += (bytes + 255) / 256 * 256;
+            return p;
+        };
+        for (int pass = 0; pass < 2; pass++) {
+            uint8_t* b = (uint8_t*)arena_nodes.p;
+            o = 0;
+            d.k0 = (W*)take(b, cap_nodes * sizeof(W));
+            d.k1 = (W*)take(b, cap_nodes * sizeof(W));
+            d.parent = (uint32_t*)take(b, cap_nodes * 4);
+            d.depth = (uint32_t*)take(b, cap_nodes * 4);
+            d.act = (uint8_t*)take(b, cap_nodes);
+            d.tlen = (uint8_t*)take(b, cap_nodes);
+            if (pass == 0 && arena_nodes.alloc(o)) return ACX_E_NOMEM;
+        }
+        for (int pass = 0; pass < 2; pass++) {
+            uint8_t* b = (uint8_t*)arena_cand.p;
+            o = 0;
+            d.ck0 = (W*)take(b, cap_cand * sizeof(W));
+            d.ck1 = (W*)take(b, cap_cand * sizeof(W));
+            d.cslot = (uint32_t*)take(b, cap_cand * 4);
+            d.cflag = (uint32_t*)take(b, cap_cand * 4);
+            d.cpos = (uint32_t*)take(b, cap_cand * 4);
+            d.clen = (uint8_t*)take(b, cap_cand);
+            d.cknown = (uint8_t*)take(b, cap_cand);
+            if (pass == 0 && arena_cand.alloc(o)) return ACX_E_NOMEM;
+        }
+        if (arena_tab.alloc(n_slots * 4)) return ACX_E_NOMEM;
+        d.slots = (uint32_t*)arena_tab.p;
+        d.smask = (uint32_t)(n_slots - 1);
+        if (greedy) {
+            if (arena_btab.alloc(n_bslots * 4)) return ACX_E_NOMEM;
+            d.bslots = (uint32_t*)arena_btab.p;
+            d.bmask = (uint32_t)(n_bslots - 1);
+        }
+        if (arena_scal.alloc(256)) return ACX_E_NOMEM;
+        uint8_t* sc = (uint8_t*)arena_scal.p;
+        d.solved_tag = (unsigned long long*)(sc + 0);
+        d.shorter_tag = (unsigned long long*)(sc + 8);
+        d.rank_tag = (unsigned long long*)(sc + 16);
+        d.err = (uint32_t*)(sc + 24);
+        d.min_len = (uint32_t*)(sc + 28);
+        if (arena_list.alloc(std::max<uint64_t>(batch_parents, 1024) * 4 * 2)) return ACX_E_NOMEM;
+        if (arena_path.alloc(8)) return ACX_E_NOMEM;
+        // rocprim temporary storage for the scan over one batch
+        size_t need = 0;
+        if (rocprim::exclusive_scan(nullptr, need, d.cflag, d.cpos, 0u, cap_cand, rocprim::plus<uint32_t>(), st) != hipSuccess)
+            return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan sizing failed");
+        tmp_bytes = need + 256;
+        if (arena_tmp.alloc(tmp_bytes)) return ACX_E_NOMEM;
+        ACX_HIP_TRY(hipMemsetAsync(d.slots, 0xff, n_slots * 4, st));
+        ACX_HIP_TRY(hipMemsetAsync(arena_scal.p, 0xff, 256, st));
+        ACX_HIP_TRY(hipMemsetAsync(d.err, 0, 4, st));
+        return ACX_OK;
+    }
+
+    int read_scalars(Scalars& s) {
+        uint8_t h[32];
+        ACX_HIP_TRY(hipMemcpyAsync(h, arena_scal.p, 32, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipStreamSynchronize(st));
+        memcpy(&s.solved_tag, h + 0, 8);
+        memcpy(&s.shorter_tag, h + 8, 8);
+        memcpy(&s.rank_tag, h + 16, 8);
+        memcpy(&s.err, h + 24, 4);
+        memcpy(&s.min_len, h + 28, 4);
+        return ACX_OK;
+    }
+
+    int reset_batch_scalars() {  // solved / shorter / rank tags back to "none"; err and min_len are sticky
+        ACX_HIP_TRY(hipMemsetAsync(arena_scal.p, 0xff, 24, st));
+        return ACX_OK;
+    }
+
+    int scan(uint32_t m, uint32_t& total) {
+        size_t tb = tmp_bytes;
+        if (rocprim::exclusive_scan(arena_tmp.p, tb, d.cflag, d.cpos, 0u, m, rocprim::plus<uint32_t>(), st) != hipSuccess)
+            return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan failed");
+        uint32_t last[2];
+        ACX_HIP_TRY(hipMemcpyAsync(&last[0], d.cpos + (m - 1), 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipMemcpyAsync(&last[1], d.cflag + (m - 1), 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipStreamSynchronize(st));
+        total = last[0] + last[1];
+        return ACX_OK;
+    }
+
+    // number of winners with tag < cutoff
+    int winners_below(uint32_t cutoff, uint32_t m, uint32_t total, uint32_t& out) {
+        if (cutoff >= m) {
+            out = total;
+            return ACX_OK;
+        }
+        ACX_HIP_TRY(hipMemcpyAsync(&out, d.cpos + cutoff, 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipStreamSynchronize(st));
+        return ACX_OK;
+    }
+
+    // first parent position whose cumulative winner count reaches `need` (need >= 1 and <= total)
+    int budget_parent(uint32_t m, uint32_t need, uint32_t& parent_pos) {
+        hipLaunchKernelGGL(k_find_rank<W>, dim3((m + 255) / 256), dim3(256), 0, st, d, m, need);
+        unsigned long long t = 0;
+        ACX_HIP_TRY(hipMemcpyAsync(&t, d.rank_tag, 8, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipStreamSynchronize(st));
+        parent_pos = (uint32_t)(t / 12);
+        return ACX_OK;
+    }
+
+    int path_of(uint32_t id, uint32_t depth, int32_t* pa, int32_t* pl, int64_t cap, int64_t* n) {
+        const int64_t len = (int64_t)depth + 1;
+        *n = len;
+        const int64_t w = std::min<int64_t>(len, cap);
+        if (w <= 0) return ACX_OK;
+        DevBuf buf;
+        if (buf.alloc((size_t)w * 8)) return ACX_E_NOMEM;
+        int32_t* da = (int32_t*)buf.p;
+        int32_t* dl = da + w;
+        hipLaunchKernelGGL(k_path<W>, dim3(1), dim3(1), 0, st, d, id, da, dl, w);
+        ACX_HIP_TRY(hipMemcpyAsync(pa, da, w * 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipMemcpyAsync(pl, dl, w * 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipStreamSynchronize(st));
+        return ACX_OK;
+    }
+
+    int node_field(uint32_t id, uint32_t& parent, uint32_t& depth) {
+        ACX_HIP_TRY(hipMemcpyAsync(&parent, d.parent + id, 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipMemcpyAsync(&depth, d.depth + id, 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipStreamSynchronize(st));
+        return ACX_OK;
+    }
+};
+
+static int err_to_rc(uint32_t e) {
+    return fail(ACX_E_ROWERR, "a move emptied a relator during the search: the reference raises %s here",
+                (e & ACX_ERR_INDEX) && !(e & ACX_ERR_ASSERT) ? "IndexError" : "AssertionError");
+}
+
+template <typename W>
+static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, int cyclical, int32_t* solved, int32_t* path_action,
+                      int32_t* path_len, int64_t path_cap, int64_t* path_n, acx_search_stats* stats) {
+    Pres<W> root;
+    bool ok = pack_relator<W>(pres, L, root.w0, root.n0);
+    ok = pack_relator<W>(pres + L, L, root.w1, root.n1) && ok;
+    if (!ok) return fail(ACX_E_ROWERR, "acx_search: the presentation is not a zero-padded word pair over {+-1,+-2}");
+    const bool greedy = kind == ACX_SEARCH_GREEDY;
+    const uint32_t bmax = (uint32_t)std::min<int64_t>(std::max<int64_t>(max_nodes, 1024), greedy ? (1 << 14) : (1 << 20));
+    Searcher<W> S;
+    int rc = S.init(L, cyclical, max_nodes, bmax, greedy);
+    if (rc) return rc;
+    SearchDev<W>& d = S.d;
+    hipStream_t st = S.st;
+    hipEvent_t ev0, ev1;
+    ACX_HIP_TRY(hipEventCreate(&ev0));
+    ACX_HIP_TRY(hipEventCreate(&ev1));
+    ACX_HIP_TRY(hipEventRecord(ev0, st));
+
+    const uint32_t tl0 = (uint32_t)(root.n0 + root.n1);
+    hipLaunchKernelGGL(k_root<W>, dim3(1), dim3(1), 0, st, d, keyops<W>::make(root.w0, root.n0), keyops<W>::make(root.w1, root.n1), tl0);
+    uint64_t nodes = 1, expanded = 0, batches = 0;
+    uint32_t min_len = tl0;
+    *solved = 0;
+    *path_n = 0;
+    uint32_t last_parent = 0, last_child_len = 0;  // greedy.py:121 return value
+    bool done = false;
+
+    // greedy: heap buckets keyed by (total length, depth) -> node ids (host side; sorted on the device when popped)
+    struct Bucket {
+        std::vector<uint32_t> ids;
+        size_t head = 0;  // ids[head..] are still queued
+    };
+    std::map<std::pair<uint32_t, uint32_t>, Bucket> buckets;
+    std::pair<uint32_t, uint32_t> sorted_key(0, 0);
+    bool have_sorted = false;
+    if (greedy) buckets[{tl0, 0u}].ids.push_back(0);
+    uint32_t bfs_head = 0;  // next FIFO position to expand
+    uint32_t* dlist = (uint32_t*)S.arena_list.p;
+    std::vector<uint32_t> hlist;
+    std::vector<uint8_t> hlen;
+    const bool debug = getenv("ACX_DEBUG") != nullptr;
+    uint32_t adaptive = 64;  // greedy batch size: grows while buckets are consumed without a cut
+
+    while (!done) {
+        // ---- choose the batch of parents -------------------------------------------------------------
+        uint32_t np = 0;
+        const uint32_t* plist = nullptr;
+        uint32_t pbegin = 0;
+        int bucket_len = -1;
+        uint32_t bucket_depth = 0;
+        if (!greedy) {
+            if (bfs_head >= nodes) break;  // queue exhausted (breadth_first.py:61)
+            np = (uint32_t)std::min<uint64_t>(nodes - bfs_head, bmax);
+            pbegin = bfs_head;
+        } else {
+            if (buckets.empty()) break;  // heap exhausted (greedy.py:71)
+            auto it = buckets.begin();
+            Bucket& bk = it->second;
+            const size_t live = bk.ids.size() - bk.head;
+            uint32_t* ids = bk.ids.data() + bk.head;
+            bucket_len = (int)it->first.first;
+            bucket_depth = it->first.second;
+            if (!(have_sorted && sorted_key == it->first) && live > 1) {
+                // order the bucket by signed state tuple on the device (merge sort on node ids)
+                DevBuf big;
+                uint32_t* buf = dlist;
+                const size_t list_cap = std::max<uint32_t>(bmax, 1024);
+                if (live > list_cap) {
+                    if (big.alloc(live * 8)) return ACX_E_NOMEM;
+                    buf = (uint32_t*)big.p;
+                }
+                uint32_t* out = buf + std::max(live, list_cap);
+                if (live > list_cap) out = buf + live;
+                ACX_HIP_TRY(hipMemcpyAsync(buf, ids, live * 4, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_rank_sort<W>, dim3((unsigned)((live + 255) / 256)), dim3(256), 0, st, d, buf, (uint32_t)live, out);
+                ACX_HIP_TRY(hipGetLastError());
+                ACX_HIP_TRY(hipMemcpyAsync(ids, out, live * 4, hipMemcpyDeviceToHost, st));
+                ACX_HIP_TRY(hipStreamSynchronize(st));
+            }
+            have_sorted = true;
+            sorted_key = it->first;
+            np = (uint32_t)std::min<size_t>(live, std::min<uint32_t>(adaptive, bmax));
+            hlist.assign(ids, ids + np);
+            ACX_HIP_TRY(hipMemcpyAsync(dlist, hlist.data(), (size_t)np * 4, hipMemcpyHostToDevice, st));
+            plist = dlist;
+        }
+        const uint32_t m = 12u * np;
+        const dim3 grid((m + 255) / 256), block(256);
+        batches++;
+        if (debug) fprintf(stderr, "[acx_search] batch %llu: np=%u nodes=%llu bucket=(%d,%u) buckets=%zu\n", (unsigned long long)batches, np,
+                           (unsigned long long)nodes, bucket_len, bucket_depth, buckets.size());
+
+        // ---- expand, dedup with min-tag resolution, number the winners ---------------------------------
+        rc = S.reset_batch_scalars();
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_expand<W>, grid, block, 0, st, d, plist, pbegin, np);
+        if (greedy) {
+            hipLaunchKernelGGL(k_lookup<W>, grid, block, 0, st, d, m);
+            ACX_HIP_TRY(hipMemsetAsync(d.bslots, 0xff, S.n_bslots * 4, st));
+            hipLaunchKernelGGL(k_insert<W>, grid, block, 0, st, d, d.bslots, d.bmask, m, 1);
+            hipLaunchKernelGGL(k_mark<W>, grid, block, 0, st, d, d.bslots, m, bucket_len);
+        } else {
+            hipLaunchKernelGGL(k_insert<W>, grid, block, 0, st, d, d.slots, d.smask, m, 0);
+            hipLaunchKernelGGL(k_mark<W>, grid, block, 0, st, d, d.slots, m, -1);
+        }
+        ACX_HIP_TRY(hipGetLastError());
+        uint32_t total = 0;
+        rc = S.scan(m, total);
+        if (rc) return rc;
+        Scalars sc;
+        rc = S.read_scalars(sc);
+        if (rc) return rc;
+        if (sc.err) return err_to_rc(sc.err);
+        if (debug) fprintf(stderr, "[acx_search]   total=%u solved=%lld shorter=%lld\n", total, (long long)sc.solved_tag, (long long)sc.shorter_tag);
+
+        // ---- where does the reference stop inside this batch? ------------------------------------------
+        uint32_t p_end = np - 1;  // last parent of the batch that the reference pops
+        bool budget_hit = false;
+        if (greedy && sc.shorter_tag != kNoTag) p_end = std::min<uint32_t>(p_end, (uint32_t)(sc.shorter_tag / 12));
+        if ((int64_t)nodes >= max_nodes) {  // only possible for the very first parent (budget <= 1)
+            p_end = 0;
+            budget_hit = true;
+        } else if ((int64_t)(nodes + total) >= max_nodes) {
+            uint32_t pb = 0;
+            rc = S.budget_parent(m, (uint32_t)(max_nodes - (int64_t)nodes), pb);
+            if (rc) return rc;
+            if (pb <= p_end) {
+                p_end = pb;
+                budget_hit = true;
+            }
+        }
+        if (sc.solved_tag != kNoTag && (uint32_t)(sc.solved_tag / 12) <= p_end) {
+            // success: path of the parent + (action, 2); checked before dedup and before the budget test
+            const uint32_t ps = (uint32_t)(sc.solved_tag / 12), as = (uint32_t)(sc.solved_tag % 12);
+            const uint32_t pid = plist ? hlist[ps] : pbegin + ps;
+            uint32_t par, dep;
+            rc = S.node_field(pid, par, dep);
+            if (rc) return rc;
+            int64_t n = 0;
+            rc = S.path_of(pid, dep, path_action, path_len, path_cap, &n);
+            if (rc) return rc;
+            if (n < path_cap) {
+                path_action[n] = (int32_t)as;
+                path_len[n] = 2;
+            }
+            *path_n = n + 1;
+            *solved = 1;
+            expanded += ps + 1;
+            // nodes inserted before the solving child (stats only)
+            uint32_t c = 0;
+            rc = S.winners_below((uint32_t)sc.solved_tag, m, total, c);
+            if (rc) return rc;
+            nodes += c;
+            min_len = 2;
+            done = true;
+            break;
+        }
+        const uint32_t cutoff = 12u * (p_end + 1);
+        uint32_t committed = 0;
+        rc = S.winners_below(cutoff, m, total, committed);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_commit<W>, dim3((cutoff + 255) / 256), block, 0, st, d, plist, pbegin, cutoff, (uint32_t)nodes, greedy ? 1 : 0);
+        ACX_HIP_TRY(hipGetLastError());
+        if (debug) { (void)hipStreamSynchronize(st); fprintf(stderr, "[acx_search]   committed %u (p_end %u)\n", committed, p_end); }
+        expanded += p_end + 1;
+
+        if (greedy) {
+            // file the new nodes into their heap buckets and drop the popped parents
+            last_parent = hlist[p_end];
+            uint8_t lc = 0;
+            ACX_HIP_TRY(hipMemcpyAsync(&lc, d.clen + (cutoff - 1), 1, hipMemcpyDeviceToHost, st));
+            hlen.resize(committed);
+            if (committed) ACX_HIP_TRY(hipMemcpyAsync(hlen.data(), d.tlen + nodes, committed, hipMemcpyDeviceToHost, st));
+            ACX_HIP_TRY(hipStreamSynchronize(st));
+            last_child_len = lc;
+            auto it = buckets.begin();
+            it->second.head += p_end + 1;
+            const bool cut = p_end + 1 < np;
+            if (it->second.head == it->second.ids.size()) {
+                buckets.erase(it);
+                have_sorted = false;
+            }
+            for (uint32_t k = 0; k < committed; k++) {
+                const std::pair<uint32_t, uint32_t> key(hlen[k], bucket_depth + 1);
+                if (have_sorted && key == sorted_key) have_sorted = false;  // cannot happen (depth differs); kept for safety
+                buckets[key].ids.push_back((uint32_t)nodes + k);
+            }
+            adaptive = cut ? 64 : std::min<uint32_t>(adaptive * 2, bmax);
+        } else {
+            bfs_head += p_end + 1;
+        }
+        nodes += committed;
+        if (budget_hit) break;  // breadth_first.py:91-95 / greedy.py:115-119
+    }
+
+    if (!*solved && greedy) {  // greedy.py:121: path of the last popped node + (11, length of its last child)
+        uint32_t par, dep;
+        rc = S.node_field(last_parent, par, dep);
+        if (rc) return rc;
+        int64_t n = 0;
+        rc = S.path_of(last_parent, dep, path_action, path_len, path_cap, &n);
+        if (rc) return rc;
+        if (n < path_cap) {
+            path_action[n] = 11;
+            path_len[n] = (int32_t)last_child_len;
+        }
+        *path_n = n + 1;
+    }
+    Scalars sc;
+    rc = S.read_scalars(sc);
+    if (rc) return rc;
+    ACX_HIP_TRY(hipEventRecord(ev1, st));
+    ACX_HIP_TRY(hipEventSynchronize(ev1));
+    float ms = 0;
+    ACX_HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    if (stats) {
+        stats->nodes = (int64_t)nodes;
+        stats->expanded = (int64_t)expanded;
+        stats->children = (int64_t)expanded * 12;
+        stats->levels = (int64_t)batches;
+        stats->min_len = (int32_t)std::min<uint32_t>(min_len, sc.min_len);
+        stats->seconds = ms * 1e-3;
+    }
+    if (*path_n > path_cap) return fail(ACX_E_CAPACITY, "path has %lld entries, buffer holds %lld", (long long)*path_n, (long long)path_cap);
+    return ACX_OK;
+}
+
+}  // namespace acx
+
+using namespace acx;
 
 extern "C" int acx_search(int kind, const int8_t* h_presentation, int L, int64_t max_nodes, int cyclical, int32_t* solved,
                           int32_t* path_action, int32_t* path_len, int64_t path_cap, int64_t* path_n, acx_search_stats* stats) {
-    (void)kind; (void)h_presentation; (void)L; (void)max_nodes; (void)cyclical; (void)solved; (void)path_action; (void)path_len;
-    (void)path_cap; (void)path_n; (void)stats;
-    return acx::fail(ACX_E_INVAL, "acx_search: not built yet");
+    if (!have_device()) return ACX_E_NODEVICE;
+    if ((kind != ACX_SEARCH_BFS && kind != ACX_SEARCH_GREEDY) || !h_presentation || L < 1 || !solved || !path_n || path_cap < 0 ||
+        (path_cap > 0 && (!path_action || !path_len)))
+        return fail(ACX_E_INVAL, "acx_search: bad argument");
+    if (L > 61) return fail(ACX_E_INVAL, "acx_search handles max_relator_length <= 61, got %d", L);
+    if (max_nodes < 0) max_nodes = 0;
+    if (L <= 29) return run_search<uint64_t>(kind, h_presentation, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats);
+    return run_search<u128>(kind, h_presentation, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats);
 }

@@ -1,0 +1,96 @@
+"""GPU parity of bfs / greedy_search (device frontier through acx_search) against the reference's
+golden results and the oracle: identical (solved, path), budget-exhaustion returns included."""
+import numpy as np
+import pytest
+
+from tests.conftest import ms_pool_generator_order
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def search():
+    import ac_solver
+    from ac_solver import _acx
+
+    _acx.require_device()
+    return ac_solver
+
+
+def _as_tuples(path):
+    return None if path is None else [tuple(x) for x in path]
+
+
+def test_reference_own_golden_paths(search, golden_json):
+    """tests/search/test_bfs.py + test_gs.py of the reference: AK(2)"""
+    ak2 = np.array([1, 1, -2, -2, -2, 0, 0, 1, 2, 1, -2, -1, -2, 0])
+    rows = {(r["algo"], r["budget"], r["cyclical"]): r for r in golden_json("search.json") if r["tag"] == "ak2"}
+    ok, path = search.bfs(presentation=ak2, max_nodes_to_explore=int(1e6))
+    assert ok and path == _as_tuples(rows[("bfs", 10**6, False)]["path"]) and len(path) == 20
+    assert search.bfs(presentation=ak2, max_nodes_to_explore=10) == (False, None)
+    ok, path = search.greedy_search(presentation=ak2, max_nodes_to_explore=int(1e6))
+    assert ok and path == _as_tuples(rows[("greedy", 10**6, False)]["path"]) and len(path) == 23
+    assert search.bfs.__name__ == "bfs" and search.greedy_search.__name__ == "greedy_search"
+
+
+def test_all_search_fixtures(search, golden_json):
+    for r in golden_json("search.json"):
+        fn = search.bfs if r["algo"] == "bfs" else search.greedy_search
+        ok, path = fn(r["presentation"], r["budget"], cyclically_reduce_after_moves=r["cyclical"])
+        assert ok == r["solved"] and path == _as_tuples(r["path"]), (r["tag"], r["algo"], r["budget"], r["cyclical"])
+
+
+def test_invalid_input(search):
+    with pytest.raises(AssertionError):
+        search.bfs([1, 0, 2, 0, 0, 0], 10)  # interior / empty relator: not a valid presentation
+
+
+@pytest.mark.parametrize("algo", ["bfs", "greedy"])
+def test_ms_pool_at_L25_vs_oracle(search, golden_json, algo):
+    """BASELINE configs 3/4 shape: MS presentations re-embedded at max_relator_length = 25"""
+    from oracle import ac_oracle as O
+
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    rng = np.random.default_rng(3)
+    for k in rng.choice(len(pool), size=24, replace=False):
+        p = np.array(pool[k])
+        half = len(p) // 2
+        row = np.zeros(50, np.int8)
+        for h in (0, 1):
+            w = p[h * half:(h + 1) * half]
+            w = w[w != 0]
+            row[h * 25:h * 25 + len(w)] = w
+        for budget in (1, 50, 2000, 60000):
+            for cyc in (False, True):
+                if algo == "bfs":
+                    want = O.bfs(row, budget, cyclically_reduce_after_moves=cyc)
+                    got = search.bfs(row, budget, cyclically_reduce_after_moves=cyc)
+                else:
+                    want = O.greedy_search(row, budget, cyclically_reduce_after_moves=cyc)
+                    got = search.greedy_search(row, budget, cyclically_reduce_after_moves=cyc)
+                assert got == want, (int(k), budget, cyc)
+
+
+def test_stats_match_oracle_node_counts(search):
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search
+    from oracle import ac_oracle as O
+
+    ak3 = np.zeros(50, np.int8)
+    ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+    ak3[25:31] = [1, 2, 1, -2, -1, -2]
+    for kind, ofn in ((_acx.SEARCH_BFS, O.bfs), (_acx.SEARCH_GREEDY, O.greedy_search)):
+        for budget in (1000, 100000):
+            ok, path, st = run_search(kind, ak3, budget, False)
+            wok, wpath, wst = ofn(ak3, budget, stats=True)
+            assert (ok, path) == (wok, wpath)
+            assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (kind, budget, st, wst)
+
+
+def test_greedy_paths_file_sample(search, golden_json):
+    """data/greedy_search_paths.txt (budget 1e6): a sample through the device frontier at native L (up to 36 -> 128-bit keys)"""
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    g = golden_json("greedy_paths_1e6.json")
+    for row in g["rows"][::9]:
+        ok, path = search.greedy_search(pool[row["pool_index"]], g["budget"])
+        assert ok and path == _as_tuples(row["path"]), row["pool_index"]
