@@ -88,6 +88,16 @@ SIGNATURES = {
     "acx_env_get_actions": (C.c_int, [_vp, C.c_int64, C.c_int, _i32p, C.c_int64, _i64p]),
     "acx_env_get_errors": (C.c_int, [_vp, _u8p, C.c_int]),
     "acx_env_max_reward": (C.c_int64, [_vp]),
+    "acx_shard_key_words": (C.c_int, [C.c_int]),
+    "acx_shard_create": (_vp, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int]),
+    "acx_shard_destroy": (None, [_vp]),
+    "acx_shard_root_record": (C.c_int, [_vp, _i8p, _i64p]),
+    "acx_shard_expand": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "acx_shard_insert": (C.c_int, [_vp, _vp, C.c_int64, _vp, _i64p, _vp]),
+    "acx_shard_commit": (C.c_int, [_vp, C.c_int64, _i64p, _i64p, _vp]),
+    "acx_shard_node_info": (C.c_int, [_vp, C.c_int64, _i64p]),
+    "acx_shard_node_count": (C.c_int64, [_vp]),
+    "acx_shard_status": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "acx_search": (C.c_int, [C.c_int, _i8p, C.c_int, C.c_int64, C.c_int, _i32p, _i32p, _i32p, C.c_int64, _i64p, C.POINTER(SearchStats)]),
 }
 for _name, (_res, _args) in SIGNATURES.items():

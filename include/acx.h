@@ -137,6 +137,34 @@ typedef struct {
 int acx_search(int kind, const int8_t *h_presentation, int L, int64_t max_nodes, int cyclical, int32_t *solved,
                int32_t *path_action, int32_t *path_len, int64_t path_cap, int64_t *path_n, acx_search_stats *stats);
 
+/* ---- sharded BFS frontier (one engine per GPU) ---------------------------------------------------
+ * The multi-GPU form of bfs (breadth_first.py:15-97): states are partitioned by hash(key) mod world, the
+ * host exchanges candidate records between ranks (RCCL all-to-all) and these calls do the per-rank work.
+ * A record is acx_shard_key_words(L) + 2 int64: the packed key, tag = 12 * global_parent_position + action
+ * (the order in which the reference generates children), parent_ref = rank << 40 | local node id.
+ * Orchestration and the cross-rank numbering live in ac-solver_amd/ac_solver/search/sharded.py. */
+typedef struct acx_shard acx_shard;
+int acx_shard_key_words(int L); /* 2 for L <= 29, 4 for L <= 61 */
+acx_shard *acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t batch_cap, int rank, int world);
+void acx_shard_destroy(acx_shard *h);
+/* the root as a record (tag 0, parent_ref -1), host buffer of key_words + 2 int64 */
+int acx_shard_root_record(acx_shard *h, const int8_t *h_presentation, int64_t *h_record);
+/* children of the local nodes d_ids[0..np) whose global frontier positions are d_gpos: 12*np records;
+ * d_solved[0] is min-combined with the tags of children of total length 2 */
+int acx_shard_expand(acx_shard *h, const int64_t *d_ids, const int64_t *d_gpos, int64_t np, int64_t *d_records,
+                     int64_t *d_solved, void *stream);
+/* exact dedup of n received records against the visited table and among themselves (minimum tag wins);
+ * the winners' tags are written ascending to d_win_tags, their count to *n_win; they stay pending */
+int acx_shard_insert(acx_shard *h, const int64_t *d_records, int64_t n, int64_t *d_win_tags, int64_t *n_win,
+                     void *stream);
+/* pending winners with tag < cutoff_tag become local nodes first_id, first_id + 1, ... in tag order */
+int acx_shard_commit(acx_shard *h, int64_t cutoff_tag, int64_t *first_id, int64_t *n_committed, void *stream);
+/* h_info3 = (action, total_length, parent_ref) of a local node; the root has action -1, parent_ref -1 */
+int acx_shard_node_info(acx_shard *h, int64_t id, int64_t *h_info3);
+int64_t acx_shard_node_count(acx_shard *h);
+/* sticky move-error bits (a move emptied a relator: the reference raises) and the smallest total length seen */
+int acx_shard_status(acx_shard *h, int32_t *err, int32_t *min_len);
+
 #ifdef __cplusplus
 }
 #endif

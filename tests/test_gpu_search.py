@@ -94,3 +94,29 @@ def test_greedy_paths_file_sample(search, golden_json):
     for row in g["rows"][::9]:
         ok, path = search.greedy_search(pool[row["pool_index"]], g["budget"])
         assert ok and path == _as_tuples(row["path"]), row["pool_index"]
+
+
+# ---- sharded frontier: several ranks of the HIP engine on one GPU (threads stand in for processes) ----
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_sharded_bfs_hip_engine_matches_reference(search, golden_json, world):
+    from ac_solver.search.sharded import SingleComm, bfs_sharded
+    from oracle import ac_oracle as O
+    from tests.shard_helpers import run_threads
+
+    ak2 = [1, 1, -2, -2, -2, 0, 0, 1, 2, 1, -2, -1, -2, 0]
+    ak3 = np.zeros(50, np.int8)
+    ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+    ak3[25:31] = [1, 2, 1, -2, -1, -2]
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    cases = [(ak2, 10**6, False, 1 << 18), (ak2, 10, False, 1 << 18), (ak2, 1, False, 4), (ak2, 3000, True, 100),
+             (ak3, 10**5, False, 1 << 14), (ak3, 5000, True, 333), (pool[1100], 20000, False, 1 << 12), (pool[600], 3000, False, 50)]
+
+    def run(comm):
+        return [bfs_sharded(p, b, cyclically_reduce_after_moves=c, comm=comm, batch_parents=bp, want_stats=True) for p, b, c, bp in cases]
+
+    results = [run(SingleComm())] if world == 1 else run_threads(world, run)
+    for res in results:
+        for (p, b, c, bp), (ok, path, st) in zip(cases, res):
+            wok, wpath, wst = O.bfs(p, b, cyclically_reduce_after_moves=c, stats=True)
+            assert (ok, path) == (wok, wpath), (world, b, c)
+            assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (world, b, c, st, wst)
