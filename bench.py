@@ -80,6 +80,65 @@ def cpu_baseline(states, seed, budget_s=12.0):
             "sample": f"{steps} ACEnv.step calls ({n} envs, MS initial states, L={L}) by oracle/ac_oracle.c in {dt:.1f} s"}
 
 
+def ak3_at_L():
+    """AK(3) = <x,y | x^3 = y^4, xyx = yxy> at max_relator_length = 25 (BASELINE config 3)."""
+    p = np.zeros(2 * L, np.int8)
+    p[:7] = [1, 1, 1, -2, -2, -2, -2]
+    p[L:L + 6] = [1, 2, 1, -2, -1, -2]
+    return p
+
+
+def search_numbers(world, rank, dev, budget):
+    """BFS nodes/s with the frontier sharded over `world` GPUs (one search, strong scaling) and, on one GPU, the
+    fused single-GPU frontier (acx_search) for bfs and greedy_search.  AK(3) at L=25 does not trivialise, so the
+    searches run to the node budget."""
+    import torch
+    import torch.distributed as dist
+
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search
+    from ac_solver.search.sharded import SingleComm, TorchDistComm, bfs_sharded
+
+    p = ak3_at_L()
+    comm = TorchDistComm(dev) if world > 1 else SingleComm()
+    bfs_sharded(p, 20000, comm=comm)  # warm-up: allocator, kernels, communicator
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    ok, path, st = bfs_sharded(p, budget, comm=comm, batch_parents=1 << 20, want_stats=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    out = {"bfs_sharded": {"nodes_per_s": st["nodes"] / float(dt[0]), "nodes": st["nodes"], "seconds": float(dt[0]), "levels": st["levels"],
+                           "n_gpus": world, "budget": budget, "input": "AK(3) at max_relator_len=25, cyclical=False", "scaling": "strong",
+                           "exchange": "all-to-all of child records + all-gather of new-node tags per chunk (RCCL)" if world > 1 else "none"}}
+    if world == 1:
+        for kind, name in ((_acx.SEARCH_BFS, "bfs"), (_acx.SEARCH_GREEDY, "greedy_search")):
+            run_search(kind, p, 20000, False)
+            t0 = time.perf_counter()
+            ok, path, s1 = run_search(kind, p, budget if kind == _acx.SEARCH_BFS else min(budget, 10**7), False)
+            dt1 = time.perf_counter() - t0
+            out[name] = {"nodes_per_s": s1["nodes"] / dt1, "nodes": s1["nodes"], "seconds": dt1, "batches": s1["levels"], "entry": "acx_search"}
+    return out
+
+
+def cpu_search_baseline(budget=10**6):
+    from oracle import ac_oracle as O
+
+    p = ak3_at_L()
+    res = {}
+    for fn, name in ((O.bfs, "bfs"), (O.greedy_search, "greedy_search")):
+        t0 = time.perf_counter()
+        ok, path, st = fn(p, budget, stats=True)
+        res[name + "_nodes_per_s"] = st["nodes"] / (time.perf_counter() - t0)
+    res["search_sample"] = f"AK(3) at L=25, budget {budget}, oracle/ac_oracle.c, 1 core"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,7 +148,8 @@ def main():
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="graph: the K launches are captured once into a hipGraph and replayed; eager: K host launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-search", action="store_true")
+    ap.add_argument("--no-search", action="store_true", help="skip the BFS / greedy frontier numbers")
+    ap.add_argument("--search-budget", type=int, default=2 * 10**7)
     args = ap.parse_args()
 
     import torch
@@ -169,6 +229,13 @@ def main():
     # sanity: the timed steps really ran (count_steps advanced, rewards written)
     assert int(env.get_counts().max()) > 0 and bool(torch.isfinite(rew).all()) and bool((rew != 0).all())
 
+    search = None
+    if not args.no_search:
+        try:
+            search = search_numbers(world, rank, dev, args.search_budget)
+        except Exception as e:  # the headline line must survive a failure of the secondary measurement
+            search = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         total_steps = N * K * world
         launch_s = dev_ms * 1e-3 / K
@@ -193,8 +260,12 @@ def main():
                          "traffic": None, "kernel": "k_env_step<u64,int8>", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * N,
                          "avg_launch_us": launch_s * 1e6},
         }
+        if search is not None:
+            out["search"] = search
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(states, 0)
+            if not args.no_search:
+                out["cpu_baseline"].update(cpu_search_baseline())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
