@@ -19,6 +19,10 @@
 #include "acx_common.h"
 #include "acx_word.h"
 
+#ifndef ACX_STEP_WAVES
+#define ACX_STEP_WAVES 8  // min waves per SIMD the env step kernel is compiled for (register budget)
+#endif
+
 namespace acx {
 
 // ---------------------------------------------------------------- host helpers (shared) -------
@@ -180,7 +184,7 @@ __global__ void __launch_bounds__(256) k_move_packed(const int8_t* __restrict__ 
 // ---------------------------------------------------------------- vectorised env --------------
 // Resident state, structure of arrays (8-byte lanes -> 512-B coalesced wave accesses):
 //   w0[n], w1[n]   packed relators
-//   meta[n]        n0 | n1 << 8 | sticky_err << 16 | count_steps << 32
+//   meta[n]        n0 | n1 << 8 | sticky_err << 16 | normal_form_flag << 24 | count_steps << 32
 template <typename W> struct EnvDev {
     W* w0;
     W* w1;
@@ -200,6 +204,7 @@ template <typename W> struct EnvLane {
     Pres<W> s;
     int32_t cnt;
     uint32_t err;
+    uint32_t red;  // both relators non-empty, freely and cyclically reduced: the steady state of ACEnv
 };
 
 template <typename W> __device__ __forceinline__ void env_load(const EnvDev<W>& e, int64_t i, EnvLane<W>& v) {
@@ -209,12 +214,13 @@ template <typename W> __device__ __forceinline__ void env_load(const EnvDev<W>& 
     v.s.n0 = (int)(m & 0xff);
     v.s.n1 = (int)((m >> 8) & 0xff);
     v.err = (uint32_t)((m >> 16) & 0xff);
+    v.red = (uint32_t)((m >> 24) & 1);
     v.cnt = (int32_t)(m >> 32);
 }
 template <typename W> __device__ __forceinline__ void env_store(const EnvDev<W>& e, int64_t i, const EnvLane<W>& v) {
     e.w0[i] = v.s.w0;
     e.w1[i] = v.s.w1;
-    e.meta[i] = (uint64_t)v.s.n0 | ((uint64_t)v.s.n1 << 8) | ((uint64_t)v.err << 16) | ((uint64_t)(uint32_t)v.cnt << 32);
+    e.meta[i] = (uint64_t)v.s.n0 | ((uint64_t)v.s.n1 << 8) | ((uint64_t)v.err << 16) | ((uint64_t)v.red << 24) | ((uint64_t)(uint32_t)v.cnt << 32);
 }
 
 // One env transition (ac_env.py:95-113) incl. the optional gymnasium-style autoreset.
@@ -223,8 +229,12 @@ template <typename W, bool SAFE>
 __device__ __forceinline__ void env_transition(const EnvDev<W>& e, int64_t i, EnvLane<W>& v, int a, bool autoreset, float clip_lo,
                                                float clip_hi, float& reward, int& done, int& trunc, bool& was_reset, Pres<W>& fin) {
     if (e.hist) e.hist[(int64_t)(v.cnt % e.H) * e.n + i] = (uint8_t)a;  // self.actions += [action], :96
-    const int er = (a < 0 || a >= 12) ? (int)ACX_ERR_ASSERT : apply_move<W, SAFE>(v.s, a, e.L, true);  // cyclical=True, :97
+    int er;  // ACMove(action, state, L, lengths) with cyclical=True, :97
+    if (a < 0 || a >= 12) er = ACX_ERR_ASSERT;
+    else if (v.red) er = apply_move_reduced<W, SAFE>(v.s, a, e.L);  // steady state: every state a step produces is in normal form
+    else er = apply_move<W, SAFE>(v.s, a, e.L, true);
     v.err = er ? (uint32_t)er : v.err;
+    v.red = er ? v.red : (uint32_t)(v.s.n0 > 0 && v.s.n1 > 0);
     const int tot = v.s.n0 + v.s.n1;
     done = tot == 2;                                                            // :101
     reward = clip_reward(done ? e.max_reward : -(float)tot, clip_lo, clip_hi);  // :102 (+ TransformReward clip)
@@ -239,42 +249,62 @@ __device__ __forceinline__ void env_transition(const EnvDev<W>& e, int64_t i, En
         const uint64_t m = e.imeta[i];
         v.s.n0 = (int)(m & 0xff);
         v.s.n1 = (int)((m >> 8) & 0xff);
+        v.red = (uint32_t)((m >> 24) & 1);
         v.cnt = 0;
     }
 }
 
-// the lane's observation row (2L entries) into its LDS slot, 8 letters per unpack
-template <typename W> __device__ __forceinline__ void write_obs_row(int8_t* row, const Pres<W>& s, int L) {
+// The lane's observation row (2L entries) into its LDS slot, four letters per v_perm_b32 (acx_word.h
+// letters4).  LC > 0 is a compile-time max_relator_length (loops unroll, the row layout folds to constants).
+template <typename W, int LC> __device__ __forceinline__ void write_obs_row(int8_t* row, const Pres<W>& s, int Lrt) {
     uint16_t* r16 = (uint16_t*)row;  // rows are 2L bytes apart: 2-byte aligned
-    for (int p = 0; p < 2 * L; p += 8) {
-        const uint64_t x = row8<W>(s.w0, s.n0, s.w1, s.n1, L, p);
-        const int valid = 2 * L - p < 8 ? 2 * L - p : 8;
+    auto put = [&](int L, int j) {
+        const uint32_t d = row_dword<W>(s.w0, s.n0, s.w1, s.n1, L, j);
+        r16[2 * j] = (uint16_t)d;
+        if (4 * j + 2 < 2 * L) r16[2 * j + 1] = (uint16_t)(d >> 16);
+    };
+    if constexpr (LC > 0) {
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (2 * q < valid) r16[(p >> 1) + q] = (uint16_t)(x >> (16 * q));
+        for (int j = 0; j < (2 * LC + 3) / 4; j++) put(LC, j);
+    } else {
+        for (int j = 0; j < (2 * Lrt + 3) / 4; j++) put(Lrt, j);
     }
 }
-template <typename W> __device__ __forceinline__ void write_obs_row(float* row, const Pres<W>& s, int L) {
+template <typename W, int LC> __device__ __forceinline__ void write_obs_row(float* row, const Pres<W>& s, int Lrt) {
     float2* r2 = (float2*)row;  // rows are 8L bytes apart: 8-byte aligned
-    for (int p = 0; p < 2 * L; p += 8) {
-        const uint64_t x = row8<W>(s.w0, s.n0, s.w1, s.n1, L, p);
-        const int valid = 2 * L - p < 8 ? 2 * L - p : 8;
+    auto put = [&](int L, int j) {
+        const uint32_t d = row_dword<W>(s.w0, s.n0, s.w1, s.n1, L, j);
+        r2[2 * j] = make_float2((float)(int8_t)d, (float)(int8_t)(d >> 8));
+        if (4 * j + 2 < 2 * L) r2[2 * j + 1] = make_float2((float)(int8_t)(d >> 16), (float)(int8_t)(d >> 24));
+    };
+    if constexpr (LC > 0) {
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (2 * q < valid) r2[(p >> 1) + q] = make_float2((float)(int8_t)(x >> (16 * q)), (float)(int8_t)(x >> (16 * q + 8)));
+        for (int j = 0; j < (2 * LC + 3) / 4; j++) put(LC, j);
+    } else {
+        for (int j = 0; j < (2 * Lrt + 3) / 4; j++) put(Lrt, j);
     }
 }
 
-template <typename W, bool SAFE, typename OBS>
-__global__ void __launch_bounds__(256) k_env_step(EnvDev<W> e, const void* __restrict__ act, int adt, OBS* __restrict__ obs,
+// LDS hand-off inside ONE wave: the wave's own ds_writes are ordered before its later ds_reads by the LDS
+// queue, so no workgroup barrier (and none of the vmcnt(0) drain a __syncthreads() drags in) is needed --
+// only a compiler-level fence so that the accesses are not reordered.
+__device__ __forceinline__ void wave_lds_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename W, bool SAFE, typename OBS, int LC>
+__global__ void __launch_bounds__(256, ACX_STEP_WAVES) k_env_step(EnvDev<W> e, const void* __restrict__ act, int adt, OBS* __restrict__ obs,
                                                   float* __restrict__ rew, float clip_lo, float clip_hi, uint8_t* __restrict__ done,
                                                   uint8_t* __restrict__ trunc, OBS* __restrict__ final_obs, int autoreset, int vec) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int RB = 2 * e.L * (int)sizeof(OBS);
+    const int L = LC > 0 ? LC : e.L;
+    const int RB = 2 * L * (int)sizeof(OBS);
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
     const int rows = (int)(e.n - row0 < 64 ? (e.n - row0 < 0 ? 0 : e.n - row0) : 64);
-    uint8_t* tile = lds + wave * 64 * RB;
+    uint8_t* tile = lds + wave * 64 * RB;  // private to this wave
     OBS* my = (OBS*)(tile + lane * RB);
     EnvLane<W> v;
     Pres<W> fin;
@@ -289,16 +319,16 @@ __global__ void __launch_bounds__(256) k_env_step(EnvDev<W> e, const void* __res
         if (rew) rew[i] = r;
         if (done) done[i] = (uint8_t)d;
         if (trunc) trunc[i] = (uint8_t)t;
-        if (obs) write_obs_row<W>(my, v.s, e.L);
+        if (obs) write_obs_row<W, LC>(my, v.s, L);
     }
     if (obs) {
-        __syncthreads();
+        wave_lds_handoff();
         if (rows > 0) wave_copy((uint8_t*)obs + row0 * RB, tile, rows * RB, lane, vec != 0);
     }
     if (final_obs) {  // terminal observation of envs that were just reset, current observation otherwise
-        __syncthreads();
-        if (lane < rows) write_obs_row<W>(my, was_reset ? fin : v.s, e.L);
-        __syncthreads();
+        wave_lds_handoff();
+        if (lane < rows) write_obs_row<W, LC>(my, was_reset ? fin : v.s, L);
+        wave_lds_handoff();
         if (rows > 0) wave_copy((uint8_t*)final_obs + row0 * RB, tile, rows * RB, lane, vec != 0);
     }
 }
@@ -335,9 +365,9 @@ __global__ void __launch_bounds__(256) k_env_observe(EnvDev<W> e, OBS* __restric
     if (lane < rows) {
         EnvLane<W> v;
         env_load<W>(e, row0 + lane, v);
-        write_obs_row<W>((OBS*)(tile + lane * RB), v.s, e.L);
+        write_obs_row<W, 0>((OBS*)(tile + lane * RB), v.s, e.L);
     }
-    __syncthreads();
+    wave_lds_handoff();
     if (rows > 0) wave_copy((uint8_t*)obs + row0 * RB, tile, rows * RB, lane, vec != 0);
 }
 
@@ -357,10 +387,11 @@ __global__ void k_env_load(EnvDev<W> e, const int8_t* __restrict__ rows, const i
         if (to_initial) ok = ok && v.s.n0 > 0 && v.s.n1 > 0;  // ACEnvConfig validates; reset(options=) does not
         rowerr[k] = ok ? 0 : (uint8_t)ACX_ERR_UNPACKABLE;
         if (!ok) return;
+        v.red = (uint32_t)(v.s.n0 > 0 && v.s.n1 > 0 && is_cyc_reduced<W, true>(v.s.w0, v.s.n0) && is_cyc_reduced<W, true>(v.s.w1, v.s.n1));
         if (to_initial) {
             e.iw0[i] = v.s.w0;
             e.iw1[i] = v.s.w1;
-            e.imeta[i] = (uint64_t)v.s.n0 | ((uint64_t)v.s.n1 << 8);
+            e.imeta[i] = (uint64_t)v.s.n0 | ((uint64_t)v.s.n1 << 8) | ((uint64_t)v.red << 24);
         }
     } else {
         v.s.w0 = e.iw0[i];
@@ -368,6 +399,7 @@ __global__ void k_env_load(EnvDev<W> e, const int8_t* __restrict__ rows, const i
         const uint64_t mm = e.imeta[i];
         v.s.n0 = (int)(mm & 0xff);
         v.s.n1 = (int)((mm >> 8) & 0xff);
+        v.red = (uint32_t)((mm >> 24) & 1);
         rowerr[k] = 0;
     }
     v.cnt = 0;
@@ -655,12 +687,17 @@ int acx_env_step(acx_env* e, const void* d_actions, int action_dtype, void* d_ob
     const bool f32 = obs_dtype == ACX_F32;
     const size_t lds = (d_obs || d_final_obs) ? (size_t)4 * 64 * 2 * e->L * (f32 ? 4 : 1) : 0;
     const int vec = aligned16(d_obs) && aligned16(d_final_obs);
-    if (f32)
-        ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_step<W, SAFE, float>), dim3(grid), dim3(256), lds, st, dev, d_actions, action_dtype, (float*)d_obs,
-                                                d_reward, clip_lo, clip_hi, d_done, d_trunc, (float*)d_final_obs, autoreset, vec));
-    else
-        ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_step<W, SAFE, int8_t>), dim3(grid), dim3(256), lds, st, dev, d_actions, action_dtype, (int8_t*)d_obs,
-                                                d_reward, clip_lo, clip_hi, d_done, d_trunc, (int8_t*)d_final_obs, autoreset, vec));
+#define ACX_STEP(OBS, LC)                                                                                                                    \
+    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_step<W, SAFE, OBS, LC>), dim3(grid), dim3(256), lds, st, dev, d_actions, action_dtype, (OBS*)d_obs, \
+                                           d_reward, clip_lo, clip_hi, d_done, d_trunc, (OBS*)d_final_obs, autoreset, vec))
+    if (e->L == 25) {  // BASELINE max_relator_length: fully unrolled observation writer
+        if (f32) ACX_STEP(float, 25);
+        else ACX_STEP(int8_t, 25);
+    } else {
+        if (f32) ACX_STEP(float, 0);
+        else ACX_STEP(int8_t, 0);
+    }
+#undef ACX_STEP
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }

@@ -202,6 +202,90 @@ template <typename W, bool SAFE = true> ACX_HD int apply_move(Pres<W>& s, int a,
     return ACX_ERR_NONE;
 }
 
+// true when the word is freely AND cyclically reduced (the normal form every ACMove(cyclical=True) leaves)
+template <typename W, bool SAFE = true> ACX_HD bool is_cyc_reduced(W w, int n) {
+    return !has_inverse_pair<W, SAFE>(w, n) && (n < 2 || get<W, SAFE>(w, 0) != (get<W, SAFE>(w, n - 1) ^ 3));
+}
+
+// ACMove(cyclical=True) when BOTH relators are already freely and cyclically reduced and non-empty -- the
+// steady state of ACEnv (every state ACEnv.step produces is in this form).  Equivalent to apply_move(..., true):
+//   * the untouched relator is a fixed point of simplify_relator;
+//   * a concatenation of reduced words is freely reduced once the junction is cancelled, so only its
+//     cyclic reduction remains;
+//   * a conjugation g r g^-1 of a cyclically reduced r either cancels at exactly one end (a rotation of r by
+//     one letter, still reduced) or at none (then the cyclic reduction strips g and g^-1 again, or the result
+//     does not fit: unchanged either way); cancelling at both ends would contradict cyclic reducedness.
+template <typename W, bool SAFE = true> ACX_HD int apply_move_reduced(Pres<W>& s, int a, int L) {
+    const int m = a + 1;
+    const bool i1 = (m & 1) != 0;
+    const int i = i1 ? 1 : 0;
+    W wi = i1 ? s.w1 : s.w0;
+    const W wj = i1 ? s.w0 : s.w1;
+    int ni = i1 ? s.n1 : s.n0;
+    const int nj = i1 ? s.n0 : s.n1;
+    if (a < 4) {
+        concat_words<W, SAFE>(wi, ni, wj, nj, (((m - i) >> 1) & 1) != 0, L, wi, ni);
+        if (ni == 0) return ACX_ERR_ASSERT;
+        cyclic_reduce<W, SAFE>(wi, ni);
+    } else {
+        const int jp = ((m - i) >> 1) & 1;
+        const int sp = ((m - i - 2 * jp) >> 2) & 1;
+        const int gc = sp ? 1 - jp : 2 + jp;
+        const bool sc = get<W, SAFE>(wi, 0) == (gc ^ 3);
+        const bool ec = get<W, SAFE>(wi, ni - 1) == gc;
+        const W left = (wi >> 2) | shl<W, SAFE>((W)(gc ^ 3), ni - 1);   // r[1:] + [g^-1]
+        const W right = ((wi << 2) | (W)gc) & mask<W, SAFE>(ni);        // [g] + r[:-1]
+        wi = sc == ec ? wi : (sc ? left : right);
+    }
+    s.w0 = i1 ? wj : wi;
+    s.w1 = i1 ? wi : wj;
+    s.n0 = i1 ? nj : ni;
+    s.n1 = i1 ? ni : nj;
+    return ACX_ERR_NONE;
+}
+
+// 4 int8 letters (one per byte, little endian) from 8 code bits; bytes at positions >= valid read 0.
+// One v_perm_b32 does the code -> letter lookup: selector bytes 0..3 pick a byte of 0x0201FFFE
+// (= letters -2,-1,+1,+2), selector 0x0c yields 0x00 (padding).
+ACX_HD uint32_t letters4(uint32_t c8, int valid) {
+    uint32_t x = c8 & 0xffu;
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    const int v = valid < 0 ? 0 : (valid > 4 ? 4 : valid);
+    const uint32_t sel = x | (uint32_t)(0x0c0c0c0cull << (8 * v));
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(0u, 0x0201FFFEu, sel);
+#else
+    uint32_t out = 0;
+    for (int b = 0; b < 4; b++) {
+        const uint32_t q = (sel >> (8 * b)) & 0xffu;
+        const uint32_t byte = q >= 12 ? (q == 12 ? 0x00u : 0xffu) : ((0x0201FFFEu >> (8 * (q & 3))) & 0xffu);
+        out |= byte << (8 * b);
+    }
+    return out;
+#endif
+}
+
+// dword j (letters 4j .. 4j+3) of the zero-padded int8 image of a relator
+template <typename W> ACX_HD uint32_t relator_dword(W w, int n, int j) {
+    return 8 * j >= wtraits<W>::kBits ? 0u : letters4((uint32_t)(w >> (8 * j)), n - 4 * j);
+}
+
+// dword j (bytes 4j .. 4j+3) of the 2L-byte observation row: r0 zero-padded to L, then r1 zero-padded to L.
+// Bytes past the row read 0.  With a compile-time L every branch folds.
+template <typename W> ACX_HD uint32_t row_dword(W w0, int n0, W w1, int n1, int L, int j) {
+    const int b = 4 * j;
+    if (b + 4 <= L) return relator_dword<W>(w0, n0, j);
+    if (b >= L) {
+        const int off = b - L, q = off >> 2, sh = off & 3;
+        const uint32_t lo = relator_dword<W>(w1, n1, q);
+        if (sh == 0) return lo;
+        const uint32_t hi = relator_dword<W>(w1, n1, q + 1);
+        return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * sh));
+    }
+    return relator_dword<W>(w0, n0, j) | (relator_dword<W>(w1, n1, 0) << (8 * (L - b)));  // the row's middle: r0 ends, r1 starts
+}
+
 // ---- int8 row <-> packed ------------------------------------------------------------------------
 // Pack one relator from L int8 letters.  Returns false if the row is not a right-padded word over
 // {+-1, +-2} (interior zero or foreign letter).

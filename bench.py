@@ -139,6 +139,58 @@ def cpu_search_baseline(budget=10**6):
     return res
 
 
+def extra_env_numbers(dev, pool):
+    """Context for the headline: the same env kernel where HBM, not launch latency, is the limit (4 Mi envs), and the
+    fused T-step rollout kernel (state resident in registers, reward/done per step) on the config-2 batch."""
+    import torch
+
+    from ac_solver import _acx
+    from ac_solver.envs.vec_env import ACVecEnv
+
+    out = {}
+    n_big, k_big = 1 << 22, 20
+    env = ACVecEnv(pool[np.arange(n_big) % len(pool)], horizon_length=HORIZON, record_actions=False, final_info=False)
+    tape = torch.randint(0, 12, (k_big, n_big), dtype=torch.uint8, device=dev)
+    obs = torch.empty((2, n_big, 2 * L), dtype=torch.int8, device=dev)
+    rew = torch.empty((2, n_big), dtype=torch.float32, device=dev)
+    done = torch.empty((2, n_big), dtype=torch.bool, device=dev)
+    trunc = torch.empty((2, n_big), dtype=torch.bool, device=dev)
+
+    def step(k):
+        _acx.check(_acx.lib.acx_env_step(env._h.ptr, tape[k].data_ptr(), _acx.U8, obs[k & 1].data_ptr(), _acx.I8, rew[k & 1].data_ptr(), 0.0, 0.0,
+                                         done[k & 1].data_ptr(), trunc[k & 1].data_ptr(), None, 1, env._stream()))
+
+    for k in range(4):
+        step(k)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(4, k_big):
+        step(k)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (k_big - 4)
+    out["throughput_regime"] = {"envs": n_big, "us_per_step_launch": us, "env_steps_per_s": n_big / us * 1e6,
+                                "achieved_GBps_algorithmic": ALGO_BYTES_PER_STEP * n_big / us / 1e3,
+                                "frac_of_hbm_peak": ALGO_BYTES_PER_STEP * n_big / us / 1e3 / HBM_PEAK_GBS}
+    del env, obs, tape
+    n, T = N_ENVS, 1000
+    env = ACVecEnv(pool[np.arange(n) % len(pool)], horizon_length=HORIZON, record_actions=False, final_info=False)
+    tape = torch.randint(0, 12, (T, n), dtype=torch.uint8, device=dev)
+    rw = torch.empty((T, n), dtype=torch.float32, device=dev)
+    dn = torch.empty((T, n), dtype=torch.bool, device=dev)
+    tr = torch.empty((T, n), dtype=torch.bool, device=dev)
+    env.rollout(tape, rw, dn, tr)
+    torch.cuda.synchronize()
+    e0.record()
+    env.rollout(tape, rw, dn, tr)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    out["fused_rollout"] = {"envs": n, "steps": T, "env_steps_per_s": n * T / ms * 1e3, "us_per_step": ms * 1e3 / T,
+                            "outputs": "f32 reward + done + truncated per step; state stays in registers (7 B/step algorithmic)"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +202,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true", help="skip the BFS / greedy frontier numbers")
     ap.add_argument("--search-budget", type=int, default=2 * 10**7)
+    ap.add_argument("--no-extras", action="store_true", help="skip the 4 Mi-env and fused-rollout context numbers")
     args = ap.parse_args()
 
     import torch
@@ -229,6 +282,12 @@ def main():
     # sanity: the timed steps really ran (count_steps advanced, rewards written)
     assert int(env.get_counts().max()) > 0 and bool(torch.isfinite(rew).all()) and bool((rew != 0).all())
 
+    extras = None
+    if rank == 0 and not args.no_extras:
+        try:
+            extras = extra_env_numbers(dev, pool)
+        except Exception as e:
+            extras = {"error": f"{type(e).__name__}: {e}"}
     search = None
     if not args.no_search:
         try:
@@ -260,6 +319,12 @@ def main():
                          "traffic": None, "kernel": "k_env_step<u64,int8>", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * N,
                          "avg_launch_us": launch_s * 1e6},
         }
+        traffic_file = os.path.join(ROOT, "profiles", "env_step_traffic.json")
+        if os.path.exists(traffic_file) and N == N_ENVS:  # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
+            with open(traffic_file) as f:
+                out["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
+        if extras is not None:
+            out["env_context"] = extras
         if search is not None:
             out["search"] = search
         if not args.no_cpu_baseline and world == 1:

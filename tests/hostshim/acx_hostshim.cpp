@@ -47,7 +47,41 @@ static void move_packed_rows(const int8_t* in, const uint8_t* act, int64_t n, in
     }
 }
 
+// steady-state fast path: rows whose relators are both non-empty and cyclically reduced; others are skipped (err 251)
+template <typename W> static void move_reduced_rows(const int8_t* in, const uint8_t* act, int64_t n, int L, int8_t* out, int32_t* len, uint8_t* err) {
+    for (int64_t r = 0; r < n; r++) {
+        const int8_t* row = in + r * 2 * L;
+        int8_t* o = out + r * 2 * L;
+        memcpy(o, row, 2 * L);
+        Pres<W> s;
+        bool ok = pack_relator<W>(row, L, s.w0, s.n0);
+        ok = pack_relator<W>(row + L, L, s.w1, s.n1) && ok;
+        ok = ok && s.n0 > 0 && s.n1 > 0 && is_cyc_reduced<W>(s.w0, s.n0) && is_cyc_reduced<W>(s.w1, s.n1) && act[r] < 12;
+        int e = 251;
+        if (ok) {
+            e = apply_move_reduced<W>(s, act[r], L);
+            if (e == ACX_ERR_NONE) {
+                for (int j = 0; 4 * j < L; j++) {  // dword-wise unpack (v_perm path on the device)
+                    uint32_t a = relator_dword<W>(s.w0, s.n0, j), b = relator_dword<W>(s.w1, s.n1, j);
+                    for (int k = 4 * j; k < 4 * j + 4 && k < L; k++) {
+                        o[k] = (int8_t)(a >> (8 * (k - 4 * j)));
+                        o[L + k] = (int8_t)(b >> (8 * (k - 4 * j)));
+                    }
+                }
+            }
+        }
+        len[2 * r] = s.n0;
+        len[2 * r + 1] = s.n1;
+        err[r] = (uint8_t)e;
+    }
+}
+
 extern "C" {
+
+void shim_move_reduced(const int8_t* in, const uint8_t* act, int64_t n, int L, int wide, int8_t* out, int32_t* len, uint8_t* err) {
+    if (wide) move_reduced_rows<u128>(in, act, n, L, out, len, err);
+    else move_reduced_rows<uint64_t>(in, act, n, L, out, len, err);
+}
 
 void shim_move_packed(const int8_t* in, const uint8_t* act, int64_t n, int L, int cyclical, int wide, int8_t* out, int32_t* len, uint8_t* err) {
     if (wide) move_packed_rows<u128>(in, act, n, L, cyclical, out, len, err);

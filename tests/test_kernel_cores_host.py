@@ -165,3 +165,36 @@ def test_packed_comparator_is_signed_tuple_order(shim):
                 want = (tuple(a.tolist()) > tuple(b.tolist())) - (tuple(a.tolist()) < tuple(b.tolist()))
                 got = shim.shim_compare(_p(a, C.c_int8), _p(b, C.c_int8), L, int(L > 32))
                 assert got == want, (a, b)
+
+
+@pytest.mark.parametrize("L", [2, 3, 7, 25, 31, 32, 36, 64])
+def test_reduced_fast_path_matches_oracle(shim, L):
+    """apply_move_reduced (the env kernel's steady-state path) == ACMove(cyclical=True) on cyclically reduced states"""
+    rng = np.random.default_rng(900 + L)
+    n = 6000
+    st = np.zeros((n, 2 * L), np.int8)
+    mv = rng.integers(0, 12, size=n).astype(np.uint8)
+    for r in range(n):
+        for h in (0, 1):
+            hi = L if r % 4 else min(L, 4)
+            w = list(rng.choice([1, -1, 2, -2], size=int(rng.integers(1, hi + 1))))
+            st[r, h * L:h * L + len(w)] = w
+        if r % 13 == 0:  # r1 = r0^+-1: concatenation cancels completely -> AssertionError
+            w = st[r, :L][st[r, :L] != 0]
+            st[r, L:] = 0
+            st[r, L:L + len(w)] = -w[::-1] if r % 2 else w
+    # normalise with the oracle so that the inputs are in the steady-state form, then step twice
+    cur, lens0, err0 = O.move_batch(st, np.full(n, 4, np.uint8), L, cyclical=True)
+    keep = err0 == 0
+    cur, mv = cur[keep], mv[keep]
+    for _ in range(2):
+        out = np.empty_like(cur); lens = np.empty((len(cur), 2), np.int32); err = np.empty(len(cur), np.uint8)
+        shim.shim_move_reduced(_p(cur, C.c_int8), _p(mv, C.c_uint8), C.c_int64(len(cur)), L, int(L > 32), _p(out, C.c_int8), _p(lens, C.c_int32), _p(err, C.c_uint8))
+        want, wl, we = O.move_batch(cur, mv, L, cyclical=True)
+        empty = (cur[:, :L] == 0).all(1) | (cur[:, L:] == 0).all(1)
+        assert np.array_equal(err == 251, empty)  # only states with an emptied relator are outside the fast path
+        assert (~empty).mean() > 0.5
+        m = err != 251
+        assert np.array_equal(err[m], we[m]) and np.array_equal(out[m], want[m]) and np.array_equal(lens[m], wl[m])
+        cur = np.ascontiguousarray(want)
+        mv = np.roll(mv, 1)
