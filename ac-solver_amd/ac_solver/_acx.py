@@ -88,6 +88,8 @@ SIGNATURES = {
     "acx_env_get_actions": (C.c_int, [_vp, C.c_int64, C.c_int, _i32p, C.c_int64, _i64p]),
     "acx_env_get_errors": (C.c_int, [_vp, _u8p, C.c_int]),
     "acx_env_max_reward": (C.c_int64, [_vp]),
+    "acx_search_many": (C.c_int, [C.c_int, _i8p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, _i32p, _i32p, _i32p, C.c_int64, _i64p,
+                               C.POINTER(SearchStats), _i32p]),
     "acx_shard_key_words": (C.c_int, [C.c_int]),
     "acx_shard_create": (_vp, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "acx_shard_destroy": (None, [_vp]),

@@ -27,3 +27,34 @@ def run_search(kind, presentation, max_nodes_to_explore, cyclical, want_stats=Fa
     path = [(int(a), int(l)) for a, l in zip(pa[: n.value], pl[: n.value])] if n.value else None
     stats = dict(nodes=st.nodes, expanded=st.expanded, children=st.children, levels=st.levels, min_len=st.min_len, seconds=st.seconds)
     return bool(solved.value), path, stats
+
+
+def run_search_many(kind, presentations, max_nodes_to_explore, cyclical, n_threads=16, path_cap=4096):
+    """Independent searches on one GPU, overlapped (acx_search_many).  `presentations` [n, 2L].
+    -> list of (solved, path, stats) in input order, each identical to what run_search returns."""
+    _acx.require_device()
+    rows = _acx.as_i8_rows(np.asarray(presentations))
+    n, width = rows.shape
+    L = width // 2
+    solved = np.zeros(n, np.int32)
+    pa = np.empty((n, path_cap), np.int32)
+    pl = np.empty((n, path_cap), np.int32)
+    pn = np.zeros(n, np.int64)
+    rcs = np.zeros(n, np.int32)
+    stats = (_acx.SearchStats * n)()
+    rc = _acx.lib.acx_search_many(kind, _acx.ptr(rows, C.c_int8), n, L, int(max_nodes_to_explore), int(bool(cyclical)), int(n_threads),
+                                  _acx.ptr(solved, C.c_int32), _acx.ptr(pa, C.c_int32), _acx.ptr(pl, C.c_int32), path_cap, _acx.ptr(pn, C.c_int64),
+                                  stats, _acx.ptr(rcs, C.c_int32))
+    if rc == _acx.E_ROWERR and (rcs == _acx.E_ROWERR).any():
+        raise AssertionError(_acx.last_error())
+    _acx.check(rc, "acx_search_many")
+    out = []
+    for k in range(n):
+        if rcs[k] == _acx.E_CAPACITY:  # rare: a path longer than path_cap -> redo that search alone
+            out.append(run_search(kind, rows[k], max_nodes_to_explore, cyclical))
+            continue
+        st = stats[k]
+        path = [(int(a), int(l)) for a, l in zip(pa[k, : pn[k]], pl[k, : pn[k]])] if pn[k] else None
+        out.append((bool(solved[k]), path, dict(nodes=st.nodes, expanded=st.expanded, children=st.children, levels=st.levels, min_len=st.min_len,
+                                                seconds=st.seconds)))
+    return out

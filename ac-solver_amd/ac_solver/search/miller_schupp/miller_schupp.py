@@ -75,12 +75,32 @@ def trivialize_miller_schupp_through_search(min_n, max_n, min_w_len, max_w_len, 
     assert search_fn.__name__ in ["greedy_search", "bfs"], f"expect search_fn to be greedy or bfs; got {search_fn.__name__}"
     rels = {n: generate_miller_schupp_presentations(n, max_w_len) for n in range(min_n, max_n + 1)}
     solved_rels, unsolved_rels, solved_paths = [], [], []
+
+    from ac_solver.search import breadth_first, greedy
+    from ac_solver.search._common import run_search_many
+
+    ours = {breadth_first.bfs: _acx.SEARCH_BFS, greedy.greedy_search: _acx.SEARCH_GREEDY}.get(search_fn)
     for n in range(min_n, max_n + 1):
+        group = [(lenw, pres) for lenw in range(min_w_len, max_w_len + 1) for pres in rels[n].get(lenw, [])]
+        if ours is not None and group:
+            # the searches of one n share max_relator_length: run them overlapped on the GPU (acx_search_many);
+            # results come back in the reference's order
+            results = run_search_many(ours, np.array([p for _, p in group], dtype=np.int8), max_nodes_to_explore, False)
+            results = [(ok, path if (ok or ours == _acx.SEARCH_GREEDY) else None, st) for ok, path, st in results]
+        else:
+            results = None
+        k = 0
         for lenw in range(min_w_len, max_w_len + 1):
             print(f"Applying {search_fn.__name__} to presentations of n = {n}, lenw = {lenw}")
-            for pres in rels[n][lenw]:
-                solved, path = search_fn(presentation=pres, max_nodes_to_explore=max_nodes_to_explore, verbose=False,
-                                         cyclically_reduce_after_moves=False)
+            for pres in rels[n].get(lenw, []):
+                if results is not None:
+                    solved, path, st = results[k]
+                    if not solved and st["nodes"] >= max_nodes_to_explore:
+                        print(f"Exiting search as number of explored nodes = {st['nodes']} has exceeded the limit {max_nodes_to_explore}")
+                else:
+                    solved, path = search_fn(presentation=pres, max_nodes_to_explore=max_nodes_to_explore, verbose=False,
+                                             cyclically_reduce_after_moves=False)
+                k += 1
                 if solved:
                     solved_rels.append(pres)
                     solved_paths.append(path)

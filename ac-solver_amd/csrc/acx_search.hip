@@ -307,8 +307,14 @@ template <typename W> struct Searcher {
     uint64_t cap_nodes = 0, cap_cand = 0, n_slots = 0, n_bslots = 0;
     hipStream_t st = nullptr;
 
+    ~Searcher() {
+        if (st) (void)hipStreamDestroy(st);
+    }
+
     int init(int L, int cyclical, int64_t max_nodes, uint32_t batch_parents, bool greedy) {
         memset(&d, 0, sizeof(d));
+        // every search owns a stream, so that searches driven from different host threads overlap on the GPU
+        ACX_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         d.L = L;
         d.cyclical = cyclical;
         cap_nodes = (uint64_t)max_nodes + 64;
@@ -971,6 +977,37 @@ extern "C" int acx_search(int kind, const int8_t* h_presentation, int L, int64_t
     if (max_nodes < 0) max_nodes = 0;
     if (L <= 29) return run_search<uint64_t>(kind, h_presentation, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats);
     return run_search<u128>(kind, h_presentation, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats);
+}
+
+// ------------------------------------------------------------------ many independent searches ----
+#include <atomic>
+#include <thread>
+
+extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t n, int L, int64_t max_nodes, int cyclical, int n_threads,
+                               int32_t* solved, int32_t* path_action, int32_t* path_len, int64_t path_cap, int64_t* path_n,
+                               acx_search_stats* stats, int32_t* rc_out) {
+    if (!have_device()) return ACX_E_NODEVICE;
+    if (n < 0 || !h_presentations || !solved || !path_n || !rc_out || path_cap < 0) return fail(ACX_E_INVAL, "acx_search_many: bad argument");
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 64) n_threads = 64;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<int64_t> next(0);
+    auto work = [&]() {
+        (void)hipSetDevice(dev);
+        for (;;) {
+            const int64_t k = next.fetch_add(1);
+            if (k >= n) break;
+            rc_out[k] = acx_search(kind, h_presentations + k * 2 * L, L, max_nodes, cyclical, solved + k, path_action ? path_action + k * path_cap : nullptr,
+                                   path_len ? path_len + k * path_cap : nullptr, path_cap, path_n + k, stats ? stats + k : nullptr);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; t++) pool.emplace_back(work);
+    for (auto& t : pool) t.join();
+    for (int64_t k = 0; k < n; k++)
+        if (rc_out[k] != ACX_OK && rc_out[k] != ACX_E_CAPACITY) return fail(ACX_E_ROWERR, "acx_search_many: search %lld failed with code %d", (long long)k, rc_out[k]);
+    return ACX_OK;
 }
 
 // ------------------------------------------------------------------ sharded frontier: C ABI ----

@@ -117,6 +117,24 @@ def search_numbers(world, rank, dev, budget):
                            "n_gpus": world, "budget": budget, "input": "AK(3) at max_relator_len=25, cyclical=False", "scaling": "strong",
                            "exchange": "all-to-all of child records + all-gather of new-node tags per chunk (RCCL)" if world > 1 else "none"}}
     if world == 1:
+        try:  # BASELINE config 4 shape on one GPU: bfs over the 1190 Miller-Schupp presentations, searches overlapped
+            from ac_solver.search._common import run_search_many
+            from ac_solver.search.miller_schupp.miller_schupp import generate_miller_schupp_presentations
+
+            t0 = time.perf_counter()
+            n_solved = n_nodes = 0
+            for n in range(1, 8):
+                d = generate_miller_schupp_presentations(n, 7)
+                rows = np.array([q for w in range(1, 8) for q in d[w]], dtype=np.int8)
+                for ok, _, s1 in run_search_many(_acx.SEARCH_BFS, rows, 10**6, True, n_threads=16):
+                    n_solved += ok
+                    n_nodes += s1["nodes"]
+            dt1 = time.perf_counter() - t0
+            out["bfs_ms_sweep"] = {"searches": 1190, "budget": 10**6, "cyclical": True, "solved": int(n_solved), "published_solved": 278,
+                                   "nodes": int(n_nodes), "seconds": dt1, "nodes_per_s": n_nodes / dt1, "searches_per_s": 1190 / dt1,
+                                   "entry": "acx_search_many (16 host threads, one HIP stream per search)"}
+        except Exception as e:
+            out["bfs_ms_sweep"] = {"error": f"{type(e).__name__}: {e}"}
         for kind, name in ((_acx.SEARCH_BFS, "bfs"), (_acx.SEARCH_GREEDY, "greedy_search")):
             run_search(kind, p, 20000, False)
             t0 = time.perf_counter()

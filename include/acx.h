@@ -137,6 +137,15 @@ typedef struct {
 int acx_search(int kind, const int8_t *h_presentation, int L, int64_t max_nodes, int cyclical, int32_t *solved,
                int32_t *path_action, int32_t *path_len, int64_t path_cap, int64_t *path_n, acx_search_stats *stats);
 
+/* n independent searches of the same kind / budget (the batch driver trivialize_miller_schupp_through_search,
+ * miller_schupp.py:95-177, runs them one after another): `n_threads` host threads, each search on its own HIP
+ * stream, so the small kernels of different searches overlap on the GPU.  Row k of every output belongs to
+ * presentation k ([n, path_cap] for the paths); rc_out[k] is that search's return code (ACX_E_CAPACITY when its
+ * path needs more than path_cap entries: path_n[k] then holds the required size). */
+int acx_search_many(int kind, const int8_t *h_presentations, int64_t n, int L, int64_t max_nodes, int cyclical,
+                    int n_threads, int32_t *solved, int32_t *path_action, int32_t *path_len, int64_t path_cap,
+                    int64_t *path_n, acx_search_stats *stats, int32_t *rc_out);
+
 /* ---- sharded BFS frontier (one engine per GPU) ---------------------------------------------------
  * The multi-GPU form of bfs (breadth_first.py:15-97): states are partitioned by hash(key) mod world, the
  * host exchanges candidate records between ranks (RCCL all-to-all) and these calls do the per-rank work.

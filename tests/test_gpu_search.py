@@ -120,3 +120,39 @@ def test_sharded_bfs_hip_engine_matches_reference(search, golden_json, world):
             wok, wpath, wst = O.bfs(p, b, cyclically_reduce_after_moves=c, stats=True)
             assert (ok, path) == (wok, wpath), (world, b, c)
             assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (world, b, c, st, wst)
+
+
+def test_many_searches_overlapped_equal_single(search, golden_json):
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search, run_search_many
+
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    rows = np.array(pool[340:510], dtype=np.int8)  # the 170 presentations of n = 3 (L = 20)
+    for kind in (_acx.SEARCH_GREEDY, _acx.SEARCH_BFS):
+        many = run_search_many(kind, rows, 3000, False, n_threads=16)
+        for k in range(0, len(rows), 7):
+            ok, path, st = run_search(kind, rows[k], 3000, False)
+            assert (ok, path) == many[k][:2] and st["nodes"] == many[k][2]["nodes"]
+
+
+def test_miller_schupp_driver_matches_reference_test_ranges(search, golden_json):
+    """tests/search/miller_schupp/test_miller_schupp.py of the reference: n, w in {1, 2} (greedy 1e6, bfs 1e4) and {3, 4} (greedy 1e4)"""
+    from ac_solver.search.miller_schupp.miller_schupp import trivialize_miller_schupp_through_search
+
+    rows = golden_json("search.json")
+
+    def expected(algo, budget, tags):
+        sel = [r for r in rows if r["algo"] == algo and r["budget"] == budget and r["tag"] in tags and not r["cyclical"]]
+        solved = [r["presentation"] for r in sel if r["solved"]]
+        unsolved = [r["presentation"] for r in sel if not r["solved"]]
+        paths = [_as_tuples(r["path"]) for r in sel if r["solved"]]
+        return solved, unsolved, paths
+
+    small = [f"ms_n{n}_w{w}" for n in (1, 2) for w in (1, 2)]
+    big = [f"ms_n{n}_w{w}" for n in (3, 4) for w in (3, 4)]
+    for algo, fn, budget, tags, rng in (("greedy", search.greedy_search, 10**6, small, (1, 2, 1, 2)), ("bfs", search.bfs, 10**4, small, (1, 2, 1, 2)),
+                                        ("greedy", search.greedy_search, 10**4, big, (3, 4, 3, 4))):
+        s, u, p = trivialize_miller_schupp_through_search(min_n=rng[0], max_n=rng[1], min_w_len=rng[2], max_w_len=rng[3],
+                                                          max_nodes_to_explore=budget, search_fn=fn)
+        ws, wu, wp = expected(algo, budget, tags)
+        assert [list(x) for x in s] == ws and [list(x) for x in u] == wu and p == wp
