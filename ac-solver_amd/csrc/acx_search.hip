@@ -196,14 +196,66 @@ template <typename W> __global__ void __launch_bounds__(256) k_find_rank(SearchD
     if (d.cflag[t] && d.cpos[t] + 1 == r) *d.rank_tag = t;
 }
 
+// What the reference does with this batch, decided on the device so that the host needs ONE read-back per batch.
+struct Decision {
+    uint32_t p_end;       // last parent of the batch that the reference pops
+    uint32_t cutoff;      // candidates with tag < cutoff are committed
+    uint32_t committed;   // number of winners below cutoff
+    uint32_t total;       // winners in the whole batch
+    uint32_t budget_hit;  // len(tree_nodes) >= max_nodes after parent p_end
+    uint32_t solved;      // a child of total length 2 was generated at or before parent p_end
+    uint32_t solved_tag;
+    uint32_t last_child_len;  // total length of child (p_end, action 11): greedy.py:121
+    uint32_t err;
+    uint32_t min_len;
+};
+
+template <typename W>
+__global__ void k_decide(SearchDev<W> d, uint32_t m, uint32_t np, unsigned long long nodes, long long max_nodes, int greedy, Decision* __restrict__ out) {
+    const uint32_t total = d.cpos[m - 1] + d.cflag[m - 1];
+    uint32_t p_end = np - 1, budget_hit = 0;
+    const unsigned long long shorter = *d.shorter_tag, solved_tag = *d.solved_tag;
+    if (greedy && shorter != kNoTag) p_end = min(p_end, (uint32_t)(shorter / 12));  // the shorter new child is the heap's next minimum
+    if ((long long)nodes >= max_nodes) {  // only possible for the very first parent (budget <= 1)
+        p_end = 0;
+        budget_hit = 1;
+    } else if ((long long)(nodes + total) >= max_nodes) {
+        // first candidate whose inclusive winner count reaches `need` (cpos + cflag is non-decreasing in t)
+        const uint32_t need = (uint32_t)(max_nodes - (long long)nodes);
+        uint32_t lo = 0, hi = m - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (d.cpos[mid] + d.cflag[mid] >= need) hi = mid;
+            else lo = mid + 1;
+        }
+        const uint32_t pb = lo / 12;
+        if (pb <= p_end) {
+            p_end = pb;
+            budget_hit = 1;
+        }
+    }
+    const uint32_t is_solved = solved_tag != kNoTag && (uint32_t)(solved_tag / 12) <= p_end;
+    const uint32_t cutoff = is_solved ? (uint32_t)solved_tag : 12u * (p_end + 1);  // on success only stats need the commit
+    out->p_end = is_solved ? (uint32_t)(solved_tag / 12) : p_end;
+    out->cutoff = cutoff;
+    out->committed = cutoff >= m ? total : d.cpos[cutoff];
+    out->total = total;
+    out->budget_hit = budget_hit;
+    out->solved = is_solved;
+    out->solved_tag = (uint32_t)solved_tag;
+    out->last_child_len = d.clen[12u * p_end + 11];
+    out->err = *d.err;
+    out->min_len = *d.min_len;
+}
+
 // Winners below `cutoff` become nodes base + cpos[t].  BFS: their table slot (already claimed in the visited
 // table) is rewritten to the final id.  Greedy: the key is inserted into the visited table now (it is known
 // to be absent and the committed keys are pairwise distinct, so a plain CAS claim is enough).
 template <typename W>
-__global__ void __launch_bounds__(256) k_commit(SearchDev<W> d, const uint32_t* __restrict__ plist, uint32_t pbegin, uint32_t cutoff, uint32_t base,
-                                                int insert_now) {
+__global__ void __launch_bounds__(256) k_commit(SearchDev<W> d, const uint32_t* __restrict__ plist, uint32_t pbegin, const Decision* __restrict__ dec, uint32_t m,
+                                                uint32_t base, int insert_now) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= cutoff || !d.cflag[t]) return;
+    if (t >= m || t >= dec->cutoff || !d.cflag[t]) return;
     const uint32_t id = base + d.cpos[t];
     const uint32_t p = t / 12u;
     const uint32_t pid = plist ? plist[p] : pbegin + p;
@@ -306,9 +358,13 @@ template <typename W> struct Searcher {
     size_t tmp_bytes = 0;
     uint64_t cap_nodes = 0, cap_cand = 0, n_slots = 0, n_bslots = 0;
     hipStream_t st = nullptr;
+    Decision* d_dec = nullptr;   // device
+    uint8_t* h_pin = nullptr;    // pinned host staging: Decision followed by the total lengths of the new nodes
+    size_t h_pin_bytes = 0;
 
     ~Searcher() {
         if (st) (void)hipStreamDestroy(st);
+        if (h_pin) (void)hipHostFree(h_pin);
     }
 
     int init(int L, int cyclical, int64_t max_nodes, uint32_t batch_parents, bool greedy) {
@@ -363,6 +419,9 @@ template <typename W> struct Searcher {
         }
         if (arena_scal.alloc(256)) return ACX_E_NOMEM;
         uint8_t* sc = (uint8_t*)arena_scal.p;
+        d_dec = (Decision*)(sc + 64);
+        h_pin_bytes = sizeof(Decision) + 64 + cap_cand;
+        if (hipHostMalloc((void**)&h_pin, h_pin_bytes, hipHostMallocDefault) != hipSuccess) return fail(ACX_E_NOMEM, "hipHostMalloc(%zu) failed", h_pin_bytes);
         d.solved_tag = (unsigned long long*)(sc + 0);
         d.shorter_tag = (unsigned long long*)(sc + 8);
         d.rank_tag = (unsigned long long*)(sc + 16);
@@ -554,48 +613,44 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         if (debug) fprintf(stderr, "[acx_search] batch %llu: np=%u nodes=%llu bucket=(%d,%u) buckets=%zu\n", (unsigned long long)batches, np,
                            (unsigned long long)nodes, bucket_len, bucket_depth, buckets.size());
 
-        // ---- expand, dedup with min-tag resolution, number the winners ---------------------------------
+        // ---- expand, dedup with min-tag resolution, number the winners, decide -- all on the stream --------
         rc = S.reset_batch_scalars();
         if (rc) return rc;
         hipLaunchKernelGGL(k_expand<W>, grid, block, 0, st, d, plist, pbegin, np);
         if (greedy) {
+            // batch-local table sized for this batch (only its used prefix is cleared)
+            uint32_t bs = 1024;
+            while (bs < 2 * m) bs <<= 1;
             hipLaunchKernelGGL(k_lookup<W>, grid, block, 0, st, d, m);
-            ACX_HIP_TRY(hipMemsetAsync(d.bslots, 0xff, S.n_bslots * 4, st));
-            hipLaunchKernelGGL(k_insert<W>, grid, block, 0, st, d, d.bslots, d.bmask, m, 1);
+            ACX_HIP_TRY(hipMemsetAsync(d.bslots, 0xff, (size_t)bs * 4, st));
+            hipLaunchKernelGGL(k_insert<W>, grid, block, 0, st, d, d.bslots, bs - 1, m, 1);
             hipLaunchKernelGGL(k_mark<W>, grid, block, 0, st, d, d.bslots, m, bucket_len);
         } else {
             hipLaunchKernelGGL(k_insert<W>, grid, block, 0, st, d, d.slots, d.smask, m, 0);
             hipLaunchKernelGGL(k_mark<W>, grid, block, 0, st, d, d.slots, m, -1);
         }
-        ACX_HIP_TRY(hipGetLastError());
-        uint32_t total = 0;
-        rc = S.scan(m, total);
-        if (rc) return rc;
-        Scalars sc;
-        rc = S.read_scalars(sc);
-        if (rc) return rc;
-        if (sc.err) return err_to_rc(sc.err);
-        if (debug) fprintf(stderr, "[acx_search]   total=%u solved=%lld shorter=%lld\n", total, (long long)sc.solved_tag, (long long)sc.shorter_tag);
-
-        // ---- where does the reference stop inside this batch? ------------------------------------------
-        uint32_t p_end = np - 1;  // last parent of the batch that the reference pops
-        bool budget_hit = false;
-        if (greedy && sc.shorter_tag != kNoTag) p_end = std::min<uint32_t>(p_end, (uint32_t)(sc.shorter_tag / 12));
-        if ((int64_t)nodes >= max_nodes) {  // only possible for the very first parent (budget <= 1)
-            p_end = 0;
-            budget_hit = true;
-        } else if ((int64_t)(nodes + total) >= max_nodes) {
-            uint32_t pb = 0;
-            rc = S.budget_parent(m, (uint32_t)(max_nodes - (int64_t)nodes), pb);
-            if (rc) return rc;
-            if (pb <= p_end) {
-                p_end = pb;
-                budget_hit = true;
-            }
+        {
+            size_t tb = S.tmp_bytes;
+            if (rocprim::exclusive_scan(S.arena_tmp.p, tb, d.cflag, d.cpos, 0u, m, rocprim::plus<uint32_t>(), st) != hipSuccess)
+                return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan failed");
         }
-        if (sc.solved_tag != kNoTag && (uint32_t)(sc.solved_tag / 12) <= p_end) {
+        hipLaunchKernelGGL(k_decide<W>, dim3(1), dim3(1), 0, st, d, m, np, (unsigned long long)nodes, (long long)max_nodes, greedy ? 1 : 0, S.d_dec);
+        hipLaunchKernelGGL(k_commit<W>, grid, block, 0, st, d, plist, pbegin, S.d_dec, m, (uint32_t)nodes, greedy ? 1 : 0);
+        ACX_HIP_TRY(hipGetLastError());
+        // one read-back: the decision and (greedy) the total lengths of the nodes this batch may have created
+        Decision* dec = (Decision*)S.h_pin;
+        uint8_t* hl = S.h_pin + sizeof(Decision) + 64 - (sizeof(Decision) % 64);
+        ACX_HIP_TRY(hipMemcpyAsync(dec, S.d_dec, sizeof(Decision), hipMemcpyDeviceToHost, st));
+        if (greedy) ACX_HIP_TRY(hipMemcpyAsync(hl, d.tlen + nodes, std::min<uint64_t>(m, S.cap_nodes - nodes), hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipStreamSynchronize(st));
+        if (dec->err) return err_to_rc(dec->err);
+        if (debug) fprintf(stderr, "[acx_search]   total=%u p_end=%u committed=%u solved=%u budget_hit=%u\n", dec->total, dec->p_end, dec->committed, dec->solved, dec->budget_hit);
+        const uint32_t p_end = dec->p_end, committed = dec->committed;
+        min_len = std::min<uint32_t>(min_len, dec->min_len);
+
+        if (dec->solved) {
             // success: path of the parent + (action, 2); checked before dedup and before the budget test
-            const uint32_t ps = (uint32_t)(sc.solved_tag / 12), as = (uint32_t)(sc.solved_tag % 12);
+            const uint32_t ps = dec->solved_tag / 12, as = dec->solved_tag % 12;
             const uint32_t pid = plist ? hlist[ps] : pbegin + ps;
             uint32_t par, dep;
             rc = S.node_field(pid, par, dep);
@@ -610,33 +665,17 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
             *path_n = n + 1;
             *solved = 1;
             expanded += ps + 1;
-            // nodes inserted before the solving child (stats only)
-            uint32_t c = 0;
-            rc = S.winners_below((uint32_t)sc.solved_tag, m, total, c);
-            if (rc) return rc;
-            nodes += c;
+            nodes += committed;  // nodes inserted before the solving child (stats only)
             min_len = 2;
             done = true;
             break;
         }
-        const uint32_t cutoff = 12u * (p_end + 1);
-        uint32_t committed = 0;
-        rc = S.winners_below(cutoff, m, total, committed);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_commit<W>, dim3((cutoff + 255) / 256), block, 0, st, d, plist, pbegin, cutoff, (uint32_t)nodes, greedy ? 1 : 0);
-        ACX_HIP_TRY(hipGetLastError());
-        if (debug) { (void)hipStreamSynchronize(st); fprintf(stderr, "[acx_search]   committed %u (p_end %u)\n", committed, p_end); }
         expanded += p_end + 1;
 
         if (greedy) {
             // file the new nodes into their heap buckets and drop the popped parents
             last_parent = hlist[p_end];
-            uint8_t lc = 0;
-            ACX_HIP_TRY(hipMemcpyAsync(&lc, d.clen + (cutoff - 1), 1, hipMemcpyDeviceToHost, st));
-            hlen.resize(committed);
-            if (committed) ACX_HIP_TRY(hipMemcpyAsync(hlen.data(), d.tlen + nodes, committed, hipMemcpyDeviceToHost, st));
-            ACX_HIP_TRY(hipStreamSynchronize(st));
-            last_child_len = lc;
+            last_child_len = dec->last_child_len;
             auto it = buckets.begin();
             it->second.head += p_end + 1;
             const bool cut = p_end + 1 < np;
@@ -645,7 +684,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
                 have_sorted = false;
             }
             for (uint32_t k = 0; k < committed; k++) {
-                const std::pair<uint32_t, uint32_t> key(hlen[k], bucket_depth + 1);
+                const std::pair<uint32_t, uint32_t> key(hl[k], bucket_depth + 1);
                 if (have_sorted && key == sorted_key) have_sorted = false;  // cannot happen (depth differs); kept for safety
                 buckets[key].ids.push_back((uint32_t)nodes + k);
             }
@@ -654,7 +693,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
             bfs_head += p_end + 1;
         }
         nodes += committed;
-        if (budget_hit) break;  // breadth_first.py:91-95 / greedy.py:115-119
+        if (dec->budget_hit) break;  // breadth_first.py:91-95 / greedy.py:115-119
     }
 
     if (!*solved && greedy) {  // greedy.py:121: path of the last popped node + (11, length of its last child)
@@ -670,9 +709,6 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         }
         *path_n = n + 1;
     }
-    Scalars sc;
-    rc = S.read_scalars(sc);
-    if (rc) return rc;
     ACX_HIP_TRY(hipEventRecord(ev1, st));
     ACX_HIP_TRY(hipEventSynchronize(ev1));
     float ms = 0;
@@ -684,7 +720,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         stats->expanded = (int64_t)expanded;
         stats->children = (int64_t)expanded * 12;
         stats->levels = (int64_t)batches;
-        stats->min_len = (int32_t)std::min<uint32_t>(min_len, sc.min_len);
+        stats->min_len = (int32_t)min_len;
         stats->seconds = ms * 1e-3;
     }
     if (*path_n > path_cap) return fail(ACX_E_CAPACITY, "path has %lld entries, buffer holds %lld", (long long)*path_n, (long long)path_cap);

@@ -16,6 +16,18 @@ for p in (PKG, ROOT):
         sys.path.insert(0, p)
 
 
+def _ensure_native_built():
+    """The suite needs libacx.so (cross-compiled by hipcc, no GPU required) and the oracle; build them once if a
+    fresh checkout has not run __graft_entry__.build() yet."""
+    if not os.path.exists(os.path.join(PKG, "lib", "libacx.so")) or not os.path.exists(os.path.join(ROOT, "oracle", "libac_oracle.so")):
+        import __graft_entry__
+
+        __graft_entry__.build()
+
+
+_ensure_native_built()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -1,0 +1,97 @@
+"""CPU checks of the C-ABI boundary: libacx.so loads without a GPU, exports every function include/acx.h
+declares, the ctypes signature table covers them all, and -- on a machine without a GPU -- every compute
+entry point fails loudly instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "acx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(acx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ac_solver import _acx
+
+    names = declared_functions()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(_acx.lib, name), f"{name} is declared in include/acx.h but not exported by libacx.so"
+    missing = [n for n in names if n not in _acx.SIGNATURES]
+    assert not missing, f"ctypes signatures missing for {missing}"
+    assert _acx.lib.acx_version() == 100
+    assert isinstance(_acx.device_count(), int)
+
+
+def test_header_flags_match_binding():
+    from ac_solver import _acx
+
+    src = open(os.path.join(ROOT, "include", "acx.h")).read()
+    consts = dict(re.findall(r"#define\s+(ACX_[A-Z0-9_]+)\s+\(?(-?\d+)\)?", src))
+    assert int(consts["ACX_F_CYCLICAL"]) == _acx.F_CYCLICAL and int(consts["ACX_F_BYTES"]) == _acx.F_BYTES
+    assert int(consts["ACX_F_NO_SIMPLIFY"]) == _acx.F_NO_SIMPLIFY and int(consts["ACX_F_NO_MOVE"]) == _acx.F_NO_MOVE
+    assert int(consts["ACX_E_NODEVICE"]) == _acx.E_NODEVICE and int(consts["ACX_E_CAPACITY"]) == _acx.E_CAPACITY
+    assert (int(consts["ACX_U8"]), int(consts["ACX_I32"]), int(consts["ACX_I64"]), int(consts["ACX_I8"]), int(consts["ACX_F32"])) == (0, 1, 2, 3, 4)
+
+
+def test_no_cpu_fallback_without_gpu():
+    from ac_solver import _acx
+
+    if _acx.device_count() > 0:
+        pytest.skip("a GPU is visible: the failure path is exercised on CPU-only machines")
+    from ac_solver.envs.ac_env import ACEnv
+    from ac_solver.envs.ac_moves import ACMove
+    from ac_solver.search.breadth_first import bfs
+    from ac_solver.search.greedy import greedy_search
+
+    with pytest.raises(_acx.AcxError):
+        ACMove(0, np.array([1, 0, 2, 0]), 2, [1, 1])
+    with pytest.raises(_acx.AcxError):
+        ACEnv()
+    with pytest.raises(_acx.AcxError):
+        bfs([1, 0, 2, 0], 10)
+    with pytest.raises(_acx.AcxError):
+        greedy_search([1, 0, 2, 0], 10)
+    rows = np.zeros((1, 4), np.int8)
+    out = np.zeros_like(rows)
+    lens = np.zeros((1, 2), np.int32)
+    err = np.zeros(1, np.uint8)
+    rc = _acx.lib.acx_move_batch(_acx.ptr(rows, C.c_int8), None, 1, 2, _acx.F_BYTES | _acx.F_NO_MOVE, _acx.ptr(out, C.c_int8), _acx.ptr(lens, C.c_int32),
+                                 _acx.ptr(err, C.c_uint8), None)
+    assert rc == _acx.E_NODEVICE and "no CPU fallback" in _acx.last_error()
+    assert not _acx.lib.acx_env_create(4, 25, 1000, 0)
+
+
+def test_host_side_helpers_without_gpu():
+    """format checks / converters are host bookkeeping and work anywhere (reference: tests/test_ac_env.py, tests/envs)"""
+    from ac_solver.envs.ac_env import ACEnvConfig
+    from ac_solver.envs.utils import (change_max_relator_length_of_presentation, convert_relators_to_presentation, generate_trivial_states,
+                                      is_array_valid_presentation, is_presentation_trivial)
+    from tests.conftest import load_json
+
+    t = load_json("unit_tables.json")
+    for r in t["is_array_valid_presentation"]:
+        assert is_array_valid_presentation(np.array(r["array"])) == r["valid"], r
+        assert is_array_valid_presentation(list(r["array"])) == r["valid"], r
+    for r in t["is_presentation_trivial"]:
+        assert is_presentation_trivial(np.array(r["array"])) == r["trivial"], r
+    for L, want in t["generate_trivial_states"].items():
+        got = generate_trivial_states(int(L))
+        assert got.shape == (8, 2 * int(L)) and got.tolist() == want
+    for r in t["convert_relators_to_presentation"]:
+        got = convert_relators_to_presentation(r["r1"], r["r2"], r["L"])
+        assert got.tolist() == r["out"] and str(got.dtype) == r["dtype"]
+    for r in t["change_max_relator_length_of_presentation"]:
+        assert change_max_relator_length_of_presentation(list(r["presentation"]), r["new_L"]).tolist() == r["out"]
+    with pytest.raises(AssertionError):  # an ndarray trips the list assert, as in the reference
+        change_max_relator_length_of_presentation(np.array([1, 0, 2, 0]), 3)
+    with pytest.raises(ValueError):
+        ACEnvConfig(initial_state=[1, 0, 0, 0])
+    assert ACEnvConfig().max_relator_length == 2
