@@ -22,6 +22,7 @@ import ctypes as C
 import numpy as np
 
 INF = 1 << 62
+_FORCE_EXCHANGE = False  # tests: route through the communicator even when world == 1
 _ID_MASK = (1 << 40) - 1
 
 
@@ -241,7 +242,7 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             hi = int(torch.searchsorted(f_gpos, i64([c1]))[0]) if f_gpos.numel() else 0
             solved = i64([INF])
             recs = engine.expand(f_ids[lo:hi].contiguous(), f_gpos[lo:hi].contiguous(), solved)
-            if world > 1:
+            if world > 1 or _FORCE_EXCHANGE:
                 owners = owner_of(recs[:, :KW], world)
                 order = torch.argsort(owners, stable=True)
                 counts = torch.bincount(owners, minlength=world).tolist()
@@ -252,7 +253,7 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
                 raise RuntimeError(f"rank {rank}: {recv.shape[0]} records exceed the per-chunk capacity {engine.batch_cap}")
             win = engine.insert(recv)
             parts = comm.all_gather_var(win)
-            all_tags = torch.sort(torch.cat(parts))[0] if world > 1 else win
+            all_tags = torch.sort(torch.cat(parts))[0] if (world > 1 or _FORCE_EXCHANGE) else win
             solved_tag = int(comm.all_reduce(solved, "min")[0])
             total_new = int(all_tags.numel())
 

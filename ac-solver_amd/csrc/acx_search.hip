@@ -120,7 +120,9 @@ __global__ void __launch_bounds__(256) k_expand(SearchDev<W> d, const uint32_t* 
     // wave-level min before the atomic keeps contention low (all 64 lanes take part)
     uint32_t m = tl;
     for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0 && m != 0xFFFFFFFFu) atomicMin(d.min_len, m);
+    // one contended address: only waves that would actually lower the minimum issue the atomic (a plain, possibly
+    // stale read can only over-estimate the current minimum, so no update is lost)
+    if ((threadIdx.x & 63) == 0 && m < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, m);
 }
 
 template <typename W> __device__ __forceinline__ bool key_equals(const SearchDev<W>& d, uint32_t id, W k0, W k1) {
@@ -770,7 +772,7 @@ __global__ void __launch_bounds__(256) k_shard_expand(SearchDev<W> d, const int6
     r[recio<W>::KW] = tag;
     r[recio<W>::KW + 1] = pref_hi | id;
     if (s.n0 + s.n1 == 2) atomicMin(solved, (unsigned long long)tag);
-    atomicMin(d.min_len, (uint32_t)(s.n0 + s.n1));
+    if ((uint32_t)(s.n0 + s.n1) < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, (uint32_t)(s.n0 + s.n1));
 }
 
 template <typename W> __global__ void __launch_bounds__(256) k_shard_tags(const int64_t* __restrict__ rec, int64_t n, uint64_t* __restrict__ tags, uint32_t* __restrict__ idx) {

@@ -156,3 +156,54 @@ def test_miller_schupp_driver_matches_reference_test_ranges(search, golden_json)
                                                           max_nodes_to_explore=budget, search_fn=fn)
         ws, wu, wp = expected(algo, budget, tags)
         assert [list(x) for x in s] == ws and [list(x) for x in u] == wu and p == wp
+
+
+def test_sharded_bfs_over_rccl_process_group(search):
+    """The production communicator (torch.distributed, backend nccl == RCCL) with device tensors, world size 1:
+    exercises all_to_all_single with split sizes, padded all_gather and all_reduce on the HIP engine's buffers."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from ac_solver.search.sharded import TorchDistComm, bfs_sharded
+    from oracle import ac_oracle as O
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        comm = TorchDistComm(torch.device("cuda", 0))
+        ak2 = [1, 1, -2, -2, -2, 0, 0, 1, 2, 1, -2, -1, -2, 0]
+        for budget in (10, 5000, 10**6):
+            got = _bfs_through_comm(bfs_sharded, ak2, budget, comm)
+            assert got == O.bfs(ak2, budget)
+    finally:
+        dist.destroy_process_group()
+
+
+def _bfs_through_comm(bfs_sharded, p, budget, comm):
+    import ac_solver.search.sharded as sh
+
+    class Forced:
+        """world-size-1 communicator that still routes every call through torch.distributed"""
+        rank, world = 0, 1
+
+        def all_to_all_rows(self, send, counts):
+            return comm.all_to_all_rows(send, counts)
+
+        def all_gather_var(self, t):
+            return comm.all_gather_var(t)
+
+        def all_reduce(self, t, op):
+            return comm.all_reduce(t, op)
+
+    saved = sh.bfs_sharded.__globals__.get("_FORCE_EXCHANGE")
+    sh._FORCE_EXCHANGE = True
+    try:
+        return bfs_sharded(p, budget, comm=Forced())
+    finally:
+        sh._FORCE_EXCHANGE = saved
