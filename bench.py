@@ -88,7 +88,7 @@ def ak3_at_L():
     return p
 
 
-def search_numbers(world, rank, dev, budget):
+def search_numbers(world, rank, dev, budget, use_dist=False):
     """BFS nodes/s with the frontier sharded over `world` GPUs (one search, strong scaling) and, on one GPU, the
     fused single-GPU frontier (acx_search) for bfs and greedy_search.  AK(3) at L=25 does not trivialise, so the
     searches run to the node budget."""
@@ -100,23 +100,23 @@ def search_numbers(world, rank, dev, budget):
     from ac_solver.search.sharded import SingleComm, TorchDistComm, bfs_sharded
 
     p = ak3_at_L()
-    comm = TorchDistComm(dev) if world > 1 else SingleComm()
+    comm = TorchDistComm(dev) if use_dist else SingleComm()
     bfs_sharded(p, 20000, comm=comm)  # warm-up: allocator, kernels, communicator
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     ok, path, st = bfs_sharded(p, budget, comm=comm, batch_parents=1 << 20, want_stats=True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     out = {"bfs_sharded": {"nodes_per_s": st["nodes"] / float(dt[0]), "nodes": st["nodes"], "seconds": float(dt[0]), "levels": st["levels"],
                            "n_gpus": world, "budget": budget, "input": "AK(3) at max_relator_len=25, cyclical=False", "scaling": "strong",
                            "exchange": "all-to-all of child records + all-gather of new-node tags per chunk (RCCL)" if world > 1 else "none"}}
-    if world == 1:
+    if world == 1 and not use_dist:
         try:  # BASELINE config 4 shape on one GPU: bfs over the 1190 Miller-Schupp presentations, searches overlapped
             from ac_solver.search._common import run_search_many
             from ac_solver.search.miller_schupp.miller_schupp import generate_miller_schupp_presentations
@@ -227,14 +227,12 @@ def main():
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    use_dist = world > 1 or bool(os.environ.get("ACX_BENCH_FORCE_DIST"))  # the env var drives the N > 1 code path on one GPU (testing)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the AC hot path only exists as HIP kernels (no CPU fallback)")
     torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from ac_solver import _acx
     from ac_solver.envs.vec_env import ACVecEnv
@@ -274,8 +272,17 @@ def main():
             graph, mode = None, "eager"
     torch.cuda.synchronize()
 
+    # the process group is created only now: the RCCL watchdog thread must not touch the runtime while the
+    # graph above is being captured (envs are independent, so nothing before this point communicates)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        dist.barrier()
+        if graph is not None:
+            graph.replay()  # one untimed replay after the communicator came up
+            torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -287,13 +294,13 @@ def main():
             launch(W + k, k)
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream: K back-to-back env kernels
 
     tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall, dev_ms = float(tmax[0]), float(tmax[1])
 
@@ -309,7 +316,7 @@ def main():
     search = None
     if not args.no_search:
         try:
-            search = search_numbers(world, rank, dev, args.search_budget)
+            search = search_numbers(world, rank, dev, args.search_budget, use_dist)
         except Exception as e:  # the headline line must survive a failure of the secondary measurement
             search = {"error": f"{type(e).__name__}: {e}"}
 
@@ -345,12 +352,12 @@ def main():
             out["env_context"] = extras
         if search is not None:
             out["search"] = search
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not use_dist:
             out["cpu_baseline"] = cpu_baseline(states, 0)
             if not args.no_search:
                 out["cpu_baseline"].update(cpu_search_baseline())
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -208,3 +208,49 @@ def test_miller_schupp_generator(acx, golden_json):
         assert [len(got[k]) for k in range(1, 8)] == [2, 2, 2, 6, 18, 42, 98]  # 170 per n (reference test_miller_schupp.py:42-56)
         total += sum(len(v) for v in got.values())
     assert total == 1190
+
+
+@pytest.mark.parametrize("L", [65, 100, 128])
+def test_byte_kernel_wide_rows(acx, L):
+    """the byte-exact kernel covers max_relator_length up to 128 (the packed one stops at 64)"""
+    from oracle import ac_oracle as O
+
+    rng = np.random.default_rng(L)
+    st = _random_states(rng, 700, L)
+    mv = rng.integers(0, 12, size=len(st)).astype(np.uint8)
+    for c in (0, 1):
+        want = O.move_batch(st, mv, L, cyclical=bool(c))
+        got = acx.move_rows(st, mv, L, acx.F_BYTES | (acx.F_CYCLICAL if c else 0))
+        for g, w in zip(got[:3], want):
+            assert np.array_equal(g, w)
+
+
+def test_device_pointer_entry_with_torch_tensors(acx):
+    """acx_move_batch_device on torch-owned buffers: every action dtype, an unaligned base pointer (byte-wise tile path)
+    and a non-default stream"""
+    import torch
+
+    from oracle import ac_oracle as O
+
+    rng = np.random.default_rng(11)
+    L, n = 25, 3001
+    st = _random_states(rng, n, L)
+    mv = rng.integers(0, 12, size=n)
+    want = O.move_batch(st, mv.astype(np.uint8), L, cyclical=True)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for adt, code in ((torch.uint8, acx.U8), (torch.int32, acx.I32), (torch.int64, acx.I64), (torch.int8, acx.I8)):
+            for shift in (0, 1):
+                buf_in = torch.zeros(n * 2 * L + 16, dtype=torch.int8, device="cuda")
+                buf_out = torch.zeros(n * 2 * L + 16, dtype=torch.int8, device="cuda")
+                d_in = buf_in[shift:shift + n * 2 * L]
+                d_in.copy_(torch.as_tensor(st.reshape(-1)))
+                d_out = buf_out[shift:shift + n * 2 * L]
+                d_act = torch.as_tensor(mv).to(device="cuda", dtype=adt)
+                d_len = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+                d_err = torch.empty(n, dtype=torch.uint8, device="cuda")
+                acx.check(acx.lib.acx_move_batch_device(d_in.data_ptr(), d_act.data_ptr(), code, n, L, acx.F_CYCLICAL, d_out.data_ptr(), d_len.data_ptr(),
+                                                        d_err.data_ptr(), None, stream.cuda_stream))
+                stream.synchronize()
+                assert np.array_equal(d_out.cpu().numpy().reshape(n, 2 * L), want[0])
+                assert np.array_equal(d_len.cpu().numpy(), want[1]) and np.array_equal(d_err.cpu().numpy(), want[2])
