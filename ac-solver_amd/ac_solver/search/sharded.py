@@ -135,12 +135,13 @@ class HipShardEngine:
                             "acx_shard_expand")
         return rec
 
-    def insert(self, recv):
+    def insert(self, recv, max_tag=None):
         torch = _torch()
         n = recv.shape[0]
         win = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
         n_win = C.c_int64(0)
-        self._acx.check(self._acx.lib.acx_shard_insert(self.h, recv.data_ptr() if n else None, n, win.data_ptr(), C.byref(n_win), self._stream()),
+        bits = 0 if max_tag is None else max(int(max_tag).bit_length(), 1)
+        self._acx.check(self._acx.lib.acx_shard_insert(self.h, recv.data_ptr() if n else None, n, bits, win.data_ptr(), C.byref(n_win), self._stream()),
                         "acx_shard_insert")
         return win[: n_win.value]
 
@@ -251,7 +252,7 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
                 recv = recs
             if recv.shape[0] > engine.batch_cap:
                 raise RuntimeError(f"rank {rank}: {recv.shape[0]} records exceed the per-chunk capacity {engine.batch_cap}")
-            win = engine.insert(recv)
+            win = engine.insert(recv, 12 * c1)
             parts = comm.all_gather_var(win)
             all_tags = torch.sort(torch.cat(parts))[0] if (world > 1 or _FORCE_EXCHANGE) else win
             solved_tag = int(comm.all_reduce(solved, "min")[0])

@@ -807,7 +807,7 @@ __global__ void __launch_bounds__(256) k_shard_win_tags(SearchDev<W> d, const in
 
 template <typename W>
 __global__ void __launch_bounds__(256) k_shard_commit(SearchDev<W> d, const int64_t* __restrict__ ctag, const int64_t* __restrict__ cpref, int64_t n,
-                                                      int64_t cutoff, uint32_t base, int64_t* __restrict__ node_pref, uint32_t* __restrict__ count) {
+                                                      int64_t cutoff, uint32_t base, int64_t* __restrict__ node_pref) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n || !d.cflag[j] || ctag[j] >= cutoff) return;
     const uint32_t id = base + d.cpos[j];
@@ -817,7 +817,17 @@ __global__ void __launch_bounds__(256) k_shard_commit(SearchDev<W> d, const int6
     d.tlen[id] = d.clen[j];
     node_pref[id] = cpref[j];
     d.slots[d.cslot[j]] = id;
-    atomicAdd(count, 1u);
+}
+
+// number of winners with tag < cutoff: candidates are in tag order, so it is cpos at the first tag >= cutoff
+template <typename W> __global__ void k_shard_count(SearchDev<W> d, const int64_t* __restrict__ ctag, int64_t n, int64_t cutoff, uint32_t* __restrict__ count) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (ctag[mid] < cutoff) lo = mid + 1;
+        else hi = mid;
+    }
+    *count = lo >= n ? d.cpos[n - 1] + d.cflag[n - 1] : d.cpos[lo];
 }
 
 template <typename W> struct ShardEngine {
@@ -942,7 +952,7 @@ template <typename W> static int shard_expand(ShardEngine<W>& E, const int64_t* 
     return ACX_OK;
 }
 
-template <typename W> static int shard_insert(ShardEngine<W>& E, const int64_t* rec, int64_t n, int64_t* win_tags, int64_t* n_win, hipStream_t st) {
+template <typename W> static int shard_insert(ShardEngine<W>& E, const int64_t* rec, int64_t n, int tag_bits, int64_t* win_tags, int64_t* n_win, hipStream_t st) {
     *n_win = 0;
     E.pending = n;
     if (n <= 0) return ACX_OK;
@@ -950,7 +960,8 @@ template <typename W> static int shard_insert(ShardEngine<W>& E, const int64_t* 
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     hipLaunchKernelGGL(k_shard_tags<W>, grid, block, 0, st, rec, n, E.tags_in, E.idx_in);
     size_t tb = E.sort_tmp;
-    if (rocprim::radix_sort_pairs(E.tmp_buf.p, tb, E.tags_in, E.tags_sorted, E.idx_in, E.idx_sorted, (size_t)n, 0, 64, st) != hipSuccess)
+    const unsigned end_bit = (unsigned)(tag_bits < 1 ? 64 : (tag_bits > 64 ? 64 : tag_bits));  // tags < 2^tag_bits: fewer radix passes
+    if (rocprim::radix_sort_pairs(E.tmp_buf.p, tb, E.tags_in, E.tags_sorted, E.idx_in, E.idx_sorted, (size_t)n, 0, end_bit, st) != hipSuccess)
         return fail(ACX_E_NODEVICE, "rocprim::radix_sort_pairs failed");
     hipLaunchKernelGGL(k_shard_gather<W>, grid, block, 0, st, E.d, rec, E.tags_sorted, E.idx_sorted, n, E.ctag, E.cpref);
     hipLaunchKernelGGL(k_insert<W>, grid, block, 0, st, E.d, E.d.slots, E.d.smask, (uint32_t)n, 0);
@@ -974,9 +985,9 @@ template <typename W> static int shard_commit(ShardEngine<W>& E, int64_t cutoff,
     const int64_t n = E.pending;
     E.pending = 0;
     if (n <= 0) return ACX_OK;
-    ACX_HIP_TRY(hipMemsetAsync(E.commit_count, 0, 4, st));
+    hipLaunchKernelGGL(k_shard_count<W>, dim3(1), dim3(1), 0, st, E.d, E.ctag, n, cutoff, E.commit_count);
     hipLaunchKernelGGL(k_shard_commit<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, E.d, E.ctag, E.cpref, n, cutoff, (uint32_t)E.nodes,
-                       E.node_pref, E.commit_count);
+                       E.node_pref);
     ACX_HIP_TRY(hipGetLastError());
     uint32_t c = 0;
     ACX_HIP_TRY(hipMemcpyAsync(&c, E.commit_count, 4, hipMemcpyDeviceToHost, st));
@@ -1100,9 +1111,9 @@ int acx_shard_expand(acx_shard* h, const int64_t* d_ids, const int64_t* d_gpos, 
     ACX_SHARD_DISPATCH(&h->any, return shard_expand<W>(E, d_ids, d_gpos, np, d_records, d_solved, (hipStream_t)stream));
 }
 
-int acx_shard_insert(acx_shard* h, const int64_t* d_records, int64_t n, int64_t* d_win_tags, int64_t* n_win, void* stream) {
+int acx_shard_insert(acx_shard* h, const int64_t* d_records, int64_t n, int tag_bits, int64_t* d_win_tags, int64_t* n_win, void* stream) {
     if (!h || n < 0 || !n_win || (n > 0 && (!d_records || !d_win_tags))) return fail(ACX_E_INVAL, "acx_shard_insert: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_insert<W>(E, d_records, n, d_win_tags, n_win, (hipStream_t)stream));
+    ACX_SHARD_DISPATCH(&h->any, return shard_insert<W>(E, d_records, n, tag_bits, d_win_tags, n_win, (hipStream_t)stream));
 }
 
 int acx_shard_commit(acx_shard* h, int64_t cutoff_tag, int64_t* first_id, int64_t* n_committed, void* stream) {

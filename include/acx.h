@@ -162,10 +162,11 @@ int acx_shard_root_record(acx_shard *h, const int8_t *h_presentation, int64_t *h
  * d_solved[0] is min-combined with the tags of children of total length 2 */
 int acx_shard_expand(acx_shard *h, const int64_t *d_ids, const int64_t *d_gpos, int64_t np, int64_t *d_records,
                      int64_t *d_solved, void *stream);
-/* exact dedup of n received records against the visited table and among themselves (minimum tag wins);
- * the winners' tags are written ascending to d_win_tags, their count to *n_win; they stay pending */
-int acx_shard_insert(acx_shard *h, const int64_t *d_records, int64_t n, int64_t *d_win_tags, int64_t *n_win,
-                     void *stream);
+/* exact dedup of n received records (any order) against the visited table and among themselves (minimum tag
+ * wins); the winners' tags are written ascending to d_win_tags, their count to *n_win; they stay pending.
+ * tag_bits: every tag is < 2^tag_bits (bounds the radix-sort passes; 0 = unknown) */
+int acx_shard_insert(acx_shard *h, const int64_t *d_records, int64_t n, int tag_bits, int64_t *d_win_tags,
+                     int64_t *n_win, void *stream);
 /* pending winners with tag < cutoff_tag become local nodes first_id, first_id + 1, ... in tag order */
 int acx_shard_commit(acx_shard *h, int64_t cutoff_tag, int64_t *first_id, int64_t *n_committed, void *stream);
 /* h_info3 = (action, total_length, parent_ref) of a local node; the root has action -1, parent_ref -1 */

@@ -78,7 +78,7 @@ class OracleShardEngine:
                 rows.append([k0, k1, tag, (self.rank << 40) | nid])
         return torch.tensor(rows, dtype=torch.int64).reshape(-1, 4)
 
-    def insert(self, recv):
+    def insert(self, recv, max_tag=None):
         recs = sorted(recv.tolist(), key=lambda r: r[2])
         seen, self.pending = set(), []
         for k0, k1, tag, pref in recs:
