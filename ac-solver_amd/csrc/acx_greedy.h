@@ -1,0 +1,745 @@
+// acx_greedy.h -- device-resident priority frontier for greedy_search (ac_solver/search/greedy.py:15-121).
+//
+// ONE persistent workgroup (1024 lanes, 16 waves) runs the whole best-first loop of one search on the
+// GPU: no host round trip per heap bucket.  The heap of the reference, keyed (total length, depth, state
+// tuple) (greedy.py:104-113), is held as BUCKETS keyed (total length, depth):
+//
+//   * a bucket is a contiguous region of node ids in an arena: [head, sorted_end) is sorted by the signed
+//     state tuple (the third heap field), [sorted_end, cnt) are later arrivals; a bucket that is selected
+//     with an unsorted tail is sorted in LDS (bitonic network on compare_pres); a bucket that does not fit
+//     the LDS is sorted as LDS-sized runs that are then merged by rank (binary searches in the other runs);
+//   * the minimum bucket is found from per-length live counts in LDS and a per-length depth bitmap in HBM;
+//   * a BATCH is a prefix of the minimum bucket (up to R*1024/12 parents, R children per lane), treated
+//     exactly as the batch-per-launch path treats it (acx_search.hip: k_expand / k_lookup / k_insert /
+//     k_mark / k_decide / k_commit): expand, success test before dedup, read-only probe of the visited table,
+//     in-batch dedup to the minimum tag in an LDS table, scan in tag order, budget / cut decision, commit;
+//   * a batch is cut after the first parent that inserts a NEW child shorter than the bucket (that child is
+//     the heap's next minimum); the speculative children of later parents are dropped.  The batch
+//     size adapts: it doubles while batches run uncut and returns to one pass after a cut.
+//
+// Several searches (acx_search_many) run as concurrent one-workgroup kernels on their own streams.
+// When a capacity of this scheme is exceeded (depth >= kDepthCap, arena exhausted) the kernel reports
+// GREEDY_FALLBACK and the host reruns the search on the batch-per-launch path.
+#pragma once
+#include "acx_word.h"
+
+namespace acx {
+
+#ifndef ACX_GREEDY_PROFILE
+#define ACX_GREEDY_PROFILE 0  // 1: thread 0 accumulates shader-clock cycles per phase (costs ~10 %); see GreedyOut::t_phase
+#endif
+
+constexpr int kGT = 1024;              // lanes of the persistent workgroup
+constexpr uint32_t kDepthCap = 16384;  // bucket table rows per total length
+
+enum : uint32_t { GREEDY_RUNNING = 0, GREEDY_SOLVED = 1, GREEDY_BUDGET = 2, GREEDY_EXHAUSTED = 3, GREEDY_FALLBACK = 4, GREEDY_MOVE_ERROR = 5 };
+
+struct BucketRec {
+    uint32_t off;         // first arena entry of the region
+    uint32_t cap;         // region size (0: never allocated)
+    uint32_t head;        // [head, cnt) are queued
+    uint32_t sorted_end;  // [head, sorted_end) is in signed state order
+    uint32_t cnt;
+    uint32_t pad[3];
+};
+
+template <typename W> struct GreedyDev {
+    SearchDev<W> d;
+    BucketRec* bk;      // [nlen * kDepthCap], zero-initialised
+    uint32_t* bitmap;   // [nlen * kDepthCap / 32]: bit set <=> bucket (len, depth) is non-empty
+    uint32_t* arena;    // bucket regions
+    W* gk0;             // scratch for sorting buckets larger than the LDS: keys and ids in run order
+    W* gk1;
+    uint32_t* gid;
+    uint16_t* fp;       // [n_slots + 4] 16-bit fingerprint of the key behind every occupied slot of the visited table
+    W root_k0, root_k1; // the initial presentation (node 0)
+    uint32_t arena_cap; // entries
+    uint32_t nlen;      // 2L + 1 total lengths
+    long long max_nodes;
+    uint32_t root_len;
+};
+
+struct GreedyOut {
+    uint32_t status, nodes, min_len, err;
+    uint32_t solved_parent, solved_action, last_parent, last_child_len;
+    unsigned long long expanded, batches;
+    uint32_t fallback_reason, max_bucket;
+    unsigned long long sorts, big_sorts;
+    uint32_t hist_sort[16];  // sorts by log2(bucket size)
+    uint32_t hist_np[16];    // batches by log2(parents)
+    unsigned long long t_phase[8];  // shader-clock cycles per phase (thread 0): select, sort, expand, probe, scan+decide, commit, file, tail
+};
+
+template <typename W> struct greedy_cfg;
+template <> struct greedy_cfg<uint64_t> { static constexpr uint32_t kSortCap = 4096; };
+template <> struct greedy_cfg<u128> { static constexpr uint32_t kSortCap = 2048; };
+
+template <typename W> __device__ __forceinline__ bool key_less(W a0, W a1, W b0, W b1) {
+    Pres<W> a, b;
+    key_to_pres<W>(a0, a1, a);
+    key_to_pres<W>(b0, b1, b);
+    return compare_pres<W>(a, b) < 0;
+}
+
+// Bitonic sort of the n entries (sid, sk0, sk1)[0..n) in LDS by signed state order; whole workgroup.
+template <typename W> __device__ __forceinline__ void lds_sort(W* sk0, W* sk1, uint32_t* sid, uint32_t n, uint32_t tid) {
+    uint32_t P = 2;
+    while (P < n) P <<= 1;
+    for (uint32_t i = n + tid; i < P; i += kGT) sid[i] = 0xFFFFFFFFu;  // padding sorts last
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t q = tid; q < P / 2; q += kGT) {
+                const uint32_t i = ((q & ~(j - 1)) << 1) | (q & (j - 1));  // the q-th index with bit j clear
+                const uint32_t x = i | j;
+                const bool asc = (i & k) == 0;
+                const uint32_t ia = sid[i], ib = sid[x];
+                bool a_after_b;
+                if (ia == 0xFFFFFFFFu) a_after_b = ib != 0xFFFFFFFFu;
+                else if (ib == 0xFFFFFFFFu) a_after_b = false;
+                else a_after_b = key_less<W>(sk0[x], sk1[x], sk0[i], sk1[i]);
+                if (a_after_b == asc) {
+                    const W t0 = sk0[i], t1 = sk1[i];
+                    sk0[i] = sk0[x];
+                    sk1[i] = sk1[x];
+                    sk0[x] = t0;
+                    sk1[x] = t1;
+                    sid[i] = ib;
+                    sid[x] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Workgroup barrier that orders LDS traffic only: outstanding global stores / atomics stay in flight (the
+// s_waitcnt vmcnt(0) that __syncthreads() carries is what exposes their latency).  Global data written before
+// it is NOT guaranteed visible to the other waves afterwards.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// exclusive prefix of up to 64 wave counts by one wave; returns the grand total (valid in every lane)
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t& total) {
+    uint32_t x = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, o);
+        if ((int)lane >= o) x += y;
+    }
+    total = (uint32_t)__shfl((int)x, 63);
+    return x - v;
+}
+
+template <typename W>
+__global__ void __launch_bounds__(kGT) k_greedy_persistent(GreedyDev<W> g, GreedyOut* __restrict__ out) {
+    constexpr uint32_t SC = greedy_cfg<W>::kSortCap;
+    constexpr int R = (int)(SC / kGT);                     // children per lane in a full batch
+    constexpr uint32_t kPmax = (uint32_t)(R * kGT) / 12u;  // parents in a full batch
+    constexpr uint32_t kBT = 2 * SC;                       // in-batch dedup table (LDS)
+    constexpr uint32_t kNW = (uint32_t)R * (kGT / 64);     // wave-level winner counts per batch (<= 64)
+    __shared__ W sk0[SC];  // sort keys; double as the candidate keys of a batch (indexed by tag)
+    __shared__ W sk1[SC];
+    __shared__ uint32_t sid[SC];
+    __shared__ uint32_t s_btab[kBT];
+    __shared__ uint8_t s_clen[SC];
+    __shared__ W sp_k0[kPmax + 3];  // parents of the running batch
+    __shared__ W sp_k1[kPmax + 3];
+    __shared__ uint32_t sp_id[kPmax + 3];
+    __shared__ uint32_t s_lcnt[132], s_len_count[132], s_hint[132], s_pushbase[132];
+    __shared__ uint32_t s_job[132 * 3];
+    __shared__ uint32_t s_wcnt[64], s_woff[64];
+    __shared__ BucketRec s_rec;
+    __shared__ BucketRec s_frec[132];  // records of the buckets (length, s_fdepth): the depth the running batches file into
+    __shared__ uint32_t s_fdepth;
+    __shared__ uint32_t s_minlen, s_mindepth, s_solved, s_shorter, s_lo, s_err, s_seen_min, s_njobs, s_arena_top, s_committed, s_flag, s_total;
+    __shared__ uint32_t s_p_end, s_cutoff, s_budget_hit, s_is_solved, s_last_parent, s_solved_pid, s_cur_len, s_cur_depth, s_nodes, s_status,
+        s_reason, s_max_bucket, s_np_cap, s_last_child_len, s_solved_action, s_sorted_in_lds;
+    __shared__ unsigned long long s_expanded, s_batches, s_sorts, s_big_sorts;
+    __shared__ uint32_t s_hist[32];
+    __shared__ unsigned long long s_tph[8], s_tc;  // phase clock, kept by thread 0
+#if ACX_GREEDY_PROFILE
+#define ACX_TICK(k) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); s_tph[k] += now__ - s_tc; s_tc = now__; } } while (0)
+#else
+#define ACX_TICK(k) do { } while (0)
+#endif
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wv = tid >> 6;
+    const SearchDev<W>& d = g.d;
+    const uint32_t nlen = g.nlen;
+    const uint32_t gmask = d.smask & ~3u;  // probe sequences start on a 4-slot group
+
+    if (tid < 132) {
+        s_len_count[tid] = 0;
+        s_hint[tid] = kDepthCap;
+    }
+    if (tid < 32) s_hist[tid] = 0;
+    if (tid < 8) s_tph[tid] = 0;
+    if (tid == 0) s_tc = clock64();
+    __syncthreads();
+    if (tid == 0) {
+        // root: node 0, first entry of the visited table and of the heap (bucket (root_len, 0))
+        d.k0[0] = g.root_k0;
+        d.k1[0] = g.root_k1;
+        d.parent[0] = kEmpty;
+        d.act[0] = 0xff;
+        d.tlen[0] = (uint8_t)g.root_len;
+        d.depth[0] = 0;
+        const uint64_t h = hash_key<W>(g.root_k0, g.root_k1);
+        d.slots[(uint32_t)h & gmask] = 0;
+        g.fp[(uint32_t)h & gmask] = (uint16_t)(h >> 48);
+        BucketRec r = {0u, 16u, 0u, 1u, 1u, {0u, 0u, 0u}};
+        g.arena[0] = 0;
+        g.bk[(size_t)g.root_len * kDepthCap] = r;
+        g.bitmap[(size_t)g.root_len * (kDepthCap / 32)] = 1u;
+        s_len_count[g.root_len] = 1;
+        s_hint[g.root_len] = 0;
+        s_arena_top = 16;
+        s_nodes = 1;
+        s_status = GREEDY_RUNNING;
+        s_reason = 0;
+        s_err = 0;
+        s_seen_min = g.root_len;
+        s_expanded = 0;
+        s_batches = 0;
+        s_sorts = 0;
+        s_big_sorts = 0;
+        s_max_bucket = 1;
+        s_last_parent = 0;
+        s_solved_pid = 0;
+        s_last_child_len = 0;
+        s_solved_action = 0;
+        s_np_cap = kGT / 12;
+        s_flag = 0;  // 1: the current bucket record in s_rec is valid
+        s_sorted_in_lds = 0;
+        s_fdepth = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+
+    for (;;) {
+        // ================================================================= select the minimum bucket ====
+        if (!s_flag) {
+            if (tid == 0) {
+                s_minlen = 0xFFFFFFFFu;
+                s_mindepth = 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            if (tid < nlen && s_len_count[tid] > 0) atomicMin(&s_minlen, tid);
+            __syncthreads();
+            const uint32_t l = s_minlen;
+            if (l == 0xFFFFFFFFu) {  // heap exhausted (greedy.py:71)
+                if (tid == 0) s_status = GREEDY_EXHAUSTED;
+                __syncthreads();
+                break;
+            }
+            {
+                const uint32_t w = s_hint[l] / 32 + tid;
+                if (w < kDepthCap / 32) {
+                    const uint32_t bits = g.bitmap[(size_t)l * (kDepthCap / 32) + w];
+                    if (bits) atomicMin(&s_mindepth, w * 32 + (uint32_t)__builtin_ctz(bits));
+                }
+            }
+            __syncthreads();
+            {
+                // the selected bucket's record comes from the LDS cache when it is a bucket of the cached depth; the cache
+                // then moves to depth + 1 (the children's depth): old records out, new records in, one trip together
+                const uint32_t D = s_mindepth, fd = s_fdepth;
+                BucketRec cur, nxt;
+                if (tid == 0) cur = D == fd ? s_frec[l] : g.bk[(size_t)l * kDepthCap + D];
+                const bool move = fd != D + 1 && D + 1 < kDepthCap && tid < nlen;
+                if (move) {
+                    nxt = g.bk[(size_t)tid * kDepthCap + D + 1];
+                    if (fd != 0xFFFFFFFFu) g.bk[(size_t)tid * kDepthCap + fd] = s_frec[tid];
+                }
+                __syncthreads();  // (tid 0 read s_frec[l] before it is replaced)
+                if (move) s_frec[tid] = nxt;
+                if (tid == 0) {
+                    s_cur_len = l;
+                    s_cur_depth = D;
+                    s_hint[l] = D;
+                    s_rec = cur;
+                    s_flag = 1;
+                    s_sorted_in_lds = 0;
+                    if (D + 1 < kDepthCap) s_fdepth = D + 1;
+                }
+            }
+            __syncthreads();
+            ACX_TICK(0);
+            // ---- order the bucket by the signed state tuple if it has an unsorted tail ----------------------
+            const uint32_t n = s_rec.cnt - s_rec.head;
+            if (s_rec.sorted_end < s_rec.cnt && n > 1) {
+                const uint32_t base = s_rec.off + s_rec.head;
+                if (tid == 0) {
+                    s_hist[min(15, 31 - __builtin_clz(n))]++;
+                    s_sorts++;
+                    if (n > SC) s_big_sorts++;
+                }
+                if (n <= 256) {
+                    // all-pairs rank sort: 1024 / n2 lanes share the comparisons of one element (n2 = n rounded up to a power of two)
+                    uint32_t myid = 0;
+                    W m0 = 0, m1 = 0;
+                    if (tid < n) {
+                        myid = g.arena[base + tid];
+                        m0 = d.k0[myid];
+                        m1 = d.k1[myid];
+                        sk0[tid] = m0;
+                        sk1[tid] = m1;
+                        s_btab[tid] = 0;  // rank
+                    }
+                    __syncthreads();
+                    uint32_t n2 = 2;
+                    while (n2 < n) n2 <<= 1;
+                    const uint32_t parts = kGT / n2, i = tid / parts, part = tid - i * parts;
+                    if (i < n) {
+                        const W e0 = sk0[i], e1 = sk1[i];
+                        uint32_t c = 0;
+                        for (uint32_t j = part; j < n; j += parts) c += key_less<W>(sk0[j], sk1[j], e0, e1) ? 1u : 0u;
+                        if (c) atomicAdd(&s_btab[i], c);
+                    }
+                    __syncthreads();
+                    uint32_t rank = 0;
+                    if (tid < n) rank = s_btab[tid];
+                    __syncthreads();
+                    if (tid < n) {
+                        sid[rank] = myid;
+                        sk0[rank] = m0;
+                        sk1[rank] = m1;
+                        g.arena[base + rank] = myid;
+                    }
+                    if (tid == 0) s_sorted_in_lds = 1;
+                } else if (n <= SC) {
+                    for (uint32_t i = tid; i < n; i += kGT) {
+                        const uint32_t id = g.arena[base + i];
+                        sid[i] = id;
+                        sk0[i] = d.k0[id];
+                        sk1[i] = d.k1[id];
+                    }
+                    lds_sort<W>(sk0, sk1, sid, n, tid);
+                    for (uint32_t i = tid; i < n; i += kGT) g.arena[base + i] = sid[i];
+                    if (tid == 0) s_sorted_in_lds = 1;
+                } else {
+                    // runs of SC entries sorted in LDS and parked in the scratch arrays ...
+                    for (uint32_t r0 = 0; r0 < n; r0 += SC) {
+                        const uint32_t rn = n - r0 < SC ? n - r0 : SC;
+                        for (uint32_t i = tid; i < rn; i += kGT) {
+                            const uint32_t id = g.arena[base + r0 + i];
+                            sid[i] = id;
+                            sk0[i] = d.k0[id];
+                            sk1[i] = d.k1[id];
+                        }
+                        lds_sort<W>(sk0, sk1, sid, rn, tid);
+                        for (uint32_t i = tid; i < rn; i += kGT) {
+                            g.gid[r0 + i] = sid[i];
+                            g.gk0[r0 + i] = sk0[i];
+                            g.gk1[r0 + i] = sk1[i];
+                        }
+                        __syncthreads();
+                    }
+                    // ... then merged by rank: final position = own index in its run + the number of smaller
+                    // entries in every other run (the keys of a bucket are pairwise distinct)
+                    for (uint32_t i = tid; i < n; i += kGT) {
+                        const W m0 = g.gk0[i], m1 = g.gk1[i];
+                        const uint32_t myrun = i / SC;
+                        uint32_t pos = i - myrun * SC;
+                        for (uint32_t r0 = 0, q = 0; r0 < n; r0 += SC, q++) {
+                            if (q == myrun) continue;
+                            uint32_t lo = r0, hi = n - r0 < SC ? n : r0 + SC;
+                            while (lo < hi) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (key_less<W>(g.gk0[mid], g.gk1[mid], m0, m1)) lo = mid + 1;
+                                else hi = mid;
+                            }
+                            pos += lo - r0;
+                        }
+                        g.arena[base + pos] = g.gid[i];
+                    }
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                s_rec.sorted_end = s_rec.cnt;
+                if (n > s_max_bucket) s_max_bucket = n;
+            }
+            __syncthreads();
+            ACX_TICK(1);
+        }
+
+        // ================================================================= one batch =====================
+        const uint32_t cur_len = s_cur_len, cur_depth = s_cur_depth;
+        const uint32_t D1 = cur_depth + 1;
+        const uint32_t live = s_rec.cnt - s_rec.head;
+        const uint32_t np = live < s_np_cap ? live : s_np_cap;
+        const uint32_t m = 12u * np;
+        const uint32_t nodes = s_nodes;
+        uint32_t bt = 256;  // in-batch table size for this batch
+        while (bt < 2 * m) bt <<= 1;
+        // stage the parents (ids and keys) in LDS: straight from the sorted arrays when the bucket was just sorted there
+        {
+            uint32_t pi = 0;
+            W p0 = 0, p1 = 0;
+            if (tid < np) {
+                if (s_sorted_in_lds) {
+                    pi = sid[tid];
+                    p0 = sk0[tid];
+                    p1 = sk1[tid];
+                } else {
+                    pi = g.arena[s_rec.off + s_rec.head + tid];
+                    p0 = d.k0[pi];
+                    p1 = d.k1[pi];
+                }
+            }
+            __syncthreads();  // the sort arrays are free from here on
+            if (tid < np) {
+                sp_id[tid] = pi;
+                sp_k0[tid] = p0;
+                sp_k1[tid] = p1;
+            }
+        }
+        if (tid == 0) {
+            s_hist[16 + 31 - __builtin_clz(np)]++;
+            s_solved = 0xFFFFFFFFu;
+            s_shorter = 0xFFFFFFFFu;
+            s_lo = 0xFFFFFFFFu;
+            s_njobs = 0;
+            s_committed = 0;
+            s_sorted_in_lds = 0;
+        }
+        if (tid < 132) s_lcnt[tid] = 0;
+        for (uint32_t i = tid; i < bt; i += kGT) s_btab[i] = kEmpty;
+        __syncthreads();
+        // per-lane candidates: tag t = r * 1024 + tid  (parent t / 12, action t % 12); keys live in LDS (sk0/sk1[t])
+        uint32_t hv[R], hb[R], fl[R];  // fl: bit0 active, bit1 known, bit2 winner, bit3 commit, bits 16.. fingerprint
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t t = (uint32_t)r * kGT + tid;
+            fl[r] = 0;
+            hv[r] = hb[r] = 0;
+            if (t < m) {
+                const uint32_t p = t / 12u;
+                Pres<W> s;
+                key_to_pres<W>(sp_k0[p], sp_k1[p], s);
+                const int e = apply_move<W, true>(s, (int)(t - 12u * p), d.L, d.cyclical != 0);
+                if (e) atomicOr(&s_err, (uint32_t)e);
+                const W c0 = keyops<W>::make(s.w0, s.n0), c1 = keyops<W>::make(s.w1, s.n1);
+                const uint32_t tl = (uint32_t)(s.n0 + s.n1);
+                sk0[t] = c0;
+                sk1[t] = c1;
+                s_clen[t] = (uint8_t)tl;
+                const uint64_t h = hash_key<W>(c0, c1);
+                hv[r] = (uint32_t)h & gmask;
+                hb[r] = (uint32_t)h & (bt - 1);
+                fl[r] = 1u | ((uint32_t)(h >> 48) << 16);
+                if (tl == 2) atomicMin(&s_solved, t);  // greedy.py:91, before the membership test
+            }
+        }
+        __syncthreads();  // candidate keys visible, tables cleared
+        ACX_TICK(2);
+        // read-only probe of the visited table: 4 slots + their 16-bit fingerprints per round trip, the lane's R
+        // candidates in flight together; a full key is fetched only behind a matching fingerprint
+        {
+            uint32_t pend = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) pend |= (fl[r] & 1u) << r;
+            while (pend) {
+                uint4 sl[R];
+                uint2 fq[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if ((pend >> r) & 1u) {
+                        sl[r] = *(const uint4*)(d.slots + hv[r]);
+                        fq[r] = *(const uint2*)(g.fp + hv[r]);
+                    }
+                }
+                uint32_t cand[R];
+                W a0[R], a1[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    cand[r] = kEmpty;
+                    if (!((pend >> r) & 1u)) continue;
+                    const uint32_t myfp = fl[r] >> 16;
+                    const uint32_t s4[4] = {sl[r].x, sl[r].y, sl[r].z, sl[r].w};
+                    const uint32_t f4[4] = {fq[r].x & 0xffffu, fq[r].x >> 16, fq[r].y & 0xffffu, fq[r].y >> 16};
+                    // sub-slot to resume at (after a fingerprint that turned out to belong to another key)
+                    const uint32_t j0 = hb[r] >> 28;
+                    bool stop = false;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (stop || (uint32_t)j < j0) continue;
+                        if (s4[j] == kEmpty) {  // first empty slot of the probe sequence: not in the table
+                            hv[r] += (uint32_t)j;
+                            pend &= ~(1u << r);
+                            stop = true;
+                        } else if (f4[j] == myfp) {
+                            cand[r] = s4[j];
+                            hb[r] = (hb[r] & 0x0FFFFFFFu) | ((uint32_t)(j + 1) << 28);
+                            stop = true;
+                        }
+                    }
+                    if (!stop) {  // group exhausted
+                        hv[r] = (hv[r] + 4) & d.smask;
+                        hb[r] &= 0x0FFFFFFFu;
+                    }
+                    if (cand[r] != kEmpty) {
+                        a0[r] = d.k0[cand[r]];
+                        a1[r] = d.k1[cand[r]];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (cand[r] == kEmpty) continue;
+                    const uint32_t t = (uint32_t)r * kGT + tid;
+                    if (a0[r] == sk0[t] && a1[r] == sk1[t]) {
+                        fl[r] |= 2u;
+                        pend &= ~(1u << r);
+                    } else if ((hb[r] >> 28) >= 4) {  // false fingerprint match in the group's last slot
+                        hv[r] = (hv[r] + 4) & d.smask;
+                        hb[r] &= 0x0FFFFFFFu;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) hb[r] &= 0x0FFFFFFFu;
+        }
+        // in-batch dedup: the minimum tag among equal keys wins
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if ((fl[r] & 3u) != 1u) continue;
+            const uint32_t t = (uint32_t)r * kGT + tid;
+            const W c0 = sk0[t], c1 = sk1[t];
+            uint32_t h = hb[r];
+            for (;;) {
+                uint32_t v = s_btab[h];
+                if (v == kEmpty) {
+                    v = atomicCAS(&s_btab[h], kEmpty, t);
+                    if (v == kEmpty) break;
+                }
+                if (sk0[v] == c0 && sk1[v] == c1) {
+                    if (v > t) atomicMin(&s_btab[h], t);
+                    break;
+                }
+                h = (h + 1) & (bt - 1);
+            }
+            hb[r] = h;
+        }
+        __syncthreads();
+        ACX_TICK(3);
+        uint32_t cpos[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t t = (uint32_t)r * kGT + tid;
+            const bool win = (fl[r] & 3u) == 1u && s_btab[hb[r]] == t;
+            if (win) fl[r] |= 4u;
+            {  // one LDS atomic per wave (tags grow with the lane, so the lowest flagged lane holds the wave's minimum)
+                const unsigned long long sb = __ballot(win && (uint32_t)s_clen[t] < cur_len);
+                if (sb && lane == (uint32_t)__builtin_ctzll(sb)) atomicMin(&s_shorter, t);
+            }
+            const unsigned long long bal = __ballot(win);
+            cpos[r] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wcnt[r * (kGT / 64) + wv] = (uint32_t)__popcll(bal);
+        }
+        __syncthreads();
+        if (wv == 0) {
+            uint32_t tot;
+            const uint32_t ex = wave_excl_scan(lane < kNW ? s_wcnt[lane] : 0u, lane, tot);
+            s_woff[lane] = ex;
+            if (lane == 0) s_total = tot;
+        }
+        __syncthreads();
+        const uint32_t total = s_total;
+        const bool over = (long long)nodes < g.max_nodes && (long long)nodes + total >= g.max_nodes;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            cpos[r] += s_woff[r * (kGT / 64) + wv];
+            if (over && (fl[r] & 4u) && (long long)cpos[r] + 1 == g.max_nodes - (long long)nodes) s_lo = (uint32_t)r * kGT + tid;  // the child that reaches the budget
+        }
+        __syncthreads();
+        if (tid == 0) {  // k_decide of the batch-per-launch path
+            uint32_t p_end = np - 1, budget_hit = 0;
+            if (s_shorter != 0xFFFFFFFFu) p_end = min(p_end, s_shorter / 12u);
+            if ((long long)nodes >= g.max_nodes) {
+                p_end = 0;
+                budget_hit = 1;
+            } else if (over) {
+                const uint32_t pb = s_lo / 12u;
+                if (pb <= p_end) {
+                    p_end = pb;
+                    budget_hit = 1;
+                }
+            }
+            const uint32_t is_solved = s_solved != 0xFFFFFFFFu && s_solved / 12u <= p_end;
+            s_cutoff = is_solved ? s_solved : 12u * (p_end + 1);
+            s_p_end = is_solved ? s_solved / 12u : p_end;
+            s_budget_hit = budget_hit;
+            s_is_solved = is_solved;
+            s_last_parent = sp_id[s_p_end];
+            s_last_child_len = s_clen[12u * s_p_end + 11u];  // greedy.py:121
+            if (is_solved) {
+                s_solved_pid = sp_id[s_solved / 12u];
+                s_solved_action = s_solved % 12u;
+            }
+        }
+        __syncthreads();
+        ACX_TICK(4);
+        const uint32_t cutoff = s_cutoff, p_end = s_p_end;
+        const bool is_solved = s_is_solved != 0;
+        uint32_t pos[R];
+        uint32_t seen = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t t = (uint32_t)r * kGT + tid;
+            pos[r] = 0;
+            if ((fl[r] & 1u) && t < 12u * (p_end + 1)) seen = min(seen, (uint32_t)s_clen[t]);
+            const bool cm = (fl[r] & 4u) && t < cutoff;
+            uint32_t tl = 0;
+            if (cm) {  // k_commit
+                fl[r] |= 8u;
+                const uint32_t id = nodes + cpos[r], p = t / 12u;
+                tl = s_clen[t];
+                d.k0[id] = sk0[t];
+                d.k1[id] = sk1[t];
+                d.parent[id] = sp_id[p];
+                d.act[id] = (uint8_t)(t - 12u * p);
+                d.tlen[id] = (uint8_t)tl;
+                d.depth[id] = D1;
+            }
+            // LDS atomics are aggregated per wave (thousands of lanes on one address would serialise):
+            unsigned long long cb = __ballot(cm);
+            if (cb && lane == 63u - (uint32_t)__builtin_clzll(cb)) atomicMax(&s_committed, cpos[r] + 1);  // cpos grows with the lane
+            while (cb) {  // position inside the target bucket: one atomicAdd per (wave, total length)
+                const uint32_t lead = (uint32_t)__builtin_ctzll(cb);
+                const uint32_t v = (uint32_t)__shfl((int)tl, (int)lead);
+                const unsigned long long same = __ballot(cm && tl == v) & cb;
+                uint32_t base = 0;
+                if (lane == lead) base = atomicAdd(&s_lcnt[v], (uint32_t)__popcll(same));
+                base = (uint32_t)__shfl((int)base, (int)lead);
+                if (cm && tl == v) pos[r] = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                cb &= ~same;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) seen = min(seen, (uint32_t)__shfl_xor((int)seen, o));
+        if (lane == 0 && seen != 0xFFFFFFFFu) atomicMin(&s_seen_min, seen);
+        // visited-table insertion: the keys are pairwise distinct and absent; the CAS goes to the empty slot the probe
+        // ended on and is only looked at after the filing phase (its round trip overlaps with it)
+        uint32_t cas_old[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) cas_old[r] = (fl[r] & 8u) ? atomicCAS(&d.slots[hv[r]], kEmpty, nodes + cpos[r]) : kEmpty;
+        lds_barrier();
+        ACX_TICK(5);
+        // ---- file the new nodes into their buckets (total length, depth + 1): one owner lane per length ----
+        if (tid < nlen && s_lcnt[tid] > 0 && !is_solved) {
+            const uint32_t k = s_lcnt[tid];
+            if (D1 >= kDepthCap) {
+                s_status = GREEDY_FALLBACK;
+                s_reason = 1;
+            } else {
+                BucketRec r = s_frec[tid];
+                const uint32_t lv = r.cnt - r.head;
+                if (r.cap == 0 || r.cnt + k > r.cap) {
+                    uint32_t nc = 16;
+                    while (nc < 2 * (lv + k)) nc <<= 1;
+                    const uint32_t no = atomicAdd(&s_arena_top, nc);
+                    if ((unsigned long long)no + nc > g.arena_cap) {
+                        s_status = GREEDY_FALLBACK;
+                        s_reason = 2;
+                        nc = 0;
+                    } else if (lv > 0) {
+                        const uint32_t j = atomicAdd(&s_njobs, 1u);
+                        s_job[3 * j] = r.off + r.head;
+                        s_job[3 * j + 1] = no;
+                        s_job[3 * j + 2] = lv;
+                    }
+                    r.sorted_end = r.sorted_end > r.head ? r.sorted_end - r.head : 0;
+                    r.head = 0;
+                    r.off = no;
+                    r.cap = nc;
+                    r.cnt = lv;
+                }
+                s_pushbase[tid] = r.off + r.cnt;
+                r.cnt += k;
+                if (s_status == GREEDY_RUNNING) {
+                    s_frec[tid] = r;
+                    if (lv == 0) atomicOr(&g.bitmap[(size_t)tid * (kDepthCap / 32) + D1 / 32], 1u << (D1 & 31));
+                    s_len_count[tid] += k;
+                    if (D1 < s_hint[tid]) s_hint[tid] = D1;
+                }
+            }
+        }
+        lds_barrier();
+        ACX_TICK(6);
+        if (s_status != GREEDY_RUNNING) break;
+        {  // settle the table insertions (a failed CAS means another new key took the slot in this batch: rare)
+            uint32_t pend = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (!(fl[r] & 8u)) continue;
+                if (cas_old[r] == kEmpty) g.fp[hv[r]] = (uint16_t)(fl[r] >> 16);
+                else pend |= 1u << r;
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (!((pend >> r) & 1u)) continue;
+                do hv[r] = (hv[r] + 1) & d.smask;
+                while (atomicCAS(&d.slots[hv[r]], kEmpty, nodes + cpos[r]) != kEmpty);
+                g.fp[hv[r]] = (uint16_t)(fl[r] >> 16);
+            }
+        }
+        for (uint32_t j = 0; j < s_njobs; j++) {  // grown buckets move to their new region
+            const uint32_t src = s_job[3 * j], dst = s_job[3 * j + 1], cnt = s_job[3 * j + 2];
+            for (uint32_t i = tid; i < cnt; i += kGT) g.arena[dst + i] = g.arena[src + i];
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if ((fl[r] & 8u) && !is_solved) g.arena[s_pushbase[s_clen[(uint32_t)r * kGT + tid]] + pos[r]] = nodes + cpos[r];
+        if (tid == 0) {
+            const uint32_t popped = p_end + 1;
+            s_batches++;
+            s_expanded += popped;
+            s_nodes = nodes + s_committed;
+            if (s_err) {
+                s_status = GREEDY_MOVE_ERROR;
+            } else if (is_solved) {
+                s_status = GREEDY_SOLVED;
+            } else {
+                s_rec.head += popped;
+                s_len_count[cur_len] -= popped;
+                const bool empty = s_rec.head == s_rec.cnt;
+                const bool cut = s_shorter != 0xFFFFFFFFu;
+                if (empty) {
+                    s_rec.head = s_rec.cnt = s_rec.sorted_end = 0;
+                    atomicAnd(&g.bitmap[(size_t)cur_len * (kDepthCap / 32) + cur_depth / 32], ~(1u << (cur_depth & 31)));
+                }
+                if (s_budget_hit) s_status = GREEDY_BUDGET;
+                if (empty || cut || s_budget_hit) {
+                    if (cur_depth == s_fdepth) s_frec[cur_len] = s_rec;
+                    else g.bk[(size_t)cur_len * kDepthCap + cur_depth] = s_rec;
+                    s_flag = 0;
+                }
+                // speculation depth: back to one pass after a cut, doubled after an uncut batch
+                s_np_cap = cut ? (uint32_t)(kGT / 12) : min(2 * s_np_cap, kPmax);
+            }
+        }
+        __syncthreads();
+        ACX_TICK(7);
+        if (s_status != GREEDY_RUNNING) break;
+    }
+#undef ACX_TICK
+    if (tid == 0) {
+        out->status = s_status;
+        out->nodes = s_nodes;
+        out->min_len = s_status == GREEDY_SOLVED ? 2u : s_seen_min;
+        out->err = s_err;
+        out->solved_parent = s_solved_pid;
+        out->solved_action = s_solved_action;
+        out->last_parent = s_last_parent;
+        out->last_child_len = s_last_child_len;
+        out->expanded = s_expanded;
+        out->batches = s_batches;
+        out->fallback_reason = s_reason;
+        out->max_bucket = s_max_bucket;
+        out->sorts = s_sorts;
+        out->big_sorts = s_big_sorts;
+        for (int k = 0; k < 8; k++) out->t_phase[k] = s_tph[k];
+        for (int k = 0; k < 16; k++) out->hist_sort[k] = s_hist[k], out->hist_np[k] = s_hist[16 + k];
+    }
+}
+
+}  // namespace acx

@@ -332,6 +332,10 @@ __global__ void __launch_bounds__(256) k_rank_sort(SearchDev<W> d, const uint32_
     if (i < n) out[rank] = mine;
 }
 
+}  // namespace acx
+#include "acx_greedy.h"
+namespace acx {
+
 // ---------------------------------------------------------------------------------------- host ---
 struct DevBuf {
     void* p = nullptr;
@@ -522,6 +526,101 @@ static int err_to_rc(uint32_t e) {
                 (e & ACX_ERR_INDEX) && !(e & ACX_ERR_ASSERT) ? "IndexError" : "AssertionError");
 }
 
+// greedy_search on the device-resident priority frontier (acx_greedy.h).  *handled = false when the persistent
+// kernel ran out of one of its capacities: the caller then reruns the search on the batch-per-launch path.
+template <typename W>
+static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int cyclical, int32_t* solved, int32_t* path_action, int32_t* path_len,
+                             int64_t path_cap, int64_t* path_n, acx_search_stats* stats, bool* handled) {
+    *handled = false;
+    Searcher<W> S;
+    int rc = S.init(L, cyclical, max_nodes, 1024, false);
+    if (rc) return rc;
+    hipStream_t st = S.st;
+    GreedyDev<W> g;
+    g.d = S.d;
+    g.nlen = (uint32_t)(2 * L + 1);
+    g.max_nodes = (long long)max_nodes;
+    g.root_len = (uint32_t)(root.n0 + root.n1);
+    const uint64_t arena_entries = std::min<uint64_t>(8ull * (uint64_t)std::max<int64_t>(max_nodes, 1) + (1ull << 20), 1ull << 31);
+    g.arena_cap = (uint32_t)arena_entries;
+    DevBuf bk, bitmap, arena, outb, gk0, gk1, gid, fpb;
+    if (fpb.alloc((S.n_slots + 8) * 2)) return ACX_E_NOMEM;  // never read behind an empty slot, so no initialisation
+    g.fp = (uint16_t*)fpb.p;
+    g.root_k0 = keyops<W>::make(root.w0, root.n0);
+    g.root_k1 = keyops<W>::make(root.w1, root.n1);
+    const size_t sort_cap = (size_t)std::max<int64_t>(max_nodes, 1) + 64;  // a bucket never holds more than all nodes
+    if (gk0.alloc(sort_cap * sizeof(W)) || gk1.alloc(sort_cap * sizeof(W)) || gid.alloc(sort_cap * 4)) return ACX_E_NOMEM;
+    g.gk0 = (W*)gk0.p;
+    g.gk1 = (W*)gk1.p;
+    g.gid = (uint32_t*)gid.p;
+    const size_t bk_bytes = (size_t)g.nlen * kDepthCap * sizeof(BucketRec), bm_bytes = (size_t)g.nlen * (kDepthCap / 32) * 4;
+    if (bk.alloc(bk_bytes) || bitmap.alloc(bm_bytes) || arena.alloc(arena_entries * 4) || outb.alloc(sizeof(GreedyOut))) return ACX_E_NOMEM;
+    g.bk = (BucketRec*)bk.p;
+    g.bitmap = (uint32_t*)bitmap.p;
+    g.arena = (uint32_t*)arena.p;
+    ACX_HIP_TRY(hipMemsetAsync(bk.p, 0, bk_bytes, st));
+    ACX_HIP_TRY(hipMemsetAsync(bitmap.p, 0, bm_bytes, st));
+    ACX_HIP_TRY(hipMemsetAsync(outb.p, 0, sizeof(GreedyOut), st));
+    hipEvent_t ev0, ev1;
+    ACX_HIP_TRY(hipEventCreate(&ev0));
+    ACX_HIP_TRY(hipEventCreate(&ev1));
+    ACX_HIP_TRY(hipEventRecord(ev0, st));
+    hipLaunchKernelGGL(k_greedy_persistent<W>, dim3(1), dim3(kGT), 0, st, g, (GreedyOut*)outb.p);
+    ACX_HIP_TRY(hipGetLastError());
+    ACX_HIP_TRY(hipEventRecord(ev1, st));
+    GreedyOut o;
+    ACX_HIP_TRY(hipMemcpyAsync(&o, outb.p, sizeof(o), hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    ACX_HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    if (getenv("ACX_DEBUG"))
+        fprintf(stderr, "[acx_greedy] status=%u nodes=%u batches=%llu expanded=%llu sorts=%llu big_sorts=%llu max_bucket=%u reason=%u %.3f ms\n", o.status, o.nodes,
+                o.batches, o.expanded, o.sorts, o.big_sorts, o.max_bucket, o.fallback_reason, ms);
+    if (getenv("ACX_DEBUG")) {
+        fprintf(stderr, "[acx_greedy] sorts by log2(n):");
+        for (int k = 0; k < 16; k++) fprintf(stderr, " %u", o.hist_sort[k]);
+        fprintf(stderr, "\n[acx_greedy] batches by log2(parents):");
+        for (int k = 0; k < 10; k++) fprintf(stderr, " %u", o.hist_np[k]);
+        fprintf(stderr, "\n");
+        unsigned long long tot = 0;
+        for (int k = 0; k < 8; k++) tot += o.t_phase[k];
+        if (tot) fprintf(stderr, "[acx_greedy] cycles%%: select %.1f sort %.1f expand %.1f probe %.1f scan %.1f commit %.1f file %.1f tail %.1f (total %.3e cycles)\n",
+                100.0 * o.t_phase[0] / tot, 100.0 * o.t_phase[1] / tot, 100.0 * o.t_phase[2] / tot, 100.0 * o.t_phase[3] / tot, 100.0 * o.t_phase[4] / tot,
+                100.0 * o.t_phase[5] / tot, 100.0 * o.t_phase[6] / tot, 100.0 * o.t_phase[7] / tot, (double)tot);
+    }
+    if (o.status == GREEDY_FALLBACK) return ACX_OK;  // *handled stays false
+    *handled = true;
+    if (o.status == GREEDY_MOVE_ERROR) return err_to_rc(o.err);
+    if (o.status != GREEDY_SOLVED && o.status != GREEDY_BUDGET && o.status != GREEDY_EXHAUSTED)
+        return fail(ACX_E_NODEVICE, "greedy frontier kernel ended in state %u", o.status);
+    *solved = o.status == GREEDY_SOLVED ? 1 : 0;
+    // greedy.py:93 (success) / :121 (failure): path of a popped node + one more (action, length) entry
+    const uint32_t tail_node = *solved ? o.solved_parent : o.last_parent;
+    uint32_t par, dep;
+    rc = S.node_field(tail_node, par, dep);
+    if (rc) return rc;
+    int64_t n = 0;
+    rc = S.path_of(tail_node, dep, path_action, path_len, path_cap, &n);
+    if (rc) return rc;
+    if (n < path_cap) {
+        path_action[n] = *solved ? (int32_t)o.solved_action : 11;
+        path_len[n] = *solved ? 2 : (int32_t)o.last_child_len;
+    }
+    *path_n = n + 1;
+    if (stats) {
+        stats->nodes = (int64_t)o.nodes;
+        stats->expanded = (int64_t)o.expanded;
+        stats->children = (int64_t)o.expanded * 12;
+        stats->levels = (int64_t)o.batches;
+        stats->min_len = (int32_t)o.min_len;
+        stats->seconds = ms * 1e-3;
+    }
+    if (*path_n > path_cap) return fail(ACX_E_CAPACITY, "path has %lld entries, buffer holds %lld", (long long)*path_n, (long long)path_cap);
+    return ACX_OK;
+}
+
 template <typename W>
 static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, int cyclical, int32_t* solved, int32_t* path_action,
                       int32_t* path_len, int64_t path_cap, int64_t* path_n, acx_search_stats* stats) {
@@ -530,6 +629,15 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
     ok = pack_relator<W>(pres + L, L, root.w1, root.n1) && ok;
     if (!ok) return fail(ACX_E_ROWERR, "acx_search: the presentation is not a zero-padded word pair over {+-1,+-2}");
     const bool greedy = kind == ACX_SEARCH_GREEDY;
+    *solved = 0;
+    *path_n = 0;
+    if (greedy && !getenv("ACX_GREEDY_HOST")) {  // device-resident priority frontier; falls through when it hits a capacity
+        bool handled = false;
+        const int grc = run_greedy_device<W>(root, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, &handled);
+        if (grc != ACX_OK || handled) return grc;
+        *solved = 0;
+        *path_n = 0;
+    }
     const uint32_t bmax = (uint32_t)std::min<int64_t>(std::max<int64_t>(max_nodes, 1024), greedy ? (1 << 14) : (1 << 20));
     Searcher<W> S;
     int rc = S.init(L, cyclical, max_nodes, bmax, greedy);

@@ -77,10 +77,17 @@ __device__ __forceinline__ int load_action(const void* p, int dtype, int64_t k) 
 
 // Per-wave cooperative copy of `nbytes` contiguous bytes, 16 B per lane per trip when both sides
 // are 16-B aligned (`vec`), byte-wise for the ragged tail / unaligned callers.
-__device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, int nbytes, int lane, bool vec) {
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifndef ACX_OBS_NT
+#define ACX_OBS_NT 1  // 1: observation tiles leave with non-temporal (streaming) stores: nothing re-reads them on the GPU side of a step
+#endif
+template <bool NT = false> __device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, int nbytes, int lane, bool vec) {
     int o = lane * 16;
     if (vec) {
-        for (; o + 16 <= nbytes; o += 64 * 16) *(uint4*)(dst + o) = *(const uint4*)(src + o);
+        for (; o + 16 <= nbytes; o += 64 * 16) {
+            if (NT) __builtin_nontemporal_store(*(const u32x4*)(src + o), (u32x4*)(dst + o));
+            else *(uint4*)(dst + o) = *(const uint4*)(src + o);
+        }
         if (o < nbytes)
             for (int b = o; b < nbytes && b < o + 16; b++) dst[b] = src[b];
     } else {
@@ -207,20 +214,25 @@ template <typename W> struct EnvLane {
     uint32_t red;  // both relators non-empty, freely and cyclically reduced: the steady state of ACEnv
 };
 
-template <typename W> __device__ __forceinline__ void env_load(const EnvDev<W>& e, int64_t i, EnvLane<W>& v) {
-    v.s.w0 = e.w0[i];
-    v.s.w1 = e.w1[i];
-    const uint64_t m = e.meta[i];
+template <typename W> __device__ __forceinline__ void env_unpack_meta(uint64_t m, EnvLane<W>& v) {
     v.s.n0 = (int)(m & 0xff);
     v.s.n1 = (int)((m >> 8) & 0xff);
     v.err = (uint32_t)((m >> 16) & 0xff);
     v.red = (uint32_t)((m >> 24) & 1);
     v.cnt = (int32_t)(m >> 32);
 }
+template <typename W> __device__ __forceinline__ uint64_t env_pack_meta(const EnvLane<W>& v) {
+    return (uint64_t)v.s.n0 | ((uint64_t)v.s.n1 << 8) | ((uint64_t)v.err << 16) | ((uint64_t)v.red << 24) | ((uint64_t)(uint32_t)v.cnt << 32);
+}
+template <typename W> __device__ __forceinline__ void env_load(const EnvDev<W>& e, int64_t i, EnvLane<W>& v) {
+    v.s.w0 = e.w0[i];
+    v.s.w1 = e.w1[i];
+    env_unpack_meta<W>(e.meta[i], v);
+}
 template <typename W> __device__ __forceinline__ void env_store(const EnvDev<W>& e, int64_t i, const EnvLane<W>& v) {
     e.w0[i] = v.s.w0;
     e.w1[i] = v.s.w1;
-    e.meta[i] = (uint64_t)v.s.n0 | ((uint64_t)v.s.n1 << 8) | ((uint64_t)v.err << 16) | ((uint64_t)v.red << 24) | ((uint64_t)(uint32_t)v.cnt << 32);
+    e.meta[i] = env_pack_meta<W>(v);
 }
 
 // One env transition (ac_env.py:95-113) incl. the optional gymnasium-style autoreset.
@@ -295,15 +307,19 @@ __device__ __forceinline__ void wave_lds_handoff() {
 }
 
 template <typename W, bool SAFE, typename OBS, int LC>
-__global__ void __launch_bounds__(256, ACX_STEP_WAVES) k_env_step(EnvDev<W> e, const void* __restrict__ act, int adt, OBS* __restrict__ obs,
+__global__ void __launch_bounds__(256, ACX_STEP_WAVES) k_env_step(W* __restrict__ sw0, W* __restrict__ sw1, uint64_t* __restrict__ smeta,
+                                                  const void* __restrict__ act, int64_t n_envs, int adt, EnvDev<W> e, OBS* __restrict__ obs,
                                                   float* __restrict__ rew, float clip_lo, float clip_hi, uint8_t* __restrict__ done,
                                                   uint8_t* __restrict__ trunc, OBS* __restrict__ final_obs, int autoreset, int vec) {
+    // The first six arguments (state arrays, actions, n, action dtype = 11 dwords) are what the first memory
+    // accesses need: with -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave, so the
+    // state loads issue without waiting for a kernarg fetch (this kernel is latency bound at 65 536 envs).
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int L = LC > 0 ? LC : e.L;
     const int RB = 2 * L * (int)sizeof(OBS);
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
-    const int rows = (int)(e.n - row0 < 64 ? (e.n - row0 < 0 ? 0 : e.n - row0) : 64);
+    const int rows = (int)(n_envs - row0 < 64 ? (n_envs - row0 < 0 ? 0 : n_envs - row0) : 64);
     uint8_t* tile = lds + wave * 64 * RB;  // private to this wave
     OBS* my = (OBS*)(tile + lane * RB);
     EnvLane<W> v;
@@ -311,11 +327,17 @@ __global__ void __launch_bounds__(256, ACX_STEP_WAVES) k_env_step(EnvDev<W> e, c
     bool was_reset = false;
     if (lane < rows) {
         const int64_t i = row0 + lane;
-        env_load<W>(e, i, v);
+        v.s.w0 = sw0[i];
+        v.s.w1 = sw1[i];
+        const uint64_t m = smeta[i];
+        const int a = load_action(act, adt, i);
+        env_unpack_meta<W>(m, v);
         float r;
         int d, t;
-        env_transition<W, SAFE>(e, i, v, load_action(act, adt, i), autoreset != 0, clip_lo, clip_hi, r, d, t, was_reset, fin);
-        env_store<W>(e, i, v);
+        env_transition<W, SAFE>(e, i, v, a, autoreset != 0, clip_lo, clip_hi, r, d, t, was_reset, fin);
+        sw0[i] = v.s.w0;
+        sw1[i] = v.s.w1;
+        smeta[i] = env_pack_meta<W>(v);
         if (rew) rew[i] = r;
         if (done) done[i] = (uint8_t)d;
         if (trunc) trunc[i] = (uint8_t)t;
@@ -323,13 +345,13 @@ __global__ void __launch_bounds__(256, ACX_STEP_WAVES) k_env_step(EnvDev<W> e, c
     }
     if (obs) {
         wave_lds_handoff();
-        if (rows > 0) wave_copy((uint8_t*)obs + row0 * RB, tile, rows * RB, lane, vec != 0);
+        if (rows > 0) wave_copy<ACX_OBS_NT != 0>((uint8_t*)obs + row0 * RB, tile, rows * RB, lane, vec != 0);
     }
     if (final_obs) {  // terminal observation of envs that were just reset, current observation otherwise
         wave_lds_handoff();
         if (lane < rows) write_obs_row<W, LC>(my, was_reset ? fin : v.s, L);
         wave_lds_handoff();
-        if (rows > 0) wave_copy((uint8_t*)final_obs + row0 * RB, tile, rows * RB, lane, vec != 0);
+        if (rows > 0) wave_copy<ACX_OBS_NT != 0>((uint8_t*)final_obs + row0 * RB, tile, rows * RB, lane, vec != 0);
     }
 }
 
@@ -368,7 +390,7 @@ __global__ void __launch_bounds__(256) k_env_observe(EnvDev<W> e, OBS* __restric
         write_obs_row<W, 0>((OBS*)(tile + lane * RB), v.s, e.L);
     }
     wave_lds_handoff();
-    if (rows > 0) wave_copy((uint8_t*)obs + row0 * RB, tile, rows * RB, lane, vec != 0);
+    if (rows > 0) wave_copy<ACX_OBS_NT != 0>((uint8_t*)obs + row0 * RB, tile, rows * RB, lane, vec != 0);
 }
 
 // rows [m, 2L] int8 (device staging) -> packed state of envs idx[k] (or env k when idx == NULL).
@@ -688,7 +710,7 @@ int acx_env_step(acx_env* e, const void* d_actions, int action_dtype, void* d_ob
     const size_t lds = (d_obs || d_final_obs) ? (size_t)4 * 64 * 2 * e->L * (f32 ? 4 : 1) : 0;
     const int vec = aligned16(d_obs) && aligned16(d_final_obs);
 #define ACX_STEP(OBS, LC)                                                                                                                    \
-    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_step<W, SAFE, OBS, LC>), dim3(grid), dim3(256), lds, st, dev, d_actions, action_dtype, (OBS*)d_obs, \
+    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_step<W, SAFE, OBS, LC>), dim3(grid), dim3(256), lds, st, dev.w0, dev.w1, dev.meta, d_actions, dev.n, action_dtype, dev, (OBS*)d_obs, \
                                            d_reward, clip_lo, clip_hi, d_done, d_trunc, (OBS*)d_final_obs, autoreset, vec))
     if (e->L == 25) {  // BASELINE max_relator_length: fully unrolled observation writer
         if (f32) ACX_STEP(float, 25);

@@ -87,6 +87,27 @@ def test_stats_match_oracle_node_counts(search):
             assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (kind, budget, st, wst)
 
 
+def test_greedy_batch_per_launch_path_equals_device_frontier(search, golden_json, monkeypatch):
+    """greedy_search runs on the persistent one-workgroup frontier (acx_greedy.h); the batch-per-launch path it falls
+    back to when a capacity is exceeded (ACX_GREEDY_HOST=1 forces it) must return the same thing."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search
+
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    ak3 = np.zeros(50, np.int8)
+    ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+    ak3[25:31] = [1, 2, 1, -2, -1, -2]
+    cases = [(ak3, 1, False), (ak3, 2, False), (ak3, 13, True), (ak3, 30000, False), (pool[1100], 20000, False), (pool[77], 5000, True), (pool[600], 10**5, False)]
+    for p, budget, cyc in cases:
+        monkeypatch.delenv("ACX_GREEDY_HOST", raising=False)
+        a = run_search(_acx.SEARCH_GREEDY, p, budget, cyc)
+        monkeypatch.setenv("ACX_GREEDY_HOST", "1")
+        b = run_search(_acx.SEARCH_GREEDY, p, budget, cyc)
+        monkeypatch.delenv("ACX_GREEDY_HOST", raising=False)
+        assert a[:2] == b[:2] and a[2]["nodes"] == b[2]["nodes"] and a[2]["expanded"] == b[2]["expanded"], (budget, cyc)
+        assert a[2]["min_len"] >= b[2]["min_len"]  # the batch path also counts children of parents it speculated on
+
+
 def test_greedy_paths_file_sample(search, golden_json):
     """data/greedy_search_paths.txt (budget 1e6): a sample through the device frontier at native L (up to 36 -> 128-bit keys)"""
     pool = ms_pool_generator_order(golden_json("ms_pool.json"))
