@@ -9,6 +9,8 @@ from dataclasses import dataclass, field
 from typing import Union
 import ctypes as C
 
+import sys
+
 import numpy as np
 
 from ac_solver import _acx
@@ -60,7 +62,8 @@ class _Handle:
             raise _acx.AcxError(f"acx_env_create failed: {_acx.last_error()}")
 
     def __del__(self):
-        if getattr(self, "ptr", None):
+        # not during interpreter shutdown: the HIP runtime may already be tearing down (a hipFree then can block forever)
+        if getattr(self, "ptr", None) and not sys.is_finalizing():
             _acx.lib.acx_env_destroy(self.ptr)
             self.ptr = None
 

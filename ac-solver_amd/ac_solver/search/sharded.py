@@ -8,9 +8,12 @@ global frontier positions; for each chunk every rank
      `12 * global_parent_position + action` is the order in which the reference generates it),
   2. routes each child record to the owner of the child's key -- ONE all-to-all (RCCL over xGMI),
   3. deduplicates what it received against its slice of the visited set, minimum tag wins (HIP),
-  4. all-gathers the tags of its new states, so that every rank derives the same global FIFO numbering,
-     the same budget decision ("first parent after which len(tree_nodes) >= max_nodes",
-     breadth_first.py:91-95) and the same success decision (smallest tag of a length-2 child, :84-85).
+  4. all-reduces (sum) one 12-bit mask per parent of the chunk -- bit a set by the owner of child (parent, a)
+     when that child is a new state -- so that every rank derives the same global FIFO numbering (position
+     of a new state = new states of earlier parents + earlier set bits of its own parent), the same budget
+     decision ("first parent after which len(tree_nodes) >= max_nodes", breadth_first.py:91-95) and the same
+     success decision (smallest tag of a length-2 child, :84-85).  The exchange is 4 bytes per PARENT; no
+     rank ever holds the tags of the other ranks' new states.
 
 The per-rank work goes through an *engine* (the C ABI `acx_shard_*` of libacx in production; the CPU
 tests plug in a NumPy engine built on the oracle) and the exchange through a *comm* (torch.distributed:
@@ -18,6 +21,7 @@ backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests; an in-process thread co
 play several ranks in the GPU tests).
 """
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -110,7 +114,8 @@ class HipShardEngine:
         self.batch_cap = int(batch_cap)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        # not during interpreter shutdown: the HIP runtime may already be tearing down (a hipFree then can block forever)
+        if getattr(self, "h", None) and not sys.is_finalizing():
             self._acx.lib.acx_shard_destroy(self.h)
             self.h = None
 
@@ -134,6 +139,21 @@ class HipShardEngine:
             self._acx.check(self._acx.lib.acx_shard_expand(self.h, ids.data_ptr(), gpos.data_ptr(), np_, rec.data_ptr(), solved.data_ptr(), self._stream()),
                             "acx_shard_expand")
         return rec
+
+    def expand_routed(self, ids, gpos, solved, world):
+        """expand + group by owner on the device: (records grouped by destination rank, counts per rank)"""
+        torch = _torch()
+        np_ = ids.numel()
+        cap = 12 * np_  # a region can take every child: no-op moves keep a child on its parent's rank, so the split is far from uniform
+        rec = torch.empty((world * cap, self.KW + 2), dtype=torch.int64, device=self.device)
+        cnt = torch.empty(world, dtype=torch.int64, device=self.device)
+        self._acx.check(self._acx.lib.acx_shard_expand_routed(self.h, ids.data_ptr() if np_ else None, gpos.data_ptr() if np_ else None, np_,
+                                                              rec.data_ptr() if np_ else None, cap, cnt.data_ptr(), solved.data_ptr(), self._stream()),
+                        "acx_shard_expand_routed")
+        counts = cnt.tolist()
+        if max(counts) > cap:
+            raise RuntimeError(f"rank {self.rank}: a send region overflowed ({max(counts)} > {cap} records)")
+        return torch.cat([rec[o * cap:o * cap + c] for o, c in enumerate(counts)]), counts
 
     def insert(self, recv, max_tag=None):
         torch = _torch()
@@ -198,6 +218,8 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
     def i64(values):
         return torch.tensor(values, dtype=torch.int64, device=dev)
 
+    pop12 = i64([bin(v).count("1") for v in range(4096)])  # popcount of a 12-bit child mask
+
     # root: inserted by its owner with tag 0, becomes global frontier position 0
     root = engine.root_record(p)
     root_t = i64(root[None, :])
@@ -242,8 +264,15 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             lo = int(torch.searchsorted(f_gpos, i64([c0]))[0]) if f_gpos.numel() else 0
             hi = int(torch.searchsorted(f_gpos, i64([c1]))[0]) if f_gpos.numel() else 0
             solved = i64([INF])
-            recs = engine.expand(f_ids[lo:hi].contiguous(), f_gpos[lo:hi].contiguous(), solved)
-            if world > 1 or _FORCE_EXCHANGE:
+            routed = (world > 1 or _FORCE_EXCHANGE) and hasattr(engine, "expand_routed")
+            if routed:
+                send, counts = engine.expand_routed(f_ids[lo:hi].contiguous(), f_gpos[lo:hi].contiguous(), solved, world)
+                recv = comm.all_to_all_rows(send, counts)
+            else:
+                recs = engine.expand(f_ids[lo:hi].contiguous(), f_gpos[lo:hi].contiguous(), solved)
+            if routed:
+                pass
+            elif world > 1 or _FORCE_EXCHANGE:
                 owners = owner_of(recs[:, :KW], world)
                 order = torch.argsort(owners, stable=True)
                 counts = torch.bincount(owners, minlength=world).tolist()
@@ -252,17 +281,32 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
                 recv = recs
             if recv.shape[0] > engine.batch_cap:
                 raise RuntimeError(f"rank {rank}: {recv.shape[0]} records exceed the per-chunk capacity {engine.batch_cap}")
-            win = engine.insert(recv, 12 * c1)
-            parts = comm.all_gather_var(win)
-            all_tags = torch.sort(torch.cat(parts))[0] if (world > 1 or _FORCE_EXCHANGE) else win
+            win = engine.insert(recv, 12 * c1)       # tags of MY new states, ascending
+            # one 12-bit mask per parent of the chunk; every (parent, action) child has exactly one owner, so SUM == OR
+            rel = win - 12 * c0
+            par, bit = rel // 12, rel % 12
+            mask = torch.zeros(c1 - c0, dtype=torch.int32, device=dev)
+            if rel.numel():
+                mask.index_add_(0, par, torch.bitwise_left_shift(torch.ones_like(bit), bit).to(torch.int32))
+            comm.all_reduce(mask, "sum")
+            mask = mask.to(torch.int64)
+            incl = torch.cumsum(pop12[mask], 0)      # new states up to and including each parent (global)
             solved_tag = int(comm.all_reduce(solved, "min")[0])
-            total_new = int(all_tags.numel())
+            total_new = int(incl[-1])
+
+            def new_before(tag):
+                """number of new states of the chunk with a tag smaller than `tag` (global)"""
+                q, a = (tag - 12 * c0) // 12, (tag - 12 * c0) % 12
+                if q >= c1 - c0:
+                    return total_new
+                return int(incl[q] - pop12[mask[q]] + pop12[mask[q] & ((1 << a) - 1)])
 
             p_end, budget_hit = c1 - 1, False
             if nodes_global >= max_nodes:          # only the very first parent can see this (budget <= 1)
                 p_end, budget_hit = c0, True
             elif nodes_global + total_new >= max_nodes:
-                pb = int(all_tags[max_nodes - nodes_global - 1]) // 12
+                # parent of the new state that reaches the budget = first parent whose inclusive count reaches it
+                pb = c0 + int(torch.searchsorted(incl, i64([max_nodes - nodes_global]))[0])
                 if pb <= p_end:
                     p_end, budget_hit = pb, True
             if solved_tag < INF and solved_tag // 12 <= p_end:
@@ -272,14 +316,15 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
                 pref = i64([(rank << 40) | int(f_ids[k]) if mine else -1])
                 comm.all_reduce(pref, "max")
                 expanded += gp + 1 - c0
-                nodes_global += int(torch.searchsorted(all_tags, i64([solved_tag]))[0])
+                nodes_global += new_before(solved_tag)
                 return finish(True, walk(int(pref[0]), [(solved_tag % 12, 2)]))
             cutoff = 12 * (p_end + 1)
             first, cnt = engine.commit(cutoff)
             if cnt:
                 next_ids.append(torch.arange(first, first + cnt, dtype=torch.int64, device=dev))
-                next_gpos.append(torch.searchsorted(all_tags, win[:cnt].contiguous()) + next_count)
-            committed = int(torch.searchsorted(all_tags, i64([cutoff]))[0])
+                mp = mask[par[:cnt]]
+                next_gpos.append(next_count + incl[par[:cnt]] - pop12[mp] + pop12[mp & (torch.bitwise_left_shift(torch.ones_like(bit[:cnt]), bit[:cnt]) - 1)])
+            committed = int(incl[p_end - c0])
             next_count += committed
             nodes_global += committed
             expanded += p_end + 1 - c0

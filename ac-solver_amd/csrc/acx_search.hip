@@ -108,11 +108,14 @@ __global__ void __launch_bounds__(256) k_expand(SearchDev<W> d, const uint32_t* 
         const uint32_t p = t / 12u, a = t - 12u * p;
         const uint32_t pid = plist ? plist[p] : pbegin + p;
         Pres<W> s;
-        key_to_pres<W>(d.k0[pid], d.k1[pid], s);
+        const W pk0 = d.k0[pid], pk1 = d.k1[pid];
+        key_to_pres<W>(pk0, pk1, s);
         const int e = apply_move<W, true>(s, (int)a, d.L, d.cyclical != 0);
         if (e) atomicOr(d.err, (uint32_t)e);  // the reference's ACMove raises: the whole search raises
-        d.ck0[t] = keyops<W>::make(s.w0, s.n0);
-        d.ck1[t] = keyops<W>::make(s.w1, s.n1);
+        const W c0 = keyops<W>::make(s.w0, s.n0), c1 = keyops<W>::make(s.w1, s.n1);
+        d.ck0[t] = c0;
+        d.ck1[t] = c1;
+        d.cknown[t] = (c0 == pk0 && c1 == pk1) ? 1 : 0;  // an unchanged state is its (visited) parent: k_insert skips the probe
         tl = (uint32_t)(s.n0 + s.n1);
         d.clen[t] = (uint8_t)tl;
         if (tl == 2) atomicMin(d.solved_tag, (unsigned long long)t);  // breadth_first.py:84 / greedy.py:91
@@ -736,7 +739,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
             hipLaunchKernelGGL(k_insert<W>, grid, block, 0, st, d, d.bslots, bs - 1, m, 1);
             hipLaunchKernelGGL(k_mark<W>, grid, block, 0, st, d, d.bslots, m, bucket_len);
         } else {
-            hipLaunchKernelGGL(k_insert<W>, grid, block, 0, st, d, d.slots, d.smask, m, 0);
+            hipLaunchKernelGGL(k_insert<W>, grid, block, 0, st, d, d.slots, d.smask, m, 1);
             hipLaunchKernelGGL(k_mark<W>, grid, block, 0, st, d, d.slots, m, -1);
         }
         {
@@ -881,6 +884,72 @@ __global__ void __launch_bounds__(256) k_shard_expand(SearchDev<W> d, const int6
     r[recio<W>::KW + 1] = pref_hi | id;
     if (s.n0 + s.n1 == 2) atomicMin(solved, (unsigned long long)tag);
     if ((uint32_t)(s.n0 + s.n1) < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, (uint32_t)(s.n0 + s.n1));
+}
+
+// Owner rank of a packed key: the arithmetic of ac_solver/search/sharded.py:owner_of on the key's int64 words.
+ACX_HD uint64_t owner_mix(uint64_t h, uint64_t w) {
+    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+ACX_HD uint32_t owner_of_key(uint64_t k0, uint64_t k1, uint32_t world) {
+    const uint64_t h = owner_mix(owner_mix(0, k0), k1);
+    return (uint32_t)((h & 0x7FFFFFFFFFFFFFFFull) % world);
+}
+ACX_HD uint32_t owner_of_key(u128 k0, u128 k1, uint32_t world) {
+    uint64_t h = owner_mix(owner_mix(0, (uint64_t)k0), (uint64_t)(k0 >> 64));
+    h = owner_mix(owner_mix(h, (uint64_t)k1), (uint64_t)(k1 >> 64));
+    return (uint32_t)((h & 0x7FFFFFFFFFFFFFFFull) % world);
+}
+
+// k_shard_expand + routing: the record of a child goes straight into the send region of the rank that owns the
+// child's key (region o = rec[o * region_cap ...], filled through a wave-aggregated cursor counts[o]), so the
+// all-to-all can leave without a sort by owner.  The order inside a region is arbitrary (the receiver orders by tag).
+template <typename W>
+__global__ void __launch_bounds__(256) k_shard_expand_routed(SearchDev<W> d, const int64_t* __restrict__ ids, const int64_t* __restrict__ gpos, int64_t np,
+                                                             int64_t pref_hi, uint32_t world, int64_t* __restrict__ rec, int64_t region_cap,
+                                                             unsigned long long* __restrict__ counts, unsigned long long* __restrict__ solved) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = t < 12 * np;
+    const uint32_t lane = threadIdx.x & 63;
+    W k0 = 0, k1 = 0;
+    int64_t tag = 0, pref = 0;
+    uint32_t owner = 0xFFFFFFFFu;
+    if (active) {
+        const int64_t p = t / 12;
+        const int a = (int)(t - 12 * p);
+        const int64_t id = ids[p];
+        Pres<W> s;
+        const W pk0 = d.k0[id], pk1 = d.k1[id];
+        key_to_pres<W>(pk0, pk1, s);
+        const int e = apply_move<W, true>(s, a, d.L, d.cyclical != 0);
+        if (e) atomicOr(d.err, (uint32_t)e);
+        k0 = keyops<W>::make(s.w0, s.n0);
+        k1 = keyops<W>::make(s.w1, s.n1);
+        tag = 12 * gpos[p] + a;
+        pref = pref_hi | id;
+        // a move that leaves the state unchanged (over-long product: ac_moves.py:64, :126) yields the parent itself, which
+        // is in the visited set already: such a child can never be new, so it is not sent at all
+        if (k0 != pk0 || k1 != pk1) owner = owner_of_key(k0, k1, world);
+        if (s.n0 + s.n1 == 2) atomicMin(solved, (unsigned long long)tag);
+        if ((uint32_t)(s.n0 + s.n1) < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, (uint32_t)(s.n0 + s.n1));
+    }
+    for (uint32_t o = 0; o < world; o++) {
+        const unsigned long long m = __ballot(owner == o);
+        if (!m) continue;
+        const uint32_t lead = (uint32_t)__builtin_ctzll(m);
+        unsigned long long base = 0;
+        if (lane == lead) base = atomicAdd(&counts[o], (unsigned long long)__popcll(m));
+        base = (unsigned long long)__shfl((long long)base, (int)lead);
+        if (owner == o) {
+            const int64_t pos = (int64_t)base + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < region_cap) {
+                int64_t* r = rec + ((int64_t)o * region_cap + pos) * (recio<W>::KW + 2);
+                recio<W>::put(r, k0, k1);
+                r[recio<W>::KW] = tag;
+                r[recio<W>::KW + 1] = pref;
+            }  // an overflow shows in counts[o] > region_cap; the host reports it
+        }
+    }
 }
 
 template <typename W> __global__ void __launch_bounds__(256) k_shard_tags(const int64_t* __restrict__ rec, int64_t n, uint64_t* __restrict__ tags, uint32_t* __restrict__ idx) {
@@ -1060,6 +1129,18 @@ template <typename W> static int shard_expand(ShardEngine<W>& E, const int64_t* 
     return ACX_OK;
 }
 
+template <typename W>
+static int shard_expand_routed(ShardEngine<W>& E, const int64_t* ids, const int64_t* gpos, int64_t np, int64_t* rec, int64_t region_cap, int64_t* counts,
+                               int64_t* solved, hipStream_t st) {
+    ACX_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)E.world * 8, st));
+    if (np <= 0) return ACX_OK;
+    const int64_t m = 12 * np;
+    hipLaunchKernelGGL(k_shard_expand_routed<W>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, E.d, ids, gpos, np, (int64_t)E.rank << 40, (uint32_t)E.world,
+                       rec, region_cap, (unsigned long long*)counts, (unsigned long long*)solved);
+    ACX_HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
 template <typename W> static int shard_insert(ShardEngine<W>& E, const int64_t* rec, int64_t n, int tag_bits, int64_t* win_tags, int64_t* n_win, hipStream_t st) {
     *n_win = 0;
     E.pending = n;
@@ -1217,6 +1298,13 @@ int acx_shard_root_record(acx_shard* h, const int8_t* h_presentation, int64_t* h
 int acx_shard_expand(acx_shard* h, const int64_t* d_ids, const int64_t* d_gpos, int64_t np, int64_t* d_records, int64_t* d_solved, void* stream) {
     if (!h || np < 0 || (np > 0 && (!d_ids || !d_gpos || !d_records || !d_solved))) return fail(ACX_E_INVAL, "acx_shard_expand: bad argument");
     ACX_SHARD_DISPATCH(&h->any, return shard_expand<W>(E, d_ids, d_gpos, np, d_records, d_solved, (hipStream_t)stream));
+}
+
+int acx_shard_expand_routed(acx_shard* h, const int64_t* d_ids, const int64_t* d_gpos, int64_t np, int64_t* d_records, int64_t region_cap,
+                            int64_t* d_counts, int64_t* d_solved, void* stream) {
+    if (!h || np < 0 || region_cap < 0 || !d_counts || (np > 0 && (!d_ids || !d_gpos || !d_records || !d_solved)))
+        return fail(ACX_E_INVAL, "acx_shard_expand_routed: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, return shard_expand_routed<W>(E, d_ids, d_gpos, np, d_records, region_cap, d_counts, d_solved, (hipStream_t)stream));
 }
 
 int acx_shard_insert(acx_shard* h, const int64_t* d_records, int64_t n, int tag_bits, int64_t* d_win_tags, int64_t* n_win, void* stream) {

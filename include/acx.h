@@ -162,6 +162,11 @@ int acx_shard_root_record(acx_shard *h, const int8_t *h_presentation, int64_t *h
  * d_solved[0] is min-combined with the tags of children of total length 2 */
 int acx_shard_expand(acx_shard *h, const int64_t *d_ids, const int64_t *d_gpos, int64_t np, int64_t *d_records,
                      int64_t *d_solved, void *stream);
+/* the same expansion with the records already routed: a child whose key belongs to rank o (owner = the hash of
+ * ac_solver/search/sharded.py:owner_of, mod world) is written to d_records[(o * region_cap + i) * (key_words + 2)],
+ * i < d_counts[o] (device int64[world], any order inside a region); d_counts[o] > region_cap reports an overflow */
+int acx_shard_expand_routed(acx_shard *h, const int64_t *d_ids, const int64_t *d_gpos, int64_t np, int64_t *d_records,
+                            int64_t region_cap, int64_t *d_counts, int64_t *d_solved, void *stream);
 /* exact dedup of n received records (any order) against the visited table and among themselves (minimum tag
  * wins); the winners' tags are written ascending to d_win_tags, their count to *n_win; they stay pending.
  * tag_bits: every tag is < 2^tag_bits (bounds the radix-sort passes; 0 = unknown) */

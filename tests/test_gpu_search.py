@@ -143,6 +143,52 @@ def test_sharded_bfs_hip_engine_matches_reference(search, golden_json, world):
             assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (world, b, c, st, wst)
 
 
+@pytest.mark.parametrize("L", [25, 36])
+def test_device_routing_matches_owner_of(search, L):
+    """acx_shard_expand_routed groups the children by the same owner function the orchestrator uses (owner_of), both key widths"""
+    import torch
+
+    from ac_solver.search.sharded import HipShardEngine, owner_of
+
+    ak3 = np.zeros(2 * L, np.int8)
+    ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+    ak3[L:L + 6] = [1, 2, 1, -2, -1, -2]
+    for world in (2, 3, 8):
+        eng = HipShardEngine(L, False, 100000, 200000, 0, world)
+        KW = eng.KW
+        root = torch.tensor(eng.root_record(ak3)[None, :], dtype=torch.int64, device=eng.device)
+        eng.insert(root)
+        first, cnt = eng.commit(1 << 62)
+        key_of = {0: tuple(root[0, :KW].tolist())}  # node id -> packed key
+        n_unmoved = 0
+        ids = torch.arange(first, first + cnt, dtype=torch.int64, device=eng.device)
+        gpos = torch.zeros_like(ids)
+        for _ in range(4):  # a few levels: 12, then up to 144, ... children
+            solved = torch.tensor([1 << 62], dtype=torch.int64, device=eng.device)
+            plain = eng.expand(ids, gpos, solved)
+            send, counts = eng.expand_routed(ids, gpos, solved, world)
+            assert plain.shape[0] == 12 * ids.numel()
+            rows = plain.tolist()
+            # a child equal to its parent (a move that changed nothing) is never new and is not routed at all
+            moved = [r for r in rows if tuple(r[:KW]) != key_of[r[KW + 1] & ((1 << 40) - 1)]]
+            assert sum(counts) == len(moved) <= len(rows)
+            n_unmoved += len(rows) - len(moved)
+            owners = owner_of(torch.tensor([r[:KW] for r in moved], dtype=torch.int64), world).tolist()
+            got_rows = send.tolist()
+            off = 0
+            for o, c in enumerate(counts):
+                want = sorted(tuple(r) for r, w in zip(moved, owners) if w == o)
+                assert want == sorted(map(tuple, got_rows[off:off + c])), (L, world, o)
+                off += c
+            win = eng.insert(plain, None).tolist()
+            first, cnt = eng.commit(1 << 62)
+            by_tag = {r[KW]: tuple(r[:KW]) for r in rows}
+            for k, tag in enumerate(win[:cnt]):
+                key_of[first + k] = by_tag[tag]
+            ids = torch.arange(first, first + cnt, dtype=torch.int64, device=eng.device)
+            gpos = torch.arange(cnt, dtype=torch.int64, device=eng.device)
+
+
 def test_many_searches_overlapped_equal_single(search, golden_json):
     from ac_solver import _acx
     from ac_solver.search._common import run_search, run_search_many
