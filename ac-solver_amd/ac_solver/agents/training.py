@@ -1,0 +1,270 @@
+"""PPO training loop on the device-resident environments (reference: ac_solver/agents/training.py:18-410).
+
+Same algorithm and bookkeeping as the reference (learning-rate schedule, GAE, clipped / KL-penalty objective,
+clipped value loss, curriculum over the initial states, ACMoves_hist, checkpoints, optional wandb scalars); what
+changes is where the rollout lives: `ACVecEnv.step` writes the float32 observation, the (clipped) reward and the
+terminated flag of every environment straight into the [num_steps, num_envs, ...] rollout tensors on the GPU, the
+policy samples on the GPU, and the host only sees the indices of environments that finished an episode.
+With torch.distributed initialised (one process per GPU) gradients are averaged over the ranks (data parallel).
+"""
+import math
+import random
+import uuid
+from collections import deque
+from os import makedirs
+from os.path import join
+
+import numpy as np
+import torch
+from torch import nn
+
+
+def get_curr_lr(n_update, lr_decay, warmup, max_lr, min_lr, total_updates):
+    """Learning rate of update `n_update` (1-based): linear warm-up over the first `warmup` fraction of the updates,
+    then a linear or cosine decay from max_lr to min_lr (training.py:18-65)."""
+    k, last = n_update - 1, total_updates - 1
+    warm_end = last * warmup
+    if warm_end > 0 and k <= warm_end:
+        return max_lr * k / warm_end
+    if lr_decay == "linear":
+        frac = (k - warm_end) / (last - warm_end)
+        return max_lr + (min_lr - max_lr) * frac
+    if lr_decay == "cosine":
+        frac = (k - warm_end) / (last - warm_end)
+        return min_lr + (max_lr - min_lr) * (1 + math.cos(frac * math.pi)) / 2
+    raise NotImplementedError("Only 'linear' and 'cosine' lr-schedules are available.")
+
+
+def compute_gae(rewards, values, dones, next_value, next_done, gamma, gae_lambda):
+    """Generalised advantage estimation over a [T, N] rollout (training.py:241-258): dones[t] is 1 when the episode
+    that produced obs[t] had just ended.  -> (advantages, returns)"""
+    T = rewards.shape[0]
+    advantages = torch.zeros_like(rewards)
+    last = torch.zeros_like(next_value)
+    for t in reversed(range(T)):
+        nonterminal = 1.0 - (next_done if t == T - 1 else dones[t + 1])
+        nextvalues = next_value if t == T - 1 else values[t + 1]
+        delta = rewards[t] + gamma * nextvalues * nonterminal - values[t]
+        advantages[t] = last = delta + gamma * gae_lambda * nonterminal * last
+    return advantages, advantages + values
+
+
+def choose_next_state(states_processed, n_states, success_record, round1_complete, repeat_solved_prob):
+    """Curriculum step of the reference (training.py:199-221): first walk through the initial states in order; once
+    every state has been started at least once, pick an unsolved state with probability 1 - repeat_solved_prob
+    (always, while nothing is solved), otherwise a solved one.  -> (next state index, round1_complete)"""
+    round1_complete = round1_complete or max(states_processed) == n_states - 1
+    if not round1_complete:
+        return max(states_processed) + 1, round1_complete
+    if len(success_record["solved"]) == 0 or (success_record["unsolved"] and random.uniform(0, 1) > repeat_solved_prob):
+        return random.choice(list(success_record["unsolved"])), round1_complete
+    return random.choice(list(success_record["solved"])), round1_complete
+
+
+def _average_gradients(params, world):
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    torch.distributed.all_reduce(flat)
+    flat /= world
+    o = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        o += n
+
+
+def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success_record, ACMoves_hist, states_processed,
+                      initial_states, progress=True, rollout_log=None):
+    """`rollout_log`, when a list, receives per update a dict of CPU copies of the rollout tensors (tests)."""
+    T, N = args.num_steps, args.num_envs
+    obs_shape = envs.single_observation_space.shape
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    world = torch.distributed.get_world_size() if dist_on else 1
+    rank = torch.distributed.get_rank() if dist_on else 0
+
+    # rollout storage: the environment kernel writes rows t+1 of obs / term and row t of rewards
+    obs = torch.zeros((T + 1, N) + obs_shape, device=device)
+    term = torch.zeros((T + 1, N), dtype=torch.bool, device=device)
+    trunc = torch.zeros(N, dtype=torch.bool, device=device)
+    actions = torch.zeros((T, N), dtype=torch.int64, device=device)
+    logprobs = torch.zeros((T, N), device=device)
+    rewards = torch.zeros((T, N), device=device)
+    values = torch.zeros((T, N), device=device)
+    init_rows = np.asarray(initial_states, np.int8)
+    init_table = torch.as_tensor(init_rows.astype(np.float32), device=device)  # [n_states, 2L]
+    ep_return = torch.zeros(N, device=device)
+    ep_length = torch.zeros(N, device=device)
+
+    global_step = 0
+    obs[0].copy_(envs.reset()[0])
+    num_updates = args.total_timesteps // args.batch_size
+    episode = 0
+    returns_queue, lengths_queue = deque([0], maxlen=100), deque([0], maxlen=100)
+    round1_complete = False
+    beta = None if args.is_loss_clip else args.beta
+    params = list(agent.parameters())
+
+    run_name = f"{args.exp_name}_ppo-ffn-nodes_{args.nodes_counts}_{uuid.uuid4()}"
+    out_dir = f"out/{run_name}"
+    wandb = None
+    if args.wandb_log and rank == 0:
+        import wandb  # noqa: F811  (optional dependency)
+
+        wandb.init(project=args.wandb_project_name, entity=args.wandb_entity, name=run_name, config=vars(args), save_code=True)
+    if rank == 0:
+        print(f"total number of timesteps: {args.total_timesteps}, updates: {num_updates}")
+    updates = range(1, num_updates + 1)
+    if progress and rank == 0:
+        try:
+            from tqdm import tqdm
+
+            updates = tqdm(updates, desc="Training Progress", total=num_updates)
+        except ImportError:  # pragma: no cover
+            pass
+    stats = {}
+
+    for update in updates:
+        random.seed(args.seed + update)
+        np.random.seed(args.seed + update)
+        torch.manual_seed(args.seed + update)
+        if args.anneal_lr:
+            optimizer.param_groups[0]["lr"] = get_curr_lr(update, args.lr_decay, args.warmup_period, args.learning_rate,
+                                                          args.learning_rate * args.min_lr_frac, num_updates)
+        events = []  # (step, env, next curriculum state) of this rollout
+
+        # ---------------------------------------------------------------- rollout (device resident) ----
+        for step in range(T):
+            global_step += N * world
+            with torch.no_grad():
+                action, logprob, _, value = agent.get_action_and_value(obs[step])
+            actions[step] = action
+            logprobs[step] = logprob
+            values[step] = value.flatten()
+            envs.step(action, out=(obs[step + 1], rewards[step], term[step + 1], trunc), check_errors=False)
+            ep_return += rewards[step]
+            ep_length += 1
+            fin = term[step + 1] | trunc
+            if not bool(fin.any()):
+                continue
+            # ---- episodes ended: bookkeeping of the reference (training.py:167-224) on the finished envs only ----
+            idx = torch.nonzero(fin).flatten()
+            idx_h = idx.tolist()
+            done_h = term[step + 1][idx].tolist()
+            ret_h, len_h = ep_return[idx].tolist(), ep_length[idx].tolist()
+            new_states = []
+            for k, i in enumerate(idx_h):
+                s = curr_states[i]
+                if done_h[k]:
+                    if s in success_record["unsolved"]:
+                        success_record["unsolved"].remove(s)
+                        success_record["solved"].add(s)
+                    moves = envs.get_actions(i, finished=True)
+                    if s not in ACMoves_hist or len(moves) < len(ACMoves_hist[s]):
+                        ACMoves_hist[s] = moves
+                returns_queue.append(ret_h[k])
+                lengths_queue.append(len_h[k])
+                episode += 1
+                curr_states[i], round1_complete = choose_next_state(states_processed, len(initial_states), success_record,
+                                                                    round1_complete, args.repeat_solved_prob)
+                states_processed.add(curr_states[i])
+                new_states.append(curr_states[i])
+                events.append((step, i, curr_states[i]))
+            ep_return[idx] = 0
+            ep_length[idx] = 0
+            # the finished envs restart from their next curriculum state (envs.envs[i].reset(options={"starting_state": ...}))
+            envs.reset_envs(idx_h, init_rows[new_states])
+            obs[step + 1].index_copy_(0, idx, init_table[torch.as_tensor(new_states, device=device)])
+        envs._raise_on_errors()
+        if rollout_log is not None:
+            rollout_log.append({"obs": obs.cpu().numpy().copy(), "actions": actions.cpu().numpy().copy(), "rewards": rewards.cpu().numpy().copy(),
+                                "term": term.cpu().numpy().copy(), "events": list(events)})
+
+        if not args.norm_rewards:
+            rewards /= envs.max_reward
+            normalized_returns = np.array(returns_queue) / envs.max_reward
+            normalized_lengths = np.array(lengths_queue) / args.horizon_length
+        else:
+            normalized_returns, normalized_lengths = np.array(returns_queue), np.array(lengths_queue)
+
+        dones = term.to(torch.float32)
+        with torch.no_grad():
+            next_value = agent.get_value(obs[T]).reshape(-1)
+            advantages, returns = compute_gae(rewards, values, dones[:T], next_value, dones[T], args.gamma, args.gae_lambda)
+
+        b_obs = obs[:T].reshape((-1,) + obs_shape)
+        b_logprobs, b_actions = logprobs.reshape(-1), actions.reshape(-1)
+        b_advantages, b_returns, b_values = advantages.reshape(-1), returns.reshape(-1), values.reshape(-1)
+
+        # ---------------------------------------------------------------- policy / value update ----
+        b_inds = np.arange(args.batch_size)
+        clipfracs = []
+        for epoch in range(args.update_epochs):
+            np.random.shuffle(b_inds)
+            for start in range(0, args.batch_size, args.minibatch_size):
+                mb = torch.as_tensor(b_inds[start:start + args.minibatch_size], device=device)
+                _, newlogprob, entropy, newvalue = agent.get_action_and_value(b_obs[mb], b_actions[mb])
+                logratio = newlogprob - b_logprobs[mb]
+                ratio = logratio.exp()
+                kl_var = (ratio - 1) - logratio  # E[kl_var] approximates KL(pi_old || pi)
+                with torch.no_grad():
+                    approx_kl = kl_var.mean()
+                    clipfracs.append(((ratio - 1.0).abs() > args.clip_coef).float().mean())
+                mb_adv = b_advantages[mb]
+                if args.norm_adv:
+                    mb_adv = (mb_adv - mb_adv.mean()) / (mb_adv.std() + 1e-8)
+                if args.is_loss_clip:
+                    pg_loss = torch.max(-mb_adv * ratio, -mb_adv * torch.clamp(ratio, 1 - args.clip_coef, 1 + args.clip_coef)).mean()
+                else:
+                    pg_loss = (-mb_adv * ratio + beta * kl_var).mean()
+                newvalue = newvalue.view(-1)
+                if args.clip_vloss:
+                    v_clipped = b_values[mb] + torch.clamp(newvalue - b_values[mb], -args.clip_coef, args.clip_coef)
+                    v_loss = 0.5 * torch.max((newvalue - b_returns[mb]) ** 2, (v_clipped - b_returns[mb]) ** 2).mean()
+                else:
+                    v_loss = 0.5 * ((newvalue - b_returns[mb]) ** 2).mean()
+                entropy_loss = entropy.mean()
+                loss = pg_loss - args.ent_coef * entropy_loss + v_loss * args.vf_coef
+                optimizer.zero_grad()
+                loss.backward()
+                if dist_on and world > 1:
+                    _average_gradients(params, world)
+                nn.utils.clip_grad_norm_(agent.parameters(), args.max_grad_norm)
+                optimizer.step()
+            if args.is_loss_clip:
+                if args.target_kl is not None and approx_kl > args.target_kl:
+                    break
+            else:
+                beta = beta / 2 if approx_kl < args.target_kl / 1.5 else (beta * 2 if approx_kl > args.target_kl * 1.5 else beta)
+
+        # the next rollout continues where this one stopped
+        obs[0].copy_(obs[T])
+        term[0].copy_(term[T])
+
+        y_pred, y_true = b_values.cpu().numpy(), b_returns.cpu().numpy()
+        var_y = np.var(y_true)
+        explained_var = np.nan if var_y == 0 else 1 - np.var(y_true - y_pred) / var_y
+        stats = {
+            "charts/global_step": global_step, "charts/episode": episode,
+            "charts/normalized_returns_mean": float(normalized_returns.mean()), "charts/normalized_lengths_mean": float(normalized_lengths.mean()),
+            "charts/learning_rate": optimizer.param_groups[0]["lr"], "charts/solved": len(success_record["solved"]),
+            "charts/unsolved": len(success_record["unsolved"]),
+            "charts/highest_solved": max(success_record["solved"]) if success_record["solved"] else -1,
+            "losses/value_loss": v_loss.item(), "losses/policy_loss": pg_loss.item(), "losses/entropy_loss": entropy_loss.item(),
+            "losses/approx_kl": approx_kl.item(), "losses/explained_variance": explained_var,
+            "losses/clipfrac": float(torch.stack(clipfracs).mean()), "debug/advantages_mean": float(b_advantages.mean()),
+            "debug/advantages_std": float(b_advantages.std()),
+        }
+        if wandb is not None:
+            wandb.log(stats)
+        if update % 100 == 0 and rank == 0:  # a checkpoint every 100 updates (training.py:384-408)
+            makedirs(out_dir, exist_ok=True)
+            checkpoint = {
+                "critic": agent.critic.state_dict(), "actor": agent.actor.state_dict(), "optimizer": optimizer.state_dict(),
+                "update": update, "episode": episode, "config": vars(args), "mean_return": normalized_returns.mean(),
+                "success_record": success_record, "value_loss": v_loss.item(), "policy_loss": pg_loss.item(),
+                "entropy_loss": entropy_loss.item(), "approx_kl": approx_kl.item(), "explained_var": explained_var,
+                "clipfrac": stats["losses/clipfrac"], "global_step": global_step, "round1_complete": round1_complete,
+                "curr_states": curr_states, "states_processed": states_processed, "ACMoves_hist": ACMoves_hist, "supermoves": None,
+            }
+            print(f"saving checkpoint to {out_dir}")
+            torch.save(checkpoint, join(out_dir, "ckpt.pt"))
+    return stats

@@ -1,0 +1,103 @@
+"""On-disk data of the Miller-Schupp experiments (reference: ac_solver/search/miller_schupp/data/*.txt and the
+`_solved` / `_unsolved` / `_paths` outputs of trivialize_miller_schupp_through_search, miller_schupp.py:160-175).
+
+One Python literal per line:
+  all_presentations.txt            1190 presentations of n = 1..7, max_w_len = 7: the greedy-solved ones first
+                                   (generator order), then the rest -- "sorted by hardness" for the PPO curriculum
+  greedy_solved_presentations.txt  the 533 presentations greedy_search trivialises with a 1e6-node budget
+  greedy_search_paths.txt          their paths, aligned line by line, in the LEGACY encoding of the published file:
+                                   actions are 1-based and the root entry is (0, length) instead of (-1, length)
+  bfs_solved_presentations.txt     the 278 presentations bfs trivialises with a 1e6-node budget (cyclic reduction on)
+
+The files are not shipped: `ensure_data_file` produces them with this build's own searches on the GPU
+(about half a minute) the first time one is asked for, into ac_solver/search/miller_schupp/data/.
+"""
+import os
+from ast import literal_eval
+
+import numpy as np
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.realpath(__file__)), "data")
+FILES = ("all_presentations.txt", "greedy_solved_presentations.txt", "greedy_search_paths.txt", "bfs_solved_presentations.txt")
+
+
+def to_legacy_path(path):
+    """[(-1, l0), (a, l), ...] -> [(0, l0), (a + 1, l), ...] (the encoding of the published greedy_search_paths.txt)"""
+    return [(int(a) + 1, int(l)) for a, l in path]
+
+
+def from_legacy_path(path):
+    return [(int(a) - 1, int(l)) for a, l in path]
+
+
+def write_literals(rows, filepath):
+    with open(filepath, "w") as f:
+        for row in rows:
+            f.write(f"{row}\n")
+
+
+def read_literals(filepath):
+    with open(filepath) as f:
+        return [literal_eval(line.strip()) for line in f if line.strip()]
+
+
+def replay_path(presentation, path, cyclical=False):
+    """Apply the actions of a search path to `presentation` on the GPU; returns the list of total lengths after each
+    move.  A path is valid when this equals its recorded lengths and ends at 2 (breadth_first.py:113-126)."""
+    from ac_solver.envs.ac_moves import ACMove
+
+    state = np.array(presentation, dtype=np.int8)
+    L = len(state) // 2
+    lengths = [int(np.count_nonzero(state[:L])), int(np.count_nonzero(state[L:]))]
+    out = []
+    for action, _ in path[1:]:
+        state, lengths = ACMove(int(action), state, L, lengths, cyclical=cyclical)
+        out.append(int(sum(lengths)))
+    return out
+
+
+def make_data_files(max_nodes_to_explore=10**6, out_dir=None, verbose=True):
+    """Run greedy_search and bfs over the 1190 Miller-Schupp presentations and write the four files."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search_many
+    from ac_solver.search.miller_schupp.miller_schupp import generate_miller_schupp_presentations
+
+    out_dir = out_dir or DATA_DIR
+    os.makedirs(out_dir, exist_ok=True)
+    solved, unsolved, paths, bfs_solved = [], [], [], []
+    for n in range(1, 8):
+        by_len = generate_miller_schupp_presentations(n, 7)
+        rows = [p for lenw in range(1, 8) for p in by_len.get(lenw, [])]
+        arr = np.array(rows, dtype=np.int8)
+        greedy = run_search_many(_acx.SEARCH_GREEDY, arr, max_nodes_to_explore, False)
+        bfs = run_search_many(_acx.SEARCH_BFS, arr, max_nodes_to_explore, True)
+        for p, (ok, path, _), (bok, _, _) in zip(rows, greedy, bfs):
+            if ok:
+                solved.append(p)
+                paths.append(to_legacy_path(path))
+            else:
+                unsolved.append(p)
+            if bok:
+                bfs_solved.append(p)
+        if verbose:
+            print(f"Miller-Schupp n = {n}: {len(rows)} presentations, {len(solved)} greedy-solved and {len(bfs_solved)} bfs-solved so far", flush=True)
+    write_literals(solved + unsolved, os.path.join(out_dir, "all_presentations.txt"))
+    write_literals(solved, os.path.join(out_dir, "greedy_solved_presentations.txt"))
+    write_literals(paths, os.path.join(out_dir, "greedy_search_paths.txt"))
+    # published order: that of all_presentations.txt
+    order = {tuple(p): k for k, p in enumerate(solved + unsolved)}
+    write_literals(sorted(bfs_solved, key=lambda p: order[tuple(p)]), os.path.join(out_dir, "bfs_solved_presentations.txt"))
+    return out_dir
+
+
+def ensure_data_file(name):
+    assert name in FILES, f"unknown data file {name}"
+    path = os.path.join(DATA_DIR, name)
+    if not os.path.exists(path):
+        print(f"{name} not found: running the Miller-Schupp searches once to produce ac_solver/search/miller_schupp/data/ ...", flush=True)
+        make_data_files()
+    return path
+
+
+if __name__ == "__main__":
+    print("wrote", make_data_files())

@@ -206,6 +206,48 @@ def extra_env_numbers(dev, pool):
     ms = e0.elapsed_time(e1)
     out["fused_rollout"] = {"envs": n, "steps": T, "env_steps_per_s": n * T / ms * 1e3, "us_per_step": ms * 1e3 / T,
                             "outputs": "f32 reward + done + truncated per step; state stays in registers (7 B/step algorithmic)"}
+    del env, tape, rw, dn, tr
+    # BASELINE config 5 shape on one GPU: PPO rollout with the reference's 2 x 256 tanh policy sampling on the device, float32
+    # observations / rewards / terminated flags written by the env kernel straight into the [T, N, ...] rollout tensors
+    try:
+        from types import SimpleNamespace
+
+        from ac_solver.agents.ppo_agent import Agent
+
+        n, T = 1 << 17, 32  # 2^20 envs over 8 GPUs = 131 072 per GPU
+        env = ACVecEnv(pool[np.arange(n) % len(pool)], horizon_length=HORIZON, obs_dtype="float32", clip_rewards=(-10, 1000), record_actions=False,
+                       final_info=False)
+        agent = Agent(SimpleNamespace(single_observation_space=SimpleNamespace(shape=(2 * L,)), single_action_space=SimpleNamespace(n=12)), [256, 256]).to(dev)
+        obs = torch.zeros((T + 1, n, 2 * L), device=dev)
+        rew = torch.zeros((T, n), device=dev)
+        term = torch.zeros((T + 1, n), dtype=torch.bool, device=dev)
+        trunc = torch.zeros(n, dtype=torch.bool, device=dev)
+        obs[0].copy_(env.reset()[0])
+
+        def rollout(with_policy):
+            for t in range(T):
+                if with_policy:
+                    with torch.no_grad():
+                        action = agent.get_action_and_value(obs[t])[0]
+                else:
+                    action = tape8[t]
+                env.step(action, out=(obs[t + 1], rew[t], term[t + 1], trunc), check_errors=False)
+
+        tape8 = torch.randint(0, 12, (T, n), dtype=torch.uint8, device=dev)
+        res = {}
+        for name, flag in (("policy_and_env", True), ("env_only", False)):
+            rollout(flag)
+            torch.cuda.synchronize()
+            e0.record()
+            rollout(flag)
+            e1.record()
+            torch.cuda.synchronize()
+            res[name] = n * T / e0.elapsed_time(e1) * 1e3
+        out["ppo_rollout"] = {"envs": n, "steps": T, "env_steps_per_s": res["policy_and_env"], "env_steps_per_s_env_kernel_only": res["env_only"],
+                              "policy": "50-256-256-12 tanh MLP actor + critic, fp32, torch", "obs": "float32 [T+1, N, 50] written by the env kernel",
+                              "algorithmic_GBps_env_only": (12 * L + 10) * res["env_only"] / 1e9}
+    except Exception as e:
+        out["ppo_rollout"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

@@ -1,0 +1,108 @@
+"""CPU tests of the PPO counterpart (ac_solver/agents): what the reference's tests/agents/test_ppo.py pins -- argparse
+defaults, layer shapes, build_network, Agent outputs, get_curr_lr -- plus GAE and the curriculum step."""
+import random
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from ac_solver.agents.args import parse_args
+from ac_solver.agents.ppo_agent import Agent, build_network, initialize_layer
+from ac_solver.agents.training import choose_next_state, compute_gae, get_curr_lr
+
+
+def _envs(width=14, n_actions=12):
+    return SimpleNamespace(single_observation_space=SimpleNamespace(shape=(width,)), single_action_space=SimpleNamespace(n=n_actions, shape=()))
+
+
+def test_parse_args_defaults_and_derived_fields():
+    a = parse_args(["--exp-name", "test_exp", "--seed", "42"])
+    assert (a.exp_name, a.seed, a.torch_deterministic, a.cuda, a.wandb_log) == ("test_exp", 42, True, True, False)
+    d = parse_args([])
+    assert (d.exp_name, d.seed, d.states_type, d.repeat_solved_prob, d.max_relator_length) == ("args", 1, "all", 0.25, 7)
+    assert d.relator1 == [1, 1, -2, -2, -2] and d.relator2 == [1, 2, 1, -2, -1, -2] and d.nodes_counts == [256, 256]
+    assert (d.horizon_length, d.num_envs, d.num_steps, d.total_timesteps) == (2000, 4, 2000, 200000)
+    assert (d.learning_rate, d.warmup_period, d.lr_decay, d.min_lr_frac, d.anneal_lr) == (2.5e-4, 0.0, "linear", 0.0, True)
+    assert (d.gamma, d.gae_lambda, d.num_minibatches, d.update_epochs) == (0.99, 0.95, 4, 1)
+    assert (d.norm_adv, d.norm_rewards, d.clip_rewards, d.min_rew, d.max_rew) == (True, False, True, -10, 1000)
+    assert (d.clip_coef, d.clip_vloss, d.ent_coef, d.vf_coef, d.max_grad_norm, d.target_kl, d.epsilon) == (0.2, True, 0.01, 0.5, 0.5, 0.01, 1e-5)
+    assert (d.is_loss_clip, d.beta, d.fixed_init_state, d.use_supermoves) == (True, 0.9, False, False)
+    assert d.batch_size == 8000 and d.minibatch_size == 2000
+    b = parse_args(["--cuda", "false", "--wandb-log", "--nodes-counts", "64", "32", "--num-envs", "8", "--num-steps", "10"])
+    assert b.cuda is False and b.wandb_log is True and b.nodes_counts == [64, 32] and b.batch_size == 80 and b.minibatch_size == 20
+    with pytest.raises(AssertionError):
+        parse_args(["--lr-decay", "step"])
+
+
+def test_layers_and_network():
+    layer = initialize_layer(nn.Linear(4, 2))
+    assert layer.weight.shape == torch.Size([2, 4]) and layer.bias.shape == torch.Size([2]) and float(layer.bias.abs().sum()) == 0.0
+    layers = build_network([4, 8, 2], 1.0)
+    assert len(layers) == 3 and isinstance(layers[0], nn.Linear) and isinstance(layers[1], nn.Tanh) and isinstance(layers[2], nn.Linear)
+    deep = build_network([50, 256, 256, 12])
+    assert [type(m).__name__ for m in deep] == ["Linear", "Tanh", "Linear", "Tanh", "Linear"]
+    assert float(deep[-1].weight.norm()) < float(deep[0].weight.norm())  # policy head: gain 0.01
+
+
+def test_agent_shapes():
+    agent = Agent(_envs(), [256, 256])
+    assert agent.critic_nodes == [14, 256, 256, 1] and agent.actor_nodes == [14, 256, 256, 12]
+    obs = torch.randn(4, 14)
+    assert agent.get_value(obs).shape == torch.Size([4, 1])
+    action, log_prob, entropy, value = agent.get_action_and_value(obs)
+    assert action.shape == log_prob.shape == entropy.shape == torch.Size([4]) and value.shape == torch.Size([4, 1])
+    _, lp2, _, _ = agent.get_action_and_value(obs, action)
+    assert torch.allclose(lp2, log_prob)
+
+
+@pytest.mark.parametrize("lr_decay, warmup, n_update, expected_lr",
+                         [("linear", 0.1, 1, 0.0), ("linear", 0.0, 1, 2.5e-04), ("cosine", 0.0, 159, 0.0), ("cosine", 0.1, 100, 9.36e-05)])
+def test_get_curr_lr_reference_cases(lr_decay, warmup, n_update, expected_lr):
+    assert np.isclose(get_curr_lr(n_update, lr_decay, warmup, 2.5e-4, 0.0, 1000 // 40), expected_lr, atol=1e-4)
+
+
+def test_get_curr_lr_schedule_shape():
+    lrs = [get_curr_lr(k, "linear", 0.2, 1.0, 0.1, 101) for k in range(1, 102)]
+    assert lrs[0] == 0.0 and abs(lrs[20] - 1.0) < 1e-12 and abs(lrs[-1] - 0.1) < 1e-12 and all(a >= b for a, b in zip(lrs[20:], lrs[21:]))
+    cos = [get_curr_lr(k, "cosine", 0.0, 1.0, 0.0, 11) for k in range(1, 12)]
+    assert abs(cos[0] - 1.0) < 1e-12 and abs(cos[5] - 0.5) < 1e-12 and abs(cos[-1]) < 1e-12
+    with pytest.raises(NotImplementedError):
+        get_curr_lr(5, "step", 0.0, 1.0, 0.0, 10)
+
+
+def test_gae_against_plain_recursion():
+    rng = np.random.default_rng(0)
+    T, N, gamma, lam = 7, 5, 0.99, 0.95
+    r, v = rng.normal(size=(T, N)), rng.normal(size=(T, N))
+    d = (rng.random((T, N)) < 0.3).astype(np.float64)
+    nv, nd = rng.normal(size=N), (rng.random(N) < 0.3).astype(np.float64)
+    adv = np.zeros((T, N))
+    for n in range(N):
+        last = 0.0
+        for t in reversed(range(T)):
+            nonterm = 1.0 - (nd[n] if t == T - 1 else d[t + 1, n])
+            nextv = nv[n] if t == T - 1 else v[t + 1, n]
+            delta = r[t, n] + gamma * nextv * nonterm - v[t, n]
+            last = adv[t, n] = delta + gamma * lam * nonterm * last
+    a, ret = compute_gae(*(torch.tensor(x) for x in (r, v, d, nv, nd)), gamma, lam)
+    assert np.allclose(a.numpy(), adv) and np.allclose(ret.numpy(), adv + v)
+
+
+def test_curriculum_walks_then_samples():
+    rec = {"solved": set(), "unsolved": set(range(5))}
+    processed = {0, 1}
+    nxt, r1 = choose_next_state(processed, 5, rec, False, 0.25)
+    assert (nxt, r1) == (2, False)
+    processed |= {2, 3, 4}
+    random.seed(0)
+    nxt, r1 = choose_next_state(processed, 5, rec, False, 0.25)
+    assert r1 is True and nxt in rec["unsolved"]  # nothing solved yet: always an unsolved state
+    rec = {"solved": {1}, "unsolved": {0, 2, 3, 4}}
+    random.seed(1)
+    picks = [choose_next_state(processed, 5, rec, True, 0.25)[0] for _ in range(400)]
+    frac_solved = sum(p == 1 for p in picks) / 400
+    assert 0.15 < frac_solved < 0.35
+    rec = {"solved": {0, 1, 2, 3, 4}, "unsolved": set()}
+    assert choose_next_state(processed, 5, rec, True, 0.25)[0] in rec["solved"]

@@ -1,0 +1,112 @@
+"""GPU tests of the PPO counterpart: the rollout tensors the training loop fills through ACVecEnv are replayed step by
+step with the CPU oracle (ACEnv.step semantics, reward clip, autoreset, curriculum restarts), and the data-file
+pipeline reproduces the reference's published Miller-Schupp results."""
+import numpy as np
+import pytest
+
+from tests.conftest import ms_pool_generator_order
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(**kw):
+    from ac_solver.agents.args import parse_args
+
+    argv = []
+    for k, v in kw.items():
+        argv += [f"--{k.replace('_', '-')}"] + [str(x) for x in (v if isinstance(v, list) else [v])]
+    return parse_args(argv)
+
+
+@pytest.mark.parametrize("is_loss_clip", [True, False])
+def test_training_loop_rollouts_replay_on_the_oracle(golden_json, is_loss_clip):
+    import torch
+    from torch.optim import Adam
+
+    from ac_solver import _acx
+    from ac_solver.agents.ppo_agent import Agent
+    from ac_solver.agents.training import ppo_training_loop
+    from ac_solver.envs.vec_env import ACVecEnv
+    from oracle import ac_oracle as O
+
+    _acx.require_device()
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    L = 18
+    easy = np.zeros(2 * L, np.int8)
+    easy[:2], easy[L] = [1, 2], 2  # <x y, y>: one move from trivial, so episodes also end by success
+    initial_states = [easy.tolist()] + [list(p) for p in pool[:9]] + [easy.tolist()]
+    N, T, H = 6, 48, 16
+    args = _args(num_envs=N, num_steps=T, total_timesteps=N * T * 3, horizon_length=H, nodes_counts=[32, 32], update_epochs=2,
+                 is_loss_clip=str(is_loss_clip).lower(), seed=3)
+    device = torch.device("cuda", 0)
+    torch.manual_seed(args.seed)
+    envs = ACVecEnv(np.asarray(initial_states[:N], np.int8), horizon_length=H, obs_dtype="float32", clip_rewards=(args.min_rew, args.max_rew),
+                    record_actions=True, final_info=False, device=device)
+    agent = Agent(envs, args.nodes_counts).to(device)
+    opt = Adam(agent.parameters(), lr=args.learning_rate, eps=args.epsilon)
+    curr = list(range(N))
+    rec = {"solved": set(), "unsolved": set(range(len(initial_states)))}
+    hist, processed, log = {}, set(curr), []
+    before = [p.detach().clone() for p in agent.parameters()]
+    stats = ppo_training_loop(envs, args, device, opt, agent, curr, rec, hist, processed, initial_states, progress=False, rollout_log=log)
+    assert len(log) == 3 and stats["charts/global_step"] == N * T * 3
+    assert all(np.isfinite(stats[k]) for k in ("losses/value_loss", "losses/policy_loss", "losses/entropy_loss", "losses/approx_kl"))
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, agent.parameters()))  # the optimizer moved the weights
+
+    max_reward = H * L * 2
+    state = np.asarray(initial_states[:N], np.int8).copy()
+    count = np.zeros(N, np.int64)
+    n_done = n_trunc = 0
+    for u, roll in enumerate(log):
+        obs = roll["obs"].astype(np.int8)
+        assert np.array_equal(obs[0], state), u
+        events = {(t, i): s for t, i, s in roll["events"]}
+        for t in range(T):
+            for i in range(N):
+                new_state, lengths = O.ACMove(int(roll["actions"][t, i]), state[i], L)
+                done = sum(lengths) == 2
+                reward = float(np.clip(max_reward if done else -sum(lengths), args.min_rew, args.max_rew))
+                assert roll["rewards"][t, i] == reward and bool(roll["term"][t + 1, i]) == done, (u, t, i)
+                count[i] += 1
+                if done or count[i] >= H:
+                    n_done, n_trunc = n_done + done, n_trunc + (not done)
+                    state[i] = np.asarray(initial_states[events[(t, i)]], np.int8)  # restart from the next curriculum state
+                    count[i] = 0
+                else:
+                    assert (t, i) not in events
+                    state[i] = new_state
+            assert np.array_equal(obs[t + 1], state), (u, t)
+    assert n_trunc > 0 and n_done > 0
+    # every solved state was recorded with the action sequence of a (shortest seen) solving episode
+    assert rec["solved"] and set(hist) == rec["solved"]
+    for s, moves in hist.items():
+        st = np.asarray(initial_states[s], np.int8)
+        for a in moves:
+            st, lengths = O.ACMove(int(a), st, L)
+        assert sum(lengths) == 2
+
+
+def test_data_files_reproduce_the_published_results(tmp_path, golden_json):
+    """greedy_search / bfs over the 1190 presentations -> the four data files; checked against index fixtures of the
+    reference's data/*.txt (order of all_presentations.txt, 533 greedy paths in the legacy encoding, 278 bfs-solved)."""
+    from ac_solver.search.miller_schupp.data_files import from_legacy_path, make_data_files, read_literals, replay_path
+
+    g = golden_json("ms_pool.json")
+    pool = ms_pool_generator_order(g)
+    out = make_data_files(out_dir=str(tmp_path), verbose=False)
+    allp = read_literals(f"{out}/all_presentations.txt")
+    solved = read_literals(f"{out}/greedy_solved_presentations.txt")
+    paths = read_literals(f"{out}/greedy_search_paths.txt")
+    bfs_solved = read_literals(f"{out}/bfs_solved_presentations.txt")
+    gs_order = g["greedy_solved_order"]
+    rest = [k for k in range(len(pool)) if k not in set(gs_order)]
+    assert allp == [pool[k] for k in gs_order] + [pool[k] for k in rest] and len(allp) == 1190
+    assert solved == allp[:533] and len(paths) == 533
+    assert bfs_solved == [pool[k] for k in g["bfs_solved_order"]] and len(bfs_solved) == 278
+    gp = golden_json("greedy_paths_1e6.json")
+    want = {r["pool_index"]: [tuple(x) for x in r["path"]] for r in gp["rows"]}
+    for k, p in zip(gs_order, paths):
+        assert p[0][0] == 0 and from_legacy_path(p) == want[k], k
+    for k in (0, 100, 532):  # a path file line really trivialises its presentation
+        path = from_legacy_path(paths[k])
+        assert replay_path(solved[k], path) == [l for _, l in path[1:]] and path[-1][1] == 2
