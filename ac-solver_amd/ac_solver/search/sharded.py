@@ -264,24 +264,36 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             lo = int(torch.searchsorted(f_gpos, i64([c0]))[0]) if f_gpos.numel() else 0
             hi = int(torch.searchsorted(f_gpos, i64([c1]))[0]) if f_gpos.numel() else 0
             solved = i64([INF])
+            # Local failures (a capacity of this rank's engine, a HIP error) must not leave the other ranks waiting in a
+            # collective: the rank keeps taking part with empty contributions and reports through the `solved` all-reduce
+            # (-1 beats every tag), so that all ranks raise together.
+            failure = None
             routed = (world > 1 or _FORCE_EXCHANGE) and hasattr(engine, "expand_routed")
-            if routed:
-                send, counts = engine.expand_routed(f_ids[lo:hi].contiguous(), f_gpos[lo:hi].contiguous(), solved, world)
-                recv = comm.all_to_all_rows(send, counts)
-            else:
-                recs = engine.expand(f_ids[lo:hi].contiguous(), f_gpos[lo:hi].contiguous(), solved)
-            if routed:
-                pass
-            elif world > 1 or _FORCE_EXCHANGE:
-                owners = owner_of(recs[:, :KW], world)
-                order = torch.argsort(owners, stable=True)
-                counts = torch.bincount(owners, minlength=world).tolist()
-                recv = comm.all_to_all_rows(recs[order].contiguous(), counts)
-            else:
-                recv = recs
-            if recv.shape[0] > engine.batch_cap:
-                raise RuntimeError(f"rank {rank}: {recv.shape[0]} records exceed the per-chunk capacity {engine.batch_cap}")
-            win = engine.insert(recv, 12 * c1)       # tags of MY new states, ascending
+            send, counts = torch.empty((0, KW + 2), dtype=torch.int64, device=dev), [0] * world
+            try:
+                if routed:
+                    send, counts = engine.expand_routed(f_ids[lo:hi].contiguous(), f_gpos[lo:hi].contiguous(), solved, world)
+                else:
+                    recs = engine.expand(f_ids[lo:hi].contiguous(), f_gpos[lo:hi].contiguous(), solved)
+                    if world > 1 or _FORCE_EXCHANGE:
+                        owners = owner_of(recs[:, :KW], world)
+                        order = torch.argsort(owners, stable=True)
+                        counts = torch.bincount(owners, minlength=world).tolist()
+                        send = recs[order].contiguous()
+            except Exception as e:  # noqa: BLE001
+                failure = e
+                send, counts = torch.empty((0, KW + 2), dtype=torch.int64, device=dev), [0] * world
+            recv = comm.all_to_all_rows(send, counts) if (world > 1 or _FORCE_EXCHANGE) else (recs if failure is None else send)
+            win = i64([])
+            try:
+                if failure is None:
+                    if recv.shape[0] > engine.batch_cap:
+                        raise RuntimeError(f"rank {rank}: {recv.shape[0]} records exceed the per-chunk capacity {engine.batch_cap}")
+                    win = engine.insert(recv, 12 * c1)       # tags of MY new states, ascending
+            except Exception as e:  # noqa: BLE001
+                failure, win = e, i64([])
+            if failure is not None:
+                solved = i64([-1])
             # one 12-bit mask per parent of the chunk; every (parent, action) child has exactly one owner, so SUM == OR
             rel = win - 12 * c0
             par, bit = rel // 12, rel % 12
@@ -292,6 +304,8 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             mask = mask.to(torch.int64)
             incl = torch.cumsum(pop12[mask], 0)      # new states up to and including each parent (global)
             solved_tag = int(comm.all_reduce(solved, "min")[0])
+            if solved_tag < 0:
+                raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure}" if failure is not None else "sharded bfs failed on another rank")
             total_new = int(incl[-1])
 
             def new_before(tag):

@@ -340,21 +340,75 @@ __global__ void __launch_bounds__(256) k_rank_sort(SearchDev<W> d, const uint32_
 namespace acx {
 
 // ---------------------------------------------------------------------------------------- host ---
+// Device blocks of finished searches are kept per host thread and handed to the next search of that thread:
+// hipMalloc / hipFree cost milliseconds and hipFree synchronises the whole device, which would serialise the
+// overlapped searches of acx_search_many.  Blocks above kMaxCachedBlock go back to the driver at once.
+struct BlockPool {
+    static constexpr size_t kMaxCachedBlock = 512ull << 20;
+    static constexpr size_t kMaxBlocks = 96;
+    std::vector<std::pair<void*, size_t>> blocks;
+    void* take(size_t bytes, size_t* got) {
+        size_t best = blocks.size();
+        for (size_t k = 0; k < blocks.size(); k++)
+            if (blocks[k].second >= bytes && blocks[k].second <= bytes + bytes / 2 + 4096 && (best == blocks.size() || blocks[k].second < blocks[best].second)) best = k;
+        if (best == blocks.size()) return nullptr;
+        void* p = blocks[best].first;
+        *got = blocks[best].second;
+        blocks[best] = blocks.back();
+        blocks.pop_back();
+        return p;
+    }
+    void give(void* p, size_t bytes) {
+        if (bytes > kMaxCachedBlock || blocks.size() >= kMaxBlocks) (void)hipFree(p);
+        else blocks.emplace_back(p, bytes);
+    }
+    void trim() {
+        for (auto& b : blocks) (void)hipFree(b.first);
+        blocks.clear();
+    }
+    // no destructor work: a worker thread trims explicitly before it ends; what the main thread still holds at process
+    // exit is released with the context (calling hipFree during runtime teardown can block)
+};
+static BlockPool& block_pool() {
+    static thread_local BlockPool pool;
+    return pool;
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
     int alloc(size_t b) {
-        bytes = b ? b : 1;
+        const size_t want = b ? b : 1;
+        p = block_pool().take(want, &bytes);
+        if (p) return ACX_OK;
+        bytes = want;
         if (hipMalloc(&p, bytes) != hipSuccess) {
-            p = nullptr;
-            return fail(ACX_E_NOMEM, "hipMalloc(%zu) failed", bytes);
+            block_pool().trim();  // give cached blocks back and retry once
+            if (hipMalloc(&p, bytes) != hipSuccess) {
+                p = nullptr;
+                return fail(ACX_E_NOMEM, "hipMalloc(%zu) failed", bytes);
+            }
         }
         return ACX_OK;
     }
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p) block_pool().give(p, bytes);
     }
 };
+
+// pinned host staging, one grow-only buffer per host thread (hipHostMalloc is as slow as hipMalloc)
+static uint8_t* pinned_staging(size_t bytes) {
+    static thread_local uint8_t* buf = nullptr;
+    static thread_local size_t cap = 0;
+    if (bytes <= cap) return buf;
+    if (buf) (void)hipHostFree(buf);
+    buf = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    if (hipHostMalloc((void**)&buf, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    cap = want;
+    return buf;
+}
 
 struct Scalars {
     unsigned long long solved_tag, shorter_tag, rank_tag;
@@ -373,7 +427,6 @@ template <typename W> struct Searcher {
 
     ~Searcher() {
         if (st) (void)hipStreamDestroy(st);
-        if (h_pin) (void)hipHostFree(h_pin);
     }
 
     int init(int L, int cyclical, int64_t max_nodes, uint32_t batch_parents, bool greedy) {
@@ -430,7 +483,8 @@ template <typename W> struct Searcher {
         uint8_t* sc = (uint8_t*)arena_scal.p;
         d_dec = (Decision*)(sc + 64);
         h_pin_bytes = sizeof(Decision) + 64 + cap_cand;
-        if (hipHostMalloc((void**)&h_pin, h_pin_bytes, hipHostMallocDefault) != hipSuccess) return fail(ACX_E_NOMEM, "hipHostMalloc(%zu) failed", h_pin_bytes);
+        h_pin = pinned_staging(h_pin_bytes);
+        if (!h_pin) return fail(ACX_E_NOMEM, "hipHostMalloc(%zu) failed", h_pin_bytes);
         d.solved_tag = (unsigned long long*)(sc + 0);
         d.shorter_tag = (unsigned long long*)(sc + 8);
         d.rank_tag = (unsigned long long*)(sc + 16);
@@ -1217,6 +1271,11 @@ extern "C" int acx_search(int kind, const int8_t* h_presentation, int L, int64_t
     return run_search<u128>(kind, h_presentation, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats);
 }
 
+extern "C" int acx_release_cached_memory(void) {
+    block_pool().trim();
+    return ACX_OK;
+}
+
 // ------------------------------------------------------------------ many independent searches ----
 #include <atomic>
 #include <thread>
@@ -1239,6 +1298,7 @@ extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t 
             rc_out[k] = acx_search(kind, h_presentations + k * 2 * L, L, max_nodes, cyclical, solved + k, path_action ? path_action + k * path_cap : nullptr,
                                    path_len ? path_len + k * path_cap : nullptr, path_cap, path_n + k, stats ? stats + k : nullptr);
         }
+        block_pool().trim();  // the blocks this thread cached go back before it ends
     };
     std::vector<std::thread> pool;
     for (int t = 0; t < n_threads; t++) pool.emplace_back(work);

@@ -261,7 +261,7 @@ def main():
                     help="graph: the K launches are captured once into a hipGraph and replayed; eager: K host launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true", help="skip the BFS / greedy frontier numbers")
-    ap.add_argument("--search-budget", type=int, default=2 * 10**7)
+    ap.add_argument("--search-budget", type=int, default=10**8)
     ap.add_argument("--no-extras", action="store_true", help="skip the 4 Mi-env and fused-rollout context numbers")
     args = ap.parse_args()
 

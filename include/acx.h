@@ -137,6 +137,10 @@ typedef struct {
 int acx_search(int kind, const int8_t *h_presentation, int L, int64_t max_nodes, int cyclical, int32_t *solved,
                int32_t *path_action, int32_t *path_len, int64_t path_cap, int64_t *path_n, acx_search_stats *stats);
 
+/* acx_search keeps the device blocks of a finished search for the next search of the same host thread (hipMalloc /
+ * hipFree are slow and hipFree synchronises the device); this returns the calling thread's cached blocks to the driver */
+int acx_release_cached_memory(void);
+
 /* n independent searches of the same kind / budget (the batch driver trivialize_miller_schupp_through_search,
  * miller_schupp.py:95-177, runs them one after another): `n_threads` host threads, each search on its own HIP
  * stream, so the small kernels of different searches overlap on the GPU.  Row k of every output belongs to

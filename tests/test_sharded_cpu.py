@@ -71,3 +71,26 @@ def test_gloo_world2_matches_reference():
     assert all(p.exitcode == 0 for p in procs)
     _check(got[0])
     assert got[0] == got[1]  # every rank returns the same answer
+
+
+def test_a_failing_rank_takes_every_rank_down_without_deadlock():
+    """A rank whose engine fails (capacity, device error) keeps taking part in the collectives of the chunk and reports
+    through the `solved` all-reduce, so that every rank raises instead of waiting forever."""
+    from ac_solver.search.sharded import bfs_sharded
+
+    class Flaky(OracleShardEngine):
+        def insert(self, recv, max_tag=None):
+            if self.rank == 1 and len(self.states) > 20:
+                raise RuntimeError("engine capacity exceeded (simulated)")
+            return super().insert(recv, max_tag)
+
+    def run(comm):
+        try:
+            bfs_sharded(AK2, 100000, comm=comm, engine_factory=Flaky, batch_parents=64)
+        except RuntimeError as e:
+            return str(e)
+        return "no error"
+
+    msgs = run_threads(3, run)
+    assert all("sharded bfs failed" in m for m in msgs), msgs
+    assert "simulated" in msgs[1]
