@@ -268,7 +268,7 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             # collective: the rank keeps taking part with empty contributions and reports through the `solved` all-reduce
             # (-1 beats every tag), so that all ranks raise together.
             failure = None
-            routed = (world > 1 or _FORCE_EXCHANGE) and hasattr(engine, "expand_routed")
+            routed = hasattr(engine, "expand_routed")  # also for one rank: the device-side routing drops unchanged children
             send, counts = torch.empty((0, KW + 2), dtype=torch.int64, device=dev), [0] * world
             try:
                 if routed:
@@ -283,7 +283,10 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             except Exception as e:  # noqa: BLE001
                 failure = e
                 send, counts = torch.empty((0, KW + 2), dtype=torch.int64, device=dev), [0] * world
-            recv = comm.all_to_all_rows(send, counts) if (world > 1 or _FORCE_EXCHANGE) else (recs if failure is None else send)
+            if world > 1 or _FORCE_EXCHANGE:
+                recv = comm.all_to_all_rows(send, counts)
+            else:
+                recv = send if (routed or failure is not None) else recs
             win = i64([])
             try:
                 if failure is None:

@@ -959,7 +959,7 @@ ACX_HD uint32_t owner_of_key(u128 k0, u128 k1, uint32_t world) {
 // child's key (region o = rec[o * region_cap ...], filled through a wave-aggregated cursor counts[o]), so the
 // all-to-all can leave without a sort by owner.  The order inside a region is arbitrary (the receiver orders by tag).
 template <typename W>
-__global__ void __launch_bounds__(256) k_shard_expand_routed(SearchDev<W> d, const int64_t* __restrict__ ids, const int64_t* __restrict__ gpos, int64_t np,
+__global__ void __launch_bounds__(1024) k_shard_expand_routed(SearchDev<W> d, const int64_t* __restrict__ ids, const int64_t* __restrict__ gpos, int64_t np,
                                                              int64_t pref_hi, uint32_t world, int64_t* __restrict__ rec, int64_t region_cap,
                                                              unsigned long long* __restrict__ counts, unsigned long long* __restrict__ solved) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -987,22 +987,33 @@ __global__ void __launch_bounds__(256) k_shard_expand_routed(SearchDev<W> d, con
         if (s.n0 + s.n1 == 2) atomicMin(solved, (unsigned long long)tag);
         if ((uint32_t)(s.n0 + s.n1) < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, (uint32_t)(s.n0 + s.n1));
     }
+    // position inside the destination region: wave-aggregated LDS counters per owner, then ONE global atomicAdd per
+    // (workgroup, owner) -- per-wave global atomics on `world` addresses serialise (1.6 ms per 12 M children)
+    __shared__ uint32_t s_cnt[64];
+    __shared__ unsigned long long s_base[64];
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t pos_in_block = 0;
     for (uint32_t o = 0; o < world; o++) {
         const unsigned long long m = __ballot(owner == o);
         if (!m) continue;
         const uint32_t lead = (uint32_t)__builtin_ctzll(m);
-        unsigned long long base = 0;
-        if (lane == lead) base = atomicAdd(&counts[o], (unsigned long long)__popcll(m));
-        base = (unsigned long long)__shfl((long long)base, (int)lead);
-        if (owner == o) {
-            const int64_t pos = (int64_t)base + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos < region_cap) {
-                int64_t* r = rec + ((int64_t)o * region_cap + pos) * (recio<W>::KW + 2);
-                recio<W>::put(r, k0, k1);
-                r[recio<W>::KW] = tag;
-                r[recio<W>::KW + 1] = pref;
-            }  // an overflow shows in counts[o] > region_cap; the host reports it
-        }
+        uint32_t base = 0;
+        if (lane == lead) base = atomicAdd(&s_cnt[o], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, (int)lead);
+        if (owner == o) pos_in_block = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (threadIdx.x < world && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (owner != 0xFFFFFFFFu) {
+        const int64_t pos = (int64_t)s_base[owner] + pos_in_block;
+        if (pos < region_cap) {
+            int64_t* r = rec + ((int64_t)owner * region_cap + pos) * (recio<W>::KW + 2);
+            recio<W>::put(r, k0, k1);
+            r[recio<W>::KW] = tag;
+            r[recio<W>::KW + 1] = pref;
+        }  // an overflow shows in counts[o] > region_cap; the host reports it
     }
 }
 
@@ -1189,7 +1200,8 @@ static int shard_expand_routed(ShardEngine<W>& E, const int64_t* ids, const int6
     ACX_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)E.world * 8, st));
     if (np <= 0) return ACX_OK;
     const int64_t m = 12 * np;
-    hipLaunchKernelGGL(k_shard_expand_routed<W>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, E.d, ids, gpos, np, (int64_t)E.rank << 40, (uint32_t)E.world,
+    if (E.world > 64) return fail(ACX_E_INVAL, "acx_shard_expand_routed handles world <= 64");
+    hipLaunchKernelGGL(k_shard_expand_routed<W>, dim3((unsigned)((m + 1023) / 1024)), dim3(1024), 0, st, E.d, ids, gpos, np, (int64_t)E.rank << 40, (uint32_t)E.world,
                        rec, region_cap, (unsigned long long*)counts, (unsigned long long*)solved);
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;

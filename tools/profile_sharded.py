@@ -32,3 +32,8 @@ else:
     res = run_threads(world, run)
     dt = max(r[0] for r in res)
     print(f"world={world} (threads on one GPU) budget={budget}: {dt:.3f}s {res[0][1]['nodes'] / dt:.3e} nodes/s")
+    if len(sys.argv) > 4:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            run_threads(world, run)
+        print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_name_column_width=60))
