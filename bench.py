@@ -106,7 +106,7 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
-    ok, path, st = bfs_sharded(p, budget, comm=comm, batch_parents=1 << 20, want_stats=True)
+    ok, path, st = bfs_sharded(p, budget, comm=comm, batch_parents=1 << 22, want_stats=True)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
