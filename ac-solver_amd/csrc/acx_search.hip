@@ -60,7 +60,27 @@ ACX_HD uint64_t fold(uint64_t k) { return k; }
 ACX_HD uint64_t fold(u128 k) { return (uint64_t)k ^ ((uint64_t)(k >> 64) * 0x9e3779b97f4a7c15ull); }
 template <typename W> ACX_HD uint64_t hash_key(W k0, W k1) { return mix64(fold(k0) * 0x9e3779b97f4a7c15ull + mix64(fold(k1))); }
 
+// Visited set of the BFS frontiers: open addressing with the FULL key inline, one entry per 32-byte (u64 keys) /
+// 64-byte (u128 keys) sector, so a probe is ONE random memory access whether the slot is empty, holds another key
+// or holds this key.  `stamp` = epoch << 32 | tag of the candidate that claimed the entry; an entry whose epoch is not
+// the running batch's is a committed state, an entry of the running epoch is provisional and folds to the minimum tag
+// among equal keys (64-bit atomicMin).  The table never stores node ids: BFS only asks "seen before?".
+template <typename W> struct TabEntry;
+template <> struct alignas(32) TabEntry<uint64_t> {
+    uint64_t k0, k1;
+    unsigned long long stamp;
+    uint64_t pad;
+};
+template <> struct alignas(64) TabEntry<u128> {
+    u128 k0, k1;
+    unsigned long long stamp;
+    uint64_t pad[3];
+};
+constexpr unsigned long long kStampEmpty = ~0ull;
+
 template <typename W> struct SearchDev {
+    TabEntry<W>* tab;  // BFS visited table (inline keys); tmask = entries - 1
+    uint32_t tmask;
     // node arena (committed nodes, id order == the reference's insertion order)
     W* k0;
     W* k1;
@@ -194,6 +214,66 @@ __global__ void __launch_bounds__(256) k_mark(SearchDev<W> d, const uint32_t* __
     if (win && bucket_len >= 0 && (int)d.clen[t] < bucket_len) atomicMin(d.shorter_tag, (unsigned long long)t);
 }
 
+// BFS: insert candidate t into the inline-key table (see TabEntry).  cslot[t] = entry that holds the key, kEmpty when
+// the candidate was skipped (a child equal to its parent).
+template <typename W>
+__global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, uint32_t epoch, int skip_known) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    if (skip_known && d.cknown[t]) {
+        d.cslot[t] = kEmpty;
+        return;
+    }
+    const W k0 = d.ck0[t], k1 = d.ck1[t];
+    const unsigned long long me = ((unsigned long long)epoch << 32) | t;
+    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.tmask;
+    for (;;) {
+        TabEntry<W>* e = d.tab + h;
+        const W e0 = e->k0, e1 = e->k1;  // one sector together with the stamp
+        unsigned long long st = e->stamp;
+        if (st == kStampEmpty) {
+            st = atomicCAS(&e->stamp, kStampEmpty, me);
+            if (st == kStampEmpty) {  // claimed: the key moves in (readers of this batch compare through the candidate arena)
+                e->k0 = k0;
+                e->k1 = k1;
+                break;
+            }
+            // lost the race: `st` is a stamp of the running epoch now
+        }
+        if ((uint32_t)(st >> 32) == epoch) {
+            const uint32_t o = (uint32_t)st;
+            if (d.ck0[o] == k0 && d.ck1[o] == k1) {
+                if (st > me) atomicMin(&e->stamp, me);
+                break;
+            }
+        } else if (e0 == k0 && e1 == k1) {
+            break;  // a committed state
+        }
+        h = (h + 1) & d.tmask;
+    }
+    d.cslot[t] = h;
+}
+
+template <typename W> __global__ void __launch_bounds__(256) k_mark_tab(SearchDev<W> d, uint32_t m, uint32_t epoch) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const uint32_t s = d.cslot[t];
+    d.cflag[t] = (s != kEmpty && d.tab[s].stamp == (((unsigned long long)epoch << 32) | t)) ? 1u : 0u;
+}
+
+template <typename W> __global__ void k_root_tab(SearchDev<W> d, W k0, W k1, uint32_t tl) {
+    d.k0[0] = k0;
+    d.k1[0] = k1;
+    d.parent[0] = kEmpty;
+    d.act[0] = 0xff;
+    d.tlen[0] = (uint8_t)tl;
+    d.depth[0] = 0;
+    TabEntry<W>* e = d.tab + ((uint32_t)hash_key<W>(k0, k1) & d.tmask);
+    e->k0 = k0;
+    e->k1 = k1;
+    e->stamp = 0;  // epoch 0 is never a running batch
+}
+
 // tag of the winner with 1-based rank r (exists and is unique)
 template <typename W> __global__ void __launch_bounds__(256) k_find_rank(SearchDev<W> d, uint32_t m, uint32_t r) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,12 +351,11 @@ __global__ void __launch_bounds__(256) k_commit(SearchDev<W> d, const uint32_t* 
     d.act[id] = (uint8_t)(t - 12u * p);
     d.tlen[id] = d.clen[t];
     d.depth[id] = d.depth[pid] + 1;
-    if (insert_now) {
+    if (insert_now == 1) {  // batch-per-launch greedy: id table
         uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.smask;
         while (atomicCAS(&d.slots[h], kEmpty, id) != kEmpty) h = (h + 1) & d.smask;
-    } else {
-        d.slots[d.cslot[t]] = id;
     }
+    // BFS (insert_now == 0): the inline-key table already holds the key under this batch's epoch; nothing to rewrite
 }
 
 // root node: id 0
@@ -429,7 +508,8 @@ template <typename W> struct Searcher {
         if (st) (void)hipStreamDestroy(st);
     }
 
-    int init(int L, int cyclical, int64_t max_nodes, uint32_t batch_parents, bool greedy) {
+    // inline_tab: BFS visited table with inline keys (TabEntry); otherwise the id table of the greedy paths
+    int init(int L, int cyclical, int64_t max_nodes, uint32_t batch_parents, bool greedy, bool inline_tab = false) {
         memset(&d, 0, sizeof(d));
         // every search owns a stream, so that searches driven from different host threads overlap on the GPU
         ACX_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -471,9 +551,15 @@ template <typename W> struct Searcher {
             d.cknown = (uint8_t*)take(b, cap_cand);
             if (pass == 0 && arena_cand.alloc(o)) return ACX_E_NOMEM;
         }
-        if (arena_tab.alloc(n_slots * 4)) return ACX_E_NOMEM;
-        d.slots = (uint32_t*)arena_tab.p;
-        d.smask = (uint32_t)(n_slots - 1);
+        if (inline_tab) {
+            if (arena_tab.alloc(n_slots * sizeof(TabEntry<W>))) return ACX_E_NOMEM;
+            d.tab = (TabEntry<W>*)arena_tab.p;
+            d.tmask = (uint32_t)(n_slots - 1);
+        } else {
+            if (arena_tab.alloc(n_slots * 4)) return ACX_E_NOMEM;
+            d.slots = (uint32_t*)arena_tab.p;
+            d.smask = (uint32_t)(n_slots - 1);
+        }
         if (greedy) {
             if (arena_btab.alloc(n_bslots * 4)) return ACX_E_NOMEM;
             d.bslots = (uint32_t*)arena_btab.p;
@@ -498,7 +584,7 @@ template <typename W> struct Searcher {
             return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan sizing failed");
         tmp_bytes = need + 256;
         if (arena_tmp.alloc(tmp_bytes)) return ACX_E_NOMEM;
-        ACX_HIP_TRY(hipMemsetAsync(d.slots, 0xff, n_slots * 4, st));
+        ACX_HIP_TRY(hipMemsetAsync(arena_tab.p, 0xff, n_slots * (inline_tab ? sizeof(TabEntry<W>) : 4), st));
         ACX_HIP_TRY(hipMemsetAsync(arena_scal.p, 0xff, 256, st));
         ACX_HIP_TRY(hipMemsetAsync(d.err, 0, 4, st));
         return ACX_OK;
@@ -697,7 +783,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
     }
     const uint32_t bmax = (uint32_t)std::min<int64_t>(std::max<int64_t>(max_nodes, 1024), greedy ? (1 << 14) : (1 << 20));
     Searcher<W> S;
-    int rc = S.init(L, cyclical, max_nodes, bmax, greedy);
+    int rc = S.init(L, cyclical, max_nodes, bmax, greedy, !greedy);
     if (rc) return rc;
     SearchDev<W>& d = S.d;
     hipStream_t st = S.st;
@@ -707,7 +793,8 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
     ACX_HIP_TRY(hipEventRecord(ev0, st));
 
     const uint32_t tl0 = (uint32_t)(root.n0 + root.n1);
-    hipLaunchKernelGGL(k_root<W>, dim3(1), dim3(1), 0, st, d, keyops<W>::make(root.w0, root.n0), keyops<W>::make(root.w1, root.n1), tl0);
+    if (greedy) hipLaunchKernelGGL(k_root<W>, dim3(1), dim3(1), 0, st, d, keyops<W>::make(root.w0, root.n0), keyops<W>::make(root.w1, root.n1), tl0);
+    else hipLaunchKernelGGL(k_root_tab<W>, dim3(1), dim3(1), 0, st, d, keyops<W>::make(root.w0, root.n0), keyops<W>::make(root.w1, root.n1), tl0);
     uint64_t nodes = 1, expanded = 0, batches = 0;
     uint32_t min_len = tl0;
     *solved = 0;
@@ -793,8 +880,8 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
             hipLaunchKernelGGL(k_insert<W>, grid, block, 0, st, d, d.bslots, bs - 1, m, 1);
             hipLaunchKernelGGL(k_mark<W>, grid, block, 0, st, d, d.bslots, m, bucket_len);
         } else {
-            hipLaunchKernelGGL(k_insert<W>, grid, block, 0, st, d, d.slots, d.smask, m, 1);
-            hipLaunchKernelGGL(k_mark<W>, grid, block, 0, st, d, d.slots, m, -1);
+            hipLaunchKernelGGL(k_insert_tab<W>, grid, block, 0, st, d, m, (uint32_t)batches, 1);  // epoch = batch number (>= 1)
+            hipLaunchKernelGGL(k_mark_tab<W>, grid, block, 0, st, d, m, (uint32_t)batches);
         }
         {
             size_t tb = S.tmp_bytes;
@@ -1058,7 +1145,6 @@ __global__ void __launch_bounds__(256) k_shard_commit(SearchDev<W> d, const int6
     d.act[id] = (uint8_t)(ctag[j] % 12);
     d.tlen[id] = d.clen[j];
     node_pref[id] = cpref[j];
-    d.slots[d.cslot[j]] = id;
 }
 
 // number of winners with tag < cutoff: candidates are in tag order, so it is cpos at the first tag >= cutoff
@@ -1086,6 +1172,7 @@ template <typename W> struct ShardEngine {
     size_t scan_tmp = 0, sort_tmp = 0;
     uint64_t cap_nodes = 0, cap_cand = 0, n_slots = 0;
     uint64_t nodes = 0;    // committed local nodes
+    uint32_t epoch = 0;    // insert calls so far (stamps of the inline-key table)
     int64_t pending = 0;   // candidates of the last insert (awaiting commit)
     int rank = 0, world = 1;
 
@@ -1133,9 +1220,9 @@ template <typename W> struct ShardEngine {
             d.clen = (uint8_t*)take(b, cap_cand);
             if (pass == 0 && cand_buf.alloc(o)) return ACX_E_NOMEM;
         }
-        if (tab_buf.alloc(n_slots * 4)) return ACX_E_NOMEM;
-        d.slots = (uint32_t*)tab_buf.p;
-        d.smask = (uint32_t)(n_slots - 1);
+        if (tab_buf.alloc(n_slots * sizeof(TabEntry<W>))) return ACX_E_NOMEM;
+        d.tab = (TabEntry<W>*)tab_buf.p;
+        d.tmask = (uint32_t)(n_slots - 1);
         if (scal_buf.alloc(256)) return ACX_E_NOMEM;
         uint8_t* sc = (uint8_t*)scal_buf.p;
         d.err = (uint32_t*)(sc + 24);
@@ -1146,7 +1233,7 @@ template <typename W> struct ShardEngine {
         if (rocprim::radix_sort_pairs(nullptr, sort_tmp, tags_in, tags_sorted, idx_in, idx_sorted, cap_cand, 0, 64, (hipStream_t) nullptr) != hipSuccess)
             return fail(ACX_E_NODEVICE, "rocprim::radix_sort_pairs sizing failed");
         if (tmp_buf.alloc(std::max(scan_tmp, sort_tmp) + 256)) return ACX_E_NOMEM;
-        ACX_HIP_TRY(hipMemset(d.slots, 0xff, n_slots * 4));
+        ACX_HIP_TRY(hipMemset(d.tab, 0xff, n_slots * sizeof(TabEntry<W>)));
         ACX_HIP_TRY(hipMemset(scal_buf.p, 0xff, 256));
         ACX_HIP_TRY(hipMemset(d.err, 0, 4));
         return ACX_OK;
@@ -1219,8 +1306,9 @@ template <typename W> static int shard_insert(ShardEngine<W>& E, const int64_t* 
     if (rocprim::radix_sort_pairs(E.tmp_buf.p, tb, E.tags_in, E.tags_sorted, E.idx_in, E.idx_sorted, (size_t)n, 0, end_bit, st) != hipSuccess)
         return fail(ACX_E_NODEVICE, "rocprim::radix_sort_pairs failed");
     hipLaunchKernelGGL(k_shard_gather<W>, grid, block, 0, st, E.d, rec, E.tags_sorted, E.idx_sorted, n, E.ctag, E.cpref);
-    hipLaunchKernelGGL(k_insert<W>, grid, block, 0, st, E.d, E.d.slots, E.d.smask, (uint32_t)n, 0);
-    hipLaunchKernelGGL(k_mark<W>, grid, block, 0, st, E.d, E.d.slots, (uint32_t)n, -1);
+    E.epoch++;
+    hipLaunchKernelGGL(k_insert_tab<W>, grid, block, 0, st, E.d, (uint32_t)n, E.epoch, 0);
+    hipLaunchKernelGGL(k_mark_tab<W>, grid, block, 0, st, E.d, (uint32_t)n, E.epoch);
     tb = E.scan_tmp;
     if (rocprim::exclusive_scan(E.tmp_buf.p, tb, E.d.cflag, E.d.cpos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st) != hipSuccess)
         return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan failed");
