@@ -423,7 +423,7 @@ namespace acx {
 // hipMalloc / hipFree cost milliseconds and hipFree synchronises the whole device, which would serialise the
 // overlapped searches of acx_search_many.  Blocks above kMaxCachedBlock go back to the driver at once.
 struct BlockPool {
-    static constexpr size_t kMaxCachedBlock = 512ull << 20;
+    static constexpr size_t kMaxCachedBlock = 1024ull << 20;
     static constexpr size_t kMaxBlocks = 96;
     std::vector<std::pair<void*, size_t>> blocks;
     void* take(size_t bytes, size_t* got) {
@@ -781,7 +781,10 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         *solved = 0;
         *path_n = 0;
     }
-    const uint32_t bmax = (uint32_t)std::min<int64_t>(std::max<int64_t>(max_nodes, 1024), greedy ? (1 << 14) : (1 << 20));
+    // parents per batch: a BFS batch far larger than the remaining budget only inflates the candidate arena and the table
+    // (every new key of a batch claims an entry, committed or not), so it is tied to the budget
+    const uint32_t bmax = greedy ? (uint32_t)std::min<int64_t>(std::max<int64_t>(max_nodes, 1024), 1 << 14)
+                                 : (uint32_t)std::min<int64_t>(std::max<int64_t>(max_nodes / 4, 1024), 1 << 20);
     Searcher<W> S;
     int rc = S.init(L, cyclical, max_nodes, bmax, greedy, !greedy);
     if (rc) return rc;

@@ -115,26 +115,42 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     out = {"bfs_sharded": {"nodes_per_s": st["nodes"] / float(dt[0]), "nodes": st["nodes"], "seconds": float(dt[0]), "levels": st["levels"],
                            "n_gpus": world, "budget": budget, "input": "AK(3) at max_relator_len=25, cyclical=False", "scaling": "strong",
-                           "exchange": "all-to-all of child records + all-gather of new-node tags per chunk (RCCL)" if world > 1 else "none"}}
-    if world == 1 and not use_dist:
-        try:  # BASELINE config 4 shape on one GPU: bfs over the 1190 Miller-Schupp presentations, searches overlapped
-            from ac_solver.search._common import run_search_many
-            from ac_solver.search.miller_schupp.miller_schupp import generate_miller_schupp_presentations
+                           "exchange": "per chunk: all-to-all of child records + all-reduce of one 12-bit child mask per parent (RCCL)" if world > 1 else "none"}}
+    # BASELINE config 4 shape: bfs over the 1190 Miller-Schupp presentations; the searches are independent, so they are dealt
+    # round-robin to the ranks (no data-path collective) and overlapped 16 at a time on each GPU.  A failure on one rank is
+    # carried through the closing all-reduce so that no rank is left waiting.
+    from ac_solver.search._common import run_search_many
+    from ac_solver.search.miller_schupp.miller_schupp import generate_miller_schupp_presentations
 
-            t0 = time.perf_counter()
-            n_solved = n_nodes = 0
-            for n in range(1, 8):
-                d = generate_miller_schupp_presentations(n, 7)
-                rows = np.array([q for w in range(1, 8) for q in d[w]], dtype=np.int8)
-                for ok, _, s1 in run_search_many(_acx.SEARCH_BFS, rows, 10**6, True, n_threads=16):
-                    n_solved += ok
-                    n_nodes += s1["nodes"]
-            dt1 = time.perf_counter() - t0
-            out["bfs_ms_sweep"] = {"searches": 1190, "budget": 10**6, "cyclical": True, "solved": int(n_solved), "published_solved": 278,
-                                   "nodes": int(n_nodes), "seconds": dt1, "nodes_per_s": n_nodes / dt1, "searches_per_s": 1190 / dt1,
-                                   "entry": "acx_search_many (16 host threads, one HIP stream per search)"}
-        except Exception as e:
-            out["bfs_ms_sweep"] = {"error": f"{type(e).__name__}: {e}"}
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    n_solved = n_nodes = n_mine = 0
+    sweep_err = None
+    try:
+        for n in range(1, 8):
+            d = generate_miller_schupp_presentations(n, 7)
+            rows = np.array([q for w in range(1, 8) for q in d[w]], dtype=np.int8)[rank::world]
+            n_mine += len(rows)
+            for ok, _, s1 in run_search_many(_acx.SEARCH_BFS, rows, 10**6, True, n_threads=16):
+                n_solved += ok
+                n_nodes += s1["nodes"]
+    except Exception as e:
+        sweep_err = e
+    tot = torch.tensor([n_solved, n_nodes, n_mine, 0.0 if sweep_err is None else 1.0], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(tot)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt1 = float(tmax[0])
+    if float(tot[3]) > 0:
+        out["bfs_ms_sweep"] = {"error": f"{type(sweep_err).__name__}: {sweep_err}" if sweep_err is not None else "failed on another rank"}
+    else:
+        out["bfs_ms_sweep"] = {"searches": int(tot[2]), "budget": 10**6, "cyclical": True, "solved": int(tot[0]), "published_solved": 278,
+                               "nodes": int(tot[1]), "seconds": dt1, "nodes_per_s": float(tot[1]) / dt1, "searches_per_s": float(tot[2]) / dt1,
+                               "n_gpus": world, "scaling": "strong",
+                               "entry": "acx_search_many per rank (16 host threads, one HIP stream per search); searches dealt round-robin to the ranks"}
+    if world == 1 and not use_dist:
         for kind, name in ((_acx.SEARCH_BFS, "bfs"), (_acx.SEARCH_GREEDY, "greedy_search")):
             run_search(kind, p, 20000, False)
             t0 = time.perf_counter()
@@ -318,6 +334,8 @@ def main():
     # graph above is being captured (envs are independent, so nothing before this point communicates)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"  # keeps RCCL's version banner out of stdout: rank 0 prints exactly one JSON line
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         dist.barrier()
         if graph is not None:
