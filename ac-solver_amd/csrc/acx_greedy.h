@@ -64,6 +64,7 @@ struct GreedyOut {
     uint32_t solved_parent, solved_action, last_parent, last_child_len;
     unsigned long long expanded, batches;
     uint32_t fallback_reason, max_bucket;
+    uint32_t path_n, pad_;
     unsigned long long sorts, big_sorts;
     uint32_t hist_sort[16];  // sorts by log2(bucket size)
     uint32_t hist_np[16];    // batches by log2(parents)
@@ -129,8 +130,11 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, ui
     return x - v;
 }
 
+// The whole search, executed by one 1024-lane workgroup.  path_act / path_len (nullable, `path_cap` entries): the
+// reference's return path, (-1, len0), (action, length) ... , written by lane 0 at the end; out->path_n is its length.
 template <typename W>
-__global__ void __launch_bounds__(kGT) k_greedy_persistent(GreedyDev<W> g, GreedyOut* __restrict__ out) {
+__device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __restrict__ out, int32_t* __restrict__ path_act,
+                                           int32_t* __restrict__ path_len, long long path_cap) {
     constexpr uint32_t SC = greedy_cfg<W>::kSortCap;
     constexpr int R = (int)(SC / kGT);                     // children per lane in a full batch
     constexpr uint32_t kPmax = (uint32_t)(R * kGT) / 12u;  // parents in a full batch
@@ -739,7 +743,39 @@ __global__ void __launch_bounds__(kGT) k_greedy_persistent(GreedyDev<W> g, Greed
         out->big_sorts = s_big_sorts;
         for (int k = 0; k < 8; k++) out->t_phase[k] = s_tph[k];
         for (int k = 0; k < 16; k++) out->hist_sort[k] = s_hist[k], out->hist_np[k] = s_hist[16 + k];
+        out->path_n = 0;
+        if (path_act && (s_status == GREEDY_SOLVED || s_status == GREEDY_BUDGET || s_status == GREEDY_EXHAUSTED)) {
+            // greedy.py:93 (success) / :121 (failure): path of a popped node + one more (action, length) entry
+            const bool ok = s_status == GREEDY_SOLVED;
+            uint32_t v = ok ? s_solved_pid : s_last_parent;
+            const uint32_t dep = d.depth[v];
+            out->path_n = dep + 2;
+            if ((long long)dep + 2 <= path_cap) {
+                path_act[dep + 1] = ok ? (int32_t)s_solved_action : 11;
+                path_len[dep + 1] = ok ? 2 : (int32_t)s_last_child_len;
+                for (uint32_t k = dep;; k--) {
+                    path_act[k] = d.act[v] == 0xff ? -1 : (int32_t)d.act[v];
+                    path_len[k] = d.tlen[v];
+                    if (k == 0) break;
+                    v = d.parent[v];
+                }
+            }
+        }
     }
+}
+
+template <typename W>
+__global__ void __launch_bounds__(kGT) k_greedy_persistent(GreedyDev<W> g, GreedyOut* __restrict__ out) {
+    greedy_run<W>(g, out, nullptr, nullptr, 0);
+}
+
+// One search per workgroup: acx_search_many runs a whole group of independent greedy searches in ONE launch (a
+// stream per search is limited by the few hardware queues a process gets; here every CU can carry a search).
+template <typename W>
+__global__ void __launch_bounds__(kGT) k_greedy_multi(const GreedyDev<W>* __restrict__ gs, GreedyOut* __restrict__ outs, int32_t* __restrict__ path_act,
+                                                      int32_t* __restrict__ path_len, long long path_cap) {
+    const GreedyDev<W> g = gs[blockIdx.x];
+    greedy_run<W>(g, outs + blockIdx.x, path_act + (size_t)blockIdx.x * path_cap, path_len + (size_t)blockIdx.x * path_cap, path_cap);
 }
 
 }  // namespace acx

@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <vector>
 
 #include "acx_common.h"
@@ -423,8 +424,8 @@ namespace acx {
 // hipMalloc / hipFree cost milliseconds and hipFree synchronises the whole device, which would serialise the
 // overlapped searches of acx_search_many.  Blocks above kMaxCachedBlock go back to the driver at once.
 struct BlockPool {
-    static constexpr size_t kMaxCachedBlock = 1024ull << 20;
-    static constexpr size_t kMaxBlocks = 96;
+    static constexpr size_t kMaxCachedBlock = 16ull << 30;  // (a thread's cache is trimmed when acx_search_many returns)
+    static constexpr size_t kMaxBlocks = 8192;
     std::vector<std::pair<void*, size_t>> blocks;
     void* take(size_t bytes, size_t* got) {
         size_t best = blocks.size();
@@ -669,40 +670,193 @@ static int err_to_rc(uint32_t e) {
                 (e & ACX_ERR_INDEX) && !(e & ACX_ERR_ASSERT) ? "IndexError" : "AssertionError");
 }
 
+// Device buffers of one greedy search on the persistent frontier
+template <typename W> struct GreedySearch {
+    Searcher<W> S;
+    DevBuf bk, bitmap, arena, gk0, gk1, gid, fpb;
+    GreedyDev<W> g;
+    // `st`: stream for the bucket-table memsets (nullptr = the search's own stream, S.st)
+    int setup(const Pres<W>& root, int L, int64_t max_nodes, int cyclical, hipStream_t st) {
+        int rc = S.init(L, cyclical, max_nodes, 1024, false);
+        if (rc) return rc;
+        if (!st) st = S.st;
+        g.d = S.d;
+        g.nlen = (uint32_t)(2 * L + 1);
+        g.max_nodes = (long long)max_nodes;
+        g.root_len = (uint32_t)(root.n0 + root.n1);
+        const uint64_t arena_entries = std::min<uint64_t>(8ull * (uint64_t)std::max<int64_t>(max_nodes, 1) + (1ull << 20), 1ull << 31);
+        g.arena_cap = (uint32_t)arena_entries;
+        if (fpb.alloc((S.n_slots + 8) * 2)) return ACX_E_NOMEM;  // never read behind an empty slot, so no initialisation
+        g.fp = (uint16_t*)fpb.p;
+        g.root_k0 = keyops<W>::make(root.w0, root.n0);
+        g.root_k1 = keyops<W>::make(root.w1, root.n1);
+        const size_t sort_cap = (size_t)std::max<int64_t>(max_nodes, 1) + 64;  // a bucket never holds more than all nodes
+        if (gk0.alloc(sort_cap * sizeof(W)) || gk1.alloc(sort_cap * sizeof(W)) || gid.alloc(sort_cap * 4)) return ACX_E_NOMEM;
+        g.gk0 = (W*)gk0.p;
+        g.gk1 = (W*)gk1.p;
+        g.gid = (uint32_t*)gid.p;
+        const size_t bk_bytes = (size_t)g.nlen * kDepthCap * sizeof(BucketRec), bm_bytes = (size_t)g.nlen * (kDepthCap / 32) * 4;
+        if (bk.alloc(bk_bytes) || bitmap.alloc(bm_bytes) || arena.alloc(arena_entries * 4)) return ACX_E_NOMEM;
+        g.bk = (BucketRec*)bk.p;
+        g.bitmap = (uint32_t*)bitmap.p;
+        g.arena = (uint32_t*)arena.p;
+        ACX_HIP_TRY(hipMemsetAsync(bk.p, 0, bk_bytes, st));
+        ACX_HIP_TRY(hipMemsetAsync(bitmap.p, 0, bm_bytes, st));
+        return ACX_OK;
+    }
+};
+
+// A group of independent greedy searches in one launch of k_greedy_multi (one workgroup each).  rc_out[k] = ACX_OK /
+// ACX_E_CAPACITY (path buffer) / ACX_E_ROWERR; need_rerun[k] = 1 when search k must be repeated on the single-search path
+// (a capacity of the persistent kernel was exceeded).
+template <typename W>
+static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_nodes, int cyclical, int32_t* solved, int32_t* path_action, int32_t* path_len,
+                            int64_t path_cap, int64_t* path_n, acx_search_stats* stats, int32_t* rc_out, uint8_t* need_rerun) {
+    // ONE device allocation for the whole group (thousands of hipMalloc calls would cost more than the searches):
+    // per search the node arrays, the id table + fingerprints, the bucket table / bitmap / arena and the sort scratch;
+    // the regions that need initialising (tables, bucket records, bitmaps) are contiguous over the group
+    const uint64_t cap_nodes = (uint64_t)max_nodes + 64 + 12 * 1024;
+    uint64_t n_slots = 1024;
+    while (n_slots < 2 * (cap_nodes + 12288)) n_slots <<= 1;
+    if (n_slots > (1ull << 31)) return fail(ACX_E_INVAL, "acx_search_many: budget too large for 32-bit node ids");
+    const uint32_t nlen = (uint32_t)(2 * L + 1);
+    const uint64_t arena_entries = std::min<uint64_t>(8ull * (uint64_t)std::max<int64_t>(max_nodes, 1) + (1ull << 20), 1ull << 31);
+    const uint64_t sort_cap = (uint64_t)std::max<int64_t>(max_nodes, 1) + 64;
+    auto up = [](uint64_t b) { return (b + 255) / 256 * 256; };
+    const uint64_t b_slots = up(n_slots * 4), b_bk = up((uint64_t)nlen * kDepthCap * sizeof(BucketRec)), b_bm = up((uint64_t)nlen * (kDepthCap / 32) * 4);
+    const uint64_t b_fp = up((n_slots + 8) * 2), b_arena = up(arena_entries * 4), b_key = up(cap_nodes * sizeof(W)), b_u32 = up(cap_nodes * 4), b_u8 = up(cap_nodes);
+    const uint64_t b_gk = up(sort_cap * sizeof(W)), b_gid = up(sort_cap * 4);
+    const uint64_t per_rest = b_fp + b_arena + 2 * b_key + 2 * b_u32 + 2 * b_u8 + 2 * b_gk + b_gid;
+    const uint64_t total = (uint64_t)n * (b_slots + b_bk + b_bm + per_rest);
+    DevBuf big;
+    if (big.alloc(total)) return ACX_E_NOMEM;
+    uint8_t* base = (uint8_t*)big.p;
+    uint8_t* p_slots = base;
+    uint8_t* p_bk = p_slots + (uint64_t)n * b_slots;
+    uint8_t* p_bm = p_bk + (uint64_t)n * b_bk;
+    uint8_t* p_rest = p_bm + (uint64_t)n * b_bm;
+    std::vector<GreedyDev<W>> hdev((size_t)n);
+    hipStream_t st = nullptr;
+    ACX_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    struct StreamGuard {
+        hipStream_t s;
+        ~StreamGuard() { (void)hipStreamDestroy(s); }
+    } guard{st};
+    ACX_HIP_TRY(hipMemsetAsync(p_slots, 0xff, (uint64_t)n * b_slots, st));
+    ACX_HIP_TRY(hipMemsetAsync(p_bk, 0, (uint64_t)n * (b_bk + b_bm), st));
+    for (int64_t k = 0; k < n; k++) {
+        need_rerun[k] = 0;
+        rc_out[k] = ACX_OK;
+        solved[k] = 0;
+        path_n[k] = 0;
+        Pres<W> root;
+        bool ok = pack_relator<W>(rows + k * 2 * L, L, root.w0, root.n0);
+        ok = pack_relator<W>(rows + k * 2 * L + L, L, root.w1, root.n1) && ok;
+        if (!ok) return fail(ACX_E_ROWERR, "acx_search_many: presentation %lld is not a zero-padded word pair over {+-1,+-2}", (long long)k);
+        GreedyDev<W>& g = hdev[k];
+        memset(&g, 0, sizeof(g));
+        uint8_t* q = p_rest + (uint64_t)k * per_rest;
+        auto take = [&](uint64_t bytes) {
+            uint8_t* r = q;
+            q += bytes;
+            return r;
+        };
+        g.d.slots = (uint32_t*)(p_slots + (uint64_t)k * b_slots);
+        g.d.smask = (uint32_t)(n_slots - 1);
+        g.bk = (BucketRec*)(p_bk + (uint64_t)k * b_bk);
+        g.bitmap = (uint32_t*)(p_bm + (uint64_t)k * b_bm);
+        g.fp = (uint16_t*)take(b_fp);
+        g.arena = (uint32_t*)take(b_arena);
+        g.d.k0 = (W*)take(b_key);
+        g.d.k1 = (W*)take(b_key);
+        g.d.parent = (uint32_t*)take(b_u32);
+        g.d.depth = (uint32_t*)take(b_u32);
+        g.d.act = take(b_u8);
+        g.d.tlen = take(b_u8);
+        g.gk0 = (W*)take(b_gk);
+        g.gk1 = (W*)take(b_gk);
+        g.gid = (uint32_t*)take(b_gid);
+        g.d.L = L;
+        g.d.cyclical = cyclical;
+        g.arena_cap = (uint32_t)arena_entries;
+        g.nlen = nlen;
+        g.max_nodes = (long long)max_nodes;
+        g.root_len = (uint32_t)(root.n0 + root.n1);
+        g.root_k0 = keyops<W>::make(root.w0, root.n0);
+        g.root_k1 = keyops<W>::make(root.w1, root.n1);
+    }
+    const int64_t pc = std::max<int64_t>(path_cap, 1);
+    DevBuf ddev, douts, dpa, dpl;
+    if (ddev.alloc((size_t)n * sizeof(GreedyDev<W>)) || douts.alloc((size_t)n * sizeof(GreedyOut)) || dpa.alloc((size_t)n * pc * 4) || dpl.alloc((size_t)n * pc * 4))
+        return ACX_E_NOMEM;
+    ACX_HIP_TRY(hipMemcpyAsync(ddev.p, hdev.data(), (size_t)n * sizeof(GreedyDev<W>), hipMemcpyHostToDevice, st));
+    ACX_HIP_TRY(hipMemsetAsync(douts.p, 0, (size_t)n * sizeof(GreedyOut), st));
+    hipEvent_t ev0, ev1;
+    ACX_HIP_TRY(hipEventCreate(&ev0));
+    ACX_HIP_TRY(hipEventCreate(&ev1));
+    ACX_HIP_TRY(hipEventRecord(ev0, st));
+    hipLaunchKernelGGL(k_greedy_multi<W>, dim3((unsigned)n), dim3(kGT), 0, st, (const GreedyDev<W>*)ddev.p, (GreedyOut*)douts.p, (int32_t*)dpa.p, (int32_t*)dpl.p,
+                       (long long)pc);
+    ACX_HIP_TRY(hipGetLastError());
+    ACX_HIP_TRY(hipEventRecord(ev1, st));
+    std::vector<GreedyOut> o((size_t)n);
+    std::vector<int32_t> pa((size_t)n * pc), pl((size_t)n * pc);
+    ACX_HIP_TRY(hipMemcpyAsync(o.data(), douts.p, (size_t)n * sizeof(GreedyOut), hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipMemcpyAsync(pa.data(), dpa.p, (size_t)n * pc * 4, hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipMemcpyAsync(pl.data(), dpl.p, (size_t)n * pc * 4, hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    ACX_HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    for (int64_t k = 0; k < n; k++) {
+        const GreedyOut& r = o[k];
+        if (r.status == GREEDY_FALLBACK) {
+            need_rerun[k] = 1;
+            continue;
+        }
+        if (r.status == GREEDY_MOVE_ERROR) {
+            rc_out[k] = err_to_rc(r.err);
+            continue;
+        }
+        if (r.status != GREEDY_SOLVED && r.status != GREEDY_BUDGET && r.status != GREEDY_EXHAUSTED) {
+            rc_out[k] = fail(ACX_E_NODEVICE, "greedy frontier kernel ended in state %u", r.status);
+            continue;
+        }
+        solved[k] = r.status == GREEDY_SOLVED ? 1 : 0;
+        path_n[k] = r.path_n;
+        if ((int64_t)r.path_n > path_cap) {
+            rc_out[k] = fail(ACX_E_CAPACITY, "path has %u entries, buffer holds %lld", r.path_n, (long long)path_cap);
+        } else if (path_action && path_len) {
+            memcpy(path_action + k * path_cap, pa.data() + k * pc, (size_t)r.path_n * 4);
+            memcpy(path_len + k * path_cap, pl.data() + k * pc, (size_t)r.path_n * 4);
+        }
+        if (stats) {
+            stats[k].nodes = (int64_t)r.nodes;
+            stats[k].expanded = (int64_t)r.expanded;
+            stats[k].children = (int64_t)r.expanded * 12;
+            stats[k].levels = (int64_t)r.batches;
+            stats[k].min_len = (int32_t)r.min_len;
+            stats[k].seconds = ms * 1e-3;  // of the whole group launch
+        }
+    }
+    return ACX_OK;
+}
+
 // greedy_search on the device-resident priority frontier (acx_greedy.h).  *handled = false when the persistent
 // kernel ran out of one of its capacities: the caller then reruns the search on the batch-per-launch path.
 template <typename W>
 static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int cyclical, int32_t* solved, int32_t* path_action, int32_t* path_len,
                              int64_t path_cap, int64_t* path_n, acx_search_stats* stats, bool* handled) {
     *handled = false;
-    Searcher<W> S;
-    int rc = S.init(L, cyclical, max_nodes, 1024, false);
+    GreedySearch<W> G;
+    int rc = G.setup(root, L, max_nodes, cyclical, nullptr);
     if (rc) return rc;
+    Searcher<W>& S = G.S;
+    GreedyDev<W>& g = G.g;
     hipStream_t st = S.st;
-    GreedyDev<W> g;
-    g.d = S.d;
-    g.nlen = (uint32_t)(2 * L + 1);
-    g.max_nodes = (long long)max_nodes;
-    g.root_len = (uint32_t)(root.n0 + root.n1);
-    const uint64_t arena_entries = std::min<uint64_t>(8ull * (uint64_t)std::max<int64_t>(max_nodes, 1) + (1ull << 20), 1ull << 31);
-    g.arena_cap = (uint32_t)arena_entries;
-    DevBuf bk, bitmap, arena, outb, gk0, gk1, gid, fpb;
-    if (fpb.alloc((S.n_slots + 8) * 2)) return ACX_E_NOMEM;  // never read behind an empty slot, so no initialisation
-    g.fp = (uint16_t*)fpb.p;
-    g.root_k0 = keyops<W>::make(root.w0, root.n0);
-    g.root_k1 = keyops<W>::make(root.w1, root.n1);
-    const size_t sort_cap = (size_t)std::max<int64_t>(max_nodes, 1) + 64;  // a bucket never holds more than all nodes
-    if (gk0.alloc(sort_cap * sizeof(W)) || gk1.alloc(sort_cap * sizeof(W)) || gid.alloc(sort_cap * 4)) return ACX_E_NOMEM;
-    g.gk0 = (W*)gk0.p;
-    g.gk1 = (W*)gk1.p;
-    g.gid = (uint32_t*)gid.p;
-    const size_t bk_bytes = (size_t)g.nlen * kDepthCap * sizeof(BucketRec), bm_bytes = (size_t)g.nlen * (kDepthCap / 32) * 4;
-    if (bk.alloc(bk_bytes) || bitmap.alloc(bm_bytes) || arena.alloc(arena_entries * 4) || outb.alloc(sizeof(GreedyOut))) return ACX_E_NOMEM;
-    g.bk = (BucketRec*)bk.p;
-    g.bitmap = (uint32_t*)bitmap.p;
-    g.arena = (uint32_t*)arena.p;
-    ACX_HIP_TRY(hipMemsetAsync(bk.p, 0, bk_bytes, st));
-    ACX_HIP_TRY(hipMemsetAsync(bitmap.p, 0, bm_bytes, st));
+    DevBuf outb;
+    if (outb.alloc(sizeof(GreedyOut))) return ACX_E_NOMEM;
     ACX_HIP_TRY(hipMemsetAsync(outb.p, 0, sizeof(GreedyOut), st));
     hipEvent_t ev0, ev1;
     ACX_HIP_TRY(hipEventCreate(&ev0));
@@ -1390,6 +1544,32 @@ extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t 
     if (n < 0 || !h_presentations || !solved || !path_n || !rc_out || path_cap < 0) return fail(ACX_E_INVAL, "acx_search_many: bad argument");
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 64) n_threads = 64;
+    if (kind == ACX_SEARCH_GREEDY && n > 1 && L >= 1 && L <= 61 && !getenv("ACX_GREEDY_HOST")) {
+        // greedy: groups of searches in ONE launch of the persistent frontier kernel, one workgroup per search
+        if (max_nodes < 0) max_nodes = 0;
+        const double per_search = 160.0 * (double)std::max<int64_t>(max_nodes, 1) + 96e6;  // bytes, generous (run_greedy_group computes the exact figure)
+        const int64_t group = (int64_t)std::max(1.0, std::min(256.0, 12e9 / per_search));
+        std::vector<uint8_t> rerun((size_t)n, 0);
+        for (int64_t k0 = 0; k0 < n; k0 += group) {
+            const int64_t m = std::min<int64_t>(group, n - k0);
+            int32_t* pa = path_action ? path_action + k0 * path_cap : nullptr;
+            int32_t* pl = path_len ? path_len + k0 * path_cap : nullptr;
+            acx_search_stats* ps = stats ? stats + k0 : nullptr;
+            const int rc = L <= 29 ? run_greedy_group<uint64_t>(h_presentations + k0 * 2 * L, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0,
+                                                                ps, rc_out + k0, rerun.data() + k0)
+                                   : run_greedy_group<u128>(h_presentations + k0 * 2 * L, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps,
+                                                            rc_out + k0, rerun.data() + k0);
+            if (rc != ACX_OK) return rc;
+        }
+        for (int64_t k = 0; k < n; k++)
+            if (rerun[k])
+                rc_out[k] = acx_search(kind, h_presentations + k * 2 * L, L, max_nodes, cyclical, solved + k, path_action ? path_action + k * path_cap : nullptr,
+                                       path_len ? path_len + k * path_cap : nullptr, path_cap, path_n + k, stats ? stats + k : nullptr);
+        block_pool().trim();
+        for (int64_t k = 0; k < n; k++)
+            if (rc_out[k] != ACX_OK && rc_out[k] != ACX_E_CAPACITY) return fail(ACX_E_ROWERR, "acx_search_many: search %lld failed with code %d", (long long)k, rc_out[k]);
+        return ACX_OK;
+    }
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::atomic<int64_t> next(0);
