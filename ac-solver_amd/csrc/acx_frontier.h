@@ -1,0 +1,459 @@
+// acx_frontier.h -- what the search translation units share: packed keys, the visited tables, the batch kernels of
+// the BFS / greedy frontiers (expand, insert with minimum-tag resolution, mark, commit, decide) and the device
+// block pool.  Included by acx_search.hip (single-GPU searches) and acx_shard.hip (per-GPU engine of the sharded BFS).
+#pragma once
+#include <string.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include <stdlib.h>
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <vector>
+#include "acx_common.h"
+#include "acx_word.h"
+
+namespace acx {
+
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kProv = 0x80000000u;  // provisional id = kProv | tag (candidate of the running batch)
+constexpr uint64_t kNoTag = ~0ull;
+
+template <typename W> struct keyops {
+    static constexpr int kShift = wtraits<W>::kBits - 6;
+    static ACX_HD W make(W w, int n) { return w | ((W)n << kShift); }
+    static ACX_HD int len(W k) { return (int)(uint32_t)(k >> kShift); }
+    static ACX_HD W word(W k) { return k & (((W)1 << kShift) - 1); }
+};
+
+ACX_HD uint64_t mix64(uint64_t x) {
+    x ^= x >> 32;
+    x *= 0xd6e8feb86659fd93ull;
+    x ^= x >> 32;
+    x *= 0xd6e8feb86659fd93ull;
+    x ^= x >> 32;
+    return x;
+}
+ACX_HD uint64_t fold(uint64_t k) { return k; }
+ACX_HD uint64_t fold(u128 k) { return (uint64_t)k ^ ((uint64_t)(k >> 64) * 0x9e3779b97f4a7c15ull); }
+template <typename W> ACX_HD uint64_t hash_key(W k0, W k1) { return mix64(fold(k0) * 0x9e3779b97f4a7c15ull + mix64(fold(k1))); }
+
+// Visited set of the BFS frontiers: open addressing with the FULL key inline, one entry per 32-byte (u64 keys) /
+// 64-byte (u128 keys) sector, so a probe is ONE random memory access whether the slot is empty, holds another key
+// or holds this key.  `stamp` = epoch << 32 | tag of the candidate that claimed the entry; an entry whose epoch is not
+// the running batch's is a committed state, an entry of the running epoch is provisional and folds to the minimum tag
+// among equal keys (64-bit atomicMin).  The table never stores node ids: BFS only asks "seen before?".
+template <typename W> struct TabEntry;
+template <> struct alignas(32) TabEntry<uint64_t> {
+    uint64_t k0, k1;
+    unsigned long long stamp;
+    uint64_t pad;
+};
+template <> struct alignas(64) TabEntry<u128> {
+    u128 k0, k1;
+    unsigned long long stamp;
+    uint64_t pad[3];
+};
+constexpr unsigned long long kStampEmpty = ~0ull;
+
+template <typename W> struct SearchDev {
+    TabEntry<W>* tab;  // BFS visited table (inline keys); tmask = entries - 1
+    uint32_t tmask;
+    // node arena (committed nodes, id order == the reference's insertion order)
+    W* k0;
+    W* k1;
+    uint32_t* parent;
+    uint8_t* act;
+    uint8_t* tlen;
+    uint32_t* depth;
+    // visited table: node id / provisional id / kEmpty
+    uint32_t* slots;
+    uint32_t smask;
+    // batch-local table (greedy) for the in-batch dedup
+    uint32_t* bslots;
+    uint32_t bmask;
+    // candidates of the running batch, indexed by tag
+    W* ck0;
+    W* ck1;
+    uint8_t* clen;
+    uint32_t* cslot;
+    uint32_t* cflag;  // 1 = winner / new
+    uint32_t* cpos;   // exclusive scan of cflag
+    uint8_t* cknown;  // greedy: already in the visited table
+    // device scalars
+    unsigned long long* solved_tag;   // min tag with total length 2
+    unsigned long long* shorter_tag;  // greedy: min tag of a NEW child shorter than the bucket
+    uint32_t* err;
+    uint32_t* min_len;
+    int32_t L;
+    int32_t cyclical;
+};
+
+template <typename W> __device__ __forceinline__ void key_to_pres(W k0, W k1, Pres<W>& s) {
+    s.w0 = keyops<W>::word(k0);
+    s.n0 = keyops<W>::len(k0);
+    s.w1 = keyops<W>::word(k1);
+    s.n1 = keyops<W>::len(k1);
+}
+
+// one lane per (parent, action): tag t = 12 * p + a
+template <typename W>
+__global__ void __launch_bounds__(256) k_expand(SearchDev<W> d, const uint32_t* __restrict__ plist, uint32_t pbegin, uint32_t np) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t tl = 0xFFFFFFFFu;
+    if (t < 12u * np) {
+        const uint32_t p = t / 12u, a = t - 12u * p;
+        const uint32_t pid = plist ? plist[p] : pbegin + p;
+        Pres<W> s;
+        const W pk0 = d.k0[pid], pk1 = d.k1[pid];
+        key_to_pres<W>(pk0, pk1, s);
+        const int e = apply_move<W, true>(s, (int)a, d.L, d.cyclical != 0);
+        if (e) atomicOr(d.err, (uint32_t)e);  // the reference's ACMove raises: the whole search raises
+        const W c0 = keyops<W>::make(s.w0, s.n0), c1 = keyops<W>::make(s.w1, s.n1);
+        d.ck0[t] = c0;
+        d.ck1[t] = c1;
+        d.cknown[t] = (c0 == pk0 && c1 == pk1) ? 1 : 0;  // an unchanged state is its (visited) parent: k_insert skips the probe
+        tl = (uint32_t)(s.n0 + s.n1);
+        d.clen[t] = (uint8_t)tl;
+        if (tl == 2) atomicMin(d.solved_tag, (unsigned long long)t);  // breadth_first.py:84 / greedy.py:91
+    }
+    // wave-level min before the atomic keeps contention low (all 64 lanes take part)
+    uint32_t m = tl;
+    for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
+    // one contended address: only waves that would actually lower the minimum issue the atomic (a plain, possibly
+    // stale read can only over-estimate the current minimum, so no update is lost)
+    if ((threadIdx.x & 63) == 0 && m < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, m);
+}
+
+template <typename W> __device__ __forceinline__ bool key_equals(const SearchDev<W>& d, uint32_t id, W k0, W k1) {
+    if (id & kProv) {
+        const uint32_t t = id & ~kProv;
+        return d.ck0[t] == k0 && d.ck1[t] == k1;
+    }
+    return d.k0[id] == k0 && d.k1[id] == k1;
+}
+
+// Insert candidate t into `slots` with min-tag resolution among equal keys.  cslot[t] = slot holding the key.
+// Occupants may be committed node ids (always win) or provisional ids of this batch.
+template <typename W>
+__global__ void __launch_bounds__(256) k_insert(SearchDev<W> d, uint32_t* __restrict__ slots, uint32_t mask, uint32_t m, int skip_known) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    if (skip_known && d.cknown[t]) {
+        d.cslot[t] = kEmpty;
+        return;
+    }
+    const W k0 = d.ck0[t], k1 = d.ck1[t];
+    const uint32_t me = kProv | t;
+    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & mask;
+    for (;;) {
+        uint32_t v = slots[h];
+        if (v == kEmpty) {
+            v = atomicCAS(&slots[h], kEmpty, me);
+            if (v == kEmpty) break;  // claimed
+        }
+        if (key_equals<W>(d, v, k0, k1)) {
+            if ((v & kProv) && v > me) atomicMin(&slots[h], me);
+            break;
+        }
+        h = (h + 1) & mask;
+    }
+    d.cslot[t] = h;
+}
+
+// read-only membership test against the visited table (greedy: speculative batches must not touch it)
+template <typename W> __global__ void __launch_bounds__(256) k_lookup(SearchDev<W> d, uint32_t m) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const W k0 = d.ck0[t], k1 = d.ck1[t];
+    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.smask;
+    uint8_t known = 0;
+    for (;;) {
+        const uint32_t v = d.slots[h];
+        if (v == kEmpty) break;
+        if (key_equals<W>(d, v, k0, k1)) {
+            known = 1;
+            break;
+        }
+        h = (h + 1) & d.smask;
+    }
+    d.cknown[t] = known;
+}
+
+// cflag[t] = 1 iff candidate t is the first discoverer of a state not seen before
+template <typename W>
+__global__ void __launch_bounds__(256) k_mark(SearchDev<W> d, const uint32_t* __restrict__ slots, uint32_t m, int bucket_len) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const uint32_t s = d.cslot[t];
+    const uint32_t win = (s != kEmpty && slots[s] == (kProv | t)) ? 1u : 0u;
+    d.cflag[t] = win;
+    if (win && bucket_len >= 0 && (int)d.clen[t] < bucket_len) atomicMin(d.shorter_tag, (unsigned long long)t);
+}
+
+// BFS: insert candidate t into the inline-key table (see TabEntry).  cslot[t] = entry that holds the key, kEmpty when
+// the candidate was skipped (a child equal to its parent).
+template <typename W>
+__global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, uint32_t epoch, int skip_known) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    if (skip_known && d.cknown[t]) {
+        d.cslot[t] = kEmpty;
+        return;
+    }
+    const W k0 = d.ck0[t], k1 = d.ck1[t];
+    const unsigned long long me = ((unsigned long long)epoch << 32) | t;
+    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.tmask;
+    for (;;) {
+        TabEntry<W>* e = d.tab + h;
+        const W e0 = e->k0, e1 = e->k1;  // one sector together with the stamp
+        unsigned long long st = e->stamp;
+        if (st == kStampEmpty) {
+            st = atomicCAS(&e->stamp, kStampEmpty, me);
+            if (st == kStampEmpty) {  // claimed: the key moves in (readers of this batch compare through the candidate arena)
+                e->k0 = k0;
+                e->k1 = k1;
+                break;
+            }
+            // lost the race: `st` is a stamp of the running epoch now
+        }
+        if ((uint32_t)(st >> 32) == epoch) {
+            const uint32_t o = (uint32_t)st;
+            if (d.ck0[o] == k0 && d.ck1[o] == k1) {
+                if (st > me) atomicMin(&e->stamp, me);
+                break;
+            }
+        } else if (e0 == k0 && e1 == k1) {
+            break;  // a committed state
+        }
+        h = (h + 1) & d.tmask;
+    }
+    d.cslot[t] = h;
+}
+
+template <typename W> __global__ void __launch_bounds__(256) k_mark_tab(SearchDev<W> d, uint32_t m, uint32_t epoch) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const uint32_t s = d.cslot[t];
+    d.cflag[t] = (s != kEmpty && d.tab[s].stamp == (((unsigned long long)epoch << 32) | t)) ? 1u : 0u;
+}
+
+template <typename W> __global__ void k_root_tab(SearchDev<W> d, W k0, W k1, uint32_t tl) {
+    d.k0[0] = k0;
+    d.k1[0] = k1;
+    d.parent[0] = kEmpty;
+    d.act[0] = 0xff;
+    d.tlen[0] = (uint8_t)tl;
+    d.depth[0] = 0;
+    TabEntry<W>* e = d.tab + ((uint32_t)hash_key<W>(k0, k1) & d.tmask);
+    e->k0 = k0;
+    e->k1 = k1;
+    e->stamp = 0;  // epoch 0 is never a running batch
+}
+
+// What the reference does with this batch, decided on the device so that the host needs ONE read-back per batch.
+struct Decision {
+    uint32_t p_end;       // last parent of the batch that the reference pops
+    uint32_t cutoff;      // candidates with tag < cutoff are committed
+    uint32_t committed;   // number of winners below cutoff
+    uint32_t total;       // winners in the whole batch
+    uint32_t budget_hit;  // len(tree_nodes) >= max_nodes after parent p_end
+    uint32_t solved;      // a child of total length 2 was generated at or before parent p_end
+    uint32_t solved_tag;
+    uint32_t last_child_len;  // total length of child (p_end, action 11): greedy.py:121
+    uint32_t err;
+    uint32_t min_len;
+};
+
+template <typename W>
+__global__ void k_decide(SearchDev<W> d, uint32_t m, uint32_t np, unsigned long long nodes, long long max_nodes, int greedy, Decision* __restrict__ out) {
+    const uint32_t total = d.cpos[m - 1] + d.cflag[m - 1];
+    uint32_t p_end = np - 1, budget_hit = 0;
+    const unsigned long long shorter = *d.shorter_tag, solved_tag = *d.solved_tag;
+    if (greedy && shorter != kNoTag) p_end = min(p_end, (uint32_t)(shorter / 12));  // the shorter new child is the heap's next minimum
+    if ((long long)nodes >= max_nodes) {  // only possible for the very first parent (budget <= 1)
+        p_end = 0;
+        budget_hit = 1;
+    } else if ((long long)(nodes + total) >= max_nodes) {
+        // first candidate whose inclusive winner count reaches `need` (cpos + cflag is non-decreasing in t)
+        const uint32_t need = (uint32_t)(max_nodes - (long long)nodes);
+        uint32_t lo = 0, hi = m - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (d.cpos[mid] + d.cflag[mid] >= need) hi = mid;
+            else lo = mid + 1;
+        }
+        const uint32_t pb = lo / 12;
+        if (pb <= p_end) {
+            p_end = pb;
+            budget_hit = 1;
+        }
+    }
+    const uint32_t is_solved = solved_tag != kNoTag && (uint32_t)(solved_tag / 12) <= p_end;
+    const uint32_t cutoff = is_solved ? (uint32_t)solved_tag : 12u * (p_end + 1);  // on success only stats need the commit
+    out->p_end = is_solved ? (uint32_t)(solved_tag / 12) : p_end;
+    out->cutoff = cutoff;
+    out->committed = cutoff >= m ? total : d.cpos[cutoff];
+    out->total = total;
+    out->budget_hit = budget_hit;
+    out->solved = is_solved;
+    out->solved_tag = (uint32_t)solved_tag;
+    out->last_child_len = d.clen[12u * p_end + 11];
+    out->err = *d.err;
+    out->min_len = *d.min_len;
+}
+
+// Winners below `cutoff` become nodes base + cpos[t].  BFS: their table slot (already claimed in the visited
+// table) is rewritten to the final id.  Greedy: the key is inserted into the visited table now (it is known
+// to be absent and the committed keys are pairwise distinct, so a plain CAS claim is enough).
+template <typename W>
+__global__ void __launch_bounds__(256) k_commit(SearchDev<W> d, const uint32_t* __restrict__ plist, uint32_t pbegin, const Decision* __restrict__ dec, uint32_t m,
+                                                uint32_t base, int insert_now) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m || t >= dec->cutoff || !d.cflag[t]) return;
+    const uint32_t id = base + d.cpos[t];
+    const uint32_t p = t / 12u;
+    const uint32_t pid = plist ? plist[p] : pbegin + p;
+    const W k0 = d.ck0[t], k1 = d.ck1[t];
+    d.k0[id] = k0;
+    d.k1[id] = k1;
+    d.parent[id] = pid;
+    d.act[id] = (uint8_t)(t - 12u * p);
+    d.tlen[id] = d.clen[t];
+    d.depth[id] = d.depth[pid] + 1;
+    if (insert_now == 1) {  // batch-per-launch greedy: id table
+        uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.smask;
+        while (atomicCAS(&d.slots[h], kEmpty, id) != kEmpty) h = (h + 1) & d.smask;
+    }
+    // BFS (insert_now == 0): the inline-key table already holds the key under this batch's epoch; nothing to rewrite
+}
+
+// root node: id 0
+template <typename W> __global__ void k_root(SearchDev<W> d, W k0, W k1, uint32_t tl) {
+    d.k0[0] = k0;
+    d.k1[0] = k1;
+    d.parent[0] = kEmpty;
+    d.act[0] = 0xff;
+    d.tlen[0] = (uint8_t)tl;
+    d.depth[0] = 0;
+    d.slots[(uint32_t)hash_key<W>(k0, k1) & d.smask] = 0;
+}
+
+// path of node `id` from the root, written root first: out_act / out_len [depth + 1]
+template <typename W> __global__ void k_path(SearchDev<W> d, uint32_t id, int32_t* out_act, int32_t* out_len, int64_t cap) {
+    const uint32_t dep = d.depth[id];
+    for (uint32_t v = id, k = dep;; k--) {
+        if ((int64_t)k < cap) {
+            out_act[k] = d.act[v] == 0xff ? -1 : (int32_t)d.act[v];
+            out_len[k] = d.tlen[v];
+        }
+        if (k == 0) break;
+        v = d.parent[v];
+    }
+}
+
+// Order a heap bucket by the signed state tuple (greedy.py:104-113 heap key, third field): rank sort.
+// Thread i counts the bucket entries that sort before its own; states inside a bucket are pairwise
+// distinct (they passed the visited set), so ranks are a permutation.  Keys are staged through LDS in
+// tiles of 256 so that every comparison reads one broadcast LDS row.  O(n^2), buckets are small.
+template <typename W>
+__global__ void __launch_bounds__(256) k_rank_sort(SearchDev<W> d, const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+    __shared__ W t0[256];
+    __shared__ W t1[256];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t mine = i < n ? in[i] : 0;
+    Pres<W> me;
+    key_to_pres<W>(d.k0[mine], d.k1[mine], me);
+    uint32_t rank = 0;
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t j = base + threadIdx.x;
+        if (j < n) {
+            const uint32_t id = in[j];
+            t0[threadIdx.x] = d.k0[id];
+            t1[threadIdx.x] = d.k1[id];
+        }
+        __syncthreads();
+        const uint32_t cnt = n - base < 256 ? n - base : 256;
+        for (uint32_t q = 0; q < cnt; q++) {
+            Pres<W> o;
+            key_to_pres<W>(t0[q], t1[q], o);
+            rank += compare_pres<W>(o, me) < 0 ? 1u : 0u;
+        }
+        __syncthreads();
+    }
+    if (i < n) out[rank] = mine;
+}
+
+
+// ---------------------------------------------------------------------------------------- host ---
+// Device blocks of finished searches are kept per host thread and handed to the next search of that thread:
+// hipMalloc / hipFree cost milliseconds and hipFree synchronises the whole device, which would serialise the
+// overlapped searches of acx_search_many.  Blocks above kMaxCachedBlock go back to the driver at once.
+struct BlockPool {
+    static constexpr size_t kMaxCachedBlock = 16ull << 30;  // (a thread's cache is trimmed when acx_search_many returns)
+    static constexpr size_t kMaxBlocks = 8192;
+    std::vector<std::pair<void*, size_t>> blocks;
+    void* take(size_t bytes, size_t* got) {
+        size_t best = blocks.size();
+        for (size_t k = 0; k < blocks.size(); k++)
+            if (blocks[k].second >= bytes && blocks[k].second <= bytes + bytes / 2 + 4096 && (best == blocks.size() || blocks[k].second < blocks[best].second)) best = k;
+        if (best == blocks.size()) return nullptr;
+        void* p = blocks[best].first;
+        *got = blocks[best].second;
+        blocks[best] = blocks.back();
+        blocks.pop_back();
+        return p;
+    }
+    void give(void* p, size_t bytes) {
+        if (bytes > kMaxCachedBlock || blocks.size() >= kMaxBlocks) (void)hipFree(p);
+        else blocks.emplace_back(p, bytes);
+    }
+    void trim() {
+        for (auto& b : blocks) (void)hipFree(b.first);
+        blocks.clear();
+    }
+    // no destructor work: a worker thread trims explicitly before it ends; what the main thread still holds at process
+    // exit is released with the context (calling hipFree during runtime teardown can block)
+};
+inline BlockPool& block_pool() {
+    static thread_local BlockPool pool;
+    return pool;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t b) {
+        const size_t want = b ? b : 1;
+        p = block_pool().take(want, &bytes);
+        if (p) return ACX_OK;
+        bytes = want;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            block_pool().trim();  // give cached blocks back and retry once
+            if (hipMalloc(&p, bytes) != hipSuccess) {
+                p = nullptr;
+                return fail(ACX_E_NOMEM, "hipMalloc(%zu) failed", bytes);
+            }
+        }
+        return ACX_OK;
+    }
+    ~DevBuf() {
+        if (p) block_pool().give(p, bytes);
+    }
+};
+
+// pinned host staging, one grow-only buffer per host thread (hipHostMalloc is as slow as hipMalloc)
+inline uint8_t* pinned_staging(size_t bytes) {
+    static thread_local uint8_t* buf = nullptr;
+    static thread_local size_t cap = 0;
+    if (bytes <= cap) return buf;
+    if (buf) (void)hipHostFree(buf);
+    buf = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    if (hipHostMalloc((void**)&buf, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    cap = want;
+    return buf;
+}
+
+}  // namespace acx

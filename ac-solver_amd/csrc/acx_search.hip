@@ -9,9 +9,9 @@
 //   * every (parent, action) pair of the batch is one lane of k_expand: tag = 12 * parent_pos + action is
 //     exactly the order in which the reference generates children
 //   * duplicates are resolved to the MINIMUM tag (the reference's "first discoverer wins",
-//     breadth_first.py:87-89): the open-addressed table stores node ids; a candidate claims an empty slot
-//     with a 32-bit CAS on a provisional id (2^31 + tag) and equal keys fold with atomicMin, the full
-//     key of the occupant is always compared (exact set, no fingerprints)
+//     breadth_first.py:87-89): a candidate claims an empty entry of the open-addressed table with a CAS on a
+//     provisional stamp and equal keys fold with atomicMin; the full key of the occupant is always compared
+//     (exact set).  BFS: 32-byte entries with the key inline (acx_frontier.h, TabEntry); greedy: an id table
 //   * winners are numbered by an exclusive scan in tag order, which reproduces the reference's insertion
 //     order; the per-parent budget test (breadth_first.py:91-95) becomes "first parent whose cumulative
 //     winner count reaches the budget"; the solved test (:84-85) "minimum tag with total length 2"
@@ -20,480 +20,10 @@
 //
 // Keys: a relator word and its length share one machine word (length in the top 6 bits):
 // W = u64 for L <= 29, u128 for L <= 61.  Roofline: HBM (random table probes); see DESIGN.md.
-#include <string.h>
-
-#include <cstring>
-
-#include <rocprim/rocprim.hpp>
-
-#include <stdlib.h>
-
-#include <algorithm>
-#include <map>
-#include <memory>
-#include <vector>
-
-#include "acx_common.h"
-#include "acx_word.h"
-
-namespace acx {
-
-constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-constexpr uint32_t kProv = 0x80000000u;  // provisional id = kProv | tag (candidate of the running batch)
-constexpr uint64_t kNoTag = ~0ull;
-
-template <typename W> struct keyops {
-    static constexpr int kShift = wtraits<W>::kBits - 6;
-    static ACX_HD W make(W w, int n) { return w | ((W)n << kShift); }
-    static ACX_HD int len(W k) { return (int)(uint32_t)(k >> kShift); }
-    static ACX_HD W word(W k) { return k & (((W)1 << kShift) - 1); }
-};
-
-ACX_HD uint64_t mix64(uint64_t x) {
-    x ^= x >> 32;
-    x *= 0xd6e8feb86659fd93ull;
-    x ^= x >> 32;
-    x *= 0xd6e8feb86659fd93ull;
-    x ^= x >> 32;
-    return x;
-}
-ACX_HD uint64_t fold(uint64_t k) { return k; }
-ACX_HD uint64_t fold(u128 k) { return (uint64_t)k ^ ((uint64_t)(k >> 64) * 0x9e3779b97f4a7c15ull); }
-template <typename W> ACX_HD uint64_t hash_key(W k0, W k1) { return mix64(fold(k0) * 0x9e3779b97f4a7c15ull + mix64(fold(k1))); }
-
-// Visited set of the BFS frontiers: open addressing with the FULL key inline, one entry per 32-byte (u64 keys) /
-// 64-byte (u128 keys) sector, so a probe is ONE random memory access whether the slot is empty, holds another key
-// or holds this key.  `stamp` = epoch << 32 | tag of the candidate that claimed the entry; an entry whose epoch is not
-// the running batch's is a committed state, an entry of the running epoch is provisional and folds to the minimum tag
-// among equal keys (64-bit atomicMin).  The table never stores node ids: BFS only asks "seen before?".
-template <typename W> struct TabEntry;
-template <> struct alignas(32) TabEntry<uint64_t> {
-    uint64_t k0, k1;
-    unsigned long long stamp;
-    uint64_t pad;
-};
-template <> struct alignas(64) TabEntry<u128> {
-    u128 k0, k1;
-    unsigned long long stamp;
-    uint64_t pad[3];
-};
-constexpr unsigned long long kStampEmpty = ~0ull;
-
-template <typename W> struct SearchDev {
-    TabEntry<W>* tab;  // BFS visited table (inline keys); tmask = entries - 1
-    uint32_t tmask;
-    // node arena (committed nodes, id order == the reference's insertion order)
-    W* k0;
-    W* k1;
-    uint32_t* parent;
-    uint8_t* act;
-    uint8_t* tlen;
-    uint32_t* depth;
-    // visited table: node id / provisional id / kEmpty
-    uint32_t* slots;
-    uint32_t smask;
-    // batch-local table (greedy) for the in-batch dedup
-    uint32_t* bslots;
-    uint32_t bmask;
-    // candidates of the running batch, indexed by tag
-    W* ck0;
-    W* ck1;
-    uint8_t* clen;
-    uint32_t* cslot;
-    uint32_t* cflag;  // 1 = winner / new
-    uint32_t* cpos;   // exclusive scan of cflag
-    uint8_t* cknown;  // greedy: already in the visited table
-    // device scalars
-    unsigned long long* solved_tag;   // min tag with total length 2
-    unsigned long long* shorter_tag;  // greedy: min tag of a NEW child shorter than the bucket
-    unsigned long long* rank_tag;     // tag of the r-th winner (budget crossing)
-    uint32_t* err;
-    uint32_t* min_len;
-    int32_t L;
-    int32_t cyclical;
-};
-
-template <typename W> __device__ __forceinline__ void key_to_pres(W k0, W k1, Pres<W>& s) {
-    s.w0 = keyops<W>::word(k0);
-    s.n0 = keyops<W>::len(k0);
-    s.w1 = keyops<W>::word(k1);
-    s.n1 = keyops<W>::len(k1);
-}
-
-// one lane per (parent, action): tag t = 12 * p + a
-template <typename W>
-__global__ void __launch_bounds__(256) k_expand(SearchDev<W> d, const uint32_t* __restrict__ plist, uint32_t pbegin, uint32_t np) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t tl = 0xFFFFFFFFu;
-    if (t < 12u * np) {
-        const uint32_t p = t / 12u, a = t - 12u * p;
-        const uint32_t pid = plist ? plist[p] : pbegin + p;
-        Pres<W> s;
-        const W pk0 = d.k0[pid], pk1 = d.k1[pid];
-        key_to_pres<W>(pk0, pk1, s);
-        const int e = apply_move<W, true>(s, (int)a, d.L, d.cyclical != 0);
-        if (e) atomicOr(d.err, (uint32_t)e);  // the reference's ACMove raises: the whole search raises
-        const W c0 = keyops<W>::make(s.w0, s.n0), c1 = keyops<W>::make(s.w1, s.n1);
-        d.ck0[t] = c0;
-        d.ck1[t] = c1;
-        d.cknown[t] = (c0 == pk0 && c1 == pk1) ? 1 : 0;  // an unchanged state is its (visited) parent: k_insert skips the probe
-        tl = (uint32_t)(s.n0 + s.n1);
-        d.clen[t] = (uint8_t)tl;
-        if (tl == 2) atomicMin(d.solved_tag, (unsigned long long)t);  // breadth_first.py:84 / greedy.py:91
-    }
-    // wave-level min before the atomic keeps contention low (all 64 lanes take part)
-    uint32_t m = tl;
-    for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
-    // one contended address: only waves that would actually lower the minimum issue the atomic (a plain, possibly
-    // stale read can only over-estimate the current minimum, so no update is lost)
-    if ((threadIdx.x & 63) == 0 && m < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, m);
-}
-
-template <typename W> __device__ __forceinline__ bool key_equals(const SearchDev<W>& d, uint32_t id, W k0, W k1) {
-    if (id & kProv) {
-        const uint32_t t = id & ~kProv;
-        return d.ck0[t] == k0 && d.ck1[t] == k1;
-    }
-    return d.k0[id] == k0 && d.k1[id] == k1;
-}
-
-// Insert candidate t into `slots` with min-tag resolution among equal keys.  cslot[t] = slot holding the key.
-// Occupants may be committed node ids (always win) or provisional ids of this batch.
-template <typename W>
-__global__ void __launch_bounds__(256) k_insert(SearchDev<W> d, uint32_t* __restrict__ slots, uint32_t mask, uint32_t m, int skip_known) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m) return;
-    if (skip_known && d.cknown[t]) {
-        d.cslot[t] = kEmpty;
-        return;
-    }
-    const W k0 = d.ck0[t], k1 = d.ck1[t];
-    const uint32_t me = kProv | t;
-    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & mask;
-    for (;;) {
-        uint32_t v = slots[h];
-        if (v == kEmpty) {
-            v = atomicCAS(&slots[h], kEmpty, me);
-            if (v == kEmpty) break;  // claimed
-        }
-        if (key_equals<W>(d, v, k0, k1)) {
-            if ((v & kProv) && v > me) atomicMin(&slots[h], me);
-            break;
-        }
-        h = (h + 1) & mask;
-    }
-    d.cslot[t] = h;
-}
-
-// read-only membership test against the visited table (greedy: speculative batches must not touch it)
-template <typename W> __global__ void __launch_bounds__(256) k_lookup(SearchDev<W> d, uint32_t m) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m) return;
-    const W k0 = d.ck0[t], k1 = d.ck1[t];
-    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.smask;
-    uint8_t known = 0;
-    for (;;) {
-        const uint32_t v = d.slots[h];
-        if (v == kEmpty) break;
-        if (key_equals<W>(d, v, k0, k1)) {
-            known = 1;
-            break;
-        }
-        h = (h + 1) & d.smask;
-    }
-    d.cknown[t] = known;
-}
-
-// cflag[t] = 1 iff candidate t is the first discoverer of a state not seen before
-template <typename W>
-__global__ void __launch_bounds__(256) k_mark(SearchDev<W> d, const uint32_t* __restrict__ slots, uint32_t m, int bucket_len) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m) return;
-    const uint32_t s = d.cslot[t];
-    const uint32_t win = (s != kEmpty && slots[s] == (kProv | t)) ? 1u : 0u;
-    d.cflag[t] = win;
-    if (win && bucket_len >= 0 && (int)d.clen[t] < bucket_len) atomicMin(d.shorter_tag, (unsigned long long)t);
-}
-
-// BFS: insert candidate t into the inline-key table (see TabEntry).  cslot[t] = entry that holds the key, kEmpty when
-// the candidate was skipped (a child equal to its parent).
-template <typename W>
-__global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, uint32_t epoch, int skip_known) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m) return;
-    if (skip_known && d.cknown[t]) {
-        d.cslot[t] = kEmpty;
-        return;
-    }
-    const W k0 = d.ck0[t], k1 = d.ck1[t];
-    const unsigned long long me = ((unsigned long long)epoch << 32) | t;
-    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.tmask;
-    for (;;) {
-        TabEntry<W>* e = d.tab + h;
-        const W e0 = e->k0, e1 = e->k1;  // one sector together with the stamp
-        unsigned long long st = e->stamp;
-        if (st == kStampEmpty) {
-            st = atomicCAS(&e->stamp, kStampEmpty, me);
-            if (st == kStampEmpty) {  // claimed: the key moves in (readers of this batch compare through the candidate arena)
-                e->k0 = k0;
-                e->k1 = k1;
-                break;
-            }
-            // lost the race: `st` is a stamp of the running epoch now
-        }
-        if ((uint32_t)(st >> 32) == epoch) {
-            const uint32_t o = (uint32_t)st;
-            if (d.ck0[o] == k0 && d.ck1[o] == k1) {
-                if (st > me) atomicMin(&e->stamp, me);
-                break;
-            }
-        } else if (e0 == k0 && e1 == k1) {
-            break;  // a committed state
-        }
-        h = (h + 1) & d.tmask;
-    }
-    d.cslot[t] = h;
-}
-
-template <typename W> __global__ void __launch_bounds__(256) k_mark_tab(SearchDev<W> d, uint32_t m, uint32_t epoch) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m) return;
-    const uint32_t s = d.cslot[t];
-    d.cflag[t] = (s != kEmpty && d.tab[s].stamp == (((unsigned long long)epoch << 32) | t)) ? 1u : 0u;
-}
-
-template <typename W> __global__ void k_root_tab(SearchDev<W> d, W k0, W k1, uint32_t tl) {
-    d.k0[0] = k0;
-    d.k1[0] = k1;
-    d.parent[0] = kEmpty;
-    d.act[0] = 0xff;
-    d.tlen[0] = (uint8_t)tl;
-    d.depth[0] = 0;
-    TabEntry<W>* e = d.tab + ((uint32_t)hash_key<W>(k0, k1) & d.tmask);
-    e->k0 = k0;
-    e->k1 = k1;
-    e->stamp = 0;  // epoch 0 is never a running batch
-}
-
-// tag of the winner with 1-based rank r (exists and is unique)
-template <typename W> __global__ void __launch_bounds__(256) k_find_rank(SearchDev<W> d, uint32_t m, uint32_t r) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m) return;
-    if (d.cflag[t] && d.cpos[t] + 1 == r) *d.rank_tag = t;
-}
-
-// What the reference does with this batch, decided on the device so that the host needs ONE read-back per batch.
-struct Decision {
-    uint32_t p_end;       // last parent of the batch that the reference pops
-    uint32_t cutoff;      // candidates with tag < cutoff are committed
-    uint32_t committed;   // number of winners below cutoff
-    uint32_t total;       // winners in the whole batch
-    uint32_t budget_hit;  // len(tree_nodes) >= max_nodes after parent p_end
-    uint32_t solved;      // a child of total length 2 was generated at or before parent p_end
-    uint32_t solved_tag;
-    uint32_t last_child_len;  // total length of child (p_end, action 11): greedy.py:121
-    uint32_t err;
-    uint32_t min_len;
-};
-
-template <typename W>
-__global__ void k_decide(SearchDev<W> d, uint32_t m, uint32_t np, unsigned long long nodes, long long max_nodes, int greedy, Decision* __restrict__ out) {
-    const uint32_t total = d.cpos[m - 1] + d.cflag[m - 1];
-    uint32_t p_end = np - 1, budget_hit = 0;
-    const unsigned long long shorter = *d.shorter_tag, solved_tag = *d.solved_tag;
-    if (greedy && shorter != kNoTag) p_end = min(p_end, (uint32_t)(shorter / 12));  // the shorter new child is the heap's next minimum
-    if ((long long)nodes >= max_nodes) {  // only possible for the very first parent (budget <= 1)
-        p_end = 0;
-        budget_hit = 1;
-    } else if ((long long)(nodes + total) >= max_nodes) {
-        // first candidate whose inclusive winner count reaches `need` (cpos + cflag is non-decreasing in t)
-        const uint32_t need = (uint32_t)(max_nodes - (long long)nodes);
-        uint32_t lo = 0, hi = m - 1;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (d.cpos[mid] + d.cflag[mid] >= need) hi = mid;
-            else lo = mid + 1;
-        }
-        const uint32_t pb = lo / 12;
-        if (pb <= p_end) {
-            p_end = pb;
-            budget_hit = 1;
-        }
-    }
-    const uint32_t is_solved = solved_tag != kNoTag && (uint32_t)(solved_tag / 12) <= p_end;
-    const uint32_t cutoff = is_solved ? (uint32_t)solved_tag : 12u * (p_end + 1);  // on success only stats need the commit
-    out->p_end = is_solved ? (uint32_t)(solved_tag / 12) : p_end;
-    out->cutoff = cutoff;
-    out->committed = cutoff >= m ? total : d.cpos[cutoff];
-    out->total = total;
-    out->budget_hit = budget_hit;
-    out->solved = is_solved;
-    out->solved_tag = (uint32_t)solved_tag;
-    out->last_child_len = d.clen[12u * p_end + 11];
-    out->err = *d.err;
-    out->min_len = *d.min_len;
-}
-
-// Winners below `cutoff` become nodes base + cpos[t].  BFS: their table slot (already claimed in the visited
-// table) is rewritten to the final id.  Greedy: the key is inserted into the visited table now (it is known
-// to be absent and the committed keys are pairwise distinct, so a plain CAS claim is enough).
-template <typename W>
-__global__ void __launch_bounds__(256) k_commit(SearchDev<W> d, const uint32_t* __restrict__ plist, uint32_t pbegin, const Decision* __restrict__ dec, uint32_t m,
-                                                uint32_t base, int insert_now) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m || t >= dec->cutoff || !d.cflag[t]) return;
-    const uint32_t id = base + d.cpos[t];
-    const uint32_t p = t / 12u;
-    const uint32_t pid = plist ? plist[p] : pbegin + p;
-    const W k0 = d.ck0[t], k1 = d.ck1[t];
-    d.k0[id] = k0;
-    d.k1[id] = k1;
-    d.parent[id] = pid;
-    d.act[id] = (uint8_t)(t - 12u * p);
-    d.tlen[id] = d.clen[t];
-    d.depth[id] = d.depth[pid] + 1;
-    if (insert_now == 1) {  // batch-per-launch greedy: id table
-        uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.smask;
-        while (atomicCAS(&d.slots[h], kEmpty, id) != kEmpty) h = (h + 1) & d.smask;
-    }
-    // BFS (insert_now == 0): the inline-key table already holds the key under this batch's epoch; nothing to rewrite
-}
-
-// root node: id 0
-template <typename W> __global__ void k_root(SearchDev<W> d, W k0, W k1, uint32_t tl) {
-    d.k0[0] = k0;
-    d.k1[0] = k1;
-    d.parent[0] = kEmpty;
-    d.act[0] = 0xff;
-    d.tlen[0] = (uint8_t)tl;
-    d.depth[0] = 0;
-    d.slots[(uint32_t)hash_key<W>(k0, k1) & d.smask] = 0;
-}
-
-// path of node `id` from the root, written root first: out_act / out_len [depth + 1]
-template <typename W> __global__ void k_path(SearchDev<W> d, uint32_t id, int32_t* out_act, int32_t* out_len, int64_t cap) {
-    const uint32_t dep = d.depth[id];
-    for (uint32_t v = id, k = dep;; k--) {
-        if ((int64_t)k < cap) {
-            out_act[k] = d.act[v] == 0xff ? -1 : (int32_t)d.act[v];
-            out_len[k] = d.tlen[v];
-        }
-        if (k == 0) break;
-        v = d.parent[v];
-    }
-}
-
-// Order a heap bucket by the signed state tuple (greedy.py:104-113 heap key, third field): rank sort.
-// Thread i counts the bucket entries that sort before its own; states inside a bucket are pairwise
-// distinct (they passed the visited set), so ranks are a permutation.  Keys are staged through LDS in
-// tiles of 256 so that every comparison reads one broadcast LDS row.  O(n^2), buckets are small.
-template <typename W>
-__global__ void __launch_bounds__(256) k_rank_sort(SearchDev<W> d, const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
-    __shared__ W t0[256];
-    __shared__ W t1[256];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t mine = i < n ? in[i] : 0;
-    Pres<W> me;
-    key_to_pres<W>(d.k0[mine], d.k1[mine], me);
-    uint32_t rank = 0;
-    for (uint32_t base = 0; base < n; base += 256) {
-        const uint32_t j = base + threadIdx.x;
-        if (j < n) {
-            const uint32_t id = in[j];
-            t0[threadIdx.x] = d.k0[id];
-            t1[threadIdx.x] = d.k1[id];
-        }
-        __syncthreads();
-        const uint32_t cnt = n - base < 256 ? n - base : 256;
-        for (uint32_t q = 0; q < cnt; q++) {
-            Pres<W> o;
-            key_to_pres<W>(t0[q], t1[q], o);
-            rank += compare_pres<W>(o, me) < 0 ? 1u : 0u;
-        }
-        __syncthreads();
-    }
-    if (i < n) out[rank] = mine;
-}
-
-}  // namespace acx
+#include "acx_frontier.h"
 #include "acx_greedy.h"
+
 namespace acx {
-
-// ---------------------------------------------------------------------------------------- host ---
-// Device blocks of finished searches are kept per host thread and handed to the next search of that thread:
-// hipMalloc / hipFree cost milliseconds and hipFree synchronises the whole device, which would serialise the
-// overlapped searches of acx_search_many.  Blocks above kMaxCachedBlock go back to the driver at once.
-struct BlockPool {
-    static constexpr size_t kMaxCachedBlock = 16ull << 30;  // (a thread's cache is trimmed when acx_search_many returns)
-    static constexpr size_t kMaxBlocks = 8192;
-    std::vector<std::pair<void*, size_t>> blocks;
-    void* take(size_t bytes, size_t* got) {
-        size_t best = blocks.size();
-        for (size_t k = 0; k < blocks.size(); k++)
-            if (blocks[k].second >= bytes && blocks[k].second <= bytes + bytes / 2 + 4096 && (best == blocks.size() || blocks[k].second < blocks[best].second)) best = k;
-        if (best == blocks.size()) return nullptr;
-        void* p = blocks[best].first;
-        *got = blocks[best].second;
-        blocks[best] = blocks.back();
-        blocks.pop_back();
-        return p;
-    }
-    void give(void* p, size_t bytes) {
-        if (bytes > kMaxCachedBlock || blocks.size() >= kMaxBlocks) (void)hipFree(p);
-        else blocks.emplace_back(p, bytes);
-    }
-    void trim() {
-        for (auto& b : blocks) (void)hipFree(b.first);
-        blocks.clear();
-    }
-    // no destructor work: a worker thread trims explicitly before it ends; what the main thread still holds at process
-    // exit is released with the context (calling hipFree during runtime teardown can block)
-};
-static BlockPool& block_pool() {
-    static thread_local BlockPool pool;
-    return pool;
-}
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    int alloc(size_t b) {
-        const size_t want = b ? b : 1;
-        p = block_pool().take(want, &bytes);
-        if (p) return ACX_OK;
-        bytes = want;
-        if (hipMalloc(&p, bytes) != hipSuccess) {
-            block_pool().trim();  // give cached blocks back and retry once
-            if (hipMalloc(&p, bytes) != hipSuccess) {
-                p = nullptr;
-                return fail(ACX_E_NOMEM, "hipMalloc(%zu) failed", bytes);
-            }
-        }
-        return ACX_OK;
-    }
-    ~DevBuf() {
-        if (p) block_pool().give(p, bytes);
-    }
-};
-
-// pinned host staging, one grow-only buffer per host thread (hipHostMalloc is as slow as hipMalloc)
-static uint8_t* pinned_staging(size_t bytes) {
-    static thread_local uint8_t* buf = nullptr;
-    static thread_local size_t cap = 0;
-    if (bytes <= cap) return buf;
-    if (buf) (void)hipHostFree(buf);
-    buf = nullptr;
-    cap = 0;
-    const size_t want = bytes + bytes / 2 + 4096;
-    if (hipHostMalloc((void**)&buf, want, hipHostMallocDefault) != hipSuccess) return nullptr;
-    cap = want;
-    return buf;
-}
-
-struct Scalars {
-    unsigned long long solved_tag, shorter_tag, rank_tag;
-    uint32_t err, min_len;
-};
 
 template <typename W> struct Searcher {
     SearchDev<W> d;
@@ -574,7 +104,6 @@ template <typename W> struct Searcher {
         if (!h_pin) return fail(ACX_E_NOMEM, "hipHostMalloc(%zu) failed", h_pin_bytes);
         d.solved_tag = (unsigned long long*)(sc + 0);
         d.shorter_tag = (unsigned long long*)(sc + 8);
-        d.rank_tag = (unsigned long long*)(sc + 16);
         d.err = (uint32_t*)(sc + 24);
         d.min_len = (uint32_t*)(sc + 28);
         if (arena_list.alloc(std::max<uint64_t>(batch_parents, 1024) * 4 * 2)) return ACX_E_NOMEM;
@@ -591,53 +120,8 @@ template <typename W> struct Searcher {
         return ACX_OK;
     }
 
-    int read_scalars(Scalars& s) {
-        uint8_t h[32];
-        ACX_HIP_TRY(hipMemcpyAsync(h, arena_scal.p, 32, hipMemcpyDeviceToHost, st));
-        ACX_HIP_TRY(hipStreamSynchronize(st));
-        memcpy(&s.solved_tag, h + 0, 8);
-        memcpy(&s.shorter_tag, h + 8, 8);
-        memcpy(&s.rank_tag, h + 16, 8);
-        memcpy(&s.err, h + 24, 4);
-        memcpy(&s.min_len, h + 28, 4);
-        return ACX_OK;
-    }
-
     int reset_batch_scalars() {  // solved / shorter / rank tags back to "none"; err and min_len are sticky
         ACX_HIP_TRY(hipMemsetAsync(arena_scal.p, 0xff, 24, st));
-        return ACX_OK;
-    }
-
-    int scan(uint32_t m, uint32_t& total) {
-        size_t tb = tmp_bytes;
-        if (rocprim::exclusive_scan(arena_tmp.p, tb, d.cflag, d.cpos, 0u, m, rocprim::plus<uint32_t>(), st) != hipSuccess)
-            return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan failed");
-        uint32_t last[2];
-        ACX_HIP_TRY(hipMemcpyAsync(&last[0], d.cpos + (m - 1), 4, hipMemcpyDeviceToHost, st));
-        ACX_HIP_TRY(hipMemcpyAsync(&last[1], d.cflag + (m - 1), 4, hipMemcpyDeviceToHost, st));
-        ACX_HIP_TRY(hipStreamSynchronize(st));
-        total = last[0] + last[1];
-        return ACX_OK;
-    }
-
-    // number of winners with tag < cutoff
-    int winners_below(uint32_t cutoff, uint32_t m, uint32_t total, uint32_t& out) {
-        if (cutoff >= m) {
-            out = total;
-            return ACX_OK;
-        }
-        ACX_HIP_TRY(hipMemcpyAsync(&out, d.cpos + cutoff, 4, hipMemcpyDeviceToHost, st));
-        ACX_HIP_TRY(hipStreamSynchronize(st));
-        return ACX_OK;
-    }
-
-    // first parent position whose cumulative winner count reaches `need` (need >= 1 and <= total)
-    int budget_parent(uint32_t m, uint32_t need, uint32_t& parent_pos) {
-        hipLaunchKernelGGL(k_find_rank<W>, dim3((m + 255) / 256), dim3(256), 0, st, d, m, need);
-        unsigned long long t = 0;
-        ACX_HIP_TRY(hipMemcpyAsync(&t, d.rank_tag, 8, hipMemcpyDeviceToHost, st));
-        ACX_HIP_TRY(hipStreamSynchronize(st));
-        parent_pos = (uint32_t)(t / 12);
         return ACX_OK;
     }
 
@@ -1138,380 +622,6 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
     return ACX_OK;
 }
 
-
-// =============================================================================================
-// Sharded frontier: one engine per GPU, states partitioned by hash(key) mod world.  The host side
-// (ac_solver/search/sharded.py) moves candidate records between ranks with an RCCL all-to-all and
-// broadcasts winner tags; everything per rank happens in the kernels below.  A record is KW+2 int64:
-// the key words, tag = 12 * global_parent_position + action, parent_ref = rank << 40 | local id.
-// =============================================================================================
-template <typename W> struct recio;
-template <> struct recio<uint64_t> {
-    static constexpr int KW = 2;
-    static ACX_HD void put(int64_t* r, uint64_t k0, uint64_t k1) { r[0] = (int64_t)k0; r[1] = (int64_t)k1; }
-    static ACX_HD void get(const int64_t* r, uint64_t& k0, uint64_t& k1) { k0 = (uint64_t)r[0]; k1 = (uint64_t)r[1]; }
-};
-template <> struct recio<u128> {
-    static constexpr int KW = 4;
-    static ACX_HD void put(int64_t* r, u128 k0, u128 k1) {
-        r[0] = (int64_t)(uint64_t)k0; r[1] = (int64_t)(uint64_t)(k0 >> 64);
-        r[2] = (int64_t)(uint64_t)k1; r[3] = (int64_t)(uint64_t)(k1 >> 64);
-    }
-    static ACX_HD void get(const int64_t* r, u128& k0, u128& k1) {
-        k0 = ((u128)(uint64_t)r[1] << 64) | (uint64_t)r[0];
-        k1 = ((u128)(uint64_t)r[3] << 64) | (uint64_t)r[2];
-    }
-};
-
-template <typename W>
-__global__ void __launch_bounds__(256) k_shard_expand(SearchDev<W> d, const int64_t* __restrict__ ids, const int64_t* __restrict__ gpos, int64_t np,
-                                                      int64_t pref_hi, int64_t* __restrict__ rec, unsigned long long* __restrict__ solved) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 12 * np) return;
-    const int64_t p = t / 12;
-    const int a = (int)(t - 12 * p);
-    const int64_t id = ids[p];
-    Pres<W> s;
-    key_to_pres<W>(d.k0[id], d.k1[id], s);
-    const int e = apply_move<W, true>(s, a, d.L, d.cyclical != 0);
-    if (e) atomicOr(d.err, (uint32_t)e);
-    int64_t* r = rec + t * (recio<W>::KW + 2);
-    recio<W>::put(r, keyops<W>::make(s.w0, s.n0), keyops<W>::make(s.w1, s.n1));
-    const int64_t tag = 12 * gpos[p] + a;
-    r[recio<W>::KW] = tag;
-    r[recio<W>::KW + 1] = pref_hi | id;
-    if (s.n0 + s.n1 == 2) atomicMin(solved, (unsigned long long)tag);
-    if ((uint32_t)(s.n0 + s.n1) < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, (uint32_t)(s.n0 + s.n1));
-}
-
-// Owner rank of a packed key: the arithmetic of ac_solver/search/sharded.py:owner_of on the key's int64 words.
-ACX_HD uint64_t owner_mix(uint64_t h, uint64_t w) {
-    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
-    return h ^ (h >> 29);
-}
-ACX_HD uint32_t owner_of_key(uint64_t k0, uint64_t k1, uint32_t world) {
-    const uint64_t h = owner_mix(owner_mix(0, k0), k1);
-    return (uint32_t)((h & 0x7FFFFFFFFFFFFFFFull) % world);
-}
-ACX_HD uint32_t owner_of_key(u128 k0, u128 k1, uint32_t world) {
-    uint64_t h = owner_mix(owner_mix(0, (uint64_t)k0), (uint64_t)(k0 >> 64));
-    h = owner_mix(owner_mix(h, (uint64_t)k1), (uint64_t)(k1 >> 64));
-    return (uint32_t)((h & 0x7FFFFFFFFFFFFFFFull) % world);
-}
-
-// k_shard_expand + routing: the record of a child goes straight into the send region of the rank that owns the
-// child's key (region o = rec[o * region_cap ...], filled through a wave-aggregated cursor counts[o]), so the
-// all-to-all can leave without a sort by owner.  The order inside a region is arbitrary (the receiver orders by tag).
-template <typename W>
-__global__ void __launch_bounds__(1024) k_shard_expand_routed(SearchDev<W> d, const int64_t* __restrict__ ids, const int64_t* __restrict__ gpos, int64_t np,
-                                                             int64_t pref_hi, uint32_t world, int64_t* __restrict__ rec, int64_t region_cap,
-                                                             unsigned long long* __restrict__ counts, unsigned long long* __restrict__ solved) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = t < 12 * np;
-    const uint32_t lane = threadIdx.x & 63;
-    W k0 = 0, k1 = 0;
-    int64_t tag = 0, pref = 0;
-    uint32_t owner = 0xFFFFFFFFu;
-    if (active) {
-        const int64_t p = t / 12;
-        const int a = (int)(t - 12 * p);
-        const int64_t id = ids[p];
-        Pres<W> s;
-        const W pk0 = d.k0[id], pk1 = d.k1[id];
-        key_to_pres<W>(pk0, pk1, s);
-        const int e = apply_move<W, true>(s, a, d.L, d.cyclical != 0);
-        if (e) atomicOr(d.err, (uint32_t)e);
-        k0 = keyops<W>::make(s.w0, s.n0);
-        k1 = keyops<W>::make(s.w1, s.n1);
-        tag = 12 * gpos[p] + a;
-        pref = pref_hi | id;
-        // a move that leaves the state unchanged (over-long product: ac_moves.py:64, :126) yields the parent itself, which
-        // is in the visited set already: such a child can never be new, so it is not sent at all
-        if (k0 != pk0 || k1 != pk1) owner = owner_of_key(k0, k1, world);
-        if (s.n0 + s.n1 == 2) atomicMin(solved, (unsigned long long)tag);
-        if ((uint32_t)(s.n0 + s.n1) < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, (uint32_t)(s.n0 + s.n1));
-    }
-    // position inside the destination region: wave-aggregated LDS counters per owner, then ONE global atomicAdd per
-    // (workgroup, owner) -- per-wave global atomics on `world` addresses serialise (1.6 ms per 12 M children)
-    __shared__ uint32_t s_cnt[64];
-    __shared__ unsigned long long s_base[64];
-    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t pos_in_block = 0;
-    for (uint32_t o = 0; o < world; o++) {
-        const unsigned long long m = __ballot(owner == o);
-        if (!m) continue;
-        const uint32_t lead = (uint32_t)__builtin_ctzll(m);
-        uint32_t base = 0;
-        if (lane == lead) base = atomicAdd(&s_cnt[o], (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, (int)lead);
-        if (owner == o) pos_in_block = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    }
-    __syncthreads();
-    if (threadIdx.x < world && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
-    __syncthreads();
-    if (owner != 0xFFFFFFFFu) {
-        const int64_t pos = (int64_t)s_base[owner] + pos_in_block;
-        if (pos < region_cap) {
-            int64_t* r = rec + ((int64_t)owner * region_cap + pos) * (recio<W>::KW + 2);
-            recio<W>::put(r, k0, k1);
-            r[recio<W>::KW] = tag;
-            r[recio<W>::KW + 1] = pref;
-        }  // an overflow shows in counts[o] > region_cap; the host reports it
-    }
-}
-
-template <typename W> __global__ void __launch_bounds__(256) k_shard_tags(const int64_t* __restrict__ rec, int64_t n, uint64_t* __restrict__ tags, uint32_t* __restrict__ idx) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    tags[i] = (uint64_t)rec[i * (recio<W>::KW + 2) + recio<W>::KW];
-    idx[i] = (uint32_t)i;
-}
-
-// candidate arena in tag order: j-th smallest tag -> slot j
-template <typename W>
-__global__ void __launch_bounds__(256) k_shard_gather(SearchDev<W> d, const int64_t* __restrict__ rec, const uint64_t* __restrict__ tags_sorted,
-                                                      const uint32_t* __restrict__ idx_sorted, int64_t n, int64_t* __restrict__ ctag, int64_t* __restrict__ cpref) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const int64_t* r = rec + (int64_t)idx_sorted[j] * (recio<W>::KW + 2);
-    W k0, k1;
-    recio<W>::get(r, k0, k1);
-    d.ck0[j] = k0;
-    d.ck1[j] = k1;
-    d.clen[j] = (uint8_t)(keyops<W>::len(k0) + keyops<W>::len(k1));
-    ctag[j] = (int64_t)tags_sorted[j];
-    cpref[j] = r[recio<W>::KW + 1];
-}
-
-template <typename W>
-__global__ void __launch_bounds__(256) k_shard_win_tags(SearchDev<W> d, const int64_t* __restrict__ ctag, int64_t n, int64_t* __restrict__ out) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n || !d.cflag[j]) return;
-    out[d.cpos[j]] = ctag[j];
-}
-
-template <typename W>
-__global__ void __launch_bounds__(256) k_shard_commit(SearchDev<W> d, const int64_t* __restrict__ ctag, const int64_t* __restrict__ cpref, int64_t n,
-                                                      int64_t cutoff, uint32_t base, int64_t* __restrict__ node_pref) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n || !d.cflag[j] || ctag[j] >= cutoff) return;
-    const uint32_t id = base + d.cpos[j];
-    d.k0[id] = d.ck0[j];
-    d.k1[id] = d.ck1[j];
-    d.act[id] = (uint8_t)(ctag[j] % 12);
-    d.tlen[id] = d.clen[j];
-    node_pref[id] = cpref[j];
-}
-
-// number of winners with tag < cutoff: candidates are in tag order, so it is cpos at the first tag >= cutoff
-template <typename W> __global__ void k_shard_count(SearchDev<W> d, const int64_t* __restrict__ ctag, int64_t n, int64_t cutoff, uint32_t* __restrict__ count) {
-    int64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (ctag[mid] < cutoff) lo = mid + 1;
-        else hi = mid;
-    }
-    *count = lo >= n ? d.cpos[n - 1] + d.cflag[n - 1] : d.cpos[lo];
-}
-
-template <typename W> struct ShardEngine {
-    SearchDev<W> d;
-    DevBuf nodes_buf, cand_buf, tab_buf, scal_buf, tmp_buf, sort_buf;
-    int64_t* node_pref = nullptr;  // [cap] parent_ref of every local node
-    int64_t* ctag = nullptr;
-    int64_t* cpref = nullptr;
-    uint64_t* tags_in = nullptr;
-    uint64_t* tags_sorted = nullptr;
-    uint32_t* idx_in = nullptr;
-    uint32_t* idx_sorted = nullptr;
-    uint32_t* commit_count = nullptr;
-    size_t scan_tmp = 0, sort_tmp = 0;
-    uint64_t cap_nodes = 0, cap_cand = 0, n_slots = 0;
-    uint64_t nodes = 0;    // committed local nodes
-    uint32_t epoch = 0;    // insert calls so far (stamps of the inline-key table)
-    int64_t pending = 0;   // candidates of the last insert (awaiting commit)
-    int rank = 0, world = 1;
-
-    int init(int L, int cyclical, int64_t node_cap, int64_t batch_cap, int rank_, int world_) {
-        memset(&d, 0, sizeof(d));
-        d.L = L;
-        d.cyclical = cyclical;
-        rank = rank_;
-        world = world_;
-        cap_nodes = (uint64_t)node_cap + 64;
-        cap_cand = (uint64_t)std::max<int64_t>(batch_cap, 1024);
-        n_slots = 1024;
-        while (n_slots < 2 * (cap_nodes + cap_cand)) n_slots <<= 1;
-        if (n_slots > (1ull << 31)) return fail(ACX_E_INVAL, "acx_shard: capacity too large for 32-bit node ids");
-        size_t o = 0;
-        auto take = [&](uint8_t* base, size_t bytes) {
-            uint8_t* p = base ? base + o : nullptr;
-            o += (bytes + 255) / 256 * 256;
-            return p;
-        };
-        for (int pass = 0; pass < 2; pass++) {
-            uint8_t* b = (uint8_t*)nodes_buf.p;
-            o = 0;
-            d.k0 = (W*)take(b, cap_nodes * sizeof(W));
-            d.k1 = (W*)take(b, cap_nodes * sizeof(W));
-            node_pref = (int64_t*)take(b, cap_nodes * 8);
-            d.act = (uint8_t*)take(b, cap_nodes);
-            d.tlen = (uint8_t*)take(b, cap_nodes);
-            if (pass == 0 && nodes_buf.alloc(o)) return ACX_E_NOMEM;
-        }
-        for (int pass = 0; pass < 2; pass++) {
-            uint8_t* b = (uint8_t*)cand_buf.p;
-            o = 0;
-            d.ck0 = (W*)take(b, cap_cand * sizeof(W));
-            d.ck1 = (W*)take(b, cap_cand * sizeof(W));
-            ctag = (int64_t*)take(b, cap_cand * 8);
-            cpref = (int64_t*)take(b, cap_cand * 8);
-            tags_in = (uint64_t*)take(b, cap_cand * 8);
-            tags_sorted = (uint64_t*)take(b, cap_cand * 8);
-            idx_in = (uint32_t*)take(b, cap_cand * 4);
-            idx_sorted = (uint32_t*)take(b, cap_cand * 4);
-            d.cslot = (uint32_t*)take(b, cap_cand * 4);
-            d.cflag = (uint32_t*)take(b, cap_cand * 4);
-            d.cpos = (uint32_t*)take(b, cap_cand * 4);
-            d.clen = (uint8_t*)take(b, cap_cand);
-            if (pass == 0 && cand_buf.alloc(o)) return ACX_E_NOMEM;
-        }
-        if (tab_buf.alloc(n_slots * sizeof(TabEntry<W>))) return ACX_E_NOMEM;
-        d.tab = (TabEntry<W>*)tab_buf.p;
-        d.tmask = (uint32_t)(n_slots - 1);
-        if (scal_buf.alloc(256)) return ACX_E_NOMEM;
-        uint8_t* sc = (uint8_t*)scal_buf.p;
-        d.err = (uint32_t*)(sc + 24);
-        d.min_len = (uint32_t*)(sc + 28);
-        commit_count = (uint32_t*)(sc + 32);
-        if (rocprim::exclusive_scan(nullptr, scan_tmp, d.cflag, d.cpos, 0u, cap_cand, rocprim::plus<uint32_t>(), (hipStream_t) nullptr) != hipSuccess)
-            return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan sizing failed");
-        if (rocprim::radix_sort_pairs(nullptr, sort_tmp, tags_in, tags_sorted, idx_in, idx_sorted, cap_cand, 0, 64, (hipStream_t) nullptr) != hipSuccess)
-            return fail(ACX_E_NODEVICE, "rocprim::radix_sort_pairs sizing failed");
-        if (tmp_buf.alloc(std::max(scan_tmp, sort_tmp) + 256)) return ACX_E_NOMEM;
-        ACX_HIP_TRY(hipMemset(d.tab, 0xff, n_slots * sizeof(TabEntry<W>)));
-        ACX_HIP_TRY(hipMemset(scal_buf.p, 0xff, 256));
-        ACX_HIP_TRY(hipMemset(d.err, 0, 4));
-        return ACX_OK;
-    }
-};
-
-struct ShardAny {
-    bool wide;
-    ShardEngine<uint64_t>* e64 = nullptr;
-    ShardEngine<u128>* e128 = nullptr;
-};
-
-#define ACX_SHARD_DISPATCH(h, ...)                   \
-    do {                                             \
-        if ((h)->wide) {                             \
-            typedef u128 W;                          \
-            auto& E = *(h)->e128;                    \
-            (void)sizeof(W);                         \
-            __VA_ARGS__;                             \
-        } else {                                     \
-            typedef uint64_t W;                      \
-            auto& E = *(h)->e64;                     \
-            (void)sizeof(W);                         \
-            __VA_ARGS__;                             \
-        }                                            \
-    } while (0)
-
-template <typename W> static int shard_root(ShardEngine<W>& E, const int8_t* pres, int64_t* rec) {
-    Pres<W> root;
-    bool ok = pack_relator<W>(pres, E.d.L, root.w0, root.n0);
-    ok = pack_relator<W>(pres + E.d.L, E.d.L, root.w1, root.n1) && ok;
-    if (!ok) return fail(ACX_E_ROWERR, "acx_shard: the presentation is not a zero-padded word pair over {+-1,+-2}");
-    recio<W>::put(rec, keyops<W>::make(root.w0, root.n0), keyops<W>::make(root.w1, root.n1));
-    rec[recio<W>::KW] = 0;
-    rec[recio<W>::KW + 1] = -1;
-    return ACX_OK;
-}
-
-template <typename W> static int shard_expand(ShardEngine<W>& E, const int64_t* ids, const int64_t* gpos, int64_t np, int64_t* rec, int64_t* solved, hipStream_t st) {
-    if (np <= 0) return ACX_OK;
-    const int64_t m = 12 * np;
-    hipLaunchKernelGGL(k_shard_expand<W>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, E.d, ids, gpos, np, (int64_t)E.rank << 40, rec,
-                       (unsigned long long*)solved);
-    ACX_HIP_TRY(hipGetLastError());
-    return ACX_OK;
-}
-
-template <typename W>
-static int shard_expand_routed(ShardEngine<W>& E, const int64_t* ids, const int64_t* gpos, int64_t np, int64_t* rec, int64_t region_cap, int64_t* counts,
-                               int64_t* solved, hipStream_t st) {
-    ACX_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)E.world * 8, st));
-    if (np <= 0) return ACX_OK;
-    const int64_t m = 12 * np;
-    if (E.world > 64) return fail(ACX_E_INVAL, "acx_shard_expand_routed handles world <= 64");
-    hipLaunchKernelGGL(k_shard_expand_routed<W>, dim3((unsigned)((m + 1023) / 1024)), dim3(1024), 0, st, E.d, ids, gpos, np, (int64_t)E.rank << 40, (uint32_t)E.world,
-                       rec, region_cap, (unsigned long long*)counts, (unsigned long long*)solved);
-    ACX_HIP_TRY(hipGetLastError());
-    return ACX_OK;
-}
-
-template <typename W> static int shard_insert(ShardEngine<W>& E, const int64_t* rec, int64_t n, int tag_bits, int64_t* win_tags, int64_t* n_win, hipStream_t st) {
-    *n_win = 0;
-    E.pending = n;
-    if (n <= 0) return ACX_OK;
-    if ((uint64_t)n > E.cap_cand) return fail(ACX_E_CAPACITY, "acx_shard_insert: %lld records exceed the batch capacity %llu", (long long)n, (unsigned long long)E.cap_cand);
-    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    hipLaunchKernelGGL(k_shard_tags<W>, grid, block, 0, st, rec, n, E.tags_in, E.idx_in);
-    size_t tb = E.sort_tmp;
-    const unsigned end_bit = (unsigned)(tag_bits < 1 ? 64 : (tag_bits > 64 ? 64 : tag_bits));  // tags < 2^tag_bits: fewer radix passes
-    if (rocprim::radix_sort_pairs(E.tmp_buf.p, tb, E.tags_in, E.tags_sorted, E.idx_in, E.idx_sorted, (size_t)n, 0, end_bit, st) != hipSuccess)
-        return fail(ACX_E_NODEVICE, "rocprim::radix_sort_pairs failed");
-    hipLaunchKernelGGL(k_shard_gather<W>, grid, block, 0, st, E.d, rec, E.tags_sorted, E.idx_sorted, n, E.ctag, E.cpref);
-    E.epoch++;
-    hipLaunchKernelGGL(k_insert_tab<W>, grid, block, 0, st, E.d, (uint32_t)n, E.epoch, 0);
-    hipLaunchKernelGGL(k_mark_tab<W>, grid, block, 0, st, E.d, (uint32_t)n, E.epoch);
-    tb = E.scan_tmp;
-    if (rocprim::exclusive_scan(E.tmp_buf.p, tb, E.d.cflag, E.d.cpos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st) != hipSuccess)
-        return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan failed");
-    hipLaunchKernelGGL(k_shard_win_tags<W>, grid, block, 0, st, E.d, E.ctag, n, win_tags);
-    ACX_HIP_TRY(hipGetLastError());
-    uint32_t last[2];
-    ACX_HIP_TRY(hipMemcpyAsync(&last[0], E.d.cpos + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    ACX_HIP_TRY(hipMemcpyAsync(&last[1], E.d.cflag + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    ACX_HIP_TRY(hipStreamSynchronize(st));
-    *n_win = (int64_t)last[0] + last[1];
-    return ACX_OK;
-}
-
-template <typename W> static int shard_commit(ShardEngine<W>& E, int64_t cutoff, int64_t* first_id, int64_t* n_committed, hipStream_t st) {
-    *first_id = (int64_t)E.nodes;
-    *n_committed = 0;
-    const int64_t n = E.pending;
-    E.pending = 0;
-    if (n <= 0) return ACX_OK;
-    hipLaunchKernelGGL(k_shard_count<W>, dim3(1), dim3(1), 0, st, E.d, E.ctag, n, cutoff, E.commit_count);
-    hipLaunchKernelGGL(k_shard_commit<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, E.d, E.ctag, E.cpref, n, cutoff, (uint32_t)E.nodes,
-                       E.node_pref);
-    ACX_HIP_TRY(hipGetLastError());
-    uint32_t c = 0;
-    ACX_HIP_TRY(hipMemcpyAsync(&c, E.commit_count, 4, hipMemcpyDeviceToHost, st));
-    ACX_HIP_TRY(hipStreamSynchronize(st));
-    if (E.nodes + c > E.cap_nodes) return fail(ACX_E_CAPACITY, "acx_shard_commit: node capacity exceeded");
-    E.nodes += c;
-    *n_committed = c;
-    return ACX_OK;
-}
-
-template <typename W> static int shard_node_info(ShardEngine<W>& E, int64_t id, int64_t* info) {
-    if (id < 0 || (uint64_t)id >= E.nodes) return fail(ACX_E_INVAL, "acx_shard_node_info: id out of range");
-    uint8_t a = 0, l = 0;
-    int64_t pr = 0;
-    ACX_HIP_TRY(hipDeviceSynchronize());
-    ACX_HIP_TRY(hipMemcpy(&a, E.d.act + id, 1, hipMemcpyDeviceToHost));
-    ACX_HIP_TRY(hipMemcpy(&l, E.d.tlen + id, 1, hipMemcpyDeviceToHost));
-    ACX_HIP_TRY(hipMemcpy(&pr, E.node_pref + id, 8, hipMemcpyDeviceToHost));
-    info[0] = pr < 0 ? -1 : (int64_t)a;
-    info[1] = l;
-    info[2] = pr;
-    return ACX_OK;
-}
-
 }  // namespace acx
 
 using namespace acx;
@@ -1590,94 +700,3 @@ extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t 
         if (rc_out[k] != ACX_OK && rc_out[k] != ACX_E_CAPACITY) return fail(ACX_E_ROWERR, "acx_search_many: search %lld failed with code %d", (long long)k, rc_out[k]);
     return ACX_OK;
 }
-
-// ------------------------------------------------------------------ sharded frontier: C ABI ----
-struct acx_shard {
-    acx::ShardAny any;
-};
-
-extern "C" {
-
-int acx_shard_key_words(int L) { return L <= 29 ? 2 : 4; }
-
-acx_shard* acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t batch_cap, int rank, int world) {
-    if (!have_device()) return nullptr;
-    if (L < 1 || L > 61 || node_cap < 1 || batch_cap < 1 || world < 1 || rank < 0 || rank >= world) {
-        fail(ACX_E_INVAL, "acx_shard_create: bad argument (1 <= L <= 61)");
-        return nullptr;
-    }
-    acx_shard* h = new (std::nothrow) acx_shard();
-    if (!h) return nullptr;
-    h->any.wide = L > 29;
-    int rc;
-    if (h->any.wide) {
-        h->any.e128 = new ShardEngine<u128>();
-        rc = h->any.e128->init(L, cyclical, node_cap, batch_cap, rank, world);
-    } else {
-        h->any.e64 = new ShardEngine<uint64_t>();
-        rc = h->any.e64->init(L, cyclical, node_cap, batch_cap, rank, world);
-    }
-    if (rc != ACX_OK) {
-        delete h->any.e64;
-        delete h->any.e128;
-        delete h;
-        return nullptr;
-    }
-    return h;
-}
-
-void acx_shard_destroy(acx_shard* h) {
-    if (!h) return;
-    delete h->any.e64;
-    delete h->any.e128;
-    delete h;
-}
-
-int acx_shard_root_record(acx_shard* h, const int8_t* h_presentation, int64_t* h_record) {
-    if (!h || !h_presentation || !h_record) return fail(ACX_E_INVAL, "acx_shard_root_record: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_root<W>(E, h_presentation, h_record));
-}
-
-int acx_shard_expand(acx_shard* h, const int64_t* d_ids, const int64_t* d_gpos, int64_t np, int64_t* d_records, int64_t* d_solved, void* stream) {
-    if (!h || np < 0 || (np > 0 && (!d_ids || !d_gpos || !d_records || !d_solved))) return fail(ACX_E_INVAL, "acx_shard_expand: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_expand<W>(E, d_ids, d_gpos, np, d_records, d_solved, (hipStream_t)stream));
-}
-
-int acx_shard_expand_routed(acx_shard* h, const int64_t* d_ids, const int64_t* d_gpos, int64_t np, int64_t* d_records, int64_t region_cap,
-                            int64_t* d_counts, int64_t* d_solved, void* stream) {
-    if (!h || np < 0 || region_cap < 0 || !d_counts || (np > 0 && (!d_ids || !d_gpos || !d_records || !d_solved)))
-        return fail(ACX_E_INVAL, "acx_shard_expand_routed: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_expand_routed<W>(E, d_ids, d_gpos, np, d_records, region_cap, d_counts, d_solved, (hipStream_t)stream));
-}
-
-int acx_shard_insert(acx_shard* h, const int64_t* d_records, int64_t n, int tag_bits, int64_t* d_win_tags, int64_t* n_win, void* stream) {
-    if (!h || n < 0 || !n_win || (n > 0 && (!d_records || !d_win_tags))) return fail(ACX_E_INVAL, "acx_shard_insert: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_insert<W>(E, d_records, n, tag_bits, d_win_tags, n_win, (hipStream_t)stream));
-}
-
-int acx_shard_commit(acx_shard* h, int64_t cutoff_tag, int64_t* first_id, int64_t* n_committed, void* stream) {
-    if (!h || !first_id || !n_committed) return fail(ACX_E_INVAL, "acx_shard_commit: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_commit<W>(E, cutoff_tag, first_id, n_committed, (hipStream_t)stream));
-}
-
-int acx_shard_node_info(acx_shard* h, int64_t id, int64_t* h_info3) {
-    if (!h || !h_info3) return fail(ACX_E_INVAL, "acx_shard_node_info: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_node_info<W>(E, id, h_info3));
-}
-
-int64_t acx_shard_node_count(acx_shard* h) {
-    if (!h) return 0;
-    return h->any.wide ? (int64_t)h->any.e128->nodes : (int64_t)h->any.e64->nodes;
-}
-
-int acx_shard_status(acx_shard* h, int32_t* err, int32_t* min_len) {
-    if (!h || !err || !min_len) return fail(ACX_E_INVAL, "acx_shard_status: bad argument");
-    uint32_t v[2];
-    ACX_HIP_TRY(hipDeviceSynchronize());
-    ACX_SHARD_DISPATCH(&h->any, ACX_HIP_TRY(hipMemcpy(v, E.d.err, 8, hipMemcpyDeviceToHost)));
-    *err = (int32_t)v[0];
-    *min_len = (int32_t)v[1];
-    return ACX_OK;
-}
-
-}  // extern "C"
