@@ -87,6 +87,25 @@ def test_stats_match_oracle_node_counts(search):
             assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (kind, budget, st, wst)
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("algo", ["greedy", "bfs"])
+def test_full_size_config3_ak3_budget_1e7_against_oracle(search, algo):
+    """BASELINE config 3 at its full size: AK(3) at max_relator_length = 25, 1e7-node budget -- identical (solved, path)
+    and identical node / expansion counts as the CPU oracle (which needs a few seconds for it)."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search
+    from oracle import ac_oracle as O
+
+    ak3 = np.zeros(50, np.int8)
+    ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+    ak3[25:31] = [1, 2, 1, -2, -1, -2]
+    kind, ofn = (_acx.SEARCH_GREEDY, O.greedy_search) if algo == "greedy" else (_acx.SEARCH_BFS, O.bfs)
+    ok, path, st = run_search(kind, ak3, 10**7, False)
+    wok, wpath, wst = ofn(ak3, 10**7, stats=True)
+    assert (ok, path) == (wok, wpath) and not ok
+    assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (st, wst)
+
+
 def test_greedy_batch_per_launch_path_equals_device_frontier(search, golden_json, monkeypatch):
     """greedy_search runs on the persistent one-workgroup frontier (acx_greedy.h); the batch-per-launch path it falls
     back to when a capacity is exceeded (ACX_GREEDY_HOST=1 forces it) must return the same thing."""
