@@ -43,6 +43,11 @@ struct BucketRec {
     uint32_t pad[3];
 };
 
+template <typename W> struct alignas(2 * sizeof(W)) NodeKey {
+    W k0, k1;
+};
+constexpr unsigned long long kTabEmpty = ~0ull;
+
 template <typename W> struct GreedyDev {
     SearchDev<W> d;
     BucketRec* bk;      // [nlen * kDepthCap], zero-initialised
@@ -51,7 +56,9 @@ template <typename W> struct GreedyDev {
     W* gk0;             // scratch for sorting buckets larger than the LDS: keys and ids in run order
     W* gk1;
     uint32_t* gid;
-    uint16_t* fp;       // [n_slots + 4] 16-bit fingerprint of the key behind every occupied slot of the visited table
+    NodeKey<W>* nkeys;  // [cap_nodes] packed key of every node, both relators in one 16 / 32-byte record (one request per compare)
+    unsigned long long* tab;  // visited table: node id | 32-bit key fingerprint << 32, kTabEmpty when free; tmask = entries - 1.
+    uint32_t tmask;           // Probe sequences advance in 16-byte pairs of slots (one memory request per step).
     W root_k0, root_k1; // the initial presentation (node 0)
     uint32_t arena_cap; // entries
     uint32_t nlen;      // 2L + 1 total lengths
@@ -68,7 +75,7 @@ struct GreedyOut {
     unsigned long long sorts, big_sorts;
     uint32_t hist_sort[16];  // sorts by log2(bucket size)
     uint32_t hist_np[16];    // batches by log2(parents)
-    unsigned long long t_phase[8];  // shader-clock cycles per phase (thread 0): select, sort, expand, probe, scan+decide, commit, file, tail
+    unsigned long long t_phase[12];  // [8] global probe rounds (cycles), [9] probe rounds of wave 0 (count)  // shader-clock cycles per phase (thread 0): select, sort, expand, probe, scan+decide, commit, file, tail
 };
 
 template <typename W> struct greedy_cfg;
@@ -159,7 +166,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         s_reason, s_max_bucket, s_np_cap, s_last_child_len, s_solved_action, s_sorted_in_lds;
     __shared__ unsigned long long s_expanded, s_batches, s_sorts, s_big_sorts;
     __shared__ uint32_t s_hist[32];
-    __shared__ unsigned long long s_tph[8], s_tc;  // phase clock, kept by thread 0
+    __shared__ unsigned long long s_tph[12], s_tc;  // phase clock, kept by thread 0
 #if ACX_GREEDY_PROFILE
 #define ACX_TICK(k) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); s_tph[k] += now__ - s_tc; s_tc = now__; } } while (0)
 #else
@@ -170,27 +177,26 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
     const uint32_t lane = tid & 63, wv = tid >> 6;
     const SearchDev<W>& d = g.d;
     const uint32_t nlen = g.nlen;
-    const uint32_t gmask = d.smask & ~3u;  // probe sequences start on a 4-slot group
+    const uint32_t gmask = g.tmask & ~1u;  // probe sequences start on a 2-slot (16-byte) pair
 
     if (tid < 132) {
         s_len_count[tid] = 0;
         s_hint[tid] = kDepthCap;
     }
     if (tid < 32) s_hist[tid] = 0;
-    if (tid < 8) s_tph[tid] = 0;
+    if (tid < 12) s_tph[tid] = 0;
     if (tid == 0) s_tc = clock64();
     __syncthreads();
     if (tid == 0) {
         // root: node 0, first entry of the visited table and of the heap (bucket (root_len, 0))
-        d.k0[0] = g.root_k0;
-        d.k1[0] = g.root_k1;
+        g.nkeys[0].k0 = g.root_k0;
+        g.nkeys[0].k1 = g.root_k1;
         d.parent[0] = kEmpty;
         d.act[0] = 0xff;
         d.tlen[0] = (uint8_t)g.root_len;
         d.depth[0] = 0;
         const uint64_t h = hash_key<W>(g.root_k0, g.root_k1);
-        d.slots[(uint32_t)h & gmask] = 0;
-        g.fp[(uint32_t)h & gmask] = (uint16_t)(h >> 48);
+        g.tab[(uint32_t)h & gmask] = (h >> 32) << 32;  // node 0 with its fingerprint
         BucketRec r = {0u, 16u, 0u, 1u, 1u, {0u, 0u, 0u}};
         g.arena[0] = 0;
         g.bk[(size_t)g.root_len * kDepthCap] = r;
@@ -283,8 +289,9 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                     W m0 = 0, m1 = 0;
                     if (tid < n) {
                         myid = g.arena[base + tid];
-                        m0 = d.k0[myid];
-                        m1 = d.k1[myid];
+                        const NodeKey<W> nk = g.nkeys[myid];
+                        m0 = nk.k0;
+                        m1 = nk.k1;
                         sk0[tid] = m0;
                         sk1[tid] = m1;
                         s_btab[tid] = 0;  // rank
@@ -314,8 +321,9 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                     for (uint32_t i = tid; i < n; i += kGT) {
                         const uint32_t id = g.arena[base + i];
                         sid[i] = id;
-                        sk0[i] = d.k0[id];
-                        sk1[i] = d.k1[id];
+                        const NodeKey<W> nk = g.nkeys[id];
+                        sk0[i] = nk.k0;
+                        sk1[i] = nk.k1;
                     }
                     lds_sort<W>(sk0, sk1, sid, n, tid);
                     for (uint32_t i = tid; i < n; i += kGT) g.arena[base + i] = sid[i];
@@ -327,8 +335,9 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                         for (uint32_t i = tid; i < rn; i += kGT) {
                             const uint32_t id = g.arena[base + r0 + i];
                             sid[i] = id;
-                            sk0[i] = d.k0[id];
-                            sk1[i] = d.k1[id];
+                            const NodeKey<W> nk = g.nkeys[id];
+                            sk0[i] = nk.k0;
+                            sk1[i] = nk.k1;
                         }
                         lds_sort<W>(sk0, sk1, sid, rn, tid);
                         for (uint32_t i = tid; i < rn; i += kGT) {
@@ -387,8 +396,9 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                     p1 = sk1[tid];
                 } else {
                     pi = g.arena[s_rec.off + s_rec.head + tid];
-                    p0 = d.k0[pi];
-                    p1 = d.k1[pi];
+                    const NodeKey<W> nk = g.nkeys[pi];
+                    p0 = nk.k0;
+                    p1 = nk.k1;
                 }
             }
             __syncthreads();  // the sort arrays are free from here on
@@ -411,12 +421,12 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         for (uint32_t i = tid; i < bt; i += kGT) s_btab[i] = kEmpty;
         __syncthreads();
         // per-lane candidates: tag t = r * 1024 + tid  (parent t / 12, action t % 12); keys live in LDS (sk0/sk1[t])
-        uint32_t hv[R], hb[R], fl[R];  // fl: bit0 active, bit1 known, bit2 winner, bit3 commit, bits 16.. fingerprint
+        uint32_t hv[R], hb[R], fl[R], fpv[R];  // fl: bit0 active, bit1 known, bit2 winner, bit3 commit; fpv: 32-bit key fingerprint
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t t = (uint32_t)r * kGT + tid;
             fl[r] = 0;
-            hv[r] = hb[r] = 0;
+            hv[r] = hb[r] = fpv[r] = 0;
             if (t < m) {
                 const uint32_t p = t / 12u;
                 Pres<W> s;
@@ -431,71 +441,64 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                 const uint64_t h = hash_key<W>(c0, c1);
                 hv[r] = (uint32_t)h & gmask;
                 hb[r] = (uint32_t)h & (bt - 1);
-                fl[r] = 1u | ((uint32_t)(h >> 48) << 16);
+                fl[r] = 1u;
+                fpv[r] = (uint32_t)(h >> 32);
                 if (tl == 2) atomicMin(&s_solved, t);  // greedy.py:91, before the membership test
             }
         }
         __syncthreads();  // candidate keys visible, tables cleared
         ACX_TICK(2);
-        // read-only probe of the visited table: 4 slots + their 16-bit fingerprints per round trip, the lane's R
-        // candidates in flight together; a full key is fetched only behind a matching fingerprint
+        // read-only probe of the visited table: a 16-byte pair of slots (id + 32-bit fingerprint each) per memory request,
+        // the lane's R candidates in flight together; a full key is fetched only behind a matching fingerprint
         {
             uint32_t pend = 0;
 #pragma unroll
             for (int r = 0; r < R; r++) pend |= (fl[r] & 1u) << r;
             while (pend) {
-                uint4 sl[R];
-                uint2 fq[R];
+#if ACX_GREEDY_PROFILE
+                if (tid == 0) s_tph[9]++;
+#endif
+                ulonglong2 sl[R];
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    if ((pend >> r) & 1u) {
-                        sl[r] = *(const uint4*)(d.slots + hv[r]);
-                        fq[r] = *(const uint2*)(g.fp + hv[r]);
-                    }
-                }
+                for (int r = 0; r < R; r++)
+                    if ((pend >> r) & 1u) sl[r] = *(const ulonglong2*)(g.tab + hv[r]);
                 uint32_t cand[R];
-                W a0[R], a1[R];
+                NodeKey<W> nk[R];
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     cand[r] = kEmpty;
                     if (!((pend >> r) & 1u)) continue;
-                    const uint32_t myfp = fl[r] >> 16;
-                    const uint32_t s4[4] = {sl[r].x, sl[r].y, sl[r].z, sl[r].w};
-                    const uint32_t f4[4] = {fq[r].x & 0xffffu, fq[r].x >> 16, fq[r].y & 0xffffu, fq[r].y >> 16};
-                    // sub-slot to resume at (after a fingerprint that turned out to belong to another key)
-                    const uint32_t j0 = hb[r] >> 28;
+                    const unsigned long long s2[2] = {sl[r].x, sl[r].y};
+                    const uint32_t j0 = hb[r] >> 28;  // sub-slot to resume at (after a fingerprint that belonged to another key)
                     bool stop = false;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
+                    for (int j = 0; j < 2; j++) {
                         if (stop || (uint32_t)j < j0) continue;
-                        if (s4[j] == kEmpty) {  // first empty slot of the probe sequence: not in the table
+                        if (s2[j] == kTabEmpty) {  // first empty slot of the probe sequence: not in the table
                             hv[r] += (uint32_t)j;
                             pend &= ~(1u << r);
                             stop = true;
-                        } else if (f4[j] == myfp) {
-                            cand[r] = s4[j];
+                        } else if ((uint32_t)(s2[j] >> 32) == fpv[r]) {
+                            cand[r] = (uint32_t)s2[j];
                             hb[r] = (hb[r] & 0x0FFFFFFFu) | ((uint32_t)(j + 1) << 28);
                             stop = true;
                         }
                     }
-                    if (!stop) {  // group exhausted
-                        hv[r] = (hv[r] + 4) & d.smask;
+                    if (!stop) {  // pair exhausted
+                        hv[r] = (hv[r] + 2) & g.tmask;
                         hb[r] &= 0x0FFFFFFFu;
                     }
-                    if (cand[r] != kEmpty) {
-                        a0[r] = d.k0[cand[r]];
-                        a1[r] = d.k1[cand[r]];
-                    }
+                    if (cand[r] != kEmpty) nk[r] = g.nkeys[cand[r]];
                 }
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     if (cand[r] == kEmpty) continue;
                     const uint32_t t = (uint32_t)r * kGT + tid;
-                    if (a0[r] == sk0[t] && a1[r] == sk1[t]) {
+                    if (nk[r].k0 == sk0[t] && nk[r].k1 == sk1[t]) {
                         fl[r] |= 2u;
                         pend &= ~(1u << r);
-                    } else if ((hb[r] >> 28) >= 4) {  // false fingerprint match in the group's last slot
-                        hv[r] = (hv[r] + 4) & d.smask;
+                    } else if ((hb[r] >> 28) >= 2) {  // false fingerprint match in the pair's last slot
+                        hv[r] = (hv[r] + 2) & g.tmask;
                         hb[r] &= 0x0FFFFFFFu;
                     }
                 }
@@ -503,6 +506,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
 #pragma unroll
             for (int r = 0; r < R; r++) hb[r] &= 0x0FFFFFFFu;
         }
+        ACX_TICK(8);
         // in-batch dedup: the minimum tag among equal keys wins
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -598,8 +602,10 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                 fl[r] |= 8u;
                 const uint32_t id = nodes + cpos[r], p = t / 12u;
                 tl = s_clen[t];
-                d.k0[id] = sk0[t];
-                d.k1[id] = sk1[t];
+                NodeKey<W> nk;
+                nk.k0 = sk0[t];
+                nk.k1 = sk1[t];
+                g.nkeys[id] = nk;
                 d.parent[id] = sp_id[p];
                 d.act[id] = (uint8_t)(t - 12u * p);
                 d.tlen[id] = (uint8_t)tl;
@@ -623,9 +629,10 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         if (lane == 0 && seen != 0xFFFFFFFFu) atomicMin(&s_seen_min, seen);
         // visited-table insertion: the keys are pairwise distinct and absent; the CAS goes to the empty slot the probe
         // ended on and is only looked at after the filing phase (its round trip overlaps with it)
-        uint32_t cas_old[R];
+        unsigned long long cas_old[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) cas_old[r] = (fl[r] & 8u) ? atomicCAS(&d.slots[hv[r]], kEmpty, nodes + cpos[r]) : kEmpty;
+        for (int r = 0; r < R; r++)
+            cas_old[r] = (fl[r] & 8u) ? atomicCAS(&g.tab[hv[r]], kTabEmpty, (unsigned long long)(nodes + cpos[r]) | ((unsigned long long)fpv[r] << 32)) : kTabEmpty;
         lds_barrier();
         ACX_TICK(5);
         // ---- file the new nodes into their buckets (total length, depth + 1): one owner lane per length ----
@@ -670,21 +677,12 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         lds_barrier();
         ACX_TICK(6);
         if (s_status != GREEDY_RUNNING) break;
-        {  // settle the table insertions (a failed CAS means another new key took the slot in this batch: rare)
-            uint32_t pend = 0;
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                if (!(fl[r] & 8u)) continue;
-                if (cas_old[r] == kEmpty) g.fp[hv[r]] = (uint16_t)(fl[r] >> 16);
-                else pend |= 1u << r;
-            }
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                if (!((pend >> r) & 1u)) continue;
-                do hv[r] = (hv[r] + 1) & d.smask;
-                while (atomicCAS(&d.slots[hv[r]], kEmpty, nodes + cpos[r]) != kEmpty);
-                g.fp[hv[r]] = (uint16_t)(fl[r] >> 16);
-            }
+        for (int r = 0; r < R; r++) {  // settle the table insertions (a failed CAS: another new key took the slot in this batch, rare)
+            if (!(fl[r] & 8u) || cas_old[r] == kTabEmpty) continue;
+            const unsigned long long mine = (unsigned long long)(nodes + cpos[r]) | ((unsigned long long)fpv[r] << 32);
+            do hv[r] = (hv[r] + 1) & g.tmask;
+            while (atomicCAS(&g.tab[hv[r]], kTabEmpty, mine) != kTabEmpty);
         }
         for (uint32_t j = 0; j < s_njobs; j++) {  // grown buckets move to their new region
             const uint32_t src = s_job[3 * j], dst = s_job[3 * j + 1], cnt = s_job[3 * j + 2];
@@ -741,7 +739,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         out->max_bucket = s_max_bucket;
         out->sorts = s_sorts;
         out->big_sorts = s_big_sorts;
-        for (int k = 0; k < 8; k++) out->t_phase[k] = s_tph[k];
+        for (int k = 0; k < 12; k++) out->t_phase[k] = s_tph[k];
         for (int k = 0; k < 16; k++) out->hist_sort[k] = s_hist[k], out->hist_np[k] = s_hist[16 + k];
         out->path_n = 0;
         if (path_act && (s_status == GREEDY_SOLVED || s_status == GREEDY_BUDGET || s_status == GREEDY_EXHAUSTED)) {

@@ -40,7 +40,8 @@ template <typename W> struct Searcher {
     }
 
     // inline_tab: BFS visited table with inline keys (TabEntry); otherwise the id table of the greedy paths
-    int init(int L, int cyclical, int64_t max_nodes, uint32_t batch_parents, bool greedy, bool inline_tab = false) {
+    // lean: no key arrays and no table (the persistent greedy frontier keeps its own: GreedyDev::nkeys / tab)
+    int init(int L, int cyclical, int64_t max_nodes, uint32_t batch_parents, bool greedy, bool inline_tab = false, bool lean = false) {
         memset(&d, 0, sizeof(d));
         // every search owns a stream, so that searches driven from different host threads overlap on the GPU
         ACX_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -62,8 +63,8 @@ template <typename W> struct Searcher {
         for (int pass = 0; pass < 2; pass++) {
             uint8_t* b = (uint8_t*)arena_nodes.p;
             o = 0;
-            d.k0 = (W*)take(b, cap_nodes * sizeof(W));
-            d.k1 = (W*)take(b, cap_nodes * sizeof(W));
+            d.k0 = (W*)take(b, lean ? 0 : cap_nodes * sizeof(W));
+            d.k1 = (W*)take(b, lean ? 0 : cap_nodes * sizeof(W));
             d.parent = (uint32_t*)take(b, cap_nodes * 4);
             d.depth = (uint32_t*)take(b, cap_nodes * 4);
             d.act = (uint8_t*)take(b, cap_nodes);
@@ -82,7 +83,10 @@ template <typename W> struct Searcher {
             d.cknown = (uint8_t*)take(b, cap_cand);
             if (pass == 0 && arena_cand.alloc(o)) return ACX_E_NOMEM;
         }
-        if (inline_tab) {
+        if (lean) {
+            d.tab = nullptr;
+            d.slots = nullptr;
+        } else if (inline_tab) {
             if (arena_tab.alloc(n_slots * sizeof(TabEntry<W>))) return ACX_E_NOMEM;
             d.tab = (TabEntry<W>*)arena_tab.p;
             d.tmask = (uint32_t)(n_slots - 1);
@@ -114,7 +118,7 @@ template <typename W> struct Searcher {
             return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan sizing failed");
         tmp_bytes = need + 256;
         if (arena_tmp.alloc(tmp_bytes)) return ACX_E_NOMEM;
-        ACX_HIP_TRY(hipMemsetAsync(arena_tab.p, 0xff, n_slots * (inline_tab ? sizeof(TabEntry<W>) : 4), st));
+        if (!lean) ACX_HIP_TRY(hipMemsetAsync(arena_tab.p, 0xff, n_slots * (inline_tab ? sizeof(TabEntry<W>) : 4), st));
         ACX_HIP_TRY(hipMemsetAsync(arena_scal.p, 0xff, 256, st));
         ACX_HIP_TRY(hipMemsetAsync(d.err, 0, 4, st));
         return ACX_OK;
@@ -157,11 +161,11 @@ static int err_to_rc(uint32_t e) {
 // Device buffers of one greedy search on the persistent frontier
 template <typename W> struct GreedySearch {
     Searcher<W> S;
-    DevBuf bk, bitmap, arena, gk0, gk1, gid, fpb;
+    DevBuf bk, bitmap, arena, gk0, gk1, gid, nkeys, tab;
     GreedyDev<W> g;
     // `st`: stream for the bucket-table memsets (nullptr = the search's own stream, S.st)
     int setup(const Pres<W>& root, int L, int64_t max_nodes, int cyclical, hipStream_t st) {
-        int rc = S.init(L, cyclical, max_nodes, 1024, false);
+        int rc = S.init(L, cyclical, max_nodes, 1024, false, false, true);
         if (rc) return rc;
         if (!st) st = S.st;
         g.d = S.d;
@@ -170,8 +174,11 @@ template <typename W> struct GreedySearch {
         g.root_len = (uint32_t)(root.n0 + root.n1);
         const uint64_t arena_entries = std::min<uint64_t>(8ull * (uint64_t)std::max<int64_t>(max_nodes, 1) + (1ull << 20), 1ull << 31);
         g.arena_cap = (uint32_t)arena_entries;
-        if (fpb.alloc((S.n_slots + 8) * 2)) return ACX_E_NOMEM;  // never read behind an empty slot, so no initialisation
-        g.fp = (uint16_t*)fpb.p;
+        if (nkeys.alloc(S.cap_nodes * sizeof(NodeKey<W>)) || tab.alloc(S.n_slots * 8)) return ACX_E_NOMEM;
+        g.nkeys = (NodeKey<W>*)nkeys.p;
+        g.tab = (unsigned long long*)tab.p;
+        g.tmask = (uint32_t)(S.n_slots - 1);
+        ACX_HIP_TRY(hipMemsetAsync(tab.p, 0xff, S.n_slots * 8, st));
         g.root_k0 = keyops<W>::make(root.w0, root.n0);
         g.root_k1 = keyops<W>::make(root.w1, root.n1);
         const size_t sort_cap = (size_t)std::max<int64_t>(max_nodes, 1) + 64;  // a bucket never holds more than all nodes
@@ -207,10 +214,10 @@ static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_no
     const uint64_t arena_entries = std::min<uint64_t>(8ull * (uint64_t)std::max<int64_t>(max_nodes, 1) + (1ull << 20), 1ull << 31);
     const uint64_t sort_cap = (uint64_t)std::max<int64_t>(max_nodes, 1) + 64;
     auto up = [](uint64_t b) { return (b + 255) / 256 * 256; };
-    const uint64_t b_slots = up(n_slots * 4), b_bk = up((uint64_t)nlen * kDepthCap * sizeof(BucketRec)), b_bm = up((uint64_t)nlen * (kDepthCap / 32) * 4);
-    const uint64_t b_fp = up((n_slots + 8) * 2), b_arena = up(arena_entries * 4), b_key = up(cap_nodes * sizeof(W)), b_u32 = up(cap_nodes * 4), b_u8 = up(cap_nodes);
+    const uint64_t b_slots = up(n_slots * 8), b_bk = up((uint64_t)nlen * kDepthCap * sizeof(BucketRec)), b_bm = up((uint64_t)nlen * (kDepthCap / 32) * 4);
+    const uint64_t b_arena = up(arena_entries * 4), b_key = up(cap_nodes * sizeof(NodeKey<W>)), b_u32 = up(cap_nodes * 4), b_u8 = up(cap_nodes);
     const uint64_t b_gk = up(sort_cap * sizeof(W)), b_gid = up(sort_cap * 4);
-    const uint64_t per_rest = b_fp + b_arena + 2 * b_key + 2 * b_u32 + 2 * b_u8 + 2 * b_gk + b_gid;
+    const uint64_t per_rest = b_arena + b_key + 2 * b_u32 + 2 * b_u8 + 2 * b_gk + b_gid;
     const uint64_t total = (uint64_t)n * (b_slots + b_bk + b_bm + per_rest);
     DevBuf big;
     if (big.alloc(total)) return ACX_E_NOMEM;
@@ -245,14 +252,12 @@ static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_no
             q += bytes;
             return r;
         };
-        g.d.slots = (uint32_t*)(p_slots + (uint64_t)k * b_slots);
-        g.d.smask = (uint32_t)(n_slots - 1);
+        g.tab = (unsigned long long*)(p_slots + (uint64_t)k * b_slots);
+        g.tmask = (uint32_t)(n_slots - 1);
         g.bk = (BucketRec*)(p_bk + (uint64_t)k * b_bk);
         g.bitmap = (uint32_t*)(p_bm + (uint64_t)k * b_bm);
-        g.fp = (uint16_t*)take(b_fp);
         g.arena = (uint32_t*)take(b_arena);
-        g.d.k0 = (W*)take(b_key);
-        g.d.k1 = (W*)take(b_key);
+        g.nkeys = (NodeKey<W>*)take(b_key);
         g.d.parent = (uint32_t*)take(b_u32);
         g.d.depth = (uint32_t*)take(b_u32);
         g.d.act = take(b_u8);
@@ -367,6 +372,8 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
         fprintf(stderr, "\n");
         unsigned long long tot = 0;
         for (int k = 0; k < 8; k++) tot += o.t_phase[k];
+        if (tot) fprintf(stderr, "[acx_greedy] probe: %.1f%% of the cycles in the table rounds, %.2f rounds per batch (wave 0)\n", 100.0 * o.t_phase[8] / (tot + o.t_phase[8]),
+                         (double)o.t_phase[9] / (double)o.batches);
         if (tot) fprintf(stderr, "[acx_greedy] cycles%%: select %.1f sort %.1f expand %.1f probe %.1f scan %.1f commit %.1f file %.1f tail %.1f (total %.3e cycles)\n",
                 100.0 * o.t_phase[0] / tot, 100.0 * o.t_phase[1] / tot, 100.0 * o.t_phase[2] / tot, 100.0 * o.t_phase[3] / tot, 100.0 * o.t_phase[4] / tot,
                 100.0 * o.t_phase[5] / tot, 100.0 * o.t_phase[6] / tot, 100.0 * o.t_phase[7] / tot, (double)tot);
