@@ -89,8 +89,28 @@ template <typename W> __device__ __forceinline__ bool key_less(W a0, W a1, W b0,
     return compare_pres<W>(a, b) < 0;
 }
 
+// compare-exchange of LDS entries i < x: afterwards entry i precedes entry x in signed state order when `asc`
+// (padding ids 0xFFFFFFFF are the largest elements)
+template <typename W> __device__ __forceinline__ void lds_cmpx(W* sk0, W* sk1, uint32_t* sid, uint32_t i, uint32_t x, bool asc) {
+    const uint32_t ia = sid[i], ib = sid[x];
+    bool a_after_b;
+    if (ia == 0xFFFFFFFFu) a_after_b = ib != 0xFFFFFFFFu;
+    else if (ib == 0xFFFFFFFFu) a_after_b = false;
+    else a_after_b = key_less<W>(sk0[x], sk1[x], sk0[i], sk1[i]);
+    if (a_after_b == asc) {
+        const W t0 = sk0[i], t1 = sk1[i];
+        sk0[i] = sk0[x];
+        sk1[i] = sk1[x];
+        sk0[x] = t0;
+        sk1[x] = t1;
+        sid[i] = ib;
+        sid[x] = ia;
+    }
+}
+
 // Bitonic sort of the n entries (sid, sk0, sk1)[0..n) in LDS by signed state order; whole workgroup.
-template <typename W> __device__ __forceinline__ void lds_sort(W* sk0, W* sk1, uint32_t* sid, uint32_t n, uint32_t tid) {
+// `descending`: direction of the final merge (a chunk of a larger bitonic network is sorted against its neighbour).
+template <typename W> __device__ __forceinline__ void lds_sort(W* sk0, W* sk1, uint32_t* sid, uint32_t n, uint32_t tid, bool descending = false) {
     uint32_t P = 2;
     while (P < n) P <<= 1;
     for (uint32_t i = n + tid; i < P; i += kGT) sid[i] = 0xFFFFFFFFu;  // padding sorts last
@@ -99,25 +119,22 @@ template <typename W> __device__ __forceinline__ void lds_sort(W* sk0, W* sk1, u
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t q = tid; q < P / 2; q += kGT) {
                 const uint32_t i = ((q & ~(j - 1)) << 1) | (q & (j - 1));  // the q-th index with bit j clear
-                const uint32_t x = i | j;
-                const bool asc = (i & k) == 0;
-                const uint32_t ia = sid[i], ib = sid[x];
-                bool a_after_b;
-                if (ia == 0xFFFFFFFFu) a_after_b = ib != 0xFFFFFFFFu;
-                else if (ib == 0xFFFFFFFFu) a_after_b = false;
-                else a_after_b = key_less<W>(sk0[x], sk1[x], sk0[i], sk1[i]);
-                if (a_after_b == asc) {
-                    const W t0 = sk0[i], t1 = sk1[i];
-                    sk0[i] = sk0[x];
-                    sk1[i] = sk1[x];
-                    sk0[x] = t0;
-                    sk1[x] = t1;
-                    sid[i] = ib;
-                    sid[x] = ia;
-                }
+                const bool asc = k == P ? !descending : (i & k) == 0;
+                lds_cmpx<W>(sk0, sk1, sid, i, i | j, asc);
             }
             __syncthreads();
         }
+    }
+}
+
+// The merge stages j = P/2 .. 1 of a bitonic network on the P (power of two) LDS entries, all in one direction.
+template <typename W> __device__ __forceinline__ void lds_merge(W* sk0, W* sk1, uint32_t* sid, uint32_t P, uint32_t tid, bool asc) {
+    for (uint32_t j = P >> 1; j > 0; j >>= 1) {
+        for (uint32_t q = tid; q < P / 2; q += kGT) {
+            const uint32_t i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+            lds_cmpx<W>(sk0, sk1, sid, i, i | j, asc);
+        }
+        __syncthreads();
     }
 }
 
@@ -329,42 +346,71 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                     for (uint32_t i = tid; i < n; i += kGT) g.arena[base + i] = sid[i];
                     if (tid == 0) s_sorted_in_lds = 1;
                 } else {
-                    // runs of SC entries sorted in LDS and parked in the scratch arrays ...
-                    for (uint32_t r0 = 0; r0 < n; r0 += SC) {
-                        const uint32_t rn = n - r0 < SC ? n - r0 : SC;
-                        for (uint32_t i = tid; i < rn; i += kGT) {
-                            const uint32_t id = g.arena[base + r0 + i];
-                            sid[i] = id;
-                            const NodeKey<W> nk = g.nkeys[id];
-                            sk0[i] = nk.k0;
-                            sk1[i] = nk.k1;
+                    // bucket larger than the LDS: one bitonic network over P = 2^k >= n entries (padding sorts last).  Chunks of
+                    // SC entries are sorted / merged in LDS; only the compare-exchange stages whose stride reaches SC stream
+                    // through the scratch arrays in HBM (coalesced, a few hundred KB per stage).
+                    uint32_t P = SC;
+                    while (P < n) P <<= 1;
+                    for (uint32_t c0 = 0; c0 < P; c0 += SC) {
+                        for (uint32_t i = tid; i < SC; i += kGT) {
+                            const uint32_t gi = c0 + i;
+                            if (gi < n) {
+                                const uint32_t id = g.arena[base + gi];
+                                const NodeKey<W> nk = g.nkeys[id];
+                                sid[i] = id;
+                                sk0[i] = nk.k0;
+                                sk1[i] = nk.k1;
+                            } else {
+                                sid[i] = 0xFFFFFFFFu;
+                            }
                         }
-                        lds_sort<W>(sk0, sk1, sid, rn, tid);
-                        for (uint32_t i = tid; i < rn; i += kGT) {
-                            g.gid[r0 + i] = sid[i];
-                            g.gk0[r0 + i] = sk0[i];
-                            g.gk1[r0 + i] = sk1[i];
+                        lds_sort<W>(sk0, sk1, sid, SC, tid, ((c0 / SC) & 1u) != 0);
+                        for (uint32_t i = tid; i < SC; i += kGT) {
+                            g.gid[c0 + i] = sid[i];
+                            g.gk0[c0 + i] = sk0[i];
+                            g.gk1[c0 + i] = sk1[i];
                         }
                         __syncthreads();
                     }
-                    // ... then merged by rank: final position = own index in its run + the number of smaller
-                    // entries in every other run (the keys of a bucket are pairwise distinct)
-                    for (uint32_t i = tid; i < n; i += kGT) {
-                        const W m0 = g.gk0[i], m1 = g.gk1[i];
-                        const uint32_t myrun = i / SC;
-                        uint32_t pos = i - myrun * SC;
-                        for (uint32_t r0 = 0, q = 0; r0 < n; r0 += SC, q++) {
-                            if (q == myrun) continue;
-                            uint32_t lo = r0, hi = n - r0 < SC ? n : r0 + SC;
-                            while (lo < hi) {
-                                const uint32_t mid = (lo + hi) >> 1;
-                                if (key_less<W>(g.gk0[mid], g.gk1[mid], m0, m1)) lo = mid + 1;
-                                else hi = mid;
+                    for (uint32_t k = 2 * SC; k <= P; k <<= 1) {
+                        for (uint32_t j = k >> 1; j >= SC; j >>= 1) {  // strides that span chunks: through HBM
+                            for (uint32_t q = tid; q < P / 2; q += kGT) {
+                                const uint32_t i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), x = i | j;
+                                const bool asc = (i & k) == 0;
+                                const uint32_t ia = g.gid[i], ib = g.gid[x];
+                                const W a0 = g.gk0[i], a1 = g.gk1[i], b0 = g.gk0[x], b1 = g.gk1[x];
+                                bool a_after_b;
+                                if (ia == 0xFFFFFFFFu) a_after_b = ib != 0xFFFFFFFFu;
+                                else if (ib == 0xFFFFFFFFu) a_after_b = false;
+                                else a_after_b = key_less<W>(b0, b1, a0, a1);
+                                if (a_after_b == asc) {
+                                    g.gid[i] = ib;
+                                    g.gk0[i] = b0;
+                                    g.gk1[i] = b1;
+                                    g.gid[x] = ia;
+                                    g.gk0[x] = a0;
+                                    g.gk1[x] = a1;
+                                }
                             }
-                            pos += lo - r0;
+                            __syncthreads();
                         }
-                        g.arena[base + pos] = g.gid[i];
+                        for (uint32_t c0 = 0; c0 < P; c0 += SC) {  // the remaining strides stay inside a chunk: in LDS
+                            for (uint32_t i = tid; i < SC; i += kGT) {
+                                sid[i] = g.gid[c0 + i];
+                                sk0[i] = g.gk0[c0 + i];
+                                sk1[i] = g.gk1[c0 + i];
+                            }
+                            __syncthreads();
+                            lds_merge<W>(sk0, sk1, sid, SC, tid, (c0 & k) == 0);
+                            for (uint32_t i = tid; i < SC; i += kGT) {
+                                g.gid[c0 + i] = sid[i];
+                                g.gk0[c0 + i] = sk0[i];
+                                g.gk1[c0 + i] = sk1[i];
+                            }
+                            __syncthreads();
+                        }
                     }
+                    for (uint32_t i = tid; i < n; i += kGT) g.arena[base + i] = g.gid[i];
                 }
                 __syncthreads();
             }
@@ -373,6 +419,13 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                 if (n > s_max_bucket) s_max_bucket = n;
             }
             __syncthreads();
+#if ACX_GREEDY_PROFILE
+            if (tid == 0) {  // sort cycles by bucket-size class: [10] n > SC, [11] 256 < n <= SC (the rest is n <= 256)
+                const unsigned long long now = clock64();
+                if (n > SC) s_tph[10] += now - s_tc;
+                else if (n > 256) s_tph[11] += now - s_tc;
+            }
+#endif
             ACX_TICK(1);
         }
 

@@ -181,7 +181,7 @@ template <typename W> struct GreedySearch {
         ACX_HIP_TRY(hipMemsetAsync(tab.p, 0xff, S.n_slots * 8, st));
         g.root_k0 = keyops<W>::make(root.w0, root.n0);
         g.root_k1 = keyops<W>::make(root.w1, root.n1);
-        const size_t sort_cap = (size_t)std::max<int64_t>(max_nodes, 1) + 64;  // a bucket never holds more than all nodes
+        const size_t sort_cap = 2 * ((size_t)std::max<int64_t>(max_nodes, 1) + 64) + 4096;  // a bucket (<= all nodes) rounded up to a power of two
         if (gk0.alloc(sort_cap * sizeof(W)) || gk1.alloc(sort_cap * sizeof(W)) || gid.alloc(sort_cap * 4)) return ACX_E_NOMEM;
         g.gk0 = (W*)gk0.p;
         g.gk1 = (W*)gk1.p;
@@ -212,7 +212,7 @@ static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_no
     if (n_slots > (1ull << 31)) return fail(ACX_E_INVAL, "acx_search_many: budget too large for 32-bit node ids");
     const uint32_t nlen = (uint32_t)(2 * L + 1);
     const uint64_t arena_entries = std::min<uint64_t>(8ull * (uint64_t)std::max<int64_t>(max_nodes, 1) + (1ull << 20), 1ull << 31);
-    const uint64_t sort_cap = (uint64_t)std::max<int64_t>(max_nodes, 1) + 64;
+    const uint64_t sort_cap = 2 * ((uint64_t)std::max<int64_t>(max_nodes, 1) + 64) + 4096;  // a bucket rounded up to a power of two
     auto up = [](uint64_t b) { return (b + 255) / 256 * 256; };
     const uint64_t b_slots = up(n_slots * 8), b_bk = up((uint64_t)nlen * kDepthCap * sizeof(BucketRec)), b_bm = up((uint64_t)nlen * (kDepthCap / 32) * 4);
     const uint64_t b_arena = up(arena_entries * 4), b_key = up(cap_nodes * sizeof(NodeKey<W>)), b_u32 = up(cap_nodes * 4), b_u8 = up(cap_nodes);
@@ -372,6 +372,7 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
         fprintf(stderr, "\n");
         unsigned long long tot = 0;
         for (int k = 0; k < 8; k++) tot += o.t_phase[k];
+        if (tot) fprintf(stderr, "[acx_greedy] sort cycles: %.1f%% of all in buckets > LDS, %.1f%% in 256 < n <= LDS\n", 100.0 * o.t_phase[10] / tot, 100.0 * o.t_phase[11] / tot);
         if (tot) fprintf(stderr, "[acx_greedy] probe: %.1f%% of the cycles in the table rounds, %.2f rounds per batch (wave 0)\n", 100.0 * o.t_phase[8] / (tot + o.t_phase[8]),
                          (double)o.t_phase[9] / (double)o.batches);
         if (tot) fprintf(stderr, "[acx_greedy] cycles%%: select %.1f sort %.1f expand %.1f probe %.1f scan %.1f commit %.1f file %.1f tail %.1f (total %.3e cycles)\n",
