@@ -202,7 +202,11 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
     }
     if (tid < 32) s_hist[tid] = 0;
     if (tid < 12) s_tph[tid] = 0;
+#if ACX_GREEDY_PROFILE
     if (tid == 0) s_tc = clock64();
+#else
+    (void)s_tc;
+#endif
     __syncthreads();
     if (tid == 0) {
         // root: node 0, first entry of the visited table and of the heap (bucket (root_len, 0))
