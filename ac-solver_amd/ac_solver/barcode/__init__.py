@@ -1,0 +1,5 @@
+"""Neighbourhood sizes in the Andrews-Curtis graph -- the workload of the reference's C++ side program
+barcode_analysis/5_steps_neibourhoods, on the GPU."""
+from ac_solver.barcode.neighbourhoods import neighbourhood_sizes, neighbourhood_sizes_of_file
+
+__all__ = ["neighbourhood_sizes", "neighbourhood_sizes_of_file"]

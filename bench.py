@@ -395,11 +395,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int8 letters packed 2 bit/letter in u64",
+            "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": f"{N} batched ACEnv.step per GPU, Miller-Schupp initial states, max_relator_len={L}, horizon {HORIZON}, "
                                    "random action tape, int8 obs + f32 reward + done/truncated into HBM rollout buffers",
-                       "envs_per_gpu": N, "max_relator_length": L, "launch": mode, "parallelism": f"dp{world} (independent envs, no collective)"},
+                       "envs_per_gpu": N, "max_relator_length": L, "launch": mode, "state": "int8 letters packed 2 bit per letter in one u64 per relator", "parallelism": f"dp{world} (independent envs, no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_env_step<u64,int8>", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * N,
                          "avg_launch_us": launch_s * 1e6},

@@ -184,6 +184,16 @@ int64_t acx_shard_node_count(acx_shard *h);
 /* sticky move-error bits (a move emptied a relator: the reference raises) and the smallest total length seen */
 int acx_shard_status(acx_shard *h, int32_t *err, int32_t *min_len);
 
+/* ---- neighbourhood sizes ------------------------------------------------------------
+ * Replaces `neibourhood` of the reference's C++ side program (barcode_analysis/5_steps_neibourhoods/neibourhoods.cpp:18-54,
+ * moves and word arithmetic AC_UTILS_no_hash.cpp:83-211): number of distinct SORTED pairs of freely reduced relators
+ * (no length cap, free reduction only) within `radius` moves of each presentation, under the 14 "classic" (classic != 0)
+ * or the 12 "prime" moves.  h_presentations [n, 2L] int8 (zeros are dropped wherever they stand, as the reference's reader
+ * does); h_sizes [n]; h_max_len [n] (nullable): the longest relator met.  One workgroup per presentation; relators of up to
+ * 192 letters (ACX_E_CAPACITY beyond). */
+int acx_ball_sizes(const int8_t *h_presentations, int64_t n, int L, int radius, int classic, int64_t *h_sizes,
+                   int32_t *h_max_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,7 @@ class Stats(C.Structure):
 
 def build():
     """Compile the oracle with gcc (seconds)."""
-    subprocess.check_call(["make", "-s", "-C", _HERE, "libac_oracle.so"])
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libac_oracle.so", "libac_ball_oracle.so"])
 
 
 def _load():
@@ -172,3 +172,26 @@ def bfs(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_redu
 def greedy_search(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False,
                   stats=False):
     return _search(_lib.ac_greedy, presentation, max_nodes_to_explore, cyclically_reduce_after_moves, stats)
+
+
+# ---- neighbourhood sizes (ac_ball_oracle.c: restatement of barcode_analysis/5_steps_neibourhoods) --------------
+_ball = None
+
+
+def ball_size(presentation, radius=5, classic=False, return_max_length=False):
+    """Size of the radius-`radius` ball around `presentation` (zero-padded row [r1 | r2]) under the reference's prime /
+    classic moves on sorted pairs of freely reduced relators (neibourhoods.cpp:18-54)."""
+    global _ball
+    if _ball is None:
+        path = os.path.join(_HERE, "libac_ball_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _ball = C.CDLL(path)
+        _ball.ac_ball_size.restype = C.c_longlong
+        _ball.ac_ball_size.argtypes = [C.POINTER(C.c_int8), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    row = np.ascontiguousarray(presentation, dtype=np.int8)
+    ml = C.c_int(0)
+    size = _ball.ac_ball_size(row.ctypes.data_as(C.POINTER(C.c_int8)), len(row) // 2, int(radius), int(bool(classic)), C.byref(ml))
+    if size < 0:
+        raise OverflowError("a relator outgrew the oracle's buffer")
+    return (int(size), ml.value) if return_max_length else int(size)

@@ -132,3 +132,18 @@ def test_greedy_paths_file_all_533(golden_json):
     for row in g["rows"]:
         ok, path = O.greedy_search(pool[row["pool_index"]], g["budget"])
         assert ok and path == [tuple(x) for x in row["path"]], row["pool_index"]
+
+
+# ---- neighbourhood sizes: the C restatement against the reference's own program ----------------
+def test_ball_oracle_matches_reference_program(golden_json):
+    """oracle/ac_ball_oracle.c vs the sizes printed by the reference's neibourhoods.cpp (tests/golden/ball_sizes.json, made by
+    oracle/tools/make_ball_golden.py from oracle/_ref/ball_ref), including the five known answers of its README."""
+    from oracle import ac_oracle as O
+
+    cases = golden_json("ball_sizes.json")["cases"]
+    readme = [c["size"] for c in cases if c["tag"] == "readme" and not c["classic"]]
+    assert readme == [28631, 49668, 72392, 28631, 28631]  # README.txt:38-44
+    for c in cases:
+        if c["radius"] == 5 and c["tag"] not in ("readme", "ms_0", "ms_1100"):
+            continue  # the full radius on a few, the smaller radii on all (keeps the CPU suite short)
+        assert O.ball_size(c["presentation"], c["radius"], c["classic"]) == c["size"], (c["tag"], c["radius"], c["classic"])
