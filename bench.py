@@ -34,6 +34,7 @@ L = 25
 N_ENVS = 65536
 HORIZON = 1000
 ALGO_BYTES_PER_STEP = 4 * L + 7  # state in + out (2 x 2L), action 1, reward f32 4, done 1, truncated 1
+SEARCH_TIMEOUT_S = int(os.environ.get("ACX_BENCH_SEARCH_TIMEOUT", "240"))  # multi-rank runs: how long the RCCL-backed secondary measurements may take
 HBM_PEAK_GBS = 8000.0            # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 
 
@@ -334,10 +335,22 @@ def main():
     # graph above is being captured (envs are independent, so nothing before this point communicates)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-            os.environ["NCCL_DEBUG"] = "WARN"  # keeps RCCL's version banner out of stdout: rank 0 prints exactly one JSON line
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        dist.barrier()
+        # RCCL writes its version banner (NCCL_DEBUG=VERSION on these boxes) to the C stdout; stdout must carry exactly one
+        # JSON line, so file descriptor 1 points at stderr while the communicator comes up
+        import ctypes
+
+        libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            libc.fflush(None)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         if graph is not None:
             graph.replay()  # one untimed replay after the communicator came up
             torch.cuda.synchronize()
@@ -367,20 +380,7 @@ def main():
     # sanity: the timed steps really ran (count_steps advanced, rewards written)
     assert int(env.get_counts().max()) > 0 and bool(torch.isfinite(rew).all()) and bool((rew != 0).all())
 
-    extras = None
-    if rank == 0 and not args.no_extras:
-        try:
-            extras = extra_env_numbers(dev, pool)
-        except Exception as e:
-            extras = {"error": f"{type(e).__name__}: {e}"}
-    search = None
-    if not args.no_search:
-        try:
-            search = search_numbers(world, rank, dev, args.search_budget, use_dist)
-        except Exception as e:  # the headline line must survive a failure of the secondary measurement
-            search = {"error": f"{type(e).__name__}: {e}"}
-
-    if rank == 0:
+    def headline(extras, search):
         total_steps = N * K * world
         launch_s = dev_ms * 1e-3 / K
         achieved = ALGO_BYTES_PER_STEP * N / launch_s / 1e9
@@ -399,7 +399,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{N} batched ACEnv.step per GPU, Miller-Schupp initial states, max_relator_len={L}, horizon {HORIZON}, "
                                    "random action tape, int8 obs + f32 reward + done/truncated into HBM rollout buffers",
-                       "envs_per_gpu": N, "max_relator_length": L, "launch": mode, "state": "int8 letters packed 2 bit per letter in one u64 per relator", "parallelism": f"dp{world} (independent envs, no collective)"},
+                       "envs_per_gpu": N, "max_relator_length": L, "launch": mode, "state": "int8 letters packed 2 bit per letter in one u64 per relator",
+                       "parallelism": f"dp{world} (independent envs, no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_env_step<u64,int8>", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * N,
                          "avg_launch_us": launch_s * 1e6},
@@ -412,6 +413,41 @@ def main():
             out["env_context"] = extras
         if search is not None:
             out["search"] = search
+        return out
+
+    # The secondary measurements of a multi-rank run go through RCCL collectives (sharded BFS).  The timed headline is
+    # already in hand: if they have not come back after SEARCH_TIMEOUT_S seconds (a rank lost, a collective stuck), rank 0
+    # still prints its one JSON line and every rank leaves, instead of the whole job hanging.
+    watchdog = None
+    if use_dist and not args.no_search:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                print(json.dumps(headline(None, {"error": f"secondary measurements did not finish within {SEARCH_TIMEOUT_S} s"})), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(SEARCH_TIMEOUT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
+    extras = None
+    if rank == 0 and not args.no_extras:
+        try:
+            extras = extra_env_numbers(dev, pool)
+        except Exception as e:
+            extras = {"error": f"{type(e).__name__}: {e}"}
+    search = None
+    if not args.no_search:
+        try:
+            search = search_numbers(world, rank, dev, args.search_budget, use_dist)
+        except Exception as e:  # the headline line must survive a failure of the secondary measurement
+            search = {"error": f"{type(e).__name__}: {e}"}
+    if watchdog is not None:
+        watchdog.cancel()
+
+    if rank == 0:
+        out = headline(extras, search)
         if not args.no_cpu_baseline and world == 1 and not use_dist:
             out["cpu_baseline"] = cpu_baseline(states, 0)
             if not args.no_search:
