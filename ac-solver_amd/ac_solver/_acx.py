@@ -96,6 +96,7 @@ SIGNATURES = {
     "acx_shard_root_record": (C.c_int, [_vp, _i8p, _i64p]),
     "acx_shard_expand": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "acx_release_cached_memory": (C.c_int, []),
+    "acx_simplex_graph": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, _i64p, _u8p, _i64p, C.POINTER(C.c_uint32), _u8p]),
     "acx_ball_sizes": (C.c_int, [_i8p, C.c_int64, C.c_int, C.c_int, C.c_int, _i64p, C.POINTER(C.c_int32)]),
     "acx_shard_expand_routed": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp]),
     "acx_shard_insert": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _i64p, _vp]),

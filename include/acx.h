@@ -194,6 +194,15 @@ int acx_shard_status(acx_shard *h, int32_t *err, int32_t *min_len);
 int acx_ball_sizes(const int8_t *h_presentations, int64_t n, int L, int radius, int classic, int64_t *h_sizes,
                    int32_t *h_max_len);
 
+/* Replaces the reference's simplex-data programs barcode_analysis/simplex_data_generation/{prime,classic}_moves/ac_bfs.cpp:12-98:
+ * breadth-first search from <a, b> over sorted pairs of freely reduced relators of total length <= n; vertex k is the
+ * k-th presentation the reference names, h_node_size[k] its total length ("0-filt"); h_edges [n_edges, 2] / h_edge_filt are
+ * its "1-simplices" / "1-filt" lists in the order it writes them (an edge per (vertex, move) whose child has a larger name,
+ * repeats included; filtration = the larger of the two sizes).  ACX_E_CAPACITY when cap_nodes / cap_edges are too small
+ * (*n_nodes / *n_edges then hold the counts reached). */
+int acx_simplex_graph(int n, int classic, int64_t cap_nodes, int64_t cap_edges, int64_t *n_nodes, uint8_t *h_node_size,
+                      int64_t *n_edges, uint32_t *h_edges, uint8_t *h_edge_filt);
+
 #ifdef __cplusplus
 }
 #endif

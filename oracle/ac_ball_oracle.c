@@ -240,3 +240,99 @@ done:
     free(s.pool);
     return result;
 }
+
+/* ---- simplex data of the graph of presentations of total length <= n (barcode_analysis/simplex_data_generation) --------
+ * Restatement of {prime,classic}_moves/ac_bfs.cpp:12-98: breadth-first search from <a, b> over sorted pairs, children of
+ * total length > n are ignored; vertices are named in the order they are first met; for every (vertex, move) whose child
+ * has total length <= n and a LARGER name one edge (vertex, child) is written, with filtration value max(size, size)
+ * (an edge can be written more than once).  The moves are those of AC_UTILS_as_sets.h:298-364 -- the same tables as
+ * 5_steps_neibourhoods (prime: 12, classic: 14).
+ * node_size[cap_nodes], edges[2 * cap_edges], edge_filt[cap_edges]; returns 0, or -1 when a capacity is too small
+ * (n_nodes / n_edges then hold what was needed so far), or -2 when a relator became empty (the reference would crash). */
+int ac_simplex_graph(int n, int classic, long long cap_nodes, long long cap_edges, long long* n_nodes, uint8_t* node_size, long long* n_edges,
+                     uint32_t* edges, uint8_t* edge_filt) {
+    Rel r1 = {1, {1}}, r2 = {1, {2}};
+    Pres start;
+    sort_pair(&r1, &r2, &start);
+    Set s;
+    s.cap = 1 << 20;
+    s.pool = (uint8_t*)malloc(s.cap);
+    s.used = 0;
+    s.nslots = 1 << 16;
+    s.slots = (int64_t*)malloc(s.nslots * sizeof(int64_t));
+    for (size_t i = 0; i < s.nslots; i++) s.slots[i] = -1;
+    s.count = 0;
+    uint8_t* buf = (uint8_t*)malloc(4 + 2 * MAXW);
+    /* names: the k-th inserted key is vertex k; its pool offset is queue[k]; name lookup = position found through a second
+       table from pool offset to name (offsets grow with insertion, so a binary search on `queue` does it) */
+    size_t qcap = 1 << 16, qtail = 0;
+    int64_t* queue = (int64_t*)malloc(qcap * sizeof(int64_t));
+    queue[qtail++] = set_insert(&s, buf, pack(&start, buf));
+    long long ne = 0;
+    int rc = 0;
+    if (cap_nodes > 0) node_size[0] = (uint8_t)(start.a.n + start.b.n);
+    const int nmoves = classic ? 14 : 12;
+    Pres* cur = (Pres*)malloc(sizeof(Pres));
+    Pres* child = (Pres*)malloc(sizeof(Pres));
+    for (size_t qhead = 0; qhead < qtail && rc == 0; qhead++) {
+        unpack(s.pool + queue[qhead], cur);
+        const int csize = cur->a.n + cur->b.n;
+        for (int t = 0; t < nmoves; t++) {
+            move(cur, t, classic, child);
+            if (child->a.n == 0 || child->b.n == 0) {
+                rc = -2;
+                break;
+            }
+            const int size = child->a.n + child->b.n;
+            if (size > n) continue;
+            const size_t len = pack(child, buf);
+            int64_t off = set_insert(&s, buf, len);
+            long long cc;
+            if (off >= 0) { /* new vertex */
+                if (qtail == qcap) {
+                    qcap *= 2;
+                    queue = (int64_t*)realloc(queue, qcap * sizeof(int64_t));
+                }
+                cc = (long long)qtail;
+                if (cc < cap_nodes) node_size[cc] = (uint8_t)size;
+                else rc = -1;
+                queue[qtail++] = off;
+            } else { /* known: find its offset, then its name */
+                size_t h = hash_bytes(buf, len) & (s.nslots - 1);
+                for (;;) {
+                    const uint8_t* k = s.pool + s.slots[h];
+                    size_t kl = 4 + (size_t)(k[0] | (k[1] << 8)) + (size_t)(k[2] | (k[3] << 8));
+                    if (kl == len && memcmp(k, buf, len) == 0) break;
+                    h = (h + 1) & (s.nslots - 1);
+                }
+                const int64_t target = s.slots[h];
+                size_t lo = 0, hi = qtail;
+                while (lo + 1 < hi) {
+                    size_t mid = (lo + hi) / 2;
+                    if (queue[mid] <= target) lo = mid;
+                    else hi = mid;
+                }
+                cc = (long long)lo;
+            }
+            if ((long long)qhead < cc) {
+                if (ne < cap_edges) {
+                    edges[2 * ne] = (uint32_t)qhead;
+                    edges[2 * ne + 1] = (uint32_t)cc;
+                    edge_filt[ne] = (uint8_t)(csize > size ? csize : size);
+                } else {
+                    rc = -1;
+                }
+                ne++;
+            }
+        }
+    }
+    *n_nodes = (long long)qtail;
+    *n_edges = ne;
+    free(cur);
+    free(child);
+    free(queue);
+    free(buf);
+    free(s.slots);
+    free(s.pool);
+    return rc;
+}

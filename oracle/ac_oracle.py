@@ -195,3 +195,20 @@ def ball_size(presentation, radius=5, classic=False, return_max_length=False):
     if size < 0:
         raise OverflowError("a relator outgrew the oracle's buffer")
     return (int(size), ml.value) if return_max_length else int(size)
+
+
+def simplex_graph(n, classic=False, cap_nodes=4_000_000, cap_edges=12_000_000):
+    """(node_size, edges [E, 2], edge_filtration) of the graph of presentations of total length <= n around <a, b>, in the
+    order the reference's ac_bfs.cpp writes them (ac_ball_oracle.c: ac_simplex_graph)."""
+    ball_size([1, 2], 0)  # loads the library
+    f = _ball.ac_simplex_graph
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(C.c_uint8), C.POINTER(C.c_longlong),
+                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
+    ns, ed, ef = np.zeros(cap_nodes, np.uint8), np.zeros(2 * cap_edges, np.uint32), np.zeros(cap_edges, np.uint8)
+    nn, ne = C.c_longlong(), C.c_longlong()
+    rc = f(int(n), int(bool(classic)), cap_nodes, cap_edges, C.byref(nn), ns.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(ne),
+           ed.ctypes.data_as(C.POINTER(C.c_uint32)), ef.ctypes.data_as(C.POINTER(C.c_uint8)))
+    if rc:
+        raise OverflowError(f"ac_simplex_graph returned {rc}")
+    return ns[:nn.value].copy(), ed[:2 * ne.value].reshape(-1, 2).copy(), ef[:ne.value].copy()

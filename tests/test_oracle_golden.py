@@ -147,3 +147,17 @@ def test_ball_oracle_matches_reference_program(golden_json):
         if c["radius"] == 5 and c["tag"] not in ("readme", "ms_0", "ms_1100"):
             continue  # the full radius on a few, the smaller radii on all (keeps the CPU suite short)
         assert O.ball_size(c["presentation"], c["radius"], c["classic"]) == c["size"], (c["tag"], c["radius"], c["classic"])
+
+
+def test_simplex_oracle_matches_reference_program(golden_npz):
+    """oracle/ac_ball_oracle.c:ac_simplex_graph vs the files written by the reference's ac_bfs.cpp (prime and classic),
+    tests/golden/simplex_data.npz made by oracle/tools/make_simplex_golden.py from oracle/_ref/simplex_*."""
+    from oracle import ac_oracle as O
+
+    g = golden_npz("simplex_data.npz")
+    for tag, classic in (("prime", False), ("classic", True)):
+        for n in (4, 6, 8):
+            sizes, edges, filt = O.simplex_graph(n, classic)
+            assert np.array_equal(sizes, g[f"{tag}_{n}_node_size"]) and np.array_equal(edges, g[f"{tag}_{n}_edges"])
+            assert np.array_equal(filt, g[f"{tag}_{n}_edge_filt"])
+    assert len(g["prime_8_node_size"]) == 9172 and len(g["prime_8_edges"]) == 17416 and len(g["classic_8_edges"]) == 26363
