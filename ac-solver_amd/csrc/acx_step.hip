@@ -268,7 +268,9 @@ __device__ __forceinline__ void env_transition(const EnvDev<W>& e, int64_t i, En
 
 // The lane's observation row (2L entries) into its LDS slot, four letters per v_perm_b32 (acx_word.h
 // letters4).  LC > 0 is a compile-time max_relator_length (loops unroll, the row layout folds to constants).
-template <typename W, int LC> __device__ __forceinline__ void write_obs_row(int8_t* row, const Pres<W>& s, int Lrt) {
+// `part` of `parts`: only that contiguous share of the row's dwords is written (k_env_step_team splits a row over the four
+// waves of a workgroup; part / parts are wave uniform).  parts == 1: the whole row.
+template <typename W, int LC> __device__ __forceinline__ void write_obs_row(int8_t* row, const Pres<W>& s, int Lrt, int part = 0, int parts = 1) {
     uint16_t* r16 = (uint16_t*)row;  // rows are 2L bytes apart: 2-byte aligned
     auto put = [&](int L, int j) {
         const uint32_t d = row_dword<W>(s.w0, s.n0, s.w1, s.n1, L, j);
@@ -276,13 +278,17 @@ template <typename W, int LC> __device__ __forceinline__ void write_obs_row(int8
         if (4 * j + 2 < 2 * L) r16[2 * j + 1] = (uint16_t)(d >> 16);
     };
     if constexpr (LC > 0) {
+        constexpr int ND = (2 * LC + 3) / 4;
+        const int per = (ND + parts - 1) / parts;
 #pragma unroll
-        for (int j = 0; j < (2 * LC + 3) / 4; j++) put(LC, j);
+        for (int j = 0; j < ND; j++)
+            if (parts == 1 || (j >= part * per && j < (part + 1) * per)) put(LC, j);
     } else {
-        for (int j = 0; j < (2 * Lrt + 3) / 4; j++) put(Lrt, j);
+        const int nd = (2 * Lrt + 3) / 4, per = (nd + parts - 1) / parts;
+        for (int j = part * per; j < nd && j < (part + 1) * per; j++) put(Lrt, j);
     }
 }
-template <typename W, int LC> __device__ __forceinline__ void write_obs_row(float* row, const Pres<W>& s, int Lrt) {
+template <typename W, int LC> __device__ __forceinline__ void write_obs_row(float* row, const Pres<W>& s, int Lrt, int part = 0, int parts = 1) {
     float2* r2 = (float2*)row;  // rows are 8L bytes apart: 8-byte aligned
     auto put = [&](int L, int j) {
         const uint32_t d = row_dword<W>(s.w0, s.n0, s.w1, s.n1, L, j);
@@ -290,10 +296,14 @@ template <typename W, int LC> __device__ __forceinline__ void write_obs_row(floa
         if (4 * j + 2 < 2 * L) r2[2 * j + 1] = make_float2((float)(int8_t)(d >> 16), (float)(int8_t)(d >> 24));
     };
     if constexpr (LC > 0) {
+        constexpr int ND = (2 * LC + 3) / 4;
+        const int per = (ND + parts - 1) / parts;
 #pragma unroll
-        for (int j = 0; j < (2 * LC + 3) / 4; j++) put(LC, j);
+        for (int j = 0; j < ND; j++)
+            if (parts == 1 || (j >= part * per && j < (part + 1) * per)) put(LC, j);
     } else {
-        for (int j = 0; j < (2 * Lrt + 3) / 4; j++) put(Lrt, j);
+        const int nd = (2 * Lrt + 3) / 4, per = (nd + parts - 1) / parts;
+        for (int j = part * per; j < nd && j < (part + 1) * per; j++) put(Lrt, j);
     }
 }
 
@@ -352,6 +362,75 @@ __global__ void __launch_bounds__(256, ACX_STEP_WAVES) k_env_step(W* __restrict_
         if (lane < rows) write_obs_row<W, LC>(my, was_reset ? fin : v.s, L);
         wave_lds_handoff();
         if (rows > 0) wave_copy<ACX_OBS_NT != 0>((uint8_t*)final_obs + row0 * RB, tile, rows * RB, lane, vec != 0);
+    }
+}
+
+// Small batches (one wave per SIMD: the per-wave instruction chain is what the kernel time consists of): a TEAM of four
+// waves serves 64 envs.  Wave 0 does what only one wave can do -- load the state, evaluate the move, store state / reward /
+// flags -- and publishes the new packed state in LDS; then all four waves unpack a quarter of every observation row into
+// the LDS tile and stream a quarter of the tile out.  No work is duplicated; the serial chain of wave 0 loses three
+// quarters of the unpack and of the copy-out.
+template <typename W, bool SAFE, typename OBS, int LC>
+__global__ void __launch_bounds__(256, 4) k_env_step_team(W* __restrict__ sw0, W* __restrict__ sw1, uint64_t* __restrict__ smeta,
+                                                         const void* __restrict__ act, int64_t n_envs, int adt, EnvDev<W> e, OBS* __restrict__ obs,
+                                                         float* __restrict__ rew, float clip_lo, float clip_hi, uint8_t* __restrict__ done,
+                                                         uint8_t* __restrict__ trunc, int autoreset, int vec) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int L = LC > 0 ? LC : e.L;
+    const int RB = 2 * L * (int)sizeof(OBS);
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int rows = (int)(n_envs - row0 < 64 ? n_envs - row0 : 64);
+    uint8_t* tile = lds;                       // 64 * RB bytes
+    W* xs0 = (W*)(lds + ((64 * RB + 15) / 16) * 16);  // new packed state of the 64 envs
+    W* xs1 = xs0 + 64;
+    uint32_t* xsn = (uint32_t*)(xs1 + 64);
+    if (wave == 0 && lane < rows) {
+        const int64_t i = row0 + lane;
+        EnvLane<W> v;
+        Pres<W> fin;
+        bool was_reset;
+        v.s.w0 = sw0[i];
+        v.s.w1 = sw1[i];
+        const uint64_t m = smeta[i];
+        const int a = load_action(act, adt, i);
+        env_unpack_meta<W>(m, v);
+        float r;
+        int d, t;
+        env_transition<W, SAFE>(e, i, v, a, autoreset != 0, clip_lo, clip_hi, r, d, t, was_reset, fin);
+        xs0[lane] = v.s.w0;
+        xs1[lane] = v.s.w1;
+        xsn[lane] = (uint32_t)v.s.n0 | ((uint32_t)v.s.n1 << 8);
+        sw0[i] = v.s.w0;
+        sw1[i] = v.s.w1;
+        smeta[i] = env_pack_meta<W>(v);
+        if (rew) rew[i] = r;
+        if (done) done[i] = (uint8_t)d;
+        if (trunc) trunc[i] = (uint8_t)t;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: wave 0's global stores stay in flight
+    if (lane < rows) {
+        Pres<W> s;
+        s.w0 = xs0[lane];
+        s.w1 = xs1[lane];
+        const uint32_t nn = xsn[lane];
+        s.n0 = (int)(nn & 0xff);
+        s.n1 = (int)(nn >> 8);
+        write_obs_row<W, LC>((OBS*)(tile + lane * RB), s, L, wave, 4);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int nbytes = rows * RB;
+    uint8_t* dst = (uint8_t*)obs + row0 * RB;
+    if (vec) {
+        int o = (int)threadIdx.x * 16;
+        for (; o + 16 <= nbytes; o += 256 * 16) {
+            if (ACX_OBS_NT) __builtin_nontemporal_store(*(const u32x4*)(tile + o), (u32x4*)(dst + o));
+            else *(uint4*)(dst + o) = *(const uint4*)(tile + o);
+        }
+        if (o < nbytes)
+            for (int b = o; b < nbytes && b < o + 16; b++) dst[b] = tile[b];
+    } else {
+        for (int b = (int)threadIdx.x; b < nbytes; b += 256) dst[b] = tile[b];
     }
 }
 
@@ -712,7 +791,25 @@ int acx_env_step(acx_env* e, const void* d_actions, int action_dtype, void* d_ob
 #define ACX_STEP(OBS, LC)                                                                                                                    \
     ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_step<W, SAFE, OBS, LC>), dim3(grid), dim3(256), lds, st, dev.w0, dev.w1, dev.meta, d_actions, dev.n, action_dtype, dev, (OBS*)d_obs, \
                                            d_reward, clip_lo, clip_hi, d_done, d_trunc, (OBS*)d_final_obs, autoreset, vec))
-    if (e->L == 25) {  // BASELINE max_relator_length: fully unrolled observation writer
+    // small batches (fewer than one wave of envs per SIMD of the chip: 256 CUs x 4 SIMDs x 64 lanes = 65 536): a team of four waves per
+    // 64 envs (k_env_step_team), when an observation but no terminal observation is written.  Measured: 2.66 vs 3.05 us at 16 384 envs,
+    // no difference at 65 536 (every SIMD then carries a full chain either way), slower above.
+    constexpr int64_t kTeamMaxEnvs = 32768;
+    const bool team = d_obs && !d_final_obs && e->n <= kTeamMaxEnvs && !getenv("ACX_ENV_NO_TEAM");
+    const unsigned tgrid = (unsigned)ceil_div<int64_t>(e->n, 64);
+    const size_t tlds = ((size_t)64 * 2 * e->L * (f32 ? 4 : 1) + 15) / 16 * 16 + 64 * (2 * (e->wide ? 16 : 8) + 4);
+#define ACX_STEP_TEAM(OBS, LC)                                                                                                               \
+    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_step_team<W, SAFE, OBS, LC>), dim3(tgrid), dim3(256), tlds, st, dev.w0, dev.w1, dev.meta, d_actions, dev.n, action_dtype, dev, (OBS*)d_obs, \
+                                           d_reward, clip_lo, clip_hi, d_done, d_trunc, autoreset, vec))
+    if (team) {
+        if (e->L == 25) {
+            if (f32) ACX_STEP_TEAM(float, 25);
+            else ACX_STEP_TEAM(int8_t, 25);
+        } else {
+            if (f32) ACX_STEP_TEAM(float, 0);
+            else ACX_STEP_TEAM(int8_t, 0);
+        }
+    } else if (e->L == 25) {  // BASELINE max_relator_length: fully unrolled observation writer
         if (f32) ACX_STEP(float, 25);
         else ACX_STEP(int8_t, 25);
     } else {
@@ -720,6 +817,7 @@ int acx_env_step(acx_env* e, const void* d_actions, int action_dtype, void* d_ob
         else ACX_STEP(int8_t, 0);
     }
 #undef ACX_STEP
+#undef ACX_STEP_TEAM
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }

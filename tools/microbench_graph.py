@@ -54,6 +54,11 @@ def main():
         r = {}
         r["torch tiny add_ (64 elts)"] = graph_time(lambda k: tiny.add_(1.0))
         r["torch add_ (N elts)"] = graph_time(lambda k: x.add_(1.0))
+        src_obs = torch.zeros((N, 2 * L), dtype=torch.int8, device="cuda")
+        src_state = torch.zeros((N, 3), dtype=torch.int64, device="cuda")
+        dst_state = torch.zeros((N, 3), dtype=torch.int64, device="cuda")
+        r["torch copy_ 50 B/env (obs-sized stream)"] = graph_time(lambda k: obsK[k].copy_(src_obs))
+        r["torch copy_ 24 B/env (state-sized stream)"] = graph_time(lambda k: dst_state.copy_(src_state))
         r["observe -> one buffer"] = graph_time(lambda k: _acx.lib.acx_env_observe(env._h.ptr, obs1.data_ptr(), _acx.I8, st()))
         r["step, no outputs but state"] = graph_time(lambda k: _acx.lib.acx_env_step(env._h.ptr, tape[k].data_ptr(), _acx.U8, None, _acx.I8, None, 0.0, 0.0, None, None, None, 1, st()))
         r["step, rew/done/trunc"] = graph_time(lambda k: _acx.lib.acx_env_step(env._h.ptr, tape[k].data_ptr(), _acx.U8, None, _acx.I8, rew[k].data_ptr(), 0.0, 0.0, done[k].data_ptr(), trunc[k].data_ptr(), None, 1, st()))
