@@ -153,11 +153,15 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
                                "entry": "acx_search_many per rank (16 host threads, one HIP stream per search); searches dealt round-robin to the ranks"}
     if world == 1 and not use_dist:
         for kind, name in ((_acx.SEARCH_BFS, "bfs"), (_acx.SEARCH_GREEDY, "greedy_search")):
-            run_search(kind, p, 20000, False)
+            b = budget if kind == _acx.SEARCH_BFS else min(budget, 10**7)
             t0 = time.perf_counter()
-            ok, path, s1 = run_search(kind, p, budget if kind == _acx.SEARCH_BFS else min(budget, 10**7), False)
+            run_search(kind, p, b, False)  # first call: also pays for the device allocations (kept by the block pool afterwards)
+            first = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            ok, path, s1 = run_search(kind, p, b, False)
             dt1 = time.perf_counter() - t0
-            out[name] = {"nodes_per_s": s1["nodes"] / dt1, "nodes": s1["nodes"], "seconds": dt1, "batches": s1["levels"], "entry": "acx_search"}
+            out[name] = {"nodes_per_s": s1["nodes"] / dt1, "nodes": s1["nodes"], "seconds": dt1, "device_seconds": s1["seconds"],
+                         "first_call_seconds": first, "batches": s1["levels"], "entry": "acx_search"}
     return out
 
 
