@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(256) k_expand(SearchDev<W> d, const uint32_t* 
         d.ck0[t] = c0;
         d.ck1[t] = c1;
         d.cknown[t] = (c0 == pk0 && c1 == pk1) ? 1 : 0;  // an unchanged state is its (visited) parent: k_insert skips the probe
+        d.cslot[t] = 0;                                    // BFS: "replaced by a smaller tag" flag of k_insert_tab
         tl = (uint32_t)(s.n0 + s.n1);
         d.clen[t] = (uint8_t)tl;
         if (tl == 2) atomicMin(d.solved_tag, (unsigned long long)t);  // breadth_first.py:84 / greedy.py:91
@@ -191,19 +192,22 @@ __global__ void __launch_bounds__(256) k_mark(SearchDev<W> d, const uint32_t* __
     if (win && bucket_len >= 0 && (int)d.clen[t] < bucket_len) atomicMin(d.shorter_tag, (unsigned long long)t);
 }
 
-// BFS: insert candidate t into the inline-key table (see TabEntry).  cslot[t] = entry that holds the key, kEmpty when
-// the candidate was skipped (a child equal to its parent).
+// BFS: insert candidate t into the inline-key table (see TabEntry).  Winner bookkeeping without a second pass over the
+// table: cflag[t] = 1 when t took the entry (claimed it empty, or replaced a larger tag of the same key), and a candidate
+// that is replaced later gets cslot[its tag] = 1 from the one that replaced it (cslot must be zero on entry); the
+// winners are then cflag & !cslot (k_mark_tab, a streaming pass).
 template <typename W>
 __global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, uint32_t epoch, int skip_known) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     if (skip_known && d.cknown[t]) {
-        d.cslot[t] = kEmpty;
+        d.cflag[t] = 0;
         return;
     }
     const W k0 = d.ck0[t], k1 = d.ck1[t];
     const unsigned long long me = ((unsigned long long)epoch << 32) | t;
     uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.tmask;
+    uint32_t took = 0;
     for (;;) {
         TabEntry<W>* e = d.tab + h;
         const W e0 = e->k0, e1 = e->k1;  // one sector together with the stamp
@@ -213,6 +217,7 @@ __global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, 
             if (st == kStampEmpty) {  // claimed: the key moves in (readers of this batch compare through the candidate arena)
                 e->k0 = k0;
                 e->k1 = k1;
+                took = 1;
                 break;
             }
             // lost the race: `st` is a stamp of the running epoch now
@@ -220,7 +225,13 @@ __global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, 
         if ((uint32_t)(st >> 32) == epoch) {
             const uint32_t o = (uint32_t)st;
             if (d.ck0[o] == k0 && d.ck1[o] == k1) {
-                if (st > me) atomicMin(&e->stamp, me);
+                if (st > me) {
+                    const unsigned long long prev = atomicMin(&e->stamp, me);  // the holder I actually replaced (if any)
+                    if (prev > me) {
+                        took = 1;
+                        d.cslot[(uint32_t)prev] = 1;  // that candidate is no longer the first discoverer
+                    }
+                }
                 break;
             }
         } else if (e0 == k0 && e1 == k1) {
@@ -228,14 +239,13 @@ __global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, 
         }
         h = (h + 1) & d.tmask;
     }
-    d.cslot[t] = h;
+    d.cflag[t] = took;
 }
 
-template <typename W> __global__ void __launch_bounds__(256) k_mark_tab(SearchDev<W> d, uint32_t m, uint32_t epoch) {
+template <typename W> __global__ void __launch_bounds__(256) k_mark_tab(SearchDev<W> d, uint32_t m) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
-    const uint32_t s = d.cslot[t];
-    d.cflag[t] = (s != kEmpty && d.tab[s].stamp == (((unsigned long long)epoch << 32) | t)) ? 1u : 0u;
+    d.cflag[t] = (d.cflag[t] && !d.cslot[t]) ? 1u : 0u;
 }
 
 template <typename W> __global__ void k_root_tab(SearchDev<W> d, W k0, W k1, uint32_t tl) {

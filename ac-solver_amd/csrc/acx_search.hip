@@ -530,7 +530,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
             hipLaunchKernelGGL(k_mark<W>, grid, block, 0, st, d, d.bslots, m, bucket_len);
         } else {
             hipLaunchKernelGGL(k_insert_tab<W>, grid, block, 0, st, d, m, (uint32_t)batches, 1);  // epoch = batch number (>= 1)
-            hipLaunchKernelGGL(k_mark_tab<W>, grid, block, 0, st, d, m, (uint32_t)batches);
+            hipLaunchKernelGGL(k_mark_tab<W>, grid, block, 0, st, d, m);
         }
         {
             size_t tb = S.tmp_bytes;

@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(256) k_shard_gather(SearchDev<W> d, const int6
     d.ck0[j] = k0;
     d.ck1[j] = k1;
     d.clen[j] = (uint8_t)(keyops<W>::len(k0) + keyops<W>::len(k1));
+    d.cslot[j] = 0;  // "replaced by a smaller tag" flag of k_insert_tab
     ctag[j] = (int64_t)tags_sorted[j];
     cpref[j] = r[recio<W>::KW + 1];
 }
@@ -330,7 +331,7 @@ template <typename W> static int shard_insert(ShardEngine<W>& E, const int64_t* 
     hipLaunchKernelGGL(k_shard_gather<W>, grid, block, 0, st, E.d, rec, E.tags_sorted, E.idx_sorted, n, E.ctag, E.cpref);
     E.epoch++;
     hipLaunchKernelGGL(k_insert_tab<W>, grid, block, 0, st, E.d, (uint32_t)n, E.epoch, 0);
-    hipLaunchKernelGGL(k_mark_tab<W>, grid, block, 0, st, E.d, (uint32_t)n, E.epoch);
+    hipLaunchKernelGGL(k_mark_tab<W>, grid, block, 0, st, E.d, (uint32_t)n);
     tb = E.scan_tmp;
     if (rocprim::exclusive_scan(E.tmp_buf.p, tb, E.d.cflag, E.d.cpos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st) != hipSuccess)
         return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan failed");
