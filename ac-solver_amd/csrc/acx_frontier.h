@@ -452,6 +452,19 @@ struct DevBuf {
     }
 };
 
+// two timing events that are released on every exit path
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t create() {
+        hipError_t e = hipEventCreate(&a);
+        return e != hipSuccess ? e : hipEventCreate(&b);
+    }
+    ~EventPair() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
 // pinned host staging, one grow-only buffer per host thread (hipHostMalloc is as slow as hipMalloc)
 inline uint8_t* pinned_staging(size_t bytes) {
     static thread_local uint8_t* buf = nullptr;

@@ -280,9 +280,9 @@ static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_no
         return ACX_E_NOMEM;
     ACX_HIP_TRY(hipMemcpyAsync(ddev.p, hdev.data(), (size_t)n * sizeof(GreedyDev<W>), hipMemcpyHostToDevice, st));
     ACX_HIP_TRY(hipMemsetAsync(douts.p, 0, (size_t)n * sizeof(GreedyOut), st));
-    hipEvent_t ev0, ev1;
-    ACX_HIP_TRY(hipEventCreate(&ev0));
-    ACX_HIP_TRY(hipEventCreate(&ev1));
+    EventPair evs;
+    ACX_HIP_TRY(evs.create());
+    hipEvent_t ev0 = evs.a, ev1 = evs.b;
     ACX_HIP_TRY(hipEventRecord(ev0, st));
     hipLaunchKernelGGL(k_greedy_multi<W>, dim3((unsigned)n), dim3(kGT), 0, st, (const GreedyDev<W>*)ddev.p, (GreedyOut*)douts.p, (int32_t*)dpa.p, (int32_t*)dpl.p,
                        (long long)pc);
@@ -296,8 +296,6 @@ static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_no
     ACX_HIP_TRY(hipStreamSynchronize(st));
     float ms = 0;
     ACX_HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     for (int64_t k = 0; k < n; k++) {
         const GreedyOut& r = o[k];
         if (r.status == GREEDY_FALLBACK) {
@@ -347,9 +345,9 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
     DevBuf outb;
     if (outb.alloc(sizeof(GreedyOut))) return ACX_E_NOMEM;
     ACX_HIP_TRY(hipMemsetAsync(outb.p, 0, sizeof(GreedyOut), st));
-    hipEvent_t ev0, ev1;
-    ACX_HIP_TRY(hipEventCreate(&ev0));
-    ACX_HIP_TRY(hipEventCreate(&ev1));
+    EventPair evs;
+    ACX_HIP_TRY(evs.create());
+    hipEvent_t ev0 = evs.a, ev1 = evs.b;
     ACX_HIP_TRY(hipEventRecord(ev0, st));
     hipLaunchKernelGGL(k_greedy_persistent<W>, dim3(1), dim3(kGT), 0, st, g, (GreedyOut*)outb.p);
     ACX_HIP_TRY(hipGetLastError());
@@ -359,8 +357,6 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
     ACX_HIP_TRY(hipStreamSynchronize(st));
     float ms = 0;
     ACX_HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     if (getenv("ACX_DEBUG"))
         fprintf(stderr, "[acx_greedy] status=%u nodes=%u batches=%llu expanded=%llu sorts=%llu big_sorts=%llu max_bucket=%u reason=%u %.3f ms\n", o.status, o.nodes,
                 o.batches, o.expanded, o.sorts, o.big_sorts, o.max_bucket, o.fallback_reason, ms);
@@ -436,9 +432,9 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
     if (rc) return rc;
     SearchDev<W>& d = S.d;
     hipStream_t st = S.st;
-    hipEvent_t ev0, ev1;
-    ACX_HIP_TRY(hipEventCreate(&ev0));
-    ACX_HIP_TRY(hipEventCreate(&ev1));
+    EventPair evs;
+    ACX_HIP_TRY(evs.create());
+    hipEvent_t ev0 = evs.a, ev1 = evs.b;
     ACX_HIP_TRY(hipEventRecord(ev0, st));
 
     const uint32_t tl0 = (uint32_t)(root.n0 + root.n1);
@@ -616,8 +612,6 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
     ACX_HIP_TRY(hipEventSynchronize(ev1));
     float ms = 0;
     ACX_HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     if (stats) {
         stats->nodes = (int64_t)nodes;
         stats->expanded = (int64_t)expanded;
