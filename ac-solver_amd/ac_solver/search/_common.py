@@ -58,3 +58,21 @@ def run_search_many(kind, presentations, max_nodes_to_explore, cyclical, n_threa
         out.append((bool(solved[k]), path, dict(nodes=st.nodes, expanded=st.expanded, children=st.children, levels=st.levels, min_len=st.min_len,
                                                 seconds=st.seconds)))
     return out
+
+
+def self_check(search_fn, budget=10**6):
+    """Solve AK(2) with `search_fn`, then replay the returned path move by move and report whether it ends at a trivial
+    presentation (what the reference's search modules do when run as scripts)."""
+    from ac_solver.envs.ac_moves import ACMove
+    from ac_solver.envs.utils import is_presentation_trivial
+
+    state = np.array([1, 1, -2, -2, -2, 0, 0, 1, 2, 1, -2, -1, -2, 0])  # AK(2) at max_relator_length = 7
+    solved, path = search_fn(presentation=state, max_nodes_to_explore=budget)
+    print(f"{search_fn.__name__}: solved = {solved}, path of {len(path) if path else 0} entries")
+    if solved:
+        lengths = [5, 6]
+        for action, _ in path[1:]:
+            state, lengths = ACMove(move_id=action, presentation=state, max_relator_length=7, lengths=lengths, cyclical=False)
+        print(f"replayed path ends at {state.tolist()}; trivial: {is_presentation_trivial(state)}")
+        return bool(is_presentation_trivial(state))
+    return False

@@ -26,17 +26,8 @@ def bfs(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_redu
     return True, path
 
 
-if __name__ == "__main__":  # the reference's self-check (breadth_first.py:100-126): solve AK(2), replay the path
-    from ac_solver.envs.ac_moves import ACMove
-    from ac_solver.envs.utils import is_presentation_trivial
 
-    presentation = np.array([1, 1, -2, -2, -2, 0, 0, 1, 2, 1, -2, -1, -2, 0])  # AK(2)
-    ans, path = bfs(presentation=presentation, max_nodes_to_explore=int(1e6))
-    if path:
-        print(f"Presentation {presentation} solved!\nPath length: {len(path)}")
-        print("Checking whether this path actually leads to a trivial state..")
-        word_lengths = [5, 6]
-        for action, _ in path[1:]:
-            presentation, word_lengths = ACMove(move_id=action, presentation=presentation, max_relator_length=7, lengths=word_lengths, cyclical=False)
-        print(f"Final state achieved: {presentation}")
-        print(f"Is trivial? {is_presentation_trivial(presentation)}")
+if __name__ == "__main__":  # the reference module's self-check (breadth_first.py:100-126)
+    from ac_solver.search._common import self_check
+
+    self_check(bfs)
