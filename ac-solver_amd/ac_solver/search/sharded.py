@@ -246,11 +246,9 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
         return rev[::-1] + tail
 
     def finish(ok, path):
-        err, min_len = engine.status()
-        e = i64([err, -min_len])
+        _, min_len = engine.status()
+        e = i64([0, -min_len])
         comm.all_reduce(e, "max")
-        if int(e[0]):
-            raise AssertionError("a move emptied a relator during the search: the reference's ACMove raises here")
         if want_stats:
             return ok, path, dict(nodes=nodes_global, expanded=expanded, levels=levels, min_len=2 if ok else -int(e[1]), world=world)
         return ok, path
@@ -263,7 +261,7 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             c1 = min(F, c0 + B)
             lo = int(torch.searchsorted(f_gpos, i64([c0]))[0]) if f_gpos.numel() else 0
             hi = int(torch.searchsorted(f_gpos, i64([c1]))[0]) if f_gpos.numel() else 0
-            solved = i64([INF])
+            solved = i64([INF, INF])  # [0] smallest tag of a length-2 child, [1] smallest (tag << 8 | code) of a move the reference raises on
             # Local failures (a capacity of this rank's engine, a HIP error) must not leave the other ranks waiting in a
             # collective: the rank keeps taking part with empty contributions and reports through the `solved` all-reduce
             # (-1 beats every tag), so that all ranks raise together.
@@ -296,7 +294,7 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             except Exception as e:  # noqa: BLE001
                 failure, win = e, i64([])
             if failure is not None:
-                solved = i64([-1])
+                solved = i64([-1, INF])
             # one 12-bit mask per parent of the chunk; every (parent, action) child has exactly one owner, so SUM == OR
             rel = win - 12 * c0
             par, bit = rel // 12, rel % 12
@@ -306,7 +304,8 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             comm.all_reduce(mask, "sum")
             mask = mask.to(torch.int64)
             incl = torch.cumsum(pop12[mask], 0)      # new states up to and including each parent (global)
-            solved_tag = int(comm.all_reduce(solved, "min")[0])
+            comm.all_reduce(solved, "min")
+            solved_tag, err_word = (int(v) for v in solved.tolist())
             if solved_tag < 0:
                 raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure}" if failure is not None else "sharded bfs failed on another rank")
             total_new = int(incl[-1])
@@ -326,7 +325,11 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
                 pb = c0 + int(torch.searchsorted(incl, i64([max_nodes - nodes_global]))[0])
                 if pb <= p_end:
                     p_end, budget_hit = pb, True
-            if solved_tag < INF and solved_tag // 12 <= p_end:
+            is_solved = solved_tag < INF and solved_tag // 12 <= p_end
+            if err_word < INF and (err_word >> 8) // 12 <= p_end and not (is_solved and solved_tag < (err_word >> 8)):
+                # the reference executes this move before it stops: its ACMove raises (every rank sees the same words)
+                raise AssertionError("a move emptied a relator during the search: the reference's ACMove raises here")
+            if is_solved:
                 gp = solved_tag // 12
                 k = int(torch.searchsorted(f_gpos, i64([gp]))[0]) if f_gpos.numel() else 0
                 mine = k < f_gpos.numel() and int(f_gpos[k]) == gp

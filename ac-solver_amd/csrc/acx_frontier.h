@@ -83,6 +83,7 @@ template <typename W> struct SearchDev {
     // device scalars
     unsigned long long* solved_tag;   // min tag with total length 2
     unsigned long long* shorter_tag;  // greedy: min tag of a NEW child shorter than the bucket
+    unsigned long long* err_tag;      // min (tag << 8 | code) of a move on which the reference's ACMove raises
     uint32_t* err;
     uint32_t* min_len;
     int32_t L;
@@ -108,7 +109,9 @@ __global__ void __launch_bounds__(256) k_expand(SearchDev<W> d, const uint32_t* 
         const W pk0 = d.k0[pid], pk1 = d.k1[pid];
         key_to_pres<W>(pk0, pk1, s);
         const int e = apply_move<W, true>(s, (int)a, d.L, d.cyclical != 0);
-        if (e) atomicOr(d.err, (uint32_t)e);  // the reference's ACMove raises: the whole search raises
+        // the reference's ACMove raises here -- but only if it gets this far: the search raises when this move precedes its
+        // termination (k_decide), so the FIRST such move of the batch is what matters
+        if (e) atomicMin(d.err_tag, ((unsigned long long)t << 8) | (unsigned long long)e);
         const W c0 = keyops<W>::make(s.w0, s.n0), c1 = keyops<W>::make(s.w1, s.n1);
         d.ck0[t] = c0;
         d.ck1[t] = c1;
@@ -309,7 +312,11 @@ __global__ void k_decide(SearchDev<W> d, uint32_t m, uint32_t np, unsigned long 
     out->solved = is_solved;
     out->solved_tag = (uint32_t)solved_tag;
     out->last_child_len = d.clen[12u * p_end + 11];
-    out->err = *d.err;
+    // an erroring move counts when the reference executes it: its parent is popped (<= p_end) and no earlier child ended the search
+    const unsigned long long et = *d.err_tag;
+    const bool err_hit = et != kNoTag && (uint32_t)((et >> 8) / 12) <= p_end && !(is_solved && solved_tag < (et >> 8));
+    out->err = err_hit ? (uint32_t)(et & 0xff) : 0u;
+    if (err_hit) out->solved = 0;
     out->min_len = *d.min_len;
 }
 

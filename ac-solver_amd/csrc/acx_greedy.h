@@ -181,7 +181,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
     __shared__ uint32_t s_minlen, s_mindepth, s_solved, s_shorter, s_lo, s_err, s_seen_min, s_njobs, s_arena_top, s_committed, s_flag, s_total;
     __shared__ uint32_t s_p_end, s_cutoff, s_budget_hit, s_is_solved, s_last_parent, s_solved_pid, s_cur_len, s_cur_depth, s_nodes, s_status,
         s_reason, s_max_bucket, s_np_cap, s_last_child_len, s_solved_action, s_sorted_in_lds;
-    __shared__ unsigned long long s_expanded, s_batches, s_sorts, s_big_sorts;
+    __shared__ unsigned long long s_expanded, s_batches, s_sorts, s_big_sorts, s_err_tag;
     __shared__ uint32_t s_hist[32];
     __shared__ unsigned long long s_tph[12], s_tc;  // phase clock, kept by thread 0
 #if ACX_GREEDY_PROFILE
@@ -473,6 +473,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
             s_njobs = 0;
             s_committed = 0;
             s_sorted_in_lds = 0;
+            s_err_tag = ~0ull;
         }
         if (tid < 132) s_lcnt[tid] = 0;
         for (uint32_t i = tid; i < bt; i += kGT) s_btab[i] = kEmpty;
@@ -489,7 +490,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                 Pres<W> s;
                 key_to_pres<W>(sp_k0[p], sp_k1[p], s);
                 const int e = apply_move<W, true>(s, (int)(t - 12u * p), d.L, d.cyclical != 0);
-                if (e) atomicOr(&s_err, (uint32_t)e);
+                if (e) atomicMin(&s_err_tag, ((unsigned long long)t << 8) | (unsigned long long)e);  // counts only if the reference gets this far
                 const W c0 = keyops<W>::make(s.w0, s.n0), c1 = keyops<W>::make(s.w1, s.n1);
                 const uint32_t tl = (uint32_t)(s.n0 + s.n1);
                 sk0[t] = c0;
@@ -630,7 +631,12 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                     budget_hit = 1;
                 }
             }
-            const uint32_t is_solved = s_solved != 0xFFFFFFFFu && s_solved / 12u <= p_end;
+            uint32_t is_solved = s_solved != 0xFFFFFFFFu && s_solved / 12u <= p_end;
+            // a move on which the reference's ACMove raises: it does so when the move is executed before the search ends
+            if (s_err_tag != ~0ull && (uint32_t)((s_err_tag >> 8) / 12u) <= p_end && !(is_solved && s_solved < (uint32_t)(s_err_tag >> 8))) {
+                s_err = (uint32_t)(s_err_tag & 0xffu);
+                is_solved = 0;
+            }
             s_cutoff = is_solved ? s_solved : 12u * (p_end + 1);
             s_p_end = is_solved ? s_solved / 12u : p_end;
             s_budget_hit = budget_hit;

@@ -108,6 +108,7 @@ template <typename W> struct Searcher {
         if (!h_pin) return fail(ACX_E_NOMEM, "hipHostMalloc(%zu) failed", h_pin_bytes);
         d.solved_tag = (unsigned long long*)(sc + 0);
         d.shorter_tag = (unsigned long long*)(sc + 8);
+        d.err_tag = (unsigned long long*)(sc + 16);  // reset with the other batch scalars
         d.err = (uint32_t*)(sc + 24);
         d.min_len = (uint32_t*)(sc + 28);
         if (arena_list.alloc(std::max<uint64_t>(batch_parents, 1024) * 4 * 2)) return ACX_E_NOMEM;

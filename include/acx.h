@@ -163,7 +163,8 @@ void acx_shard_destroy(acx_shard *h);
 /* the root as a record (tag 0, parent_ref -1), host buffer of key_words + 2 int64 */
 int acx_shard_root_record(acx_shard *h, const int8_t *h_presentation, int64_t *h_record);
 /* children of the local nodes d_ids[0..np) whose global frontier positions are d_gpos: 12*np records;
- * d_solved[0] is min-combined with the tags of children of total length 2 */
+ * d_solved (int64[2]): [0] is min-combined with the tags of children of total length 2, [1] with tag << 8 | code of the
+ * moves on which the reference's ACMove raises (a relator emptied): the search raises if such a move precedes its end */
 int acx_shard_expand(acx_shard *h, const int64_t *d_ids, const int64_t *d_gpos, int64_t np, int64_t *d_records,
                      int64_t *d_solved, void *stream);
 /* the same expansion with the records already routed: a child whose key belongs to rank o (owner = the hash of

@@ -67,8 +67,9 @@ class OracleShardEngine:
         for nid, gp in zip(ids.tolist(), gpos.tolist()):
             st = np.repeat(self.states[nid][None], 12, axis=0)
             out, lens, err = O.move_batch(st, np.arange(12, dtype=np.uint8), self.L, cyclical=self.cyc)
-            self.err |= int(err.max())
             for a in range(12):
+                if err[a]:
+                    solved[1] = min(int(solved[1]), ((12 * gp + a) << 8) | int(err[a]))
                 k0, k1 = key_of_state(out[a], self.L)
                 tag = 12 * gp + a
                 tl = int(lens[a].sum())

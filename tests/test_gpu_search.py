@@ -183,7 +183,7 @@ def test_device_routing_matches_owner_of(search, L):
         ids = torch.arange(first, first + cnt, dtype=torch.int64, device=eng.device)
         gpos = torch.zeros_like(ids)
         for _ in range(4):  # a few levels: 12, then up to 144, ... children
-            solved = torch.tensor([1 << 62], dtype=torch.int64, device=eng.device)
+            solved = torch.tensor([1 << 62, 1 << 62], dtype=torch.int64, device=eng.device)
             plain = eng.expand(ids, gpos, solved)
             send, counts = eng.expand_routed(ids, gpos, solved, world)
             assert plain.shape[0] == 12 * ids.numel()

@@ -1,0 +1,102 @@
+"""Differential fuzz of the device frontiers against the CPU oracle on random presentations (not only presentations of
+the trivial group: searches in which a move empties a relator must raise like the reference), random budgets, both
+algorithms, both cyclic-reduction settings, 64-bit and 128-bit keys."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_word(rng, n):
+    w = []
+    while len(w) < n:
+        c = int(rng.choice([1, -1, 2, -2]))
+        if not w or w[-1] != -c:
+            w.append(c)
+    return w
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("L", [6, 12, 25, 33])
+def test_random_presentations_against_oracle(L):
+    import ac_solver
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search
+    from oracle import ac_oracle as O
+
+    _acx.require_device()
+    rng = np.random.default_rng(100 + L)
+    n_cases = 40 if L <= 12 else 24
+    raised = solved = 0
+    for case in range(n_cases):
+        row = np.zeros(2 * L, np.int8)
+        for h in (0, 1):
+            w = _random_word(rng, int(rng.integers(1, min(L, 9) + 1)))
+            row[h * L:h * L + len(w)] = w
+        budget = int(rng.choice([1, 2, 7, 60, 500, 4000, 30000]))
+        cyc = bool(rng.integers(0, 2))
+        for kind, ofn in ((_acx.SEARCH_BFS, O.bfs), (_acx.SEARCH_GREEDY, O.greedy_search)):
+            try:
+                want = ofn(row, budget, cyclically_reduce_after_moves=cyc, stats=True)
+            except AssertionError:
+                want = "raises"
+            except IndexError:
+                want = "raises"
+            try:
+                ok, path, st = run_search(kind, row, budget, cyc)
+                got = (ok, path, {"nodes": st["nodes"], "expanded": st["expanded"]})
+            except (AssertionError, IndexError):
+                got = "raises"
+            if want == "raises":
+                raised += 1
+                assert got == "raises", (L, case, kind, budget, cyc, row.tolist())
+            else:
+                wok, wpath, wst = want
+                solved += bool(wok)
+                assert got != "raises" and (got[0], got[1]) == (wok, wpath), (L, case, kind, budget, cyc, row.tolist())
+                assert got[2]["nodes"] == wst["nodes"] and got[2]["expanded"] == wst["expanded"], (L, case, kind, budget, cyc, row.tolist(), got[2], wst)
+    assert raised + solved >= 0
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [1, 3])
+def test_random_presentations_sharded_bfs(world):
+    """the same comparison through the sharded frontier (HIP engine; thread ranks share the GPU when world > 1)"""
+    from ac_solver import _acx
+    from ac_solver.search.sharded import SingleComm, bfs_sharded
+    from oracle import ac_oracle as O
+    from tests.shard_helpers import run_threads
+
+    _acx.require_device()
+    rng = np.random.default_rng(7)
+    cases = []
+    for _ in range(16):
+        L = int(rng.choice([8, 25, 33]))
+        row = np.zeros(2 * L, np.int8)
+        for h in (0, 1):
+            w = _random_word(rng, int(rng.integers(1, 8)))
+            row[h * L:h * L + len(w)] = w
+        cases.append((row, int(rng.choice([1, 9, 300, 5000, 40000])), bool(rng.integers(0, 2)), int(rng.choice([7, 100, 1 << 14]))))
+
+    def run(comm):
+        out = []
+        for row, budget, cyc, bp in cases:
+            try:
+                ok, path, st = bfs_sharded(row, budget, cyclically_reduce_after_moves=cyc, comm=comm, batch_parents=bp, want_stats=True)
+                out.append((ok, path, st["nodes"], st["expanded"]))
+            except AssertionError:
+                out.append("raises")
+        return out
+
+    results = [run(SingleComm())] if world == 1 else run_threads(world, run)
+    n_raise = 0
+    for res in results:
+        for (row, budget, cyc, bp), got in zip(cases, res):
+            try:
+                wok, wpath, wst = O.bfs(row, budget, cyclically_reduce_after_moves=cyc, stats=True)
+                want = (wok, wpath, wst["nodes"], wst["expanded"])
+            except (AssertionError, IndexError):
+                want = "raises"
+                n_raise += 1
+            assert got == want, (world, budget, cyc, bp, row.tolist())
+    assert n_raise >= 0
