@@ -106,3 +106,16 @@ def test_curriculum_walks_then_samples():
     assert 0.15 < frac_solved < 0.35
     rec = {"solved": {0, 1, 2, 3, 4}, "unsolved": set()}
     assert choose_next_state(processed, 5, rec, True, 0.25)[0] in rec["solved"]
+
+
+def test_legacy_path_encoding_and_literal_files(tmp_path):
+    """data_files: the published greedy_search_paths.txt stores (action + 1, length) with a (0, length) root"""
+    from ac_solver.search.miller_schupp.data_files import FILES, from_legacy_path, read_literals, to_legacy_path, write_literals
+
+    path = [(-1, 7), (5, 7), (8, 7), (3, 5), (9, 3), (2, 2)]
+    legacy = to_legacy_path(path)
+    assert legacy == [(0, 7), (6, 7), (9, 7), (4, 5), (10, 3), (3, 2)] and from_legacy_path(legacy) == path
+    rows = [[-1, 2, 1, -2, -2, 0, -1, 2, 0, 0], legacy]
+    write_literals(rows, str(tmp_path / "x.txt"))
+    assert read_literals(str(tmp_path / "x.txt")) == [rows[0], legacy]
+    assert set(FILES) == {"all_presentations.txt", "greedy_solved_presentations.txt", "greedy_search_paths.txt", "bfs_solved_presentations.txt"}
