@@ -3,7 +3,6 @@
 import math
 
 import numpy as np
-import torch
 from torch import nn
 from torch.distributions import Categorical
 

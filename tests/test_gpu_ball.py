@@ -1,6 +1,5 @@
 """GPU parity of the neighbourhood-size kernel (acx_ball_sizes) with the reference's own program (golden sizes) and the
 C oracle, both move sets; plus the edge cases of the reference's reader (zeros anywhere, unsorted input pair)."""
-import numpy as np
 import pytest
 
 from tests.conftest import ms_pool_generator_order

@@ -19,7 +19,6 @@ def _random_word(rng, n):
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("L", [6, 12, 25, 33])
 def test_random_presentations_against_oracle(L):
-    import ac_solver
     from ac_solver import _acx
     from ac_solver.search._common import run_search
     from oracle import ac_oracle as O
