@@ -56,9 +56,6 @@ def get_env(args, device=None):
     """-> (envs, initial_states, curr_states, success_record, ACMoves_hist, states_processed)"""
     from ac_solver.envs.vec_env import ACVecEnv
 
-    if args.norm_rewards:
-        raise NotImplementedError("--norm-rewards (running return normalisation) is not part of the device environment; rewards are "
-                                  "rescaled by max_reward as in the reference's default configuration")
     if args.use_supermoves:
         raise NotImplementedError("ACEnv with supermoves is not yet implemented.")  # ac_env.py:62-65
     if args.fixed_init_state:
@@ -77,7 +74,8 @@ def get_env(args, device=None):
     clip = None
     if args.clip_rewards:
         assert args.min_rew < args.max_rew, "min_rew must be less than max_rew"
-        clip = (args.min_rew, args.max_rew)
+        if not args.norm_rewards:  # with --norm-rewards the clip follows the normalisation (training loop), as make_env stacks the wrappers
+            clip = (args.min_rew, args.max_rew)
     envs = ACVecEnv(rows, horizon_length=args.horizon_length, obs_dtype="float32", clip_rewards=clip, record_actions=True,
                     final_info=False, device=device)
     states_processed = set(curr_states)

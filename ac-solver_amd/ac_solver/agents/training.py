@@ -61,6 +61,30 @@ def choose_next_state(states_processed, n_states, success_record, round1_complet
     return random.choice(list(success_record["solved"])), round1_complete
 
 
+class RunningReturnNormalizer:
+    """Per-environment reward normalisation as gymnasium 0.28.1's `NormalizeReward` wrapper does it around every single
+    env (environment.py:44-46 of the reference): a discounted return is accumulated, its running variance is tracked
+    (Welford / Chan update with one sample per step, initial mean 0, variance 1, count 1e-4) and the reward is divided by
+    sqrt(variance + 1e-8).  gymnasium is a third-party dependency that is not part of the reference tree: this follows
+    its published algorithm and is not pinned by a fixture."""
+
+    def __init__(self, n, gamma, device, epsilon=1e-8):
+        self.gamma, self.epsilon = gamma, epsilon
+        self.returns = torch.zeros(n, device=device, dtype=torch.float64)
+        self.mean = torch.zeros(n, device=device, dtype=torch.float64)
+        self.var = torch.ones(n, device=device, dtype=torch.float64)
+        self.count = torch.full((n,), 1e-4, device=device, dtype=torch.float64)
+
+    def __call__(self, rewards, terminated):
+        self.returns = self.returns * self.gamma * (1.0 - terminated.to(torch.float64)) + rewards.to(torch.float64)
+        delta = self.returns - self.mean
+        tot = self.count + 1.0
+        self.mean = self.mean + delta / tot
+        self.var = (self.var * self.count + delta * delta * self.count / tot) / tot
+        self.count = tot
+        return (rewards.to(torch.float64) / torch.sqrt(self.var + self.epsilon)).to(rewards.dtype)
+
+
 def _average_gradients(params, world):
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     torch.distributed.all_reduce(flat)
@@ -94,6 +118,7 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
     ep_return = torch.zeros(N, device=device)
     ep_length = torch.zeros(N, device=device)
 
+    normalizer = RunningReturnNormalizer(N, args.gamma, device) if args.norm_rewards else None
     global_step = 0
     obs[0].copy_(envs.reset()[0])
     num_updates = args.total_timesteps // args.batch_size
@@ -140,6 +165,10 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             logprobs[step] = logprob
             values[step] = value.flatten()
             envs.step(action, out=(obs[step + 1], rewards[step], term[step + 1], trunc), check_errors=False)
+            if normalizer is not None:  # NormalizeReward, then TransformReward(clip) as make_env stacks them
+                rewards[step] = normalizer(rewards[step], term[step + 1])
+                if args.clip_rewards:
+                    rewards[step].clamp_(args.min_rew, args.max_rew)
             ep_return += rewards[step]
             ep_length += 1
             fin = term[step + 1] | trunc

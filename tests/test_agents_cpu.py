@@ -119,3 +119,23 @@ def test_legacy_path_encoding_and_literal_files(tmp_path):
     write_literals(rows, str(tmp_path / "x.txt"))
     assert read_literals(str(tmp_path / "x.txt")) == [rows[0], legacy]
     assert set(FILES) == {"all_presentations.txt", "greedy_solved_presentations.txt", "greedy_search_paths.txt", "bfs_solved_presentations.txt"}
+
+
+def test_running_return_normalizer_matches_the_scalar_recursion():
+    from ac_solver.agents.training import RunningReturnNormalizer
+
+    rng = np.random.default_rng(1)
+    T, N, gamma = 30, 3, 0.99
+    rew = rng.normal(size=(T, N)) * 5
+    term = rng.random((T, N)) < 0.2
+    norm = RunningReturnNormalizer(N, gamma, torch.device("cpu"))
+    got = np.stack([norm(torch.tensor(rew[t]), torch.tensor(term[t])).numpy() for t in range(T)])
+    for n in range(N):  # gymnasium's RunningMeanStd.update_from_moments with a batch of one sample, per env
+        mean, var, count, ret = 0.0, 1.0, 1e-4, 0.0
+        for t in range(T):
+            ret = ret * gamma * (1.0 - float(term[t, n])) + rew[t, n]
+            delta, tot = ret - mean, count + 1.0
+            new_mean = mean + delta / tot
+            m2 = var * count + 0.0 + delta ** 2 * count * 1.0 / tot
+            mean, var, count = new_mean, m2 / tot, tot
+            assert np.isclose(got[t, n], rew[t, n] / np.sqrt(var + 1e-8), rtol=1e-12), (t, n)
