@@ -805,6 +805,9 @@ int acx_env_step(acx_env* e, const void* d_actions, int action_dtype, void* d_ob
         if (e->L == 25) {
             if (f32) ACX_STEP_TEAM(float, 25);
             else ACX_STEP_TEAM(int8_t, 25);
+        } else if (e->L == 36) {
+            if (f32) ACX_STEP_TEAM(float, 36);
+            else ACX_STEP_TEAM(int8_t, 36);
         } else {
             if (f32) ACX_STEP_TEAM(float, 0);
             else ACX_STEP_TEAM(int8_t, 0);
@@ -812,6 +815,9 @@ int acx_env_step(acx_env* e, const void* d_actions, int action_dtype, void* d_ob
     } else if (e->L == 25) {  // BASELINE max_relator_length: fully unrolled observation writer
         if (f32) ACX_STEP(float, 25);
         else ACX_STEP(int8_t, 25);
+    } else if (e->L == 36) {  // the reference's PPO configuration (agents/environment.py:87)
+        if (f32) ACX_STEP(float, 36);
+        else ACX_STEP(int8_t, 36);
     } else {
         if (f32) ACX_STEP(float, 0);
         else ACX_STEP(int8_t, 0);

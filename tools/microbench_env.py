@@ -13,7 +13,7 @@ from ac_solver import _acx
 from ac_solver.envs.vec_env import ACVecEnv
 from bench import ms_pool_at_L
 
-L = 25
+L = int(os.environ.get("ACX_MB_L", "25"))
 
 
 def timeit(fn, reps):

@@ -12,7 +12,7 @@ from ac_solver import _acx
 from ac_solver.envs.vec_env import ACVecEnv
 from bench import ms_pool_at_L
 
-L, K = 25, 500
+L, K = int(os.environ.get("ACX_MB_L", "25")), 500
 
 
 def graph_time(body):
