@@ -1,8 +1,12 @@
 """Differential fuzz of the device frontiers against the CPU oracle on random presentations (not only presentations of
 the trivial group: searches in which a move empties a relator must raise like the reference), random budgets, both
 algorithms, both cyclic-reduction settings, 64-bit and 128-bit keys."""
+import os
+
 import numpy as np
 import pytest
+
+SEED = int(os.environ.get("ACX_FUZZ_SEED", "0"))  # soak runs: other seeds, other cases
 
 pytestmark = pytest.mark.gpu
 
@@ -24,7 +28,7 @@ def test_random_presentations_against_oracle(L):
     from oracle import ac_oracle as O
 
     _acx.require_device()
-    rng = np.random.default_rng(100 + L)
+    rng = np.random.default_rng(100 + L + 1000 * SEED)
     n_cases = 40 if L <= 12 else 24
     raised = solved = 0
     for case in range(n_cases):
@@ -67,7 +71,7 @@ def test_random_presentations_sharded_bfs(world):
     from tests.shard_helpers import run_threads
 
     _acx.require_device()
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(7 + 1000 * SEED)
     cases = []
     for _ in range(16):
         L = int(rng.choice([8, 25, 33]))
