@@ -90,6 +90,16 @@ template <typename W> struct SearchDev {
     int32_t cyclical;
 };
 
+// Shift flavour of the moves in the search kernels.  Search keys cap max_relator_length at 29 (u64) / 61 (u128), so the plain
+// hardware shifts (SAFE = false in acx_word.h) would be enough -- but the k_expand that hipcc builds from them (exactly 24
+// VGPRs) returned corrupted children on MI355X whenever more than one wave per SIMD was resident; the identical code object
+// with 32 VGPRs declared, or at one wave per SIMD, is correct (tools/_build experiments, DESIGN.md "known hazards").  The
+// range-checked shifts cost a few instructions per move and have been bit-exact in every run, so they stay.
+#ifndef ACX_SEARCH_SAFE
+#define ACX_SEARCH_SAFE 1
+#endif
+constexpr bool kSearchSafe = ACX_SEARCH_SAFE != 0;
+
 template <typename W> __device__ __forceinline__ void key_to_pres(W k0, W k1, Pres<W>& s) {
     s.w0 = keyops<W>::word(k0);
     s.n0 = keyops<W>::len(k0);
@@ -108,7 +118,7 @@ __global__ void __launch_bounds__(256) k_expand(SearchDev<W> d, const uint32_t* 
         Pres<W> s;
         const W pk0 = d.k0[pid], pk1 = d.k1[pid];
         key_to_pres<W>(pk0, pk1, s);
-        const int e = apply_move<W, true>(s, (int)a, d.L, d.cyclical != 0);
+        const int e = apply_move<W, kSearchSafe>(s, (int)a, d.L, d.cyclical != 0);
         // the reference's ACMove raises here -- but only if it gets this far: the search raises when this move precedes its
         // termination (k_decide), so the FIRST such move of the batch is what matters
         if (e) atomicMin(d.err_tag, ((unsigned long long)t << 8) | (unsigned long long)e);

@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) k_shard_expand(SearchDev<W> d, const int6
     const int64_t id = ids[p];
     Pres<W> s;
     key_to_pres<W>(d.k0[id], d.k1[id], s);
-    const int e = apply_move<W, true>(s, a, d.L, d.cyclical != 0);
+    const int e = apply_move<W, kSearchSafe>(s, a, d.L, d.cyclical != 0);
     if (e) atomicMin(solved + 1, ((unsigned long long)(12 * gpos[p] + a) << 8) | (unsigned long long)e);  // first erroring move (global tag)
     int64_t* r = rec + t * (recio<W>::KW + 2);
     recio<W>::put(r, keyops<W>::make(s.w0, s.n0), keyops<W>::make(s.w1, s.n1));
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(1024) k_shard_expand_routed(SearchDev<W> d, co
         Pres<W> s;
         const W pk0 = d.k0[id], pk1 = d.k1[id];
         key_to_pres<W>(pk0, pk1, s);
-        const int e = apply_move<W, true>(s, a, d.L, d.cyclical != 0);
+        const int e = apply_move<W, kSearchSafe>(s, a, d.L, d.cyclical != 0);
         if (e) atomicMin(solved + 1, ((unsigned long long)(12 * gpos[p] + a) << 8) | (unsigned long long)e);  // first erroring move (global tag)
         k0 = keyops<W>::make(s.w0, s.n0);
         k1 = keyops<W>::make(s.w1, s.n1);
