@@ -34,8 +34,7 @@ int main(int argc, char** argv) {
     hipMemcpy(d.k0, k0.data(), n * 8, hipMemcpyHostToDevice); hipMemcpy(d.k1, k1.data(), n * 8, hipMemcpyHostToDevice);
     for (int rep = 0; rep < 3; rep++) {
         hipMemset(d.ck0, 0, m * 8); hipMemset(d.ck1, 0, m * 8);
-        if (rep < 2) hipLaunchKernelGGL(k_expand<W>, dim3((m + 255) / 256), dim3(256), 0, 0, d, (const uint32_t*)nullptr, 0u, (uint32_t)n);
-        else hipLaunchKernelGGL(k_expand_parent<W>, dim3((n + 255) / 256), dim3(256), 0, 0, d, (const uint32_t*)nullptr, 0u, (uint32_t)n);
+        hipLaunchKernelGGL(k_expand<W>, dim3((m + 255) / 256), dim3(256), 0, 0, d, (const uint32_t*)nullptr, 0u, (uint32_t)n);
         std::vector<W> h0(m), h1(m); std::vector<uint8_t> hl(m), hk(m); unsigned long long hs[8];
         hipMemcpy(h0.data(), d.ck0, m * 8, hipMemcpyDeviceToHost); hipMemcpy(h1.data(), d.ck1, m * 8, hipMemcpyDeviceToHost);
         hipMemcpy(hl.data(), d.clen, m, hipMemcpyDeviceToHost); hipMemcpy(hk.data(), d.cknown, m, hipMemcpyDeviceToHost); hipMemcpy(hs, sc, 64, hipMemcpyDeviceToHost);
