@@ -123,19 +123,24 @@ def move_batch(states, actions, max_relator_length, cyclical=True):
     return out, lens, err
 
 
-def env_rollout(states, counts, horizon, tape, want_outputs=True):
+def env_rollout(states, counts, horizon, tape, want_outputs=True, out=None):
     """ACEnv.step over an action tape [T, n]; `states` [n, 2L] and `counts` [n] are updated in place.
 
-    Returns (reward [T, n] int32, done [T, n] u8, truncated [T, n] u8, err [n] u8) or None."""
+    Returns (reward [T, n] int32, done [T, n] u8, truncated [T, n] u8, err [n] u8) or None.  `out` = (reward, done,
+    truncated) arrays to fill instead of fresh ones (timing loops)."""
     n, W = states.shape
     T = tape.shape[0]
     assert states.dtype == np.int8 and counts.dtype == np.int32 and tape.dtype == np.uint8
     assert states.flags.c_contiguous and tape.flags.c_contiguous
     err = np.zeros(n, dtype=np.uint8)
     if want_outputs:
-        rew = np.empty((T, n), dtype=np.int32)
-        done = np.empty((T, n), dtype=np.uint8)
-        trunc = np.empty((T, n), dtype=np.uint8)
+        if out is not None:
+            rew, done, trunc = out
+            assert rew.shape == (T, n) and rew.dtype == np.int32 and done.dtype == np.uint8 and trunc.dtype == np.uint8
+        else:
+            rew = np.empty((T, n), dtype=np.int32)
+            done = np.empty((T, n), dtype=np.uint8)
+            trunc = np.empty((T, n), dtype=np.uint8)
         args = (_p(rew, C.c_int32), _p(done, C.c_uint8), _p(trunc, C.c_uint8))
     else:
         rew = done = trunc = None
