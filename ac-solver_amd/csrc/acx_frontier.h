@@ -355,6 +355,154 @@ __global__ void __launch_bounds__(256) k_commit(SearchDev<W> d, const uint32_t* 
     // BFS (insert_now == 0): the inline-key table already holds the key under this batch's epoch; nothing to rewrite
 }
 
+// ---- BFS: winners -> nodes in ONE pass (mark + scan + commit) -----------------------------------------------------------
+// A tile of kCompactTile consecutive candidates per workgroup.  The tile counts its winners (cflag & !cslot, see
+// k_insert_tab), gets the number of winners before it through a decoupled look-back over per-tile status words
+// (epoch << 34 | state << 32 | count; tiles are handed out by a ticket so that a tile only ever waits for tiles that
+// already run), and writes its winners as nodes base + rank, rank = position among the batch's winners in tag order.
+// Every winner of the batch is written (ids below cap_nodes): in a BFS a batch is cut short only when the search
+// ends, and k_decide_tab then derives the counts the reference would have from the tags of the written nodes.
+constexpr uint32_t kCompactItems = 8;
+constexpr uint32_t kCompactTile = 256 * kCompactItems;
+constexpr unsigned long long kTileAgg = 1ull, kTileIncl = 2ull;
+
+template <typename W>
+__global__ void __launch_bounds__(256) k_compact_tab(SearchDev<W> d, uint32_t pbegin, uint32_t m, uint32_t base, uint32_t cap_nodes, uint32_t epoch,
+                                                     unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t* __restrict__ total_out) {
+    __shared__ uint32_t s_tile, s_prefix, s_wsum[4];
+    __shared__ uint16_t s_list[kCompactTile];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile, ntiles = (m + kCompactTile - 1) / kCompactTile;
+    const uint32_t t0 = tile * kCompactTile + tid * kCompactItems;
+    uint32_t fl = 0;  // bit i: candidate t0 + i is a winner
+    if (t0 + kCompactItems <= m) {
+        const uint4 a0 = *(const uint4*)(d.cflag + t0), a1 = *(const uint4*)(d.cflag + t0 + 4);
+        const uint4 b0 = *(const uint4*)(d.cslot + t0), b1 = *(const uint4*)(d.cslot + t0 + 4);
+        fl = (a0.x && !b0.x ? 1u : 0u) | (a0.y && !b0.y ? 2u : 0u) | (a0.z && !b0.z ? 4u : 0u) | (a0.w && !b0.w ? 8u : 0u) |
+             (a1.x && !b1.x ? 16u : 0u) | (a1.y && !b1.y ? 32u : 0u) | (a1.z && !b1.z ? 64u : 0u) | (a1.w && !b1.w ? 128u : 0u);
+    } else {
+        for (uint32_t i = 0; i < kCompactItems; i++)
+            if (t0 + i < m && d.cflag[t0 + i] && !d.cslot[t0 + i]) fl |= 1u << i;
+    }
+    const uint32_t cnt = (uint32_t)__popc(fl);
+    uint32_t incl = cnt;  // inclusive scan over the wave
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= (uint32_t)o) incl += v;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < wave; w++) wbase += s_wsum[w];
+    const uint32_t block_total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    // local winner list (offsets inside the tile), in tag order
+    {
+        uint32_t pos = wbase + incl - cnt, f = fl;
+        while (f) {
+            const uint32_t i = (uint32_t)__builtin_ctz(f);
+            f &= f - 1;
+            s_list[pos++] = (uint16_t)(tid * kCompactItems + i);
+        }
+    }
+    if (wave == 0) {
+        const unsigned long long tagged = (unsigned long long)epoch << 34;
+        if (lane == 0)
+            __hip_atomic_store(&status[tile], tagged | ((tile == 0 ? kTileIncl : kTileAgg) << 32) | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        long long j0 = (long long)tile - 1;
+        while (j0 >= 0) {  // 64 predecessors per round, nearest first
+            const long long j = j0 - (long long)lane;
+            unsigned long long w = tagged | (kTileIncl << 32);  // before the first tile: inclusive 0
+            for (;;) {
+                if (j >= 0) w = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ready = (w >> 34) == (unsigned long long)epoch && ((w >> 32) & 3ull) != 0;
+                if (__all(ready)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const unsigned long long inc = __ballot(((w >> 32) & 3ull) == kTileIncl);
+            const uint32_t first = inc ? (uint32_t)__builtin_ctzll(inc) : 63u;  // nearest predecessor that knows its inclusive count
+            uint32_t v = lane <= first ? (uint32_t)w : 0u;
+            for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+            excl += v;
+            if (inc) break;
+            j0 -= 64;
+        }
+        if (lane == 0) {
+            if (tile != 0) __hip_atomic_store(&status[tile], tagged | (kTileIncl << 32) | (excl + block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = excl;
+            if (tile == ntiles - 1) {
+                *total_out = excl + block_total;
+                *ticket = 0;  // every ticket of this launch has been taken
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t first_id = base + s_prefix, tbase = tile * kCompactTile;
+    for (uint32_t j = tid; j < block_total; j += 256) {
+        const uint32_t id = first_id + j;
+        if (id >= cap_nodes) break;  // beyond the budget: never read
+        const uint32_t t = tbase + s_list[j];
+        const uint32_t p = t / 12u, pid = pbegin + p;
+        d.k0[id] = d.ck0[t];
+        d.k1[id] = d.ck1[t];
+        d.parent[id] = pid;
+        d.act[id] = (uint8_t)(t - 12u * p);
+        d.tlen[id] = d.clen[t];
+        d.depth[id] = d.depth[pid] + 1;
+    }
+}
+
+// k_decide for the one-pass BFS commit: the winners of the batch are nodes base .. base + total - 1 in tag order, so
+// "winners before tag T" is a binary search over their (parent, action) and the budget-crossing candidate is winner need - 1.
+template <typename W>
+__global__ void k_decide_tab(SearchDev<W> d, uint32_t m, uint32_t np, uint32_t pbegin, uint32_t base, uint32_t cap_nodes, long long max_nodes,
+                             const uint32_t* __restrict__ total_in, Decision* __restrict__ out) {
+    const uint32_t total = *total_in;
+    const unsigned long long nodes = base;
+    uint32_t p_end = np - 1, budget_hit = 0;
+    const unsigned long long solved_tag = *d.solved_tag;
+    auto tag_of = [&](uint32_t j) { return 12u * (d.parent[base + j] - pbegin) + (uint32_t)d.act[base + j]; };
+    if ((long long)nodes >= max_nodes) {
+        p_end = 0;
+        budget_hit = 1;
+    } else if ((long long)(nodes + total) >= max_nodes) {
+        const uint32_t need = (uint32_t)(max_nodes - (long long)nodes);
+        const uint32_t pb = tag_of(need - 1) / 12u;
+        if (pb <= p_end) {
+            p_end = pb;
+            budget_hit = 1;
+        }
+    }
+    const uint32_t is_solved = solved_tag != kNoTag && (uint32_t)(solved_tag / 12) <= p_end;
+    const uint32_t cutoff = is_solved ? (uint32_t)solved_tag : 12u * (p_end + 1);
+    uint32_t committed = total;
+    if (cutoff < m) {  // winners with a tag below the cutoff (only a terminating batch gets here)
+        const unsigned long long room = (unsigned long long)cap_nodes - nodes;
+        uint32_t lo = 0, hi = (unsigned long long)total < room ? total : (uint32_t)room;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (tag_of(mid) < cutoff) lo = mid + 1;
+            else hi = mid;
+        }
+        committed = lo;
+    }
+    out->p_end = is_solved ? (uint32_t)(solved_tag / 12) : p_end;
+    out->cutoff = cutoff;
+    out->committed = committed;
+    out->total = total;
+    out->budget_hit = budget_hit;
+    out->solved = is_solved;
+    out->solved_tag = (uint32_t)solved_tag;
+    out->last_child_len = d.clen[12u * p_end + 11];
+    const unsigned long long et = *d.err_tag;
+    const bool err_hit = et != kNoTag && (uint32_t)((et >> 8) / 12) <= p_end && !(is_solved && solved_tag < (et >> 8));
+    out->err = err_hit ? (uint32_t)(et & 0xff) : 0u;
+    if (err_hit) out->solved = 0;
+    out->min_len = *d.min_len;
+}
+
 // root node: id 0
 template <typename W> __global__ void k_root(SearchDev<W> d, W k0, W k1, uint32_t tl) {
     d.k0[0] = k0;

@@ -27,7 +27,10 @@ namespace acx {
 
 template <typename W> struct Searcher {
     SearchDev<W> d;
-    DevBuf arena_nodes, arena_cand, arena_tab, arena_btab, arena_scal, arena_tmp, arena_list, arena_path;
+    DevBuf arena_nodes, arena_cand, arena_tab, arena_btab, arena_scal, arena_tmp, arena_list, arena_path, arena_status;
+    unsigned long long* d_status = nullptr;  // one-pass BFS commit: per-tile look-back words
+    uint32_t* d_ticket = nullptr;
+    uint32_t* d_total = nullptr;
     size_t tmp_bytes = 0;
     uint64_t cap_nodes = 0, cap_cand = 0, n_slots = 0, n_bslots = 0;
     hipStream_t st = nullptr;
@@ -122,6 +125,15 @@ template <typename W> struct Searcher {
         if (!lean) ACX_HIP_TRY(hipMemsetAsync(arena_tab.p, 0xff, n_slots * (inline_tab ? sizeof(TabEntry<W>) : 4), st));
         ACX_HIP_TRY(hipMemsetAsync(arena_scal.p, 0xff, 256, st));
         ACX_HIP_TRY(hipMemsetAsync(d.err, 0, 4, st));
+        d_ticket = (uint32_t*)(sc + 128);
+        d_total = (uint32_t*)(sc + 132);
+        ACX_HIP_TRY(hipMemsetAsync(d_ticket, 0, 8, st));
+        if (inline_tab) {  // status words of k_compact_tab: epoch 0 = never written
+            const size_t tiles = cap_cand / kCompactTile + 2;
+            if (arena_status.alloc(tiles * 8)) return ACX_E_NOMEM;
+            d_status = (unsigned long long*)arena_status.p;
+            ACX_HIP_TRY(hipMemsetAsync(d_status, 0, tiles * 8, st));
+        }
         return ACX_OK;
     }
 
@@ -462,6 +474,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
     std::vector<uint32_t> hlist;
     std::vector<uint8_t> hlen;
     const bool debug = getenv("ACX_DEBUG") != nullptr;
+    const bool classic_commit = getenv("ACX_BFS_CLASSIC_COMMIT") != nullptr;  // A/B: mark + scan + decide + commit as four launches
     uint32_t adaptive = 64;  // greedy batch size: grows while buckets are consumed without a cut
 
     while (!done) {
@@ -527,15 +540,20 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
             hipLaunchKernelGGL(k_mark<W>, grid, block, 0, st, d, d.bslots, m, bucket_len);
         } else {
             hipLaunchKernelGGL(k_insert_tab<W>, grid, block, 0, st, d, m, (uint32_t)batches, 1);  // epoch = batch number (>= 1)
-            hipLaunchKernelGGL(k_mark_tab<W>, grid, block, 0, st, d, m);
+            if (classic_commit) hipLaunchKernelGGL(k_mark_tab<W>, grid, block, 0, st, d, m);
         }
-        {
+        if (!greedy && !classic_commit) {
+            // winners -> nodes in one pass, then the decision from the written nodes
+            hipLaunchKernelGGL(k_compact_tab<W>, dim3((m + kCompactTile - 1) / kCompactTile), block, 0, st, d, pbegin, m, (uint32_t)nodes, (uint32_t)S.cap_nodes,
+                               (uint32_t)batches, S.d_status, S.d_ticket, S.d_total);
+            hipLaunchKernelGGL(k_decide_tab<W>, dim3(1), dim3(1), 0, st, d, m, np, pbegin, (uint32_t)nodes, (uint32_t)S.cap_nodes, (long long)max_nodes, S.d_total, S.d_dec);
+        } else {
             size_t tb = S.tmp_bytes;
             if (rocprim::exclusive_scan(S.arena_tmp.p, tb, d.cflag, d.cpos, 0u, m, rocprim::plus<uint32_t>(), st) != hipSuccess)
                 return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan failed");
+            hipLaunchKernelGGL(k_decide<W>, dim3(1), dim3(1), 0, st, d, m, np, (unsigned long long)nodes, (long long)max_nodes, greedy ? 1 : 0, S.d_dec);
+            hipLaunchKernelGGL(k_commit<W>, grid, block, 0, st, d, plist, pbegin, S.d_dec, m, (uint32_t)nodes, greedy ? 1 : 0);
         }
-        hipLaunchKernelGGL(k_decide<W>, dim3(1), dim3(1), 0, st, d, m, np, (unsigned long long)nodes, (long long)max_nodes, greedy ? 1 : 0, S.d_dec);
-        hipLaunchKernelGGL(k_commit<W>, grid, block, 0, st, d, plist, pbegin, S.d_dec, m, (uint32_t)nodes, greedy ? 1 : 0);
         ACX_HIP_TRY(hipGetLastError());
         // one read-back: the decision and (greedy) the total lengths of the nodes this batch may have created
         Decision* dec = (Decision*)S.h_pin;
