@@ -139,6 +139,10 @@ __global__ void __launch_bounds__(256) k_expand(SearchDev<W> d, const uint32_t* 
     if ((threadIdx.x & 63) == 0 && m < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, m);
 }
 
+// A probe sequence longer than its table means the table is full or damaged: the kernels stop probing and report it through
+// the sticky error word instead of spinning forever.
+constexpr uint32_t kErrTableFull = 0x40000000u;
+
 template <typename W> __device__ __forceinline__ bool key_equals(const SearchDev<W>& d, uint32_t id, W k0, W k1) {
     if (id & kProv) {
         const uint32_t t = id & ~kProv;
@@ -159,7 +163,7 @@ __global__ void __launch_bounds__(256) k_insert(SearchDev<W> d, uint32_t* __rest
     }
     const W k0 = d.ck0[t], k1 = d.ck1[t];
     const uint32_t me = kProv | t;
-    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & mask;
+    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & mask, probes = 0;
     for (;;) {
         uint32_t v = slots[h];
         if (v == kEmpty) {
@@ -171,6 +175,11 @@ __global__ void __launch_bounds__(256) k_insert(SearchDev<W> d, uint32_t* __rest
             break;
         }
         h = (h + 1) & mask;
+        if (++probes > mask) {
+            atomicOr(d.err, kErrTableFull);
+            h = kEmpty;
+            break;
+        }
     }
     d.cslot[t] = h;
 }
@@ -180,7 +189,7 @@ template <typename W> __global__ void __launch_bounds__(256) k_lookup(SearchDev<
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     const W k0 = d.ck0[t], k1 = d.ck1[t];
-    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.smask;
+    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.smask, probes = 0;
     uint8_t known = 0;
     for (;;) {
         const uint32_t v = d.slots[h];
@@ -190,6 +199,10 @@ template <typename W> __global__ void __launch_bounds__(256) k_lookup(SearchDev<
             break;
         }
         h = (h + 1) & d.smask;
+        if (++probes > d.smask) {
+            atomicOr(d.err, kErrTableFull);
+            break;
+        }
     }
     d.cknown[t] = known;
 }
@@ -219,7 +232,7 @@ __global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, 
     }
     const W k0 = d.ck0[t], k1 = d.ck1[t];
     const unsigned long long me = ((unsigned long long)epoch << 32) | t;
-    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.tmask;
+    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.tmask, probes = 0;
     uint32_t took = 0;
     for (;;) {
         TabEntry<W>* e = d.tab + h;
@@ -251,6 +264,10 @@ __global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, 
             break;  // a committed state
         }
         h = (h + 1) & d.tmask;
+        if (++probes > d.tmask) {
+            atomicOr(d.err, kErrTableFull);
+            break;
+        }
     }
     d.cflag[t] = took;
 }
@@ -327,6 +344,7 @@ __global__ void k_decide(SearchDev<W> d, uint32_t m, uint32_t np, unsigned long 
     const bool err_hit = et != kNoTag && (uint32_t)((et >> 8) / 12) <= p_end && !(is_solved && solved_tag < (et >> 8));
     out->err = err_hit ? (uint32_t)(et & 0xff) : 0u;
     if (err_hit) out->solved = 0;
+    if (*d.err & kErrTableFull) out->err = 0xFE;  // not a move error: a probe sequence ran through its whole table
     out->min_len = *d.min_len;
 }
 
@@ -349,8 +367,14 @@ __global__ void __launch_bounds__(256) k_commit(SearchDev<W> d, const uint32_t* 
     d.tlen[id] = d.clen[t];
     d.depth[id] = d.depth[pid] + 1;
     if (insert_now == 1) {  // batch-per-launch greedy: id table
-        uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.smask;
-        while (atomicCAS(&d.slots[h], kEmpty, id) != kEmpty) h = (h + 1) & d.smask;
+        uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.smask, probes = 0;
+        while (atomicCAS(&d.slots[h], kEmpty, id) != kEmpty) {
+            h = (h + 1) & d.smask;
+            if (++probes > d.smask) {
+                atomicOr(d.err, kErrTableFull);
+                break;
+            }
+        }
     }
     // BFS (insert_now == 0): the inline-key table already holds the key under this batch's epoch; nothing to rewrite
 }
@@ -500,6 +524,7 @@ __global__ void k_decide_tab(SearchDev<W> d, uint32_t m, uint32_t np, uint32_t p
     const bool err_hit = et != kNoTag && (uint32_t)((et >> 8) / 12) <= p_end && !(is_solved && solved_tag < (et >> 8));
     out->err = err_hit ? (uint32_t)(et & 0xff) : 0u;
     if (err_hit) out->solved = 0;
+    if (*d.err & kErrTableFull) out->err = 0xFE;  // not a move error: a probe sequence ran through its whole table
     out->min_len = *d.min_len;
 }
 

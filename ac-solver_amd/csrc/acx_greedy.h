@@ -29,7 +29,10 @@ namespace acx {
 #define ACX_GREEDY_PROFILE 0  // 1: thread 0 accumulates shader-clock cycles per phase (costs ~10 %); see GreedyOut::t_phase
 #endif
 
-constexpr int kGT = 1024;              // lanes of the persistent workgroup
+#ifndef ACX_GREEDY_THREADS
+#define ACX_GREEDY_THREADS 1024
+#endif
+constexpr int kGT = ACX_GREEDY_THREADS;  // lanes of the persistent workgroup
 constexpr uint32_t kDepthCap = 16384;  // bucket table rows per total length
 
 enum : uint32_t { GREEDY_RUNNING = 0, GREEDY_SOLVED = 1, GREEDY_BUDGET = 2, GREEDY_EXHAUSTED = 3, GREEDY_FALLBACK = 4, GREEDY_MOVE_ERROR = 5 };

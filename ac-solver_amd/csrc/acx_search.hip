@@ -561,6 +561,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         ACX_HIP_TRY(hipMemcpyAsync(dec, S.d_dec, sizeof(Decision), hipMemcpyDeviceToHost, st));
         if (greedy) ACX_HIP_TRY(hipMemcpyAsync(hl, d.tlen + nodes, std::min<uint64_t>(m, S.cap_nodes - nodes), hipMemcpyDeviceToHost, st));
         ACX_HIP_TRY(hipStreamSynchronize(st));
+        if (dec->err == 0xFE) return fail(ACX_E_CAPACITY, "acx_search: a probe sequence ran through the whole visited table (table full or damaged)");
         if (dec->err) return err_to_rc(dec->err);
         if (debug) fprintf(stderr, "[acx_search]   total=%u p_end=%u committed=%u solved=%u budget_hit=%u\n", dec->total, dec->p_end, dec->committed, dec->solved, dec->budget_hit);
         const uint32_t p_end = dec->p_end, committed = dec->committed;

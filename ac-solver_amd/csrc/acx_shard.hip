@@ -259,6 +259,7 @@ template <typename W> struct ShardEngine {
         ACX_HIP_TRY(hipMemset(d.tab, 0xff, n_slots * sizeof(TabEntry<W>)));
         ACX_HIP_TRY(hipMemset(scal_buf.p, 0xff, 256));
         ACX_HIP_TRY(hipMemset(d.err, 0, 4));
+        ACX_HIP_TRY(hipDeviceSynchronize());  // the fills run on the null stream; the engine's calls arrive on the caller's (possibly non-blocking) stream
         return ACX_OK;
     }
 };

@@ -719,6 +719,7 @@ acx_env* acx_env_create(int64_t n, int L, int64_t horizon, int flags) {
         return nullptr;
     }
     (void)hipMemset(e->arena, 0, total);
+    (void)hipDeviceSynchronize();  // the fill runs on the null stream; later calls come in on caller streams that may not wait for it
     if (e->wide) carve<u128>(e->d128, (uint8_t*)e->arena, n, L, e->H, horizon, hist, &total);
     else carve<uint64_t>(e->d64, (uint8_t*)e->arena, n, L, e->H, horizon, hist, &total);
     // default ACEnvConfig.initial_state is the trivial presentation <x, y> (ac_env.py:16-18)
