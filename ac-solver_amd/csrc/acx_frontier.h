@@ -80,6 +80,8 @@ template <typename W> struct SearchDev {
     uint32_t* cflag;  // 1 = winner / new
     uint32_t* cpos;   // exclusive scan of cflag
     uint8_t* cknown;  // greedy: already in the visited table
+    uint8_t* btook;   // fused BFS: byte-wide "took the entry" / "was replaced" flags of k_insert_tab (instead of cflag / cslot;
+    uint8_t* brepl;   // null on the other paths): a quarter of the flag traffic of the three kernels that touch them
     // device scalars
     unsigned long long* solved_tag;   // min tag with total length 2
     unsigned long long* shorter_tag;  // greedy: min tag of a NEW child shorter than the bucket
@@ -126,7 +128,8 @@ __global__ void __launch_bounds__(256) k_expand(SearchDev<W> d, const uint32_t* 
         d.ck0[t] = c0;
         d.ck1[t] = c1;
         d.cknown[t] = (c0 == pk0 && c1 == pk1) ? 1 : 0;  // an unchanged state is its (visited) parent: k_insert skips the probe
-        d.cslot[t] = 0;                                    // BFS: "replaced by a smaller tag" flag of k_insert_tab
+        if (d.brepl) d.brepl[t] = 0;                       // BFS: "replaced by a smaller tag" flag of k_insert_tab
+        else d.cslot[t] = 0;
         tl = (uint32_t)(s.n0 + s.n1);
         d.clen[t] = (uint8_t)tl;
         if (tl == 2) atomicMin(d.solved_tag, (unsigned long long)t);  // breadth_first.py:84 / greedy.py:91
@@ -227,7 +230,8 @@ __global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, 
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     if (skip_known && d.cknown[t]) {
-        d.cflag[t] = 0;
+        if (d.btook) d.btook[t] = 0;
+        else d.cflag[t] = 0;
         return;
     }
     const W k0 = d.ck0[t], k1 = d.ck1[t];
@@ -255,7 +259,8 @@ __global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, 
                     const unsigned long long prev = atomicMin(&e->stamp, me);  // the holder I actually replaced (if any)
                     if (prev > me) {
                         took = 1;
-                        d.cslot[(uint32_t)prev] = 1;  // that candidate is no longer the first discoverer
+                        if (d.brepl) d.brepl[(uint32_t)prev] = 1;  // that candidate is no longer the first discoverer
+                        else d.cslot[(uint32_t)prev] = 1;
                     }
                 }
                 break;
@@ -269,7 +274,8 @@ __global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, 
             break;
         }
     }
-    d.cflag[t] = took;
+    if (d.btook) d.btook[t] = (uint8_t)took;
+    else d.cflag[t] = took;
 }
 
 template <typename W> __global__ void __launch_bounds__(256) k_mark_tab(SearchDev<W> d, uint32_t m) {
@@ -400,15 +406,15 @@ __global__ void __launch_bounds__(256) k_compact_tab(SearchDev<W> d, uint32_t pb
     __syncthreads();
     const uint32_t tile = s_tile, ntiles = (m + kCompactTile - 1) / kCompactTile;
     const uint32_t t0 = tile * kCompactTile + tid * kCompactItems;
-    uint32_t fl = 0;  // bit i: candidate t0 + i is a winner
+    uint32_t fl = 0;  // bit i: candidate t0 + i is a winner (took its entry and was not replaced)
     if (t0 + kCompactItems <= m) {
-        const uint4 a0 = *(const uint4*)(d.cflag + t0), a1 = *(const uint4*)(d.cflag + t0 + 4);
-        const uint4 b0 = *(const uint4*)(d.cslot + t0), b1 = *(const uint4*)(d.cslot + t0 + 4);
-        fl = (a0.x && !b0.x ? 1u : 0u) | (a0.y && !b0.y ? 2u : 0u) | (a0.z && !b0.z ? 4u : 0u) | (a0.w && !b0.w ? 8u : 0u) |
-             (a1.x && !b1.x ? 16u : 0u) | (a1.y && !b1.y ? 32u : 0u) | (a1.z && !b1.z ? 64u : 0u) | (a1.w && !b1.w ? 128u : 0u);
+        const unsigned long long tb = *(const unsigned long long*)(d.btook + t0), rb = *(const unsigned long long*)(d.brepl + t0);
+        const unsigned long long w = tb & ~rb;  // bytes are 0 / 1
+#pragma unroll
+        for (uint32_t i = 0; i < kCompactItems; i++) fl |= (uint32_t)((w >> (8u * i)) & 1ull) << i;
     } else {
         for (uint32_t i = 0; i < kCompactItems; i++)
-            if (t0 + i < m && d.cflag[t0 + i] && !d.cslot[t0 + i]) fl |= 1u << i;
+            if (t0 + i < m && d.btook[t0 + i] && !d.brepl[t0 + i]) fl |= 1u << i;
     }
     const uint32_t cnt = (uint32_t)__popc(fl);
     uint32_t incl = cnt;  // inclusive scan over the wave

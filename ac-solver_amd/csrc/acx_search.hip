@@ -84,6 +84,10 @@ template <typename W> struct Searcher {
             d.cpos = (uint32_t*)take(b, cap_cand * 4);
             d.clen = (uint8_t*)take(b, cap_cand);
             d.cknown = (uint8_t*)take(b, cap_cand);
+            if (inline_tab && !getenv("ACX_BFS_CLASSIC_COMMIT")) {  // one-pass BFS commit: byte flags
+                d.btook = take(b, cap_cand);
+                d.brepl = take(b, cap_cand);
+            }
             if (pass == 0 && arena_cand.alloc(o)) return ACX_E_NOMEM;
         }
         if (lean) {
