@@ -153,6 +153,8 @@ class HipShardEngine:
         counts = cnt.tolist()
         if max(counts) > cap:
             raise RuntimeError(f"rank {self.rank}: a send region overflowed ({max(counts)} > {cap} records)")
+        if world == 1:
+            return rec[:counts[0]], counts  # one region: already contiguous
         return torch.cat([rec[o * cap:o * cap + c] for o, c in enumerate(counts)]), counts
 
     def insert(self, recv, max_tag=None):
