@@ -87,6 +87,26 @@ def test_stats_match_oracle_node_counts(search):
             assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (kind, budget, st, wst)
 
 
+def test_bfs_budget_sweep_around_batch_and_tile_edges(search):
+    """Every small budget, and budgets around the tile size of the one-pass commit (2048 candidates) and the batch sizes:
+    node and expansion counts, result and path equal the oracle's (the budget cut is taken from the written nodes)."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search
+    from oracle import ac_oracle as O
+
+    ak3 = np.zeros(50, np.int8)
+    ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+    ak3[25:31] = [1, 2, 1, -2, -1, -2]
+    ak2 = np.array([1, 1, -2, -2, -2, 0, 0, 1, 2, 1, -2, -1, -2, 0], np.int8)
+    budgets = list(range(1, 140)) + list(range(2040, 2058)) + list(range(4090, 4104)) + list(range(12280, 12300, 3)) + [24575, 24576, 24577, 99999]
+    for pres, cyc in ((ak3, False), (ak3, True), (ak2, False)):
+        for budget in budgets:
+            ok, path, st = run_search(_acx.SEARCH_BFS, pres, budget, cyc)
+            wok, wpath, wst = O.bfs(pres, budget, cyclically_reduce_after_moves=cyc, stats=True)
+            assert (ok, path) == (wok, wpath), (cyc, budget)
+            assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (cyc, budget, st, wst)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("algo", ["greedy", "bfs"])
 def test_full_size_config3_ak3_budget_1e7_against_oracle(search, algo):
