@@ -99,7 +99,10 @@ def test_bfs_budget_sweep_around_batch_and_tile_edges(search):
     ak3[25:31] = [1, 2, 1, -2, -1, -2]
     ak2 = np.array([1, 1, -2, -2, -2, 0, 0, 1, 2, 1, -2, -1, -2, 0], np.int8)
     budgets = list(range(1, 140)) + list(range(2040, 2058)) + list(range(4090, 4104)) + list(range(12280, 12300, 3)) + [24575, 24576, 24577, 99999]
-    for pres, cyc in ((ak3, False), (ak3, True), (ak2, False)):
+    ak3w = np.zeros(72, np.int8)  # max_relator_length 36: 128-bit keys
+    ak3w[:7] = ak3[:7]
+    ak3w[36:42] = ak3[25:31]
+    for pres, cyc in ((ak3, False), (ak3, True), (ak2, False), (ak3w, False)):
         for budget in budgets:
             ok, path, st = run_search(_acx.SEARCH_BFS, pres, budget, cyc)
             wok, wpath, wst = O.bfs(pres, budget, cyclically_reduce_after_moves=cyc, stats=True)
