@@ -401,6 +401,7 @@ __global__ void __launch_bounds__(256) k_compact_tab(SearchDev<W> d, uint32_t pb
                                                      unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t* __restrict__ total_out) {
     __shared__ uint32_t s_tile, s_prefix, s_wsum[4];
     __shared__ uint16_t s_list[kCompactTile];
+    asm volatile("" ::: "v31");  // declare 32 VGPRs: the kernel needs exactly 24, the count of the k_expand build of DESIGN.md section 7 (free: 8 waves/SIMD either way)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();

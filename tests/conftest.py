@@ -32,6 +32,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """GPU runs: import torch before the first test.  On a fresh box the first `import torch` pages the whole image in
+    and can take minutes (three suite runs of round 1 sat in it for 5+ minutes, inside whichever test imported torch
+    first); done here it is charged to no test's timeout and shows up under its own name."""
+    expr = (session.config.getoption("markexpr", "") or "").replace(" ", "")
+    if "gpu" in expr and "notgpu" not in expr:
+        import time
+
+        t0 = time.time()
+        sys.stderr.write("[conftest] importing torch (first import on a fresh box can take minutes) ...\n")
+        sys.stderr.flush()
+        import torch  # noqa: F401
+
+        sys.stderr.write(f"[conftest] torch imported in {time.time() - t0:.1f} s\n")
+        sys.stderr.flush()
+
+
 def load_json(name):
     with open(os.path.join(GOLDEN, name)) as f:
         return json.load(f)
