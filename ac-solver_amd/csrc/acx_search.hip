@@ -13,7 +13,8 @@
 //     provisional stamp and equal keys fold with atomicMin; the full key of the occupant is always compared
 //     (exact set).  BFS: 32-byte entries with the key inline (acx_frontier.h, TabEntry); greedy: an id table
 //   * winners are numbered by an exclusive scan in tag order, which reproduces the reference's insertion
-//     order; the per-parent budget test (breadth_first.py:91-95) becomes "first parent whose cumulative
+//     order (BFS: inside k_compact_tab, which also writes the nodes -- one pass over the batch; the greedy
+//     batch-per-launch path: flag pass + rocprim scan + k_commit); the per-parent budget test (breadth_first.py:91-95) becomes "first parent whose cumulative
 //     winner count reaches the budget"; the solved test (:84-85) "minimum tag with total length 2"
 //   * greedy additionally stops a batch right after the first parent that inserts a NEW child shorter than
 //     the bucket (that child is the heap's next minimum); later parents stay queued
