@@ -46,6 +46,8 @@ _FLAGS = [
     ("--max-grad-norm", float, 0.5, "the maximum norm for gradient clipping"),
     ("--target-kl", float, 0.01, "the target KL divergence threshold"),
     ("--epsilon", float, 0.00001, "epsilon of the Adam optimizer"),
+    # not in the reference: lifts its `num_envs <= number of initial states` assert (agents/environment.py:80-83)
+    ("--tile-initial-states", "bool", False, "allow more environments than initial states: environment i starts from state i mod n"),
 ]
 
 

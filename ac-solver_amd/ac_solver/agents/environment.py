@@ -52,8 +52,10 @@ def make_env(presentation, args):
     return thunk
 
 
-def get_env(args, device=None):
-    """-> (envs, initial_states, curr_states, success_record, ACMoves_hist, states_processed)"""
+def get_env(args, device=None, rank=0, world=1):
+    """-> (envs, initial_states, curr_states, success_record, ACMoves_hist, states_processed)
+    One process per GPU (`rank` of `world`): the Miller-Schupp states are dealt rank::world, environment i of rank r
+    starts from state r + i * world, so the ranks together cover num_envs * world distinct states."""
     from ac_solver.envs.vec_env import ACVecEnv
 
     if args.use_supermoves:
@@ -65,12 +67,15 @@ def get_env(args, device=None):
         curr_states = [0] * args.num_envs
     else:
         initial_states = load_initial_states_from_text_file(states_type=args.states_type)
-        assert args.num_envs <= len(initial_states), \
-            "Expect number of environments to be less than number of distinct initial states for now"
+        n_states = len(initial_states)
+        if not getattr(args, "tile_initial_states", False):  # the reference's limit (environment.py:80-83)
+            assert args.num_envs * world <= n_states, \
+                "Expect number of environments to be less than number of distinct initial states for now"
         args.max_relator_length = 36  # max(4n + 2) over 1 <= n <= 7 (environment.py:87)
         initial_states = [change_max_relator_length_of_presentation(s, args.max_relator_length) for s in initial_states]
-        rows = np.asarray(initial_states[:args.num_envs], np.int8)
-        curr_states = list(range(args.num_envs))
+        # --tile-initial-states: more environments than states (BASELINE config 5: 131 072 per GPU) start from state i mod n
+        curr_states = [(rank + i * world) % n_states for i in range(args.num_envs)]
+        rows = np.asarray(initial_states, np.int8)[curr_states]
     clip = None
     if args.clip_rewards:
         assert args.min_rew < args.max_rew, "min_rew must be less than max_rew"

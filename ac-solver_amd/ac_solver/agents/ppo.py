@@ -37,7 +37,7 @@ def train_ppo(argv=None):
     torch.manual_seed(args.seed)
     torch.backends.cudnn.deterministic = args.torch_deterministic
 
-    envs, initial_states, curr_states, success_record, ACMoves_hist, states_processed = get_env(args, device=device)
+    envs, initial_states, curr_states, success_record, ACMoves_hist, states_processed = get_env(args, device=device, rank=rank, world=world)
     agent = Agent(envs, args.nodes_counts).to(device)
     if world > 1:  # identical initial weights on every rank
         for p in agent.parameters():

@@ -49,13 +49,15 @@ def compute_gae(rewards, values, dones, next_value, next_done, gamma, gae_lambda
     return advantages, advantages + values
 
 
-def choose_next_state(states_processed, n_states, success_record, round1_complete, repeat_solved_prob):
+def choose_next_state(states_processed, n_states, success_record, round1_complete, repeat_solved_prob, stride=1):
     """Curriculum step of the reference (training.py:199-221): first walk through the initial states in order; once
     every state has been started at least once, pick an unsolved state with probability 1 - repeat_solved_prob
-    (always, while nothing is solved), otherwise a solved one.  -> (next state index, round1_complete)"""
-    round1_complete = round1_complete or max(states_processed) == n_states - 1
+    (always, while nothing is solved), otherwise a solved one.  -> (next state index, round1_complete)
+    `stride` > 1 (data parallel, one process per GPU): the states are dealt rank::world, so a rank's first round walks its
+    own residue class and the ranks together start every state once."""
+    round1_complete = round1_complete or max(states_processed) + stride > n_states - 1
     if not round1_complete:
-        return max(states_processed) + 1, round1_complete
+        return max(states_processed) + stride, round1_complete
     if len(success_record["solved"]) == 0 or (success_record["unsolved"] and random.uniform(0, 1) > repeat_solved_prob):
         return random.choice(list(success_record["unsolved"])), round1_complete
     return random.choice(list(success_record["solved"])), round1_complete
@@ -86,6 +88,7 @@ class RunningReturnNormalizer:
 
 
 def _average_gradients(params, world):
+    """One all-reduce per minibatch over ONE flat bucket (the policy + critic are ~0.6 MB: a single RCCL call over xGMI)."""
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     torch.distributed.all_reduce(flat)
     flat /= world
@@ -94,6 +97,26 @@ def _average_gradients(params, world):
         n = p.numel()
         p.grad.copy_(flat[o:o + n].view_as(p.grad))
         o += n
+
+
+def _global_mean(x, world):
+    """Mean over the ranks of a scalar tensor: every rank must take the SAME early-stop / KL-penalty decision, or the
+    per-minibatch all-reduces of the ranks stop pairing up (the reference is single-process and has no such step)."""
+    y = x.detach().clone().reshape(1)
+    torch.distributed.all_reduce(y)
+    return (y / world)[0]
+
+
+def _share_success_record(success_record, n_states, device):
+    """Union of the ranks' solved sets (one all-reduce of an n_states mask per update): the curriculum of every rank
+    then samples from what ANY rank has solved."""
+    mask = torch.zeros(n_states, dtype=torch.int32, device=device)
+    if success_record["solved"]:
+        mask[torch.as_tensor(sorted(success_record["solved"]), device=device)] = 1
+    torch.distributed.all_reduce(mask, op=torch.distributed.ReduceOp.MAX)
+    solved = set(torch.nonzero(mask).flatten().tolist())
+    success_record["solved"] |= solved
+    success_record["unsolved"] -= solved
 
 
 def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success_record, ACMoves_hist, states_processed,
@@ -127,6 +150,9 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
     round1_complete = False
     beta = None if args.is_loss_clip else args.beta
     params = list(agent.parameters())
+    # data parallel: the Miller-Schupp states are dealt rank::world (get_env), so the first curriculum round of a rank
+    # walks its own residue class; a single fixed initial state has nothing to deal
+    stride = world if dist_on and world > 1 and len(initial_states) > 1 else 1
 
     run_name = f"{args.exp_name}_ppo-ffn-nodes_{args.nodes_counts}_{uuid.uuid4()}"
     out_dir = f"out/{run_name}"
@@ -193,7 +219,7 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
                 lengths_queue.append(len_h[k])
                 episode += 1
                 curr_states[i], round1_complete = choose_next_state(states_processed, len(initial_states), success_record,
-                                                                    round1_complete, args.repeat_solved_prob)
+                                                                    round1_complete, args.repeat_solved_prob, stride=stride)
                 states_processed.add(curr_states[i])
                 new_states.append(curr_states[i])
                 events.append((step, i, curr_states[i]))
@@ -258,11 +284,15 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
                     _average_gradients(params, world)
                 nn.utils.clip_grad_norm_(agent.parameters(), args.max_grad_norm)
                 optimizer.step()
+            if dist_on and world > 1:  # one decision for all ranks (see _global_mean)
+                approx_kl = _global_mean(approx_kl, world)
             if args.is_loss_clip:
                 if args.target_kl is not None and approx_kl > args.target_kl:
                     break
             else:
                 beta = beta / 2 if approx_kl < args.target_kl / 1.5 else (beta * 2 if approx_kl > args.target_kl * 1.5 else beta)
+        if dist_on and world > 1:
+            _share_success_record(success_record, len(initial_states), device)
 
         # the next rollout continues where this one stopped
         obs[0].copy_(obs[T])
@@ -284,6 +314,13 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
         }
         if wandb is not None:
             wandb.log(stats)
+        if update % 100 == 0 and dist_on and world > 1:  # the checkpoint holds the shortest solution any rank has found
+            gathered = [None] * world
+            torch.distributed.all_gather_object(gathered, ACMoves_hist)
+            for other in gathered:
+                for s_idx, moves in other.items():
+                    if s_idx not in ACMoves_hist or len(moves) < len(ACMoves_hist[s_idx]):
+                        ACMoves_hist[s_idx] = moves
         if update % 100 == 0 and rank == 0:  # a checkpoint every 100 updates (training.py:384-408)
             makedirs(out_dir, exist_ok=True)
             checkpoint = {

@@ -57,8 +57,10 @@ template <> struct alignas(64) TabEntry<u128> {
 constexpr unsigned long long kStampEmpty = ~0ull;
 
 template <typename W> struct SearchDev {
-    TabEntry<W>* tab;  // BFS visited table (inline keys); tmask = entries - 1
+    TabEntry<W>* tab;  // sharded BFS visited table (inline keys); tmask = entries - 1
     uint32_t tmask;
+    unsigned long long* stab;  // fused single-GPU BFS: stamp table (acx_bfs.h); stmask = slots - 1
+    uint32_t stmask;
     // node arena (committed nodes, id order == the reference's insertion order)
     W* k0;
     W* k1;
@@ -526,7 +528,7 @@ __global__ void k_decide_tab(SearchDev<W> d, uint32_t m, uint32_t np, uint32_t p
     out->budget_hit = budget_hit;
     out->solved = is_solved;
     out->solved_tag = (uint32_t)solved_tag;
-    out->last_child_len = d.clen[12u * p_end + 11];
+    out->last_child_len = d.clen ? d.clen[12u * p_end + 11] : 0u;  // only greedy_search returns it (greedy.py:121)
     const unsigned long long et = *d.err_tag;
     const bool err_hit = et != kNoTag && (uint32_t)((et >> 8) / 12) <= p_end && !(is_solved && solved_tag < (et >> 8));
     out->err = err_hit ? (uint32_t)(et & 0xff) : 0u;

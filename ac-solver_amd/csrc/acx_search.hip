@@ -22,6 +22,7 @@
 // Keys: a relator word and its length share one machine word (length in the top 6 bits):
 // W = u64 for L <= 29, u128 for L <= 61.  Roofline: HBM (random table probes); see DESIGN.md.
 #include "acx_frontier.h"
+#include "acx_bfs.h"
 #include "acx_greedy.h"
 
 namespace acx {
@@ -43,9 +44,10 @@ template <typename W> struct Searcher {
         if (st) (void)hipStreamDestroy(st);
     }
 
-    // inline_tab: BFS visited table with inline keys (TabEntry); otherwise the id table of the greedy paths
+    // inline_tab: BFS visited table with inline keys (TabEntry, round 1; kept for A/B runs: ACX_BFS_INLINE_TAB=1);
+    // stamp_tab: the 8-byte stamp table of acx_bfs.h (no candidate keys at all); otherwise the id table of the greedy paths
     // lean: no key arrays and no table (the persistent greedy frontier keeps its own: GreedyDev::nkeys / tab)
-    int init(int L, int cyclical, int64_t max_nodes, uint32_t batch_parents, bool greedy, bool inline_tab = false, bool lean = false) {
+    int init(int L, int cyclical, int64_t max_nodes, uint32_t batch_parents, bool greedy, bool inline_tab = false, bool lean = false, bool stamp_tab = false) {
         memset(&d, 0, sizeof(d));
         // every search owns a stream, so that searches driven from different host threads overlap on the GPU
         ACX_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -78,22 +80,28 @@ template <typename W> struct Searcher {
         for (int pass = 0; pass < 2; pass++) {
             uint8_t* b = (uint8_t*)arena_cand.p;
             o = 0;
-            d.ck0 = (W*)take(b, cap_cand * sizeof(W));
-            d.ck1 = (W*)take(b, cap_cand * sizeof(W));
-            d.cslot = (uint32_t*)take(b, cap_cand * 4);
-            d.cflag = (uint32_t*)take(b, cap_cand * 4);
-            d.cpos = (uint32_t*)take(b, cap_cand * 4);
-            d.clen = (uint8_t*)take(b, cap_cand);
-            d.cknown = (uint8_t*)take(b, cap_cand);
-            if (inline_tab && !getenv("ACX_BFS_CLASSIC_COMMIT")) {  // one-pass BFS commit: byte flags
-                d.btook = take(b, cap_cand);
-                d.brepl = take(b, cap_cand);
+            if (!stamp_tab) {
+                d.ck0 = (W*)take(b, cap_cand * sizeof(W));
+                d.ck1 = (W*)take(b, cap_cand * sizeof(W));
+                d.cslot = (uint32_t*)take(b, cap_cand * 4);
+                d.cflag = (uint32_t*)take(b, cap_cand * 4);
+                d.cpos = (uint32_t*)take(b, cap_cand * 4);
+                d.clen = (uint8_t*)take(b, cap_cand);
+                d.cknown = (uint8_t*)take(b, cap_cand);
+            }
+            if (stamp_tab || (inline_tab && !getenv("ACX_BFS_CLASSIC_COMMIT"))) {  // one-pass BFS commit: byte flags
+                d.btook = take(b, cap_cand + 8);
+                d.brepl = take(b, cap_cand + 8);
             }
             if (pass == 0 && arena_cand.alloc(o)) return ACX_E_NOMEM;
         }
         if (lean) {
             d.tab = nullptr;
             d.slots = nullptr;
+        } else if (stamp_tab) {
+            if (arena_tab.alloc(n_slots * 8)) return ACX_E_NOMEM;
+            d.stab = (unsigned long long*)arena_tab.p;
+            d.stmask = (uint32_t)(n_slots - 1);
         } else if (inline_tab) {
             if (arena_tab.alloc(n_slots * sizeof(TabEntry<W>))) return ACX_E_NOMEM;
             d.tab = (TabEntry<W>*)arena_tab.p;
@@ -121,19 +129,20 @@ template <typename W> struct Searcher {
         d.min_len = (uint32_t*)(sc + 28);
         if (arena_list.alloc(std::max<uint64_t>(batch_parents, 1024) * 4 * 2)) return ACX_E_NOMEM;
         if (arena_path.alloc(8)) return ACX_E_NOMEM;
-        // rocprim temporary storage for the scan over one batch
-        size_t need = 0;
-        if (rocprim::exclusive_scan(nullptr, need, d.cflag, d.cpos, 0u, cap_cand, rocprim::plus<uint32_t>(), st) != hipSuccess)
-            return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan sizing failed");
-        tmp_bytes = need + 256;
-        if (arena_tmp.alloc(tmp_bytes)) return ACX_E_NOMEM;
-        if (!lean) ACX_HIP_TRY(hipMemsetAsync(arena_tab.p, 0xff, n_slots * (inline_tab ? sizeof(TabEntry<W>) : 4), st));
+        if (!stamp_tab) {  // rocprim temporary storage for the scan over one batch
+            size_t need = 0;
+            if (rocprim::exclusive_scan(nullptr, need, d.cflag, d.cpos, 0u, cap_cand, rocprim::plus<uint32_t>(), st) != hipSuccess)
+                return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan sizing failed");
+            tmp_bytes = need + 256;
+            if (arena_tmp.alloc(tmp_bytes)) return ACX_E_NOMEM;
+        }
+        if (!lean) ACX_HIP_TRY(hipMemsetAsync(arena_tab.p, 0xff, n_slots * (stamp_tab ? 8 : inline_tab ? sizeof(TabEntry<W>) : 4), st));
         ACX_HIP_TRY(hipMemsetAsync(arena_scal.p, 0xff, 256, st));
         ACX_HIP_TRY(hipMemsetAsync(d.err, 0, 4, st));
         d_ticket = (uint32_t*)(sc + 128);
         d_total = (uint32_t*)(sc + 132);
         ACX_HIP_TRY(hipMemsetAsync(d_ticket, 0, 8, st));
-        if (inline_tab) {  // status words of k_compact_tab: epoch 0 = never written
+        if (inline_tab || stamp_tab) {  // status words of k_compact_tab / k_bfs_compact: epoch 0 = never written
             const size_t tiles = cap_cand / kCompactTile + 2;
             if (arena_status.alloc(tiles * 8)) return ACX_E_NOMEM;
             d_status = (unsigned long long*)arena_status.p;
@@ -445,8 +454,10 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
     // (every new key of a batch claims an entry, committed or not), so it is tied to the budget
     const uint32_t bmax = greedy ? (uint32_t)std::min<int64_t>(std::max<int64_t>(max_nodes, 1024), 1 << 14)
                                  : (uint32_t)std::min<int64_t>(std::max<int64_t>(max_nodes / 4, 1024), 1 << 20);
+    // BFS: the stamp table of acx_bfs.h; ACX_BFS_INLINE_TAB=1 selects round 1's inline-key table (A/B measurements)
+    const bool stamp = !greedy && !getenv("ACX_BFS_INLINE_TAB") && !getenv("ACX_BFS_CLASSIC_COMMIT");
     Searcher<W> S;
-    int rc = S.init(L, cyclical, max_nodes, bmax, greedy, !greedy);
+    int rc = S.init(L, cyclical, max_nodes, bmax, greedy, !greedy && !stamp, false, stamp);
     if (rc) return rc;
     SearchDev<W>& d = S.d;
     hipStream_t st = S.st;
@@ -457,6 +468,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
 
     const uint32_t tl0 = (uint32_t)(root.n0 + root.n1);
     if (greedy) hipLaunchKernelGGL(k_root<W>, dim3(1), dim3(1), 0, st, d, keyops<W>::make(root.w0, root.n0), keyops<W>::make(root.w1, root.n1), tl0);
+    else if (stamp) hipLaunchKernelGGL(k_bfs_root<W>, dim3(1), dim3(1), 0, st, d, keyops<W>::make(root.w0, root.n0), keyops<W>::make(root.w1, root.n1), tl0);
     else hipLaunchKernelGGL(k_root_tab<W>, dim3(1), dim3(1), 0, st, d, keyops<W>::make(root.w0, root.n0), keyops<W>::make(root.w1, root.n1), tl0);
     uint64_t nodes = 1, expanded = 0, batches = 0;
     uint32_t min_len = tl0;
@@ -534,6 +546,15 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         // ---- expand, dedup with min-tag resolution, number the winners, decide -- all on the stream --------
         rc = S.reset_batch_scalars();
         if (rc) return rc;
+        if (batches >= (1ull << 30)) return fail(ACX_E_CAPACITY, "acx_search: more than 2^30 batches (the look-back words carry a 30-bit batch number)");
+        if (stamp) {
+            // expand + dedup in one kernel, winners -> nodes in one pass, then the decision from the written nodes
+            ACX_HIP_TRY(hipMemsetAsync(d.brepl, 0, m, st));
+            hipLaunchKernelGGL(k_bfs_expand_insert<W>, dim3((m + kBfsBlock - 1) / kBfsBlock), dim3(kBfsBlock), 0, st, d, pbegin, np);
+            hipLaunchKernelGGL(k_bfs_compact<W>, dim3((m + kCompactTile - 1) / kCompactTile), block, 0, st, d, pbegin, m, (uint32_t)nodes, (uint32_t)S.cap_nodes,
+                               (uint32_t)batches, S.d_status, S.d_ticket, S.d_total);
+            hipLaunchKernelGGL(k_decide_tab<W>, dim3(1), dim3(1), 0, st, d, m, np, pbegin, (uint32_t)nodes, (uint32_t)S.cap_nodes, (long long)max_nodes, S.d_total, S.d_dec);
+        } else {
         hipLaunchKernelGGL(k_expand<W>, grid, block, 0, st, d, plist, pbegin, np);
         if (greedy) {
             // batch-local table sized for this batch (only its used prefix is cleared)
@@ -558,6 +579,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
                 return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan failed");
             hipLaunchKernelGGL(k_decide<W>, dim3(1), dim3(1), 0, st, d, m, np, (unsigned long long)nodes, (long long)max_nodes, greedy ? 1 : 0, S.d_dec);
             hipLaunchKernelGGL(k_commit<W>, grid, block, 0, st, d, plist, pbegin, S.d_dec, m, (uint32_t)nodes, greedy ? 1 : 0);
+        }
         }
         ACX_HIP_TRY(hipGetLastError());
         // one read-back: the decision and (greedy) the total lengths of the nodes this batch may have created
