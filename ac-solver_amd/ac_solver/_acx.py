@@ -78,15 +78,15 @@ SIGNATURES = {
     "acx_simplify_relators": (C.c_int, [_i8p, C.c_int64, C.c_int, C.c_int, _i8p, _i32p, _u8p]),
     "acx_env_create": (_vp, [C.c_int64, C.c_int, C.c_int64, C.c_int]),
     "acx_env_destroy": (None, [_vp]),
-    "acx_env_set_initial": (C.c_int, [_vp, _i8p, _i64p, C.c_int64]),
-    "acx_env_reset": (C.c_int, [_vp, _i8p, _i64p, C.c_int64]),
+    "acx_env_set_initial": (C.c_int, [_vp, _i8p, _i64p, C.c_int64, _vp]),
+    "acx_env_reset": (C.c_int, [_vp, _i8p, _i64p, C.c_int64, _vp]),
     "acx_env_step": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_float, C.c_float, _vp, _vp, _vp, C.c_int, _vp]),
     "acx_env_step_host": (C.c_int, [_vp, _i64p, _i8p, _f32p, _u8p, _u8p, _i8p, C.c_int]),
     "acx_env_rollout": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_float, C.c_float, _vp, _vp, C.c_int, _vp]),
     "acx_env_observe": (C.c_int, [_vp, _vp, C.c_int, _vp]),
-    "acx_env_get": (C.c_int, [_vp, _i64p, C.c_int64, _i8p, _i32p, _i32p]),
-    "acx_env_get_actions": (C.c_int, [_vp, C.c_int64, C.c_int, _i32p, C.c_int64, _i64p]),
-    "acx_env_get_errors": (C.c_int, [_vp, _u8p, C.c_int]),
+    "acx_env_get": (C.c_int, [_vp, _i64p, C.c_int64, _i8p, _i32p, _i32p, _vp]),
+    "acx_env_get_actions": (C.c_int, [_vp, C.c_int64, C.c_int, _i32p, C.c_int64, _i64p, _vp]),
+    "acx_env_get_errors": (C.c_int, [_vp, _u8p, C.c_int, _vp]),
     "acx_env_max_reward": (C.c_int64, [_vp]),
     "acx_search_many": (C.c_int, [C.c_int, _i8p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, _i32p, _i32p, _i32p, C.c_int64, _i64p,
                                C.POINTER(SearchStats), _i32p]),
@@ -96,6 +96,8 @@ SIGNATURES = {
     "acx_shard_root_record": (C.c_int, [_vp, _i8p, _i64p]),
     "acx_shard_expand": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "acx_release_cached_memory": (C.c_int, []),
+    "acx_search_digest_enable": (C.c_int, [C.c_int]),
+    "acx_search_last_digest": (C.c_int, [C.POINTER(C.c_uint64)]),
     "acx_simplex_graph": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, _i64p, _u8p, _i64p, C.POINTER(C.c_uint32), _u8p]),
     "acx_ball_sizes": (C.c_int, [_i8p, C.c_int64, C.c_int, C.c_int, C.c_int, _i64p, C.POINTER(C.c_int32)]),
     "acx_shard_expand_routed": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp]),

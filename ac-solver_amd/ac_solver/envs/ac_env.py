@@ -93,7 +93,7 @@ class ACEnv(Env):
         self._dtype = self.initial_state.dtype
         self._h = _Handle(1, L, self.horizon_length, 0)
         row = _acx.as_i8_rows(self.initial_state.reshape(1, -1))
-        _acx.check(_acx.lib.acx_env_set_initial(self._h.ptr, _acx.ptr(row, C.c_int8), None, 1), "acx_env_set_initial")
+        _acx.check(_acx.lib.acx_env_set_initial(self._h.ptr, _acx.ptr(row, C.c_int8), None, 1, None), "acx_env_set_initial")
         self.state = np.copy(self.initial_state)
         self.count_steps = 0
         self.lengths = [int(np.count_nonzero(self.state[:L])), int(np.count_nonzero(self.state[L:]))]
@@ -111,7 +111,7 @@ class ACEnv(Env):
         _acx.check(_acx.lib.acx_env_step_host(self._h.ptr, _acx.ptr(act, C.c_int64), _acx.ptr(obs, C.c_int8), _acx.ptr(rew, C.c_float),
                                               _acx.ptr(done, C.c_uint8), _acx.ptr(trunc, C.c_uint8), None, 0), "acx_env_step_host")
         err = np.empty(1, np.uint8)
-        _acx.check(_acx.lib.acx_env_get_errors(self._h.ptr, _acx.ptr(err, C.c_uint8), 1))
+        _acx.check(_acx.lib.acx_env_get_errors(self._h.ptr, _acx.ptr(err, C.c_uint8), 1, None))
         if err[0]:
             # the reference's ACMove raised before state/lengths/count_steps were touched (ac_env.py:97);
             # the kernel left the device state and counter untouched as well
@@ -129,7 +129,7 @@ class ACEnv(Env):
         start = options["starting_state"] if options and "starting_state" in options else self.initial_state
         self.state = np.copy(start)
         row = _acx.as_i8_rows(np.asarray(self.state).reshape(1, -1))
-        _acx.check(_acx.lib.acx_env_reset(self._h.ptr, _acx.ptr(row, C.c_int8), None, 1), "acx_env_reset")
+        _acx.check(_acx.lib.acx_env_reset(self._h.ptr, _acx.ptr(row, C.c_int8), None, 1, None), "acx_env_reset")
         self.lengths = [int(np.count_nonzero(self.state[:L])), int(np.count_nonzero(self.state[L:]))]
         self.count_steps = 0
         self.actions = []

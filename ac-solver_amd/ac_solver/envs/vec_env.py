@@ -109,7 +109,7 @@ class ACVecEnv:
         with torch.cuda.device(self.device):
             self._h = _Handle(self.num_envs, L, self.horizon_length, _acx.ENV_RECORD_ACTIONS if record_actions else 0)
             rows = _acx.as_i8_rows(states)
-            _acx.check(_acx.lib.acx_env_set_initial(self._h.ptr, _acx.ptr(rows, C.c_int8), None, self.num_envs), "acx_env_set_initial")
+            _acx.check(_acx.lib.acx_env_set_initial(self._h.ptr, _acx.ptr(rows, C.c_int8), None, self.num_envs, None), "acx_env_set_initial")
         self.initial_states = rows
         self.envs = _EnvList(self)
         n = self.num_envs
@@ -138,7 +138,7 @@ class ACVecEnv:
 
     def _raise_on_errors(self):
         err = np.empty(self.num_envs, np.uint8)
-        _acx.check(_acx.lib.acx_env_get_errors(self._h.ptr, _acx.ptr(err, C.c_uint8), 1))
+        _acx.check(_acx.lib.acx_env_get_errors(self._h.ptr, _acx.ptr(err, C.c_uint8), 1, self._stream()))
         if err.any():
             i = int(np.flatnonzero(err)[0])
             raise (IndexError if err[i] == _acx.ERR_INDEX else AssertionError)(
@@ -147,7 +147,7 @@ class ACVecEnv:
     # ------------------------------------------------------------------ gymnasium-style surface
     def reset(self, *, seed=None, options=None):
         """All envs back to their initial states.  -> (obs tensor [n, 2L], {})"""
-        _acx.check(_acx.lib.acx_env_reset(self._h.ptr, None, None, self.num_envs), "acx_env_reset")
+        _acx.check(_acx.lib.acx_env_reset(self._h.ptr, None, None, self.num_envs, self._stream()), "acx_env_reset")
         return self.observe(), {}
 
     def observe(self, out=None):
@@ -196,8 +196,8 @@ class ACVecEnv:
         """ACEnv.reset for some envs: states None -> initial state, else options={'starting_state': row}."""
         idx = np.ascontiguousarray(indices, np.int64)
         rows = None if states is None else _acx.as_i8_rows(states)
-        _acx.check(_acx.lib.acx_env_reset(self._h.ptr, None if rows is None else _acx.ptr(rows, C.c_int8), _acx.ptr(idx, C.c_int64), len(idx)),
-                   "acx_env_reset")
+        _acx.check(_acx.lib.acx_env_reset(self._h.ptr, None if rows is None else _acx.ptr(rows, C.c_int8), _acx.ptr(idx, C.c_int64), len(idx),
+                                          self._stream()), "acx_env_reset")
 
     def _get(self, indices):
         idx = np.ascontiguousarray(np.arange(self.num_envs) if indices is None else indices, np.int64)
@@ -205,7 +205,7 @@ class ACVecEnv:
         ln = np.empty((len(idx), 2), np.int32)
         ct = np.empty(len(idx), np.int32)
         _acx.check(_acx.lib.acx_env_get(self._h.ptr, _acx.ptr(idx, C.c_int64), len(idx), _acx.ptr(st, C.c_int8), _acx.ptr(ln, C.c_int32),
-                                        _acx.ptr(ct, C.c_int32)), "acx_env_get")
+                                        _acx.ptr(ct, C.c_int32), self._stream()), "acx_env_get")
         return st, ln, ct
 
     def get_states(self, indices=None):
@@ -222,5 +222,6 @@ class ACVecEnv:
         cap = max(self.horizon_length, 16)
         buf = np.empty(cap, np.int32)
         n = C.c_int64()
-        _acx.check(_acx.lib.acx_env_get_actions(self._h.ptr, i, int(finished), _acx.ptr(buf, C.c_int32), cap, C.byref(n)), "acx_env_get_actions")
+        _acx.check(_acx.lib.acx_env_get_actions(self._h.ptr, i, int(finished), _acx.ptr(buf, C.c_int32), cap, C.byref(n), self._stream()),
+                   "acx_env_get_actions")
         return buf[: n.value].tolist()

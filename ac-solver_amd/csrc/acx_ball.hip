@@ -242,6 +242,7 @@ struct Job {
 };
 
 __global__ void __launch_bounds__(kThreads) k_ball(Job* jobs) {
+    ACX_VGPR_PAD("v87");
     __shared__ Job J;  // this workgroup's job (pointers, capacities, root)
     __shared__ uint32_t s_next, s_status, s_maxlen, s_count;
     const uint32_t tid = threadIdx.x;

@@ -18,9 +18,9 @@
 //     equal keys is a 64-bit atomicMin on the slot, as before.  No epochs, no commit pass.
 //   * expand and insert are ONE kernel: the child never travels through a candidate arena (16 B written + 16 B read
 //     per child before); k_bfs_compact recomputes the winners' keys the same way.
-//   * children equal to their parent or to their GRANDPARENT are dropped before any probe (both are visited by
-//     construction), and a 1024-candidate workgroup first folds its own duplicates in an LDS table: only the smallest
-//     tag of each key inside the tile goes to the global table.
+//   * children equal to their parent are dropped before any probe (visited by construction), and a workgroup first
+//     folds the duplicates among its own 256 candidates in an LDS table: only the smallest tag of each key inside the
+//     tile goes to the global table.
 //
 // Visibility across the eight non-coherent L2s: as in round 1, only the returned values of the device-scope CAS /
 // atomicMin decide; a plain (possibly stale) load of a slot can only show an older state of the same slot, which the
@@ -32,31 +32,44 @@ namespace acx {
 
 constexpr unsigned long long kSlotFree = ~0ull;
 constexpr uint32_t kSelfAction = 15u;  // slot names the node itself (the root)
-constexpr int kBfsBlock = 1024;        // lanes = candidates per workgroup tile (85 parents)
-constexpr int kBfsLdsSlots = 2048;
-
-// Every kernel that inlines apply_move declares at least 32 VGPRs (see DESIGN.md "24-VGPR hazard"): an empty asm that
-// names v31 as clobbered raises the kernel descriptor's count without costing an instruction or occupancy.
-#define ACX_MIN_VGPRS_32() asm volatile("" ::: "v31")
+#ifndef ACX_BFS_BLOCK
+#define ACX_BFS_BLOCK 256
+#endif
+// lanes = candidates per workgroup tile.  Measured on the 1e8-node AK(3) search: 1024 lanes (85 parents, folds 55 % of the
+// in-batch duplicates in LDS) 14.0 ms, 512 13.2, 256 (21 parents, 40 %) 12.8, 128 13.0, 64 13.0 -- the wider tile's extra
+// folds do not pay for sixteen waves meeting at two barriers.
+constexpr int kBfsBlock = ACX_BFS_BLOCK;
+constexpr int kBfsLdsSlots = 2 * kBfsBlock;
 
 ACX_HD unsigned long long slot_make(uint64_t hk, uint32_t pid, uint32_t act) { return (hk & ~((1ull << 36) - 1)) | ((unsigned long long)pid << 4) | act; }
 ACX_HD uint32_t slot_parent(unsigned long long s) { return (uint32_t)(s >> 4); }
 ACX_HD uint32_t slot_action(unsigned long long s) { return (uint32_t)s & 15u; }
 
+// The move code of the BFS kernels.  MODE 0: the general ACMove (apply_move) -- needed when the ROOT is not in normal form
+// (unreduced input: its children can even have an empty relator, utils.py:261-278).  With a root in normal form every node
+// of the search is, and the kernels run the shorter apply_move_nf: MODE 1 for cyclical = False, MODE 2 for cyclical = True.
+enum : int { kMoveGeneral = 0, kMoveNf = 1, kMoveNfCyclical = 2 };
+template <typename W, int MODE> __device__ __forceinline__ int search_move(Pres<W>& s, int a, int L, bool cyclical) {
+    if (MODE == kMoveNf) return apply_move_nf<W, kSearchSafe>(s, a, L, false);
+    if (MODE == kMoveNfCyclical) return apply_move_nf<W, kSearchSafe>(s, a, L, true);
+    return apply_move<W, kSearchSafe>(s, a, L, cyclical);
+}
+
 // key of the state a slot names: child `act` of node `pid` (or the node itself)
-template <typename W> __device__ __forceinline__ void slot_key(const SearchDev<W>& d, uint32_t pid, uint32_t act, W& q0, W& q1) {
+template <typename W, int MODE> __device__ __forceinline__ void slot_key(const SearchDev<W>& d, uint32_t pid, uint32_t act, W& q0, W& q1) {
     q0 = d.k0[pid];
     q1 = d.k1[pid];
     if (act != kSelfAction) {
         Pres<W> s;
         key_to_pres<W>(q0, q1, s);
-        (void)apply_move<W, kSearchSafe>(s, (int)act, d.L, d.cyclical != 0);
+        (void)search_move<W, MODE>(s, (int)act, d.L, d.cyclical != 0);
         q0 = keyops<W>::make(s.w0, s.n0);
         q1 = keyops<W>::make(s.w1, s.n1);
     }
 }
 
 template <typename W> __global__ void k_bfs_root(SearchDev<W> d, W k0, W k1, uint32_t tl) {
+    ACX_VGPR_PAD("v15");
     d.k0[0] = k0;
     d.k1[0] = k1;
     d.parent[0] = kEmpty;
@@ -64,17 +77,21 @@ template <typename W> __global__ void k_bfs_root(SearchDev<W> d, W k0, W k1, uin
     d.tlen[0] = (uint8_t)tl;
     d.depth[0] = 0;
     const uint64_t hk = hash_key<W>(k0, k1);
-    d.stab[(uint32_t)hk & d.stmask] = slot_make(hk, 0u, kSelfAction);
+    d.stab[(uint32_t)hk & d.stmask & ~3u] = slot_make(hk, 0u, kSelfAction);  // first slot of its bucket
 }
 
 // one lane per (parent, action): tag t = 12 * p + a.  btook[t] = 1 when t took its slot (claimed it free, or replaced a
 // larger tag of the same key); brepl[tag] = 1 is set for a holder that was replaced (brepl is zero on entry).
-template <typename W>
-__global__ void __launch_bounds__(kBfsBlock, 8) k_bfs_expand_insert(SearchDev<W> d, uint32_t pbegin, uint32_t np) {
+template <typename W, int MODE>
+__global__ void __launch_bounds__(kBfsBlock, (sizeof(W) == 8 && MODE != kMoveGeneral) ? 8 : 4) k_bfs_expand_insert(SearchDev<W> d, uint32_t pbegin, uint32_t np) {
     __shared__ W s_k0[kBfsBlock];
     __shared__ W s_k1[kBfsBlock];
     __shared__ uint32_t s_slot[kBfsLdsSlots];
-    ACX_MIN_VGPRS_32();
+    if (MODE == kMoveGeneral) {
+        ACX_VGPR_PAD_W(W, "v71", "v95");
+    } else {
+        ACX_VGPR_PAD_W(W, "v63", "v95");
+    }
     const uint32_t tid = threadIdx.x;
     const uint32_t t = blockIdx.x * kBfsBlock + tid;
     const uint32_t m = 12u * np;
@@ -88,18 +105,39 @@ __global__ void __launch_bounds__(kBfsBlock, 8) k_bfs_expand_insert(SearchDev<W>
         a = t - 12u * p;
         pid = pbegin + p;
         const W pk0 = d.k0[pid], pk1 = d.k1[pid];
+#ifdef ACX_BFS_GRANDPARENT
         const uint32_t gp = d.parent[pid];
+#endif
         Pres<W> s;
         key_to_pres<W>(pk0, pk1, s);
-        const int e = apply_move<W, kSearchSafe>(s, (int)a, d.L, d.cyclical != 0);
+        const int e = search_move<W, MODE>(s, (int)a, d.L, d.cyclical != 0);
         // the reference's ACMove raises here -- but only if it gets this far (k_decide_tab): the FIRST such move of the batch counts
         if (e) atomicMin(d.err_tag, ((unsigned long long)t << 8) | (unsigned long long)e);
         c0 = keyops<W>::make(s.w0, s.n0);
         c1 = keyops<W>::make(s.w1, s.n1);
+#ifdef ACX_BFS_CHECK_NF
+        {
+            Pres<W> g;
+            key_to_pres<W>(pk0, pk1, g);
+            const int eg = apply_move<W, kSearchSafe>(g, (int)a, d.L, d.cyclical != 0);
+            Pres<W> par;
+            key_to_pres<W>(pk0, pk1, par);
+            if (!is_normal_form<W>(par, d.cyclical != 0)) {
+                if (a == 0) printf("EXPAND: parent %u not in normal form: %llx %llx (node parent %u act %u)\n", pid, (unsigned long long)pk0, (unsigned long long)pk1, d.parent[pid], (unsigned)d.act[pid]);
+            } else if (eg != e || keyops<W>::make(g.w0, g.n0) != c0 || keyops<W>::make(g.w1, g.n1) != c1)
+                printf("NF MISMATCH pid %u a %u pk %llx %llx nf %llx %llx (e %d) general %llx %llx (e %d)\n", pid, a, (unsigned long long)pk0, (unsigned long long)pk1,
+                       (unsigned long long)c0, (unsigned long long)c1, e, (unsigned long long)keyops<W>::make(g.w0, g.n0), (unsigned long long)keyops<W>::make(g.w1, g.n1), eg);
+        }
+#endif
         tl = (uint32_t)(s.n0 + s.n1);
         if (tl == 2) atomicMin(d.solved_tag, (unsigned long long)t);  // breadth_first.py:84: tested before the dedup
         probe = !(c0 == pk0 && c1 == pk1);                            // unchanged state = its (visited) parent
-        if (probe && gp != kEmpty) probe = !(d.k0[gp] == c0 && d.k1[gp] == c1);  // back to the (visited) grandparent
+#ifdef ACX_BFS_GRANDPARENT
+        // 8 % of all children undo the move that made their parent.  Testing for it here (two dependent loads in front of the
+        // barrier, for every lane) measured 0.4 ms SLOWER per 1e8-node search than letting those children find the
+        // grandparent's slot in the table, so it is off.
+        if (probe && gp != kEmpty) probe = !(d.k0[gp] == c0 && d.k1[gp] == c1);
+#endif
     }
     {  // smallest total length of the batch: wave minimum, then one atomic per wave that lowers it
         uint32_t mn = tl;
@@ -131,36 +169,52 @@ __global__ void __launch_bounds__(kBfsBlock, 8) k_bfs_expand_insert(SearchDev<W>
     uint32_t took = 0;
     if (probe && s_slot[ls] == tid) {
         // ---- the global stamp table ------------------------------------------------------------------------------------
+        // Slots are probed a BUCKET at a time: four slots = one aligned 32-byte sector = one memory access.  A key lives in
+        // the first slot that was free in scan order (bucket of its hash from slot 0, then the following buckets), so a later
+        // probe meets it before it meets a free slot.  With one slot per step nearly every wave had a lane that needed a
+        // second or third dependent (load, CAS) round trip; with buckets the first load almost always decides.
         const unsigned long long me = slot_make(hk, pid, a);
-        uint32_t h = (uint32_t)hk & d.stmask, probes = 0;
-        for (;;) {
-            unsigned long long st = d.stab[h];
-            if (st == kSlotFree) {
-                st = atomicCAS(&d.stab[h], kSlotFree, me);
+        uint32_t base = (uint32_t)hk & d.stmask & ~3u, probes = 0;
+        bool open = true;
+        while (open) {
+            const ulonglong2 lo = *(const ulonglong2*)(d.stab + base), hi = *(const ulonglong2*)(d.stab + base + 2);
+            const unsigned long long v0 = lo.x, v1 = lo.y, v2 = hi.x, v3 = hi.y;
+            auto hot = [&](unsigned long long v) { return v == kSlotFree || (v >> 36) == (me >> 36); };  // free, or my fingerprint
+            uint32_t cand = (hot(v0) ? 1u : 0u) | (hot(v1) ? 2u : 0u) | (hot(v2) ? 4u : 0u) | (hot(v3) ? 8u : 0u);
+            while (cand) {
+                const uint32_t j = (uint32_t)__builtin_ctz(cand);
+                cand &= cand - 1;
+                unsigned long long st = j == 0 ? v0 : (j == 1 ? v1 : (j == 2 ? v2 : v3));
+                unsigned long long* slot = d.stab + base + j;
                 if (st == kSlotFree) {
-                    took = 1;
-                    break;
-                }
-            }
-            if ((st >> 36) == (me >> 36)) {  // fingerprint match: rebuild the occupant's key
-                const uint32_t hp = slot_parent(st), ha = slot_action(st);
-                W q0, q1;
-                slot_key<W>(d, hp, ha, q0, q1);
-                if (q0 == c0 && q1 == c1) {
-                    if (hp >= pbegin && ha != kSelfAction && st > me) {  // a candidate of this batch with a larger tag
-                        const unsigned long long prev = atomicMin(&d.stab[h], me);
-                        if (prev > me) {
-                            took = 1;
-                            d.brepl[12u * (slot_parent(prev) - pbegin) + slot_action(prev)] = 1;  // no longer the first discoverer
-                        }
+                    st = atomicCAS(slot, kSlotFree, me);
+                    if (st == kSlotFree) {
+                        took = 1;
+                        open = false;
+                        break;
                     }
-                    break;
+                }
+                if ((st >> 36) == (me >> 36)) {  // fingerprint match: rebuild the occupant's key
+                    const uint32_t hp = slot_parent(st), ha = slot_action(st);
+                    W q0, q1;
+                    slot_key<W, MODE>(d, hp, ha, q0, q1);
+                    if (q0 == c0 && q1 == c1) {
+                        if (hp >= pbegin && ha != kSelfAction && st > me) {  // a candidate of this batch with a larger tag
+                            const unsigned long long prev = atomicMin(slot, me);
+                            if (prev > me) {
+                                took = 1;
+                                d.brepl[12u * (slot_parent(prev) - pbegin) + slot_action(prev)] = 1;  // no longer the first discoverer
+                            }
+                        }
+                        open = false;
+                        break;
+                    }
                 }
             }
-            h = (h + 1) & d.stmask;
-            if (++probes > d.stmask) {
+            base = (base + 4) & d.stmask;
+            if (open && ++probes > d.stmask / 4) {
                 atomicOr(d.err, kErrTableFull);
-                break;
+                open = false;
             }
         }
     }
@@ -168,12 +222,16 @@ __global__ void __launch_bounds__(kBfsBlock, 8) k_bfs_expand_insert(SearchDev<W>
 }
 
 // Winners -> nodes in one pass: k_compact_tab (acx_frontier.h) with the winners' keys recomputed from their parents.
-template <typename W>
+template <typename W, int MODE>
 __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pbegin, uint32_t m, uint32_t base, uint32_t cap_nodes, uint32_t epoch,
                                                      unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t* __restrict__ total_out) {
     __shared__ uint32_t s_tile, s_prefix, s_wsum[4];
     __shared__ uint16_t s_list[kCompactTile];
-    ACX_MIN_VGPRS_32();
+#ifdef ACX_HAZARD_REPRO  // tools/hazard24/repro_compact.sh: the build that corrupts (exactly the 32 registers the kernel uses)
+    asm volatile("" ::: "v31");
+#else
+    ACX_VGPR_PAD_W(W, "v47", "v63");
+#endif
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
@@ -249,7 +307,18 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
         const uint32_t p = t / 12u, pid = pbegin + p, a = t - 12u * p;
         Pres<W> s;
         key_to_pres<W>(d.k0[pid], d.k1[pid], s);
-        (void)apply_move<W, kSearchSafe>(s, (int)a, d.L, d.cyclical != 0);
+        (void)search_move<W, MODE>(s, (int)a, d.L, d.cyclical != 0);
+#ifdef ACX_BFS_CHECK_NF
+        {
+            Pres<W> g;
+            key_to_pres<W>(d.k0[pid], d.k1[pid], g);
+            (void)apply_move<W, kSearchSafe>(g, (int)a, d.L, d.cyclical != 0);
+            if (g.w0 != s.w0 || g.w1 != s.w1 || g.n0 != s.n0 || g.n1 != s.n1 || !is_normal_form<W>(s, d.cyclical != 0))
+                printf("COMPACT: node %u = move(%u, %u): parent %llx %llx nf %llx %llx general %llx %llx\n", id, pid, a, (unsigned long long)d.k0[pid], (unsigned long long)d.k1[pid],
+                       (unsigned long long)keyops<W>::make(s.w0, s.n0), (unsigned long long)keyops<W>::make(s.w1, s.n1), (unsigned long long)keyops<W>::make(g.w0, g.n0),
+                       (unsigned long long)keyops<W>::make(g.w1, g.n1));
+        }
+#endif
         d.k0[id] = keyops<W>::make(s.w0, s.n0);
         d.k1[id] = keyops<W>::make(s.w1, s.n1);
         d.parent[id] = pid;

@@ -33,4 +33,25 @@ Scratch& scratch(int slot);
 
 template <typename T> static inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
 
+// Register padding of the kernels ("the top of a wave's register allocation").  Twice now a kernel that
+// keeps live values in the LAST vector register it declares (k_expand with 24, k_bfs_compact with 32) returned corrupted
+// packed words on MI355X, differently on every run, while the byte-identical code with a few more registers declared is
+// bit-exact.  Every kernel therefore names a register at least 8 above its own need as clobbered in an empty asm statement:
+// no instruction, no occupancy (the pads stay inside the next occupancy step), and tests/test_abi_cpu.py compiles the
+// library with and without the pads (-DACX_NO_VGPR_PAD) to check the margin of every kernel.
+#ifdef ACX_NO_VGPR_PAD
+#define ACX_VGPR_PAD(reg) ((void)0)
+#else
+#define ACX_VGPR_PAD(reg) asm volatile("" ::: reg)
+#endif
+// by key width: W = uint64_t kernels and the wider unsigned __int128 ones
+#define ACX_VGPR_PAD_W(W, reg64, reg128) \
+    do {                                 \
+        if (sizeof(W) == 8) {            \
+            ACX_VGPR_PAD(reg64);         \
+        } else {                         \
+            ACX_VGPR_PAD(reg128);        \
+        }                                \
+    } while (0)
+
 }  // namespace acx

@@ -114,6 +114,7 @@ template <typename W> __device__ __forceinline__ void key_to_pres(W k0, W k1, Pr
 // one lane per (parent, action): tag t = 12 * p + a
 template <typename W>
 __global__ void __launch_bounds__(256) k_expand(SearchDev<W> d, const uint32_t* __restrict__ plist, uint32_t pbegin, uint32_t np) {
+    ACX_VGPR_PAD_W(W, "v39", "v55");
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t tl = 0xFFFFFFFFu;
     if (t < 12u * np) {
@@ -160,6 +161,7 @@ template <typename W> __device__ __forceinline__ bool key_equals(const SearchDev
 // Occupants may be committed node ids (always win) or provisional ids of this batch.
 template <typename W>
 __global__ void __launch_bounds__(256) k_insert(SearchDev<W> d, uint32_t* __restrict__ slots, uint32_t mask, uint32_t m, int skip_known) {
+    ACX_VGPR_PAD_W(W, "v31", "v39");
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     if (skip_known && d.cknown[t]) {
@@ -191,6 +193,7 @@ __global__ void __launch_bounds__(256) k_insert(SearchDev<W> d, uint32_t* __rest
 
 // read-only membership test against the visited table (greedy: speculative batches must not touch it)
 template <typename W> __global__ void __launch_bounds__(256) k_lookup(SearchDev<W> d, uint32_t m) {
+    ACX_VGPR_PAD("v31");
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     const W k0 = d.ck0[t], k1 = d.ck1[t];
@@ -215,6 +218,7 @@ template <typename W> __global__ void __launch_bounds__(256) k_lookup(SearchDev<
 // cflag[t] = 1 iff candidate t is the first discoverer of a state not seen before
 template <typename W>
 __global__ void __launch_bounds__(256) k_mark(SearchDev<W> d, const uint32_t* __restrict__ slots, uint32_t m, int bucket_len) {
+    ACX_VGPR_PAD("v15");
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     const uint32_t s = d.cslot[t];
@@ -229,6 +233,7 @@ __global__ void __launch_bounds__(256) k_mark(SearchDev<W> d, const uint32_t* __
 // winners are then cflag & !cslot (k_mark_tab, a streaming pass).
 template <typename W>
 __global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, uint32_t epoch, int skip_known) {
+    ACX_VGPR_PAD_W(W, "v39", "v47");
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     if (skip_known && d.cknown[t]) {
@@ -281,12 +286,14 @@ __global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, 
 }
 
 template <typename W> __global__ void __launch_bounds__(256) k_mark_tab(SearchDev<W> d, uint32_t m) {
+    ACX_VGPR_PAD("v15");
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     d.cflag[t] = (d.cflag[t] && !d.cslot[t]) ? 1u : 0u;
 }
 
 template <typename W> __global__ void k_root_tab(SearchDev<W> d, W k0, W k1, uint32_t tl) {
+    ACX_VGPR_PAD("v23");
     d.k0[0] = k0;
     d.k1[0] = k1;
     d.parent[0] = kEmpty;
@@ -315,6 +322,7 @@ struct Decision {
 
 template <typename W>
 __global__ void k_decide(SearchDev<W> d, uint32_t m, uint32_t np, unsigned long long nodes, long long max_nodes, int greedy, Decision* __restrict__ out) {
+    ACX_VGPR_PAD("v23");
     const uint32_t total = d.cpos[m - 1] + d.cflag[m - 1];
     uint32_t p_end = np - 1, budget_hit = 0;
     const unsigned long long shorter = *d.shorter_tag, solved_tag = *d.solved_tag;
@@ -362,6 +370,7 @@ __global__ void k_decide(SearchDev<W> d, uint32_t m, uint32_t np, unsigned long 
 template <typename W>
 __global__ void __launch_bounds__(256) k_commit(SearchDev<W> d, const uint32_t* __restrict__ plist, uint32_t pbegin, const Decision* __restrict__ dec, uint32_t m,
                                                 uint32_t base, int insert_now) {
+    ACX_VGPR_PAD("v31");
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m || t >= dec->cutoff || !d.cflag[t]) return;
     const uint32_t id = base + d.cpos[t];
@@ -403,7 +412,7 @@ __global__ void __launch_bounds__(256) k_compact_tab(SearchDev<W> d, uint32_t pb
                                                      unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t* __restrict__ total_out) {
     __shared__ uint32_t s_tile, s_prefix, s_wsum[4];
     __shared__ uint16_t s_list[kCompactTile];
-    asm volatile("" ::: "v31");  // declare 32 VGPRs: the kernel needs exactly 24, the count of the k_expand build of DESIGN.md section 7 (free: 8 waves/SIMD either way)
+    ACX_VGPR_PAD("v39");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
@@ -492,6 +501,7 @@ __global__ void __launch_bounds__(256) k_compact_tab(SearchDev<W> d, uint32_t pb
 template <typename W>
 __global__ void k_decide_tab(SearchDev<W> d, uint32_t m, uint32_t np, uint32_t pbegin, uint32_t base, uint32_t cap_nodes, long long max_nodes,
                              const uint32_t* __restrict__ total_in, Decision* __restrict__ out) {
+    ACX_VGPR_PAD("v23");
     const uint32_t total = *total_in;
     const unsigned long long nodes = base;
     uint32_t p_end = np - 1, budget_hit = 0;
@@ -539,6 +549,7 @@ __global__ void k_decide_tab(SearchDev<W> d, uint32_t m, uint32_t np, uint32_t p
 
 // root node: id 0
 template <typename W> __global__ void k_root(SearchDev<W> d, W k0, W k1, uint32_t tl) {
+    ACX_VGPR_PAD("v15");
     d.k0[0] = k0;
     d.k1[0] = k1;
     d.parent[0] = kEmpty;
@@ -550,6 +561,7 @@ template <typename W> __global__ void k_root(SearchDev<W> d, W k0, W k1, uint32_
 
 // path of node `id` from the root, written root first: out_act / out_len [depth + 1]
 template <typename W> __global__ void k_path(SearchDev<W> d, uint32_t id, int32_t* out_act, int32_t* out_len, int64_t cap) {
+    ACX_VGPR_PAD("v15");
     const uint32_t dep = d.depth[id];
     for (uint32_t v = id, k = dep;; k--) {
         if ((int64_t)k < cap) {
@@ -567,6 +579,7 @@ template <typename W> __global__ void k_path(SearchDev<W> d, uint32_t id, int32_
 // tiles of 256 so that every comparison reads one broadcast LDS row.  O(n^2), buckets are small.
 template <typename W>
 __global__ void __launch_bounds__(256) k_rank_sort(SearchDev<W> d, const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+    ACX_VGPR_PAD_W(W, "v39", "v47");
     __shared__ W t0[256];
     __shared__ W t1[256];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

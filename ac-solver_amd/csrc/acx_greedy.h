@@ -828,6 +828,9 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
     }
 }
 
+// No register pad here (ACX_VGPR_PAD, acx_common.h): a 1024-lane workgroup may use at most 128 registers per lane and the
+// frontier needs them all (it already spills); `amdgpu_num_vgpr(120)` does not lower the allocation under this launch bound.
+// These two kernels are covered by the repeat-determinism tests instead (tests/test_gpu_determinism.py).
 template <typename W>
 __global__ void __launch_bounds__(kGT) k_greedy_persistent(GreedyDev<W> g, GreedyOut* __restrict__ out) {
     greedy_run<W>(g, out, nullptr, nullptr, 0);

@@ -21,11 +21,61 @@
 //
 // Keys: a relator word and its length share one machine word (length in the top 6 bits):
 // W = u64 for L <= 29, u128 for L <= 61.  Roofline: HBM (random table probes); see DESIGN.md.
+#include <atomic>
+
 #include "acx_frontier.h"
 #include "acx_bfs.h"
 #include "acx_greedy.h"
 
 namespace acx {
+
+// ---- node-arena digest (repeat-determinism tests) ------------------------------------------------------------------------
+// acx_search_digest_enable(1) makes every search of this process finish with one extra pass that folds (id, key, parent,
+// action) of all its nodes into a 64-bit sum; acx_search_last_digest returns the calling thread's last one.
+static std::atomic<int> g_digest_on{0};
+static thread_local uint64_t t_last_digest = 0;
+
+template <typename W, typename KEYS>
+__global__ void __launch_bounds__(256) k_digest(KEYS keys, const uint32_t* __restrict__ parent, const uint8_t* __restrict__ act, uint32_t n, unsigned long long* __restrict__ out) {
+    ACX_VGPR_PAD("v31");
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long h = 0;
+    if (i < n) {
+        W k0, k1;
+        keys(i, k0, k1);
+        h = mix64(fold(k0) + 0x9e3779b97f4a7c15ull * (i + 1)) ^ mix64(fold(k1) ^ ((uint64_t)parent[i] << 8 | act[i]));
+        h = mix64(h + i);
+    }
+    for (int o = 32; o > 0; o >>= 1) h += (unsigned long long)__shfl_xor((long long)h, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+template <typename W> struct SoaKeys {
+    const W* k0;
+    const W* k1;
+    __device__ void operator()(uint32_t i, W& a, W& b) const {
+        a = k0[i];
+        b = k1[i];
+    }
+};
+template <typename W> struct AosKeys {
+    const NodeKey<W>* nk;
+    __device__ void operator()(uint32_t i, W& a, W& b) const {
+        a = nk[i].k0;
+        b = nk[i].k1;
+    }
+};
+template <typename W, typename KEYS> static int node_digest(KEYS keys, const uint32_t* parent, const uint8_t* act, uint64_t n, hipStream_t st) {
+    if (!g_digest_on.load()) return ACX_OK;
+    DevBuf out;
+    if (out.alloc(8)) return ACX_E_NOMEM;
+    ACX_HIP_TRY(hipMemsetAsync(out.p, 0, 8, st));
+    hipLaunchKernelGGL((k_digest<W, KEYS>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, parent, act, (uint32_t)n, (unsigned long long*)out.p);
+    unsigned long long h = 0;
+    ACX_HIP_TRY(hipMemcpyAsync(&h, out.p, 8, hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
+    t_last_digest = h;
+    return ACX_OK;
+}
 
 template <typename W> struct Searcher {
     SearchDev<W> d;
@@ -429,6 +479,8 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
         stats->min_len = (int32_t)o.min_len;
         stats->seconds = ms * 1e-3;
     }
+    rc = node_digest<W>(AosKeys<W>{g.nkeys}, S.d.parent, S.d.act, o.nodes, st);
+    if (rc) return rc;
     if (*path_n > path_cap) return fail(ACX_E_CAPACITY, "path has %lld entries, buffer holds %lld", (long long)*path_n, (long long)path_cap);
     return ACX_OK;
 }
@@ -456,6 +508,8 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
                                  : (uint32_t)std::min<int64_t>(std::max<int64_t>(max_nodes / 4, 1024), 1 << 20);
     // BFS: the stamp table of acx_bfs.h; ACX_BFS_INLINE_TAB=1 selects round 1's inline-key table (A/B measurements)
     const bool stamp = !greedy && !getenv("ACX_BFS_INLINE_TAB") && !getenv("ACX_BFS_CLASSIC_COMMIT");
+    // a root in normal form keeps the whole search in normal form: the kernels then run the shorter move code (acx_bfs.h)
+    const int move_mode = !is_normal_form<W>(root, cyclical != 0) || getenv("ACX_BFS_GENERAL_MOVE") ? kMoveGeneral : (cyclical ? kMoveNfCyclical : kMoveNf);
     Searcher<W> S;
     int rc = S.init(L, cyclical, max_nodes, bmax, greedy, !greedy && !stamp, false, stamp);
     if (rc) return rc;
@@ -550,9 +604,25 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         if (stamp) {
             // expand + dedup in one kernel, winners -> nodes in one pass, then the decision from the written nodes
             ACX_HIP_TRY(hipMemsetAsync(d.brepl, 0, m, st));
-            hipLaunchKernelGGL(k_bfs_expand_insert<W>, dim3((m + kBfsBlock - 1) / kBfsBlock), dim3(kBfsBlock), 0, st, d, pbegin, np);
-            hipLaunchKernelGGL(k_bfs_compact<W>, dim3((m + kCompactTile - 1) / kCompactTile), block, 0, st, d, pbegin, m, (uint32_t)nodes, (uint32_t)S.cap_nodes,
-                               (uint32_t)batches, S.d_status, S.d_ticket, S.d_total);
+            const dim3 egrid((m + kBfsBlock - 1) / kBfsBlock), eblock(kBfsBlock), cgrid((m + kCompactTile - 1) / kCompactTile);
+#ifndef ACX_BFS_EXPAND_MODE
+#define ACX_BFS_EXPAND_MODE(M) M
+#endif
+#ifndef ACX_BFS_COMPACT_MODE
+#define ACX_BFS_COMPACT_MODE(M) M
+#endif
+#define ACX_BFS_LAUNCH(MODE)                                                                                                                          \
+    hipLaunchKernelGGL((k_bfs_expand_insert<W, ACX_BFS_EXPAND_MODE(MODE)>), egrid, eblock, 0, st, d, pbegin, np);                                     \
+    hipLaunchKernelGGL((k_bfs_compact<W, ACX_BFS_COMPACT_MODE(MODE)>), cgrid, block, 0, st, d, pbegin, m, (uint32_t)nodes, (uint32_t)S.cap_nodes, (uint32_t)batches, S.d_status, \
+                       S.d_ticket, S.d_total)
+            if (move_mode == kMoveNf) {
+                ACX_BFS_LAUNCH(kMoveNf);
+            } else if (move_mode == kMoveNfCyclical) {
+                ACX_BFS_LAUNCH(kMoveNfCyclical);
+            } else {
+                ACX_BFS_LAUNCH(kMoveGeneral);
+            }
+#undef ACX_BFS_LAUNCH
             hipLaunchKernelGGL(k_decide_tab<W>, dim3(1), dim3(1), 0, st, d, m, np, pbegin, (uint32_t)nodes, (uint32_t)S.cap_nodes, (long long)max_nodes, S.d_total, S.d_dec);
         } else {
         hipLaunchKernelGGL(k_expand<W>, grid, block, 0, st, d, plist, pbegin, np);
@@ -667,6 +737,8 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         stats->min_len = (int32_t)min_len;
         stats->seconds = ms * 1e-3;
     }
+    rc = node_digest<W>(SoaKeys<W>{d.k0, d.k1}, d.parent, d.act, std::min<uint64_t>(nodes, S.cap_nodes), st);
+    if (rc) return rc;
     if (*path_n > path_cap) return fail(ACX_E_CAPACITY, "path has %lld entries, buffer holds %lld", (long long)*path_n, (long long)path_cap);
     return ACX_OK;
 }
@@ -687,13 +759,23 @@ extern "C" int acx_search(int kind, const int8_t* h_presentation, int L, int64_t
     return run_search<u128>(kind, h_presentation, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats);
 }
 
+extern "C" int acx_search_digest_enable(int on) {
+    g_digest_on.store(on ? 1 : 0);
+    return ACX_OK;
+}
+
+extern "C" int acx_search_last_digest(uint64_t* digest) {
+    if (!digest) return fail(ACX_E_INVAL, "acx_search_last_digest: null pointer");
+    *digest = t_last_digest;
+    return ACX_OK;
+}
+
 extern "C" int acx_release_cached_memory(void) {
     block_pool().trim();
     return ACX_OK;
 }
 
 // ------------------------------------------------------------------ many independent searches ----
-#include <atomic>
 #include <thread>
 
 extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t n, int L, int64_t max_nodes, int cyclical, int n_threads,

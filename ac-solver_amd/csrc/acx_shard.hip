@@ -31,6 +31,7 @@ template <> struct recio<u128> {
 template <typename W>
 __global__ void __launch_bounds__(256) k_shard_expand(SearchDev<W> d, const int64_t* __restrict__ ids, const int64_t* __restrict__ gpos, int64_t np,
                                                       int64_t pref_hi, int64_t* __restrict__ rec, unsigned long long* __restrict__ solved) {
+    ACX_VGPR_PAD_W(W, "v39", "v55");
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 12 * np) return;
     const int64_t p = t / 12;
@@ -71,6 +72,7 @@ template <typename W>
 __global__ void __launch_bounds__(1024) k_shard_expand_routed(SearchDev<W> d, const int64_t* __restrict__ ids, const int64_t* __restrict__ gpos, int64_t np,
                                                              int64_t pref_hi, uint32_t world, int64_t* __restrict__ rec, int64_t region_cap,
                                                              unsigned long long* __restrict__ counts, unsigned long long* __restrict__ solved) {
+    ACX_VGPR_PAD_W(W, "v39", "v55");
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = t < 12 * np;
     const uint32_t lane = threadIdx.x & 63;
@@ -127,6 +129,7 @@ __global__ void __launch_bounds__(1024) k_shard_expand_routed(SearchDev<W> d, co
 }
 
 template <typename W> __global__ void __launch_bounds__(256) k_shard_tags(const int64_t* __restrict__ rec, int64_t n, uint64_t* __restrict__ tags, uint32_t* __restrict__ idx) {
+    ACX_VGPR_PAD("v23");
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     tags[i] = (uint64_t)rec[i * (recio<W>::KW + 2) + recio<W>::KW];
@@ -137,6 +140,7 @@ template <typename W> __global__ void __launch_bounds__(256) k_shard_tags(const 
 template <typename W>
 __global__ void __launch_bounds__(256) k_shard_gather(SearchDev<W> d, const int64_t* __restrict__ rec, const uint64_t* __restrict__ tags_sorted,
                                                       const uint32_t* __restrict__ idx_sorted, int64_t n, int64_t* __restrict__ ctag, int64_t* __restrict__ cpref) {
+    ACX_VGPR_PAD_W(W, "v31", "v39");
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int64_t* r = rec + (int64_t)idx_sorted[j] * (recio<W>::KW + 2);
@@ -152,6 +156,7 @@ __global__ void __launch_bounds__(256) k_shard_gather(SearchDev<W> d, const int6
 
 template <typename W>
 __global__ void __launch_bounds__(256) k_shard_win_tags(SearchDev<W> d, const int64_t* __restrict__ ctag, int64_t n, int64_t* __restrict__ out) {
+    ACX_VGPR_PAD("v23");
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n || !d.cflag[j]) return;
     out[d.cpos[j]] = ctag[j];
@@ -160,6 +165,7 @@ __global__ void __launch_bounds__(256) k_shard_win_tags(SearchDev<W> d, const in
 template <typename W>
 __global__ void __launch_bounds__(256) k_shard_commit(SearchDev<W> d, const int64_t* __restrict__ ctag, const int64_t* __restrict__ cpref, int64_t n,
                                                       int64_t cutoff, uint32_t base, int64_t* __restrict__ node_pref) {
+    ACX_VGPR_PAD("v31");
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n || !d.cflag[j] || ctag[j] >= cutoff) return;
     const uint32_t id = base + d.cpos[j];
@@ -172,6 +178,7 @@ __global__ void __launch_bounds__(256) k_shard_commit(SearchDev<W> d, const int6
 
 // number of winners with tag < cutoff: candidates are in tag order, so it is cpos at the first tag >= cutoff
 template <typename W> __global__ void k_shard_count(SearchDev<W> d, const int64_t* __restrict__ ctag, int64_t n, int64_t cutoff, uint32_t* __restrict__ count) {
+    ACX_VGPR_PAD("v15");
     int64_t lo = 0, hi = n;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;

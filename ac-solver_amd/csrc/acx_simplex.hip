@@ -64,6 +64,7 @@ __device__ __forceinline__ bool apply(const Pres<W>& p, int t, bool classic, Pre
 
 // candidate t = M * parent + move; children above the length cap are flagged `known` (k_insert skips them)
 __global__ void __launch_bounds__(256) k_expand_pairs(SearchDev<W> d, uint32_t pbegin, uint32_t np, int M, int ncap, int classic) {
+    ACX_VGPR_PAD("v39");
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (uint32_t)M * np) return;
     const uint32_t p = t / (uint32_t)M, k = t - p * (uint32_t)M;
@@ -80,6 +81,7 @@ __global__ void __launch_bounds__(256) k_expand_pairs(SearchDev<W> d, uint32_t p
 }
 
 __global__ void __launch_bounds__(256) k_commit_pairs(SearchDev<W> d, uint32_t m, uint32_t base, uint32_t cap_nodes) {
+    ACX_VGPR_PAD("v23");
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m || !d.cflag[t]) return;
     const uint32_t id = base + d.cpos[t];
@@ -93,6 +95,7 @@ __global__ void __launch_bounds__(256) k_commit_pairs(SearchDev<W> d, uint32_t m
 
 // after the commit every kept candidate's table slot holds the final name of its state
 __global__ void __launch_bounds__(256) k_edge_flags(SearchDev<W> d, uint32_t m, uint32_t pbegin, int M, uint32_t* __restrict__ eflag) {
+    ACX_VGPR_PAD("v15");
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     eflag[t] = (!d.cknown[t] && pbegin + t / (uint32_t)M < d.slots[d.cslot[t]]) ? 1u : 0u;
@@ -101,6 +104,7 @@ __global__ void __launch_bounds__(256) k_edge_flags(SearchDev<W> d, uint32_t m, 
 __global__ void __launch_bounds__(256) k_edge_write(SearchDev<W> d, uint32_t m, uint32_t pbegin, int M, const uint32_t* __restrict__ eflag,
                                                      const uint32_t* __restrict__ epos, unsigned long long ebase, unsigned long long cap_edges,
                                                      uint32_t* __restrict__ edges, uint8_t* __restrict__ efilt) {
+    ACX_VGPR_PAD("v23");
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m || !eflag[t]) return;
     const unsigned long long e = ebase + epos[t];
@@ -112,7 +116,8 @@ __global__ void __launch_bounds__(256) k_edge_write(SearchDev<W> d, uint32_t m, 
     efilt[e] = a > b ? a : b;
 }
 
-__global__ void k_root_pairs(SearchDev<W> d) {  // <a, b>: relators [a] and [b], vertex 0
+__global__ void k_root_pairs(SearchDev<W> d) {
+    ACX_VGPR_PAD("v23");  // <a, b>: relators [a] and [b], vertex 0
     const W k0 = keyops<W>::make((W)2, 1), k1 = keyops<W>::make((W)3, 1);
     d.k0[0] = k0;
     d.k1[0] = k1;

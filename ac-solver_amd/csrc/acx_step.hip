@@ -104,6 +104,7 @@ template <int MAXL>
 __global__ void __launch_bounds__(64) k_move_bytes(const int8_t* __restrict__ in, const void* __restrict__ act, int adt, int64_t n,
                                                    int L, int flags, int8_t* __restrict__ out, int32_t* __restrict__ len,
                                                    uint8_t* __restrict__ err, int32_t* __restrict__ fit) {
+    if (MAXL <= 32) ACX_VGPR_PAD("v127");  // <128> already needs all 256 registers (byte-exact path: no packed-word code)
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     int8_t row[2 * MAXL], res[2 * MAXL], w1[MAXL], w2[MAXL];
@@ -129,6 +130,7 @@ __global__ void __launch_bounds__(64) k_move_bytes(const int8_t* __restrict__ in
 template <int MAXW>
 __global__ void __launch_bounds__(64) k_simplify_rows(const int8_t* __restrict__ in, int64_t n, int width, int cyclical,
                                                       int8_t* __restrict__ out, int32_t* __restrict__ len, uint8_t* __restrict__ err) {
+    ACX_VGPR_PAD("v23");
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     int8_t row[MAXW], res[MAXW];
@@ -148,6 +150,7 @@ template <typename W>
 __global__ void __launch_bounds__(256) k_move_packed(const int8_t* __restrict__ in, const void* __restrict__ act, int adt, int64_t n,
                                                      int L, int cyclical, int8_t* __restrict__ out, int32_t* __restrict__ len,
                                                      uint8_t* __restrict__ err, int vec) {
+    ACX_VGPR_PAD("v63");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int RB = 2 * L;
@@ -321,6 +324,7 @@ __global__ void __launch_bounds__(256, ACX_STEP_WAVES) k_env_step(W* __restrict_
                                                   const void* __restrict__ act, int64_t n_envs, int adt, EnvDev<W> e, OBS* __restrict__ obs,
                                                   float* __restrict__ rew, float clip_lo, float clip_hi, uint8_t* __restrict__ done,
                                                   uint8_t* __restrict__ trunc, OBS* __restrict__ final_obs, int autoreset, int vec) {
+    ACX_VGPR_PAD("v71");
     // The first six arguments (state arrays, actions, n, action dtype = 11 dwords) are what the first memory
     // accesses need: with -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave, so the
     // state loads issue without waiting for a kernarg fetch (this kernel is latency bound at 65 536 envs).
@@ -375,6 +379,7 @@ __global__ void __launch_bounds__(256, 4) k_env_step_team(W* __restrict__ sw0, W
                                                          const void* __restrict__ act, int64_t n_envs, int adt, EnvDev<W> e, OBS* __restrict__ obs,
                                                          float* __restrict__ rew, float clip_lo, float clip_hi, uint8_t* __restrict__ done,
                                                          uint8_t* __restrict__ trunc, int autoreset, int vec) {
+    ACX_VGPR_PAD("v63");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int L = LC > 0 ? LC : e.L;
@@ -438,6 +443,7 @@ template <typename W, bool SAFE>
 __global__ void __launch_bounds__(256) k_env_rollout(EnvDev<W> e, const uint8_t* __restrict__ tape, int64_t T, float* __restrict__ rew,
                                                      float clip_lo, float clip_hi, uint8_t* __restrict__ done,
                                                      uint8_t* __restrict__ trunc, int autoreset) {
+    ACX_VGPR_PAD_W(W, "v63", "v79");
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= e.n) return;
     EnvLane<W> v;
@@ -457,6 +463,7 @@ __global__ void __launch_bounds__(256) k_env_rollout(EnvDev<W> e, const uint8_t*
 
 template <typename W, typename OBS>
 __global__ void __launch_bounds__(256) k_env_observe(EnvDev<W> e, OBS* __restrict__ obs, int vec) {
+    ACX_VGPR_PAD("v63");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int RB = 2 * e.L * (int)sizeof(OBS);
@@ -477,6 +484,7 @@ __global__ void __launch_bounds__(256) k_env_observe(EnvDev<W> e, OBS* __restric
 template <typename W>
 __global__ void k_env_load(EnvDev<W> e, const int8_t* __restrict__ rows, const int64_t* __restrict__ idx, int64_t m, int to_initial,
                            uint8_t* __restrict__ rowerr) {
+    ACX_VGPR_PAD_W(W, "v31", "v39");
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
     const int64_t i = idx ? idx[k] : k;
@@ -512,6 +520,7 @@ __global__ void k_env_load(EnvDev<W> e, const int8_t* __restrict__ rows, const i
 template <typename W>
 __global__ void k_env_gather(EnvDev<W> e, const int64_t* __restrict__ idx, int64_t m, int8_t* __restrict__ rows, int32_t* __restrict__ len,
                              int32_t* __restrict__ cnt, uint8_t* __restrict__ err, int clear_err) {
+    ACX_VGPR_PAD_W(W, "v47", "v63");
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
     const int64_t i = idx ? idx[k] : k;
@@ -728,7 +737,7 @@ acx_env* acx_env_create(int64_t n, int L, int64_t horizon, int flags) {
         init[i * 2 * L] = 1;
         init[i * 2 * L + L] = 2;
     }
-    if (acx_env_set_initial(e, init.data(), nullptr, n) != ACX_OK) {
+    if (acx_env_set_initial(e, init.data(), nullptr, n, nullptr) != ACX_OK) {
         acx_env_destroy(e);
         return nullptr;
     }
@@ -743,7 +752,10 @@ void acx_env_destroy(acx_env* e) {
 
 int64_t acx_env_max_reward(const acx_env* e) { return e ? e->horizon * e->L * 2 : 0; }
 
-static int env_load_rows(acx_env* e, const int8_t* h_states, const int64_t* h_idx, int64_t m, int to_initial) {
+// Host-buffer entries of the environment: everything they do (uploads, the kernel, the read-back) is queued on the CALLER's
+// stream and the call returns after that stream has drained, so a reset between two steps is ordered with the steps of the
+// same stream also when that stream is a non-blocking side stream (torch side streams, graph capture streams are).
+static int env_load_rows(acx_env* e, const int8_t* h_states, const int64_t* h_idx, int64_t m, int to_initial, hipStream_t st) {
     if (!e || m < 0 || (h_idx == nullptr && m != e->n && m != 0)) return fail(ACX_E_INVAL, "env reset: idx == NULL needs n_idx == n");
     if (m == 0) return ACX_OK;
     if (h_idx)
@@ -756,27 +768,28 @@ static int env_load_rows(acx_env* e, const int8_t* h_states, const int64_t* h_id
     int rc = s.ensure(total);
     if (rc) return rc;
     uint8_t* b = (uint8_t*)s.p;
-    if (h_states) ACX_HIP_TRY(hipMemcpy(b + o_rows, h_states, m * row, hipMemcpyHostToDevice));
-    if (h_idx) ACX_HIP_TRY(hipMemcpy(b + o_idx, h_idx, m * 8, hipMemcpyHostToDevice));
+    if (h_states) ACX_HIP_TRY(hipMemcpyAsync(b + o_rows, h_states, m * row, hipMemcpyHostToDevice, st));
+    if (h_idx) ACX_HIP_TRY(hipMemcpyAsync(b + o_idx, h_idx, m * 8, hipMemcpyHostToDevice, st));
     const unsigned grid = (unsigned)ceil_div<int64_t>(m, 256);
     const int8_t* rows = h_states ? (const int8_t*)(b + o_rows) : nullptr;
     const int64_t* idx = h_idx ? (const int64_t*)(b + o_idx) : nullptr;
-    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL(k_env_load<W>, dim3(grid), dim3(256), 0, nullptr, dev, rows, idx, m, to_initial, b + o_err));
+    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL(k_env_load<W>, dim3(grid), dim3(256), 0, st, dev, rows, idx, m, to_initial, b + o_err));
     ACX_HIP_TRY(hipGetLastError());
     std::vector<uint8_t> err((size_t)m);
-    ACX_HIP_TRY(hipMemcpy(err.data(), b + o_err, m, hipMemcpyDeviceToHost));
+    ACX_HIP_TRY(hipMemcpyAsync(err.data(), b + o_err, m, hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
     for (int64_t k = 0; k < m; k++)
         if (err[k]) return fail(ACX_E_ROWERR, "row %lld is not a valid presentation over {+-1,+-2} (ACEnvConfig raises ValueError)", (long long)k);
     return ACX_OK;
 }
 
-int acx_env_set_initial(acx_env* e, const int8_t* h_states, const int64_t* h_idx, int64_t n_idx) {
+int acx_env_set_initial(acx_env* e, const int8_t* h_states, const int64_t* h_idx, int64_t n_idx, void* stream) {
     if (!h_states) return fail(ACX_E_INVAL, "acx_env_set_initial: states required");
-    return env_load_rows(e, h_states, h_idx, n_idx, 1);
+    return env_load_rows(e, h_states, h_idx, n_idx, 1, (hipStream_t)stream);
 }
 
-int acx_env_reset(acx_env* e, const int8_t* h_states, const int64_t* h_idx, int64_t n_idx) {
-    return env_load_rows(e, h_states, h_idx, n_idx, 0);
+int acx_env_reset(acx_env* e, const int8_t* h_states, const int64_t* h_idx, int64_t n_idx, void* stream) {
+    return env_load_rows(e, h_states, h_idx, n_idx, 0, (hipStream_t)stream);
 }
 
 int acx_env_step(acx_env* e, const void* d_actions, int action_dtype, void* d_obs, int obs_dtype, float* d_reward, float clip_lo,
@@ -880,7 +893,8 @@ int acx_env_observe(acx_env* e, void* d_obs, int obs_dtype, void* stream) {
     return ACX_OK;
 }
 
-int acx_env_get(acx_env* e, const int64_t* h_idx, int64_t m, int8_t* h_state, int32_t* h_len, int32_t* h_count) {
+int acx_env_get(acx_env* e, const int64_t* h_idx, int64_t m, int8_t* h_state, int32_t* h_len, int32_t* h_count, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
     if (!e || m < 0 || (!h_idx && m != e->n)) return fail(ACX_E_INVAL, "acx_env_get: bad argument");
     if (m == 0) return ACX_OK;
     if (h_idx)
@@ -893,30 +907,32 @@ int acx_env_get(acx_env* e, const int64_t* h_idx, int64_t m, int8_t* h_state, in
     int rc = s.ensure(total);
     if (rc) return rc;
     uint8_t* b = (uint8_t*)s.p;
-    if (h_idx) ACX_HIP_TRY(hipMemcpy(b + o_idx, h_idx, m * 8, hipMemcpyHostToDevice));
-    ACX_HIP_TRY(hipDeviceSynchronize());  // steps may be in flight on other streams
+    if (h_idx) ACX_HIP_TRY(hipMemcpyAsync(b + o_idx, h_idx, m * 8, hipMemcpyHostToDevice, st));
     const unsigned grid = (unsigned)ceil_div<int64_t>(m, 256);
     const int64_t* idx = h_idx ? (const int64_t*)(b + o_idx) : nullptr;
-    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL(k_env_gather<W>, dim3(grid), dim3(256), 0, nullptr, dev, idx, m, (int8_t*)(b + o_rows), (int32_t*)(b + o_len),
+    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL(k_env_gather<W>, dim3(grid), dim3(256), 0, st, dev, idx, m, (int8_t*)(b + o_rows), (int32_t*)(b + o_len),
                                                         (int32_t*)(b + o_cnt), (uint8_t*)nullptr, 0));
     ACX_HIP_TRY(hipGetLastError());
-    if (h_state) ACX_HIP_TRY(hipMemcpy(h_state, b + o_rows, m * row, hipMemcpyDeviceToHost));
-    if (h_len) ACX_HIP_TRY(hipMemcpy(h_len, b + o_len, m * 8, hipMemcpyDeviceToHost));
-    if (h_count) ACX_HIP_TRY(hipMemcpy(h_count, b + o_cnt, m * 4, hipMemcpyDeviceToHost));
+    if (h_state) ACX_HIP_TRY(hipMemcpyAsync(h_state, b + o_rows, m * row, hipMemcpyDeviceToHost, st));
+    if (h_len) ACX_HIP_TRY(hipMemcpyAsync(h_len, b + o_len, m * 8, hipMemcpyDeviceToHost, st));
+    if (h_count) ACX_HIP_TRY(hipMemcpyAsync(h_count, b + o_cnt, m * 4, hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
     return ACX_OK;
 }
 
-int acx_env_get_actions(acx_env* e, int64_t i, int which, int32_t* h_out, int64_t cap, int64_t* n_out) {
+int acx_env_get_actions(acx_env* e, int64_t i, int which, int32_t* h_out, int64_t cap, int64_t* n_out, void* stream) {
     if (!e || i < 0 || i >= e->n || !n_out) return fail(ACX_E_INVAL, "acx_env_get_actions: bad argument");
     if (!(e->flags & ACX_ENV_RECORD_ACTIONS)) return fail(ACX_E_INVAL, "env was created without ACX_ENV_RECORD_ACTIONS");
-    ACX_HIP_TRY(hipDeviceSynchronize());
+    hipStream_t st = (hipStream_t)stream;
     const uint8_t* hist = e->wide ? e->d128.hist : e->d64.hist;
     int32_t cnt = 0;
     if (which) {
-        ACX_HIP_TRY(hipMemcpy(&cnt, (e->wide ? e->d128.last_len : e->d64.last_len) + i, 4, hipMemcpyDeviceToHost));
+        ACX_HIP_TRY(hipMemcpyAsync(&cnt, (e->wide ? e->d128.last_len : e->d64.last_len) + i, 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipStreamSynchronize(st));
     } else {
         uint64_t m = 0;
-        ACX_HIP_TRY(hipMemcpy(&m, (e->wide ? e->d128.meta : e->d64.meta) + i, 8, hipMemcpyDeviceToHost));
+        ACX_HIP_TRY(hipMemcpyAsync(&m, (e->wide ? e->d128.meta : e->d64.meta) + i, 8, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipStreamSynchronize(st));
         cnt = (int32_t)(m >> 32);
     }
     *n_out = cnt;
@@ -925,22 +941,24 @@ int acx_env_get_actions(acx_env* e, int64_t i, int which, int32_t* h_out, int64_
     if (cnt == 0) return ACX_OK;
     std::vector<uint8_t> col((size_t)cnt);
     // strided column read: row t of the ring, column i
-    ACX_HIP_TRY(hipMemcpy2D(col.data(), 1, hist + i, (size_t)e->n, 1, (size_t)cnt, hipMemcpyDeviceToHost));
+    ACX_HIP_TRY(hipMemcpy2DAsync(col.data(), 1, hist + i, (size_t)e->n, 1, (size_t)cnt, hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
     for (int32_t t = 0; t < cnt; t++) h_out[t] = col[t];
     return ACX_OK;
 }
 
-int acx_env_get_errors(acx_env* e, uint8_t* h_err, int clear) {
+int acx_env_get_errors(acx_env* e, uint8_t* h_err, int clear, void* stream) {
     if (!e || !h_err) return fail(ACX_E_INVAL, "acx_env_get_errors: bad argument");
+    hipStream_t st = (hipStream_t)stream;
     Scratch& s = scratch(1);
     int rc = s.ensure((size_t)e->n);
     if (rc) return rc;
-    ACX_HIP_TRY(hipDeviceSynchronize());
     const unsigned grid = (unsigned)ceil_div<int64_t>(e->n, 256);
-    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL(k_env_gather<W>, dim3(grid), dim3(256), 0, nullptr, dev, (const int64_t*)nullptr, e->n, (int8_t*)nullptr,
+    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL(k_env_gather<W>, dim3(grid), dim3(256), 0, st, dev, (const int64_t*)nullptr, e->n, (int8_t*)nullptr,
                                                         (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)s.p, clear));
     ACX_HIP_TRY(hipGetLastError());
-    ACX_HIP_TRY(hipMemcpy(h_err, s.p, e->n, hipMemcpyDeviceToHost));
+    ACX_HIP_TRY(hipMemcpyAsync(h_err, s.p, e->n, hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
     return ACX_OK;
 }
 

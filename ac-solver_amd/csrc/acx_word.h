@@ -244,6 +244,43 @@ template <typename W, bool SAFE = true> ACX_HD int apply_move_reduced(Pres<W>& s
     return ACX_ERR_NONE;
 }
 
+// true when both relators are non-empty and in the normal form every ACMove leaves behind: freely reduced, and
+// cyclically reduced when `cyclical`
+template <typename W, bool SAFE = true> ACX_HD bool is_normal_form(const Pres<W>& s, bool cyclical) {
+    if (s.n0 == 0 || s.n1 == 0) return false;
+    if (cyclical) return is_cyc_reduced<W, SAFE>(s.w0, s.n0) && is_cyc_reduced<W, SAFE>(s.w1, s.n1);
+    return !has_inverse_pair<W, SAFE>(s.w0, s.n0) && !has_inverse_pair<W, SAFE>(s.w1, s.n1);
+}
+
+// ACMove on a presentation in normal form (is_normal_form) -- every node of a search except possibly its root.
+// Equivalent to apply_move: the untouched relator is a fixed point of simplify_relator; a concatenation of freely
+// reduced words is freely reduced once the junction is cancelled (concat_words); g r g^-1 with the end cancellation of
+// conjugate_word is freely reduced when r is (the two ends cannot both cancel against a reduced r of length <= 2); with
+// `cyclical` see apply_move_reduced.
+template <typename W, bool SAFE = true> ACX_HD int apply_move_nf(Pres<W>& s, int a, int L, bool cyclical) {
+    if (cyclical) return apply_move_reduced<W, SAFE>(s, a, L);
+    const int m = a + 1;
+    const bool i1 = (m & 1) != 0;
+    const int i = i1 ? 1 : 0;
+    W wi = i1 ? s.w1 : s.w0;
+    const W wj = i1 ? s.w0 : s.w1;
+    int ni = i1 ? s.n1 : s.n0;
+    const int nj = i1 ? s.n0 : s.n1;
+    if (a < 4) {
+        concat_words<W, SAFE>(wi, ni, wj, nj, (((m - i) >> 1) & 1) != 0, L, wi, ni);
+        if (ni == 0) return ACX_ERR_ASSERT;
+    } else {
+        const int jp = ((m - i) >> 1) & 1;
+        const int sp = ((m - i - 2 * jp) >> 2) & 1;
+        conjugate_word<W, SAFE>(wi, ni, sp ? 1 - jp : 2 + jp, L, wi, ni);
+    }
+    s.w0 = i1 ? wj : wi;
+    s.w1 = i1 ? wi : wj;
+    s.n0 = i1 ? nj : ni;
+    s.n1 = i1 ? ni : nj;
+    return ACX_ERR_NONE;
+}
+
 // 4 int8 letters (one per byte, little endian) from 8 code bits; bytes at positions >= valid read 0.
 // One v_perm_b32 does the code -> letter lookup: selector bytes 0..3 pick a byte of 0x0201FFFE
 // (= letters -2,-1,+1,+2), selector 0x0c yields 0x00 (padding).

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACX_VERSION 100
+#define ACX_VERSION 200
 
 /* return codes */
 #define ACX_OK 0
@@ -83,12 +83,15 @@ typedef struct acx_env acx_env;
 
 acx_env *acx_env_create(int64_t n, int L, int64_t horizon, int flags);
 void acx_env_destroy(acx_env *env);
+/* The entries below that take HOST buffers and a `stream` queue their uploads, their kernel and their read-back on that
+ * stream and return once it has drained: they are ordered with the steps the caller queued on the same stream (NULL =
+ * the null stream), also when that stream is a non-blocking side stream. */
 /* ACEnvConfig.initial_state for the envs idx[0..n_idx) (NULL = all, rows in env order); also resets them.
  * Rows must be valid presentations (ACEnvConfig.__post_init__, ac_env.py:22-35): else ACX_E_ROWERR. */
-int acx_env_set_initial(acx_env *env, const int8_t *h_states, const int64_t *h_idx, int64_t n_idx);
+int acx_env_set_initial(acx_env *env, const int8_t *h_states, const int64_t *h_idx, int64_t n_idx, void *stream);
 /* ACEnv.reset (ac_env.py:115-131): h_states NULL -> back to the initial state, else
  * options={"starting_state": row}.  Zeroes count_steps and the action history of those envs. */
-int acx_env_reset(acx_env *env, const int8_t *h_states, const int64_t *h_idx, int64_t n_idx);
+int acx_env_reset(acx_env *env, const int8_t *h_states, const int64_t *h_idx, int64_t n_idx, void *stream);
 /* ACEnv.step for all n envs (ac_env.py:95-113).  d_obs [n,2L] (ACX_I8 or ACX_F32) receives the state
  * after the step -- after the autoreset when `autoreset` and the env finished, in which case
  * d_final_obs (nullable, same dtype) holds the terminal observation.  d_reward [n] f32 =
@@ -109,13 +112,14 @@ int acx_env_rollout(acx_env *env, const uint8_t *d_tape, int64_t T, float *d_rew
 int acx_env_observe(acx_env *env, void *d_obs, int obs_dtype, void *stream);
 /* host copies for the single-env Python surface: state [n_idx,2L] i8, lengths [n_idx,2] i32,
  * count_steps [n_idx] i32 */
-int acx_env_get(acx_env *env, const int64_t *h_idx, int64_t n_idx, int8_t *h_state, int32_t *h_len, int32_t *h_count);
+int acx_env_get(acx_env *env, const int64_t *h_idx, int64_t n_idx, int8_t *h_state, int32_t *h_len, int32_t *h_count,
+                void *stream);
 /* info["actions"] of env i (needs ACX_ENV_RECORD_ACTIONS): which = 0 the actions since its last reset,
  * which = 1 the actions of the episode that the last step's autoreset just ended (final_info). */
-int acx_env_get_actions(acx_env *env, int64_t i, int which, int32_t *h_out, int64_t cap, int64_t *n_out);
+int acx_env_get_actions(acx_env *env, int64_t i, int which, int32_t *h_out, int64_t cap, int64_t *n_out, void *stream);
 /* sticky per-env error bytes (a move hit the reference's AssertionError / IndexError: that env's state and
  * step counter were left untouched, as when the reference's step() raises); h_err [n]; clear != 0 zeroes them */
-int acx_env_get_errors(acx_env *env, uint8_t *h_err, int clear);
+int acx_env_get_errors(acx_env *env, uint8_t *h_err, int clear, void *stream);
 int64_t acx_env_max_reward(const acx_env *env); /* horizon * L * 2, ac_env.py:80 */
 
 /* ---- search ---------------------------------------------------------------------------------
@@ -136,6 +140,12 @@ typedef struct {
 
 int acx_search(int kind, const int8_t *h_presentation, int L, int64_t max_nodes, int cyclical, int32_t *solved,
                int32_t *path_action, int32_t *path_len, int64_t path_cap, int64_t *path_n, acx_search_stats *stats);
+
+/* Test hook (repeat-determinism tests): with the switch on, every acx_search of the process ends with one extra pass that
+ * folds (id, packed key, parent, action) of ALL nodes of the search into a 64-bit sum; acx_search_last_digest returns the
+ * one of the calling thread's last search.  Two runs of the same search must give the same digest, node for node. */
+int acx_search_digest_enable(int on);
+int acx_search_last_digest(uint64_t *digest);
 
 /* acx_search keeps the device blocks of a finished search for the next search of the same host thread (hipMalloc /
  * hipFree are slow and hipFree synchronises the device); this returns the calling thread's cached blocks to the driver */

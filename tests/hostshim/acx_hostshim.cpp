@@ -76,7 +76,36 @@ template <typename W> static void move_reduced_rows(const int8_t* in, const uint
     }
 }
 
+// search fast path: rows in normal form (is_normal_form); others are skipped (err 251)
+template <typename W> static void move_nf_rows(const int8_t* in, const uint8_t* act, int64_t n, int L, int cyclical, int8_t* out, int32_t* len, uint8_t* err) {
+    for (int64_t r = 0; r < n; r++) {
+        const int8_t* row = in + r * 2 * L;
+        int8_t* o = out + r * 2 * L;
+        memcpy(o, row, 2 * L);
+        Pres<W> s;
+        bool ok = pack_relator<W>(row, L, s.w0, s.n0);
+        ok = pack_relator<W>(row + L, L, s.w1, s.n1) && ok;
+        ok = ok && act[r] < 12 && is_normal_form<W>(s, cyclical != 0);
+        int e = 251;
+        if (ok) {
+            e = apply_move_nf<W>(s, act[r], L, cyclical != 0);
+            if (e == ACX_ERR_NONE) {
+                unpack_relator<W>(s.w0, s.n0, L, o);
+                unpack_relator<W>(s.w1, s.n1, L, o + L);
+            }
+        }
+        len[2 * r] = s.n0;
+        len[2 * r + 1] = s.n1;
+        err[r] = (uint8_t)e;
+    }
+}
+
 extern "C" {
+
+void shim_move_nf(const int8_t* in, const uint8_t* act, int64_t n, int L, int cyclical, int wide, int8_t* out, int32_t* len, uint8_t* err) {
+    if (wide) move_nf_rows<u128>(in, act, n, L, cyclical, out, len, err);
+    else move_nf_rows<uint64_t>(in, act, n, L, cyclical, out, len, err);
+}
 
 void shim_move_reduced(const int8_t* in, const uint8_t* act, int64_t n, int L, int wide, int8_t* out, int32_t* len, uint8_t* err) {
     if (wide) move_reduced_rows<u128>(in, act, n, L, out, len, err);

@@ -1,0 +1,130 @@
+"""Repeat-determinism gates.
+
+The corruption seen twice on MI355X (a kernel holding live values in the last vector register it declares) showed up as
+results that differ from run to run.  These tests run the same work several times and demand identical node arenas /
+states -- and equality with the oracle -- on the searches that exposed it:
+
+* bfs on Miller-Schupp presentation 145, cyclical, budget 1e6: the case that caught k_bfs_compact (32 registers) in round 2;
+* bfs / greedy_search on AK(3) at L = 25 with a 1e7 budget (the round-1 k_expand case, persistent greedy frontier);
+* 65 536 environments x 1000 launches of k_env_step against the fused k_env_rollout.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.conftest import ms_pool_generator_order
+
+pytestmark = pytest.mark.gpu
+
+
+def _ak3(L=25):
+    p = np.zeros(2 * L, np.int8)
+    p[:7] = [1, 1, 1, -2, -2, -2, -2]
+    p[L:L + 6] = [1, 2, 1, -2, -1, -2]
+    return p
+
+
+def _search_with_digest(kind, p, budget, cyclical):
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search
+
+    ok, path, st = run_search(kind, p, budget, cyclical, True)
+    d = C.c_uint64()
+    _acx.check(_acx.lib.acx_search_last_digest(C.byref(d)))
+    return ok, path, st["nodes"], st["expanded"], d.value
+
+
+@pytest.fixture()
+def digests():
+    from ac_solver import _acx
+
+    _acx.require_device()
+    _acx.check(_acx.lib.acx_search_digest_enable(1))
+    yield
+    _acx.check(_acx.lib.acx_search_digest_enable(0))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("index,cyclical", [(145, True), (314, True), (145, False)])
+def test_bfs_ms_presentation_1e6_repeats_to_the_node(digests, golden_json, index, cyclical):
+    from ac_solver import _acx
+    from oracle import ac_oracle as O
+
+    p = np.array(ms_pool_generator_order(golden_json("ms_pool.json"))[index], np.int8)
+    wok, wpath, wst = O.bfs(p, 10**6, cyclically_reduce_after_moves=cyclical, stats=True)
+    runs = [_search_with_digest(_acx.SEARCH_BFS, p, 10**6, cyclical) for _ in range(6)]
+    assert len(set(runs_k[4] for runs_k in runs)) == 1, [hex(r[4]) for r in runs]
+    for ok, path, nodes, expanded, _ in runs:
+        assert (ok, path, nodes, expanded) == (wok, wpath, wst["nodes"], wst["expanded"])
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("algo", ["bfs", "greedy"])
+def test_ak3_1e7_repeats_to_the_node(digests, algo):
+    from ac_solver import _acx
+
+    kind = _acx.SEARCH_BFS if algo == "bfs" else _acx.SEARCH_GREEDY
+    runs = [_search_with_digest(kind, _ak3(), 10**7, False) for _ in range(5)]
+    assert len({(r[0], str(r[1]), r[2], r[3], r[4]) for r in runs}) == 1, [(r[2], r[3], hex(r[4])) for r in runs]
+
+
+@pytest.mark.timeout(300)
+def test_general_and_normal_form_move_code_build_the_same_arena(digests, monkeypatch):
+    """the two move codes of the BFS kernels (acx_bfs.h: apply_move / apply_move_nf) must give the same nodes"""
+    from ac_solver import _acx
+
+    a = _search_with_digest(_acx.SEARCH_BFS, _ak3(), 3 * 10**6, False)
+    monkeypatch.setenv("ACX_BFS_GENERAL_MOVE", "1")
+    b = _search_with_digest(_acx.SEARCH_BFS, _ak3(), 3 * 10**6, False)
+    assert a == b
+
+
+@pytest.mark.timeout(600)
+def test_env_step_launches_equal_the_fused_rollout_three_times(golden_json):
+    """k_env_step (one launch per step, plain shifts) x 1000 on 65 536 environments, three times over, against the fused
+    k_env_rollout: final states, step counters and a checksum of every reward / flag must agree."""
+    import torch
+
+    from ac_solver.envs.vec_env import ACVecEnv
+
+    L, N, T = 25, 65536, 1000
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    rows = np.zeros((len(pool), 2 * L), np.int8)
+    for k, p in enumerate(pool):
+        half = len(p) // 2
+        for h in (0, 1):
+            w = [x for x in p[h * half:(h + 1) * half] if x != 0]
+            rows[k, h * L:h * L + len(w)] = w
+    states = rows[np.arange(N) % len(rows)]
+    tape = torch.as_tensor(np.random.default_rng(5).integers(0, 12, size=(T, N), dtype=np.uint8), device="cuda")
+
+    def fused():
+        env = ACVecEnv(states, horizon_length=1000, record_actions=False, final_info=False)
+        env.reset()
+        rw = torch.empty((T, N), dtype=torch.float32, device="cuda")
+        dn = torch.empty((T, N), dtype=torch.bool, device="cuda")
+        tr = torch.empty((T, N), dtype=torch.bool, device="cuda")
+        env.rollout(tape, rw, dn, tr)
+        torch.cuda.synchronize()
+        return env.get_states(), env.get_counts(), rw.double().sum(0).cpu().numpy(), dn.sum(0).cpu().numpy(), tr.sum(0).cpu().numpy()
+
+    def stepped():
+        env = ACVecEnv(states, horizon_length=1000, record_actions=False, final_info=False)
+        env.reset()
+        rsum = torch.zeros(N, dtype=torch.float64, device="cuda")
+        dsum = torch.zeros(N, dtype=torch.int64, device="cuda")
+        tsum = torch.zeros(N, dtype=torch.int64, device="cuda")
+        for t in range(T):
+            _, r, d, tr, _ = env.step(tape[t], check_errors=False)
+            rsum += r
+            dsum += d
+            tsum += tr
+        torch.cuda.synchronize()
+        return env.get_states(), env.get_counts(), rsum.cpu().numpy(), dsum.cpu().numpy(), tsum.cpu().numpy()
+
+    want = fused()
+    for _ in range(3):
+        got = stepped()
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b)

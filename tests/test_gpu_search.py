@@ -316,3 +316,25 @@ def _bfs_through_comm(bfs_sharded, p, budget, comm):
         return bfs_sharded(p, budget, comm=Forced())
     finally:
         sh._FORCE_EXCHANGE = saved
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("cyclical", [False, True])
+def test_config4_all_1190_ms_presentations_bfs_1e4_vs_oracle(search, golden_json, cyclical):
+    """BASELINE config 4 / SURVEY 8(d): bfs on ALL 1190 Miller-Schupp presentations (native max_relator_length 18..36, so both
+    key widths) with budget 1e4 -- (solved, path) and the node / expansion counts against the C oracle, one by one."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search_many
+    from oracle import ac_oracle as O
+
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    assert len(pool) == 1190
+    bad = []
+    for lo in range(0, 1190, 170):
+        rows = np.array(pool[lo:lo + 170], dtype=np.int8)
+        got = run_search_many(_acx.SEARCH_BFS, rows, 10**4, cyclical, n_threads=16)
+        for k, (ok, path, st) in enumerate(got):
+            wok, wpath, wst = O.bfs(rows[k], 10**4, cyclically_reduce_after_moves=cyclical, stats=True)
+            if (ok, path) != (wok, wpath) or st["nodes"] != wst["nodes"] or st["expanded"] != wst["expanded"]:
+                bad.append((lo + k, ok, wok, st["nodes"], wst["nodes"], st["expanded"], wst["expanded"]))
+    assert not bad, bad[:10]

@@ -198,3 +198,41 @@ def test_reduced_fast_path_matches_oracle(shim, L):
         assert np.array_equal(err[m], we[m]) and np.array_equal(out[m], want[m]) and np.array_equal(lens[m], wl[m])
         cur = np.ascontiguousarray(want)
         mv = np.roll(mv, 1)
+
+
+@pytest.mark.parametrize("cyc", [False, True])
+@pytest.mark.parametrize("L", [2, 3, 7, 25, 29, 36, 61])
+def test_normal_form_search_path_matches_oracle(shim, L, cyc):
+    """apply_move_nf (what the search kernels run on every node but an unreduced root) == ACMove on states in the normal
+    form ACMove itself leaves behind, for both `cyclical` values; states outside the normal form are refused (251)."""
+    rng = np.random.default_rng(1700 + 2 * L + int(cyc))
+    n = 6000
+    st = np.zeros((n, 2 * L), np.int8)
+    mv = rng.integers(0, 12, size=n).astype(np.uint8)
+    for r in range(n):
+        for h in (0, 1):
+            hi = L if r % 4 else min(L, 4)
+            w = list(rng.choice([1, -1, 2, -2], size=int(rng.integers(1, hi + 1))))
+            st[r, h * L:h * L + len(w)] = w
+        if r % 11 == 0:  # r1 = r0^+-1: a concatenation cancels completely -> AssertionError in the reference
+            w = st[r, :L][st[r, :L] != 0]
+            st[r, L:] = 0
+            st[r, L:L + len(w)] = -w[::-1] if r % 2 else w
+    raw_err = np.empty(n, np.uint8)
+    out = np.empty_like(st); lens = np.empty((n, 2), np.int32)
+    shim.shim_move_nf(_p(st, C.c_int8), _p(mv, C.c_uint8), C.c_int64(n), L, int(cyc), int(L > 32), _p(out, C.c_int8), _p(lens, C.c_int32), _p(raw_err, C.c_uint8))
+    assert (raw_err == 251).mean() > 0.2  # random words are mostly NOT reduced: refused
+    cur, _, err0 = O.move_batch(st, np.full(n, 4, np.uint8), L, cyclical=cyc)  # one ACMove puts both relators into normal form
+    # (an unreduced input can leave an EMPTY relator without an error, utils.py:261-278: such states are outside the normal form)
+    keep = (err0 == 0) & (cur[:, 0] != 0) & (cur[:, L] != 0)
+    cur, mv = np.ascontiguousarray(cur[keep]), mv[keep]
+    for _ in range(3):
+        out = np.empty_like(cur); lens = np.empty((len(cur), 2), np.int32); err = np.empty(len(cur), np.uint8)
+        shim.shim_move_nf(_p(cur, C.c_int8), _p(mv, C.c_uint8), C.c_int64(len(cur)), L, int(cyc), int(L > 32), _p(out, C.c_int8), _p(lens, C.c_int32), _p(err, C.c_uint8))
+        want, wl, we = O.move_batch(cur, mv, L, cyclical=cyc)
+        assert (err != 251).all()
+        assert np.array_equal(err, we) and np.array_equal(out, want) and np.array_equal(lens, wl)
+        assert (we != 0).any() or L > 7  # the AssertionError rows are exercised at the small widths
+        ok = we == 0
+        cur = np.ascontiguousarray(want[ok])
+        mv = np.roll(mv[ok], 1)

@@ -4,7 +4,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
 cd "$ROOT/ac-solver_amd/csrc"
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=14"
+F=${ACX_BASEFLAGS:-"--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed -mllvm -amdgpu-kernarg-preload-count=14"}
 mkdir -p /tmp/acx_var
 for f in acx_step acx_search acx_shard acx_ball acx_simplex; do /opt/rocm/bin/hipcc $F "$@" -c $f.hip -o /tmp/acx_var/${f}_$name.o & done
 wait
