@@ -13,9 +13,15 @@ into row t of PPO-style rollout buffers that are already resident in HBM.
 One process per GPU (torch.distributed / RCCL only for the barrier and the MAX over ranks: the
 environments are independent, so there is no data-path collective -> "scaling": "weak").
 Rank 0 prints ONE JSON line.  `roofline` prices the env kernel against HBM with the ALGORITHMIC bytes
-of one step (4L + 7 = 107 B at L = 25); `cpu_baseline` times the CPU oracle (plain C port
-of the reference's algorithm, oracle/ac_oracle.c) on one host core on a bounded sample of the same
-workload.
+of one step (4L + 7 = 107 B at L = 25); `search.bfs.roofline` / `search.greedy_search.roofline`
+price the frontier kernels with SURVEY 8(d)'s (64 + 72 f) B per generated child; `cpu_baseline` times the
+CPU oracle (plain C port of the reference's algorithm, oracle/ac_oracle.c) on one host core and on all of
+them, and the pure Python / NumPy restatement (oracle/ac_numpy.py), on bounded samples of the same workloads.
+
+Timed region: the K steps are captured once into a hipGraph; the graph is replayed R times back to back
+(R = ceil(16384 / K), so the window is >= 50 ms whatever K is) between barrier + synchronize on both
+sides; `ms_per_step` = window / (R * K), `repeats` = R.  A 20-step and a 1000-step run therefore report the
+same per-step time instead of one graph replay's fixed cost spread over 20 steps.
 """
 import argparse
 import json
@@ -36,6 +42,26 @@ HORIZON = 1000
 ALGO_BYTES_PER_STEP = 4 * L + 7  # state in + out (2 x 2L), action 1, reward f32 4, done 1, truncated 1
 SEARCH_TIMEOUT_S = int(os.environ.get("ACX_BENCH_SEARCH_TIMEOUT", "240"))  # multi-rank runs: how long the RCCL-backed secondary measurements may take
 HBM_PEAK_GBS = 8000.0            # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+MIN_TIMED_STEPS = 16384          # the K-step graph is replayed ceil(MIN_TIMED_STEPS / K) times: a window of >= 50 ms
+
+
+def search_roofline(stats, kernel, traffic_key):
+    """one generated child costs 64 B (one random table sector) + f * 72 B when it is new (slot, frontier append,
+    parent / action / length record), f = nodes / children.  achieved = those bytes / the device time of the search."""
+    children, nodes, dev_s = stats["children"], stats["nodes"], stats["seconds"]
+    f = nodes / max(children, 1)
+    algo = (64.0 + 72.0 * f) * children
+    out = {"bound": "hbm", "achieved": algo / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / dev_s / 1e9 / HBM_PEAK_GBS,
+           "traffic": None, "kernel": kernel, "algorithmic_bytes": algo, "bytes_per_child": 64.0 + 72.0 * f, "children": children,
+           "new_fraction": f, "device_seconds": dev_s}
+    tf = os.path.join(ROOT, "profiles", "search_traffic.json")
+    if os.path.exists(tf):  # HBM bytes of the same search from rocprofv3 --pmc passes (profiles/README.md): provenance stated
+        with open(tf) as fh:
+            t = json.load(fh).get(traffic_key)
+        if t and t.get("children") == children:
+            out["traffic"] = t["hbm_bytes"]
+            out["traffic_source"] = t["source"]
+    return out
 
 
 def ms_pool_at_L(L):
@@ -202,7 +228,10 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
             ok, path, s1 = run_search(kind, p, b, False)
             dt1 = time.perf_counter() - t0
             out[name] = {"nodes_per_s": s1["nodes"] / dt1, "nodes": s1["nodes"], "seconds": dt1, "device_seconds": s1["seconds"],
-                         "first_call_seconds": first, "batches": s1["levels"], "entry": "acx_search"}
+                         "first_call_seconds": first, "batches": s1["levels"], "entry": "acx_search",
+                         "roofline": search_roofline(s1, "k_bfs_expand_insert<u64> (expand + visited-table dedup, one launch per batch)"
+                                                     if kind == _acx.SEARCH_BFS else "k_greedy_persistent<u64> (one workgroup)",
+                                                     "bfs_ak3_1e8" if kind == _acx.SEARCH_BFS else "greedy_ak3_1e7")}
     return out
 
 
@@ -217,6 +246,33 @@ def cpu_search_baseline(budget=10**6):
         res[name + "_nodes_per_s"] = st["nodes"] / (time.perf_counter() - t0)
     res["search_sample"] = f"AK(3) at L=25, budget {budget}, oracle/ac_oracle.c, 1 core"
     return res
+
+
+def cpu_python_baseline(states, budget_s=4.0):
+    """BASELINE.md section 4, leg (3): the pure Python / NumPy restatement that mirrors the reference call for call
+    (oracle/ac_numpy.py, pinned on the reference's fixtures) -- what a user of the reference gets from one interpreter."""
+    from oracle import ac_numpy as P
+
+    rng = np.random.default_rng(0)
+    envs = [P.Env(states[i], HORIZON) for i in range(16)]
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for e in envs:
+            for a in rng.integers(0, 12, size=64):
+                _, _, done, trunc = e.step(int(a))
+                if done or trunc:
+                    e.reset()
+            steps += 64
+    dt = time.perf_counter() - t0
+    out = {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+           "sample": f"{steps} ACEnv.step calls (16 envs, MS initial states, L={L}) by oracle/ac_numpy.py (NumPy, one interpreter) in {dt:.1f} s"}
+    p = ak3_at_L()
+    for fn, name, b in ((P.bfs, "bfs", 3000), (P.greedy_search, "greedy_search", 3000)):
+        t0 = time.perf_counter()
+        fn(p, b)
+        out[name + "_nodes_per_s"] = b / (time.perf_counter() - t0)
+    out["search_sample"] = "AK(3) at L=25, budget 3000, oracle/ac_numpy.py"
+    return out
 
 
 def extra_env_numbers(dev, pool):
@@ -400,34 +456,50 @@ def main():
             graph.replay()  # one untimed replay after the communicator came up
             torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    R = max(1, -(-MIN_TIMED_STEPS // K))  # same on every rank (depends on K only)
+
+    def run_k_steps():
+        if graph is not None:
+            graph.replay()
+        else:
+            for k in range(K):
+                launch(W + k, k)
+
+    # one isolated K-step pass (what round 1 timed): carries the fixed cost of one graph replay + synchronize
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_k_steps()
+    torch.cuda.synchronize()
+    single_wall = time.perf_counter() - t0
+    # the timed region: R back-to-back passes of the same K steps (the env keeps stepping, rows of the rollout buffers are
+    # rewritten), barrier + synchronize on both sides, HIP events on the launch stream around the same window
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record()
-    if graph is not None:
-        graph.replay()
-    else:
-        for k in range(K):
-            launch(W + k, k)
+    for _ in range(R):
+        run_k_steps()
     ev1.record()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream: K back-to-back env kernels
+    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream: R * K back-to-back env kernels
 
-    tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([wall, dev_ms, single_wall], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall, dev_ms = float(tmax[0]), float(tmax[1])
+    wall, dev_ms, single_wall = float(tmax[0]), float(tmax[1]), float(tmax[2])
 
     # sanity: the timed steps really ran (count_steps advanced, rewards written)
     assert int(env.get_counts().max()) > 0 and bool(torch.isfinite(rew).all()) and bool((rew != 0).all())
 
     def headline(extras, search):
-        total_steps = N * K * world
-        launch_s = dev_ms * 1e-3 / K
+        total_steps = N * K * R * world
+        launch_s = dev_ms * 1e-3 / (K * R)
         achieved = ALGO_BYTES_PER_STEP * N / launch_s / 1e9
         out = {
             "metric": "AC env-steps/sec at max_relator_len=25",
@@ -436,7 +508,10 @@ def main():
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": wall * 1e3 / K,
+            "ms_per_step": wall * 1e3 / (K * R),
+            "repeats": R,
+            "timed_window_ms": wall * 1e3,
+            "ms_per_step_single_pass": single_wall * 1e3 / K,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -448,12 +523,26 @@ def main():
                        "parallelism": f"dp{world} (independent envs, no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_env_step<u64,int8>", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * N,
-                         "avg_launch_us": launch_s * 1e6},
+                         "avg_launch_us": launch_s * 1e6, "launches_timed": K * R},
         }
         traffic_file = os.path.join(ROOT, "profiles", "env_step_traffic.json")
         if os.path.exists(traffic_file) and N == N_ENVS:  # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
             with open(traffic_file) as f:
                 out["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
+            # not measured in this run: counters need their own rocprofv3 passes (tools/pmc_env.py; 2 x FETCH_SIZE + WRITE_SIZE)
+            out["roofline"]["traffic_source"] = "profiles/env_step_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and batch)"
+        # the same kernel under rocprofv3 --kernel-trace: the profiler stamps every dispatch of the replayed graph begin-to-end
+        # (launch latency included, no overlap with its neighbours), which is longer than the back-to-back launch period timed here
+        prof = os.path.join(ROOT, "profiles", "r2_bench_graph_kernel_stats.csv")
+        if os.path.exists(prof) and N == N_ENVS:
+            import csv
+
+            with open(prof) as f:
+                for row in csv.DictReader(f):
+                    if "k_env_step<" in row["Name"]:
+                        us = float(row["AverageNs"]) * 1e-3
+                        out["roofline"]["rocprof"] = {"avg_kernel_us": us, "calls": int(row["Calls"]), "source": "profiles/r2_bench_graph_kernel_stats.csv",
+                                                      "frac_by_kernel_duration": ALGO_BYTES_PER_STEP * N / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
         if extras is not None:
             out["env_context"] = extras
         if search is not None:
@@ -470,7 +559,7 @@ def main():
         def give_up():
             if rank == 0:
                 print(json.dumps(headline(None, {"error": f"secondary measurements did not finish within {SEARCH_TIMEOUT_S} s"})), flush=True)
-            os._exit(0)
+            os._exit(3)  # every rank leaves with a failure code: the headline is printed, but the run did hang
 
         watchdog = threading.Timer(SEARCH_TIMEOUT_S, give_up)
         watchdog.daemon = True
@@ -497,6 +586,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(states, 0)
             if not args.no_search:
                 out["cpu_baseline"].update(cpu_search_baseline())
+            out["cpu_baseline"]["python_numpy"] = cpu_python_baseline(states)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

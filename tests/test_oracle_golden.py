@@ -161,3 +161,63 @@ def test_simplex_oracle_matches_reference_program(golden_npz):
             assert np.array_equal(sizes, g[f"{tag}_{n}_node_size"]) and np.array_equal(edges, g[f"{tag}_{n}_edges"])
             assert np.array_equal(filt, g[f"{tag}_{n}_edge_filt"])
     assert len(g["prime_8_node_size"]) == 9172 and len(g["prime_8_edges"]) == 17416 and len(g["classic_8_edges"]) == 26363
+
+
+# ---- the pure Python / NumPy restatement (bench.py's third CPU-baseline leg) against the same reference fixtures ----
+def test_numpy_restatement_tables(golden_json):
+    from oracle import ac_numpy as P
+
+    t = golden_json("unit_tables.json")
+    for r in t["simplify_relator"]:
+        out, n = P.simplify_relator(np.array(r["relator"]), r["L"], cyclical=r["cyclical"], padded=r["padded"])
+        assert out.tolist() == r["out"] and n == r["length"], r
+    for r in t["is_array_valid_presentation"]:
+        assert P.is_array_valid_presentation(np.array(r["array"])) == r["valid"], r
+    for name in ("concatenate_relators", "conjugate"):
+        for r in t[name]:
+            out, lens = getattr(P, name)(np.array(r["presentation"]), r["L"], r["i"], r["j"], r["sign"], r["lengths"])
+            assert out.tolist() == r["out"] and lens == r["out_lengths"], (name, r)
+    for r in t["ACMove"]:
+        out, lens = P.ACMove(r["move"], np.array(r["presentation"]), r["L"], [4, 4], cyclical=r["cyclical"])
+        assert out.tolist() == r["out"] and lens == r["out_lengths"]
+
+
+@pytest.mark.parametrize("L", [3, 7, 25, 36])
+def test_numpy_restatement_acmove_fuzz_sample(golden_npz, L):
+    from oracle import ac_numpy as P
+
+    z = golden_npz("acmove_fuzz.npz")
+    st, mv, cy, err = z[f"L{L}_state"], z[f"L{L}_move"], z[f"L{L}_cyclical"], z[f"L{L}_err"]
+    def padded_words(row):  # both halves non-empty words padded on the right: the domain the searches and the env live in
+        return all(0 < np.count_nonzero(h) and not h[np.count_nonzero(h):].any() and h[:np.count_nonzero(h)].all() for h in (row[:L], row[L:]))
+
+    # the cases where the reference returns; its raises and its behaviour on malformed rows are pinned on the C oracle
+    pick = [k for k in np.flatnonzero(err == 0)[::5] if padded_words(st[k])][:500]
+    assert len(pick) > 100
+    for k in pick:
+        row = st[k]
+        lens = [int(np.count_nonzero(row[:L])), int(np.count_nonzero(row[L:]))]
+        out, ol = P.ACMove(int(mv[k]), row.copy(), L, lens, cyclical=bool(cy[k]))
+        assert out.tolist() == z[f"L{L}_out"][k].tolist() and ol == z[f"L{L}_lens"][k].tolist(), k
+
+
+def test_numpy_restatement_env_and_searches(golden_npz, golden_json):
+    from oracle import ac_numpy as P
+
+    z = golden_npz("env_traj.npz")
+    for e in range(0, 1024, 97):  # a few environments of the BASELINE config-2 recipe, first 32 steps
+        env = P.Env(z["init"][e], horizon_length=int(z["horizon"]))
+        for t in range(32):
+            _, r, d, tr = env.step(int(z["tape"][t, e]))
+            assert (int(r), bool(d), bool(tr)) == (int(z["reward"][t, e]), bool(z["done"][t, e]), bool(z["truncated"][t, e])), (e, t)
+        assert env.state.tolist() == z["state_t31"][e].tolist()
+    n = 0
+    for r in golden_json("search.json"):
+        if r["budget"] > 2000:
+            continue
+        fn = P.bfs if r["algo"] == "bfs" else P.greedy_search
+        ok, path = fn(r["presentation"], r["budget"], cyclically_reduce_after_moves=r["cyclical"])
+        want = [tuple(x) for x in r["path"]] if r["path"] is not None else None
+        assert ok == r["solved"] and path == want, (r["tag"], r["algo"], r["budget"])
+        n += 1
+    assert n >= 20
