@@ -5,15 +5,18 @@ States are partitioned by `hash(packed key) mod world`.  A level is processed in
 global frontier positions; for each chunk every rank
 
   1. expands the frontier nodes it owns (HIP kernel, 12 children per node; a child's tag
-     `12 * global_parent_position + action` is the order in which the reference generates it),
-  2. routes each child record to the owner of the child's key -- ONE all-to-all (RCCL over xGMI),
-  3. deduplicates what it received against its slice of the visited set, minimum tag wins (HIP),
-  4. all-reduces (sum) one 12-bit mask per parent of the chunk -- bit a set by the owner of child (parent, a)
-     when that child is a new state -- so that every rank derives the same global FIFO numbering (position
-     of a new state = new states of earlier parents + earlier set bits of its own parent), the same budget
-     decision ("first parent after which len(tree_nodes) >= max_nodes", breadth_first.py:91-95) and the same
-     success decision (smallest tag of a length-2 child, :84-85).  The exchange is 4 bytes per PARENT; no
-     rank ever holds the tags of the other ranks' new states.
+     `12 * global_parent_position + action` is the order in which the reference generates it) and writes each
+     child record straight into the send region of the owner of the child's key,
+  2. ONE all-to-all (RCCL over xGMI),
+  3. deduplicates what it received against its slice of the visited set, minimum tag wins (HIP), and sets bit a of
+     a 12-bit mask of parent p for every child (p, a) that is a new state it owns,
+  4. all-reduces (sum) those masks -- 4 bytes per PARENT -- so that every rank derives the same global FIFO
+     numbering (position of a new state = new states of earlier parents + earlier set bits of its own parent),
+     the same budget decision ("first parent after which len(tree_nodes) >= max_nodes", breadth_first.py:91-95)
+     and the same success decision (smallest tag of a length-2 child, :84-85); no rank ever holds the tags of the
+     other ranks' new states,
+  5. turns its new states into nodes, numbered through the masks (no sort); they are its slice of the next level.
+Per chunk the host reads back the send counts and ONE pack of decision scalars.
 
 The per-rank work goes through an *engine* (the C ABI `acx_shard_*` of libacx in production; the CPU
 tests plug in a NumPy engine built on the oracle) and the exchange through a *comm* (torch.distributed:
@@ -47,16 +50,23 @@ class TorchDistComm:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
-    def all_to_all_rows(self, send, counts):
-        """send [m, C] int64 grouped by destination, counts[d] rows for rank d -> rows received, grouped by source"""
+    def all_to_all_regions(self, regions):
+        """regions[d]: the rows [m_d, C] int64 for rank d (views of the engine's send buffer) -> the rows received, grouped by
+        source, in one tensor.  RCCL takes the regions as they lie (grouped send / recv, no staging copy); gloo (CPU tests) gets
+        one contiguous buffer with split sizes."""
         torch = _torch()
+        counts = [int(r.shape[0]) for r in regions]
         c_send = torch.tensor(counts, dtype=torch.int64, device=self.device)
         c_recv = torch.empty_like(c_send)
         self.dist.all_to_all_single(c_recv, c_send, group=self.group)
         recv_counts = c_recv.tolist()
-        cols = send.shape[1]
-        recv = torch.empty((sum(recv_counts), cols), dtype=send.dtype, device=self.device)
-        self.dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=recv_counts, input_split_sizes=list(counts), group=self.group)
+        cols = regions[0].shape[1]
+        recv = torch.empty((sum(recv_counts), cols), dtype=regions[0].dtype, device=self.device)
+        if self.dist.get_backend(self.group) == "nccl":
+            offs = np.concatenate([[0], np.cumsum(recv_counts)])
+            self.dist.all_to_all([recv[offs[k]:offs[k + 1]] for k in range(self.world)], [r.contiguous() for r in regions], group=self.group)
+        else:
+            self.dist.all_to_all_single(recv, torch.cat(regions).contiguous(), output_split_sizes=recv_counts, input_split_sizes=counts, group=self.group)
         return recv
 
     def all_gather_var(self, t):
@@ -84,8 +94,8 @@ class SingleComm:
 
     rank, world = 0, 1
 
-    def all_to_all_rows(self, send, counts):
-        return send
+    def all_to_all_regions(self, regions):
+        return regions[0]
 
     def all_gather_var(self, t):
         return [t]
@@ -98,7 +108,7 @@ class SingleComm:
 class HipShardEngine:
     """Per-rank frontier slice on one GPU: thin wrapper over the acx_shard_* C ABI (include/acx.h)."""
 
-    def __init__(self, L, cyclical, node_cap, batch_cap, rank, world, device=None):
+    def __init__(self, L, cyclical, node_cap, batch_cap, chunk_parents, rank, world, device=None):
         from ac_solver import _acx
 
         torch = _torch()
@@ -108,10 +118,11 @@ class HipShardEngine:
         self.KW = _acx.lib.acx_shard_key_words(L)
         self.rank = rank
         with torch.cuda.device(self.device):
-            self.h = _acx.lib.acx_shard_create(L, int(bool(cyclical)), int(node_cap), int(batch_cap), rank, world)
+            self.h = _acx.lib.acx_shard_create(L, int(bool(cyclical)), int(node_cap), int(batch_cap), int(chunk_parents), rank, world)
         if not self.h:
             raise _acx.AcxError(f"acx_shard_create failed: {_acx.last_error()}")
         self.batch_cap = int(batch_cap)
+        self._keep = None  # the received records stay alive until the commit that reads them
 
     def __del__(self):
         # not during interpreter shutdown: the HIP runtime may already be tearing down (a hipFree then can block forever)
@@ -131,46 +142,58 @@ class HipShardEngine:
         self._acx.check(rc, "acx_shard_root_record")
         return rec
 
-    def expand(self, ids, gpos, solved):
-        torch = _torch()
-        np_ = ids.numel()
-        rec = torch.empty((12 * np_, self.KW + 2), dtype=torch.int64, device=self.device)
-        if np_:
-            self._acx.check(self._acx.lib.acx_shard_expand(self.h, ids.data_ptr(), gpos.data_ptr(), np_, rec.data_ptr(), solved.data_ptr(), self._stream()),
-                            "acx_shard_expand")
-        return rec
+    def seed(self, record):
+        rec = None if record is None else np.ascontiguousarray(record, np.int64)
+        self._acx.check(self._acx.lib.acx_shard_seed(self.h, None if rec is None else self._acx.ptr(rec, C.c_int64), self._stream()), "acx_shard_seed")
 
-    def expand_routed(self, ids, gpos, solved, world):
-        """expand + group by owner on the device: (records grouped by destination rank, counts per rank)"""
-        torch = _torch()
-        np_ = ids.numel()
-        cap = 12 * np_  # a region can take every child: no-op moves keep a child on its parent's rank, so the split is far from uniform
-        rec = torch.empty((world * cap, self.KW + 2), dtype=torch.int64, device=self.device)
-        cnt = torch.empty(world, dtype=torch.int64, device=self.device)
-        self._acx.check(self._acx.lib.acx_shard_expand_routed(self.h, ids.data_ptr() if np_ else None, gpos.data_ptr() if np_ else None, np_,
-                                                              rec.data_ptr() if np_ else None, cap, cnt.data_ptr(), solved.data_ptr(), self._stream()),
-                        "acx_shard_expand_routed")
-        counts = cnt.tolist()
-        if max(counts) > cap:
-            raise RuntimeError(f"rank {self.rank}: a send region overflowed ({max(counts)} > {cap} records)")
-        if world == 1:
-            return rec[:counts[0]], counts  # one region: already contiguous
-        return torch.cat([rec[o * cap:o * cap + c] for o, c in enumerate(counts)]), counts
+    def level_begin(self):
+        n = C.c_int64(0)
+        self._acx.check(self._acx.lib.acx_shard_level_begin(self.h, C.byref(n)), "acx_shard_level_begin")
+        return n.value
 
-    def insert(self, recv, max_tag=None):
+    def expand_routed(self, c0, c1, n_local, solved, world):
+        """children of my frontier nodes with global position in [c0, c1): one region of records per destination rank (views)"""
+        torch = _torch()
+        full = 12 * min(c1 - c0, n_local)  # a region that could take every child
+        # the owner hash spreads a large chunk evenly: regions are sized for 1.25 x the even share and the expansion is simply
+        # repeated with full-size regions in the (never yet seen) case that one overflows -- the kernel only writes records
+        # and min-combines `solved`, so a second run is harmless
+        cap = full if world == 1 else min(full, int(1.25 * full / world) + 4096)
+        for attempt in (0, 1):
+            rec = torch.empty((world * cap, self.KW + 2), dtype=torch.int64, device=self.device)
+            cnt = torch.empty(world, dtype=torch.int64, device=self.device)
+            self._acx.check(self._acx.lib.acx_shard_expand_routed(self.h, int(c0), int(c1), rec.data_ptr() if cap else None, cap, cnt.data_ptr(),
+                                                                  solved.data_ptr(), self._stream()), "acx_shard_expand_routed")
+            if cap == 0:
+                return [rec[:0] for _ in range(world)]
+            counts = cnt.tolist()
+            if max(counts) <= cap:
+                return [rec[o * cap:o * cap + c] for o, c in enumerate(counts)]
+            if cap == full:
+                raise RuntimeError(f"rank {self.rank}: a send region overflowed ({max(counts)} > {cap} records)")
+            cap = full
+
+    def insert(self, recv, c0, n_parents):
+        """-> int32 [n_parents]: bit a of entry p - c0 set when child (p, a) is a new state of this rank"""
         torch = _torch()
         n = recv.shape[0]
-        win = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
-        n_win = C.c_int64(0)
-        bits = 0 if max_tag is None else max(int(max_tag).bit_length(), 1)
-        self._acx.check(self._acx.lib.acx_shard_insert(self.h, recv.data_ptr() if n else None, n, bits, win.data_ptr(), C.byref(n_win), self._stream()),
+        recv = recv.contiguous()
+        self._keep = recv
+        mask = torch.empty(max(n_parents, 1), dtype=torch.int32, device=self.device)
+        self._acx.check(self._acx.lib.acx_shard_insert(self.h, recv.data_ptr() if n else None, n, int(c0), int(n_parents), mask.data_ptr(), self._stream()),
                         "acx_shard_insert")
-        return win[: n_win.value]
+        return mask[:n_parents]
 
-    def commit(self, cutoff):
-        first, cnt = C.c_int64(0), C.c_int64(0)
-        self._acx.check(self._acx.lib.acx_shard_commit(self.h, int(cutoff), C.byref(first), C.byref(cnt), self._stream()), "acx_shard_commit")
-        return first.value, cnt.value
+    def commit(self, cutoff, lmask, lprefix, gmask, gprefix, gpos_base, n_commit):
+        p = lambda t: t.data_ptr() if t is not None and t.numel() else None  # noqa: E731
+        self._acx.check(self._acx.lib.acx_shard_commit(self.h, int(cutoff), p(lmask), p(lprefix), p(gmask), p(gprefix), int(gpos_base), int(n_commit),
+                                                       self._stream()), "acx_shard_commit")
+        self._keep = None
+
+    def find(self, gpos):
+        out = C.c_int64(-1)
+        self._acx.check(self._acx.lib.acx_shard_find(self.h, int(gpos), C.byref(out), self._stream()), "acx_shard_find")
+        return out.value
 
     def node_info(self, node_id):
         info = np.zeros(3, np.int64)
@@ -183,8 +206,8 @@ class HipShardEngine:
         return err.value, ml.value
 
 
-def _default_engine(L, cyclical, node_cap, batch_cap, rank, world):
-    return HipShardEngine(L, cyclical, node_cap, batch_cap, rank, world)
+def _default_engine(L, cyclical, node_cap, batch_cap, chunk_parents, rank, world):
+    return HipShardEngine(L, cyclical, node_cap, batch_cap, chunk_parents, rank, world)
 
 
 # ------------------------------------------------------------------------------------- orchestrator ---
@@ -212,24 +235,21 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
     world, rank = comm.world, comm.rank
     B = int(max(1, min(batch_parents, max(max_nodes, 64))))          # global parents per chunk
     batch_cap = int(12 * B * (2.0 / world if world > 1 else 1.0)) + 4096  # records one rank may receive per chunk
-    node_cap = (max_nodes + 12 if world == 1 else int(2.0 * max_nodes / world)) + 4096
-    engine = (engine_factory or _default_engine)(L, cyclically_reduce_after_moves, node_cap, batch_cap, rank, world)
+    node_cap = (max_nodes + 12 * min(B, max_nodes) if world == 1 else int(2.0 * max_nodes / world)) + 4096
+    engine = (engine_factory or _default_engine)(L, cyclically_reduce_after_moves, node_cap, batch_cap, B, rank, world)
     dev = getattr(engine, "device", torch.device("cpu"))
     KW = engine.KW
+    exchange = world > 1 or _FORCE_EXCHANGE
 
     def i64(values):
         return torch.tensor(values, dtype=torch.int64, device=dev)
 
     pop12 = i64([bin(v).count("1") for v in range(4096)])  # popcount of a 12-bit child mask
 
-    # root: inserted by its owner with tag 0, becomes global frontier position 0
+    # root: node 0 of its owner, global frontier position 0
     root = engine.root_record(p)
-    root_t = i64(root[None, :])
-    owner_root = int(owner_of(root_t[:, :KW], world)[0])
-    win = engine.insert(root_t if rank == owner_root else root_t[:0])
-    first, cnt = engine.commit(INF)
-    f_ids = i64(list(range(first, first + cnt)))
-    f_gpos = i64([0] * cnt)
+    owner_root = int(owner_of(torch.tensor(root[None, :KW], dtype=torch.int64), world)[0])
+    engine.seed(root if rank == owner_root else None)
     F = 1
     nodes_global = 1
     expanded = levels = 0
@@ -257,103 +277,87 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
 
     while F > 0:
         levels += 1
-        next_ids, next_gpos, next_count = [], [], 0
+        n_local = engine.level_begin()  # my slice of the level: the nodes I committed while the previous level was expanded
+        next_count = 0
         c0 = 0
         while c0 < F:
             c1 = min(F, c0 + B)
-            lo = int(torch.searchsorted(f_gpos, i64([c0]))[0]) if f_gpos.numel() else 0
-            hi = int(torch.searchsorted(f_gpos, i64([c1]))[0]) if f_gpos.numel() else 0
+            n_par = c1 - c0
             solved = i64([INF, INF])  # [0] smallest tag of a length-2 child, [1] smallest (tag << 8 | code) of a move the reference raises on
             # Local failures (a capacity of this rank's engine, a HIP error) must not leave the other ranks waiting in a
             # collective: the rank keeps taking part with empty contributions and reports through the `solved` all-reduce
             # (-1 beats every tag), so that all ranks raise together.
             failure = None
-            routed = hasattr(engine, "expand_routed")  # also for one rank: the device-side routing drops unchanged children
-            send, counts = torch.empty((0, KW + 2), dtype=torch.int64, device=dev), [0] * world
+            empty = [torch.empty((0, KW + 2), dtype=torch.int64, device=dev) for _ in range(world)]
+            regions = empty
             try:
-                if routed:
-                    send, counts = engine.expand_routed(f_ids[lo:hi].contiguous(), f_gpos[lo:hi].contiguous(), solved, world)
-                else:
-                    recs = engine.expand(f_ids[lo:hi].contiguous(), f_gpos[lo:hi].contiguous(), solved)
-                    if world > 1 or _FORCE_EXCHANGE:
-                        owners = owner_of(recs[:, :KW], world)
-                        order = torch.argsort(owners, stable=True)
-                        counts = torch.bincount(owners, minlength=world).tolist()
-                        send = recs[order].contiguous()
+                regions = engine.expand_routed(c0, c1, n_local, solved, world)
             except Exception as e:  # noqa: BLE001
-                failure = e
-                send, counts = torch.empty((0, KW + 2), dtype=torch.int64, device=dev), [0] * world
-            if world > 1 or _FORCE_EXCHANGE:
-                recv = comm.all_to_all_rows(send, counts)
-            else:
-                recv = send if (routed or failure is not None) else recs
-            win = i64([])
+                failure, regions = e, empty
+            recv = comm.all_to_all_regions(regions) if exchange else regions[0]
+            lmask = torch.zeros(n_par, dtype=torch.int32, device=dev)
             try:
                 if failure is None:
                     if recv.shape[0] > engine.batch_cap:
                         raise RuntimeError(f"rank {rank}: {recv.shape[0]} records exceed the per-chunk capacity {engine.batch_cap}")
-                    win = engine.insert(recv, 12 * c1)       # tags of MY new states, ascending
+                    lmask = engine.insert(recv, c0, n_par)   # one 12-bit mask per parent: MY new states
             except Exception as e:  # noqa: BLE001
-                failure, win = e, i64([])
+                failure, lmask = e, torch.zeros(n_par, dtype=torch.int32, device=dev)
             if failure is not None:
                 solved = i64([-1, INF])
-            # one 12-bit mask per parent of the chunk; every (parent, action) child has exactly one owner, so SUM == OR
-            rel = win - 12 * c0
-            par, bit = rel // 12, rel % 12
-            mask = torch.zeros(c1 - c0, dtype=torch.int32, device=dev)
-            if rel.numel():
-                mask.index_add_(0, par, torch.bitwise_left_shift(torch.ones_like(bit), bit).to(torch.int32))
-            comm.all_reduce(mask, "sum")
-            mask = mask.to(torch.int64)
-            incl = torch.cumsum(pop12[mask], 0)      # new states up to and including each parent (global)
+            # every (parent, action) child has exactly one owner, so SUM == OR
+            gmask = lmask.clone()
+            comm.all_reduce(gmask, "sum")
             comm.all_reduce(solved, "min")
-            solved_tag, err_word = (int(v) for v in solved.tolist())
+            lpop, gpop = pop12[lmask.to(torch.int64)], pop12[gmask.to(torch.int64)]
+            lincl, gincl = torch.cumsum(lpop, 0), torch.cumsum(gpop, 0)   # new states up to and including each parent
+            # ONE read-back for every decision of the chunk: the success / error words, the number of new states, the first
+            # parent whose inclusive count reaches what is left of the budget, and the counts a cut at that parent (or at the
+            # first parent) would commit
+            need = max(max_nodes - nodes_global, 0)
+            pb = torch.clamp(torch.searchsorted(gincl, i64([need])), max=n_par - 1)
+            pack = torch.cat([solved, gincl[-1:], pb, gincl[pb], lincl[pb], lincl[-1:], gincl[:1], lincl[:1]]).tolist()
+            solved_tag, err_word, total_new, pb_rel, g_at_pb, l_at_pb, l_total, g_first, l_first = (int(v) for v in pack)
             if solved_tag < 0:
                 raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure}" if failure is not None else "sharded bfs failed on another rank")
-            total_new = int(incl[-1])
-
-            def new_before(tag):
-                """number of new states of the chunk with a tag smaller than `tag` (global)"""
-                q, a = (tag - 12 * c0) // 12, (tag - 12 * c0) % 12
-                if q >= c1 - c0:
-                    return total_new
-                return int(incl[q] - pop12[mask[q]] + pop12[mask[q] & ((1 << a) - 1)])
 
             p_end, budget_hit = c1 - 1, False
+            commit_global, commit_local = total_new, l_total
             if nodes_global >= max_nodes:          # only the very first parent can see this (budget <= 1)
-                p_end, budget_hit = c0, True
+                p_end, budget_hit, commit_global, commit_local = c0, True, g_first, l_first
             elif nodes_global + total_new >= max_nodes:
                 # parent of the new state that reaches the budget = first parent whose inclusive count reaches it
-                pb = c0 + int(torch.searchsorted(incl, i64([max_nodes - nodes_global]))[0])
-                if pb <= p_end:
-                    p_end, budget_hit = pb, True
+                p_end, budget_hit, commit_global, commit_local = c0 + pb_rel, True, g_at_pb, l_at_pb
             is_solved = solved_tag < INF and solved_tag // 12 <= p_end
             if err_word < INF and (err_word >> 8) // 12 <= p_end and not (is_solved and solved_tag < (err_word >> 8)):
                 # the reference executes this move before it stops: its ACMove raises (every rank sees the same words)
                 raise AssertionError("a move emptied a relator during the search: the reference's ACMove raises here")
             if is_solved:
                 gp = solved_tag // 12
-                k = int(torch.searchsorted(f_gpos, i64([gp]))[0]) if f_gpos.numel() else 0
-                mine = k < f_gpos.numel() and int(f_gpos[k]) == gp
-                pref = i64([(rank << 40) | int(f_ids[k]) if mine else -1])
+                mine = engine.find(gp)
+                pref = i64([(rank << 40) | mine if mine >= 0 else -1])
                 comm.all_reduce(pref, "max")
+                q, a = gp - c0, solved_tag % 12
+                before = int(gincl[q] - gpop[q] + pop12[int(gmask[q]) & ((1 << a) - 1)])  # new states with a smaller tag (global)
                 expanded += gp + 1 - c0
-                nodes_global += new_before(solved_tag)
-                return finish(True, walk(int(pref[0]), [(solved_tag % 12, 2)]))
-            cutoff = 12 * (p_end + 1)
-            first, cnt = engine.commit(cutoff)
-            if cnt:
-                next_ids.append(torch.arange(first, first + cnt, dtype=torch.int64, device=dev))
-                mp = mask[par[:cnt]]
-                next_gpos.append(next_count + incl[par[:cnt]] - pop12[mp] + pop12[mp & (torch.bitwise_left_shift(torch.ones_like(bit[:cnt]), bit[:cnt]) - 1)])
-            committed = int(incl[p_end - c0])
-            next_count += committed
-            nodes_global += committed
+                nodes_global += before
+                return finish(True, walk(int(pref[0]), [(a, 2)]))
+            # a capacity failure of one rank's commit goes through the same "everybody raises" path as above
+            failure = None
+            try:
+                engine.commit(12 * (p_end + 1), lmask, lincl - lpop, gmask, gincl - gpop, next_count, commit_local)
+            except Exception as e:  # noqa: BLE001
+                failure = e
+            ok_all = i64([0 if failure is None else 1])
+            if exchange:
+                comm.all_reduce(ok_all, "max")
+            if int(ok_all[0]):
+                raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure}" if failure is not None else "sharded bfs failed on another rank")
+            next_count += commit_global
+            nodes_global += commit_global
             expanded += p_end + 1 - c0
             if budget_hit:
                 return finish(False, None)
             c0 = c1
-        f_ids = torch.cat(next_ids) if next_ids else i64([])
-        f_gpos = torch.cat(next_gpos) if next_gpos else i64([])
         F = next_count
     return finish(False, None)

@@ -1,5 +1,11 @@
 // acx_shard.hip -- per-GPU engine of the sharded BFS frontier (multi-GPU form of bfs, breadth_first.py:15-97) and its
 // C ABI (acx_shard_*).  Orchestration across ranks: ac-solver_amd/ac_solver/search/sharded.py.
+//
+// Round 2: the engine keeps its frontier on the device (the nodes committed during a level ARE the next level, a
+// contiguous id range in global FIFO order), dedups what it receives in an 8-byte stamp table (bucketed probing, one CAS
+// per new state; the keys of occupants are read from the received records / the node arena) and turns winners into nodes
+// through per-parent child masks -- the same 12-bit masks the ranks all-reduce -- so nothing is ever sorted and a chunk
+// costs the host two read-backs (send counts, the decision scalars).
 #include "acx_frontier.h"
 
 namespace acx {
@@ -14,6 +20,11 @@ template <typename W> struct recio;
 template <> struct recio<uint64_t> {
     static constexpr int KW = 2;
     static ACX_HD void put(int64_t* r, uint64_t k0, uint64_t k1) { r[0] = (int64_t)k0; r[1] = (int64_t)k1; }
+    // the whole 32-byte record as two 16-byte stores (records are 32-byte aligned)
+    static __device__ __forceinline__ void put_all(int64_t* r, uint64_t k0, uint64_t k1, int64_t tag, int64_t pref) {
+        ((ulonglong2*)r)[0] = make_ulonglong2(k0, k1);
+        ((ulonglong2*)r)[1] = make_ulonglong2((unsigned long long)tag, (unsigned long long)pref);
+    }
     static ACX_HD void get(const int64_t* r, uint64_t& k0, uint64_t& k1) { k0 = (uint64_t)r[0]; k1 = (uint64_t)r[1]; }
 };
 template <> struct recio<u128> {
@@ -26,29 +37,12 @@ template <> struct recio<u128> {
         k0 = ((u128)(uint64_t)r[1] << 64) | (uint64_t)r[0];
         k1 = ((u128)(uint64_t)r[3] << 64) | (uint64_t)r[2];
     }
+    static __device__ __forceinline__ void put_all(int64_t* r, u128 k0, u128 k1, int64_t tag, int64_t pref) {  // 48 bytes, 16-byte aligned
+        ((ulonglong2*)r)[0] = make_ulonglong2((uint64_t)k0, (uint64_t)(k0 >> 64));
+        ((ulonglong2*)r)[1] = make_ulonglong2((uint64_t)k1, (uint64_t)(k1 >> 64));
+        ((ulonglong2*)r)[2] = make_ulonglong2((unsigned long long)tag, (unsigned long long)pref);
+    }
 };
-
-template <typename W>
-__global__ void __launch_bounds__(256) k_shard_expand(SearchDev<W> d, const int64_t* __restrict__ ids, const int64_t* __restrict__ gpos, int64_t np,
-                                                      int64_t pref_hi, int64_t* __restrict__ rec, unsigned long long* __restrict__ solved) {
-    ACX_VGPR_PAD_W(W, "v39", "v55");
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 12 * np) return;
-    const int64_t p = t / 12;
-    const int a = (int)(t - 12 * p);
-    const int64_t id = ids[p];
-    Pres<W> s;
-    key_to_pres<W>(d.k0[id], d.k1[id], s);
-    const int e = apply_move<W, kSearchSafe>(s, a, d.L, d.cyclical != 0);
-    if (e) atomicMin(solved + 1, ((unsigned long long)(12 * gpos[p] + a) << 8) | (unsigned long long)e);  // first erroring move (global tag)
-    int64_t* r = rec + t * (recio<W>::KW + 2);
-    recio<W>::put(r, keyops<W>::make(s.w0, s.n0), keyops<W>::make(s.w1, s.n1));
-    const int64_t tag = 12 * gpos[p] + a;
-    r[recio<W>::KW] = tag;
-    r[recio<W>::KW + 1] = pref_hi | id;
-    if (s.n0 + s.n1 == 2) atomicMin(solved, (unsigned long long)tag);
-    if ((uint32_t)(s.n0 + s.n1) < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, (uint32_t)(s.n0 + s.n1));
-}
 
 // Owner rank of a packed key: the arithmetic of ac_solver/search/sharded.py:owner_of on the key's int64 words.
 ACX_HD uint64_t owner_mix(uint64_t h, uint64_t w) {
@@ -65,148 +59,261 @@ ACX_HD uint32_t owner_of_key(u128 k0, u128 k1, uint32_t world) {
     return (uint32_t)((h & 0x7FFFFFFFFFFFFFFFull) % world);
 }
 
-// k_shard_expand + routing: the record of a child goes straight into the send region of the rank that owns the
-// child's key (region o = rec[o * region_cap ...], filled through a wave-aggregated cursor counts[o]), so the
-// all-to-all can leave without a sort by owner.  The order inside a region is arbitrary (the receiver orders by tag).
-template <typename W>
-__global__ void __launch_bounds__(1024) k_shard_expand_routed(SearchDev<W> d, const int64_t* __restrict__ ids, const int64_t* __restrict__ gpos, int64_t np,
-                                                             int64_t pref_hi, uint32_t world, int64_t* __restrict__ rec, int64_t region_cap,
-                                                             unsigned long long* __restrict__ counts, unsigned long long* __restrict__ solved) {
-    ACX_VGPR_PAD_W(W, "v39", "v55");
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = t < 12 * np;
-    const uint32_t lane = threadIdx.x & 63;
-    W k0 = 0, k1 = 0;
-    int64_t tag = 0, pref = 0;
-    uint32_t owner = 0xFFFFFFFFu;
-    if (active) {
-        const int64_t p = t / 12;
-        const int a = (int)(t - 12 * p);
-        const int64_t id = ids[p];
-        Pres<W> s;
-        const W pk0 = d.k0[id], pk1 = d.k1[id];
-        key_to_pres<W>(pk0, pk1, s);
-        const int e = apply_move<W, kSearchSafe>(s, a, d.L, d.cyclical != 0);
-        if (e) atomicMin(solved + 1, ((unsigned long long)(12 * gpos[p] + a) << 8) | (unsigned long long)e);  // first erroring move (global tag)
-        k0 = keyops<W>::make(s.w0, s.n0);
-        k1 = keyops<W>::make(s.w1, s.n1);
-        tag = 12 * gpos[p] + a;
-        pref = pref_hi | id;
-        // a move that leaves the state unchanged (over-long product: ac_moves.py:64, :126) yields the parent itself, which
-        // is in the visited set already: such a child can never be new, so it is not sent at all
-        if (k0 != pk0 || k1 != pk1) owner = owner_of_key(k0, k1, world);
-        if (s.n0 + s.n1 == 2) atomicMin(solved, (unsigned long long)tag);
-        if ((uint32_t)(s.n0 + s.n1) < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, (uint32_t)(s.n0 + s.n1));
+
+// ---- local frontier ------------------------------------------------------------------------------------------------------
+// node arena: k0 / k1 (packed key), node_pref (parent_ref), act, tlen, gpos (d.depth: global FIFO position inside its level)
+// The nodes [lvl_lo, lvl_hi) are the current level, ascending in gpos.
+
+// first node of [lo, hi) whose gpos is >= c
+__device__ __forceinline__ uint32_t lower_gpos(const uint32_t* __restrict__ gpos, uint32_t lo, uint32_t hi, uint32_t c) {
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (gpos[mid] < c) lo = mid + 1;
+        else hi = mid;
     }
-    // position inside the destination region: wave-aggregated LDS counters per owner, then ONE global atomicAdd per
-    // (workgroup, owner) -- per-wave global atomics on `world` addresses serialise (1.6 ms per 12 M children)
+    return lo;
+}
+
+// Children of the local frontier nodes with gpos in [c0, c1), each written straight into the send region of the rank
+// that owns its key (region o = rec[o * region_cap ...]), so the all-to-all can leave without a sort by owner.  The order
+// inside a region is arbitrary.  A workgroup expands kRouteItems x 1024 children and reserves its share of every region
+// with ONE atomicAdd per owner: the cursors are single words, and one word takes only ~90 returning atomics per
+// microsecond (a reservation per 1024 children cost 3.7 of the kernel's 8.3 ms on a 1e8-node search).
+constexpr int kRouteItems = 4;
+
+template <typename W>
+__global__ void __launch_bounds__(1024) k_shard_expand_routed(SearchDev<W> d, uint32_t lvl_lo, uint32_t lvl_hi, uint32_t c0, uint32_t c1, int64_t pref_hi,
+                                                             uint32_t world, int64_t* __restrict__ rec, int64_t region_cap, unsigned long long* __restrict__ counts,
+                                                             unsigned long long* __restrict__ solved) {
+    ACX_VGPR_PAD_W(W, "v71", "v103");
+    __shared__ uint32_t s_lo, s_hi;
     __shared__ uint32_t s_cnt[64];
     __shared__ unsigned long long s_base[64];
+    if (threadIdx.x == 0) {
+        s_lo = lower_gpos(d.depth, lvl_lo, lvl_hi, c0);
+        s_hi = lower_gpos(d.depth, lvl_lo, lvl_hi, c1);
+    }
     if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t pos_in_block = 0;
-    for (uint32_t o = 0; o < world; o++) {
-        const unsigned long long m = __ballot(owner == o);
-        if (!m) continue;
-        const uint32_t lead = (uint32_t)__builtin_ctzll(m);
-        uint32_t base = 0;
-        if (lane == lead) base = atomicAdd(&s_cnt[o], (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, (int)lead);
-        if (owner == o) pos_in_block = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const int64_t np = (int64_t)s_hi - s_lo;
+    const uint32_t lane = threadIdx.x & 63;
+    W k0[kRouteItems], k1[kRouteItems];
+    int64_t tag[kRouteItems];
+    uint32_t owner[kRouteItems], pos_in_block[kRouteItems], ids[kRouteItems];
+#pragma unroll
+    for (int it = 0; it < kRouteItems; it++) {
+        const int64_t t = ((int64_t)blockIdx.x * kRouteItems + it) * 1024 + threadIdx.x;
+        owner[it] = 0xFFFFFFFFu;
+        pos_in_block[it] = 0;
+        k0[it] = k1[it] = 0;
+        tag[it] = 0;
+        ids[it] = 0;
+        if (t < 12 * np) {
+            const int64_t p = t / 12;
+            const int a = (int)(t - 12 * p);
+            const uint32_t id = s_lo + (uint32_t)p;
+            Pres<W> s;
+            const W pk0 = d.k0[id], pk1 = d.k1[id];
+            key_to_pres<W>(pk0, pk1, s);
+            const int e = apply_move<W, kSearchSafe>(s, a, d.L, d.cyclical != 0);
+            tag[it] = 12 * (int64_t)d.depth[id] + a;
+            ids[it] = id;
+            if (e) atomicMin(solved + 1, ((unsigned long long)tag[it] << 8) | (unsigned long long)e);  // first erroring move (global tag)
+            k0[it] = keyops<W>::make(s.w0, s.n0);
+            k1[it] = keyops<W>::make(s.w1, s.n1);
+            // a move that leaves the state unchanged (over-long product: ac_moves.py:64, :126) yields the parent itself, which
+            // is in the visited set already: such a child can never be new, so it is not sent at all
+            if (k0[it] != pk0 || k1[it] != pk1) owner[it] = owner_of_key(k0[it], k1[it], world);
+            if (s.n0 + s.n1 == 2) atomicMin(solved, (unsigned long long)tag[it]);
+            if ((uint32_t)(s.n0 + s.n1) < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, (uint32_t)(s.n0 + s.n1));
+        }
+        // position inside the workgroup's share of the destination region: wave-aggregated LDS counters per owner
+        for (uint32_t o = 0; o < world; o++) {
+            const unsigned long long m = __ballot(owner[it] == o);
+            if (!m) continue;
+            const uint32_t lead = (uint32_t)__builtin_ctzll(m);
+            uint32_t base = 0;
+            if (lane == lead) base = atomicAdd(&s_cnt[o], (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, (int)lead);
+            if (owner[it] == o) pos_in_block[it] = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        }
     }
     __syncthreads();
     if (threadIdx.x < world && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
     __syncthreads();
-    if (owner != 0xFFFFFFFFu) {
-        const int64_t pos = (int64_t)s_base[owner] + pos_in_block;
-        if (pos < region_cap) {
-            int64_t* r = rec + ((int64_t)owner * region_cap + pos) * (recio<W>::KW + 2);
-            recio<W>::put(r, k0, k1);
-            r[recio<W>::KW] = tag;
-            r[recio<W>::KW + 1] = pref;
-        }  // an overflow shows in counts[o] > region_cap; the host reports it
+#pragma unroll
+    for (int it = 0; it < kRouteItems; it++) {
+        if (owner[it] == 0xFFFFFFFFu) continue;
+        const int64_t pos = (int64_t)s_base[owner[it]] + pos_in_block[it];
+        if (pos < region_cap)  // an overflow shows in counts[o] > region_cap; the host reports it
+            recio<W>::put_all(rec + ((int64_t)owner[it] * region_cap + pos) * (recio<W>::KW + 2), k0[it], k1[it], tag[it], pref_hi | ids[it]);
     }
 }
 
-template <typename W> __global__ void __launch_bounds__(256) k_shard_tags(const int64_t* __restrict__ rec, int64_t n, uint64_t* __restrict__ tags, uint32_t* __restrict__ idx) {
-    ACX_VGPR_PAD("v23");
+// ---- dedup of the received records -----------------------------------------------------------------------------------------
+// Stamp table (cf. acx_bfs.h): 8-byte slots probed four at a time (one 32-byte sector), all ones = free.
+//   fingerprint(27) | provisional(1) | payload(36)
+// provisional: payload = index of a record of the running chunk (key and tag in rec[payload]); committed: payload = local
+// node id (key in the node arena).  Among equal keys the smaller tag takes the slot with a CAS (retried when another
+// record got there first).  Two byte flags per tag of the chunk, both zero on entry: btook[tag - tag0] is set by a record
+// that takes a slot, brepl[tag - tag0] by the record that pushes it out again -- "took and was not replaced" does not
+// depend on the order in which the two stores land.  k_shard_pack folds them into one 12-bit child mask per parent.
+constexpr unsigned long long kShardFree = ~0ull;
+constexpr unsigned long long kShardProv = 1ull << 36;
+constexpr unsigned long long kShardPayload = kShardProv - 1;
+
+template <typename W>
+__global__ void __launch_bounds__(256) k_shard_insert(SearchDev<W> d, const int64_t* __restrict__ rec, int64_t n, int64_t tag0, uint32_t* __restrict__ cslot,
+                                                      uint8_t* __restrict__ took_i) {
+    ACX_VGPR_PAD("v63");
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    tags[i] = (uint64_t)rec[i * (recio<W>::KW + 2) + recio<W>::KW];
-    idx[i] = (uint32_t)i;
+    const int64_t* r = rec + i * (recio<W>::KW + 2);
+    W c0, c1;
+    recio<W>::get(r, c0, c1);
+    const int64_t tag = r[recio<W>::KW];
+    const uint64_t hk = hash_key<W>(c0, c1);
+    const unsigned long long fp = hk & ~((1ull << 37) - 1);
+    const unsigned long long me = fp | kShardProv | (unsigned long long)i;
+    uint32_t base = (uint32_t)hk & d.stmask & ~3u, probes = 0, took = 0;
+    bool open = true;
+    while (open) {
+        const ulonglong2 lo = *(const ulonglong2*)(d.stab + base), hi = *(const ulonglong2*)(d.stab + base + 2);
+        const unsigned long long v0 = lo.x, v1 = lo.y, v2 = hi.x, v3 = hi.y;
+        auto hot = [&](unsigned long long v) { return v == kShardFree || (v >> 37) == (me >> 37); };
+        uint32_t cand = (hot(v0) ? 1u : 0u) | (hot(v1) ? 2u : 0u) | (hot(v2) ? 4u : 0u) | (hot(v3) ? 8u : 0u);
+        while (cand && open) {
+            const uint32_t j = (uint32_t)__builtin_ctz(cand);
+            cand &= cand - 1;
+            unsigned long long st = j == 0 ? v0 : (j == 1 ? v1 : (j == 2 ? v2 : v3));
+            unsigned long long* slot = d.stab + base + j;
+            for (;;) {  // until this slot is decided for me (it changes only among records of MY key once it holds my key)
+                if (st == kShardFree) {
+                    const unsigned long long old = atomicCAS(slot, kShardFree, me);
+                    if (old == kShardFree) {
+                        took = 1;
+                        open = false;
+                        break;
+                    }
+                    st = old;
+                }
+                if ((st >> 37) != (me >> 37)) break;  // another key's fingerprint: next slot
+                W q0, q1;
+                int64_t qtag = -1;  // committed states beat every record
+                if (st & kShardProv) {
+                    const int64_t* h = rec + (int64_t)(st & kShardPayload) * (recio<W>::KW + 2);
+                    recio<W>::get(h, q0, q1);
+                    qtag = h[recio<W>::KW];
+                } else {
+                    const uint32_t id = (uint32_t)(st & kShardPayload);
+                    q0 = d.k0[id];
+                    q1 = d.k1[id];
+                }
+                if (q0 != c0 || q1 != c1) break;  // same fingerprint, other key: next slot
+                if (qtag < 0 || qtag < tag) {     // seen before, or a record of this chunk with a smaller tag holds it
+                    open = false;
+                    break;
+                }
+                const unsigned long long old = atomicCAS(slot, st, me);  // push the larger tag out
+                if (old == st) {
+                    took = 1;
+                    d.brepl[qtag - tag0] = 1;  // no longer the first discoverer
+                    open = false;
+                    break;
+                }
+                st = old;  // somebody else replaced it meanwhile: look again
+            }
+            if (took) cslot[i] = base + j;
+        }
+        base = (base + 4) & d.stmask;
+        if (open && ++probes > d.stmask / 4) {
+            atomicOr(d.err, kErrTableFull);
+            open = false;
+        }
+    }
+    if (took) d.btook[tag - tag0] = 1;
+    took_i[i] = (uint8_t)took;  // the same flag by record index (coalesced): k_shard_commit skips the records that never took a slot
 }
 
-// candidate arena in tag order: j-th smallest tag -> slot j
+// one 12-bit mask per parent of the chunk: bit a set when child (parent, a) is a new state of this rank
+template <typename W> __global__ void __launch_bounds__(256) k_shard_pack(SearchDev<W> d, int64_t n_parents, int32_t* __restrict__ lmask) {
+    ACX_VGPR_PAD("v23");
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_parents) return;
+    const uint32_t* t = (const uint32_t*)(d.btook + 12 * p);  // 12 bytes, 4-byte aligned
+    const uint32_t* r = (const uint32_t*)(d.brepl + 12 * p);
+    int32_t m = 0;
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+        const uint32_t v = t[w] & ~r[w];  // bytes are 0 / 1
+        m |= (int32_t)(((v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u)) << (4 * w));
+    }
+    lmask[p] = m;
+}
+
+// Winners with a tag below the cutoff become local nodes: id = base + (winners of this rank with a smaller tag), which the
+// per-parent masks give without a sort; gpos likewise from the all-reduced masks.  Their slot is rewritten to the node id.
 template <typename W>
-__global__ void __launch_bounds__(256) k_shard_gather(SearchDev<W> d, const int64_t* __restrict__ rec, const uint64_t* __restrict__ tags_sorted,
-                                                      const uint32_t* __restrict__ idx_sorted, int64_t n, int64_t* __restrict__ ctag, int64_t* __restrict__ cpref) {
-    ACX_VGPR_PAD_W(W, "v31", "v39");
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const int64_t* r = rec + (int64_t)idx_sorted[j] * (recio<W>::KW + 2);
+__global__ void __launch_bounds__(256) k_shard_commit(SearchDev<W> d, const int64_t* __restrict__ rec, int64_t n, int64_t tag0, int64_t cutoff,
+                                                      const int32_t* __restrict__ lmask, const int64_t* __restrict__ lprefix, const int32_t* __restrict__ gmask,
+                                                      const int64_t* __restrict__ gprefix, uint32_t base, int64_t gpos_base, const uint32_t* __restrict__ cslot,
+                                                      const uint8_t* __restrict__ took_i, int64_t* __restrict__ node_pref, uint32_t cap_nodes) {
+    ACX_VGPR_PAD_W(W, "v39", "v47");
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !took_i[i]) return;
+    const int64_t* r = rec + i * (recio<W>::KW + 2);
+    const int64_t tag = r[recio<W>::KW];
+    const int64_t rel = tag - tag0, par = rel / 12;
+    if (tag >= cutoff || d.brepl[rel]) return;
+    const uint32_t below = (1u << (uint32_t)(rel % 12)) - 1u;
+    const uint32_t id = base + (uint32_t)lprefix[par] + (uint32_t)__popc((uint32_t)lmask[par] & below);
+    if (id >= cap_nodes) return;  // the host has refused this commit already (capacity): never reached
     W k0, k1;
     recio<W>::get(r, k0, k1);
-    d.ck0[j] = k0;
-    d.ck1[j] = k1;
-    d.clen[j] = (uint8_t)(keyops<W>::len(k0) + keyops<W>::len(k1));
-    d.cslot[j] = 0;  // "replaced by a smaller tag" flag of k_insert_tab
-    ctag[j] = (int64_t)tags_sorted[j];
-    cpref[j] = r[recio<W>::KW + 1];
+    d.k0[id] = k0;
+    d.k1[id] = k1;
+    d.act[id] = (uint8_t)(tag % 12);
+    d.tlen[id] = (uint8_t)(keyops<W>::len(k0) + keyops<W>::len(k1));
+    d.depth[id] = (uint32_t)(gpos_base + gprefix[par] + __popc((uint32_t)gmask[par] & below));
+    node_pref[id] = r[recio<W>::KW + 1];
+    const uint64_t hk = hash_key<W>(k0, k1);
+    d.stab[cslot[i]] = (hk & ~((1ull << 37) - 1)) | (unsigned long long)id;
 }
 
-template <typename W>
-__global__ void __launch_bounds__(256) k_shard_win_tags(SearchDev<W> d, const int64_t* __restrict__ ctag, int64_t n, int64_t* __restrict__ out) {
+template <typename W> __global__ void k_shard_seed(SearchDev<W> d, W k0, W k1, int64_t* __restrict__ node_pref) {
     ACX_VGPR_PAD("v23");
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n || !d.cflag[j]) return;
-    out[d.cpos[j]] = ctag[j];
+    d.k0[0] = k0;
+    d.k1[0] = k1;
+    d.act[0] = 0xff;
+    d.tlen[0] = (uint8_t)(keyops<W>::len(k0) + keyops<W>::len(k1));
+    d.depth[0] = 0;
+    node_pref[0] = -1;
+    const uint64_t hk = hash_key<W>(k0, k1);
+    d.stab[(uint32_t)hk & d.stmask & ~3u] = hk & ~((1ull << 37) - 1);  // committed stamp of node 0, first slot of its bucket
 }
 
-template <typename W>
-__global__ void __launch_bounds__(256) k_shard_commit(SearchDev<W> d, const int64_t* __restrict__ ctag, const int64_t* __restrict__ cpref, int64_t n,
-                                                      int64_t cutoff, uint32_t base, int64_t* __restrict__ node_pref) {
-    ACX_VGPR_PAD("v31");
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n || !d.cflag[j] || ctag[j] >= cutoff) return;
-    const uint32_t id = base + d.cpos[j];
-    d.k0[id] = d.ck0[j];
-    d.k1[id] = d.ck1[j];
-    d.act[id] = (uint8_t)(ctag[j] % 12);
-    d.tlen[id] = d.clen[j];
-    node_pref[id] = cpref[j];
-}
-
-// number of winners with tag < cutoff: candidates are in tag order, so it is cpos at the first tag >= cutoff
-template <typename W> __global__ void k_shard_count(SearchDev<W> d, const int64_t* __restrict__ ctag, int64_t n, int64_t cutoff, uint32_t* __restrict__ count) {
-    ACX_VGPR_PAD("v15");
-    int64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (ctag[mid] < cutoff) lo = mid + 1;
-        else hi = mid;
-    }
-    *count = lo >= n ? d.cpos[n - 1] + d.cflag[n - 1] : d.cpos[lo];
+template <typename W> __global__ void k_shard_find(SearchDev<W> d, uint32_t lvl_lo, uint32_t lvl_hi, uint32_t gpos, int64_t* __restrict__ out) {
+    ACX_VGPR_PAD("v23");
+    const uint32_t k = lower_gpos(d.depth, lvl_lo, lvl_hi, gpos);
+    *out = (k < lvl_hi && d.depth[k] == gpos) ? (int64_t)k : -1;
 }
 
 template <typename W> struct ShardEngine {
     SearchDev<W> d;
-    DevBuf nodes_buf, cand_buf, tab_buf, scal_buf, tmp_buf, sort_buf;
+    DevBuf nodes_buf, cand_buf, tab_buf, scal_buf;
     int64_t* node_pref = nullptr;  // [cap] parent_ref of every local node
-    int64_t* ctag = nullptr;
-    int64_t* cpref = nullptr;
-    uint64_t* tags_in = nullptr;
-    uint64_t* tags_sorted = nullptr;
-    uint32_t* idx_in = nullptr;
-    uint32_t* idx_sorted = nullptr;
-    uint32_t* commit_count = nullptr;
-    size_t scan_tmp = 0, sort_tmp = 0;
-    uint64_t cap_nodes = 0, cap_cand = 0, n_slots = 0;
-    uint64_t nodes = 0;    // committed local nodes
-    uint32_t epoch = 0;    // insert calls so far (stamps of the inline-key table)
-    int64_t pending = 0;   // candidates of the last insert (awaiting commit)
+    uint32_t* cslot = nullptr;     // [cap_cand] slot a record took
+    uint8_t* took_i = nullptr;     // [cap_cand] "took a slot", by record index
+    int64_t* d_find = nullptr;
+    uint64_t cap_nodes = 0, cap_cand = 0, n_slots = 0, chunk_tags = 0;
+    uint64_t nodes = 0;            // committed local nodes
+    uint64_t lvl_lo = 0, lvl_hi = 0;
+    int64_t pending = 0;           // records of the last insert (awaiting commit)
+    const int64_t* pending_rec = nullptr;
+    int64_t pending_tag0 = 0;
     int rank = 0, world = 1;
 
-    int init(int L, int cyclical, int64_t node_cap, int64_t batch_cap, int rank_, int world_) {
+    int init(int L, int cyclical, int64_t node_cap, int64_t batch_cap, int64_t chunk_parents, int rank_, int world_) {
         memset(&d, 0, sizeof(d));
         d.L = L;
         d.cyclical = cyclical;
@@ -214,9 +321,10 @@ template <typename W> struct ShardEngine {
         world = world_;
         cap_nodes = (uint64_t)node_cap + 64;
         cap_cand = (uint64_t)std::max<int64_t>(batch_cap, 1024);
+        chunk_tags = 12ull * (uint64_t)std::max<int64_t>(chunk_parents, 1);
         n_slots = 1024;
         while (n_slots < 2 * (cap_nodes + cap_cand)) n_slots <<= 1;
-        if (n_slots > (1ull << 31)) return fail(ACX_E_INVAL, "acx_shard: capacity too large for 32-bit node ids");
+        if (n_slots > (1ull << 31) || cap_nodes > (1ull << 31)) return fail(ACX_E_INVAL, "acx_shard: capacity too large for 32-bit node ids");
         size_t o = 0;
         auto take = [&](uint8_t* base, size_t bytes) {
             uint8_t* p = base ? base + o : nullptr;
@@ -229,6 +337,7 @@ template <typename W> struct ShardEngine {
             d.k0 = (W*)take(b, cap_nodes * sizeof(W));
             d.k1 = (W*)take(b, cap_nodes * sizeof(W));
             node_pref = (int64_t*)take(b, cap_nodes * 8);
+            d.depth = (uint32_t*)take(b, cap_nodes * 4);
             d.act = (uint8_t*)take(b, cap_nodes);
             d.tlen = (uint8_t*)take(b, cap_nodes);
             if (pass == 0 && nodes_buf.alloc(o)) return ACX_E_NOMEM;
@@ -236,34 +345,21 @@ template <typename W> struct ShardEngine {
         for (int pass = 0; pass < 2; pass++) {
             uint8_t* b = (uint8_t*)cand_buf.p;
             o = 0;
-            d.ck0 = (W*)take(b, cap_cand * sizeof(W));
-            d.ck1 = (W*)take(b, cap_cand * sizeof(W));
-            ctag = (int64_t*)take(b, cap_cand * 8);
-            cpref = (int64_t*)take(b, cap_cand * 8);
-            tags_in = (uint64_t*)take(b, cap_cand * 8);
-            tags_sorted = (uint64_t*)take(b, cap_cand * 8);
-            idx_in = (uint32_t*)take(b, cap_cand * 4);
-            idx_sorted = (uint32_t*)take(b, cap_cand * 4);
-            d.cslot = (uint32_t*)take(b, cap_cand * 4);
-            d.cflag = (uint32_t*)take(b, cap_cand * 4);
-            d.cpos = (uint32_t*)take(b, cap_cand * 4);
-            d.clen = (uint8_t*)take(b, cap_cand);
+            cslot = (uint32_t*)take(b, cap_cand * 4);
+            took_i = take(b, cap_cand);
+            d.btook = take(b, chunk_tags);  // one byte per tag of a chunk
+            d.brepl = take(b, chunk_tags);
             if (pass == 0 && cand_buf.alloc(o)) return ACX_E_NOMEM;
         }
-        if (tab_buf.alloc(n_slots * sizeof(TabEntry<W>))) return ACX_E_NOMEM;
-        d.tab = (TabEntry<W>*)tab_buf.p;
-        d.tmask = (uint32_t)(n_slots - 1);
+        if (tab_buf.alloc(n_slots * 8)) return ACX_E_NOMEM;
+        d.stab = (unsigned long long*)tab_buf.p;
+        d.stmask = (uint32_t)(n_slots - 1);
         if (scal_buf.alloc(256)) return ACX_E_NOMEM;
         uint8_t* sc = (uint8_t*)scal_buf.p;
         d.err = (uint32_t*)(sc + 24);
         d.min_len = (uint32_t*)(sc + 28);
-        commit_count = (uint32_t*)(sc + 32);
-        if (rocprim::exclusive_scan(nullptr, scan_tmp, d.cflag, d.cpos, 0u, cap_cand, rocprim::plus<uint32_t>(), (hipStream_t) nullptr) != hipSuccess)
-            return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan sizing failed");
-        if (rocprim::radix_sort_pairs(nullptr, sort_tmp, tags_in, tags_sorted, idx_in, idx_sorted, cap_cand, 0, 64, (hipStream_t) nullptr) != hipSuccess)
-            return fail(ACX_E_NODEVICE, "rocprim::radix_sort_pairs sizing failed");
-        if (tmp_buf.alloc(std::max(scan_tmp, sort_tmp) + 256)) return ACX_E_NOMEM;
-        ACX_HIP_TRY(hipMemset(d.tab, 0xff, n_slots * sizeof(TabEntry<W>)));
+        d_find = (int64_t*)(sc + 64);
+        ACX_HIP_TRY(hipMemset(d.stab, 0xff, n_slots * 8));
         ACX_HIP_TRY(hipMemset(scal_buf.p, 0xff, 256));
         ACX_HIP_TRY(hipMemset(d.err, 0, 4));
         ACX_HIP_TRY(hipDeviceSynchronize());  // the fills run on the null stream; the engine's calls arrive on the caller's (possibly non-blocking) stream
@@ -303,72 +399,72 @@ template <typename W> static int shard_root(ShardEngine<W>& E, const int8_t* pre
     return ACX_OK;
 }
 
-template <typename W> static int shard_expand(ShardEngine<W>& E, const int64_t* ids, const int64_t* gpos, int64_t np, int64_t* rec, int64_t* solved, hipStream_t st) {
-    if (np <= 0) return ACX_OK;
-    const int64_t m = 12 * np;
-    hipLaunchKernelGGL(k_shard_expand<W>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, E.d, ids, gpos, np, (int64_t)E.rank << 40, rec,
-                       (unsigned long long*)solved);
+template <typename W> static int shard_seed(ShardEngine<W>& E, const int64_t* rec, hipStream_t st) {
+    if (E.nodes) return fail(ACX_E_INVAL, "acx_shard_seed: the engine already holds nodes");
+    if (rec) {
+        W k0, k1;
+        recio<W>::get(rec, k0, k1);
+        hipLaunchKernelGGL(k_shard_seed<W>, dim3(1), dim3(1), 0, st, E.d, k0, k1, E.node_pref);
+        ACX_HIP_TRY(hipGetLastError());
+        E.nodes = 1;
+    }
+    return ACX_OK;
+}
+
+template <typename W>
+static int shard_expand_routed(ShardEngine<W>& E, int64_t c0, int64_t c1, int64_t* rec, int64_t region_cap, int64_t* counts, int64_t* solved, hipStream_t st) {
+    ACX_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)E.world * 8, st));
+    if (E.world > 64) return fail(ACX_E_INVAL, "acx_shard_expand_routed handles world <= 64");
+    const int64_t np_max = std::min<int64_t>(c1 - c0, (int64_t)(E.lvl_hi - E.lvl_lo));
+    if (np_max <= 0) return ACX_OK;
+    const int64_t m = 12 * np_max;
+    hipLaunchKernelGGL(k_shard_expand_routed<W>, dim3((unsigned)((m + 1024 * kRouteItems - 1) / (1024 * kRouteItems))), dim3(1024), 0, st, E.d, (uint32_t)E.lvl_lo, (uint32_t)E.lvl_hi, (uint32_t)c0,
+                       (uint32_t)c1, (int64_t)E.rank << 40, (uint32_t)E.world, rec, region_cap, (unsigned long long*)counts, (unsigned long long*)solved);
+    ACX_HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
+template <typename W> static int shard_insert(ShardEngine<W>& E, const int64_t* rec, int64_t n, int64_t c0, int64_t n_parents, int32_t* lmask, hipStream_t st) {
+    E.pending = n;
+    E.pending_rec = rec;
+    E.pending_tag0 = 12 * c0;
+    if (n_parents < 0 || 12ull * (uint64_t)n_parents > E.chunk_tags)
+        return fail(ACX_E_CAPACITY, "acx_shard_insert: a chunk of %lld parents exceeds the engine's %llu", (long long)n_parents, (unsigned long long)(E.chunk_tags / 12));
+    if ((uint64_t)n > E.cap_cand) return fail(ACX_E_CAPACITY, "acx_shard_insert: %lld records exceed the batch capacity %llu", (long long)n, (unsigned long long)E.cap_cand);
+    if (n_parents <= 0) return ACX_OK;
+    const dim3 block(256);
+    ACX_HIP_TRY(hipMemsetAsync(E.d.btook, 0, (size_t)n_parents * 12, st));
+    ACX_HIP_TRY(hipMemsetAsync(E.d.brepl, 0, (size_t)n_parents * 12, st));
+    if (n > 0) hipLaunchKernelGGL(k_shard_insert<W>, dim3((unsigned)((n + 255) / 256)), block, 0, st, E.d, rec, n, E.pending_tag0, E.cslot, E.took_i);
+    hipLaunchKernelGGL(k_shard_pack<W>, dim3((unsigned)((n_parents + 255) / 256)), block, 0, st, E.d, n_parents, lmask);
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
 
 template <typename W>
-static int shard_expand_routed(ShardEngine<W>& E, const int64_t* ids, const int64_t* gpos, int64_t np, int64_t* rec, int64_t region_cap, int64_t* counts,
-                               int64_t* solved, hipStream_t st) {
-    ACX_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)E.world * 8, st));
-    if (np <= 0) return ACX_OK;
-    const int64_t m = 12 * np;
-    if (E.world > 64) return fail(ACX_E_INVAL, "acx_shard_expand_routed handles world <= 64");
-    hipLaunchKernelGGL(k_shard_expand_routed<W>, dim3((unsigned)((m + 1023) / 1024)), dim3(1024), 0, st, E.d, ids, gpos, np, (int64_t)E.rank << 40, (uint32_t)E.world,
-                       rec, region_cap, (unsigned long long*)counts, (unsigned long long*)solved);
-    ACX_HIP_TRY(hipGetLastError());
-    return ACX_OK;
-}
-
-template <typename W> static int shard_insert(ShardEngine<W>& E, const int64_t* rec, int64_t n, int tag_bits, int64_t* win_tags, int64_t* n_win, hipStream_t st) {
-    *n_win = 0;
-    E.pending = n;
-    if (n <= 0) return ACX_OK;
-    if ((uint64_t)n > E.cap_cand) return fail(ACX_E_CAPACITY, "acx_shard_insert: %lld records exceed the batch capacity %llu", (long long)n, (unsigned long long)E.cap_cand);
-    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    hipLaunchKernelGGL(k_shard_tags<W>, grid, block, 0, st, rec, n, E.tags_in, E.idx_in);
-    size_t tb = E.sort_tmp;
-    const unsigned end_bit = (unsigned)(tag_bits < 1 ? 64 : (tag_bits > 64 ? 64 : tag_bits));  // tags < 2^tag_bits: fewer radix passes
-    if (rocprim::radix_sort_pairs(E.tmp_buf.p, tb, E.tags_in, E.tags_sorted, E.idx_in, E.idx_sorted, (size_t)n, 0, end_bit, st) != hipSuccess)
-        return fail(ACX_E_NODEVICE, "rocprim::radix_sort_pairs failed");
-    hipLaunchKernelGGL(k_shard_gather<W>, grid, block, 0, st, E.d, rec, E.tags_sorted, E.idx_sorted, n, E.ctag, E.cpref);
-    E.epoch++;
-    hipLaunchKernelGGL(k_insert_tab<W>, grid, block, 0, st, E.d, (uint32_t)n, E.epoch, 0);
-    hipLaunchKernelGGL(k_mark_tab<W>, grid, block, 0, st, E.d, (uint32_t)n);
-    tb = E.scan_tmp;
-    if (rocprim::exclusive_scan(E.tmp_buf.p, tb, E.d.cflag, E.d.cpos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st) != hipSuccess)
-        return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan failed");
-    hipLaunchKernelGGL(k_shard_win_tags<W>, grid, block, 0, st, E.d, E.ctag, n, win_tags);
-    ACX_HIP_TRY(hipGetLastError());
-    uint32_t last[2];
-    ACX_HIP_TRY(hipMemcpyAsync(&last[0], E.d.cpos + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    ACX_HIP_TRY(hipMemcpyAsync(&last[1], E.d.cflag + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    ACX_HIP_TRY(hipStreamSynchronize(st));
-    *n_win = (int64_t)last[0] + last[1];
-    return ACX_OK;
-}
-
-template <typename W> static int shard_commit(ShardEngine<W>& E, int64_t cutoff, int64_t* first_id, int64_t* n_committed, hipStream_t st) {
-    *first_id = (int64_t)E.nodes;
-    *n_committed = 0;
+static int shard_commit(ShardEngine<W>& E, int64_t cutoff, const int32_t* lmask, const int64_t* lprefix, const int32_t* gmask, const int64_t* gprefix,
+                        int64_t gpos_base, int64_t n_commit, hipStream_t st) {
     const int64_t n = E.pending;
     E.pending = 0;
-    if (n <= 0) return ACX_OK;
-    hipLaunchKernelGGL(k_shard_count<W>, dim3(1), dim3(1), 0, st, E.d, E.ctag, n, cutoff, E.commit_count);
-    hipLaunchKernelGGL(k_shard_commit<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, E.d, E.ctag, E.cpref, n, cutoff, (uint32_t)E.nodes,
-                       E.node_pref);
-    ACX_HIP_TRY(hipGetLastError());
-    uint32_t c = 0;
-    ACX_HIP_TRY(hipMemcpyAsync(&c, E.commit_count, 4, hipMemcpyDeviceToHost, st));
+    if (n_commit < 0) return fail(ACX_E_INVAL, "acx_shard_commit: negative count");
+    // checked BEFORE anything is written: an overfull rank must not touch memory behind its node arena
+    if (E.nodes + (uint64_t)n_commit > E.cap_nodes) return fail(ACX_E_CAPACITY, "acx_shard_commit: node capacity exceeded (%llu + %lld > %llu)",
+                                                                (unsigned long long)E.nodes, (long long)n_commit, (unsigned long long)E.cap_nodes);
+    if (n > 0 && n_commit > 0) {
+        hipLaunchKernelGGL(k_shard_commit<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, E.d, E.pending_rec, n, E.pending_tag0, cutoff, lmask, lprefix, gmask,
+                           gprefix, (uint32_t)E.nodes, gpos_base, E.cslot, E.took_i, E.node_pref, (uint32_t)E.cap_nodes);
+        ACX_HIP_TRY(hipGetLastError());
+    }
+    E.nodes += (uint64_t)n_commit;
+    return ACX_OK;
+}
+
+template <typename W> static int shard_find(ShardEngine<W>& E, int64_t gpos, int64_t* id, hipStream_t st) {
+    *id = -1;
+    if (E.lvl_hi == E.lvl_lo || gpos < 0) return ACX_OK;
+    hipLaunchKernelGGL(k_shard_find<W>, dim3(1), dim3(1), 0, st, E.d, (uint32_t)E.lvl_lo, (uint32_t)E.lvl_hi, (uint32_t)gpos, E.d_find);
+    ACX_HIP_TRY(hipMemcpyAsync(id, E.d_find, 8, hipMemcpyDeviceToHost, st));
     ACX_HIP_TRY(hipStreamSynchronize(st));
-    if (E.nodes + c > E.cap_nodes) return fail(ACX_E_CAPACITY, "acx_shard_commit: node capacity exceeded");
-    E.nodes += c;
-    *n_committed = c;
     return ACX_OK;
 }
 
@@ -399,9 +495,9 @@ extern "C" {
 
 int acx_shard_key_words(int L) { return L <= 29 ? 2 : 4; }
 
-acx_shard* acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t batch_cap, int rank, int world) {
+acx_shard* acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t batch_cap, int64_t chunk_parents, int rank, int world) {
     if (!have_device()) return nullptr;
-    if (L < 1 || L > 61 || node_cap < 1 || batch_cap < 1 || world < 1 || rank < 0 || rank >= world) {
+    if (L < 1 || L > 61 || node_cap < 1 || batch_cap < 1 || chunk_parents < 1 || world < 1 || rank < 0 || rank >= world) {
         fail(ACX_E_INVAL, "acx_shard_create: bad argument (1 <= L <= 61)");
         return nullptr;
     }
@@ -411,10 +507,10 @@ acx_shard* acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t batch
     int rc;
     if (h->any.wide) {
         h->any.e128 = new ShardEngine<u128>();
-        rc = h->any.e128->init(L, cyclical, node_cap, batch_cap, rank, world);
+        rc = h->any.e128->init(L, cyclical, node_cap, batch_cap, chunk_parents, rank, world);
     } else {
         h->any.e64 = new ShardEngine<uint64_t>();
-        rc = h->any.e64->init(L, cyclical, node_cap, batch_cap, rank, world);
+        rc = h->any.e64->init(L, cyclical, node_cap, batch_cap, chunk_parents, rank, world);
     }
     if (rc != ACX_OK) {
         delete h->any.e64;
@@ -437,26 +533,42 @@ int acx_shard_root_record(acx_shard* h, const int8_t* h_presentation, int64_t* h
     ACX_SHARD_DISPATCH(&h->any, return shard_root<W>(E, h_presentation, h_record));
 }
 
-int acx_shard_expand(acx_shard* h, const int64_t* d_ids, const int64_t* d_gpos, int64_t np, int64_t* d_records, int64_t* d_solved, void* stream) {
-    if (!h || np < 0 || (np > 0 && (!d_ids || !d_gpos || !d_records || !d_solved))) return fail(ACX_E_INVAL, "acx_shard_expand: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_expand<W>(E, d_ids, d_gpos, np, d_records, d_solved, (hipStream_t)stream));
+int acx_shard_seed(acx_shard* h, const int64_t* h_record, void* stream) {
+    if (!h) return fail(ACX_E_INVAL, "acx_shard_seed: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, return shard_seed<W>(E, h_record, (hipStream_t)stream));
 }
 
-int acx_shard_expand_routed(acx_shard* h, const int64_t* d_ids, const int64_t* d_gpos, int64_t np, int64_t* d_records, int64_t region_cap,
-                            int64_t* d_counts, int64_t* d_solved, void* stream) {
-    if (!h || np < 0 || region_cap < 0 || !d_counts || (np > 0 && (!d_ids || !d_gpos || !d_records || !d_solved)))
+int acx_shard_level_begin(acx_shard* h, int64_t* n_local) {
+    if (!h) return fail(ACX_E_INVAL, "acx_shard_level_begin: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, {
+        E.lvl_lo = E.lvl_hi;
+        E.lvl_hi = E.nodes;
+        if (n_local) *n_local = (int64_t)(E.lvl_hi - E.lvl_lo);
+    });
+    return ACX_OK;
+}
+
+int acx_shard_expand_routed(acx_shard* h, int64_t c0, int64_t c1, int64_t* d_records, int64_t region_cap, int64_t* d_counts, int64_t* d_solved, void* stream) {
+    if (!h || c0 < 0 || c1 < c0 || region_cap < 0 || !d_counts || !d_solved || (region_cap > 0 && !d_records))
         return fail(ACX_E_INVAL, "acx_shard_expand_routed: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_expand_routed<W>(E, d_ids, d_gpos, np, d_records, region_cap, d_counts, d_solved, (hipStream_t)stream));
+    ACX_SHARD_DISPATCH(&h->any, return shard_expand_routed<W>(E, c0, c1, d_records, region_cap, d_counts, d_solved, (hipStream_t)stream));
 }
 
-int acx_shard_insert(acx_shard* h, const int64_t* d_records, int64_t n, int tag_bits, int64_t* d_win_tags, int64_t* n_win, void* stream) {
-    if (!h || n < 0 || !n_win || (n > 0 && (!d_records || !d_win_tags))) return fail(ACX_E_INVAL, "acx_shard_insert: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_insert<W>(E, d_records, n, tag_bits, d_win_tags, n_win, (hipStream_t)stream));
+int acx_shard_insert(acx_shard* h, const int64_t* d_records, int64_t n, int64_t c0, int64_t n_parents, int32_t* d_child_mask, void* stream) {
+    if (!h || n < 0 || c0 < 0 || (n > 0 && !d_records) || (n_parents > 0 && !d_child_mask)) return fail(ACX_E_INVAL, "acx_shard_insert: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, return shard_insert<W>(E, d_records, n, c0, n_parents, d_child_mask, (hipStream_t)stream));
 }
 
-int acx_shard_commit(acx_shard* h, int64_t cutoff_tag, int64_t* first_id, int64_t* n_committed, void* stream) {
-    if (!h || !first_id || !n_committed) return fail(ACX_E_INVAL, "acx_shard_commit: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_commit<W>(E, cutoff_tag, first_id, n_committed, (hipStream_t)stream));
+int acx_shard_commit(acx_shard* h, int64_t cutoff_tag, const int32_t* d_local_mask, const int64_t* d_local_prefix, const int32_t* d_global_mask,
+                     const int64_t* d_global_prefix, int64_t gpos_base, int64_t n_commit, void* stream) {
+    if (!h || (n_commit > 0 && (!d_local_mask || !d_local_prefix || !d_global_mask || !d_global_prefix))) return fail(ACX_E_INVAL, "acx_shard_commit: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, return shard_commit<W>(E, cutoff_tag, d_local_mask, d_local_prefix, d_global_mask, d_global_prefix, gpos_base, n_commit,
+                                                       (hipStream_t)stream));
+}
+
+int acx_shard_find(acx_shard* h, int64_t gpos, int64_t* id, void* stream) {
+    if (!h || !id) return fail(ACX_E_INVAL, "acx_shard_find: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, return shard_find<W>(E, gpos, id, (hipStream_t)stream));
 }
 
 int acx_shard_node_info(acx_shard* h, int64_t id, int64_t* h_info3) {

@@ -165,30 +165,43 @@ int acx_search_many(int kind, const int8_t *h_presentations, int64_t n, int L, i
  * host exchanges candidate records between ranks (RCCL all-to-all) and these calls do the per-rank work.
  * A record is acx_shard_key_words(L) + 2 int64: the packed key, tag = 12 * global_parent_position + action
  * (the order in which the reference generates children), parent_ref = rank << 40 | local node id.
+ * The engine keeps its slice of the frontier on the device: the nodes it commits during a level are the next
+ * level, in global FIFO order.  A level is processed in chunks of consecutive global positions [c0, c1).
  * Orchestration and the cross-rank numbering live in ac-solver_amd/ac_solver/search/sharded.py. */
 typedef struct acx_shard acx_shard;
 int acx_shard_key_words(int L); /* 2 for L <= 29, 4 for L <= 61 */
-acx_shard *acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t batch_cap, int rank, int world);
+/* node_cap: local nodes; batch_cap: records this rank may receive per chunk; chunk_parents: global parents per chunk */
+acx_shard *acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t batch_cap, int64_t chunk_parents, int rank,
+                            int world);
 void acx_shard_destroy(acx_shard *h);
 /* the root as a record (tag 0, parent_ref -1), host buffer of key_words + 2 int64 */
 int acx_shard_root_record(acx_shard *h, const int8_t *h_presentation, int64_t *h_record);
-/* children of the local nodes d_ids[0..np) whose global frontier positions are d_gpos: 12*np records;
+/* the owner of the root passes its record (local node 0, global position 0), every other rank NULL */
+int acx_shard_seed(acx_shard *h, const int64_t *h_record, void *stream);
+/* the nodes committed since the previous call become the current level; *n_local (nullable) = how many */
+int acx_shard_level_begin(acx_shard *h, int64_t *n_local);
+/* children of the local nodes of the current level whose global positions lie in [c0, c1), already routed: a child
+ * whose key belongs to rank o (owner = the hash of ac_solver/search/sharded.py:owner_of, mod world) is written to
+ * d_records[(o * region_cap + i) * (key_words + 2)], i < d_counts[o] (device int64[world], any order inside a region);
+ * d_counts[o] > region_cap reports an overflow.  Children equal to their parent are not sent (visited by construction).
  * d_solved (int64[2]): [0] is min-combined with the tags of children of total length 2, [1] with tag << 8 | code of the
  * moves on which the reference's ACMove raises (a relator emptied): the search raises if such a move precedes its end */
-int acx_shard_expand(acx_shard *h, const int64_t *d_ids, const int64_t *d_gpos, int64_t np, int64_t *d_records,
-                     int64_t *d_solved, void *stream);
-/* the same expansion with the records already routed: a child whose key belongs to rank o (owner = the hash of
- * ac_solver/search/sharded.py:owner_of, mod world) is written to d_records[(o * region_cap + i) * (key_words + 2)],
- * i < d_counts[o] (device int64[world], any order inside a region); d_counts[o] > region_cap reports an overflow */
-int acx_shard_expand_routed(acx_shard *h, const int64_t *d_ids, const int64_t *d_gpos, int64_t np, int64_t *d_records,
-                            int64_t region_cap, int64_t *d_counts, int64_t *d_solved, void *stream);
-/* exact dedup of n received records (any order) against the visited table and among themselves (minimum tag
- * wins); the winners' tags are written ascending to d_win_tags, their count to *n_win; they stay pending.
- * tag_bits: every tag is < 2^tag_bits (bounds the radix-sort passes; 0 = unknown) */
-int acx_shard_insert(acx_shard *h, const int64_t *d_records, int64_t n, int tag_bits, int64_t *d_win_tags,
-                     int64_t *n_win, void *stream);
-/* pending winners with tag < cutoff_tag become local nodes first_id, first_id + 1, ... in tag order */
-int acx_shard_commit(acx_shard *h, int64_t cutoff_tag, int64_t *first_id, int64_t *n_committed, void *stream);
+int acx_shard_expand_routed(acx_shard *h, int64_t c0, int64_t c1, int64_t *d_records, int64_t region_cap,
+                            int64_t *d_counts, int64_t *d_solved, void *stream);
+/* exact dedup of n received records of the chunk starting at global parent c0 (any order) against the visited table and
+ * among themselves (minimum tag wins).  d_child_mask (int32[n_parents], written): bit a of entry p - c0 is set when
+ * child (p, a) is a new state owned by this rank.  The records must stay valid until acx_shard_commit. */
+int acx_shard_insert(acx_shard *h, const int64_t *d_records, int64_t n, int64_t c0, int64_t n_parents,
+                     int32_t *d_child_mask, void *stream);
+/* the new states with tag < cutoff_tag become local nodes, in tag order.  d_local_mask is what acx_shard_insert wrote,
+ * d_global_mask its sum over the ranks; the *_prefix arrays (int64[n_parents]) hold the exclusive running popcounts of
+ * the masks; gpos_base = new states of the level before this chunk; n_commit = this rank's new states below the cutoff
+ * (the orchestrator knows it from the local mask).  ACX_E_CAPACITY, before anything is written, when they do not fit. */
+int acx_shard_commit(acx_shard *h, int64_t cutoff_tag, const int32_t *d_local_mask, const int64_t *d_local_prefix,
+                     const int32_t *d_global_mask, const int64_t *d_global_prefix, int64_t gpos_base, int64_t n_commit,
+                     void *stream);
+/* local id of the node of the current level at global position gpos, -1 when another rank owns it */
+int acx_shard_find(acx_shard *h, int64_t gpos, int64_t *id, void *stream);
 /* h_info3 = (action, total_length, parent_ref) of a local node; the root has action -1, parent_ref -1 */
 int acx_shard_node_info(acx_shard *h, int64_t id, int64_t *h_info3);
 int64_t acx_shard_node_count(acx_shard *h);

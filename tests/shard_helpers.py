@@ -45,16 +45,20 @@ def state_of_key(k0, k1, L):
 
 
 class OracleShardEngine:
+    """The engine interface of ac_solver/search/sharded.py (seed / level_begin / expand_routed / insert / commit / find /
+    node_info / status) on the CPU: NumPy + the C oracle's ACMove.  Test infrastructure only."""
+
     KW = 2
 
-    def __init__(self, L, cyclical, node_cap, batch_cap, rank, world):
+    def __init__(self, L, cyclical, node_cap, batch_cap, chunk_parents, rank, world):
         assert L <= 29
         self.L, self.cyc, self.rank, self.world = L, bool(cyclical), rank, world
-        self.batch_cap = batch_cap
+        self.batch_cap, self.node_cap = batch_cap, node_cap
         self.device = torch.device("cpu")
-        self.states, self.prefs, self.acts, self.tlens = [], [], [], []
+        self.states, self.prefs, self.acts, self.tlens, self.gpos = [], [], [], [], []
         self.visited = {}
         self.pending = []
+        self.lvl_lo = self.lvl_hi = 0
         self.err = 0
         self.min_len = 1 << 30
 
@@ -62,48 +66,84 @@ class OracleShardEngine:
         k0, k1 = key_of_state(np.asarray(p), self.L)
         return np.array([k0, k1, 0, -1], np.int64)
 
-    def expand(self, ids, gpos, solved):
+    def _add(self, k0, k1, act, pref, gpos):
+        st = state_of_key(k0, k1, self.L)
+        self.visited[(k0, k1)] = len(self.states)
+        self.states.append(st)
+        self.prefs.append(pref)
+        self.acts.append(act)
+        self.tlens.append(int(np.count_nonzero(st)))
+        self.gpos.append(gpos)
+
+    def seed(self, record):
+        if record is not None:
+            self._add(int(record[0]), int(record[1]), 0, -1, 0)
+
+    def level_begin(self):
+        self.lvl_lo, self.lvl_hi = self.lvl_hi, len(self.states)
+        return self.lvl_hi - self.lvl_lo
+
+    def expand_routed(self, c0, c1, n_local, solved, world):
+        from ac_solver.search.sharded import owner_of
+
         rows = []
-        for nid, gp in zip(ids.tolist(), gpos.tolist()):
+        for nid in range(self.lvl_lo, self.lvl_hi):
+            gp = self.gpos[nid]
+            if not c0 <= gp < c1:
+                continue
             st = np.repeat(self.states[nid][None], 12, axis=0)
             out, lens, err = O.move_batch(st, np.arange(12, dtype=np.uint8), self.L, cyclical=self.cyc)
             for a in range(12):
-                if err[a]:
-                    solved[1] = min(int(solved[1]), ((12 * gp + a) << 8) | int(err[a]))
-                k0, k1 = key_of_state(out[a], self.L)
                 tag = 12 * gp + a
+                if err[a]:
+                    solved[1] = min(int(solved[1]), (tag << 8) | int(err[a]))
                 tl = int(lens[a].sum())
                 self.min_len = min(self.min_len, tl)
                 if tl == 2:
                     solved[0] = min(int(solved[0]), tag)
+                if np.array_equal(out[a], self.states[nid]):
+                    continue  # an unchanged child is its (visited) parent: never sent
+                k0, k1 = key_of_state(out[a], self.L)
                 rows.append([k0, k1, tag, (self.rank << 40) | nid])
-        return torch.tensor(rows, dtype=torch.int64).reshape(-1, 4)
+        recs = torch.tensor(rows, dtype=torch.int64).reshape(-1, 4)
+        owners = owner_of(recs[:, :2], world) if len(rows) else torch.zeros(0, dtype=torch.int64)
+        return [recs[owners == o].contiguous() for o in range(world)]
 
-    def insert(self, recv, max_tag=None):
+    def insert(self, recv, c0, n_parents):
         recs = sorted(recv.tolist(), key=lambda r: r[2])
         seen, self.pending = set(), []
+        mask = torch.zeros(n_parents, dtype=torch.int32)
         for k0, k1, tag, pref in recs:
             if (k0, k1) in self.visited or (k0, k1) in seen:
                 continue
             seen.add((k0, k1))
             self.pending.append((k0, k1, tag, pref))
-        return torch.tensor([r[2] for r in self.pending], dtype=torch.int64)
+            mask[tag // 12 - c0] |= 1 << (tag % 12)
+        self.c0 = c0
+        return mask
 
-    def commit(self, cutoff):
-        first = len(self.states)
-        n = 0
-        for k0, k1, tag, pref in self.pending:
-            if tag >= cutoff:
-                break
-            st = state_of_key(k0, k1, self.L)
-            self.visited[(k0, k1)] = len(self.states)
-            self.states.append(st)
-            self.prefs.append(pref)
-            self.acts.append(tag % 12)
-            self.tlens.append(int(np.count_nonzero(st)))
-            n += 1
+    def commit(self, cutoff, lmask, lprefix, gmask, gprefix, gpos_base, n_commit):
+        todo = [r for r in self.pending if r[2] < cutoff]
+        assert len(todo) == n_commit, (len(todo), n_commit)
+        if len(self.states) + n_commit > self.node_cap + 64:
+            raise RuntimeError("engine capacity exceeded")
+        for k0, k1, tag, pref in todo:
+            par, a = tag // 12 - self.c0, tag % 12
+            gp = gpos_base + int(gprefix[par]) + bin(int(gmask[par]) & ((1 << a) - 1)).count("1")
+            lid = len(self.states)
+            assert lid == self._base(lprefix, lmask, par, a, todo)
+            self._add(k0, k1, a, pref, gp)
         self.pending = []
-        return first, n
+
+    def _base(self, lprefix, lmask, par, a, todo):
+        first = len(self.states) - sum(1 for r in todo if (r[0], r[1]) in self.visited)
+        return first + int(lprefix[par]) + bin(int(lmask[par]) & ((1 << a) - 1)).count("1")
+
+    def find(self, gpos):
+        for nid in range(self.lvl_lo, self.lvl_hi):
+            if self.gpos[nid] == gpos:
+                return nid
+        return -1
 
     def node_info(self, nid):
         return (-1 if self.prefs[nid] < 0 else self.acts[nid]), self.tlens[nid], self.prefs[nid]
@@ -131,10 +171,8 @@ class ThreadComm:
         self.s.barrier.wait()
         return vals
 
-    def all_to_all_rows(self, send, counts):
-        offs = np.concatenate([[0], np.cumsum(counts)])
-        pieces = [send[offs[d]:offs[d + 1]] for d in range(self.world)]
-        everyone = self._exchange(pieces)
+    def all_to_all_regions(self, regions):
+        everyone = self._exchange(list(regions))
         return torch.cat([everyone[src][self.rank] for src in range(self.world)])
 
     def all_gather_var(self, t):

@@ -187,48 +187,61 @@ def test_sharded_bfs_hip_engine_matches_reference(search, golden_json, world):
 
 @pytest.mark.parametrize("L", [25, 36])
 def test_device_routing_matches_owner_of(search, L):
-    """acx_shard_expand_routed groups the children by the same owner function the orchestrator uses (owner_of), both key widths"""
+    """acx_shard_expand_routed groups the children by the same owner function the orchestrator uses (owner_of), both key
+    widths; fed back into ONE engine (as if it owned every key) the engine calls reproduce a plain BFS level by level."""
     import torch
 
     from ac_solver.search.sharded import HipShardEngine, owner_of
+    from oracle import ac_oracle as O
 
     ak3 = np.zeros(2 * L, np.int8)
     ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
     ak3[L:L + 6] = [1, 2, 1, -2, -1, -2]
+    pop12 = torch.tensor([bin(v).count("1") for v in range(4096)], dtype=torch.int64, device="cuda")
     for world in (2, 3, 8):
-        eng = HipShardEngine(L, False, 100000, 200000, 0, world)
+        eng = HipShardEngine(L, False, 100000, 200000, 4096, 0, world)
         KW = eng.KW
-        root = torch.tensor(eng.root_record(ak3)[None, :], dtype=torch.int64, device=eng.device)
-        eng.insert(root)
-        first, cnt = eng.commit(1 << 62)
-        key_of = {0: tuple(root[0, :KW].tolist())}  # node id -> packed key
-        n_unmoved = 0
-        ids = torch.arange(first, first + cnt, dtype=torch.int64, device=eng.device)
-        gpos = torch.zeros_like(ids)
-        for _ in range(4):  # a few levels: 12, then up to 144, ... children
+        eng.seed(eng.root_record(ak3))
+        level = [ak3.copy()]          # host mirror of the frontier (oracle moves), in global FIFO order
+        visited = {tuple(ak3.tolist())}
+        first_id = 0                  # local id of the level's first node (this engine commits everything: ids are FIFO order)
+        for _ in range(4):            # a few levels: 12, then up to 144, ... children
+            F = len(level)
+            n_local = eng.level_begin()
+            assert n_local == F
             solved = torch.tensor([1 << 62, 1 << 62], dtype=torch.int64, device=eng.device)
-            plain = eng.expand(ids, gpos, solved)
-            send, counts = eng.expand_routed(ids, gpos, solved, world)
-            assert plain.shape[0] == 12 * ids.numel()
-            rows = plain.tolist()
-            # a child equal to its parent (a move that changed nothing) is never new and is not routed at all
-            moved = [r for r in rows if tuple(r[:KW]) != key_of[r[KW + 1] & ((1 << 40) - 1)]]
-            assert sum(counts) == len(moved) <= len(rows)
-            n_unmoved += len(rows) - len(moved)
-            owners = owner_of(torch.tensor([r[:KW] for r in moved], dtype=torch.int64), world).tolist()
-            got_rows = send.tolist()
+            regions = eng.expand_routed(0, F, n_local, solved, world)
+            send, counts = torch.cat(regions), [int(r.shape[0]) for r in regions]
+            # expected children (the unchanged ones are never sent), tag -> state
+            want, nxt = {}, []
+            for gp, st in enumerate(level):
+                out, lens, err = O.move_batch(np.repeat(st[None], 12, axis=0), np.arange(12, dtype=np.uint8), L, cyclical=False)
+                for a in range(12):
+                    if not np.array_equal(out[a], st):
+                        want[12 * gp + a] = out[a]
+            rows = send.tolist()
+            assert sum(counts) == len(rows) == len(want)
+            assert sorted(r[KW] for r in rows) == sorted(want)
+            owners = owner_of(send[:, :KW].cpu(), world).tolist()
             off = 0
             for o, c in enumerate(counts):
-                want = sorted(tuple(r) for r, w in zip(moved, owners) if w == o)
-                assert want == sorted(map(tuple, got_rows[off:off + c])), (L, world, o)
+                assert all(w == o for w in owners[off:off + c]), (L, world, o)
                 off += c
-            win = eng.insert(plain, None).tolist()
-            first, cnt = eng.commit(1 << 62)
-            by_tag = {r[KW]: tuple(r[:KW]) for r in rows}
-            for k, tag in enumerate(win[:cnt]):
-                key_of[first + k] = by_tag[tag]
-            ids = torch.arange(first, first + cnt, dtype=torch.int64, device=eng.device)
-            gpos = torch.arange(cnt, dtype=torch.int64, device=eng.device)
+            assert all(r[KW + 1] == (0 << 40) | (first_id + r[KW] // 12) for r in rows)  # parent_ref = rank << 40 | local id
+            lmask = eng.insert(send, 0, F)
+            lpop = pop12[lmask.to(torch.int64)]
+            lincl = torch.cumsum(lpop, 0)
+            n_new = int(lincl[-1])
+            eng.commit(1 << 62, lmask, lincl - lpop, lmask, lincl - lpop, 0, n_new)
+            for tag in sorted(want):
+                key = tuple(want[tag].tolist())
+                if key not in visited:
+                    visited.add(key)
+                    nxt.append(want[tag])
+                    assert (int(lmask[tag // 12]) >> (tag % 12)) & 1, tag
+            assert n_new == len(nxt)
+            first_id += F
+            level = nxt
 
 
 def test_many_searches_overlapped_equal_single(search, golden_json):
@@ -301,8 +314,8 @@ def _bfs_through_comm(bfs_sharded, p, budget, comm):
         """world-size-1 communicator that still routes every call through torch.distributed"""
         rank, world = 0, 1
 
-        def all_to_all_rows(self, send, counts):
-            return comm.all_to_all_rows(send, counts)
+        def all_to_all_regions(self, regions):
+            return comm.all_to_all_regions(regions)
 
         def all_gather_var(self, t):
             return comm.all_gather_var(t)
@@ -338,3 +351,76 @@ def test_config4_all_1190_ms_presentations_bfs_1e4_vs_oracle(search, golden_json
             if (ok, path) != (wok, wpath) or st["nodes"] != wst["nodes"] or st["expanded"] != wst["expanded"]:
                 bad.append((lo + k, ok, wok, st["nodes"], wst["nodes"], st["expanded"], wst["expanded"]))
     assert not bad, bad[:10]
+
+
+def _two_process_worker(rank, world, port, q):
+    """child process of test_sharded_bfs_two_processes_share_one_gpu: its own HIP context on cuda:0, gloo between the processes"""
+    import os
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ac_solver.search.sharded import TorchDistComm, bfs_sharded
+
+        class HostStaged(TorchDistComm):
+            """gloo moves host tensors: device tensors are staged through the host around every collective"""
+
+            def __init__(self):
+                super().__init__(torch.device("cpu"))
+
+            def all_to_all_regions(self, regions):
+                return super().all_to_all_regions([r.cpu() for r in regions]).to("cuda")
+
+            def all_reduce(self, t, op):
+                h = t.cpu()
+                super().all_reduce(h, op)
+                t.copy_(h)
+                return t
+
+        torch.cuda.set_device(0)
+        comm = HostStaged()
+        ak2 = [1, 1, -2, -2, -2, 0, 0, 1, 2, 1, -2, -1, -2, 0]
+        ak3 = np.zeros(50, np.int8)
+        ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+        ak3[25:31] = [1, 2, 1, -2, -1, -2]
+        res = [bfs_sharded(p, b, cyclically_reduce_after_moves=c, comm=comm, batch_parents=bp, want_stats=True)
+               for p, b, c, bp in ((ak2, 10**6, False, 1 << 16), (ak2, 500, True, 7), (ak3, 300000, False, 1 << 14), (ak3, 20000, True, 333))]
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_bfs_two_processes_share_one_gpu():
+    """The first multi-PROCESS run of acx_shard_*: two freshly spawned processes (the parent touches no GPU API before the
+    spawn), each with its own engine on cuda:0, exchanging records over gloo with host-staged tensors.  Every rank must
+    return the oracle's answer."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from oracle import ac_oracle as O
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_process_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=500) for _ in range(2))
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    ak2 = [1, 1, -2, -2, -2, 0, 0, 1, 2, 1, -2, -1, -2, 0]
+    ak3 = np.zeros(50, np.int8)
+    ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+    ak3[25:31] = [1, 2, 1, -2, -1, -2]
+    cases = ((ak2, 10**6, False), (ak2, 500, True), (ak3, 300000, False), (ak3, 20000, True))
+    for r in (0, 1):
+        for (p, b, c), (ok, path, st) in zip(cases, got[r]):
+            wok, wpath, wst = O.bfs(p, b, cyclically_reduce_after_moves=c, stats=True)
+            assert (ok, path) == (wok, wpath), (r, b, c)
+            assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (r, b, c, st, wst)

@@ -79,10 +79,10 @@ def test_a_failing_rank_takes_every_rank_down_without_deadlock():
     from ac_solver.search.sharded import bfs_sharded
 
     class Flaky(OracleShardEngine):
-        def insert(self, recv, max_tag=None):
+        def insert(self, recv, c0, n_parents):
             if self.rank == 1 and len(self.states) > 20:
                 raise RuntimeError("engine capacity exceeded (simulated)")
-            return super().insert(recv, max_tag)
+            return super().insert(recv, c0, n_parents)
 
     def run(comm):
         try:

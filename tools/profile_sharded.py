@@ -14,7 +14,7 @@ world = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 bp = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
 
 def run(comm):
-    sh.bfs_sharded(ak3, 20000, comm=comm)
+    sh.bfs_sharded(ak3, budget, comm=comm, batch_parents=bp)  # warm-up at full size: the first run pays for every device allocation
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ok, path, st = sh.bfs_sharded(ak3, budget, comm=comm, batch_parents=bp, want_stats=True)
