@@ -48,6 +48,7 @@ _FLAGS = [
     ("--epsilon", float, 0.00001, "epsilon of the Adam optimizer"),
     # not in the reference: lifts its `num_envs <= number of initial states` assert (agents/environment.py:80-83)
     ("--tile-initial-states", "bool", False, "allow more environments than initial states: environment i starts from state i mod n"),
+    ("--fused-policy", "bool", False, "rollouts sample through the fused MFMA policy kernel (bf16 operands, f32 accumulation) instead of the f32 torch modules"),
 ]
 
 

@@ -1,0 +1,69 @@
+"""Rollout-time inference of the PPO agent on the matrix cores: `acx_policy_sample` (csrc/acx_policy.hip) evaluates actor
+and critic (reference: ac_solver/agents/ppo_agent.py:11-109, two tanh MLPs of width 256) on every environment and samples the
+action in one kernel -- bf16 operands, f32 accumulation.  Opt-in (`--fused-policy` of ac_solver.agents.ppo): the reference's
+policy is f32 torch, which stays the default and is what the PPO update always differentiates."""
+import numpy as np
+import torch
+
+from ac_solver import _acx
+
+
+def _fragments(w, rows, cols):
+    """nn.Linear weight [out, in] zero-padded to [rows, cols] (multiples of 32 / 16) -> the A-operand fragments of
+    v_mfma_f32_32x32x16_bf16 in the order the kernel reads them: [out block][k step][lane][8], lane = 32 * (k half) + row"""
+    out, inp = w.shape
+    pad = torch.zeros((rows, cols), dtype=torch.float32, device=w.device)
+    pad[:out, :inp] = w.detach().float()
+    t = pad.view(rows // 32, 32, cols // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()  # [ob][ks][h][r][j]
+    return t.view(-1).to(torch.bfloat16)
+
+
+def supported(agent, in_dim):
+    def shape_ok(seq, out):
+        lin = [m for m in seq if isinstance(m, torch.nn.Linear)]
+        return (len(lin) == 3 and lin[0].in_features == in_dim and lin[0].out_features == 256 and lin[1].in_features == 256
+                and lin[1].out_features == 256 and lin[2].in_features == 256 and lin[2].out_features == out)
+
+    n_act = [m for m in agent.actor if isinstance(m, torch.nn.Linear)][-1].out_features
+    return in_dim <= 80 and n_act <= 16 and shape_ok(agent.actor, n_act) and shape_ok(agent.critic, 1)
+
+
+def pack_network(seq, in_dim):
+    """[Linear, Tanh, Linear, Tanh, Linear] -> one uint8 device tensor: fragments of the three layers, then the f32 biases"""
+    lin = [m for m in seq if isinstance(m, torch.nn.Linear)]
+    ks1 = (in_dim + 15) // 16
+    parts = [_fragments(lin[0].weight, 256, 16 * ks1), _fragments(lin[1].weight, 256, 256), _fragments(lin[2].weight, 32, 256)]
+    b3 = torch.zeros(32, dtype=torch.float32, device=lin[2].bias.device)
+    b3[:lin[2].out_features] = lin[2].bias.detach().float()
+    raw = [p.view(torch.uint8) for p in parts] + [b.detach().float().contiguous().view(torch.uint8) for b in (lin[0].bias, lin[1].bias)] + [b3.view(torch.uint8)]
+    out = torch.cat(raw).contiguous()
+    assert out.numel() == _acx.lib.acx_policy_packed_bytes(in_dim)
+    return out
+
+
+class FusedPolicy:
+    """`sample(obs, action, logprob, value)` = agent.get_action_and_value(obs) for a rollout step, written into the caller's
+    tensors; `refresh()` re-packs the weights (call it after every optimizer step)."""
+
+    def __init__(self, agent, in_dim, seed=0):
+        if not supported(agent, in_dim):
+            raise ValueError("the fused policy kernel handles in -> 256 -> 256 -> out tanh networks with in <= 80 and out <= 16")
+        _acx.require_device()
+        self.agent, self.in_dim = agent, int(in_dim)
+        self.n_actions = [m for m in agent.actor if isinstance(m, torch.nn.Linear)][-1].out_features
+        self._seed = np.random.default_rng(seed)
+        self.refresh()
+
+    def refresh(self):
+        with torch.no_grad():
+            self.actor = pack_network(self.agent.actor, self.in_dim)
+            self.critic = pack_network(self.agent.critic, self.in_dim)
+
+    def sample(self, obs, action, logprob, value):
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[-1] == self.in_dim
+        assert action.dtype == torch.int64 and logprob.dtype == torch.float32 and value.dtype == torch.float32
+        n = obs.numel() // self.in_dim
+        seed = int(self._seed.integers(0, 1 << 63))
+        _acx.check(_acx.lib.acx_policy_sample(obs.data_ptr(), n, self.in_dim, self.actor.data_ptr(), self.critic.data_ptr(), self.n_actions, seed,
+                                              action.data_ptr(), logprob.data_ptr(), value.data_ptr(), torch.cuda.current_stream(obs.device).cuda_stream),
+                   "acx_policy_sample")

@@ -3,6 +3,7 @@
 import math
 
 import numpy as np
+import torch
 from torch import nn
 from torch.distributions import Categorical
 
@@ -44,3 +45,13 @@ class Agent(nn.Module):
         if action is None:
             action = dist.sample()
         return action, dist.log_prob(action), dist.entropy(), self.critic(x)
+
+    def sample_action_and_value(self, x):
+        """`get_action_and_value(x)` without a host synchronisation, so that a rollout step can be captured into a hipGraph
+        (torch's Categorical validates its arguments with a device-to-host read).  The action is drawn with the Gumbel-max
+        trick -- argmax(log p + G), G ~ Gumbel(0, 1), is an exact sample of Categorical(p) -- from the same logits; the
+        log-probability, entropy and value are the same expressions.  -> (action, log-probability, entropy, value)"""
+        logp = torch.log_softmax(self.actor(x).float(), dim=-1)
+        u = torch.rand_like(logp).clamp_(min=1e-20, max=1.0 - 1e-7)
+        action = torch.argmax(logp - torch.log(-torch.log(u)), dim=-1)
+        return action, logp.gather(-1, action.unsqueeze(-1)).squeeze(-1), -(logp.exp() * logp).sum(-1), self.critic(x)

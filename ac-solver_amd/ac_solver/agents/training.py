@@ -150,6 +150,11 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
     round1_complete = False
     beta = None if args.is_loss_clip else args.beta
     params = list(agent.parameters())
+    fused = None
+    if getattr(args, "fused_policy", False):  # opt-in: rollout inference on the matrix cores (agents/fused_policy.py); the update stays f32 torch
+        from ac_solver.agents.fused_policy import FusedPolicy
+
+        fused = FusedPolicy(agent, int(np.prod(obs_shape)), seed=args.seed)
     # data parallel: the Miller-Schupp states are dealt rank::world (get_env), so the first curriculum round of a rank
     # walks its own residue class; a single fixed initial state has nothing to deal
     stride = world if dist_on and world > 1 and len(initial_states) > 1 else 1
@@ -181,15 +186,21 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             optimizer.param_groups[0]["lr"] = get_curr_lr(update, args.lr_decay, args.warmup_period, args.learning_rate,
                                                           args.learning_rate * args.min_lr_frac, num_updates)
         events = []  # (step, env, next curriculum state) of this rollout
+        if fused is not None:
+            fused.refresh()  # the weights of the last update
 
         # ---------------------------------------------------------------- rollout (device resident) ----
         for step in range(T):
             global_step += N * world
-            with torch.no_grad():
-                action, logprob, _, value = agent.get_action_and_value(obs[step])
-            actions[step] = action
-            logprobs[step] = logprob
-            values[step] = value.flatten()
+            if fused is not None:
+                fused.sample(obs[step], actions[step], logprobs[step], values[step])
+                action = actions[step]
+            else:
+                with torch.no_grad():
+                    action, logprob, _, value = agent.get_action_and_value(obs[step])
+                actions[step] = action
+                logprobs[step] = logprob
+                values[step] = value.flatten()
             envs.step(action, out=(obs[step + 1], rewards[step], term[step + 1], trunc), check_errors=False)
             if normalizer is not None:  # NormalizeReward, then TransformReward(clip) as make_env stacks them
                 rewards[step] = normalizer(rewards[step], term[step + 1])

@@ -346,9 +346,19 @@ def extra_env_numbers(dev, pool):
         trunc = torch.zeros(n, dtype=torch.bool, device=dev)
         obs[0].copy_(env.reset()[0])
 
-        def rollout(with_policy):
+        from ac_solver.agents.fused_policy import FusedPolicy
+
+        fused = FusedPolicy(agent, 2 * L)
+        act = torch.zeros((T, n), dtype=torch.int64, device=dev)
+        logp = torch.zeros((T, n), device=dev)
+        val = torch.zeros((T, n), device=dev)
+
+        def rollout(policy):
             for t in range(T):
-                if with_policy:
+                if policy == "fused":      # acx_policy_sample: both MLPs + the action draw in one MFMA kernel (bf16 operands, f32 accumulation)
+                    fused.sample(obs[t], act[t], logp[t], val[t])
+                    action = act[t]
+                elif policy == "torch":    # the reference's f32 torch modules
                     with torch.no_grad():
                         action = agent.get_action_and_value(obs[t])[0]
                 else:
@@ -357,17 +367,21 @@ def extra_env_numbers(dev, pool):
 
         tape8 = torch.randint(0, 12, (T, n), dtype=torch.uint8, device=dev)
         res = {}
-        for name, flag in (("policy_and_env", True), ("env_only", False)):
-            rollout(flag)
+        for name in ("fused", "torch", "none"):
+            rollout(name)
             torch.cuda.synchronize()
             e0.record()
-            rollout(flag)
+            rollout(name)
             e1.record()
             torch.cuda.synchronize()
             res[name] = n * T / e0.elapsed_time(e1) * 1e3
-        out["ppo_rollout"] = {"envs": n, "steps": T, "env_steps_per_s": res["policy_and_env"], "env_steps_per_s_env_kernel_only": res["env_only"],
-                              "policy": "50-256-256-12 tanh MLP actor + critic, fp32, torch", "obs": "float32 [T+1, N, 50] written by the env kernel",
-                              "algorithmic_GBps_env_only": (12 * L + 10) * res["env_only"] / 1e9}
+        flop = 2.0 * ((2 * L) * 256 + 256 * 256 + 256 * 12) + 2.0 * ((2 * L) * 256 + 256 * 256 + 256)  # actor + critic, per environment
+        out["ppo_rollout"] = {"envs": n, "steps": T, "env_steps_per_s": res["fused"], "env_steps_per_s_torch_f32_policy": res["torch"],
+                              "env_steps_per_s_env_kernel_only": res["none"],
+                              "policy": "50-256-256-12 / 50-256-256-1 tanh MLPs; fused = acx_policy_sample (v_mfma_f32_32x32x16_bf16, f32 accumulation, "
+                                        "Gumbel-max draw in the kernel), torch = the reference's f32 modules",
+                              "policy_tflops_fused": flop * n / max(n / res["fused"] - n / res["none"], 1e-9) / 1e12,
+                              "obs": "float32 [T+1, N, 50] written by the env kernel", "algorithmic_GBps_env_only": (12 * L + 10) * res["none"] / 1e9}
     except Exception as e:
         out["ppo_rollout"] = {"error": f"{type(e).__name__}: {e}"}
     return out

@@ -208,6 +208,18 @@ int64_t acx_shard_node_count(acx_shard *h);
 /* sticky move-error bits (a move emptied a relator: the reference raises) and the smallest total length seen */
 int acx_shard_status(acx_shard *h, int32_t *err, int32_t *min_len);
 
+/* ---- PPO rollout: fused policy inference ---------------------------------------------------------------
+ * The agent of ac_solver/agents/ppo_agent.py:11-109 -- actor and critic, each in_dim -> 256 -> 256 -> {n_actions, 1} with
+ * tanh -- evaluated on n_env observations and sampled, in ONE kernel on the matrix cores (bf16 operands, f32 accumulation):
+ * d_action[e] ~ Categorical(softmax(actor(obs[e]))) (Gumbel-max with a counter-based hash of (seed, e, action): pass a
+ * fresh seed per call), d_logprob[e] its log-probability, d_value[e] = critic(obs[e]).  d_obs [n_env, in_dim] f32 row-major
+ * (what acx_env_step writes with ACX_F32).  d_actor / d_critic: the networks packed by
+ * ac_solver/agents/fused_policy.py:pack_network (acx_policy_packed_bytes(in_dim) bytes each).  in_dim <= 80,
+ * n_actions <= 16, hidden width 256.  Inference only; the PPO update runs in torch on the f32 master weights. */
+int acx_policy_sample(const float *d_obs, int64_t n_env, int in_dim, const void *d_actor, const void *d_critic,
+                      int n_actions, uint64_t seed, int64_t *d_action, float *d_logprob, float *d_value, void *stream);
+int64_t acx_policy_packed_bytes(int in_dim);
+
 /* ---- neighbourhood sizes ------------------------------------------------------------
  * Replaces `neibourhood` of the reference's C++ side program (barcode_analysis/5_steps_neibourhoods/neibourhoods.cpp:18-54,
  * moves and word arithmetic AC_UTILS_no_hash.cpp:83-211): number of distinct SORTED pairs of freely reduced relators

@@ -110,3 +110,17 @@ def test_data_files_reproduce_the_published_results(tmp_path, golden_json):
     for k in (0, 100, 532):  # a path file line really trivialises its presentation
         path = from_legacy_path(paths[k])
         assert replay_path(solved[k], path) == [l for _, l in path[1:]] and path[-1][1] == 2
+
+
+@pytest.mark.timeout(600)
+def test_train_ppo_runs_baseline_config5_shape(tmp_path, monkeypatch):
+    """BASELINE config 5 per GPU: `python -m ac_solver.agents.ppo --num-envs 131072` -- more environments than the 1190 initial
+    states (--tile-initial-states lifts the reference's assert), rollouts through the fused MFMA policy kernel; two updates."""
+    from ac_solver.agents.ppo import train_ppo
+
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(AssertionError):  # the reference's limit stays the default (agents/environment.py:80-83)
+        train_ppo(["--num-envs", "2048", "--num-steps", "4", "--total-timesteps", "8192"])
+    stats = train_ppo(["--num-envs", "131072", "--num-steps", "8", "--total-timesteps", str(2 * 8 * 131072), "--tile-initial-states", "--fused-policy",
+                       "--horizon-length", "200", "--num-minibatches", "4"])
+    assert stats["charts/global_step"] == 2 * 8 * 131072 and np.isfinite(stats["losses/value_loss"]) and np.isfinite(stats["losses/policy_loss"])

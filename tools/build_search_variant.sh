@@ -8,5 +8,5 @@ cd "$ROOT/ac-solver_amd/csrc"
 F=${ACX_BASEFLAGS:-"--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed -mllvm -amdgpu-kernarg-preload-count=14"}
 mkdir -p /tmp/acx_var
 /opt/rocm/bin/hipcc $F "$@" -c acx_search.hip -o /tmp/acx_var/acx_search_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../lib/var_$name.so acx_step.o /tmp/acx_var/acx_search_$name.o acx_shard.o acx_ball.o acx_simplex.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../lib/var_$name.so acx_step.o /tmp/acx_var/acx_search_$name.o acx_shard.o acx_ball.o acx_simplex.o acx_policy.o
 echo built ../lib/var_$name.so
