@@ -81,8 +81,12 @@ class _EnvList:
 
 class ACVecEnv:
     def __init__(self, initial_states, horizon_length=1000, obs_dtype="int8", clip_rewards=None, record_actions=True,
-                 final_info=True, device=None):
+                 final_info=True, device=None, reward_dtype="float32"):
+        """`reward_dtype="float64"`: `step` (without `out`) returns the rewards as float64, the dtype gymnasium's
+        SyncVectorEnv hands to the reference's training loop; the kernel always writes float32 (exact: rewards are integers
+        below 2^24 in magnitude, or clipped)."""
         torch = _torch()
+        self._reward_f64 = {"float32": False, "float64": True}[reward_dtype]
         _acx.require_device()
         states = np.asarray(initial_states)
         if states.ndim != 2 or states.shape[1] % 2:
@@ -178,6 +182,8 @@ class ACVecEnv:
                     final_obs[i] = rows[k]
                     final_info[i] = {"actions": self.get_actions(int(i), finished=True)} if (done_h[i] and self.record_actions) else {}
                 infos = {"final_observation": final_obs, "_final_observation": fin.copy(), "final_info": final_info, "_final_info": fin.copy()}
+        if self._reward_f64 and out is None:
+            rew = rew.to(_torch().float64)
         return obs, rew, done, trunc, infos
 
     def rollout(self, tape, reward=None, terminated=None, truncated=None, autoreset=True):

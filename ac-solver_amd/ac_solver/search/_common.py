@@ -6,8 +6,23 @@ import numpy as np
 from ac_solver import _acx
 
 
-def run_search(kind, presentation, max_nodes_to_explore, cyclical, want_stats=False):
+def run_search(kind, presentation, max_nodes_to_explore, cyclical, want_stats=False, verbose=False):
+    """`verbose`: print "New minimal length found: l" for every child that is shorter than everything generated before it, as
+    the reference does while it searches (breadth_first.py:79-82, greedy.py:85-89); here the lines come out when the
+    search returns, in the reference's order."""
     _acx.require_device()
+    if verbose:
+        _acx.check(_acx.lib.acx_search_minima_enable(1))
+        try:
+            out = run_search(kind, presentation, max_nodes_to_explore, cyclical, want_stats)
+            n = C.c_int64(0)
+            buf = np.zeros(256, np.int32)
+            _acx.check(_acx.lib.acx_search_last_minima(_acx.ptr(buf, C.c_int32), len(buf), C.byref(n)))
+            for length in buf[: n.value].tolist():
+                print(f"New minimal length found: {length}")
+            return out
+        finally:
+            _acx.check(_acx.lib.acx_search_minima_enable(0))
     p = _acx.as_i8_rows(np.array(presentation))
     L = p.size // 2
     cap = 1 << 12

@@ -16,13 +16,11 @@ def bfs(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_redu
     """Returns (is_search_successful, path); path = [(-1, len0), (action, total_length), ...] or None."""
     assert is_array_valid_presentation(presentation), f"{presentation} is not a valid presentation"
     solved, path, stats = run_search(_acx.SEARCH_BFS, np.array(presentation, dtype=np.int8), max_nodes_to_explore,
-                                     cyclically_reduce_after_moves)
+                                     cyclically_reduce_after_moves, verbose=verbose)  # verbose: the per-improvement lines (:79-82)
     if not solved:
         if stats["nodes"] >= max_nodes_to_explore:
             print(f"Exiting search as number of explored nodes = {stats['nodes']} has exceeded the limit {max_nodes_to_explore}")
         return False, None
-    if verbose:
-        print(f"New minimal length found: {stats['min_len']}")
     return True, path
 
 

@@ -13,10 +13,18 @@ from ac_solver.search._common import run_search
 
 def greedy_search(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False):
     """Returns (is_search_successful, path); path = [(-1, len0), (action, total_length), ...]."""
-    solved, path, stats = run_search(_acx.SEARCH_GREEDY, np.array(presentation, dtype=np.int8), max_nodes_to_explore,
-                                     cyclically_reduce_after_moves)
+    presentation = np.array(presentation, dtype=np.int8)
+    solved, path, stats = run_search(_acx.SEARCH_GREEDY, presentation, max_nodes_to_explore, cyclically_reduce_after_moves,
+                                     verbose=verbose)  # verbose: the per-improvement lines (greedy.py:85-89)
     if solved:
-        if verbose:
+        if verbose:  # greedy.py:92-101
+            from ac_solver.envs.ac_moves import ACMove
+
+            L = len(presentation) // 2
+            state, lengths = presentation, [int(np.count_nonzero(presentation[:L])), int(np.count_nonzero(presentation[L:]))]
+            for action, _ in path[1:]:
+                state, lengths = ACMove(action, state, L, lengths, cyclical=cyclically_reduce_after_moves)
+            print(f"Found {state[0:1], state[L:L + 1]} after exploring {stats['expanded']} nodes")
             print(f"Path to a trivial state: (tuples are of form (action, length of a state)) {path}")
             print(f"Total path length: {len(path)}")
         return True, path

@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(kBfsBlock, (sizeof(W) == 8 && MODE != kMoveGen
         }
 #endif
         tl = (uint32_t)(s.n0 + s.n1);
+        if (d.first_len && tl < d.min_len_start) atomicMin(&d.first_len[tl], (unsigned long long)t);  // a candidate for "New minimal length found"
         if (tl == 2) atomicMin(d.solved_tag, (unsigned long long)t);  // breadth_first.py:84: tested before the dedup
         probe = !(c0 == pk0 && c1 == pk1);                            // unchanged state = its (visited) parent
 #ifdef ACX_BFS_GRANDPARENT

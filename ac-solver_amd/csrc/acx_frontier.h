@@ -90,6 +90,10 @@ template <typename W> struct SearchDev {
     unsigned long long* err_tag;      // min (tag << 8 | code) of a move on which the reference's ACMove raises
     uint32_t* err;
     uint32_t* min_len;
+    // verbose searches (acx_search_minima_enable): first_len[l] = smallest tag of the running batch whose child has total
+    // length l, recorded for l < min_len_start (the minimum when the batch began); null when off
+    unsigned long long* first_len;
+    uint32_t min_len_start;
     int32_t L;
     int32_t cyclical;
 };
@@ -135,6 +139,7 @@ __global__ void __launch_bounds__(256) k_expand(SearchDev<W> d, const uint32_t* 
         else d.cslot[t] = 0;
         tl = (uint32_t)(s.n0 + s.n1);
         d.clen[t] = (uint8_t)tl;
+        if (d.first_len && tl < d.min_len_start) atomicMin(&d.first_len[tl], (unsigned long long)t);  // a candidate for "New minimal length found"
         if (tl == 2) atomicMin(d.solved_tag, (unsigned long long)t);  // breadth_first.py:84 / greedy.py:91
     }
     // wave-level min before the atomic keeps contention low (all 64 lanes take part)

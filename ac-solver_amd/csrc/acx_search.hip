@@ -34,6 +34,12 @@ namespace acx {
 // action) of all its nodes into a 64-bit sum; acx_search_last_digest returns the calling thread's last one.
 static std::atomic<int> g_digest_on{0};
 static thread_local uint64_t t_last_digest = 0;
+// acx_search_minima_enable(1): every search records the total lengths at which the reference's verbose mode prints "New
+// minimal length found" (breadth_first.py:79-82, greedy.py:85-89): each child, in generation order, that is shorter than
+// everything generated before it, up to the child that ends the search.  acx_search_last_minima returns the sequence.
+static std::atomic<int> g_minima_on{0};
+static thread_local std::vector<int32_t> t_last_minima;
+constexpr int kFirstLen = 128;  // total lengths are <= 2 * 61
 
 template <typename W, typename KEYS>
 __global__ void __launch_bounds__(256) k_digest(KEYS keys, const uint32_t* __restrict__ parent, const uint8_t* __restrict__ act, uint32_t n, unsigned long long* __restrict__ out) {
@@ -79,7 +85,8 @@ template <typename W, typename KEYS> static int node_digest(KEYS keys, const uin
 
 template <typename W> struct Searcher {
     SearchDev<W> d;
-    DevBuf arena_nodes, arena_cand, arena_tab, arena_btab, arena_scal, arena_tmp, arena_list, arena_path, arena_status;
+    DevBuf arena_nodes, arena_cand, arena_tab, arena_btab, arena_scal, arena_tmp, arena_list, arena_path, arena_status, arena_first;
+    unsigned long long h_first[kFirstLen];
     unsigned long long* d_status = nullptr;  // one-pass BFS commit: per-tile look-back words
     uint32_t* d_ticket = nullptr;
     uint32_t* d_total = nullptr;
@@ -177,6 +184,10 @@ template <typename W> struct Searcher {
         d.err_tag = (unsigned long long*)(sc + 16);  // reset with the other batch scalars
         d.err = (uint32_t*)(sc + 24);
         d.min_len = (uint32_t*)(sc + 28);
+        if (g_minima_on.load()) {
+            if (arena_first.alloc(kFirstLen * 8)) return ACX_E_NOMEM;
+            d.first_len = (unsigned long long*)arena_first.p;
+        }
         if (arena_list.alloc(std::max<uint64_t>(batch_parents, 1024) * 4 * 2)) return ACX_E_NOMEM;
         if (arena_path.alloc(8)) return ACX_E_NOMEM;
         if (!stamp_tab) {  // rocprim temporary storage for the scan over one batch
@@ -203,7 +214,22 @@ template <typename W> struct Searcher {
 
     int reset_batch_scalars() {  // solved / shorter / rank tags back to "none"; err and min_len are sticky
         ACX_HIP_TRY(hipMemsetAsync(arena_scal.p, 0xff, 24, st));
+        if (d.first_len) ACX_HIP_TRY(hipMemsetAsync(d.first_len, 0xff, kFirstLen * 8, st));
         return ACX_OK;
+    }
+
+    // the lengths the reference prints during this batch: children with a tag <= end_tag, in tag order, each shorter than
+    // everything before it (call after the batch's stream has been synchronised and h_first read back)
+    void collect_minima(uint32_t& running_min, unsigned long long end_tag) {
+        std::vector<std::pair<unsigned long long, int>> hits;
+        for (int l = 0; l < kFirstLen && (uint32_t)l < running_min; l++)
+            if (h_first[l] != ~0ull && h_first[l] <= end_tag) hits.emplace_back(h_first[l], l);
+        std::sort(hits.begin(), hits.end());
+        for (auto& hit : hits)
+            if ((uint32_t)hit.second < running_min) {
+                running_min = (uint32_t)hit.second;
+                t_last_minima.push_back(hit.second);
+            }
     }
 
     int path_of(uint32_t id, uint32_t depth, int32_t* pa, int32_t* pl, int64_t cap, int64_t* n) {
@@ -495,7 +521,8 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
     const bool greedy = kind == ACX_SEARCH_GREEDY;
     *solved = 0;
     *path_n = 0;
-    if (greedy && !getenv("ACX_GREEDY_HOST")) {  // device-resident priority frontier; falls through when it hits a capacity
+    // (verbose searches run greedy batch by batch: the per-improvement lengths need each batch's decision on the host)
+    if (greedy && !getenv("ACX_GREEDY_HOST") && !g_minima_on.load()) {  // device-resident priority frontier; falls through when it hits a capacity
         bool handled = false;
         const int grc = run_greedy_device<W>(root, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, &handled);
         if (grc != ACX_OK || handled) return grc;
@@ -547,6 +574,8 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
     const bool debug = getenv("ACX_DEBUG") != nullptr;
     const bool classic_commit = getenv("ACX_BFS_CLASSIC_COMMIT") != nullptr;  // A/B: mark + scan + decide + commit as four launches
     uint32_t adaptive = 64;  // greedy batch size: grows while buckets are consumed without a cut
+    uint32_t printed_min = tl0;  // verbose mode: the minimum the reference has printed so far
+    t_last_minima.clear();
 
     while (!done) {
         // ---- choose the batch of parents -------------------------------------------------------------
@@ -600,6 +629,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         // ---- expand, dedup with min-tag resolution, number the winners, decide -- all on the stream --------
         rc = S.reset_batch_scalars();
         if (rc) return rc;
+        d.min_len_start = printed_min;
         if (batches >= (1ull << 30)) return fail(ACX_E_CAPACITY, "acx_search: more than 2^30 batches (the look-back words carry a 30-bit batch number)");
         if (stamp) {
             // expand + dedup in one kernel, winners -> nodes in one pass, then the decision from the written nodes
@@ -656,6 +686,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         Decision* dec = (Decision*)S.h_pin;
         uint8_t* hl = S.h_pin + sizeof(Decision) + 64 - (sizeof(Decision) % 64);
         ACX_HIP_TRY(hipMemcpyAsync(dec, S.d_dec, sizeof(Decision), hipMemcpyDeviceToHost, st));
+        if (d.first_len) ACX_HIP_TRY(hipMemcpyAsync(S.h_first, d.first_len, kFirstLen * 8, hipMemcpyDeviceToHost, st));
         if (greedy) ACX_HIP_TRY(hipMemcpyAsync(hl, d.tlen + nodes, std::min<uint64_t>(m, S.cap_nodes - nodes), hipMemcpyDeviceToHost, st));
         ACX_HIP_TRY(hipStreamSynchronize(st));
         if (dec->err == 0xFE) return fail(ACX_E_CAPACITY, "acx_search: a probe sequence ran through the whole visited table (table full or damaged)");
@@ -663,6 +694,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         if (debug) fprintf(stderr, "[acx_search]   total=%u p_end=%u committed=%u solved=%u budget_hit=%u\n", dec->total, dec->p_end, dec->committed, dec->solved, dec->budget_hit);
         const uint32_t p_end = dec->p_end, committed = dec->committed;
         min_len = std::min<uint32_t>(min_len, dec->min_len);
+        if (d.first_len) S.collect_minima(printed_min, dec->solved ? (unsigned long long)dec->solved_tag : 12ull * (p_end + 1) - 1);
 
         if (dec->solved) {
             // success: path of the parent + (action, 2); checked before dedup and before the budget test
@@ -757,6 +789,18 @@ extern "C" int acx_search(int kind, const int8_t* h_presentation, int L, int64_t
     if (max_nodes < 0) max_nodes = 0;
     if (L <= 29) return run_search<uint64_t>(kind, h_presentation, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats);
     return run_search<u128>(kind, h_presentation, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats);
+}
+
+extern "C" int acx_search_minima_enable(int on) {
+    g_minima_on.store(on ? 1 : 0);
+    return ACX_OK;
+}
+
+extern "C" int acx_search_last_minima(int32_t* lengths, int64_t cap, int64_t* n) {
+    if (!n || cap < 0 || (cap > 0 && !lengths)) return fail(ACX_E_INVAL, "acx_search_last_minima: bad argument");
+    *n = (int64_t)t_last_minima.size();
+    for (int64_t k = 0; k < *n && k < cap; k++) lengths[k] = t_last_minima[(size_t)k];
+    return ACX_OK;
 }
 
 extern "C" int acx_search_digest_enable(int on) {

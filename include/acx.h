@@ -141,6 +141,14 @@ typedef struct {
 int acx_search(int kind, const int8_t *h_presentation, int L, int64_t max_nodes, int cyclical, int32_t *solved,
                int32_t *path_action, int32_t *path_len, int64_t path_cap, int64_t *path_n, acx_search_stats *stats);
 
+/* verbose=True of bfs / greedy_search (breadth_first.py:79-82, greedy.py:85-89: "New minimal length found: l" whenever a child
+ * is shorter than everything generated before it): with the switch on, acx_search records those lengths, in the order the
+ * reference prints them and up to the child that ends the search; acx_search_last_minima returns the calling thread's last
+ * sequence (*n = its length, the first min(*n, cap) entries are written).  greedy_search then runs batch by batch on the
+ * host-driven path (same result, slower). */
+int acx_search_minima_enable(int on);
+int acx_search_last_minima(int32_t *lengths, int64_t cap, int64_t *n);
+
 /* Test hook (repeat-determinism tests): with the switch on, every acx_search of the process ends with one extra pass that
  * folds (id, packed key, parent, action) of ALL nodes of the search into a 64-bit sum; acx_search_last_digest returns the
  * one of the calling thread's last search.  Two runs of the same search must give the same digest, node for node. */

@@ -424,3 +424,17 @@ def test_sharded_bfs_two_processes_share_one_gpu():
             wok, wpath, wst = O.bfs(p, b, cyclically_reduce_after_moves=c, stats=True)
             assert (ok, path) == (wok, wpath), (r, b, c)
             assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (r, b, c, st, wst)
+
+
+def test_verbose_prints_the_references_lines(search, golden_json, capsys):
+    """verbose=True: the same lines, in the same order, as the reference prints (tests/golden/verbose_lines.json holds its
+    captured stdout): every "New minimal length found", the greedy success report, the budget message."""
+    from ac_solver import bfs, greedy_search
+
+    for row in golden_json("verbose_lines.json"):
+        fn = bfs if row["algo"] == "bfs" else greedy_search
+        capsys.readouterr()
+        ok, _ = fn(np.array(row["presentation"], dtype=np.int8), max_nodes_to_explore=row["budget"], verbose=True,
+                   cyclically_reduce_after_moves=row["cyclical"])
+        out = capsys.readouterr().out.splitlines()
+        assert ok == row["solved"] and out == row["lines"], (row["algo"], row["budget"], row["cyclical"], out, row["lines"])
