@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
                                                      unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t* __restrict__ total_out) {
     __shared__ uint32_t s_tile, s_prefix, s_wsum[4];
     __shared__ uint16_t s_list[kCompactTile];
-#ifdef ACX_HAZARD_REPRO  // tools/hazard24/repro_compact.sh: the build that corrupts (exactly the 32 registers the kernel uses)
+#ifdef ACX_HAZARD_REPRO  // tools/hazard24/repro_compact.sh: the kernel as it was when it corrupted (exactly the 32 registers it uses)
     asm volatile("" ::: "v31");
 #else
     ACX_VGPR_PAD_W(W, "v47", "v63");
@@ -240,10 +240,13 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
     const uint32_t t0 = tile * kCompactTile + tid * kCompactItems;
     uint32_t fl = 0;  // bit i: candidate t0 + i is a winner (took its slot and was not replaced)
     if (t0 + kCompactItems <= m) {
-        const unsigned long long tb = *(const unsigned long long*)(d.btook + t0), rb = *(const unsigned long long*)(d.brepl + t0);
-        const unsigned long long w = tb & ~rb;  // bytes are 0 / 1
 #pragma unroll
-        for (uint32_t i = 0; i < kCompactItems; i++) fl |= (uint32_t)((w >> (8u * i)) & 1ull) << i;
+        for (uint32_t q = 0; q < kCompactItems / 8; q++) {
+            const unsigned long long tb = *(const unsigned long long*)(d.btook + t0 + 8 * q), rb = *(const unsigned long long*)(d.brepl + t0 + 8 * q);
+            const unsigned long long w = tb & ~rb;  // bytes are 0 / 1
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) fl |= (uint32_t)((w >> (8u * i)) & 1ull) << (8 * q + i);
+        }
     } else {
         for (uint32_t i = 0; i < kCompactItems; i++)
             if (t0 + i < m && d.btook[t0 + i] && !d.brepl[t0 + i]) fl |= 1u << i;
@@ -301,6 +304,8 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
     }
     __syncthreads();
     const uint32_t first_id = base + s_prefix, tbase = tile * kCompactTile;
+#ifdef ACX_HAZARD_REPRO
+    // the write loop of commit 57c6f83 (one winner per lane and round), kept verbatim for the reproducer of DESIGN.md section 7
     for (uint32_t j = tid; j < block_total; j += 256) {
         const uint32_t id = first_id + j;
         if (id >= cap_nodes) break;  // beyond the budget: never read
@@ -309,17 +314,6 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
         Pres<W> s;
         key_to_pres<W>(d.k0[pid], d.k1[pid], s);
         (void)search_move<W, MODE>(s, (int)a, d.L, d.cyclical != 0);
-#ifdef ACX_BFS_CHECK_NF
-        {
-            Pres<W> g;
-            key_to_pres<W>(d.k0[pid], d.k1[pid], g);
-            (void)apply_move<W, kSearchSafe>(g, (int)a, d.L, d.cyclical != 0);
-            if (g.w0 != s.w0 || g.w1 != s.w1 || g.n0 != s.n0 || g.n1 != s.n1 || !is_normal_form<W>(s, d.cyclical != 0))
-                printf("COMPACT: node %u = move(%u, %u): parent %llx %llx nf %llx %llx general %llx %llx\n", id, pid, a, (unsigned long long)d.k0[pid], (unsigned long long)d.k1[pid],
-                       (unsigned long long)keyops<W>::make(s.w0, s.n0), (unsigned long long)keyops<W>::make(s.w1, s.n1), (unsigned long long)keyops<W>::make(g.w0, g.n0),
-                       (unsigned long long)keyops<W>::make(g.w1, g.n1));
-        }
-#endif
         d.k0[id] = keyops<W>::make(s.w0, s.n0);
         d.k1[id] = keyops<W>::make(s.w1, s.n1);
         d.parent[id] = pid;
@@ -327,6 +321,57 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
         d.tlen[id] = (uint8_t)(s.n0 + s.n1);
         d.depth[id] = d.depth[pid] + 1;
     }
+#else
+    // kU winners per lane and round: their parent keys and depths are loaded together, then the moves, then the stores
+    // (kU = 4 -- one memory round trip for four nodes -- measured no faster than 1 on the 1e8-node search: the pass is not
+    // bound by this loop's latency; 1 keeps the kernel at 36 registers)
+#ifndef ACX_COMPACT_UNROLL
+#define ACX_COMPACT_UNROLL 1
+#endif
+    constexpr uint32_t kU = ACX_COMPACT_UNROLL;
+    for (uint32_t j0 = tid; j0 < block_total; j0 += 256 * kU) {
+        W pk0[kU], pk1[kU];
+        uint32_t pid[kU], act[kU], dep[kU];
+        bool on[kU];
+#pragma unroll
+        for (uint32_t u = 0; u < kU; u++) {
+            const uint32_t j = j0 + 256 * u;
+            on[u] = j < block_total && first_id + j < cap_nodes;  // ids beyond the budget are never read
+            const uint32_t t = tbase + s_list[on[u] ? j : 0];
+            const uint32_t p = t / 12u;
+            pid[u] = pbegin + p;
+            act[u] = t - 12u * p;
+            pk0[u] = on[u] ? d.k0[pid[u]] : (W)0;
+            pk1[u] = on[u] ? d.k1[pid[u]] : (W)0;
+            dep[u] = on[u] ? d.depth[pid[u]] : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kU; u++) {
+            if (!on[u]) continue;
+            const uint32_t id = first_id + j0 + 256 * u;
+            Pres<W> s;
+            key_to_pres<W>(pk0[u], pk1[u], s);
+            (void)search_move<W, MODE>(s, (int)act[u], d.L, d.cyclical != 0);
+#ifdef ACX_BFS_CHECK_NF
+            {
+                Pres<W> g;
+                key_to_pres<W>(pk0[u], pk1[u], g);
+                (void)apply_move<W, kSearchSafe>(g, (int)act[u], d.L, d.cyclical != 0);
+                if (g.w0 != s.w0 || g.w1 != s.w1 || g.n0 != s.n0 || g.n1 != s.n1 || !is_normal_form<W>(s, d.cyclical != 0))
+                    printf("COMPACT: node %u = move(%u, %u): parent %llx %llx nf %llx %llx general %llx %llx\n", id, pid[u], act[u], (unsigned long long)pk0[u],
+                           (unsigned long long)pk1[u], (unsigned long long)keyops<W>::make(s.w0, s.n0), (unsigned long long)keyops<W>::make(s.w1, s.n1),
+                           (unsigned long long)keyops<W>::make(g.w0, g.n0), (unsigned long long)keyops<W>::make(g.w1, g.n1));
+            }
+#endif
+            d.k0[id] = keyops<W>::make(s.w0, s.n0);
+            d.k1[id] = keyops<W>::make(s.w1, s.n1);
+            d.parent[id] = pid[u];
+            d.act[id] = (uint8_t)act[u];
+            d.tlen[id] = (uint8_t)(s.n0 + s.n1);
+            d.depth[id] = dep[u] + 1;
+        }
+    }
+#endif
 }
 
 }  // namespace acx

@@ -408,7 +408,13 @@ __global__ void __launch_bounds__(256) k_commit(SearchDev<W> d, const uint32_t* 
 // already run), and writes its winners as nodes base + rank, rank = position among the batch's winners in tag order.
 // Every winner of the batch is written (ids below cap_nodes): in a BFS a batch is cut short only when the search
 // ends, and k_decide_tab then derives the counts the reference would have from the tags of the written nodes.
-constexpr uint32_t kCompactItems = 8;
+// 32 candidates per lane, 8192 per tile: every tile takes a ticket from ONE counter, and a single word serves only ~90
+// returning atomics per microsecond -- with 2048-candidate tiles the 162 000 tickets of a 1e8-node search were 1.8 of the
+// pass's 2.9 ms.
+#ifndef ACX_COMPACT_ITEMS
+#define ACX_COMPACT_ITEMS 32
+#endif
+constexpr uint32_t kCompactItems = ACX_COMPACT_ITEMS;  // a multiple of 8, at most 32 (one flag bit each in a 32-bit word)
 constexpr uint32_t kCompactTile = 256 * kCompactItems;
 constexpr unsigned long long kTileAgg = 1ull, kTileIncl = 2ull;
 
@@ -417,7 +423,7 @@ __global__ void __launch_bounds__(256) k_compact_tab(SearchDev<W> d, uint32_t pb
                                                      unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t* __restrict__ total_out) {
     __shared__ uint32_t s_tile, s_prefix, s_wsum[4];
     __shared__ uint16_t s_list[kCompactTile];
-    ACX_VGPR_PAD("v39");
+    ACX_VGPR_PAD("v47");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
@@ -425,10 +431,13 @@ __global__ void __launch_bounds__(256) k_compact_tab(SearchDev<W> d, uint32_t pb
     const uint32_t t0 = tile * kCompactTile + tid * kCompactItems;
     uint32_t fl = 0;  // bit i: candidate t0 + i is a winner (took its entry and was not replaced)
     if (t0 + kCompactItems <= m) {
-        const unsigned long long tb = *(const unsigned long long*)(d.btook + t0), rb = *(const unsigned long long*)(d.brepl + t0);
-        const unsigned long long w = tb & ~rb;  // bytes are 0 / 1
 #pragma unroll
-        for (uint32_t i = 0; i < kCompactItems; i++) fl |= (uint32_t)((w >> (8u * i)) & 1ull) << i;
+        for (uint32_t q = 0; q < kCompactItems / 8; q++) {
+            const unsigned long long tb = *(const unsigned long long*)(d.btook + t0 + 8 * q), rb = *(const unsigned long long*)(d.brepl + t0 + 8 * q);
+            const unsigned long long w = tb & ~rb;  // bytes are 0 / 1
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) fl |= (uint32_t)((w >> (8u * i)) & 1ull) << (8 * q + i);
+        }
     } else {
         for (uint32_t i = 0; i < kCompactItems; i++)
             if (t0 + i < m && d.btook[t0 + i] && !d.brepl[t0 + i]) fl |= 1u << i;
