@@ -75,6 +75,19 @@ def run_search_many(kind, presentations, max_nodes_to_explore, cyclical, n_threa
     return out
 
 
+def run_search_groups(kind, groups, max_nodes_to_explore, cyclical, n_threads=16, path_cap=4096):
+    """`run_search_many` on several batches of presentations of DIFFERENT widths at once (the Miller-Schupp presentations of each
+    n have their own max_relator_length): one host thread per batch, so that their launches share the GPU -- a batch of 170
+    one-workgroup searches fills 170 of the 256 compute units.  -> list (per batch) of lists of (solved, path, stats)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    if len(groups) <= 1:
+        return [run_search_many(kind, g, max_nodes_to_explore, cyclical, n_threads, path_cap) for g in groups]
+    with ThreadPoolExecutor(max_workers=len(groups)) as ex:
+        futs = [ex.submit(run_search_many, kind, g, max_nodes_to_explore, cyclical, n_threads, path_cap) for g in groups]
+        return [f.result() for f in futs]
+
+
 def self_check(search_fn, budget=10**6):
     """Solve AK(2) with `search_fn`, then replay the returned path move by move and report whether it ends at a trivial
     presentation (what the reference's search modules do when run as scripts)."""

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 #include "acx_common.h"
 #include "acx_word.h"
@@ -622,38 +623,57 @@ __global__ void __launch_bounds__(256) k_rank_sort(SearchDev<W> d, const uint32_
 
 
 // ---------------------------------------------------------------------------------------- host ---
-// Device blocks of finished searches are kept per host thread and handed to the next search of that thread:
-// hipMalloc / hipFree cost milliseconds and hipFree synchronises the whole device, which would serialise the
-// overlapped searches of acx_search_many.  Blocks above kMaxCachedBlock go back to the driver at once.
+// Device blocks of finished searches are kept in one process-wide pool and handed to the next search: hipMalloc / hipFree
+// cost milliseconds per call -- erratically up to seconds for the 10 GB arenas of a group of searches -- and hipFree
+// synchronises the whole device, which would serialise the overlapped searches of acx_search_many.  (Round 1 kept a pool per
+// host thread; worker threads then had to return their blocks before they ended, and every acx_search_many paid the
+// allocations again.)  The pool holds at most kMaxCachedTotal bytes; acx_release_cached_memory empties it.
 struct BlockPool {
-    static constexpr size_t kMaxCachedBlock = 16ull << 30;  // (a thread's cache is trimmed when acx_search_many returns)
+    static constexpr size_t kMaxCachedBlock = 48ull << 30;
+    static constexpr size_t kMaxCachedTotal = 96ull << 30;
     static constexpr size_t kMaxBlocks = 8192;
+    std::mutex mu;
     std::vector<std::pair<void*, size_t>> blocks;
+    size_t cached = 0;
     void* take(size_t bytes, size_t* got) {
+        std::lock_guard<std::mutex> lock(mu);
         size_t best = blocks.size();
         for (size_t k = 0; k < blocks.size(); k++)
             if (blocks[k].second >= bytes && blocks[k].second <= bytes + bytes / 2 + 4096 && (best == blocks.size() || blocks[k].second < blocks[best].second)) best = k;
         if (best == blocks.size()) return nullptr;
         void* p = blocks[best].first;
         *got = blocks[best].second;
+        cached -= blocks[best].second;
         blocks[best] = blocks.back();
         blocks.pop_back();
         return p;
     }
     void give(void* p, size_t bytes) {
-        if (bytes > kMaxCachedBlock || blocks.size() >= kMaxBlocks) (void)hipFree(p);
-        else blocks.emplace_back(p, bytes);
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (bytes <= kMaxCachedBlock && cached + bytes <= kMaxCachedTotal && blocks.size() < kMaxBlocks) {
+                blocks.emplace_back(p, bytes);
+                cached += bytes;
+                return;
+            }
+        }
+        (void)hipFree(p);
     }
     void trim() {
-        for (auto& b : blocks) (void)hipFree(b.first);
-        blocks.clear();
+        std::vector<std::pair<void*, size_t>> old;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            old.swap(blocks);
+            cached = 0;
+        }
+        for (auto& b : old) (void)hipFree(b.first);
     }
-    // no destructor work: a worker thread trims explicitly before it ends; what the main thread still holds at process
-    // exit is released with the context (calling hipFree during runtime teardown can block)
+    // no destructor work: what the pool still holds at process exit is released with the context (calling hipFree during
+    // runtime teardown can block)
 };
 inline BlockPool& block_pool() {
-    static thread_local BlockPool pool;
-    return pool;
+    static BlockPool* pool = new BlockPool();  // never destroyed (see above)
+    return *pool;
 }
 
 struct DevBuf {

@@ -25,6 +25,7 @@
 
 #include "acx_frontier.h"
 #include "acx_bfs.h"
+#include "acx_bfs_multi.h"
 #include "acx_greedy.h"
 
 namespace acx {
@@ -420,6 +421,138 @@ static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_no
         } else if (path_action && path_len) {
             memcpy(path_action + k * path_cap, pa.data() + k * pc, (size_t)r.path_n * 4);
             memcpy(path_len + k * path_cap, pl.data() + k * pc, (size_t)r.path_n * 4);
+        }
+        if (stats) {
+            stats[k].nodes = (int64_t)r.nodes;
+            stats[k].expanded = (int64_t)r.expanded;
+            stats[k].children = (int64_t)r.expanded * 12;
+            stats[k].levels = (int64_t)r.batches;
+            stats[k].min_len = (int32_t)r.min_len;
+            stats[k].seconds = ms * 1e-3;  // of the whole group launch
+        }
+    }
+    return ACX_OK;
+}
+
+// A group of independent breadth-first searches in one launch of k_bfs_multi (one workgroup each).  rc_out[k] = ACX_OK /
+// ACX_E_CAPACITY (path buffer, or a probe sequence that ran through the whole table) / ACX_E_ROWERR (the reference raises).
+template <typename W>
+static int run_bfs_group(const int8_t* rows, int64_t n, int L, int64_t max_nodes, int cyclical, int32_t* solved, int32_t* path_action, int32_t* path_len,
+                         int64_t path_cap, int64_t* path_n, acx_search_stats* stats, int32_t* rc_out) {
+    const uint64_t cap_nodes = (uint64_t)std::max<int64_t>(max_nodes, 1) + 12 * kBmMaxParents + 64;
+    uint64_t n_slots = 1024;
+    while (n_slots < 2 * cap_nodes) n_slots <<= 1;
+    if (n_slots > (1ull << 31)) return fail(ACX_E_INVAL, "acx_search_many: budget too large for 32-bit node ids");
+    auto up = [](uint64_t b) { return (b + 255) / 256 * 256; };
+    const uint64_t b_tab = up(n_slots * 8), b_key = up(cap_nodes * sizeof(W)), b_u32 = up(cap_nodes * 4), b_u8 = up(cap_nodes);
+    const uint64_t per_rest = 2 * b_key + 2 * b_u32 + 2 * b_u8;
+    DevBuf big;
+    if (big.alloc((uint64_t)n * (b_tab + per_rest))) return ACX_E_NOMEM;
+    uint8_t* p_tab = (uint8_t*)big.p;
+    uint8_t* p_rest = p_tab + (uint64_t)n * b_tab;
+    hipStream_t st = nullptr;
+    ACX_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    struct StreamGuard {
+        hipStream_t s;
+        ~StreamGuard() { (void)hipStreamDestroy(s); }
+    } guard{st};
+    ACX_HIP_TRY(hipMemsetAsync(p_tab, 0xff, (uint64_t)n * b_tab, st));
+    // a root in normal form keeps its whole search in normal form (acx_bfs.h): those searches run the shorter move code
+    std::vector<BfsJob<W>> hjobs((size_t)n);
+    std::vector<int64_t> order[2];  // [0] general move code, [1] normal form
+    for (int64_t k = 0; k < n; k++) {
+        rc_out[k] = ACX_OK;
+        solved[k] = 0;
+        path_n[k] = 0;
+        Pres<W> root;
+        bool ok = pack_relator<W>(rows + k * 2 * L, L, root.w0, root.n0);
+        ok = pack_relator<W>(rows + k * 2 * L + L, L, root.w1, root.n1) && ok;
+        if (!ok) return fail(ACX_E_ROWERR, "acx_search_many: presentation %lld is not a zero-padded word pair over {+-1,+-2}", (long long)k);
+        order[is_normal_form<W>(root, cyclical != 0) && !getenv("ACX_BFS_GENERAL_MOVE") ? 1 : 0].push_back(k);
+        BfsJob<W>& g = hjobs[(size_t)k];
+        memset(&g, 0, sizeof(g));
+        uint8_t* q = p_rest + (uint64_t)k * per_rest;
+        auto take = [&](uint64_t bytes) {
+            uint8_t* r = q;
+            q += bytes;
+            return r;
+        };
+        g.stab = (unsigned long long*)(p_tab + (uint64_t)k * b_tab);
+        g.stmask = (uint32_t)(n_slots - 1);
+        g.k0 = (W*)take(b_key);
+        g.k1 = (W*)take(b_key);
+        g.parent = (uint32_t*)take(b_u32);
+        g.depth = (uint32_t*)take(b_u32);
+        g.act = take(b_u8);
+        g.tlen = take(b_u8);
+        g.cap_nodes = (uint32_t)cap_nodes;
+        g.root_k0 = keyops<W>::make(root.w0, root.n0);
+        g.root_k1 = keyops<W>::make(root.w1, root.n1);
+        g.max_nodes = (long long)max_nodes;
+        g.L = L;
+        g.cyclical = cyclical;
+    }
+    // jobs of one move code are contiguous on the device: [general ...][normal form ...]; slot j of the launch arrays
+    std::vector<BfsJob<W>> sorted_jobs;
+    std::vector<int64_t> slot_of;  // launch slot -> search index
+    for (int m = 0; m < 2; m++)
+        for (int64_t k : order[m]) {
+            sorted_jobs.push_back(hjobs[(size_t)k]);
+            slot_of.push_back(k);
+        }
+    const int64_t pc = std::max<int64_t>(path_cap, 1);
+    DevBuf djobs, douts, dpa, dpl;
+    if (djobs.alloc((size_t)n * sizeof(BfsJob<W>)) || douts.alloc((size_t)n * sizeof(BfsOut)) || dpa.alloc((size_t)n * pc * 4) || dpl.alloc((size_t)n * pc * 4)) return ACX_E_NOMEM;
+    ACX_HIP_TRY(hipMemcpyAsync(djobs.p, sorted_jobs.data(), (size_t)n * sizeof(BfsJob<W>), hipMemcpyHostToDevice, st));
+    ACX_HIP_TRY(hipMemsetAsync(douts.p, 0, (size_t)n * sizeof(BfsOut), st));
+    EventPair evs;
+    ACX_HIP_TRY(evs.create());
+    ACX_HIP_TRY(hipEventRecord(evs.a, st));
+    const int64_t n_gen = (int64_t)order[0].size(), n_nf = (int64_t)order[1].size();
+    const BfsJob<W>* dj = (const BfsJob<W>*)djobs.p;
+    BfsOut* dout = (BfsOut*)douts.p;
+    if (n_gen)
+        hipLaunchKernelGGL((k_bfs_multi<W, kMoveGeneral>), dim3((unsigned)n_gen), dim3(kBmT), 0, st, dj, dout, (int32_t*)dpa.p, (int32_t*)dpl.p, (long long)pc);
+    if (n_nf) {
+        if (cyclical)
+            hipLaunchKernelGGL((k_bfs_multi<W, kMoveNfCyclical>), dim3((unsigned)n_nf), dim3(kBmT), 0, st, dj + n_gen, dout + n_gen, (int32_t*)dpa.p + n_gen * pc,
+                               (int32_t*)dpl.p + n_gen * pc, (long long)pc);
+        else
+            hipLaunchKernelGGL((k_bfs_multi<W, kMoveNf>), dim3((unsigned)n_nf), dim3(kBmT), 0, st, dj + n_gen, dout + n_gen, (int32_t*)dpa.p + n_gen * pc,
+                               (int32_t*)dpl.p + n_gen * pc, (long long)pc);
+    }
+    ACX_HIP_TRY(hipGetLastError());
+    ACX_HIP_TRY(hipEventRecord(evs.b, st));
+    std::vector<BfsOut> o((size_t)n);
+    std::vector<int32_t> pa((size_t)n * pc), pl((size_t)n * pc);
+    ACX_HIP_TRY(hipMemcpyAsync(o.data(), douts.p, (size_t)n * sizeof(BfsOut), hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipMemcpyAsync(pa.data(), dpa.p, (size_t)n * pc * 4, hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipMemcpyAsync(pl.data(), dpl.p, (size_t)n * pc * 4, hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    ACX_HIP_TRY(hipEventElapsedTime(&ms, evs.a, evs.b));
+    for (int64_t j = 0; j < n; j++) {
+        const int64_t k = slot_of[(size_t)j];
+        const BfsOut& r = o[(size_t)j];
+        if (r.status == BFS_MOVE_ERROR) {
+            rc_out[k] = err_to_rc(r.err);
+            continue;
+        }
+        if (r.status == BFS_TABLE_FULL) {
+            rc_out[k] = fail(ACX_E_CAPACITY, "acx_search_many: a probe sequence ran through the whole visited table of search %lld", (long long)k);
+            continue;
+        }
+        if (r.status != BFS_SOLVED && r.status != BFS_BUDGET && r.status != BFS_EXHAUSTED) {
+            rc_out[k] = fail(ACX_E_NODEVICE, "bfs frontier kernel ended in state %u", r.status);
+            continue;
+        }
+        solved[k] = r.status == BFS_SOLVED ? 1 : 0;
+        path_n[k] = r.path_n;
+        if ((int64_t)r.path_n > path_cap) {
+            rc_out[k] = fail(ACX_E_CAPACITY, "path has %u entries, buffer holds %lld", r.path_n, (long long)path_cap);
+        } else if (path_action && path_len && r.path_n) {
+            memcpy(path_action + k * path_cap, pa.data() + j * pc, (size_t)r.path_n * 4);
+            memcpy(path_len + k * path_cap, pl.data() + j * pc, (size_t)r.path_n * 4);
         }
         if (stats) {
             stats[k].nodes = (int64_t)r.nodes;
@@ -850,7 +983,24 @@ extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t 
             if (rerun[k])
                 rc_out[k] = acx_search(kind, h_presentations + k * 2 * L, L, max_nodes, cyclical, solved + k, path_action ? path_action + k * path_cap : nullptr,
                                        path_len ? path_len + k * path_cap : nullptr, path_cap, path_n + k, stats ? stats + k : nullptr);
-        block_pool().trim();
+        for (int64_t k = 0; k < n; k++)
+            if (rc_out[k] != ACX_OK && rc_out[k] != ACX_E_CAPACITY) return fail(ACX_E_ROWERR, "acx_search_many: search %lld failed with code %d", (long long)k, rc_out[k]);
+        return ACX_OK;
+    }
+    if (kind == ACX_SEARCH_BFS && n > 1 && L >= 1 && L <= 61 && !getenv("ACX_BFS_MANY_STREAMS") && !g_minima_on.load() && !g_digest_on.load()) {
+        // bfs: groups of searches in ONE launch, one persistent workgroup per search (acx_bfs_multi.h)
+        if (max_nodes < 0) max_nodes = 0;
+        const double per_search = (L <= 29 ? 26.0 : 42.0) * (double)std::max<int64_t>(max_nodes, 1) + 16.0 * 2.0 * (double)std::max<int64_t>(max_nodes, 1) + 4e6;
+        const int64_t group = (int64_t)std::max(1.0, std::min(4096.0, 48e9 / per_search));
+        for (int64_t k0 = 0; k0 < n; k0 += group) {
+            const int64_t m = std::min<int64_t>(group, n - k0);
+            int32_t* pa = path_action ? path_action + k0 * path_cap : nullptr;
+            int32_t* pl = path_len ? path_len + k0 * path_cap : nullptr;
+            acx_search_stats* ps = stats ? stats + k0 : nullptr;
+            const int rc = L <= 29 ? run_bfs_group<uint64_t>(h_presentations + k0 * 2 * L, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0)
+                                   : run_bfs_group<u128>(h_presentations + k0 * 2 * L, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0);
+            if (rc != ACX_OK) return rc;
+        }
         for (int64_t k = 0; k < n; k++)
             if (rc_out[k] != ACX_OK && rc_out[k] != ACX_E_CAPACITY) return fail(ACX_E_ROWERR, "acx_search_many: search %lld failed with code %d", (long long)k, rc_out[k]);
         return ACX_OK;
@@ -866,7 +1016,6 @@ extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t 
             rc_out[k] = acx_search(kind, h_presentations + k * 2 * L, L, max_nodes, cyclical, solved + k, path_action ? path_action + k * path_cap : nullptr,
                                    path_len ? path_len + k * path_cap : nullptr, path_cap, path_n + k, stats ? stats + k : nullptr);
         }
-        block_pool().trim();  // the blocks this thread cached go back before it ends
     };
     std::vector<std::thread> pool;
     for (int t = 0; t < n_threads; t++) pool.emplace_back(work);

@@ -196,17 +196,28 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
 
     if use_dist:
         dist.barrier()
-    t0 = time.perf_counter()
     n_solved = n_nodes = n_mine = 0
     sweep_err = None
+    from ac_solver.search._common import run_search_groups
+
+    groups = []
+    for n in range(1, 8):  # the presentations of each n have their own max_relator_length: seven batches, all in flight together
+        d = generate_miller_schupp_presentations(n, 7)
+        groups.append(np.array([q for w in range(1, 8) for q in d[w]], dtype=np.int8)[rank::world])
+    n_mine = sum(len(g) for g in groups)
     try:
-        for n in range(1, 8):
-            d = generate_miller_schupp_presentations(n, 7)
-            rows = np.array([q for w in range(1, 8) for q in d[w]], dtype=np.int8)[rank::world]
-            n_mine += len(rows)
-            for ok, _, s1 in run_search_many(_acx.SEARCH_BFS, rows, 10**6, True, n_threads=16):
-                n_solved += ok
-                n_nodes += s1["nodes"]
+        run_search_groups(_acx.SEARCH_BFS, groups, 10**6, True)  # first call: pays for the device allocations (kept by the block pool)
+    except Exception as e:
+        sweep_err = e
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    try:
+        if sweep_err is None:
+            for res in run_search_groups(_acx.SEARCH_BFS, groups, 10**6, True):
+                for ok, _, s1 in res:
+                    n_solved += ok
+                    n_nodes += s1["nodes"]
     except Exception as e:
         sweep_err = e
     tot = torch.tensor([n_solved, n_nodes, n_mine, 0.0 if sweep_err is None else 1.0], dtype=torch.float64, device=dev)
@@ -221,7 +232,8 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
         out["bfs_ms_sweep"] = {"searches": int(tot[2]), "budget": 10**6, "cyclical": True, "solved": int(tot[0]), "published_solved": 278,
                                "nodes": int(tot[1]), "seconds": dt1, "nodes_per_s": float(tot[1]) / dt1, "searches_per_s": float(tot[2]) / dt1,
                                "n_gpus": world, "scaling": "strong",
-                               "entry": "acx_search_many per rank (16 host threads, one HIP stream per search); searches dealt round-robin to the ranks"}
+                               "entry": "acx_search_many per rank: one persistent workgroup per search (k_bfs_multi), the seven max_relator_lengths in "
+                                        "flight together; searches dealt round-robin to the ranks"}
     if world == 1 and not use_dist:
         for kind, name in ((_acx.SEARCH_BFS, "bfs"), (_acx.SEARCH_GREEDY, "greedy_search")):
             b = budget if kind == _acx.SEARCH_BFS else min(budget, 10**7)

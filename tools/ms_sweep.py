@@ -11,7 +11,7 @@ sys.path[:0] = [os.path.join(ROOT, "ac-solver_amd"), ROOT]
 import numpy as np
 
 from ac_solver import _acx
-from ac_solver.search._common import run_search_many
+from ac_solver.search._common import run_search_groups, run_search_many
 
 g = json.load(open(os.path.join(ROOT, "tests/golden/ms_pool.json")))
 pool = []
@@ -23,12 +23,16 @@ budget = int(float(sys.argv[2])) if len(sys.argv) > 2 else 10**6
 threads = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 cyc = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False
 kind = _acx.SEARCH_BFS if algo == "bfs" else _acx.SEARCH_GREEDY
+together = len(sys.argv) > 5 and sys.argv[5] == "together"  # all seven widths at once (one host thread per n)
 t0 = time.perf_counter()
 solved_idx, nodes, paths = [], 0, {}
+groups = [np.array(pool[(n - 1) * 170:n * 170], dtype=np.int8) for n in range(1, 8)]
+if together:
+    all_res = run_search_groups(kind, groups, budget, cyc, n_threads=threads)
 for n in range(1, 8):
-    rows = np.array(pool[(n - 1) * 170:n * 170], dtype=np.int8)
+    rows = groups[n - 1]
     t1 = time.perf_counter()
-    res = run_search_many(kind, rows, budget, cyc, n_threads=threads)
+    res = all_res[n - 1] if together else run_search_many(kind, rows, budget, cyc, n_threads=threads)
     for k, (ok, path, st) in enumerate(res):
         nodes += st["nodes"]
         if ok:
