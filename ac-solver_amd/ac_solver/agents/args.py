@@ -48,6 +48,8 @@ _FLAGS = [
     ("--epsilon", float, 0.00001, "epsilon of the Adam optimizer"),
     # not in the reference: lifts its `num_envs <= number of initial states` assert (agents/environment.py:80-83)
     ("--tile-initial-states", "bool", False, "allow more environments than initial states: environment i starts from state i mod n"),
+    ("--supermoves", str, "", "opt-in supermoves, e.g. '11,4,2;0,1': action 12 + s runs the s-th ';'-separated list of base moves as one step "
+                               "(the reference's --use_supermoves has no implementation to follow: it raises NotImplementedError, here too)"),
     ("--fused-policy", "bool", False, "rollouts sample through the fused MFMA policy kernel (bf16 operands, f32 accumulation) instead of the f32 torch modules"),
 ]
 

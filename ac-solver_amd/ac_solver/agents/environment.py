@@ -81,8 +81,9 @@ def get_env(args, device=None, rank=0, world=1):
         assert args.min_rew < args.max_rew, "min_rew must be less than max_rew"
         if not args.norm_rewards:  # with --norm-rewards the clip follows the normalisation (training loop), as make_env stacks the wrappers
             clip = (args.min_rew, args.max_rew)
+    supermoves = [[int(a) for a in q.split(",")] for q in getattr(args, "supermoves", "").split(";") if q.strip()] or None
     envs = ACVecEnv(rows, horizon_length=args.horizon_length, obs_dtype="float32", clip_rewards=clip, record_actions=True,
-                    final_info=False, device=device)
+                    final_info=False, device=device, supermoves=supermoves)
     states_processed = set(curr_states)
     success_record = {"solved": set(), "unsolved": set(range(len(initial_states)))}
     ACMoves_hist = {}

@@ -340,7 +340,8 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
                 "success_record": success_record, "value_loss": v_loss.item(), "policy_loss": pg_loss.item(),
                 "entropy_loss": entropy_loss.item(), "approx_kl": approx_kl.item(), "explained_var": explained_var,
                 "clipfrac": stats["losses/clipfrac"], "global_step": global_step, "round1_complete": round1_complete,
-                "curr_states": curr_states, "states_processed": states_processed, "ACMoves_hist": ACMoves_hist, "supermoves": None,
+                "curr_states": curr_states, "states_processed": states_processed, "ACMoves_hist": ACMoves_hist,
+                "supermoves": ({12 + k: q for k, q in enumerate(envs.supermoves)} if getattr(envs, "supermoves", None) else None),
             }
             print(f"saving checkpoint to {out_dir}")
             torch.save(checkpoint, join(out_dir, "ckpt.pt"))

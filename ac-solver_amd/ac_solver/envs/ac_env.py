@@ -52,6 +52,29 @@ class ACEnvConfig:
         )
 
 
+def normalise_supermoves(spec):
+    """`use_supermoves` in its opt-in form -- a dict {action id: [base moves]} with ids 12, 13, ... or a list of move lists --
+    -> list of move lists (supermove s is action 12 + s).  The reference only knows False (and raises for anything else,
+    ac_env.py:62-65); True keeps raising here as well: it names no supermoves."""
+    if isinstance(spec, dict):
+        ids = sorted(spec)
+        if ids != list(range(12, 12 + len(ids))):
+            raise ValueError("supermove ids must be 12, 13, ... without gaps")
+        seqs = [list(spec[k]) for k in ids]
+    else:
+        seqs = [list(q) for q in spec]
+    for q in seqs:
+        if not q or any(int(a) not in range(12) for a in q):
+            raise ValueError("a supermove is a non-empty list of base moves 0..11")
+    return [[int(a) for a in q] for q in seqs]
+
+
+def upload_supermoves(handle_ptr, seqs, stream=None):
+    moves = np.array([a for q in seqs for a in q], np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(q) for q in seqs])]).astype(np.int32)
+    _acx.check(_acx.lib.acx_env_set_supermoves(handle_ptr, _acx.ptr(moves, C.c_uint8), _acx.ptr(offs, C.c_int32), len(seqs), stream), "acx_env_set_supermoves")
+
+
 class _Handle:
     """Owns one acx_env; frees it with the Python object."""
 
@@ -78,8 +101,13 @@ class ACEnv(Env):
         self.max_relator_length = config.max_relator_length
         self.initial_state = config.initial_state
         self.horizon_length = config.horizon_length
+        # the reference's behaviour (ac_env.py:62-65) for every value it knows; a dict / list of move lists is this
+        # build's opt-in extension (include/acx.h: acx_env_set_supermoves)
+        self.supermoves = None
         if config.use_supermoves:
-            raise NotImplementedError("ACEnv with supermoves is not yet implemented in this library.")
+            if config.use_supermoves is True or not isinstance(config.use_supermoves, (dict, list, tuple)):
+                raise NotImplementedError("ACEnv with supermoves is not yet implemented in this library.")
+            self.supermoves = normalise_supermoves(config.use_supermoves)
         L = self.max_relator_length
         if L > 64:
             raise ValueError("ACEnv supports max_relator_length <= 64 on the device")
@@ -87,11 +115,13 @@ class ACEnv(Env):
             raise ValueError("ACEnv is a two-generator environment: letters must be in {+-1, +-2}")
 
         self.observation_space = Box(np.full(2 * L, -self.n_gen, dtype=np.int8), np.full(2 * L, self.n_gen, dtype=np.int8), dtype=np.int8)
-        self.action_space = Discrete(12)
+        self.action_space = Discrete(12 + (len(self.supermoves) if self.supermoves else 0))
         self.max_reward = self.horizon_length * L * self.n_gen
 
         self._dtype = self.initial_state.dtype
         self._h = _Handle(1, L, self.horizon_length, 0)
+        if self.supermoves:
+            upload_supermoves(self._h.ptr, self.supermoves)
         row = _acx.as_i8_rows(self.initial_state.reshape(1, -1))
         _acx.check(_acx.lib.acx_env_set_initial(self._h.ptr, _acx.ptr(row, C.c_int8), None, 1, None), "acx_env_set_initial")
         self.state = np.copy(self.initial_state)
@@ -102,7 +132,7 @@ class ACEnv(Env):
     def step(self, action):
         self.actions += [action]
         L = self.max_relator_length
-        assert action in range(0, 12), f"Expect n to be in range 0-11 (both inclusive); got {action}"
+        assert action in range(0, self.action_space.n), f"Expect n to be in range 0-{self.action_space.n - 1} (both inclusive); got {action}"
         act = np.array([int(action)], dtype=np.int64)
         obs = np.empty((1, 2 * L), np.int8)
         rew = np.empty(1, np.float32)

@@ -81,7 +81,7 @@ class _EnvList:
 
 class ACVecEnv:
     def __init__(self, initial_states, horizon_length=1000, obs_dtype="int8", clip_rewards=None, record_actions=True,
-                 final_info=True, device=None, reward_dtype="float32"):
+                 final_info=True, device=None, reward_dtype="float32", supermoves=None):
         """`reward_dtype="float64"`: `step` (without `out`) returns the rewards as float64, the dtype gymnasium's
         SyncVectorEnv hands to the reference's training loop; the kernel always writes float32 (exact: rewards are integers
         below 2^24 in magnitude, or clipped)."""
@@ -107,13 +107,23 @@ class ACVecEnv:
         self.final_info = final_info
         self.record_actions = record_actions
         self.single_observation_space = Box(np.full(2 * L, -2, np.int8), np.full(2 * L, 2, np.int8), dtype=np.int8)
-        self.single_action_space = Discrete(12)
+        self.supermoves = None
+        if supermoves:  # opt-in: action 12 + s = the s-th list of base moves as one step
+            from ac_solver.envs.ac_env import normalise_supermoves
+
+            self.supermoves = normalise_supermoves(supermoves)
+        n_actions = 12 + (len(self.supermoves) if self.supermoves else 0)
+        self.single_action_space = Discrete(n_actions)
         self.observation_space = Box(np.full((self.num_envs, 2 * L), -2, np.int8), np.full((self.num_envs, 2 * L), 2, np.int8), dtype=np.int8)
-        self.action_space = Discrete(12)
+        self.action_space = Discrete(n_actions)
         with torch.cuda.device(self.device):
             self._h = _Handle(self.num_envs, L, self.horizon_length, _acx.ENV_RECORD_ACTIONS if record_actions else 0)
             rows = _acx.as_i8_rows(states)
             _acx.check(_acx.lib.acx_env_set_initial(self._h.ptr, _acx.ptr(rows, C.c_int8), None, self.num_envs, None), "acx_env_set_initial")
+            if self.supermoves:
+                from ac_solver.envs.ac_env import upload_supermoves
+
+                upload_supermoves(self._h.ptr, self.supermoves)
         self.initial_states = rows
         self.envs = _EnvList(self)
         n = self.num_envs

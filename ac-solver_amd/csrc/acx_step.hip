@@ -208,6 +208,11 @@ template <typename W> struct EnvDev {
     int32_t L, H;
     int64_t horizon;
     float max_reward;
+    // supermoves (opt-in, acx_env_set_supermoves): action 12 + s runs the base moves
+    // sm_moves[sm_off[s] .. sm_off[s + 1]) as ONE environment step; null when the env has none
+    const uint8_t* sm_moves;
+    const int32_t* sm_off;
+    int32_t n_super;
 };
 
 template <typename W> struct EnvLane {
@@ -240,12 +245,28 @@ template <typename W> __device__ __forceinline__ void env_store(const EnvDev<W>&
 
 // One env transition (ac_env.py:95-113) incl. the optional gymnasium-style autoreset.
 // `fin` receives the terminal state when the env finished and was reset.
-template <typename W, bool SAFE>
+// SUPER: the env may have supermoves (a separate instantiation: the plain kernels carry none of this).
+template <typename W, bool SAFE, bool SUPER = false>
 __device__ __forceinline__ void env_transition(const EnvDev<W>& e, int64_t i, EnvLane<W>& v, int a, bool autoreset, float clip_lo,
                                                float clip_hi, float& reward, int& done, int& trunc, bool& was_reset, Pres<W>& fin) {
     if (e.hist) e.hist[(int64_t)(v.cnt % e.H) * e.n + i] = (uint8_t)a;  // self.actions += [action], :96
     int er;  // ACMove(action, state, L, lengths) with cyclical=True, :97
-    if (a < 0 || a >= 12) er = ACX_ERR_ASSERT;
+    if (SUPER && a >= 12 && a < 12 + e.n_super) {
+        // a supermove: its base moves one after the other, all or nothing -- if one of them raises in the reference's ACMove
+        // the state is what it was before the step (as when step() raises before assigning)
+        const Pres<W> s0 = v.s;
+        const uint32_t red0 = v.red;
+        er = ACX_ERR_NONE;
+        for (int k = e.sm_off[a - 12]; k < e.sm_off[a - 11] && !er; k++) {
+            const int b = e.sm_moves[k];
+            er = v.red ? apply_move_reduced<W, SAFE>(v.s, b, e.L) : apply_move<W, SAFE>(v.s, b, e.L, true);
+            if (!er) v.red = (uint32_t)(v.s.n0 > 0 && v.s.n1 > 0);
+        }
+        if (er) {
+            v.s = s0;
+            v.red = red0;
+        }
+    } else if (a < 0 || a >= 12) er = ACX_ERR_ASSERT;
     else if (v.red) er = apply_move_reduced<W, SAFE>(v.s, a, e.L);  // steady state: every state a step produces is in normal form
     else er = apply_move<W, SAFE>(v.s, a, e.L, true);
     v.err = er ? (uint32_t)er : v.err;
@@ -319,12 +340,16 @@ __device__ __forceinline__ void wave_lds_handoff() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <typename W, bool SAFE, typename OBS, int LC>
-__global__ void __launch_bounds__(256, ACX_STEP_WAVES) k_env_step(W* __restrict__ sw0, W* __restrict__ sw1, uint64_t* __restrict__ smeta,
+template <typename W, bool SAFE, typename OBS, int LC, bool SUPER = false>
+__global__ void __launch_bounds__(256, SUPER ? 5 : ACX_STEP_WAVES) k_env_step(W* __restrict__ sw0, W* __restrict__ sw1, uint64_t* __restrict__ smeta,
                                                   const void* __restrict__ act, int64_t n_envs, int adt, EnvDev<W> e, OBS* __restrict__ obs,
                                                   float* __restrict__ rew, float clip_lo, float clip_hi, uint8_t* __restrict__ done,
                                                   uint8_t* __restrict__ trunc, OBS* __restrict__ final_obs, int autoreset, int vec) {
-    ACX_VGPR_PAD("v71");
+    if (SUPER) {
+        ACX_VGPR_PAD("v111");
+    } else {
+        ACX_VGPR_PAD("v71");
+    }
     // The first six arguments (state arrays, actions, n, action dtype = 11 dwords) are what the first memory
     // accesses need: with -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave, so the
     // state loads issue without waiting for a kernarg fetch (this kernel is latency bound at 65 536 envs).
@@ -348,7 +373,7 @@ __global__ void __launch_bounds__(256, ACX_STEP_WAVES) k_env_step(W* __restrict_
         env_unpack_meta<W>(m, v);
         float r;
         int d, t;
-        env_transition<W, SAFE>(e, i, v, a, autoreset != 0, clip_lo, clip_hi, r, d, t, was_reset, fin);
+        env_transition<W, SAFE, SUPER>(e, i, v, a, autoreset != 0, clip_lo, clip_hi, r, d, t, was_reset, fin);
         sw0[i] = v.s.w0;
         sw1[i] = v.s.w1;
         smeta[i] = env_pack_meta<W>(v);
@@ -439,11 +464,15 @@ __global__ void __launch_bounds__(256, 4) k_env_step_team(W* __restrict__ sw0, W
     }
 }
 
-template <typename W, bool SAFE>
+template <typename W, bool SAFE, bool SUPER = false>
 __global__ void __launch_bounds__(256) k_env_rollout(EnvDev<W> e, const uint8_t* __restrict__ tape, int64_t T, float* __restrict__ rew,
                                                      float clip_lo, float clip_hi, uint8_t* __restrict__ done,
                                                      uint8_t* __restrict__ trunc, int autoreset) {
-    ACX_VGPR_PAD_W(W, "v63", "v79");
+    if (SUPER) {
+        ACX_VGPR_PAD_W(W, "v79", "v103");
+    } else {
+        ACX_VGPR_PAD_W(W, "v63", "v79");
+    }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= e.n) return;
     EnvLane<W> v;
@@ -453,7 +482,7 @@ __global__ void __launch_bounds__(256) k_env_rollout(EnvDev<W> e, const uint8_t*
         float r;
         int d, tr;
         bool was_reset;
-        env_transition<W, SAFE>(e, i, v, tape[t * e.n + i], autoreset != 0, clip_lo, clip_hi, r, d, tr, was_reset, fin);
+        env_transition<W, SAFE, SUPER>(e, i, v, tape[t * e.n + i], autoreset != 0, clip_lo, clip_hi, r, d, tr, was_reset, fin);
         if (rew) rew[t * e.n + i] = r;
         if (done) done[t * e.n + i] = (uint8_t)d;
         if (trunc) trunc[t * e.n + i] = (uint8_t)tr;
@@ -554,6 +583,8 @@ struct acx_env {
     bool wide;     // W = u128
     bool safe;     // L equals the word capacity: shifts may reach the full width
     void* arena;   // one allocation holding all device arrays
+    void* super_buf = nullptr;  // supermove tables (acx_env_set_supermoves)
+    int n_super = 0;
     EnvDev<uint64_t> d64;
     EnvDev<u128> d128;
 };
@@ -681,6 +712,9 @@ template <typename W> static void carve(EnvDev<W>& d, uint8_t* base, int64_t n, 
     d.H = H;
     d.horizon = horizon;
     d.max_reward = (float)(horizon * L * 2);
+    d.sm_moves = nullptr;
+    d.sm_off = nullptr;
+    d.n_super = 0;
     *total = o;
 }
 
@@ -747,7 +781,38 @@ acx_env* acx_env_create(int64_t n, int L, int64_t horizon, int flags) {
 void acx_env_destroy(acx_env* e) {
     if (!e) return;
     if (e->arena) (void)hipFree(e->arena);
+    if (e->super_buf) (void)hipFree(e->super_buf);
     delete e;
+}
+
+int acx_env_set_supermoves(acx_env* e, const uint8_t* h_moves, const int32_t* h_offsets, int n_super, void* stream) {
+    if (!e || n_super < 0 || n_super > 52 || (n_super > 0 && (!h_moves || !h_offsets))) return fail(ACX_E_INVAL, "acx_env_set_supermoves: 0..52 supermoves");
+    if (n_super && h_offsets[0] != 0) return fail(ACX_E_INVAL, "acx_env_set_supermoves: offsets start at 0");
+    for (int s = 0; s < n_super; s++) {
+        if (h_offsets[s + 1] <= h_offsets[s] || h_offsets[s + 1] - h_offsets[s] > 64) return fail(ACX_E_INVAL, "acx_env_set_supermoves: a supermove has 1..64 moves");
+        for (int k = h_offsets[s]; k < h_offsets[s + 1]; k++)
+            if (h_moves[k] >= 12) return fail(ACX_E_INVAL, "acx_env_set_supermoves: base moves are 0..11");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    ACX_HIP_TRY(hipStreamSynchronize(st));  // steps that still read the old tables
+    if (e->super_buf) (void)hipFree(e->super_buf);
+    e->super_buf = nullptr;
+    e->n_super = n_super;
+    const uint8_t* d_moves = nullptr;
+    const int32_t* d_off = nullptr;
+    if (n_super) {
+        const size_t nm = (size_t)h_offsets[n_super], off_bytes = (size_t)(n_super + 1) * 4;
+        if (hipMalloc(&e->super_buf, off_bytes + nm) != hipSuccess) return fail(ACX_E_NOMEM, "acx_env_set_supermoves: hipMalloc failed");
+        ACX_HIP_TRY(hipMemcpyAsync(e->super_buf, h_offsets, off_bytes, hipMemcpyHostToDevice, st));
+        ACX_HIP_TRY(hipMemcpyAsync((uint8_t*)e->super_buf + off_bytes, h_moves, nm, hipMemcpyHostToDevice, st));
+        ACX_HIP_TRY(hipStreamSynchronize(st));
+        d_off = (const int32_t*)e->super_buf;
+        d_moves = (const uint8_t*)e->super_buf + off_bytes;
+    }
+    e->d64.sm_moves = e->d128.sm_moves = d_moves;
+    e->d64.sm_off = e->d128.sm_off = d_off;
+    e->d64.n_super = e->d128.n_super = n_super;
+    return ACX_OK;
 }
 
 int64_t acx_env_max_reward(const acx_env* e) { return e ? e->horizon * e->L * 2 : 0; }
@@ -815,7 +880,14 @@ int acx_env_step(acx_env* e, const void* d_actions, int action_dtype, void* d_ob
 #define ACX_STEP_TEAM(OBS, LC)                                                                                                               \
     ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_step_team<W, SAFE, OBS, LC>), dim3(tgrid), dim3(256), tlds, st, dev.w0, dev.w1, dev.meta, d_actions, dev.n, action_dtype, dev, (OBS*)d_obs, \
                                            d_reward, clip_lo, clip_hi, d_done, d_trunc, autoreset, vec))
-    if (team) {
+    if (e->n_super) {  // an env with supermoves: the general kernel with the macro loop (no unrolled / team variants)
+        if (f32)
+            ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_step<W, true, float, 0, true>), dim3(grid), dim3(256), lds, st, dev.w0, dev.w1, dev.meta, d_actions, dev.n,
+                                                   action_dtype, dev, (float*)d_obs, d_reward, clip_lo, clip_hi, d_done, d_trunc, (float*)d_final_obs, autoreset, vec));
+        else
+            ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_step<W, true, int8_t, 0, true>), dim3(grid), dim3(256), lds, st, dev.w0, dev.w1, dev.meta, d_actions, dev.n,
+                                                   action_dtype, dev, (int8_t*)d_obs, d_reward, clip_lo, clip_hi, d_done, d_trunc, (int8_t*)d_final_obs, autoreset, vec));
+    } else if (team) {
         if (e->L == 25) {
             if (f32) ACX_STEP_TEAM(float, 25);
             else ACX_STEP_TEAM(int8_t, 25);
@@ -873,8 +945,12 @@ int acx_env_rollout(acx_env* e, const uint8_t* d_tape, int64_t T, float* d_rewar
     if (T == 0) return ACX_OK;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div<int64_t>(e->n, 256);
-    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_rollout<W, SAFE>), dim3(grid), dim3(256), 0, st, dev, d_tape, T, d_reward, clip_lo, clip_hi, d_done, d_trunc,
-                                            autoreset));
+    if (e->n_super)
+        ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_rollout<W, true, true>), dim3(grid), dim3(256), 0, st, dev, d_tape, T, d_reward, clip_lo, clip_hi, d_done, d_trunc,
+                                                autoreset));
+    else
+        ACX_ENV_DISPATCH(e, hipLaunchKernelGGL((k_env_rollout<W, SAFE>), dim3(grid), dim3(256), 0, st, dev, d_tape, T, d_reward, clip_lo, clip_hi, d_done, d_trunc,
+                                                autoreset));
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }

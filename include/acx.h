@@ -92,6 +92,13 @@ int acx_env_set_initial(acx_env *env, const int8_t *h_states, const int64_t *h_i
 /* ACEnv.reset (ac_env.py:115-131): h_states NULL -> back to the initial state, else
  * options={"starting_state": row}.  Zeroes count_steps and the action history of those envs. */
 int acx_env_reset(acx_env *env, const int8_t *h_states, const int64_t *h_idx, int64_t n_idx, void *stream);
+/* Supermoves.  The reference declares `use_supermoves` (envs/ac_env.py:20, agents/args.py:107-114) and raises
+ * NotImplementedError when it is set (ac_env.py:62-65); there is no reference behaviour to reproduce.  Opt-in here: action
+ * 12 + s runs the base moves h_moves[h_offsets[s] .. h_offsets[s + 1]) (each 0..11) as ONE environment step -- state = the
+ * composition of ACMove, reward / done / truncated from the final state, one count_steps, one history entry; if one of the
+ * base moves raises in the reference's ACMove the whole step does (state unchanged).  n_super = 0 removes them.
+ * At most 52 supermoves of at most 64 moves. */
+int acx_env_set_supermoves(acx_env *env, const uint8_t *h_moves, const int32_t *h_offsets, int n_super, void *stream);
 /* ACEnv.step for all n envs (ac_env.py:95-113).  d_obs [n,2L] (ACX_I8 or ACX_F32) receives the state
  * after the step -- after the autoreset when `autoreset` and the env finished, in which case
  * d_final_obs (nullable, same dtype) holds the terminal observation.  d_reward [n] f32 =
