@@ -74,25 +74,32 @@ __device__ __forceinline__ uint32_t lower_gpos(const uint32_t* __restrict__ gpos
     return lo;
 }
 
+// [lo, hi) = the local frontier nodes with gpos in [c0, c1): found ONCE per chunk by one lane (two binary searches of ~25
+// dependent loads each: done at the top of every workgroup of the expansion they cost it 8 of its 11 ms on a 1e8-node search)
+template <typename W> __global__ void k_shard_bounds(SearchDev<W> d, uint32_t lvl_lo, uint32_t lvl_hi, uint32_t c0, uint32_t c1, uint32_t* __restrict__ out) {
+    ACX_VGPR_PAD("v23");
+    out[0] = lower_gpos(d.depth, lvl_lo, lvl_hi, c0);
+    out[1] = lower_gpos(d.depth, lvl_lo, lvl_hi, c1);
+}
+
 // Children of the local frontier nodes with gpos in [c0, c1), each written straight into the send region of the rank
 // that owns its key (region o = rec[o * region_cap ...]), so the all-to-all can leave without a sort by owner.  The order
 // inside a region is arbitrary.  A workgroup expands kRouteItems x 1024 children and reserves its share of every region
 // with ONE atomicAdd per owner: the cursors are single words, and one word takes only ~90 returning atomics per
 // microsecond (a reservation per 1024 children cost 3.7 of the kernel's 8.3 ms on a 1e8-node search).
-constexpr int kRouteItems = 4;
+#ifndef ACX_ROUTE_ITEMS
+#define ACX_ROUTE_ITEMS 4
+#endif
+constexpr int kRouteItems = ACX_ROUTE_ITEMS;
 
 template <typename W>
-__global__ void __launch_bounds__(1024) k_shard_expand_routed(SearchDev<W> d, uint32_t lvl_lo, uint32_t lvl_hi, uint32_t c0, uint32_t c1, int64_t pref_hi,
+__global__ void __launch_bounds__(1024) k_shard_expand_routed(SearchDev<W> d, const uint32_t* __restrict__ bounds, int64_t pref_hi,
                                                              uint32_t world, int64_t* __restrict__ rec, int64_t region_cap, unsigned long long* __restrict__ counts,
                                                              unsigned long long* __restrict__ solved) {
     ACX_VGPR_PAD_W(W, "v71", "v103");
-    __shared__ uint32_t s_lo, s_hi;
     __shared__ uint32_t s_cnt[64];
     __shared__ unsigned long long s_base[64];
-    if (threadIdx.x == 0) {
-        s_lo = lower_gpos(d.depth, lvl_lo, lvl_hi, c0);
-        s_hi = lower_gpos(d.depth, lvl_lo, lvl_hi, c1);
-    }
+    const uint32_t s_lo = bounds[0], s_hi = bounds[1];
     if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const int64_t np = (int64_t)s_hi - s_lo;
@@ -305,6 +312,7 @@ template <typename W> struct ShardEngine {
     uint32_t* cslot = nullptr;     // [cap_cand] slot a record took
     uint8_t* took_i = nullptr;     // [cap_cand] "took a slot", by record index
     int64_t* d_find = nullptr;
+    uint32_t* d_bounds = nullptr;  // [2] frontier slice of the running chunk
     uint64_t cap_nodes = 0, cap_cand = 0, n_slots = 0, chunk_tags = 0;
     uint64_t nodes = 0;            // committed local nodes
     uint64_t lvl_lo = 0, lvl_hi = 0;
@@ -359,6 +367,7 @@ template <typename W> struct ShardEngine {
         d.err = (uint32_t*)(sc + 24);
         d.min_len = (uint32_t*)(sc + 28);
         d_find = (int64_t*)(sc + 64);
+        d_bounds = (uint32_t*)(sc + 96);
         ACX_HIP_TRY(hipMemset(d.stab, 0xff, n_slots * 8));
         ACX_HIP_TRY(hipMemset(scal_buf.p, 0xff, 256));
         ACX_HIP_TRY(hipMemset(d.err, 0, 4));
@@ -418,8 +427,9 @@ static int shard_expand_routed(ShardEngine<W>& E, int64_t c0, int64_t c1, int64_
     const int64_t np_max = std::min<int64_t>(c1 - c0, (int64_t)(E.lvl_hi - E.lvl_lo));
     if (np_max <= 0) return ACX_OK;
     const int64_t m = 12 * np_max;
-    hipLaunchKernelGGL(k_shard_expand_routed<W>, dim3((unsigned)((m + 1024 * kRouteItems - 1) / (1024 * kRouteItems))), dim3(1024), 0, st, E.d, (uint32_t)E.lvl_lo, (uint32_t)E.lvl_hi, (uint32_t)c0,
-                       (uint32_t)c1, (int64_t)E.rank << 40, (uint32_t)E.world, rec, region_cap, (unsigned long long*)counts, (unsigned long long*)solved);
+    hipLaunchKernelGGL(k_shard_bounds<W>, dim3(1), dim3(1), 0, st, E.d, (uint32_t)E.lvl_lo, (uint32_t)E.lvl_hi, (uint32_t)c0, (uint32_t)c1, E.d_bounds);
+    hipLaunchKernelGGL(k_shard_expand_routed<W>, dim3((unsigned)((m + 1024 * kRouteItems - 1) / (1024 * kRouteItems))), dim3(1024), 0, st, E.d, E.d_bounds,
+                       (int64_t)E.rank << 40, (uint32_t)E.world, rec, region_cap, (unsigned long long*)counts, (unsigned long long*)solved);
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }

@@ -188,6 +188,23 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
                            "levels": st["levels"],
                            "n_gpus": world, "budget": budget, "input": "AK(3) at max_relator_len=25, cyclical=False", "scaling": "strong",
                            "exchange": "per chunk: all-to-all of child records + all-reduce of one 12-bit child mask per parent (RCCL)" if world > 1 else "none"}}
+    if world > 1:
+        # the same frontier with the budget grown with the number of GPUs (weak scaling: 1e8 nodes per GPU)
+        try:
+            wb = budget * world
+            bfs_sharded(p, wb, comm=comm, batch_parents=1 << 22)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            _, _, stw = bfs_sharded(p, wb, comm=comm, batch_parents=1 << 22, want_stats=True)
+            torch.cuda.synchronize()
+            dist.barrier()
+            dtw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(dtw, op=dist.ReduceOp.MAX)
+            out["bfs_sharded_weak"] = {"nodes_per_s": stw["nodes"] / float(dtw[0]), "nodes": stw["nodes"], "seconds": float(dtw[0]), "levels": stw["levels"],
+                                       "n_gpus": world, "budget": wb, "scaling": "weak"}
+        except Exception as e:  # noqa: BLE001
+            out["bfs_sharded_weak"] = {"error": f"{type(e).__name__}: {e}"}
     # BASELINE config 4 shape: bfs over the 1190 Miller-Schupp presentations; the searches are independent, so they are dealt
     # round-robin to the ranks (no data-path collective) and overlapped 16 at a time on each GPU.  A failure on one rank is
     # carried through the closing all-reduce so that no rank is left waiting.
