@@ -17,6 +17,8 @@
 //     the heap's next minimum); the speculative children of later parents are dropped.  The batch
 //     size adapts: it doubles while batches run uncut and returns to one pass after a cut.
 //
+// A single search (acx_search) hands buckets of >= GreedyDev::hand_min queued parents to the whole-GPU kernels of
+// acx_greedy_mega.h: the kernel parks what it keeps in LDS (GreedyState), returns GREEDY_HANDOFF and is relaunched afterwards.
 // Several searches (acx_search_many) run as concurrent one-workgroup kernels on their own streams.
 // When a capacity of this scheme is exceeded (depth >= kDepthCap, arena exhausted) the kernel reports
 // GREEDY_FALLBACK and the host reruns the search on the batch-per-launch path.
@@ -35,7 +37,17 @@ namespace acx {
 constexpr int kGT = ACX_GREEDY_THREADS;  // lanes of the persistent workgroup
 constexpr uint32_t kDepthCap = 16384;  // bucket table rows per total length
 
-enum : uint32_t { GREEDY_RUNNING = 0, GREEDY_SOLVED = 1, GREEDY_BUDGET = 2, GREEDY_EXHAUSTED = 3, GREEDY_FALLBACK = 4, GREEDY_MOVE_ERROR = 5 };
+enum : uint32_t { GREEDY_RUNNING = 0, GREEDY_SOLVED = 1, GREEDY_BUDGET = 2, GREEDY_EXHAUSTED = 3, GREEDY_FALLBACK = 4, GREEDY_MOVE_ERROR = 5, GREEDY_HANDOFF = 6 };
+
+// What the persistent workgroup keeps in LDS between batches, parked in HBM when a single search hands a big bucket to the
+// whole-GPU kernels of acx_greedy_mega.h (GREEDY_HANDOFF) and read back when it is relaunched (`resume`).
+struct GreedyState {
+    uint32_t len_count[132], hint[132], hist[32];
+    uint32_t arena_top, nodes, status, reason, err, seen_min, np_cap, last_parent, solved_pid, last_child_len, solved_action, max_bucket;
+    uint32_t cur_len, cur_depth, resume, pad_;
+    unsigned long long expanded, batches, sorts, big_sorts, mega_batches, mega_parents;
+    unsigned long long t_phase[12];  // ACX_GREEDY_PROFILE
+};
 
 struct BucketRec {
     uint32_t off;         // first arena entry of the region
@@ -67,6 +79,8 @@ template <typename W> struct GreedyDev {
     uint32_t nlen;      // 2L + 1 total lengths
     long long max_nodes;
     uint32_t root_len;
+    uint32_t hand_min;   // 0: never; else a selected bucket with at least this many queued parents ends the kernel with GREEDY_HANDOFF
+    GreedyState* state;  // nullable (k_greedy_multi): where the frontier is parked / resumed from
 };
 
 struct GreedyOut {
@@ -75,6 +89,7 @@ struct GreedyOut {
     unsigned long long expanded, batches;
     uint32_t fallback_reason, max_bucket;
     uint32_t path_n, pad_;
+    uint32_t hand_len, hand_depth, hand_live, hand_sort;  // GREEDY_HANDOFF: the bucket, its queued parents, 1 = it has an unsorted tail
     unsigned long long sorts, big_sorts;
     uint32_t hist_sort[16];  // sorts by log2(bucket size)
     uint32_t hist_np[16];    // batches by log2(parents)
@@ -211,7 +226,37 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
     (void)s_tc;
 #endif
     __syncthreads();
-    if (tid == 0) {
+    const bool resume = g.state != nullptr && g.state->resume != 0;
+    if (resume) {  // relaunched after a hand-off: the frontier as it was parked (and as the whole-GPU kernels left it)
+        const GreedyState* ps = g.state;
+        if (tid < 132) {
+            s_len_count[tid] = ps->len_count[tid];
+            s_hint[tid] = ps->hint[tid];
+        }
+        if (tid < 32) s_hist[tid] = ps->hist[tid];
+        if (tid < 12) s_tph[tid] = ps->t_phase[tid];
+        if (tid == 0) {
+            s_arena_top = ps->arena_top;
+            s_nodes = ps->nodes;
+            s_status = ps->status;
+            s_reason = ps->reason;
+            s_err = ps->err;
+            s_seen_min = ps->seen_min;
+            s_expanded = ps->expanded;
+            s_batches = ps->batches;
+            s_sorts = ps->sorts;
+            s_big_sorts = ps->big_sorts;
+            s_max_bucket = ps->max_bucket;
+            s_last_parent = ps->last_parent;
+            s_solved_pid = ps->solved_pid;
+            s_last_child_len = ps->last_child_len;
+            s_solved_action = ps->solved_action;
+            s_np_cap = ps->np_cap;
+            s_flag = 0;
+            s_sorted_in_lds = 0;
+            s_fdepth = 0xFFFFFFFFu;
+        }
+    } else if (tid == 0) {
         // root: node 0, first entry of the visited table and of the heap (bucket (root_len, 0))
         g.nkeys[0].k0 = g.root_k0;
         g.nkeys[0].k1 = g.root_k1;
@@ -249,7 +294,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
     }
     __syncthreads();
 
-    for (;;) {
+    while (s_status == GREEDY_RUNNING) {  // (a resumed search may have ended in the whole-GPU kernels)
         // ================================================================= select the minimum bucket ====
         if (!s_flag) {
             if (tid == 0) {
@@ -298,8 +343,16 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
             }
             __syncthreads();
             ACX_TICK(0);
-            // ---- order the bucket by the signed state tuple if it has an unsorted tail ----------------------
             const uint32_t n = s_rec.cnt - s_rec.head;
+            if (g.hand_min && n >= g.hand_min) {
+                // a big bucket: park the frontier; the host runs this bucket on the whole GPU and relaunches this kernel
+                // (every bucket record goes back to HBM: the selected one is there already, the cached depth follows)
+                if (tid < nlen && s_fdepth != 0xFFFFFFFFu) g.bk[(size_t)tid * kDepthCap + s_fdepth] = s_frec[tid];
+                if (tid == 0) s_status = GREEDY_HANDOFF;
+                __syncthreads();
+                break;
+            }
+            // ---- order the bucket by the signed state tuple if it has an unsorted tail ----------------------
             if (s_rec.sorted_end < s_rec.cnt && n > 1) {
                 const uint32_t base = s_rec.off + s_rec.head;
                 if (tid == 0) {
@@ -790,7 +843,41 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         if (s_status != GREEDY_RUNNING) break;
     }
 #undef ACX_TICK
+    if (g.state) {
+        GreedyState* ps = g.state;
+        if (tid < 132) {
+            ps->len_count[tid] = s_len_count[tid];
+            ps->hint[tid] = s_hint[tid];
+        }
+        if (tid < 32) ps->hist[tid] = s_hist[tid];
+        if (tid < 12) ps->t_phase[tid] = s_tph[tid];
+        if (tid == 0) {
+            ps->arena_top = s_arena_top;
+            ps->nodes = s_nodes;
+            ps->status = s_status == GREEDY_HANDOFF ? (uint32_t)GREEDY_RUNNING : s_status;
+            ps->reason = s_reason;
+            ps->err = s_err;
+            ps->seen_min = s_seen_min;
+            ps->expanded = s_expanded;
+            ps->batches = s_batches;
+            ps->sorts = s_sorts;
+            ps->big_sorts = s_big_sorts;
+            ps->max_bucket = s_max_bucket;
+            ps->last_parent = s_last_parent;
+            ps->solved_pid = s_solved_pid;
+            ps->last_child_len = s_last_child_len;
+            ps->solved_action = s_solved_action;
+            ps->np_cap = s_np_cap;
+            ps->cur_len = s_cur_len;
+            ps->cur_depth = s_cur_depth;
+            ps->resume = 1;
+        }
+    }
     if (tid == 0) {
+        out->hand_len = s_cur_len;
+        out->hand_depth = s_cur_depth;
+        out->hand_live = s_status == GREEDY_HANDOFF ? s_rec.cnt - s_rec.head : 0u;
+        out->hand_sort = s_status == GREEDY_HANDOFF && s_rec.sorted_end < s_rec.cnt ? 1u : 0u;
         out->status = s_status;
         out->nodes = s_nodes;
         out->min_len = s_status == GREEDY_SOLVED ? 2u : s_seen_min;

@@ -27,6 +27,7 @@
 #include "acx_bfs.h"
 #include "acx_bfs_multi.h"
 #include "acx_greedy.h"
+#include "acx_greedy_mega.h"
 
 namespace acx {
 
@@ -276,6 +277,8 @@ template <typename W> struct GreedySearch {
         g.nlen = (uint32_t)(2 * L + 1);
         g.max_nodes = (long long)max_nodes;
         g.root_len = (uint32_t)(root.n0 + root.n1);
+        g.hand_min = 0;
+        g.state = nullptr;
         const uint64_t arena_entries = std::min<uint64_t>(8ull * (uint64_t)std::max<int64_t>(max_nodes, 1) + (1ull << 20), 1ull << 31);
         g.arena_cap = (uint32_t)arena_entries;
         if (nkeys.alloc(S.cap_nodes * sizeof(NodeKey<W>)) || tab.alloc(S.n_slots * 8)) return ACX_E_NOMEM;
@@ -375,6 +378,8 @@ static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_no
         g.nlen = nlen;
         g.max_nodes = (long long)max_nodes;
         g.root_len = (uint32_t)(root.n0 + root.n1);
+        g.hand_min = 0;
+        g.state = nullptr;
         g.root_k0 = keyops<W>::make(root.w0, root.n0);
         g.root_k1 = keyops<W>::make(root.w1, root.n1);
     }
@@ -581,18 +586,80 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
     DevBuf outb;
     if (outb.alloc(sizeof(GreedyOut))) return ACX_E_NOMEM;
     ACX_HIP_TRY(hipMemsetAsync(outb.p, 0, sizeof(GreedyOut), st));
+    // big buckets go to the whole-GPU kernels of acx_greedy_mega.h (0: the persistent workgroup does everything)
+    uint32_t hand_min = 1024;
+    if (const char* hm = getenv("ACX_GREEDY_HAND_MIN")) hand_min = (uint32_t)strtoul(hm, nullptr, 10);
+    DevBuf stateb, mck0, mck1, mclen, minfo, midv, mposv, mtab, mscal;
+    MegaDev<W> md;
+    GreedyState hstate;
+    if (hand_min) {
+        if (stateb.alloc(sizeof(GreedyState)) || mck0.alloc((size_t)kMegaTags * sizeof(W)) || mck1.alloc((size_t)kMegaTags * sizeof(W)) || mclen.alloc(kMegaTags) ||
+            minfo.alloc((size_t)kMegaTags * 4) || midv.alloc((size_t)kMegaTags * 4) || mposv.alloc((size_t)kMegaTags * 4) || mtab.alloc((size_t)kMegaSlots * 4) ||
+            mscal.alloc(sizeof(MegaScalars)))
+            return ACX_E_NOMEM;
+        ACX_HIP_TRY(hipMemsetAsync(stateb.p, 0, sizeof(GreedyState), st));
+        g.hand_min = hand_min;
+        g.state = (GreedyState*)stateb.p;
+        md.ck0 = (W*)mck0.p;
+        md.ck1 = (W*)mck1.p;
+        md.clen = (uint8_t*)mclen.p;
+        md.info = (uint32_t*)minfo.p;
+        md.idv = (uint32_t*)midv.p;
+        md.posv = (uint32_t*)mposv.p;
+        md.mtab = (uint32_t*)mtab.p;
+        md.sc = (MegaScalars*)mscal.p;
+    } else {
+        g.hand_min = 0;
+        g.state = nullptr;
+    }
+    md.g = g;
     EventPair evs;
     ACX_HIP_TRY(evs.create());
     hipEvent_t ev0 = evs.a, ev1 = evs.b;
     ACX_HIP_TRY(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(k_greedy_persistent<W>, dim3(1), dim3(kGT), 0, st, g, (GreedyOut*)outb.p);
-    ACX_HIP_TRY(hipGetLastError());
-    ACX_HIP_TRY(hipEventRecord(ev1, st));
     GreedyOut o;
-    ACX_HIP_TRY(hipMemcpyAsync(&o, outb.p, sizeof(o), hipMemcpyDeviceToHost, st));
-    ACX_HIP_TRY(hipStreamSynchronize(st));
+    unsigned long long handoffs = 0;
+    for (;;) {
+        hipLaunchKernelGGL(k_greedy_persistent<W>, dim3(1), dim3(kGT), 0, st, g, (GreedyOut*)outb.p);
+        ACX_HIP_TRY(hipGetLastError());
+        ACX_HIP_TRY(hipMemcpyAsync(&o, outb.p, sizeof(o), hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipStreamSynchronize(st));
+        if (o.status != GREEDY_HANDOFF) break;
+        handoffs++;
+        // ---- the selected bucket on the whole GPU: order it, then mega-batches until it is used up, cut, or the search ends ----
+        uint32_t live = o.hand_live;
+        if (o.hand_sort) {
+            const uint32_t n = live, SC = kMegaRun;
+            hipLaunchKernelGGL(k_gm_runsort<W>, dim3((n + SC - 1) / SC), dim3(kGT), 0, st, md, n);
+            hipLaunchKernelGGL(k_gm_merge<W>, dim3((n + 255) / 256), dim3(256), 0, st, md, n);
+        }
+        for (;;) {
+            const uint32_t np = std::min<uint32_t>(live, kMegaParents), m = 12u * np;
+            uint32_t slots = 1024;
+            while (slots < 2 * m) slots <<= 1;
+            hipLaunchKernelGGL(k_gm_begin<W>, dim3(std::max<uint32_t>(1, slots / 1024)), dim3(256), 0, st, md, slots);
+            hipLaunchKernelGGL(k_gm_expand<W>, dim3((m + 255) / 256), dim3(256), 0, st, md, m, slots - 1);
+            hipLaunchKernelGGL(k_gm_mark<W>, dim3((m + kMegaTile - 1) / kMegaTile), dim3(kMegaTile), 0, st, md, m);
+            hipLaunchKernelGGL(k_gm_decide<W>, dim3(1), dim3(256), 0, st, md, np, m);
+            hipLaunchKernelGGL(k_gm_commit<W>, dim3((m + kMegaTile - 1) / kMegaTile), dim3(kMegaTile), 0, st, md, m);
+            hipLaunchKernelGGL(k_gm_file<W>, dim3(1), dim3(256), 0, st, md, np);
+            hipLaunchKernelGGL(k_gm_push<W>, dim3((m + 255) / 256), dim3(256), 0, st, md, m);
+            ACX_HIP_TRY(hipGetLastError());
+            uint32_t res[3];  // status, cut, remaining (consecutive in MegaScalars)
+            ACX_HIP_TRY(hipMemcpyAsync(res, (const uint8_t*)mscal.p + offsetof(MegaScalars, status), sizeof(res), hipMemcpyDeviceToHost, st));
+            ACX_HIP_TRY(hipStreamSynchronize(st));
+            if (res[0] != GREEDY_RUNNING || res[1] || res[2] == 0) break;
+            live = res[2];
+        }
+    }
+    ACX_HIP_TRY(hipEventRecord(ev1, st));
+    ACX_HIP_TRY(hipEventSynchronize(ev1));
     float ms = 0;
     ACX_HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    if (hand_min && getenv("ACX_DEBUG")) {
+        ACX_HIP_TRY(hipMemcpy(&hstate, stateb.p, sizeof(hstate), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[acx_greedy] hand-offs=%llu mega-batches=%llu with %llu parents\n", handoffs, hstate.mega_batches, hstate.mega_parents);
+    }
     if (getenv("ACX_DEBUG"))
         fprintf(stderr, "[acx_greedy] status=%u nodes=%u batches=%llu expanded=%llu sorts=%llu big_sorts=%llu max_bucket=%u reason=%u %.3f ms\n", o.status, o.nodes,
                 o.batches, o.expanded, o.sorts, o.big_sorts, o.max_bucket, o.fallback_reason, ms);

@@ -150,6 +150,35 @@ def test_greedy_batch_per_launch_path_equals_device_frontier(search, golden_json
         assert a[2]["min_len"] >= b[2]["min_len"]  # the batch path also counts children of parents it speculated on
 
 
+@pytest.mark.parametrize("hand_min", [1, 6, 100])
+def test_greedy_whole_gpu_batches_equal_the_reference(search, golden_json, monkeypatch, hand_min):
+    """A single greedy_search hands buckets of >= 1024 parents to the whole-GPU kernels (acx_greedy_mega.h).  With the
+    threshold lowered (ACX_GREEDY_HAND_MIN) every bucket of the fixture searches takes that route: reference-generated
+    paths (all widths incl. 128-bit words, both `cyclical`, solved / budget / raising rows) and the oracle's node counts."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search
+    from oracle import ac_oracle as O
+
+    monkeypatch.setenv("ACX_GREEDY_HAND_MIN", str(hand_min))
+    cap = 10**5 if hand_min == 1 else 10**6
+    n = 0
+    for r in golden_json("search.json"):
+        if r["algo"] != "greedy" or r["budget"] > cap:
+            continue
+        ok, path = search.greedy_search(r["presentation"], r["budget"], cyclically_reduce_after_moves=r["cyclical"])
+        assert ok == r["solved"] and path == _as_tuples(r["path"]), (r["tag"], r["budget"], r["cyclical"])
+        n += 1
+    assert n > 100
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    rng = np.random.default_rng(hand_min)
+    for k in rng.choice(len(pool), size=6, replace=False):
+        for budget, cyc in ((40000, False), (7000, True)):
+            got = run_search(_acx.SEARCH_GREEDY, np.array(pool[k], dtype=np.int8), budget, cyc)
+            wok, wpath, wst = O.greedy_search(pool[k], budget, cyclically_reduce_after_moves=cyc, stats=True)
+            assert got[:2] == (wok, wpath), (int(k), budget, cyc)
+            assert got[2]["nodes"] == wst["nodes"] and got[2]["expanded"] == wst["expanded"], (int(k), budget, cyc)
+
+
 def test_greedy_paths_file_sample(search, golden_json):
     """data/greedy_search_paths.txt (budget 1e6): a sample through the device frontier at native L (up to 36 -> 128-bit keys)"""
     pool = ms_pool_generator_order(golden_json("ms_pool.json"))
