@@ -8,14 +8,33 @@ import torch
 from ac_solver import _acx
 
 
-def _fragments(w, rows, cols):
-    """nn.Linear weight [out, in] zero-padded to [rows, cols] (multiples of 32 / 16) -> the A-operand fragments of
-    v_mfma_f32_32x32x16_bf16 in the order the kernel reads them: [out block][k step][lane][8], lane = 32 * (k half) + row"""
+TANH_SCALE = 2.0 / float(np.log(2.0))  # tanh(x) = 1 - 2 / (2^(x * TANH_SCALE) + 1): folded into the layers that feed a tanh
+
+
+def _fragments(w, b, rows, cols, hidden_input, scale=1.0):
+    """nn.Linear weight [out, in] / bias zero-padded to [rows, cols] (multiples of 32 / 16) -> the A-operand fragments of
+    v_mfma_f32_32x32x16_bf16 in the order the kernel reads them: [out block][bias step, k steps][lane][8], lane = 32 * h + row.
+    Element j of lane (row, h) in k-step ks is input 16 ks + 8 h + j for the first layer; for a layer fed by a hidden layer it
+    is hidden unit 32 (ks >> 1) + 16 (ks & 1) + 8 (j >> 2) + 4 h + (j & 3): the eight accumulator registers the lane of the
+    previous layer already holds (csrc/acx_policy.hip).  The bias step carries b as bf16 hi + lo in j = 0, 1 of h = 0.
+    `scale` multiplies weight and bias before the rounding to bf16 (TANH_SCALE for the two hidden layers)."""
     out, inp = w.shape
-    pad = torch.zeros((rows, cols), dtype=torch.float32, device=w.device)
-    pad[:out, :inp] = w.detach().float()
-    t = pad.view(rows // 32, 32, cols // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()  # [ob][ks][h][r][j]
-    return t.view(-1).to(torch.bfloat16)
+    dev = w.device
+    pad = torch.zeros((rows, cols), dtype=torch.float32, device=dev)
+    pad[:out, :inp] = w.detach().float() * scale
+    nks = cols // 16
+    ks = torch.arange(nks, device=dev).view(nks, 1, 1)
+    hh = torch.arange(2, device=dev).view(1, 2, 1)
+    j = torch.arange(8, device=dev).view(1, 1, 8)
+    idx = (32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * hh + (j & 3)) if hidden_input else (16 * ks + 8 * hh + j)
+    t = pad[:, idx.reshape(-1)].view(rows // 32, 32, nks, 2, 8).permute(0, 2, 3, 1, 4)  # [ob][ks][h][row][j]
+    bias = torch.zeros(rows, dtype=torch.float32, device=dev)
+    bias[:out] = b.detach().float() * scale
+    hi = bias.to(torch.bfloat16).float()
+    bf = torch.zeros((rows // 32, 1, 2, 32, 8), dtype=torch.float32, device=dev)
+    bf[:, 0, 0, :, 0] = hi.view(-1, 32)
+    bf[:, 0, 0, :, 1] = (bias - hi).view(-1, 32)
+    return torch.cat([bf, t], dim=1).contiguous().view(-1).to(torch.bfloat16)
 
 
 def supported(agent, in_dim):
@@ -29,14 +48,12 @@ def supported(agent, in_dim):
 
 
 def pack_network(seq, in_dim):
-    """[Linear, Tanh, Linear, Tanh, Linear] -> one uint8 device tensor: fragments of the three layers, then the f32 biases"""
+    """[Linear, Tanh, Linear, Tanh, Linear] -> one uint8 device tensor: the fragments of the three layers, bias fragments included"""
     lin = [m for m in seq if isinstance(m, torch.nn.Linear)]
     ks1 = (in_dim + 15) // 16
-    parts = [_fragments(lin[0].weight, 256, 16 * ks1), _fragments(lin[1].weight, 256, 256), _fragments(lin[2].weight, 32, 256)]
-    b3 = torch.zeros(32, dtype=torch.float32, device=lin[2].bias.device)
-    b3[:lin[2].out_features] = lin[2].bias.detach().float()
-    raw = [p.view(torch.uint8) for p in parts] + [b.detach().float().contiguous().view(torch.uint8) for b in (lin[0].bias, lin[1].bias)] + [b3.view(torch.uint8)]
-    out = torch.cat(raw).contiguous()
+    parts = [_fragments(lin[0].weight, lin[0].bias, 256, 16 * ks1, False, TANH_SCALE), _fragments(lin[1].weight, lin[1].bias, 256, 256, True, TANH_SCALE),
+             _fragments(lin[2].weight, lin[2].bias, 32, 256, True)]
+    out = torch.cat([p.view(torch.uint8) for p in parts]).contiguous()
     assert out.numel() == _acx.lib.acx_policy_packed_bytes(in_dim)
     return out
 

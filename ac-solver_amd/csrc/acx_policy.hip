@@ -7,18 +7,21 @@
 //
 // Formulation (one wave = 32 environments, one workgroup = 8 waves = 256 environments):
 //   every layer is computed TRANSPOSED,  H^T[out, env] = W[out, in] . X^T[in, env] + b,  with v_mfma_f32_32x32x16_bf16:
-//   A = a 32 x 16 tile of the nn.Linear weight (pre-packed on the host into per-lane fragments, 16 B per lane; fetched once
-//   per workgroup and k-step from L2 -- the whole network is 350 KB -- into a double-buffered LDS stage that all eight
-//   waves read), B = 16 inputs x 32 environments, C = 32 outputs x 32 environments
-//   with the environment on the lane.  The 256 outputs of a hidden layer are eight such tiles = 128 accumulator registers;
-//   bias is the accumulator's initial value, tanh is applied in registers, and the activations go through a bf16
-//   [env][hidden] image in LDS (row pitch 528 B: conflict-free 16-byte fragment reads) to become the next layer's B operand.
+//   A = a 32 x 16 tile of the nn.Linear weight (a 1 KB per-lane fragment packed on the host), B = 16 inputs x 32 environments,
+//   C = 32 outputs x 32 environments with the environment on the lane.  Output block by output block (32 hidden units = one
+//   16-register accumulator): its bias step and k-steps, then tanh -> bf16 in registers -- which IS the B operand of two
+//   k-steps of the next layer (see "K order" below): activations never touch LDS.
+//   Weights: the whole fragment sequence of both networks (2 x 185 KB at 50 inputs) streams once per workgroup through a ring
+//   of six 17 KB LDS slots, filled by global_load_lds_dwordx4 five chunks ahead of the MFMAs that read them (counted vmcnt,
+//   raw s_barrier per chunk), shared by the eight waves.
 //   The heads leave the 12 logits / the value of an environment in two lanes (l and l + 32); one shuffle gathers them and
 //   lane l < 32 finishes: log-softmax, a Gumbel-max draw (counter-based hash of (seed, env, action): an exact sample of
 //   Categorical(softmax(logits))), log-probability, value.
 // Arithmetic: bf16 inputs, weights and activations, f32 accumulation (the reference's policy is f32 torch: the test compares
 // with a torch f32 forward at bf16 tolerance and with a bf16-rounded emulation tightly).  Only inference: the PPO update
 // keeps torch autograd on the f32 master weights; FusedPolicy.refresh() re-packs them after every optimizer step.
+#include <type_traits>
+
 #include "acx_common.h"
 
 namespace acx {
@@ -27,18 +30,24 @@ namespace policy {
 typedef __attribute__((ext_vector_type(8))) short frag_ab;   // 8 bf16
 typedef __attribute__((ext_vector_type(16))) float frag_cd;  // 32 x 32 f32 tile: 16 per lane
 
-constexpr int kHidden = 256;
-constexpr int kRowPitch = kHidden * 2 + 16;  // bytes per environment in the LDS activation image
 
 __device__ __forceinline__ unsigned short bf16_of(float x) {  // round to nearest even
     unsigned int u = __float_as_uint(x);
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
-__device__ __forceinline__ float tanh_fast(float x) {
-    // tanh(x) = 1 - 2 / (exp(2x) + 1) with v_exp_f32 (2^y) and v_rcp_f32; overflow gives +inf -> 1, underflow 0 -> -1
-    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // 2 / ln 2
-    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+__device__ __forceinline__ float tanh_scaled(float y) {
+    // tanh(x) = 1 - 2 / (exp(2x) + 1) for y = x * 2 / ln 2 (the factor is folded into the layer's weights and bias on the host):
+    // v_exp_f32 (2^y), v_add, v_rcp_f32, v_fma; overflow gives +inf -> 1, underflow 0 -> -1
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y) + 1.0f), 1.0f);
+}
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
 }
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x ^= x >> 32;
@@ -49,45 +58,65 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
-// packed network: [layer 1: 8 out-blocks x KS1 k-steps][layer 2: 8 x 16][head: 1 x 16] fragments of 64 lanes x 8 bf16,
-// then the f32 biases (256 + 256 + 32)
-struct Net {
-    const frag_ab* w1;
-    const frag_ab* w2;
-    const frag_ab* w3;
-    const float* b1;
-    const float* b2;
-    const float* b3;
+// ---- packed network (ac_solver/agents/fused_policy.py::pack_network) ----------------------------------------------------------
+// A sequence of 1 KB FRAGMENTS (64 lanes x 8 bf16, the A operand of one MFMA), grouped by 32-row output block:
+//   layer 1: 8 blocks x (1 bias fragment + KS1 k-steps), layer 2: 8 x (1 + 16), head: 1 x (1 + 16).
+// The bias fragment carries b[row] as bf16 hi + lo in k = 0, 1; its B operand is the constant (1, 1, 0, ...), so an output
+// block starts as  acc = mfma(bias fragment, ones, 0)  -- no bias loads, no accumulator initialisation.
+// K order of layer 2 / head: the hidden value that the PREVIOUS layer's accumulator holds in register v of lane (env, h) of
+// output block ob is row 32 ob + 8 (v >> 2) + 4 h + (v & 3).  A k-step may contract ANY 16 hidden units as long as A and B
+// agree, so k-step 2 ob + half takes exactly the eight values v = 8 half .. 8 half + 7 that each lane already owns:
+// tanh -> bf16 -> the next layer's B operand never leaves the lane's registers (no activation image, no LDS round trip).
+constexpr int kWaves = 8;          // waves per workgroup: 256 environments share every staged fragment
+constexpr int kSlotFrags = 17;     // fragments per ring slot (one output block of a 256-wide layer)
+constexpr int kSlotBytes = kSlotFrags * 1024;
+constexpr int kRing = 6;           // slots
+constexpr int kAhead = kRing - 1;  // chunks in flight ahead of the one being consumed
+#ifndef ACX_POLICY_FRAG_AHEAD
+#define ACX_POLICY_FRAG_AHEAD 5
+#endif
+constexpr int kFragAhead = ACX_POLICY_FRAG_AHEAD;  // A fragments read from LDS this many MFMAs ahead of their use
+
+template <int KS1> struct plan {
+    static constexpr int F1 = KS1 + 1;             // fragments per layer-1 output block
+    static constexpr int OPC = kSlotFrags / F1;    // layer-1 output blocks per chunk
+    static constexpr int C1 = (8 + OPC - 1) / OPC; // layer-1 chunks
+    static constexpr int CN = C1 + 8 + 1;          // chunks per network
+    static constexpr int C = 2 * CN;               // actor, then critic
+    static constexpr int first(int cc) { return cc < C1 ? cc * OPC * F1 : (cc < C1 + 8 ? 8 * F1 + (cc - C1) * 17 : 8 * F1 + 8 * 17); }
+    static constexpr int obs_in(int cc) { return (cc + 1) * OPC < 8 ? OPC : 8 - cc * OPC; }
+    static constexpr int count(int cc) { return cc < C1 ? obs_in(cc) * F1 : 17; }
+    // vmcnt that retires chunk c: every wave issues three loads per chunk (fragments w and w + 8, an eighth of fragment 16)
+    static constexpr int pending_after(int c) {
+        int n = 0;
+        for (int k = c + 1; k < C && k < c + kAhead; k++) n += 3;  // (c >= C - 1: nothing)
+        return n;
+    }
 };
 
-constexpr int kWaves = 8;                                  // waves per workgroup: 256 environments share every staged weight tile
-constexpr int kActBytes = kWaves * 32 * kRowPitch;         // LDS: the activation images ...
-constexpr int kStageFrags = 8 * 64;                        // ... and two buffers of the 8 weight fragments (8 KB) of one k-step
-
-// one hidden layer: acc[ob] += W[32 ob .. +32][16 ks .. +16] . B(ks) over `nks` k-steps.  The k-step's eight weight fragments
-// are fetched ONCE per workgroup (thread t brings fragment t of 512), parked in LDS and read from there by all eight waves;
-// the fetch of k-step ks + 1 is in flight while the MFMAs of k-step ks run (two buffers, one barrier per k-step).  Reading the
-// fragments per wave straight from L2 needs 128 B/clk per CU at full MFMA rate -- twice what a CU's vector memory path
-// delivers -- and left the matrix pipe at 12 % (232 -> 158 us per 131 072 environments with register prefetch alone).
-template <typename BFRAG>
-__device__ __forceinline__ void layer(frag_cd (&acc)[8], const frag_ab* __restrict__ w, int nks, BFRAG bfrag, frag_ab* __restrict__ stage, uint32_t tid, uint32_t lane) {
-    const uint32_t ob_t = tid >> 6, lane_t = tid & 63u;
-    frag_ab nxt = w[(ob_t * nks) * 64 + lane_t];
-    stage[tid] = nxt;
-    __syncthreads();
-    for (int ks = 0; ks < nks; ks++) {
-        const frag_ab* cur = stage + (ks & 1) * kStageFrags;
-        if (ks + 1 < nks) nxt = w[(ob_t * nks + ks + 1) * 64 + lane_t];
-        const frag_ab b = bfrag(ks);
-#pragma unroll
-        for (int ob = 0; ob < 8; ob++) acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[ob * 64 + lane], b, acc[ob], 0, 0, 0);
-        if (ks + 1 < nks) stage[((ks + 1) & 1) * kStageFrags + tid] = nxt;
-        __syncthreads();
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
     }
+}
+
+// one lane-linear 1 KB fragment global -> LDS without a register stop (global_load_lds_dwordx4; M0 = LDS destination of the wave).
+// `mask`: the lanes that take part (EXEC for this one instruction) -- a masked-off load is issued all the same, so every wave
+// issues the same number of loads per chunk and the counted s_waitcnt below holds for all of them, without a branch.
+__device__ __forceinline__ void glds16(const frag_ab* __restrict__ src_lane, uint32_t lds_dst, unsigned long long mask) {
+    unsigned keep;
+    unsigned long long keep_exec;
+    asm volatile(
+        "s_mov_b64 %1, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0\n\ts_mov_b64 exec, %1"
+        : "=&s"(keep), "=&s"(keep_exec)
+        : "v"(src_lane), "s"(lds_dst), "s"(mask)
+        : "memory");
 }
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: round to nearest even, two at a time
     f32x2 v;
     v[0] = a;
@@ -95,73 +124,16 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // v_cvt_pk_b
     const bf16x2 r = __builtin_convertvector(v, bf16x2);
     return __builtin_bit_cast(uint32_t, r);
 }
-
-__device__ __forceinline__ void store_tanh(const frag_cd (&acc)[8], uint8_t* __restrict__ row, uint32_t h) {
-    // tanh -> bf16 -> LDS image [env r][hidden]: the lane owns hidden rows (v&3) + 8 (v>>2) + 4h of each 32-block
-#pragma unroll
-    for (int ob = 0; ob < 8; ob++)
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-            *(uint2*)(row + 2 * (32 * ob + 8 * g + 4 * h)) = make_uint2(pack_bf16(tanh_fast(acc[ob][4 * g]), tanh_fast(acc[ob][4 * g + 1])),
-                                                                        pack_bf16(tanh_fast(acc[ob][4 * g + 2]), tanh_fast(acc[ob][4 * g + 3])));
-}
-
-// accumulators start from the bias: the lane's rows (v&3) + 8 (v>>2) + 4h of block ob are four runs of four consecutive floats
-__device__ __forceinline__ void load_bias(frag_cd (&acc)[8], const float* __restrict__ b, uint32_t h) {
-#pragma unroll
-    for (int ob = 0; ob < 8; ob++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float4 v = *(const float4*)(b + 32 * ob + 8 * g + 4 * h);
-            acc[ob][4 * g] = v.x;
-            acc[ob][4 * g + 1] = v.y;
-            acc[ob][4 * g + 2] = v.z;
-            acc[ob][4 * g + 3] = v.w;
-        }
-}
-
-// one network on the wave's 32 environments; returns the head tile (outputs 0..31 x 32 environments)
 template <int KS1>
-__device__ __forceinline__ frag_cd forward(const Net& n, const frag_ab (&x)[KS1], uint8_t* __restrict__ act, frag_ab* __restrict__ stage, uint32_t tid, uint32_t lane) {
-    const uint32_t r = lane & 31u, h = lane >> 5;
-    uint8_t* row = act + r * kRowPitch;
-    frag_cd acc[8];
-    // ---- layer 1 -----------------------------------------------------------------------------------------------------------
-    load_bias(acc, n.b1, h);
-    layer(acc, n.w1, KS1, [&](int ks) {
-        frag_ab b = x[0];
-#pragma unroll
-        for (int k = 1; k < KS1; k++) b = ks == k ? x[k] : b;  // register array, no dynamic indexing
-        return b;
-    }, stage, tid, lane);
-    store_tanh(acc, row, h);
-    // ---- layer 2 (a wave reads back only its own 32 rows; the barriers of layer() order the image anyway) -----------------------
-    load_bias(acc, n.b2, h);
-    layer(acc, n.w2, 16, [&](int ks) { return *(const frag_ab*)(row + 2 * (16 * ks + 8 * h)); }, stage, tid, lane);
-    store_tanh(acc, row, h);
-    // ---- head: one output block, its 16 fragments straight from L2 -------------------------------------------------------------
-    frag_cd out;
-#pragma unroll
-    for (int v = 0; v < 16; v++) out[v] = n.b3[(v & 3) + 8 * (v >> 2) + 4 * h];
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's rows of the image are complete
-#pragma unroll 8
-    for (int ks = 0; ks < 16; ks++) {
-        const frag_ab b = *(const frag_ab*)(row + 2 * (16 * ks + 8 * h));
-        out = __builtin_amdgcn_mfma_f32_32x32x16_bf16(n.w3[ks * 64 + lane], b, out, 0, 0, 0);
-    }
-    return out;
-}
-
-template <int KS1>
-__global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const float* __restrict__ obs, int64_t n_env, int in_dim, Net actor, Net critic, int n_actions,
-                                                                 unsigned long long seed, int64_t* __restrict__ action, float* __restrict__ logprob,
-                                                                 float* __restrict__ value) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];  // activation images, then the two weight stages
+__global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const float* __restrict__ obs, int64_t n_env, int in_dim, const frag_ab* __restrict__ actor,
+                                                                 const frag_ab* __restrict__ critic, int n_actions, unsigned long long seed,
+                                                                 int64_t* __restrict__ action, float* __restrict__ logprob, float* __restrict__ value) {
+    using P = plan<KS1>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];  // the fragment ring
     ACX_VGPR_PAD("v255");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, r = lane & 31u, h = lane >> 5;
     const int64_t env = ((int64_t)blockIdx.x * kWaves + wave) * 32 + r;
-    uint8_t* act = s_mem + wave * 32 * kRowPitch;
-    frag_ab* stage = (frag_ab*)(s_mem + kActBytes);
+    const uint32_t ring = (uint32_t)(uintptr_t)s_mem;  // LDS byte address (low half of the flat address)
     // B operand of layer 1: the lane's environment, inputs 16 ks + 8 h .. + 7 (zero beyond in_dim / n_env)
     frag_ab x[KS1];
 #pragma unroll
@@ -171,8 +143,124 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const float* _
             const int k = 16 * ks + 8 * (int)h + j;
             x[ks][j] = (env < n_env && k < in_dim) ? (short)bf16_of(obs[env * in_dim + k]) : (short)0;
         }
-    const frag_cd logit = forward<KS1>(actor, x, act, stage, tid, lane);
-    const frag_cd val = forward<KS1>(critic, x, act, stage, tid, lane);
+    frag_ab ones;
+#pragma unroll
+    for (int j = 0; j < 8; j++) ones[j] = (h == 0 && j < 2) ? (short)0x3F80 : (short)0;
+
+    const frag_ab* src_w[2] = {actor + wave * 64 + lane, critic + wave * 64 + lane};  // fragment `wave` of a chunk, this lane's 16 bytes
+    const frag_ab* src_l[2] = {actor + lane, critic + lane};                              // fragment 0 of a chunk, this lane's 16 bytes
+    const uint32_t ring_w = __builtin_amdgcn_readfirstlane(ring + wave * 1024u);
+    auto uniform64 = [](unsigned long long v) {  // (the EXEC masks must live in scalar registers)
+        return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    };
+    const unsigned long long all = uniform64(~0ull), none = uniform64(0ull);
+    const unsigned long long eighth = uniform64(0xFFull << (8u * wave));
+    auto issue = [&](auto ic) {  // chunk c of the stream -> ring slot c % kRing
+        constexpr int c = decltype(ic)::value;
+        constexpr int cc = c % P::CN, cnt = P::count(cc), slot = c % kRing, net = c < P::CN ? 0 : 1;
+        constexpr size_t first = (size_t)P::first(cc) * 64;
+        glds16(src_w[net] + first, ring_w + slot * kSlotBytes, all);
+        glds16(src_w[net] + first + 8 * 64, ring_w + slot * kSlotBytes + 8 * 1024, cnt >= 16 ? all : uniform64(wave + 8 < (uint32_t)cnt ? ~0ull : 0ull));
+        glds16(src_l[net] + first + 16 * 64, __builtin_amdgcn_readfirstlane(ring + slot * kSlotBytes + 16 * 1024), cnt == 17 ? eighth : none);
+    };
+    static_for<0, kAhead>(issue);
+
+#ifdef ACX_POLICY_STAMP
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
+    frag_ab hb1[16], hb2[16];  // tanh outputs of layers 1 and 2 as B operands (k-step 2 ob + half <- accumulator registers 8 half ..)
+    frag_cd pend;              // accumulator of the previous output block: its tanh is spread among this block's MFMAs
+    frag_cd head[2];
+    const frag_cd zero = {0};
+    // One output block: NM MFMAs (bias step, then the k-steps with B = bfrag(ks)) on the fragments S[0 .. NM), and -- in the gaps the
+    // matrix pipe leaves in the wave's issue slots -- the tanh of the PREVIOUS block's sixteen accumulator registers, a few after each
+    // MFMA.  __builtin_amdgcn_sched_barrier(0) pins that interleaving (left alone the scheduler runs all MFMAs, then all tanh:
+    // the wave then alternates between a phase that idles the matrix pipe and one that idles the vector pipe); the A fragments
+    // are read from LDS kFragAhead MFMAs ahead.
+    frag_ab apre[kFragAhead];  // the first fragments of the NEXT block, read at the end of the running one (no LDS latency bubble at a block's start)
+    auto block = [&](auto nm, const frag_ab* __restrict__ S, auto nm_next, const frag_ab* __restrict__ Snext, auto bfrag, bool have_pend, frag_ab& out_lo,
+                     frag_ab& out_hi) -> frag_cd {
+        constexpr int NM = decltype(nm)::value, NMN = decltype(nm_next)::value;
+        frag_ab a[NM];
+        u32x4 lo, hi;
+#pragma unroll
+        for (int i = 0; i < kFragAhead && i < NM; i++) a[i] = apre[i];
+        frag_cd acc;
+        constexpr int U = (NM + 1) / 2;                    // units of two MFMAs
+        constexpr int UT = (NM & 1) && U > 1 ? U - 1 : U;  // the units that carry tanh work (an odd block's last MFMA may consume out_hi)
+        static_for<0, U>([&](auto uu) {
+            constexpr int u = decltype(uu)::value;
+            static_for<2 * u, (2 * u + 2 < NM ? 2 * u + 2 : NM)>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                if constexpr (i + kFragAhead < NM) a[i + kFragAhead] = S[(i + kFragAhead) * 64];
+                if constexpr (i == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], ones, zero, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bfrag(std::integral_constant<int, i - 1>{}), acc, 0, 0, 0);
+            });
+            if (have_pend && u < UT) {
+                // two values at a time, their instruction chains interleaved: a transcendental's result is not consumed by the next
+                // instruction (that costs an s_nop each time), and the pair shares one v_cvt_pk_bf16_f32
+#pragma unroll
+                for (int q = 8 * u / UT; q < 8 * (u + 1) / UT; q++) {
+                    const float ea = __builtin_amdgcn_exp2f(pend[2 * q]), eb = __builtin_amdgcn_exp2f(pend[2 * q + 1]);
+                    const float da = ea + 1.0f, db = eb + 1.0f;
+                    const float ra = __builtin_amdgcn_rcpf(da), rb = __builtin_amdgcn_rcpf(db);
+                    const uint32_t pk = pack_bf16(__builtin_fmaf(-2.0f, ra, 1.0f), __builtin_fmaf(-2.0f, rb, 1.0f));
+                    if (q < 4) lo[q] = pk;
+                    else hi[q - 4] = pk;
+                    if (q == 3) out_lo = __builtin_bit_cast(frag_ab, lo);
+                    if (q == 7) out_hi = __builtin_bit_cast(frag_ab, hi);
+                }
+            }
+            if constexpr (u == U - 1) {
+#pragma unroll
+                for (int i = 0; i < kFragAhead && i < NMN; i++) apre[i] = Snext[i * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        return acc;
+    };
+    frag_ab unused_lo, unused_hi;
+    // chunk 0 has landed (for everyone: barrier) -> its first fragments
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(P::pending_after(0)) : "memory");
+#pragma unroll
+    for (int i = 0; i < kFragAhead && i < P::F1; i++) apre[i] = ((const frag_ab*)s_mem + lane)[i * 64];
+    static_for<0, P::C>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        constexpr int net = c / P::CN, cc = c % P::CN, slot = c % kRing;
+        constexpr int ccn = (c + 1) % P::CN, nm_of_next_chunk = c + 1 >= P::C ? 0 : (ccn < P::C1 ? P::F1 : 17);
+        // chunk c + 1 has landed for this wave's own loads ... and, behind the barrier, for everyone's (the running block reads its
+        // first fragments before it ends); chunk c - 1 is consumed, so its slot takes chunk c + kAhead
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(P::pending_after(c + 1)) : "memory");
+#ifdef ACX_POLICY_STAMP  // diagnostic build: shader-clock stamp per chunk into the (over-allocated) logprob buffer
+        logprob[n_env + (blockIdx.x & 1) * 512 + wave * 64 + c] = (float)(long long)(__builtin_amdgcn_s_memtime() - t_start);  // (no branch: all lanes store the same word)
+#endif
+        if constexpr (c + kAhead < P::C) issue(std::integral_constant<int, c + kAhead>{});
+        const frag_ab* S = (const frag_ab*)(s_mem + slot * kSlotBytes) + lane;
+        const frag_ab* Sn = (const frag_ab*)(s_mem + ((c + 1) % kRing) * kSlotBytes) + lane;  // first block of the next chunk
+        if constexpr (cc < P::C1) {  // ---- layer 1: a few output blocks per chunk
+            static_for<0, P::obs_in(cc)>([&](auto kk) {
+                constexpr int k = decltype(kk)::value, ob = cc * P::OPC + k;
+                constexpr int prev = ob > 0 ? ob - 1 : 0;
+                constexpr bool last = k + 1 == P::obs_in(cc);
+                const frag_cd acc = block(std::integral_constant<int, P::F1>{}, S + (k * P::F1) * 64, std::integral_constant<int, last ? nm_of_next_chunk : P::F1>{},
+                                          last ? Sn : S + ((k + 1) * P::F1) * 64, [&](auto ks) { return x[decltype(ks)::value]; }, ob > 0,
+                                          ob > 0 ? hb1[2 * prev] : unused_lo, ob > 0 ? hb1[2 * prev + 1] : unused_hi);
+                pend = acc;
+            });
+        } else if constexpr (cc < P::C1 + 8) {  // ---- layer 2: one output block per chunk; block 0 also finishes layer 1's last tanh
+            constexpr int ob = cc - P::C1;
+            constexpr int prev = ob > 0 ? ob - 1 : 0;
+            const frag_cd acc = block(std::integral_constant<int, 17>{}, S, std::integral_constant<int, nm_of_next_chunk>{}, Sn,
+                                      [&](auto ks) { return hb1[decltype(ks)::value]; }, true, ob > 0 ? hb2[2 * prev] : hb1[14],
+                                      ob > 0 ? hb2[2 * prev + 1] : hb1[15]);
+            pend = acc;
+        } else {  // ---- head (with the tanh of layer 2's last block)
+            head[net] = block(std::integral_constant<int, 17>{}, S, std::integral_constant<int, nm_of_next_chunk>{}, Sn,
+                              [&](auto ks) { return hb2[decltype(ks)::value]; }, true, hb2[14], hb2[15]);
+        }
+    });
+    const frag_cd& logit = head[0];
+    const frag_cd& val = head[1];
     // outputs 0..3 and 8..11 sit in lane half 0 (registers 0..3, 4..7), outputs 4..7 and 12..15 in half 1: gather into half 0
     float lg[16];
 #pragma unroll
@@ -182,19 +270,26 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const float* _
         lg[(v & 3) + 8 * (v >> 2) + 4] = other;
     }
     if (h == 0 && env < n_env) {
+        // (loops over all 16 head outputs with a test against n_actions: a runtime trip count would index lg[] dynamically)
         float mx = -3.0e38f;
-        for (int a = 0; a < n_actions; a++) mx = fmaxf(mx, lg[a]);
+#pragma unroll
+        for (int a = 0; a < 16; a++) mx = a < n_actions ? fmaxf(mx, lg[a]) : mx;
         float sum = 0.0f;
-        for (int a = 0; a < n_actions; a++) sum += __expf(lg[a] - mx);
+#pragma unroll
+        for (int a = 0; a < 16; a++) sum += a < n_actions ? __expf(lg[a] - mx) : 0.0f;
         const float lse = mx + __logf(sum);
         int best = 0;
         float best_score = -3.0e38f, best_lp = 0.0f;
-        for (int a = 0; a < n_actions; a++) {
-            const uint64_t bits = mix64(seed ^ mix64((uint64_t)env * 16u + (uint64_t)a + 0x9e3779b97f4a7c15ull));
-            const float u = ((float)(bits >> 40) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+        // Gumbel-max with a counter-based 32-bit hash (two rounds of the murmur3 finaliser over (env, action), keyed by both seed
+        // halves): cheap next to the 64-bit multiplies of mix64, which were a tenth of the kernel
+        const uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int a = 0; a < 16; a++) {
+            const uint32_t bits = fmix32(fmix32(((uint32_t)env * 16u + (uint32_t)a) ^ s_lo) + s_hi + (uint32_t)(env >> 28));
+            const float u = ((float)(bits >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
             const float lp = lg[a] - lse;
             const float score = lp - __logf(-__logf(u));
-            if (score > best_score) {
+            if (a < n_actions && score > best_score) {
                 best_score = score;
                 best = a;
                 best_lp = lp;
@@ -203,6 +298,9 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const float* _
         action[env] = best;
         logprob[env] = best_lp;
         value[env] = val[0];
+#ifdef ACX_POLICY_STAMP
+        logprob[n_env + (blockIdx.x & 1) * 512 + wave * 64 + 63] = (float)(long long)(__builtin_amdgcn_s_memtime() - t_start);
+#endif
     }
 }
 
@@ -219,20 +317,10 @@ extern "C" int acx_policy_sample(const float* d_obs, int64_t n_env, int in_dim, 
     if (in_dim < 1 || in_dim > 80 || n_actions < 1 || n_actions > 16) return fail(ACX_E_INVAL, "acx_policy_sample handles 1..80 inputs and 1..16 actions");
     if (n_env == 0) return ACX_OK;
     const int ks1 = (in_dim + 15) / 16;
-    auto net = [&](const void* p) {
-        policy::Net n;
-        const policy::frag_ab* f = (const policy::frag_ab*)p;
-        n.w1 = f;
-        n.w2 = n.w1 + 8 * ks1 * 64;
-        n.w3 = n.w2 + 8 * 16 * 64;
-        n.b1 = (const float*)(n.w3 + 16 * 64);
-        n.b2 = n.b1 + 256;
-        n.b3 = n.b2 + 256;
-        return n;
-    };
-    const policy::Net a = net(d_actor), c = net(d_critic);
+    const policy::frag_ab* a = (const policy::frag_ab*)d_actor;
+    const policy::frag_ab* c = (const policy::frag_ab*)d_critic;
     const dim3 grid((unsigned)((n_env + 32 * policy::kWaves - 1) / (32 * policy::kWaves))), block(64 * policy::kWaves);
-    const size_t lds = policy::kActBytes + 2 * policy::kStageFrags * sizeof(policy::frag_ab);
+    const size_t lds = (size_t)policy::kRing * policy::kSlotBytes;
     hipStream_t st = (hipStream_t)stream;
 #define ACX_POLICY_LAUNCH(KS)                                                                                                                        \
     ACX_HIP_TRY(hipFuncSetAttribute((const void*)policy::k_policy_sample<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
@@ -250,8 +338,8 @@ extern "C" int acx_policy_sample(const float* d_obs, int64_t n_env, int in_dim, 
     return ACX_OK;
 }
 
-/* bytes of one packed network for acx_policy_sample: fragments of the three layers + the f32 biases */
+/* bytes of one packed network for acx_policy_sample: the fragments of the three layers (bias fragments included) */
 extern "C" int64_t acx_policy_packed_bytes(int in_dim) {
     const int64_t ks1 = (in_dim + 15) / 16;
-    return (8 * ks1 + 8 * 16 + 16) * 64 * 16 + (256 + 256 + 32) * 4;
+    return (8 * (ks1 + 1) + 8 * 17 + 17) * 1024;
 }

@@ -26,16 +26,21 @@ def _agent(in_dim, n_act, seed):
 
 
 def _emulate(seq, x):
-    """the kernel's arithmetic in torch: bf16 operands, f32 accumulation, bf16 activations"""
+    """the kernel's arithmetic in torch: bf16 operands, f32 accumulation, bf16 activations; the hidden layers' weights and
+    biases carry the factor 2 / ln 2 of tanh(x) = 1 - 2 / (2^(2x / ln 2) + 1) before they are rounded (fused_policy.TANH_SCALE)"""
     import torch
+
+    from ac_solver.agents.fused_policy import TANH_SCALE
 
     bf = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
     lin = [m for m in seq if isinstance(m, torch.nn.Linear)]
     h = bf(x)
     for k, m in enumerate(lin):
-        h = h @ bf(m.weight).T + m.bias
         if k < 2:
-            h = bf(torch.tanh(h))
+            y = h @ bf(m.weight * TANH_SCALE).T + m.bias * TANH_SCALE
+            h = bf(1.0 - 2.0 / (torch.exp2(y) + 1.0))
+        else:
+            h = h @ bf(m.weight).T + m.bias
     return h
 
 
