@@ -139,3 +139,33 @@ def test_running_return_normalizer_matches_the_scalar_recursion():
             m2 = var * count + 0.0 + delta ** 2 * count * 1.0 / tot
             mean, var, count = new_mean, m2 / tot, tot
             assert np.isclose(got[t, n], rew[t, n] / np.sqrt(var + 1e-8), rtol=1e-12), (t, n)
+
+
+def test_fused_policy_fragments_decode_back_to_the_layer():
+    """agents/fused_policy._fragments writes a layer as the A operands of v_mfma_f32_32x32x16_bf16 in the order csrc/acx_policy.hip
+    consumes them.  Decoded with the instruction's operand layout (lane = 32 h + row holds k = 8 h + j of the k-step) and the
+    kernel's K order for layers fed by a hidden layer, the fragments give back scale * W (rounded to bf16) and the bias as hi + lo."""
+    import torch
+
+    from ac_solver.agents.fused_policy import TANH_SCALE, _fragments
+
+    torch.manual_seed(5)
+    for out, inp, rows, cols, hidden, scale in ((256, 50, 256, 64, False, TANH_SCALE), (256, 256, 256, 256, True, TANH_SCALE), (12, 256, 32, 256, True, 1.0)):
+        w, b = torch.randn(out, inp), torch.randn(out)
+        nks = cols // 16
+        f = _fragments(w, b, rows, cols, hidden, scale).float().view(rows // 32, 1 + nks, 2, 32, 8)  # [ob][step][h][row][j]
+        dense = torch.zeros(rows, cols)
+        for ks in range(nks):
+            for h in range(2):
+                for j in range(8):
+                    k = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3) if hidden else 16 * ks + 8 * h + j
+                    dense[:, k] = f[:, 1 + ks, h, :, j].reshape(-1)
+        want = torch.zeros(rows, cols)
+        want[:out, :inp] = (w * scale).to(torch.bfloat16).float()
+        assert torch.equal(dense, want)
+        bias = f[:, 0, 0, :, 0].reshape(-1) + f[:, 0, 0, :, 1].reshape(-1)
+        assert float((bias[:out] - b * scale).abs().max()) < 1e-4 and float(bias[out:].abs().sum()) == 0.0
+        assert float(f[:, 0, 1].abs().max()) == 0.0 and float(f[:, 0, 0, :, 2:].abs().max()) == 0.0
+        if hidden:  # every k-step of a hidden-fed layer contracts 16 distinct hidden units, all 256 exactly once
+            seen = sorted(32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3) for ks in range(nks) for h in range(2) for j in range(8))
+            assert seen == list(range(256))
