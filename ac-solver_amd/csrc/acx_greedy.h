@@ -174,10 +174,9 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, ui
 
 // The whole search, executed by one 1024-lane workgroup.  path_act / path_len (nullable, `path_cap` entries): the
 // reference's return path, (-1, len0), (action, length) ... , written by lane 0 at the end; out->path_n is its length.
-template <typename W>
+template <typename W, uint32_t SC = greedy_cfg<W>::kSortCap>
 __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __restrict__ out, int32_t* __restrict__ path_act,
                                            int32_t* __restrict__ path_len, long long path_cap) {
-    constexpr uint32_t SC = greedy_cfg<W>::kSortCap;
     constexpr int R = (int)(SC / kGT);                     // children per lane in a full batch
     constexpr uint32_t kPmax = (uint32_t)(R * kGT) / 12u;  // parents in a full batch
     constexpr uint32_t kBT = 2 * SC;                       // in-batch dedup table (LDS)
@@ -918,9 +917,17 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
 // No register pad here (ACX_VGPR_PAD, acx_common.h): a 1024-lane workgroup may use at most 128 registers per lane and the
 // frontier needs them all (it already spills); `amdgpu_num_vgpr(120)` does not lower the allocation under this launch bound.
 // These two kernels are covered by the repeat-determinism tests instead (tests/test_gpu_determinism.py).
+// The single search hands buckets of >= hand_min (1024) parents to acx_greedy_mega.h, so its own batches can be smaller:
+// kSingleSortCap = 1024 candidates (one child per lane, 85 parents per batch) needs 36 bytes of scratch per lane where the
+// 4096-candidate form of the many-search kernel needs 280, and the latency chain of a small batch is that much shorter
+// (AK(3), 1e7 nodes: 234 -> 211 ms although the batches become more).
+#ifndef ACX_GREEDY_SINGLE_SC
+#define ACX_GREEDY_SINGLE_SC 1024  // 0: as the many-search kernel
+#endif
+template <typename W> constexpr uint32_t kSingleSortCap = ACX_GREEDY_SINGLE_SC ? (uint32_t)ACX_GREEDY_SINGLE_SC : greedy_cfg<W>::kSortCap;
 template <typename W>
 __global__ void __launch_bounds__(kGT) k_greedy_persistent(GreedyDev<W> g, GreedyOut* __restrict__ out) {
-    greedy_run<W>(g, out, nullptr, nullptr, 0);
+    greedy_run<W, kSingleSortCap<W>>(g, out, nullptr, nullptr, 0);
 }
 
 // One search per workgroup: acx_search_many runs a whole group of independent greedy searches in ONE launch (a

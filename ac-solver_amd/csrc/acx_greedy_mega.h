@@ -512,7 +512,7 @@ template <typename W> __global__ void __launch_bounds__(256) k_gm_file(MegaDev<W
                 if (sc->budget_hit) status = GREEDY_BUDGET;
                 sc->cut = cut ? 1u : 0u;
                 sc->remaining = r.cnt - r.head;
-                ps->np_cap = cut ? (uint32_t)(kGT / 12) : (uint32_t)(greedy_cfg<W>::kSortCap / 12u);
+                ps->np_cap = cut ? (uint32_t)(kGT / 12) : (uint32_t)(kSingleSortCap<W> / 12u);
             }
         }
         ps->status = status;
