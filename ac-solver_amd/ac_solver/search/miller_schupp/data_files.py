@@ -59,18 +59,21 @@ def replay_path(presentation, path, cyclical=False):
 def make_data_files(max_nodes_to_explore=10**6, out_dir=None, verbose=True):
     """Run greedy_search and bfs over the 1190 Miller-Schupp presentations and write the four files."""
     from ac_solver import _acx
-    from ac_solver.search._common import run_search_many
+    from ac_solver.search._common import run_search_groups
     from ac_solver.search.miller_schupp.miller_schupp import generate_miller_schupp_presentations
 
     out_dir = out_dir or DATA_DIR
     os.makedirs(out_dir, exist_ok=True)
     solved, unsolved, paths, bfs_solved = [], [], [], []
+    all_rows = []
     for n in range(1, 8):
         by_len = generate_miller_schupp_presentations(n, 7)
-        rows = [p for lenw in range(1, 8) for p in by_len.get(lenw, [])]
-        arr = np.array(rows, dtype=np.int8)
-        greedy = run_search_many(_acx.SEARCH_GREEDY, arr, max_nodes_to_explore, False)
-        bfs = run_search_many(_acx.SEARCH_BFS, arr, max_nodes_to_explore, True)
+        all_rows.append([p for lenw in range(1, 8) for p in by_len.get(lenw, [])])
+    arrs = [np.array(rows, dtype=np.int8) for rows in all_rows]
+    greedy_all = run_search_groups(_acx.SEARCH_GREEDY, arrs, max_nodes_to_explore, False)  # the seven widths in flight together
+    bfs_all = run_search_groups(_acx.SEARCH_BFS, arrs, max_nodes_to_explore, True)
+    for n in range(1, 8):
+        rows, greedy, bfs = all_rows[n - 1], greedy_all[n - 1], bfs_all[n - 1]
         for p, (ok, path, _), (bok, _, _) in zip(rows, greedy, bfs):
             if ok:
                 solved.append(p)

@@ -77,18 +77,20 @@ def trivialize_miller_schupp_through_search(min_n, max_n, min_w_len, max_w_len, 
     solved_rels, unsolved_rels, solved_paths = [], [], []
 
     from ac_solver.search import breadth_first, greedy
-    from ac_solver.search._common import run_search_many
+    from ac_solver.search._common import run_search_groups
 
     ours = {breadth_first.bfs: _acx.SEARCH_BFS, greedy.greedy_search: _acx.SEARCH_GREEDY}.get(search_fn)
+    groups = {n: [(lenw, pres) for lenw in range(min_w_len, max_w_len + 1) for pres in rels[n].get(lenw, [])] for n in range(min_n, max_n + 1)}
+    by_n = {}
+    if ours is not None:
+        # the searches of one n share max_relator_length and go to the GPU as one batch (acx_search_many), the batches of all n
+        # are in flight together; results come back in the reference's order
+        ns = [n for n in groups if groups[n]]
+        res = run_search_groups(ours, [np.array([p for _, p in groups[n]], dtype=np.int8) for n in ns], max_nodes_to_explore, False)
+        for n, r in zip(ns, res):
+            by_n[n] = [(ok, path if (ok or ours == _acx.SEARCH_GREEDY) else None, st) for ok, path, st in r]
     for n in range(min_n, max_n + 1):
-        group = [(lenw, pres) for lenw in range(min_w_len, max_w_len + 1) for pres in rels[n].get(lenw, [])]
-        if ours is not None and group:
-            # the searches of one n share max_relator_length: run them overlapped on the GPU (acx_search_many);
-            # results come back in the reference's order
-            results = run_search_many(ours, np.array([p for _, p in group], dtype=np.int8), max_nodes_to_explore, False)
-            results = [(ok, path if (ok or ours == _acx.SEARCH_GREEDY) else None, st) for ok, path, st in results]
-        else:
-            results = None
+        results = by_n.get(n)
         k = 0
         for lenw in range(min_w_len, max_w_len + 1):
             print(f"Applying {search_fn.__name__} to presentations of n = {n}, lenw = {lenw}")

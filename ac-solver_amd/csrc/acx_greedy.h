@@ -97,7 +97,10 @@ struct GreedyOut {
 };
 
 template <typename W> struct greedy_cfg;
-template <> struct greedy_cfg<uint64_t> { static constexpr uint32_t kSortCap = 4096; };
+#ifndef ACX_GREEDY_MULTI_SC
+#define ACX_GREEDY_MULTI_SC 4096
+#endif
+template <> struct greedy_cfg<uint64_t> { static constexpr uint32_t kSortCap = ACX_GREEDY_MULTI_SC; };
 template <> struct greedy_cfg<u128> { static constexpr uint32_t kSortCap = 2048; };
 
 template <typename W> __device__ __forceinline__ bool key_less(W a0, W a1, W b0, W b1) {

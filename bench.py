@@ -211,10 +211,6 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
     from ac_solver.search._common import run_search_many
     from ac_solver.search.miller_schupp.miller_schupp import generate_miller_schupp_presentations
 
-    if use_dist:
-        dist.barrier()
-    n_solved = n_nodes = n_mine = 0
-    sweep_err = None
     from ac_solver.search._common import run_search_groups
 
     groups = []
@@ -222,35 +218,46 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
         d = generate_miller_schupp_presentations(n, 7)
         groups.append(np.array([q for w in range(1, 8) for q in d[w]], dtype=np.int8)[rank::world])
     n_mine = sum(len(g) for g in groups)
-    try:
-        run_search_groups(_acx.SEARCH_BFS, groups, 10**6, True)  # first call: pays for the device allocations (kept by the block pool)
-    except Exception as e:
-        sweep_err = e
-    if use_dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    try:
-        if sweep_err is None:
-            for res in run_search_groups(_acx.SEARCH_BFS, groups, 10**6, True):
-                for ok, _, s1 in res:
-                    n_solved += ok
-                    n_nodes += s1["nodes"]
-    except Exception as e:
-        sweep_err = e
-    tot = torch.tensor([n_solved, n_nodes, n_mine, 0.0 if sweep_err is None else 1.0], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(tot)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt1 = float(tmax[0])
-    if float(tot[3]) > 0:
-        out["bfs_ms_sweep"] = {"error": f"{type(sweep_err).__name__}: {sweep_err}" if sweep_err is not None else "failed on another rank"}
-    else:
-        out["bfs_ms_sweep"] = {"searches": int(tot[2]), "budget": 10**6, "cyclical": True, "solved": int(tot[0]), "published_solved": 278,
-                               "nodes": int(tot[1]), "seconds": dt1, "nodes_per_s": float(tot[1]) / dt1, "searches_per_s": float(tot[2]) / dt1,
-                               "n_gpus": world, "scaling": "strong",
-                               "entry": "acx_search_many per rank: one persistent workgroup per search (k_bfs_multi), the seven max_relator_lengths in "
-                                        "flight together; searches dealt round-robin to the ranks"}
+
+    def sweep(kind, cyclical, published, entry):
+        if use_dist:
+            dist.barrier()
+        n_solved = n_nodes = 0
+        sweep_err = None
+        try:
+            run_search_groups(kind, groups, 10**6, cyclical)  # first call: pays for the device allocations (kept by the block pool)
+        except Exception as e:  # noqa: BLE001
+            sweep_err = e
+        if use_dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        try:
+            if sweep_err is None:
+                for res in run_search_groups(kind, groups, 10**6, cyclical):
+                    for ok, _, s1 in res:
+                        n_solved += ok
+                        n_nodes += s1["nodes"]
+        except Exception as e:  # noqa: BLE001
+            sweep_err = e
+        tot = torch.tensor([n_solved, n_nodes, n_mine, 0.0 if sweep_err is None else 1.0], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(tot)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt1 = float(tmax[0])
+        if float(tot[3]) > 0:
+            return {"error": f"{type(sweep_err).__name__}: {sweep_err}" if sweep_err is not None else "failed on another rank"}
+        return {"searches": int(tot[2]), "budget": 10**6, "cyclical": cyclical, "solved": int(tot[0]), "published_solved": published,
+                "nodes": int(tot[1]), "seconds": dt1, "nodes_per_s": float(tot[1]) / dt1, "searches_per_s": float(tot[2]) / dt1,
+                "n_gpus": world, "scaling": "strong", "entry": entry}
+
+    out["bfs_ms_sweep"] = sweep(_acx.SEARCH_BFS, True, 278,
+                                "acx_search_many per rank: one persistent workgroup per search (k_bfs_multi), the seven max_relator_lengths in "
+                                "flight together; searches dealt round-robin to the ranks")
+    # the reference's other published experiment: greedy_search, budget 1e6, on the same 1190 (533 solved)
+    out["greedy_ms_sweep"] = sweep(_acx.SEARCH_GREEDY, False, 533,
+                                   "acx_search_many per rank: one persistent workgroup per search (k_greedy_multi), the seven "
+                                   "max_relator_lengths in flight together; searches dealt round-robin to the ranks")
     if world == 1 and not use_dist:
         for kind, name in ((_acx.SEARCH_BFS, "bfs"), (_acx.SEARCH_GREEDY, "greedy_search")):
             b = budget if kind == _acx.SEARCH_BFS else min(budget, 10**7)
