@@ -1,4 +1,4 @@
-// acx_bfs_multi.h -- MANY independent breadth-first searches in one launch: one persistent 1024-lane workgroup per search.
+// acx_bfs_multi.h -- MANY independent breadth-first searches in one launch: one persistent workgroup per search.
 //
 // BASELINE config 4 is bfs over the 1190 Miller-Schupp presentations with a budget of 1e6 nodes each
 // (trivialize_miller_schupp_through_search, miller_schupp.py:95-177, runs them one after another).  Driven as 1190 separate
@@ -19,13 +19,16 @@
 namespace acx {
 
 #ifndef ACX_BFS_MULTI_THREADS
-#define ACX_BFS_MULTI_THREADS 1024
+#define ACX_BFS_MULTI_THREADS 512
 #endif
 constexpr int kBmT = ACX_BFS_MULTI_THREADS;  // lanes of the workgroup
-// children per lane and chunk.  One: a chunk is 85 parents = 1020 children.  With two per lane (170 parents) the two probes of a
-// lane run one after the other -- their dependent memory round trips add up -- and a chunk took 44 us instead of 2 x 12.
+// Workgroup shape: 512 lanes x 3 children per lane (a chunk is 128 parents).  A search is a chain of dependent memory round
+// trips per chunk, so what counts for a sweep is how many searches a compute unit carries: at <= 128 registers two
+// 8-wave workgroups share a CU (the 1190 Miller-Schupp searches: 0.26 s; 1024 x 1, one workgroup per CU: 0.33 s; 512 x 2:
+// 0.28 s; 512 x 4 needs more registers than two workgroups get: 0.33 s).  More children per lane lengthen the chunk (the
+// probes of a lane run one after the other), fewer leave lanes idle.
 #ifndef ACX_BFS_MULTI_ITEMS
-#define ACX_BFS_MULTI_ITEMS 1
+#define ACX_BFS_MULTI_ITEMS 3
 #endif
 template <typename W> struct bm_cfg {
     static constexpr int kItems = ACX_BFS_MULTI_ITEMS;
@@ -76,9 +79,9 @@ __global__ void __launch_bounds__(kBmT) k_bfs_multi(const BfsJob<W>* __restrict_
     __shared__ unsigned long long s_err_tag;
     __shared__ uint32_t s_solved_tag, s_min_len, s_pb, s_committed, s_head, s_nodes, s_status, s_full;
     if (MODE == kMoveGeneral) {
-        ACX_VGPR_PAD("v127");
+        ACX_VGPR_PAD_W(W, "v143", "v151");
     } else {
-        ACX_VGPR_PAD_W(W, "v95", "v127");
+        ACX_VGPR_PAD_W(W, "v119", "v127");
     }
     const BfsJob<W> g = jobs[blockIdx.x];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
