@@ -97,11 +97,19 @@ struct GreedyOut {
 };
 
 template <typename W> struct greedy_cfg;
-#ifndef ACX_GREEDY_MULTI_SC
-#define ACX_GREEDY_MULTI_SC 4096
+// k_greedy_multi (one search per workgroup, many searches per launch): lanes and candidates per batch.  Measured on the 1190
+// Miller-Schupp searches of 1e6 nodes (tools/ms_sweep_warm.py greedy): 1024 lanes x 4 children 0.40 s, 1024 x 2 0.43 s;
+// 512-lane workgroups, two per compute unit (128 registers each): x 4 0.50 s, x 2 0.49 s, x 1 0.55 s -- unlike the BFS
+// kernel (acx_bfs_multi.h) this one gains nothing from a second search per compute unit, its batches need the lanes.
+#ifndef ACX_GREEDY_MULTI_THREADS
+#define ACX_GREEDY_MULTI_THREADS 1024
 #endif
-template <> struct greedy_cfg<uint64_t> { static constexpr uint32_t kSortCap = ACX_GREEDY_MULTI_SC; };
-template <> struct greedy_cfg<u128> { static constexpr uint32_t kSortCap = 2048; };
+constexpr uint32_t kGreedyMultiThreads = ACX_GREEDY_MULTI_THREADS;
+#ifndef ACX_GREEDY_MULTI_R
+#define ACX_GREEDY_MULTI_R 4
+#endif
+template <> struct greedy_cfg<uint64_t> { static constexpr uint32_t kSortCap = ACX_GREEDY_MULTI_R * kGreedyMultiThreads; };
+template <> struct greedy_cfg<u128> { static constexpr uint32_t kSortCap = 2 * kGreedyMultiThreads; };
 
 template <typename W> __device__ __forceinline__ bool key_less(W a0, W a1, W b0, W b1) {
     Pres<W> a, b;
@@ -131,7 +139,7 @@ template <typename W> __device__ __forceinline__ void lds_cmpx(W* sk0, W* sk1, u
 
 // Bitonic sort of the n entries (sid, sk0, sk1)[0..n) in LDS by signed state order; whole workgroup.
 // `descending`: direction of the final merge (a chunk of a larger bitonic network is sorted against its neighbour).
-template <typename W> __device__ __forceinline__ void lds_sort(W* sk0, W* sk1, uint32_t* sid, uint32_t n, uint32_t tid, bool descending = false) {
+template <typename W, uint32_t kGT> __device__ __forceinline__ void lds_sort(W* sk0, W* sk1, uint32_t* sid, uint32_t n, uint32_t tid, bool descending = false) {
     uint32_t P = 2;
     while (P < n) P <<= 1;
     for (uint32_t i = n + tid; i < P; i += kGT) sid[i] = 0xFFFFFFFFu;  // padding sorts last
@@ -149,7 +157,7 @@ template <typename W> __device__ __forceinline__ void lds_sort(W* sk0, W* sk1, u
 }
 
 // The merge stages j = P/2 .. 1 of a bitonic network on the P (power of two) LDS entries, all in one direction.
-template <typename W> __device__ __forceinline__ void lds_merge(W* sk0, W* sk1, uint32_t* sid, uint32_t P, uint32_t tid, bool asc) {
+template <typename W, uint32_t kGT> __device__ __forceinline__ void lds_merge(W* sk0, W* sk1, uint32_t* sid, uint32_t P, uint32_t tid, bool asc) {
     for (uint32_t j = P >> 1; j > 0; j >>= 1) {
         for (uint32_t q = tid; q < P / 2; q += kGT) {
             const uint32_t i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
@@ -177,7 +185,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, ui
 
 // The whole search, executed by one 1024-lane workgroup.  path_act / path_len (nullable, `path_cap` entries): the
 // reference's return path, (-1, len0), (action, length) ... , written by lane 0 at the end; out->path_n is its length.
-template <typename W, uint32_t SC = greedy_cfg<W>::kSortCap>
+template <typename W, uint32_t SC, uint32_t kGT>  // SC candidates per batch, kGT lanes (shadows the namespace constant: the single search's workgroup)
 __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __restrict__ out, int32_t* __restrict__ path_act,
                                            int32_t* __restrict__ path_len, long long path_cap) {
     constexpr int R = (int)(SC / kGT);                     // children per lane in a full batch
@@ -404,7 +412,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                         sk0[i] = nk.k0;
                         sk1[i] = nk.k1;
                     }
-                    lds_sort<W>(sk0, sk1, sid, n, tid);
+                    lds_sort<W, kGT>(sk0, sk1, sid, n, tid);
                     for (uint32_t i = tid; i < n; i += kGT) g.arena[base + i] = sid[i];
                     if (tid == 0) s_sorted_in_lds = 1;
                 } else {
@@ -426,7 +434,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                                 sid[i] = 0xFFFFFFFFu;
                             }
                         }
-                        lds_sort<W>(sk0, sk1, sid, SC, tid, ((c0 / SC) & 1u) != 0);
+                        lds_sort<W, kGT>(sk0, sk1, sid, SC, tid, ((c0 / SC) & 1u) != 0);
                         for (uint32_t i = tid; i < SC; i += kGT) {
                             g.gid[c0 + i] = sid[i];
                             g.gk0[c0 + i] = sk0[i];
@@ -463,7 +471,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                                 sk1[i] = g.gk1[c0 + i];
                             }
                             __syncthreads();
-                            lds_merge<W>(sk0, sk1, sid, SC, tid, (c0 & k) == 0);
+                            lds_merge<W, kGT>(sk0, sk1, sid, SC, tid, (c0 & k) == 0);
                             for (uint32_t i = tid; i < SC; i += kGT) {
                                 g.gid[c0 + i] = sid[i];
                                 g.gk0[c0 + i] = sk0[i];
@@ -930,16 +938,16 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
 template <typename W> constexpr uint32_t kSingleSortCap = ACX_GREEDY_SINGLE_SC ? (uint32_t)ACX_GREEDY_SINGLE_SC : greedy_cfg<W>::kSortCap;
 template <typename W>
 __global__ void __launch_bounds__(kGT) k_greedy_persistent(GreedyDev<W> g, GreedyOut* __restrict__ out) {
-    greedy_run<W, kSingleSortCap<W>>(g, out, nullptr, nullptr, 0);
+    greedy_run<W, kSingleSortCap<W>, (uint32_t)kGT>(g, out, nullptr, nullptr, 0);
 }
 
 // One search per workgroup: acx_search_many runs a whole group of independent greedy searches in ONE launch (a
 // stream per search is limited by the few hardware queues a process gets; here every CU can carry a search).
 template <typename W>
-__global__ void __launch_bounds__(kGT) k_greedy_multi(const GreedyDev<W>* __restrict__ gs, GreedyOut* __restrict__ outs, int32_t* __restrict__ path_act,
+__global__ void __launch_bounds__(kGreedyMultiThreads) k_greedy_multi(const GreedyDev<W>* __restrict__ gs, GreedyOut* __restrict__ outs, int32_t* __restrict__ path_act,
                                                       int32_t* __restrict__ path_len, long long path_cap) {
     const GreedyDev<W> g = gs[blockIdx.x];
-    greedy_run<W>(g, outs + blockIdx.x, path_act + (size_t)blockIdx.x * path_cap, path_len + (size_t)blockIdx.x * path_cap, path_cap);
+    greedy_run<W, greedy_cfg<W>::kSortCap, kGreedyMultiThreads>(g, outs + blockIdx.x, path_act + (size_t)blockIdx.x * path_cap, path_len + (size_t)blockIdx.x * path_cap, path_cap);
 }
 
 }  // namespace acx

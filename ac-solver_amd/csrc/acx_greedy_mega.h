@@ -76,7 +76,7 @@ template <typename W> __global__ void __launch_bounds__(kGT) k_gm_runsort(MegaDe
         sk1[i] = nk.k1;
     }
     __syncthreads();
-    lds_sort<W>(sk0, sk1, sid, cnt, tid);
+    lds_sort<W, (uint32_t)kGT>(sk0, sk1, sid, cnt, tid);
     for (uint32_t i = tid; i < cnt; i += kGT) {
         g.gid[i0 + i] = sid[i];
         g.gk0[i0 + i] = sk0[i];

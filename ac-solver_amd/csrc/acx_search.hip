@@ -393,7 +393,7 @@ static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_no
     ACX_HIP_TRY(evs.create());
     hipEvent_t ev0 = evs.a, ev1 = evs.b;
     ACX_HIP_TRY(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(k_greedy_multi<W>, dim3((unsigned)n), dim3(kGT), 0, st, (const GreedyDev<W>*)ddev.p, (GreedyOut*)douts.p, (int32_t*)dpa.p, (int32_t*)dpl.p,
+    hipLaunchKernelGGL(k_greedy_multi<W>, dim3((unsigned)n), dim3(kGreedyMultiThreads), 0, st, (const GreedyDev<W>*)ddev.p, (GreedyOut*)douts.p, (int32_t*)dpa.p, (int32_t*)dpl.p,
                        (long long)pc);
     ACX_HIP_TRY(hipGetLastError());
     ACX_HIP_TRY(hipEventRecord(ev1, st));
