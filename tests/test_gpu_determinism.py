@@ -80,6 +80,19 @@ def test_general_and_normal_form_move_code_build_the_same_arena(digests, monkeyp
     assert a == b
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("switch", ["ACX_BFS_INLINE_TAB", "ACX_BFS_CLASSIC_COMMIT"])
+def test_round1_bfs_paths_build_the_same_arena(digests, monkeypatch, switch):
+    """acx_search keeps round 1's BFS for A/B measurements (inline-key visited table, k_insert_tab + one-pass k_compact_tab; and
+    with ACX_BFS_CLASSIC_COMMIT its mark / scan / commit launches): same nodes in the same order as the stamp-table kernels"""
+    from ac_solver import _acx
+
+    a = _search_with_digest(_acx.SEARCH_BFS, _ak3(), 2 * 10**6, False)
+    monkeypatch.setenv(switch, "1")
+    b = _search_with_digest(_acx.SEARCH_BFS, _ak3(), 2 * 10**6, False)
+    assert a == b
+
+
 @pytest.mark.timeout(600)
 def test_env_step_launches_equal_the_fused_rollout_three_times(golden_json):
     """k_env_step (one launch per step, plain shifts) x 1000 on 65 536 environments, three times over, against the fused
