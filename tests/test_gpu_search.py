@@ -179,6 +179,24 @@ def test_greedy_whole_gpu_batches_equal_the_reference(search, golden_json, monke
             assert got[2]["nodes"] == wst["nodes"] and got[2]["expanded"] == wst["expanded"], (int(k), budget, cyc)
 
 
+@pytest.mark.timeout(600)
+def test_greedy_buckets_larger_than_one_whole_gpu_batch(search):
+    """AK(3) with a 3e7-node budget meets buckets of 36 000 parents: more than the 16 384 of one mega-batch (acx_greedy_mega.h),
+    so a bucket is worked off in several of them; and the cyclically reducing search at 1e7.  Node for node as the oracle."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search
+    from oracle import ac_oracle as O
+
+    ak3 = np.zeros(50, np.int8)
+    ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+    ak3[25:31] = [1, 2, 1, -2, -1, -2]
+    for budget, cyc in ((3 * 10**7, False), (10**7, True)):
+        ok, path, st = run_search(_acx.SEARCH_GREEDY, ak3, budget, cyc)
+        wok, wpath, wst = O.greedy_search(ak3, budget, cyclically_reduce_after_moves=cyc, stats=True)
+        assert (ok, path) == (wok, wpath), (budget, cyc)
+        assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (budget, cyc, st, wst)
+
+
 def test_greedy_paths_file_sample(search, golden_json):
     """data/greedy_search_paths.txt (budget 1e6): a sample through the device frontier at native L (up to 36 -> 128-bit keys)"""
     pool = ms_pool_generator_order(golden_json("ms_pool.json"))
