@@ -193,6 +193,39 @@ def test_large_batch_packed_equals_bytes_and_oracle(acx):
         assert np.array_equal(x, w) and np.array_equal(y, w)
 
 
+def test_inverse_moves_round_trip_at_full_size(acx):
+    """Size-independent property at 2 Mi rows per move pair (L = 25, no oracle in the loop): on freely reduced relators every AC
+    move that is carried out is undone by its inverse move -- r_i r_j then r_i r_j^-1 (0 <-> 2, 1 <-> 3), conjugation by g then by
+    g^-1 (4 <-> 8, 5 <-> 9, 6 <-> 10, 7 <-> 11) -- and a move that does not fit max_relator_length leaves the row as it was."""
+    L, n = 25, 1 << 21
+    rng = np.random.default_rng(11)
+    letters = np.array([1, -1, 2, -2], np.int8)
+    st = np.zeros((n, 2 * L), np.int8)
+    for h in (0, 1):
+        code = np.empty((n, L), np.int64)
+        code[:, 0] = rng.integers(0, 4, n)
+        step = rng.integers(0, 3, (n, L))
+        for k in range(1, L):
+            code[:, k] = ((code[:, k - 1] ^ 1) + 1 + step[:, k]) % 4  # any letter but the inverse of the previous one
+        ln = rng.integers(1, L + 1, n)
+        half = letters[code]
+        half[np.arange(L)[None, :] >= ln[:, None]] = 0
+        st[:, h * L:(h + 1) * L] = half
+    total = applied = 0
+    for a, b in ((0, 2), (2, 0), (1, 3), (3, 1), (4, 8), (8, 4), (5, 9), (9, 5), (6, 10), (10, 6), (7, 11), (11, 7)):
+        s1, len1, err1, _ = acx.move_rows(st, np.full(n, a, np.uint8), L, 0)
+        moved = (s1 != st).any(1)
+        # (a product that cancels completely leaves an empty relator: the reference's ACMove raises there, err1 != 0)
+        alive = (len1 > 0).all(1) & (err1 == 0)
+        assert float(alive.mean()) > 0.99
+        s2, _, err2, _ = acx.move_rows(np.where(alive[:, None], s1, st), np.full(n, b, np.uint8), L, 0)
+        ok = moved & alive
+        assert not err2[ok].any() and np.array_equal(s2[ok], st[ok]), (a, b)
+        total += n
+        applied += int(ok.sum())
+    assert applied > 0.5 * total
+
+
 def test_miller_schupp_generator(acx, golden_json):
     from ac_solver.search.miller_schupp.miller_schupp import generate_miller_schupp_presentations
 
