@@ -69,6 +69,22 @@ def test_ak3_1e7_repeats_to_the_node(digests, algo):
     assert len({(r[0], str(r[1]), r[2], r[3], r[4]) for r in runs}) == 1, [(r[2], r[3], hex(r[4])) for r in runs]
 
 
+@pytest.mark.timeout(600)
+def test_bfs_at_the_bench_budget_repeats_and_agrees_with_the_sharded_engine(digests):
+    """BASELINE's BFS workload at its full size (AK(3), max_relator_length 25, 1e8 nodes -- out of the oracle's reach inside a test):
+    the fused search three times gives one node arena (digest), and the sharded engine on one rank, which numbers its nodes through
+    a different mechanism (records, masks, prefix popcounts), reaches the same node and expansion counts."""
+    from ac_solver import _acx
+    from ac_solver.search.sharded import bfs_sharded
+
+    runs = [_search_with_digest(_acx.SEARCH_BFS, _ak3(), 10**8, False) for _ in range(3)]
+    assert len({(r[0], str(r[1]), r[2], r[3], r[4]) for r in runs}) == 1, [(r[2], r[3], hex(r[4])) for r in runs]
+    ok, path, nodes, expanded, _ = runs[0]
+    assert not ok and nodes == 10**8 + 1
+    sok, spath, st = bfs_sharded(_ak3(), 10**8, batch_parents=1 << 22, want_stats=True)
+    assert (sok, spath) == (ok, path) and st["nodes"] == nodes and st["expanded"] == expanded
+
+
 @pytest.mark.timeout(300)
 def test_general_and_normal_form_move_code_build_the_same_arena(digests, monkeypatch):
     """the two move codes of the BFS kernels (acx_bfs.h: apply_move / apply_move_nf) must give the same nodes"""
