@@ -348,8 +348,9 @@ def extra_env_numbers(dev, pool):
     out["throughput_regime"] = {"envs": n_big, "us_per_step_launch": us, "env_steps_per_s": n_big / us * 1e6,
                                 "achieved_GBps_algorithmic": ALGO_BYTES_PER_STEP * n_big / us / 1e3,
                                 "frac_of_hbm_peak": ALGO_BYTES_PER_STEP * n_big / us / 1e3 / HBM_PEAK_GBS,
-                                "note": "by ALGORITHMIC bytes; the 100 MB of packed state (24 of the 107 B per env-step) stay in the 256 MB Infinity "
-                                        "Cache, so the HBM traffic proper is the observation / reward / flag write stream: 83 of 107 B"}
+                                "note": "by SURVEY 8(d)'s ALGORITHMIC bytes (int8 row in + observation row out + action, reward, flags = 107 B per env-step); "
+                                        "the kernel's own packed state (24 B read + 24 B written per env-step, 100 MB in all) stays in the 256 MB Infinity "
+                                        "Cache at this size, what goes to HBM is the 56-B observation / reward / flag stream"}
     del env, obs, tape
     n, T = N_ENVS, 1000
     env = ACVecEnv(pool[np.arange(n) % len(pool)], horizon_length=HORIZON, record_actions=False, final_info=False)
