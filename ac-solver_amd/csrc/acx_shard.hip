@@ -6,7 +6,7 @@
 // per new state; the keys of occupants are read from the received records / the node arena) and turns winners into nodes
 // through per-parent child masks -- the same 12-bit masks the ranks all-reduce -- so nothing is ever sorted and a chunk
 // costs the host two read-backs (send counts, the decision scalars).
-#include "acx_frontier.h"
+#include "acx_bfs.h"  // search_move: the shorter move code for searches whose root is in normal form
 
 namespace acx {
 
@@ -92,7 +92,7 @@ template <typename W> __global__ void k_shard_bounds(SearchDev<W> d, uint32_t lv
 #endif
 constexpr int kRouteItems = ACX_ROUTE_ITEMS;
 
-template <typename W>
+template <typename W, int MODE>
 __global__ void __launch_bounds__(1024) k_shard_expand_routed(SearchDev<W> d, const uint32_t* __restrict__ bounds, int64_t pref_hi,
                                                              uint32_t world, int64_t* __restrict__ rec, int64_t region_cap, unsigned long long* __restrict__ counts,
                                                              unsigned long long* __restrict__ solved) {
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(1024) k_shard_expand_routed(SearchDev<W> d, co
             Pres<W> s;
             const W pk0 = d.k0[id], pk1 = d.k1[id];
             key_to_pres<W>(pk0, pk1, s);
-            const int e = apply_move<W, kSearchSafe>(s, a, d.L, d.cyclical != 0);
+            const int e = search_move<W, MODE>(s, a, d.L, d.cyclical != 0);
             tag[it] = 12 * (int64_t)d.depth[id] + a;
             ids[it] = id;
             if (e) atomicMin(solved + 1, ((unsigned long long)tag[it] << 8) | (unsigned long long)e);  // first erroring move (global tag)
@@ -320,6 +320,7 @@ template <typename W> struct ShardEngine {
     const int64_t* pending_rec = nullptr;
     int64_t pending_tag0 = 0;
     int rank = 0, world = 1;
+    int move_mode = kMoveGeneral;  // acx_bfs.h: set from the root (acx_shard_root_record, which every rank calls)
 
     int init(int L, int cyclical, int64_t node_cap, int64_t batch_cap, int64_t chunk_parents, int rank_, int world_) {
         memset(&d, 0, sizeof(d));
@@ -402,6 +403,8 @@ template <typename W> static int shard_root(ShardEngine<W>& E, const int8_t* pre
     bool ok = pack_relator<W>(pres, E.d.L, root.w0, root.n0);
     ok = pack_relator<W>(pres + E.d.L, E.d.L, root.w1, root.n1) && ok;
     if (!ok) return fail(ACX_E_ROWERR, "acx_shard: the presentation is not a zero-padded word pair over {+-1,+-2}");
+    // a root in normal form keeps the whole search in normal form (acx_bfs.h)
+    E.move_mode = !is_normal_form<W>(root, E.d.cyclical != 0) ? kMoveGeneral : (E.d.cyclical ? kMoveNfCyclical : kMoveNf);
     recio<W>::put(rec, keyops<W>::make(root.w0, root.n0), keyops<W>::make(root.w1, root.n1));
     rec[recio<W>::KW] = 0;
     rec[recio<W>::KW + 1] = -1;
@@ -428,8 +431,18 @@ static int shard_expand_routed(ShardEngine<W>& E, int64_t c0, int64_t c1, int64_
     if (np_max <= 0) return ACX_OK;
     const int64_t m = 12 * np_max;
     hipLaunchKernelGGL(k_shard_bounds<W>, dim3(1), dim3(1), 0, st, E.d, (uint32_t)E.lvl_lo, (uint32_t)E.lvl_hi, (uint32_t)c0, (uint32_t)c1, E.d_bounds);
-    hipLaunchKernelGGL(k_shard_expand_routed<W>, dim3((unsigned)((m + 1024 * kRouteItems - 1) / (1024 * kRouteItems))), dim3(1024), 0, st, E.d, E.d_bounds,
-                       (int64_t)E.rank << 40, (uint32_t)E.world, rec, region_cap, (unsigned long long*)counts, (unsigned long long*)solved);
+    const dim3 grid((unsigned)((m + 1024 * kRouteItems - 1) / (1024 * kRouteItems)));
+#define ACX_SHARD_EXPAND(MODE)                                                                                                                           \
+    hipLaunchKernelGGL((k_shard_expand_routed<W, MODE>), grid, dim3(1024), 0, st, E.d, E.d_bounds, (int64_t)E.rank << 40, (uint32_t)E.world, rec, region_cap, \
+                       (unsigned long long*)counts, (unsigned long long*)solved)
+    if (E.move_mode == kMoveNf) {
+        ACX_SHARD_EXPAND(kMoveNf);
+    } else if (E.move_mode == kMoveNfCyclical) {
+        ACX_SHARD_EXPAND(kMoveNfCyclical);
+    } else {
+        ACX_SHARD_EXPAND(kMoveGeneral);
+    }
+#undef ACX_SHARD_EXPAND
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
