@@ -261,16 +261,18 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const float* _
     });
     const frag_cd& logit = head[0];
     const frag_cd& val = head[1];
-    // outputs 0..3 and 8..11 sit in lane half 0 (registers 0..3, 4..7), outputs 4..7 and 12..15 in half 1: gather into half 0
+    // outputs 0..3 and 8..11 sit in lane half 0 (registers 0..3, 4..7), outputs 4..7 and 12..15 in half 1: both halves gather all 16
     float lg[16];
 #pragma unroll
     for (int v = 0; v < 8; v++) {
         const float other = __shfl_xor(logit[v], 32);
-        lg[(v & 3) + 8 * (v >> 2)] = logit[v];
-        lg[(v & 3) + 8 * (v >> 2) + 4] = other;
+        lg[(v & 3) + 8 * (v >> 2)] = h ? other : logit[v];
+        lg[(v & 3) + 8 * (v >> 2) + 4] = h ? logit[v] : other;
     }
-    if (h == 0 && env < n_env) {
-        // (loops over all 16 head outputs with a test against n_actions: a runtime trip count would index lg[] dynamically)
+    {
+        // Both lanes of an environment (l and l + 32) hold all 16 head outputs: each draws for eight of the actions (lane half h:
+        // actions 8 h .. 8 h + 7), one shuffle picks the better of the two candidates.  (Loops run over all 16 outputs with a test
+        // against n_actions: a runtime trip count would index lg[] dynamically.)
         float mx = -3.0e38f;
 #pragma unroll
         for (int a = 0; a < 16; a++) mx = a < n_actions ? fmaxf(mx, lg[a]) : mx;
@@ -284,10 +286,12 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const float* _
         // halves): cheap next to the 64-bit multiplies of mix64, which were a tenth of the kernel
         const uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
 #pragma unroll
-        for (int a = 0; a < 16; a++) {
+        for (int k = 0; k < 8; k++) {
+            const int a = 8 * (int)h + k;
+            const float lga = h ? lg[8 + k] : lg[k];
             const uint32_t bits = fmix32(fmix32(((uint32_t)env * 16u + (uint32_t)a) ^ s_lo) + s_hi + (uint32_t)(env >> 28));
             const float u = ((float)(bits >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
-            const float lp = lg[a] - lse;
+            const float lp = lga - lse;
             const float score = lp - __logf(-__logf(u));
             if (a < n_actions && score > best_score) {
                 best_score = score;
@@ -295,9 +299,17 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const float* _
                 best_lp = lp;
             }
         }
-        action[env] = best;
-        logprob[env] = best_lp;
-        value[env] = val[0];
+        const float o_score = __shfl_xor(best_score, 32), o_lp = __shfl_xor(best_lp, 32);
+        const int o_best = __shfl_xor(best, 32);
+        if (o_score > best_score || (o_score == best_score && o_best < best)) {  // (ties: the lower action, as a scan in action order would)
+            best = o_best;
+            best_lp = o_lp;
+        }
+        if (h == 0 && env < n_env) {
+            action[env] = best;
+            logprob[env] = best_lp;
+            value[env] = val[0];
+        }
 #ifdef ACX_POLICY_STAMP
         logprob[n_env + (blockIdx.x & 1) * 512 + wave * 64 + 63] = (float)(long long)(__builtin_amdgcn_s_memtime() - t_start);
 #endif
