@@ -81,7 +81,8 @@ template <typename W> __global__ void k_bfs_root(SearchDev<W> d, W k0, W k1, uin
 }
 
 // one lane per (parent, action): tag t = 12 * p + a.  btook[t] = 1 when t took its slot (claimed it free, or replaced a
-// larger tag of the same key); brepl[tag] = 1 is set for a holder that was replaced (brepl is zero on entry).
+// larger tag of the same key); brepl[tag] = 1 is set for a holder that was replaced (brepl is zero on entry:
+// cleared once per search, k_bfs_compact zeroes what a batch set).
 template <typename W, int MODE>
 __global__ void __launch_bounds__(kBfsBlock, (sizeof(W) == 8 && MODE != kMoveGeneral) ? 8 : 4) k_bfs_expand_insert(SearchDev<W> d, uint32_t pbegin, uint32_t np) {
     __shared__ W s_k0[kBfsBlock];
@@ -243,13 +244,18 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
 #pragma unroll
         for (uint32_t q = 0; q < kCompactItems / 8; q++) {
             const unsigned long long tb = *(const unsigned long long*)(d.btook + t0 + 8 * q), rb = *(const unsigned long long*)(d.brepl + t0 + 8 * q);
+            if (rb) *(unsigned long long*)(d.brepl + t0 + 8 * q) = 0;  // zero again for the next batch (no memset launch per batch)
             const unsigned long long w = tb & ~rb;  // bytes are 0 / 1
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) fl |= (uint32_t)((w >> (8u * i)) & 1ull) << (8 * q + i);
         }
     } else {
         for (uint32_t i = 0; i < kCompactItems; i++)
-            if (t0 + i < m && d.btook[t0 + i] && !d.brepl[t0 + i]) fl |= 1u << i;
+            if (t0 + i < m) {
+                const uint8_t rb = d.brepl[t0 + i];
+                if (rb) d.brepl[t0 + i] = 0;
+                if (d.btook[t0 + i] && !rb) fl |= 1u << i;
+            }
     }
     const uint32_t cnt = (uint32_t)__popc(fl);
     uint32_t incl = cnt;

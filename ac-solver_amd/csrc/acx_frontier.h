@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(256) k_compact_tab(SearchDev<W> d, uint32_t pb
 // "winners before tag T" is a binary search over their (parent, action) and the budget-crossing candidate is winner need - 1.
 template <typename W>
 __global__ void k_decide_tab(SearchDev<W> d, uint32_t m, uint32_t np, uint32_t pbegin, uint32_t base, uint32_t cap_nodes, long long max_nodes,
-                             const uint32_t* __restrict__ total_in, Decision* __restrict__ out) {
+                             const uint32_t* __restrict__ total_in, Decision* __restrict__ out, int reset_tags = 0) {
     ACX_VGPR_PAD("v23");
     const uint32_t total = *total_in;
     const unsigned long long nodes = base;
@@ -560,6 +560,11 @@ __global__ void k_decide_tab(SearchDev<W> d, uint32_t m, uint32_t np, uint32_t p
     if (err_hit) out->solved = 0;
     if (*d.err & kErrTableFull) out->err = 0xFE;  // not a move error: a probe sequence ran through its whole table
     out->min_len = *d.min_len;
+    if (reset_tags) {  // the batch's success / error tags back to "none" for the next batch (saves a memset launch per batch)
+        *d.solved_tag = kNoTag;
+        *d.shorter_tag = kNoTag;
+        *d.err_tag = kNoTag;
+    }
 }
 
 // root node: id 0

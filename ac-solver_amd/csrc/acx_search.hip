@@ -202,6 +202,7 @@ template <typename W> struct Searcher {
         if (!lean) ACX_HIP_TRY(hipMemsetAsync(arena_tab.p, 0xff, n_slots * (stamp_tab ? 8 : inline_tab ? sizeof(TabEntry<W>) : 4), st));
         ACX_HIP_TRY(hipMemsetAsync(arena_scal.p, 0xff, 256, st));
         ACX_HIP_TRY(hipMemsetAsync(d.err, 0, 4, st));
+        if (stamp_tab) ACX_HIP_TRY(hipMemsetAsync(d.brepl, 0, cap_cand + 8, st));  // once: k_bfs_compact zeroes what a batch sets
         d_ticket = (uint32_t*)(sc + 128);
         d_total = (uint32_t*)(sc + 132);
         ACX_HIP_TRY(hipMemsetAsync(d_ticket, 0, 8, st));
@@ -827,13 +828,14 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
                            (unsigned long long)nodes, bucket_len, bucket_depth, buckets.size());
 
         // ---- expand, dedup with min-tag resolution, number the winners, decide -- all on the stream --------
-        rc = S.reset_batch_scalars();
-        if (rc) return rc;
+        if (!stamp || d.first_len) {  // (the stamp-table BFS resets its tags in k_decide_tab and its flags in k_bfs_compact)
+            rc = S.reset_batch_scalars();
+            if (rc) return rc;
+        }
         d.min_len_start = printed_min;
         if (batches >= (1ull << 30)) return fail(ACX_E_CAPACITY, "acx_search: more than 2^30 batches (the look-back words carry a 30-bit batch number)");
         if (stamp) {
             // expand + dedup in one kernel, winners -> nodes in one pass, then the decision from the written nodes
-            ACX_HIP_TRY(hipMemsetAsync(d.brepl, 0, m, st));
             const dim3 egrid((m + kBfsBlock - 1) / kBfsBlock), eblock(kBfsBlock), cgrid((m + kCompactTile - 1) / kCompactTile);
 #ifndef ACX_BFS_EXPAND_MODE
 #define ACX_BFS_EXPAND_MODE(M) M
@@ -853,7 +855,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
                 ACX_BFS_LAUNCH(kMoveGeneral);
             }
 #undef ACX_BFS_LAUNCH
-            hipLaunchKernelGGL(k_decide_tab<W>, dim3(1), dim3(1), 0, st, d, m, np, pbegin, (uint32_t)nodes, (uint32_t)S.cap_nodes, (long long)max_nodes, S.d_total, S.d_dec);
+            hipLaunchKernelGGL(k_decide_tab<W>, dim3(1), dim3(1), 0, st, d, m, np, pbegin, (uint32_t)nodes, (uint32_t)S.cap_nodes, (long long)max_nodes, S.d_total, S.d_dec, 1);
         } else {
         hipLaunchKernelGGL(k_expand<W>, grid, block, 0, st, d, plist, pbegin, np);
         if (greedy) {
@@ -872,7 +874,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
             // winners -> nodes in one pass, then the decision from the written nodes
             hipLaunchKernelGGL(k_compact_tab<W>, dim3((m + kCompactTile - 1) / kCompactTile), block, 0, st, d, pbegin, m, (uint32_t)nodes, (uint32_t)S.cap_nodes,
                                (uint32_t)batches, S.d_status, S.d_ticket, S.d_total);
-            hipLaunchKernelGGL(k_decide_tab<W>, dim3(1), dim3(1), 0, st, d, m, np, pbegin, (uint32_t)nodes, (uint32_t)S.cap_nodes, (long long)max_nodes, S.d_total, S.d_dec);
+            hipLaunchKernelGGL(k_decide_tab<W>, dim3(1), dim3(1), 0, st, d, m, np, pbegin, (uint32_t)nodes, (uint32_t)S.cap_nodes, (long long)max_nodes, S.d_total, S.d_dec, 1);
         } else {
             size_t tb = S.tmp_bytes;
             if (rocprim::exclusive_scan(S.arena_tmp.p, tb, d.cflag, d.cpos, 0u, m, rocprim::plus<uint32_t>(), st) != hipSuccess)
