@@ -99,7 +99,7 @@ SIGNATURES = {
     "acx_shard_destroy": (None, [_vp]),
     "acx_shard_root_record": (C.c_int, [_vp, _i8p, _i64p]),
     "acx_release_cached_memory": (C.c_int, []),
-    "acx_policy_sample": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, C.c_int, C.c_uint64, _vp, _vp, _vp, _vp]),
+    "acx_policy_sample": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _vp, _vp, C.c_int, C.c_uint64, _vp, _vp, _vp, _vp]),
     "acx_policy_packed_bytes": (C.c_int64, [C.c_int]),
     "acx_search_minima_enable": (C.c_int, [C.c_int]),
     "acx_search_last_minima": (C.c_int, [_i32p, C.c_int64, _i64p]),

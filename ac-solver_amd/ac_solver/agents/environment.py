@@ -82,7 +82,9 @@ def get_env(args, device=None, rank=0, world=1):
         if not args.norm_rewards:  # with --norm-rewards the clip follows the normalisation (training loop), as make_env stacks the wrappers
             clip = (args.min_rew, args.max_rew)
     supermoves = [[int(a) for a in q.split(",")] for q in getattr(args, "supermoves", "").split(";") if q.strip()] or None
-    envs = ACVecEnv(rows, horizon_length=args.horizon_length, obs_dtype="float32", clip_rewards=clip, record_actions=True,
+    # with the fused policy kernel the rollout keeps int8 observation rows (a quarter of the bytes written and read per step);
+    # the update widens a minibatch to f32 when it needs it (training.py)
+    envs = ACVecEnv(rows, horizon_length=args.horizon_length, obs_dtype="int8" if getattr(args, "fused_policy", False) else "float32", clip_rewards=clip, record_actions=True,
                     final_info=False, device=device, supermoves=supermoves)
     states_processed = set(curr_states)
     success_record = {"solved": set(), "unsolved": set(range(len(initial_states)))}

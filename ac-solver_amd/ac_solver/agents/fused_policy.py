@@ -77,10 +77,10 @@ class FusedPolicy:
             self.critic = pack_network(self.agent.critic, self.in_dim)
 
     def sample(self, obs, action, logprob, value):
-        assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[-1] == self.in_dim
+        assert obs.dtype in (torch.float32, torch.int8) and obs.is_contiguous() and obs.shape[-1] == self.in_dim
         assert action.dtype == torch.int64 and logprob.dtype == torch.float32 and value.dtype == torch.float32
         n = obs.numel() // self.in_dim
         seed = int(self._seed.integers(0, 1 << 63))
-        _acx.check(_acx.lib.acx_policy_sample(obs.data_ptr(), n, self.in_dim, self.actor.data_ptr(), self.critic.data_ptr(), self.n_actions, seed,
+        _acx.check(_acx.lib.acx_policy_sample(obs.data_ptr(), _acx.I8 if obs.dtype == torch.int8 else _acx.F32, n, self.in_dim, self.actor.data_ptr(), self.critic.data_ptr(), self.n_actions, seed,
                                               action.data_ptr(), logprob.data_ptr(), value.data_ptr(), torch.cuda.current_stream(obs.device).cuda_stream),
                    "acx_policy_sample")

@@ -129,7 +129,9 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
     rank = torch.distributed.get_rank() if dist_on else 0
 
     # rollout storage: the environment kernel writes rows t+1 of obs / term and row t of rewards
-    obs = torch.zeros((T + 1, N) + obs_shape, device=device)
+    fused_on = bool(getattr(args, "fused_policy", False))
+    obs_dtype = torch.int8 if fused_on else torch.float32  # (get_env creates the environments with the matching obs_dtype)
+    obs = torch.zeros((T + 1, N) + obs_shape, dtype=obs_dtype, device=device)
     term = torch.zeros((T + 1, N), dtype=torch.bool, device=device)
     trunc = torch.zeros(N, dtype=torch.bool, device=device)
     actions = torch.zeros((T, N), dtype=torch.int64, device=device)
@@ -137,7 +139,7 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
     rewards = torch.zeros((T, N), device=device)
     values = torch.zeros((T, N), device=device)
     init_rows = np.asarray(initial_states, np.int8)
-    init_table = torch.as_tensor(init_rows.astype(np.float32), device=device)  # [n_states, 2L]
+    init_table = torch.as_tensor(init_rows, device=device).to(obs_dtype)  # [n_states, 2L]
     ep_return = torch.zeros(N, device=device)
     ep_length = torch.zeros(N, device=device)
 
@@ -151,7 +153,7 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
     beta = None if args.is_loss_clip else args.beta
     params = list(agent.parameters())
     fused = None
-    if getattr(args, "fused_policy", False):  # opt-in: rollout inference on the matrix cores (agents/fused_policy.py); the update stays f32 torch
+    if fused_on:  # opt-in: rollout inference on the matrix cores (agents/fused_policy.py); the update stays f32 torch
         from ac_solver.agents.fused_policy import FusedPolicy
 
         fused = FusedPolicy(agent, int(np.prod(obs_shape)), seed=args.seed)
@@ -253,7 +255,7 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
 
         dones = term.to(torch.float32)
         with torch.no_grad():
-            next_value = agent.get_value(obs[T]).reshape(-1)
+            next_value = agent.get_value(obs[T].float()).reshape(-1)
             advantages, returns = compute_gae(rewards, values, dones[:T], next_value, dones[T], args.gamma, args.gae_lambda)
 
         b_obs = obs[:T].reshape((-1,) + obs_shape)
@@ -267,7 +269,7 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             np.random.shuffle(b_inds)
             for start in range(0, args.batch_size, args.minibatch_size):
                 mb = torch.as_tensor(b_inds[start:start + args.minibatch_size], device=device)
-                _, newlogprob, entropy, newvalue = agent.get_action_and_value(b_obs[mb], b_actions[mb])
+                _, newlogprob, entropy, newvalue = agent.get_action_and_value(b_obs[mb].float(), b_actions[mb])
                 logratio = newlogprob - b_logprobs[mb]
                 ratio = logratio.exp()
                 kl_var = (ratio - 1) - logratio  # E[kl_var] approximates KL(pi_old || pi)

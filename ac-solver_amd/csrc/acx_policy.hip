@@ -125,7 +125,7 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // v_cvt_pk_b
     return __builtin_bit_cast(uint32_t, r);
 }
 template <int KS1>
-__global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const float* __restrict__ obs, int64_t n_env, int in_dim, const frag_ab* __restrict__ actor,
+__global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __restrict__ obs_any, int obs_i8, int64_t n_env, int in_dim, const frag_ab* __restrict__ actor,
                                                                  const frag_ab* __restrict__ critic, int n_actions, unsigned long long seed,
                                                                  int64_t* __restrict__ action, float* __restrict__ logprob, float* __restrict__ value) {
     using P = plan<KS1>;
@@ -141,7 +141,9 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const float* _
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int k = 16 * ks + 8 * (int)h + j;
-            x[ks][j] = (env < n_env && k < in_dim) ? (short)bf16_of(obs[env * in_dim + k]) : (short)0;
+            float o = 0.0f;  // (int8 observations -- what acx_env_step writes with ACX_I8 -- are a quarter of the bytes of the f32 rows)
+            if (env < n_env && k < in_dim) o = obs_i8 ? (float)((const int8_t*)obs_any)[env * in_dim + k] : ((const float*)obs_any)[env * in_dim + k];
+            x[ks][j] = (short)bf16_of(o);
         }
     frag_ab ones;
 #pragma unroll
@@ -321,10 +323,11 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const float* _
 
 using namespace acx;
 
-extern "C" int acx_policy_sample(const float* d_obs, int64_t n_env, int in_dim, const void* d_actor, const void* d_critic, int n_actions, uint64_t seed,
+extern "C" int acx_policy_sample(const void* d_obs, int obs_dtype, int64_t n_env, int in_dim, const void* d_actor, const void* d_critic, int n_actions, uint64_t seed,
                                  int64_t* d_action, float* d_logprob, float* d_value, void* stream) {
     if (!have_device()) return ACX_E_NODEVICE;
     if (!d_obs || !d_actor || !d_critic || !d_action || !d_logprob || !d_value || n_env < 0) return fail(ACX_E_INVAL, "acx_policy_sample: bad argument");
+    if (obs_dtype != ACX_F32 && obs_dtype != ACX_I8) return fail(ACX_E_INVAL, "acx_policy_sample: observations are ACX_F32 or ACX_I8");
     // 80 inputs = max_relator_length 40 (the reference trains at 36); wider first layers would not leave the register margin of ACX_VGPR_PAD
     if (in_dim < 1 || in_dim > 80 || n_actions < 1 || n_actions > 16) return fail(ACX_E_INVAL, "acx_policy_sample handles 1..80 inputs and 1..16 actions");
     if (n_env == 0) return ACX_OK;
@@ -336,7 +339,7 @@ extern "C" int acx_policy_sample(const float* d_obs, int64_t n_env, int in_dim, 
     hipStream_t st = (hipStream_t)stream;
 #define ACX_POLICY_LAUNCH(KS)                                                                                                                        \
     ACX_HIP_TRY(hipFuncSetAttribute((const void*)policy::k_policy_sample<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
-    hipLaunchKernelGGL((policy::k_policy_sample<KS>), grid, block, lds, st, d_obs, n_env, in_dim, a, c, n_actions, (unsigned long long)seed, d_action, \
+    hipLaunchKernelGGL((policy::k_policy_sample<KS>), grid, block, lds, st, d_obs, obs_dtype == ACX_I8 ? 1 : 0, n_env, in_dim, a, c, n_actions, (unsigned long long)seed, d_action, \
                        d_logprob, d_value)
     switch (ks1) {
         case 1: ACX_POLICY_LAUNCH(1); break;

@@ -414,9 +414,28 @@ def extra_env_numbers(dev, pool):
             e1.record()
             torch.cuda.synchronize()
             res[name] = n * T / e0.elapsed_time(e1) * 1e3
+        # the same rollout with int8 observation rows (a quarter of the bytes the env kernel writes and the policy kernel reads;
+        # the update would widen a minibatch to f32 when it needs it)
+        env8 = ACVecEnv(pool[np.arange(n) % len(pool)], horizon_length=HORIZON, obs_dtype="int8", clip_rewards=(-10, 1000), record_actions=False,
+                        final_info=False)
+        obs8 = torch.zeros((T + 1, n, 2 * L), dtype=torch.int8, device=dev)
+        obs8[0].copy_(env8.reset()[0])
+
+        def rollout8():
+            for t in range(T):
+                fused.sample(obs8[t], act[t], logp[t], val[t])
+                env8.step(act[t], out=(obs8[t + 1], rew[t], term[t + 1], trunc), check_errors=False)
+
+        rollout8()
+        torch.cuda.synchronize()
+        e0.record()
+        rollout8()
+        e1.record()
+        torch.cuda.synchronize()
+        res["fused_i8"] = n * T / e0.elapsed_time(e1) * 1e3
         flop = 2.0 * ((2 * L) * 256 + 256 * 256 + 256 * 12) + 2.0 * ((2 * L) * 256 + 256 * 256 + 256)  # actor + critic, per environment
         out["ppo_rollout"] = {"envs": n, "steps": T, "env_steps_per_s": res["fused"], "env_steps_per_s_torch_f32_policy": res["torch"],
-                              "env_steps_per_s_env_kernel_only": res["none"],
+                              "env_steps_per_s_env_kernel_only": res["none"], "env_steps_per_s_int8_obs": res["fused_i8"],
                               "policy": "50-256-256-12 / 50-256-256-1 tanh MLPs; fused = acx_policy_sample (v_mfma_f32_32x32x16_bf16, f32 accumulation, "
                                         "Gumbel-max draw in the kernel), torch = the reference's f32 modules",
                               "policy_tflops_fused": flop * n / max(n / res["fused"] - n / res["none"], 1e-9) / 1e12,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACX_VERSION 200
+#define ACX_VERSION 201
 
 /* return codes */
 #define ACX_OK 0
@@ -227,11 +227,11 @@ int acx_shard_status(acx_shard *h, int32_t *err, int32_t *min_len);
  * The agent of ac_solver/agents/ppo_agent.py:11-109 -- actor and critic, each in_dim -> 256 -> 256 -> {n_actions, 1} with
  * tanh -- evaluated on n_env observations and sampled, in ONE kernel on the matrix cores (bf16 operands, f32 accumulation):
  * d_action[e] ~ Categorical(softmax(actor(obs[e]))) (Gumbel-max with a counter-based hash of (seed, e, action): pass a
- * fresh seed per call), d_logprob[e] its log-probability, d_value[e] = critic(obs[e]).  d_obs [n_env, in_dim] f32 row-major
- * (what acx_env_step writes with ACX_F32).  d_actor / d_critic: the networks packed by
+ * fresh seed per call), d_logprob[e] its log-probability, d_value[e] = critic(obs[e]).  d_obs [n_env, in_dim] row-major, obs_dtype
+ * ACX_F32 or ACX_I8 (what acx_env_step writes with either; the int8 rows are a quarter of the bytes).  d_actor / d_critic: the networks packed by
  * ac_solver/agents/fused_policy.py:pack_network (acx_policy_packed_bytes(in_dim) bytes each).  in_dim <= 80,
  * n_actions <= 16, hidden width 256.  Inference only; the PPO update runs in torch on the f32 master weights. */
-int acx_policy_sample(const float *d_obs, int64_t n_env, int in_dim, const void *d_actor, const void *d_critic,
+int acx_policy_sample(const void *d_obs, int obs_dtype, int64_t n_env, int in_dim, const void *d_actor, const void *d_critic,
                       int n_actions, uint64_t seed, int64_t *d_action, float *d_logprob, float *d_value, void *stream);
 int64_t acx_policy_packed_bytes(int in_dim);
 

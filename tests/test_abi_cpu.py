@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_acx.lib, name), f"{name} is declared in include/acx.h but not exported by libacx.so"
     missing = [n for n in names if n not in _acx.SIGNATURES]
     assert not missing, f"ctypes signatures missing for {missing}"
-    assert _acx.lib.acx_version() == 200
+    assert _acx.lib.acx_version() == 201
     assert isinstance(_acx.device_count(), int)
 
 

@@ -97,3 +97,24 @@ def test_fused_policy_samples_the_policys_distribution():
     fp.refresh()
     fp.sample(obs, action, logp, val)
     assert float((action == 3).double().mean()) > 0.999
+
+
+def test_int8_observations_give_the_same_outputs():
+    """acx_env_step writes int8 or float32 observation rows; the policy kernel reads either (the letters -2..2 are exact in both):
+    same seed -> same actions, log-probabilities and values"""
+    import torch
+
+    from ac_solver.agents.fused_policy import FusedPolicy
+
+    n, in_dim = 3001, 50
+    agent = _agent(in_dim, 12, 21)
+    obs = torch.randint(-2, 3, (n, in_dim), device="cuda")
+    outs = []
+    for o in (obs.float(), obs.to(torch.int8)):
+        fp = FusedPolicy(agent, in_dim, seed=9)
+        a = torch.zeros(n, dtype=torch.int64, device="cuda")
+        lp, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        fp.sample(o.contiguous(), a, lp, v)
+        outs.append((a.clone(), lp.clone(), v.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
