@@ -632,10 +632,11 @@ __global__ void __launch_bounds__(256) k_rank_sort(SearchDev<W> d, const uint32_
 // cost milliseconds per call -- erratically up to seconds for the 10 GB arenas of a group of searches -- and hipFree
 // synchronises the whole device, which would serialise the overlapped searches of acx_search_many.  (Round 1 kept a pool per
 // host thread; worker threads then had to return their blocks before they ended, and every acx_search_many paid the
-// allocations again.)  The pool holds at most kMaxCachedTotal bytes; acx_release_cached_memory empties it.
+// allocations again.)  The pool holds at most 60 % of the device memory; acx_release_cached_memory empties it.
 struct BlockPool {
     static constexpr size_t kMaxCachedBlock = 48ull << 30;
-    static constexpr size_t kMaxCachedTotal = 96ull << 30;
+    size_t max_cached_total = 0;  // 60 % of the device's memory (173 GB of an MI355X's 288), set at first use: the two sweeps of
+                                  // bench.py (bfs, then greedy over the 1190 presentations) keep ~150 GB of arenas between runs
     static constexpr size_t kMaxBlocks = 8192;
     std::mutex mu;
     std::vector<std::pair<void*, size_t>> blocks;
@@ -656,7 +657,11 @@ struct BlockPool {
     void give(void* p, size_t bytes) {
         {
             std::lock_guard<std::mutex> lock(mu);
-            if (bytes <= kMaxCachedBlock && cached + bytes <= kMaxCachedTotal && blocks.size() < kMaxBlocks) {
+            if (!max_cached_total) {
+                size_t free_b = 0, total_b = 0;
+                max_cached_total = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? total_b / 10 * 6 : (96ull << 30);
+            }
+            if (bytes <= kMaxCachedBlock && cached + bytes <= max_cached_total && blocks.size() < kMaxBlocks) {
                 blocks.emplace_back(p, bytes);
                 cached += bytes;
                 return;
