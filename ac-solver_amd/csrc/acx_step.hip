@@ -66,7 +66,7 @@ Scratch& scratch(int slot) {
 }
 
 // ---------------------------------------------------------------- device helpers --------------
-__device__ __forceinline__ int load_action(const void* p, int dtype, int64_t k) {
+__device__ __forceinline__ int load_action(const void* p, int dtype, int64_t k) {  // (a non-temporal load here measured 0.1 us slower per step)
     switch (dtype) {
         case ACX_U8: return ((const uint8_t*)p)[k];
         case ACX_I32: return ((const int32_t*)p)[k];
@@ -78,6 +78,13 @@ __device__ __forceinline__ int load_action(const void* p, int dtype, int64_t k) 
 // Per-wave cooperative copy of `nbytes` contiguous bytes, 16 B per lane per trip when both sides
 // are 16-B aligned (`vec`), byte-wise for the ragged tail / unaligned callers.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifndef ACX_STEP_NT_FLAGS
+#define ACX_STEP_NT_FLAGS 1  // 1: reward / done / truncated leave with non-temporal stores
+#endif
+template <bool NT, typename T> __device__ __forceinline__ void env_store_out(T* p, T v) {
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 #ifndef ACX_OBS_NT
 #define ACX_OBS_NT 1  // 1: observation tiles leave with non-temporal (streaming) stores: nothing re-reads them on the GPU side of a step
 #endif
@@ -377,9 +384,11 @@ __global__ void __launch_bounds__(256, SUPER ? 5 : ACX_STEP_WAVES) k_env_step(W*
         sw0[i] = v.s.w0;
         sw1[i] = v.s.w1;
         smeta[i] = env_pack_meta<W>(v);
-        if (rew) rew[i] = r;
-        if (done) done[i] = (uint8_t)d;
-        if (trunc) trunc[i] = (uint8_t)t;
+        // reward and flags leave with non-temporal (streaming) stores like the observation tile: nothing on the GPU side of a step
+        // re-reads them, and as ordinary stores they cost the 65 536-env step 0.3 us (3.86 -> 3.55 us per launch)
+        if (rew) env_store_out<ACX_STEP_NT_FLAGS != 0>(rew + i, r);
+        if (done) env_store_out<ACX_STEP_NT_FLAGS != 0>(done + i, (uint8_t)d);
+        if (trunc) env_store_out<ACX_STEP_NT_FLAGS != 0>(trunc + i, (uint8_t)t);
         if (obs) write_obs_row<W, LC>(my, v.s, L);
     }
     if (obs) {
@@ -434,9 +443,9 @@ __global__ void __launch_bounds__(256, 4) k_env_step_team(W* __restrict__ sw0, W
         sw0[i] = v.s.w0;
         sw1[i] = v.s.w1;
         smeta[i] = env_pack_meta<W>(v);
-        if (rew) rew[i] = r;
-        if (done) done[i] = (uint8_t)d;
-        if (trunc) trunc[i] = (uint8_t)t;
+        if (rew) env_store_out<ACX_STEP_NT_FLAGS != 0>(rew + i, r);
+        if (done) env_store_out<ACX_STEP_NT_FLAGS != 0>(done + i, (uint8_t)d);
+        if (trunc) env_store_out<ACX_STEP_NT_FLAGS != 0>(trunc + i, (uint8_t)t);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: wave 0's global stores stay in flight
     if (lane < rows) {
@@ -483,9 +492,9 @@ __global__ void __launch_bounds__(256) k_env_rollout(EnvDev<W> e, const uint8_t*
         int d, tr;
         bool was_reset;
         env_transition<W, SAFE, SUPER>(e, i, v, tape[t * e.n + i], autoreset != 0, clip_lo, clip_hi, r, d, tr, was_reset, fin);
-        if (rew) rew[t * e.n + i] = r;
-        if (done) done[t * e.n + i] = (uint8_t)d;
-        if (trunc) trunc[t * e.n + i] = (uint8_t)tr;
+        if (rew) env_store_out<ACX_STEP_NT_FLAGS != 0>(rew + t * e.n + i, r);
+        if (done) env_store_out<ACX_STEP_NT_FLAGS != 0>(done + t * e.n + i, (uint8_t)d);
+        if (trunc) env_store_out<ACX_STEP_NT_FLAGS != 0>(trunc + t * e.n + i, (uint8_t)tr);
     }
     env_store<W>(e, i, v);
 }
