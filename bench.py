@@ -18,10 +18,11 @@ price the frontier kernels with SURVEY 8(d)'s (64 + 72 f) B per generated child;
 CPU oracle (plain C port of the reference's algorithm, oracle/ac_oracle.c) on one host core and on all of
 them, and the pure Python / NumPy restatement (oracle/ac_numpy.py), on bounded samples of the same workloads.
 
-Timed region: the K steps are captured once into a hipGraph; the graph is replayed R times back to back
-(R = ceil(16384 / K), so the window is >= 50 ms whatever K is) between barrier + synchronize on both
-sides; `ms_per_step` = window / (R * K), `repeats` = R.  A 20-step and a 1000-step run therefore report the
-same per-step time instead of one graph replay's fixed cost spread over 20 steps.
+Timed region: R = ceil(16384 / K) passes over the K steps (a window of >= 50 ms whatever K is), back to back between
+barrier + synchronize on both sides; `ms_per_step` = window / (R * K), `repeats` = R.  The passes are captured into
+hipGraphs of up to 1024 kernel nodes (`graph_nodes`; K = 20: 51 passes per graph, launched 17 times): two graph launches
+leave a bubble of ~6 us between them on the GPU, which a 20-node graph would pay every 20 steps.  A 20-step and a 1000-step
+run therefore report the per-step time of the kernel chain, not one graph launch's fixed cost spread over 20 steps.
 """
 import argparse
 import json
@@ -42,7 +43,9 @@ HORIZON = 1000
 ALGO_BYTES_PER_STEP = 4 * L + 7  # state in + out (2 x 2L), action 1, reward f32 4, done 1, truncated 1
 SEARCH_TIMEOUT_S = int(os.environ.get("ACX_BENCH_SEARCH_TIMEOUT", "240"))  # multi-rank runs: how long the RCCL-backed secondary measurements may take
 HBM_PEAK_GBS = 8000.0            # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
-MIN_TIMED_STEPS = 16384          # the K-step graph is replayed ceil(MIN_TIMED_STEPS / K) times: a window of >= 50 ms
+MIN_TIMED_STEPS = 16384          # the K steps are repeated ceil(MIN_TIMED_STEPS / K) times: a window of >= 50 ms
+GRAPH_NODES_MAX = 1024           # passes of the same K steps captured into ONE hipGraph (K = 20: 51 passes): consecutive graph
+                                 # launches leave a ~6 us bubble on the GPU, which a 20-node graph pays every 20 steps
 
 
 def search_roofline(stats, kernel, traffic_key):
@@ -495,14 +498,19 @@ def main():
         launch(t, t % K)
     torch.cuda.synchronize()
 
+    R = max(1, -(-MIN_TIMED_STEPS // K))  # passes over the K steps in the timed window; same on every rank (depends on K only)
+    P = max(1, min(R, GRAPH_NODES_MAX // K))  # passes per graph
+    G = -(-R // P)                            # graph launches in the timed window
+    R = P * G
     mode = args.mode
     graph = None
     if mode == "graph":
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):  # capturing does not execute: the env stays in its post-warm-up state
-                for k in range(K):
-                    launch(W + k, k)
+                for _ in range(P):
+                    for k in range(K):
+                        launch(W + k, k)
         except Exception as e:  # pragma: no cover
             print(f"[bench] graph capture failed ({e}); falling back to eager launches", file=sys.stderr)
             graph, mode = None, "eager"
@@ -532,16 +540,16 @@ def main():
             graph.replay()  # one untimed replay after the communicator came up
             torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    R = max(1, -(-MIN_TIMED_STEPS // K))  # same on every rank (depends on K only)
 
-    def run_k_steps():
+    def run_k_steps():  # P passes of the K steps
         if graph is not None:
             graph.replay()
         else:
-            for k in range(K):
-                launch(W + k, k)
+            for _ in range(P):
+                for k in range(K):
+                    launch(W + k, k)
 
-    # one isolated K-step pass (what round 1 timed): carries the fixed cost of one graph replay + synchronize
+    # one isolated graph launch (P passes; round 1 timed one pass): carries the fixed cost of one graph replay + synchronize
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -556,7 +564,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(R):
+    for _ in range(G):
         run_k_steps()
     ev1.record()
     torch.cuda.synchronize()
@@ -587,7 +595,8 @@ def main():
             "ms_per_step": wall * 1e3 / (K * R),
             "repeats": R,
             "timed_window_ms": wall * 1e3,
-            "ms_per_step_single_pass": single_wall * 1e3 / K,
+            "graph_nodes": K * P if mode == "graph" else 0,
+            "ms_per_step_single_pass": single_wall * 1e3 / (K * P),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

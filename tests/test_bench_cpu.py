@@ -48,3 +48,6 @@ def test_timed_window_is_at_least_16384_steps_for_any_k():
     for k in (1, 20, 1000, 16384, 50000):
         r = max(1, -(-bench.MIN_TIMED_STEPS // k))
         assert r * k >= bench.MIN_TIMED_STEPS and (r == 1 or (r - 1) * k < bench.MIN_TIMED_STEPS)
+        p = max(1, min(r, bench.GRAPH_NODES_MAX // k))  # passes captured into one graph; the graph is launched ceil(r / p) times
+        g = -(-r // p)
+        assert p * k <= max(k, bench.GRAPH_NODES_MAX) and p * g >= r and p * (g - 1) < r
