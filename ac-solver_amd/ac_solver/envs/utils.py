@@ -34,6 +34,21 @@ def is_array_valid_presentation(array):
     return True
 
 
+def are_rows_valid_presentations(rows):
+    """`is_array_valid_presentation` for every row of a 2-D array at once (ACVecEnv checks 10^5..10^6 initial states): -> bool
+    array.  Same predicate: each half of a row has at least one letter and zeros only behind its last letter."""
+    rows = np.asarray(rows)
+    assert rows.ndim == 2 and rows.shape[1] % 2 == 0
+    L = rows.shape[1] // 2
+    ok = np.ones(rows.shape[0], dtype=bool)
+    pos = np.arange(L)[None, :]
+    for half in (rows[:, :L], rows[:, L:]):
+        nz = half != 0
+        n = nz.sum(axis=1)
+        ok &= (n > 0) & ~(nz & (pos >= n[:, None])).any(axis=1)
+    return ok
+
+
 def is_presentation_trivial(presentation):
     """True iff the presentation is one of the eight length-2 trivial ones <x^+-1, y^+-1> / <y^+-1, x^+-1>.
     Reference: utils.py:57-87."""

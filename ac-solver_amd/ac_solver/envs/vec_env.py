@@ -21,7 +21,7 @@ import numpy as np
 from ac_solver import _acx
 from ac_solver._gym import Box, Discrete
 from ac_solver.envs.ac_env import _Handle
-from ac_solver.envs.utils import is_array_valid_presentation
+from ac_solver.envs.utils import are_rows_valid_presentations, is_array_valid_presentation
 
 _ACTION_DTYPES = None
 
@@ -91,9 +91,8 @@ class ACVecEnv:
         states = np.asarray(initial_states)
         if states.ndim != 2 or states.shape[1] % 2:
             raise ValueError("initial_states must be [num_envs, 2 * max_relator_length]")
-        for row in states:
-            if not is_array_valid_presentation(row):
-                raise ValueError("initial state must be a valid presentation")  # ACEnvConfig.__post_init__
+        if not are_rows_valid_presentations(states).all():  # is_array_valid_presentation on every row, vectorised
+            raise ValueError("initial state must be a valid presentation")  # ACEnvConfig.__post_init__
         self.num_envs, width = states.shape
         self.max_relator_length = L = width // 2
         self.horizon_length = int(horizon_length)

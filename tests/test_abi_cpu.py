@@ -80,6 +80,22 @@ def test_host_side_helpers_without_gpu():
     for r in t["is_array_valid_presentation"]:
         assert is_array_valid_presentation(np.array(r["array"])) == r["valid"], r
         assert is_array_valid_presentation(list(r["array"])) == r["valid"], r
+    # the row-wise form ACVecEnv uses on its initial states: the reference's table (rows of one width at a time) and random rows
+    from ac_solver.envs.utils import are_rows_valid_presentations
+
+    by_width = {}
+    for r in t["is_array_valid_presentation"]:
+        a = np.array(r["array"])
+        if a.ndim == 1 and len(a) and len(a) % 2 == 0:
+            by_width.setdefault(len(a), []).append((a, r["valid"]))
+    for rows in by_width.values():
+        assert are_rows_valid_presentations(np.stack([a for a, _ in rows])).tolist() == [v for _, v in rows]
+    rng = np.random.default_rng(3)
+    rows = rng.integers(-2, 3, size=(4000, 12)).astype(np.int8)
+    for k in range(0, 4000, 2):
+        for h in (0, 1):
+            rows[k, h * 6 + rng.integers(0, 7):(h + 1) * 6] = 0
+    assert are_rows_valid_presentations(rows).tolist() == [is_array_valid_presentation(r) for r in rows]
     for r in t["is_presentation_trivial"]:
         assert is_presentation_trivial(np.array(r["array"])) == r["trivial"], r
     for L, want in t["generate_trivial_states"].items():
