@@ -119,6 +119,15 @@ def _share_success_record(success_record, n_states, device):
     success_record["unsolved"] -= solved
 
 
+def refresh_behaviour_stats(agent, obs, actions, logprobs, values):
+    """logprobs[t], values[t] <- the f32 agent's log pi(actions[t] | obs[t]) and V(obs[t]) for every rollout row t (in place)."""
+    with torch.no_grad():
+        for t in range(actions.shape[0]):
+            _, lp, _, v = agent.get_action_and_value(obs[t].float(), actions[t])
+            logprobs[t].copy_(lp)
+            values[t].copy_(v.flatten())
+
+
 def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success_record, ACMoves_hist, states_processed,
                       initial_states, progress=True, rollout_log=None):
     """`rollout_log`, when a list, receives per update a dict of CPU copies of the rollout tensors (tests)."""
@@ -254,6 +263,13 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             normalized_returns, normalized_lengths = np.array(returns_queue), np.array(lengths_queue)
 
         dones = term.to(torch.float32)
+        if fused is not None:
+            # The rollout's log-probabilities and values came out of the bf16 matrix-core kernel (|dlogp| up to ~0.1 against
+            # the f32 modules).  The update differentiates the f32 modules, and the reference forms its importance ratio
+            # against log-probabilities of THAT policy (training.py:283-291): so the behaviour statistics the update uses are
+            # recomputed here with one f32 forward over the batch -- the ratio of the first minibatch of the first epoch is then
+            # exactly 1, as in the reference.  One row of the rollout at a time keeps the temporaries at [N, 256].
+            refresh_behaviour_stats(agent, obs, actions, logprobs, values)
         with torch.no_grad():
             next_value = agent.get_value(obs[T].float()).reshape(-1)
             advantages, returns = compute_gae(rewards, values, dones[:T], next_value, dones[T], args.gamma, args.gae_lambda)
@@ -274,6 +290,8 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
                 ratio = logratio.exp()
                 kl_var = (ratio - 1) - logratio  # E[kl_var] approximates KL(pi_old || pi)
                 with torch.no_grad():
+                    if epoch == 0 and start == 0:  # before any step of this update the ratio is 1 (reference: training.py:283-291)
+                        ratio0_dev = (ratio - 1.0).abs().max()
                     approx_kl = kl_var.mean()
                     clipfracs.append(((ratio - 1.0).abs() > args.clip_coef).float().mean())
                 mb_adv = b_advantages[mb]
@@ -323,7 +341,7 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             "losses/value_loss": v_loss.item(), "losses/policy_loss": pg_loss.item(), "losses/entropy_loss": entropy_loss.item(),
             "losses/approx_kl": approx_kl.item(), "losses/explained_variance": explained_var,
             "losses/clipfrac": float(torch.stack(clipfracs).mean()), "debug/advantages_mean": float(b_advantages.mean()),
-            "debug/advantages_std": float(b_advantages.std()),
+            "debug/advantages_std": float(b_advantages.std()), "debug/ratio0_maxdev": float(ratio0_dev),
         }
         if wandb is not None:
             wandb.log(stats)

@@ -138,10 +138,10 @@ class ACEnv(Env):
         rew = np.empty(1, np.float32)
         done = np.empty(1, np.uint8)
         trunc = np.empty(1, np.uint8)
-        _acx.check(_acx.lib.acx_env_step_host(self._h.ptr, _acx.ptr(act, C.c_int64), _acx.ptr(obs, C.c_int8), _acx.ptr(rew, C.c_float),
-                                              _acx.ptr(done, C.c_uint8), _acx.ptr(trunc, C.c_uint8), None, 0), "acx_env_step_host")
         err = np.empty(1, np.uint8)
-        _acx.check(_acx.lib.acx_env_get_errors(self._h.ptr, _acx.ptr(err, C.c_uint8), 1, None))
+        _acx.check(_acx.lib.acx_env_step_host(self._h.ptr, _acx.ptr(act, C.c_int64), _acx.ptr(obs, C.c_int8), _acx.ptr(rew, C.c_float),
+                                              _acx.ptr(done, C.c_uint8), _acx.ptr(trunc, C.c_uint8), None, 0, _acx.ptr(err, C.c_uint8), None),
+                   "acx_env_step_host")  # one launch, one read-back, one synchronisation
         if err[0]:
             # the reference's ACMove raised before state/lengths/count_steps were touched (ac_env.py:97);
             # the kernel left the device state and counter untouched as well

@@ -100,6 +100,10 @@ __global__ void __launch_bounds__(kBmT) k_bfs_multi(const BfsJob<W>* __restrict_
         s_status = BFS_RUNNING;
         s_min_len = (uint32_t)g.tlen[0];
         s_full = 0;
+        s_solved_tag = 0xFFFFFFFFu;
+        s_err_tag = ~0ull;
+        s_pb = 0xFFFFFFFFu;
+        s_committed = 0;
     }
     uint32_t solved_parent = 0, solved_action = 0, err_code = 0;
     __syncthreads();
@@ -110,12 +114,8 @@ __global__ void __launch_bounds__(kBmT) k_bfs_multi(const BfsJob<W>* __restrict_
             break;
         }
         const uint32_t np = min(nodes - head, (uint32_t)kBmParents), m = 12u * np;
-        if (tid == 0) {
-            s_solved_tag = 0xFFFFFFFFu;
-            s_err_tag = ~0ull;
-            s_pb = 0xFFFFFFFFu;
-            s_committed = 0;
-        }
+        // (s_solved_tag / s_err_tag / s_pb / s_committed are reset by lane 0 BEHIND the chunk's last reads of them, in front of the
+        // barrier that ends the iteration -- a reset up here would race with the other waves' atomicMin of the expand phase)
         for (uint32_t i = tid; i < (uint32_t)kBmLds; i += kBmT) s_slot[i] = kEmpty;
         // ---- expand: candidate c = it * 1024 + tid is child (parent c / 12, action c % 12): c IS the reference's generation order
         bool probe[kBmItems];
@@ -295,6 +295,10 @@ __global__ void __launch_bounds__(kBmT) k_bfs_multi(const BfsJob<W>* __restrict_
         if (tid == 0) {
             s_nodes = nodes + s_committed;
             s_head = head + p_end + 1;
+            s_solved_tag = 0xFFFFFFFFu;  // for the next chunk (every read of this chunk's values is behind the barrier above)
+            s_err_tag = ~0ull;
+            s_pb = 0xFFFFFFFFu;
+            s_committed = 0;
             if (s_full) s_status = BFS_TABLE_FULL;
             else if (err_hit) s_status = BFS_MOVE_ERROR;
             else if (is_solved) s_status = BFS_SOLVED;

@@ -632,51 +632,73 @@ __global__ void __launch_bounds__(256) k_rank_sort(SearchDev<W> d, const uint32_
 // cost milliseconds per call -- erratically up to seconds for the 10 GB arenas of a group of searches -- and hipFree
 // synchronises the whole device, which would serialise the overlapped searches of acx_search_many.  (Round 1 kept a pool per
 // host thread; worker threads then had to return their blocks before they ended, and every acx_search_many paid the
-// allocations again.)  The pool holds at most 60 % of the device memory; acx_release_cached_memory empties it.
+// allocations again.)  Blocks are keyed by the device they live on (a process may search on several GPUs: thread ranks of the
+// sharded engine, acx_search after torch.cuda.set_device); per device the pool holds at most 60 % of the memory and stops
+// caching once less than an eighth of the device is free; acx_release_cached_memory empties it.
 struct BlockPool {
     static constexpr size_t kMaxCachedBlock = 48ull << 30;
-    size_t max_cached_total = 0;  // 60 % of the device's memory (173 GB of an MI355X's 288), set at first use: the two sweeps of
-                                  // bench.py (bfs, then greedy over the 1190 presentations) keep ~150 GB of arenas between runs
     static constexpr size_t kMaxBlocks = 8192;
+    static constexpr int kMaxDevices = 16;
+    struct Block {
+        void* p;
+        size_t bytes;
+        int dev;  // the device the block was allocated on: a block is only ever handed to a caller whose current device is that one
+    };
     std::mutex mu;
-    std::vector<std::pair<void*, size_t>> blocks;
-    size_t cached = 0;
-    void* take(size_t bytes, size_t* got) {
+    std::vector<Block> blocks;
+    size_t cached[kMaxDevices] = {};
+    size_t max_cached[kMaxDevices] = {};  // 60 % of a device's memory (173 GB of an MI355X's 288), set at first use: the two sweeps of
+                                          // bench.py (bfs, then greedy over the 1190 presentations) keep ~150 GB of arenas between runs
+    static int current_device() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+        return dev;
+    }
+    void* take(size_t bytes, size_t* got, int dev) {
         std::lock_guard<std::mutex> lock(mu);
         size_t best = blocks.size();
         for (size_t k = 0; k < blocks.size(); k++)
-            if (blocks[k].second >= bytes && blocks[k].second <= bytes + bytes / 2 + 4096 && (best == blocks.size() || blocks[k].second < blocks[best].second)) best = k;
+            if (blocks[k].dev == dev && blocks[k].bytes >= bytes && blocks[k].bytes <= bytes + bytes / 2 + 4096 &&
+                (best == blocks.size() || blocks[k].bytes < blocks[best].bytes))
+                best = k;
         if (best == blocks.size()) return nullptr;
-        void* p = blocks[best].first;
-        *got = blocks[best].second;
-        cached -= blocks[best].second;
+        void* p = blocks[best].p;
+        *got = blocks[best].bytes;
+        cached[dev] -= blocks[best].bytes;
         blocks[best] = blocks.back();
         blocks.pop_back();
         return p;
     }
-    void give(void* p, size_t bytes) {
+    void give(void* p, size_t bytes, int dev) {
         {
             std::lock_guard<std::mutex> lock(mu);
-            if (!max_cached_total) {
-                size_t free_b = 0, total_b = 0;
-                max_cached_total = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? total_b / 10 * 6 : (96ull << 30);
-            }
-            if (bytes <= kMaxCachedBlock && cached + bytes <= max_cached_total && blocks.size() < kMaxBlocks) {
-                blocks.emplace_back(p, bytes);
-                cached += bytes;
+            size_t free_b = 0, total_b = 0;
+            const bool info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;  // (of the CURRENT device: only used when that is `dev`)
+            const bool mine = current_device() == dev;
+            if (!max_cached[dev]) max_cached[dev] = info && mine ? total_b / 10 * 6 : (96ull << 30);
+            // other users of the device (torch's allocator: a PPO run after a sweep) must not starve behind this cache: once less
+            // than an eighth of the device is free, blocks go back to the driver instead of into the pool
+            const bool roomy = !info || !mine || free_b > total_b / 8;
+            if (roomy && bytes <= kMaxCachedBlock && cached[dev] + bytes <= max_cached[dev] && blocks.size() < kMaxBlocks) {
+                blocks.push_back({p, bytes, dev});
+                cached[dev] += bytes;
                 return;
             }
         }
         (void)hipFree(p);
     }
+    size_t cached_on(int dev) {
+        std::lock_guard<std::mutex> lock(mu);
+        return cached[dev];
+    }
     void trim() {
-        std::vector<std::pair<void*, size_t>> old;
+        std::vector<Block> old;
         {
             std::lock_guard<std::mutex> lock(mu);
             old.swap(blocks);
-            cached = 0;
+            for (size_t& c : cached) c = 0;
         }
-        for (auto& b : old) (void)hipFree(b.first);
+        for (auto& b : old) (void)hipFree(b.p);
     }
     // no destructor work: what the pool still holds at process exit is released with the context (calling hipFree during
     // runtime teardown can block)
@@ -686,12 +708,24 @@ inline BlockPool& block_pool() {
     return *pool;
 }
 
+// Bytes one group of searches (acx_search_many) may allocate: `want`, but never more than an eighth of what the device can
+// still give (free memory + this pool's cached blocks) -- up to seven callers run groups side by side (the seven relator
+// widths of the Miller-Schupp sweep, ac_solver/search/_common.py:run_search_groups).
+inline double group_byte_budget(double want) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return want;
+    const double avail = (double)free_b + (double)block_pool().cached_on(BlockPool::current_device());
+    return std::max(256e6, std::min(want, avail / 8.0));
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    int dev = 0;
     int alloc(size_t b) {
         const size_t want = b ? b : 1;
-        p = block_pool().take(want, &bytes);
+        dev = BlockPool::current_device();
+        p = block_pool().take(want, &bytes, dev);
         if (p) return ACX_OK;
         bytes = want;
         if (hipMalloc(&p, bytes) != hipSuccess) {
@@ -704,7 +738,7 @@ struct DevBuf {
         return ACX_OK;
     }
     ~DevBuf() {
-        if (p) block_pool().give(p, bytes);
+        if (p) block_pool().give(p, bytes, dev);
     }
 };
 

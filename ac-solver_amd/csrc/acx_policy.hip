@@ -92,6 +92,11 @@ template <int KS1> struct plan {
         for (int k = c + 1; k < C && k < c + kAhead; k++) n += 3;  // (c >= C - 1: nothing)
         return n;
     }
+    // Top of loop iteration c: chunks 0 .. min(c + kAhead, C) - 1 have been issued (chunk c + kAhead only goes out AFTER this wait
+    // and its barrier, into the slot chunk c - 1 leaves).  The running block reads the first fragments of chunk c + 1 before it
+    // ends, so chunk c + 1 must have landed: at most the loads of the chunks issued behind it may stay in flight.
+    static constexpr int issued_at_top(int c) { return c + kAhead < C ? c + kAhead : C; }
+    static constexpr int pending_at_top(int c) { return issued_at_top(c) > c + 2 ? 3 * (issued_at_top(c) - (c + 2)) : 0; }
 };
 
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
@@ -232,7 +237,8 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __
         constexpr int ccn = (c + 1) % P::CN, nm_of_next_chunk = c + 1 >= P::C ? 0 : (ccn < P::C1 ? P::F1 : 17);
         // chunk c + 1 has landed for this wave's own loads ... and, behind the barrier, for everyone's (the running block reads its
         // first fragments before it ends); chunk c - 1 is consumed, so its slot takes chunk c + kAhead
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(P::pending_after(c + 1)) : "memory");
+        static_assert(P::issued_at_top(c) - P::pending_at_top(c) / 3 >= (c + 2 < P::C ? c + 2 : P::C), "chunk c + 1 must have landed behind this wait");
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(P::pending_at_top(c)) : "memory");
 #ifdef ACX_POLICY_STAMP  // diagnostic build: shader-clock stamp per chunk into the (over-allocated) logprob buffer
         logprob[n_env + (blockIdx.x & 1) * 512 + wave * 64 + c] = (float)(long long)(__builtin_amdgcn_s_memtime() - t_start);  // (no branch: all lanes store the same word)
 #endif
@@ -292,7 +298,9 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __
             const int a = 8 * (int)h + k;
             const float lga = h ? lg[8 + k] : lg[k];
             const uint32_t bits = fmix32(fmix32(((uint32_t)env * 16u + (uint32_t)a) ^ s_lo) + s_hi + (uint32_t)(env >> 28));
-            const float u = ((float)(bits >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+            // 23 random bits: (k + 0.5) * 2^-23 is exact in f32 for every k < 2^23, so u stays strictly inside (0, 1)
+            // (with 24 bits k + 0.5 rounds to 2^24 for the largest k: u = 1, an infinite Gumbel score, once per 2^24 draws)
+            const float u = ((float)(bits >> 9) + 0.5f) * (1.0f / 8388608.0f);
             const float lp = lga - lse;
             const float score = lp - __logf(-__logf(u));
             if (a < n_actions && score > best_score) {

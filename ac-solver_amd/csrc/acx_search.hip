@@ -39,7 +39,7 @@ static thread_local uint64_t t_last_digest = 0;
 // acx_search_minima_enable(1): every search records the total lengths at which the reference's verbose mode prints "New
 // minimal length found" (breadth_first.py:79-82, greedy.py:85-89): each child, in generation order, that is shorter than
 // everything generated before it, up to the child that ends the search.  acx_search_last_minima returns the sequence.
-static std::atomic<int> g_minima_on{0};
+static thread_local int t_minima_on = 0;  // per calling thread: a verbose search must not slow down or lose the lines of searches on other threads
 static thread_local std::vector<int32_t> t_last_minima;
 constexpr int kFirstLen = 128;  // total lengths are <= 2 * 61
 
@@ -186,7 +186,7 @@ template <typename W> struct Searcher {
         d.err_tag = (unsigned long long*)(sc + 16);  // reset with the other batch scalars
         d.err = (uint32_t*)(sc + 24);
         d.min_len = (uint32_t*)(sc + 28);
-        if (g_minima_on.load()) {
+        if (t_minima_on) {
             if (arena_first.alloc(kFirstLen * 8)) return ACX_E_NOMEM;
             d.first_len = (unsigned long long*)arena_first.p;
         }
@@ -723,7 +723,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
     *solved = 0;
     *path_n = 0;
     // (verbose searches run greedy batch by batch: the per-improvement lengths need each batch's decision on the host)
-    if (greedy && !getenv("ACX_GREEDY_HOST") && !g_minima_on.load()) {  // device-resident priority frontier; falls through when it hits a capacity
+    if (greedy && !getenv("ACX_GREEDY_HOST") && !t_minima_on) {  // device-resident priority frontier; falls through when it hits a capacity
         bool handled = false;
         const int grc = run_greedy_device<W>(root, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, &handled);
         if (grc != ACX_OK || handled) return grc;
@@ -994,7 +994,7 @@ extern "C" int acx_search(int kind, const int8_t* h_presentation, int L, int64_t
 }
 
 extern "C" int acx_search_minima_enable(int on) {
-    g_minima_on.store(on ? 1 : 0);
+    t_minima_on = on ? 1 : 0;
     return ACX_OK;
 }
 
@@ -1035,7 +1035,7 @@ extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t 
         // greedy: groups of searches in ONE launch of the persistent frontier kernel, one workgroup per search
         if (max_nodes < 0) max_nodes = 0;
         const double per_search = 160.0 * (double)std::max<int64_t>(max_nodes, 1) + 96e6;  // bytes, generous (run_greedy_group computes the exact figure)
-        const int64_t group = (int64_t)std::max(1.0, std::min(256.0, 12e9 / per_search));
+        const int64_t group = (int64_t)std::max(1.0, std::min(256.0, group_byte_budget(12e9) / per_search));
         std::vector<uint8_t> rerun((size_t)n, 0);
         for (int64_t k0 = 0; k0 < n; k0 += group) {
             const int64_t m = std::min<int64_t>(group, n - k0);
@@ -1056,11 +1056,11 @@ extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t 
             if (rc_out[k] != ACX_OK && rc_out[k] != ACX_E_CAPACITY) return fail(ACX_E_ROWERR, "acx_search_many: search %lld failed with code %d", (long long)k, rc_out[k]);
         return ACX_OK;
     }
-    if (kind == ACX_SEARCH_BFS && n > 1 && L >= 1 && L <= 61 && !getenv("ACX_BFS_MANY_STREAMS") && !g_minima_on.load() && !g_digest_on.load()) {
+    if (kind == ACX_SEARCH_BFS && n > 1 && L >= 1 && L <= 61 && !getenv("ACX_BFS_MANY_STREAMS") && !t_minima_on && !g_digest_on.load()) {
         // bfs: groups of searches in ONE launch, one persistent workgroup per search (acx_bfs_multi.h)
         if (max_nodes < 0) max_nodes = 0;
         const double per_search = (L <= 29 ? 26.0 : 42.0) * (double)std::max<int64_t>(max_nodes, 1) + 16.0 * 2.0 * (double)std::max<int64_t>(max_nodes, 1) + 4e6;
-        const int64_t group = (int64_t)std::max(1.0, std::min(4096.0, 48e9 / per_search));
+        const int64_t group = (int64_t)std::max(1.0, std::min(4096.0, group_byte_budget(48e9) / per_search));
         for (int64_t k0 = 0; k0 < n; k0 += group) {
             const int64_t m = std::min<int64_t>(group, n - k0);
             int32_t* pa = path_action ? path_action + k0 * path_cap : nullptr;

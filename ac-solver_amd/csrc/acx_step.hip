@@ -585,6 +585,21 @@ __global__ void k_env_gather(EnvDev<W> e, const int64_t* __restrict__ idx, int64
 // =================================================================== C ABI ======================
 using namespace acx;
 
+// pinned host staging of the host-buffer step, one grow-only buffer per host thread
+static uint8_t* step_staging(size_t bytes) {
+    static thread_local uint8_t* buf = nullptr;
+    static thread_local size_t cap = 0;
+    if (bytes <= cap) return buf;
+    if (buf) (void)hipHostFree(buf);
+    buf = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    if (hipHostMalloc((void**)&buf, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    cap = want;
+    return buf;
+}
+
+
 struct acx_env {
     int64_t n;
     int L, H, flags, device;
@@ -656,16 +671,20 @@ int acx_move_batch(const int8_t* h_in, const uint8_t* h_action, int64_t n, int L
     int rc = s.ensure(total);
     if (rc) return rc;
     uint8_t* b = (uint8_t*)s.p;
-    ACX_HIP_TRY(hipMemcpy(b + o_in, h_in, n * row, hipMemcpyHostToDevice));
-    if (h_action) ACX_HIP_TRY(hipMemcpy(b + o_act, h_action, n, hipMemcpyHostToDevice));
+    uint8_t* h = step_staging(total);  // pinned mirror of the block: one upload, one read-back, one synchronisation
+    if (!h) return fail(ACX_E_NOMEM, "acx_move_batch: hipHostMalloc(%zu) failed", total);
+    memcpy(h + o_in, h_in, (size_t)n * row);
+    if (h_action) memcpy(h + o_act, h_action, (size_t)n);
+    ACX_HIP_TRY(hipMemcpyAsync(b + o_in, h + o_in, h_action ? o_act + (size_t)n : (size_t)n * row, hipMemcpyHostToDevice, nullptr));
     rc = acx_move_batch_device((const int8_t*)(b + o_in), h_action ? b + o_act : nullptr, ACX_U8, n, L, flags, (int8_t*)(b + o_out),
                                (int32_t*)(b + o_len), b + o_err, h_fit ? (int32_t*)(b + o_fit) : nullptr, nullptr);
     if (rc) return rc;
-    ACX_HIP_TRY(hipDeviceSynchronize());
-    ACX_HIP_TRY(hipMemcpy(h_out, b + o_out, n * row, hipMemcpyDeviceToHost));
-    ACX_HIP_TRY(hipMemcpy(h_len, b + o_len, n * 8, hipMemcpyDeviceToHost));
-    ACX_HIP_TRY(hipMemcpy(h_err, b + o_err, n, hipMemcpyDeviceToHost));
-    if (h_fit) ACX_HIP_TRY(hipMemcpy(h_fit, b + o_fit, n * 4, hipMemcpyDeviceToHost));
+    ACX_HIP_TRY(hipMemcpyAsync(h + o_out, b + o_out, (h_fit ? total : o_fit) - o_out, hipMemcpyDeviceToHost, nullptr));
+    ACX_HIP_TRY(hipStreamSynchronize(nullptr));
+    memcpy(h_out, h + o_out, (size_t)n * row);
+    memcpy(h_len, h + o_len, (size_t)n * 8);
+    memcpy(h_err, h + o_err, (size_t)n);
+    if (h_fit) memcpy(h_fit, h + o_fit, (size_t)n * 4);
     return ACX_OK;
 }
 
@@ -684,17 +703,21 @@ int acx_simplify_relators(const int8_t* h_in, int64_t n, int width, int cyclical
     int rc = s.ensure(total);
     if (rc) return rc;
     uint8_t* b = (uint8_t*)s.p;
-    ACX_HIP_TRY(hipMemcpy(b + o_in, h_in, n * width, hipMemcpyHostToDevice));
+    uint8_t* h = step_staging(total);
+    if (!h) return fail(ACX_E_NOMEM, "acx_simplify_relators: hipHostMalloc(%zu) failed", total);
+    memcpy(h + o_in, h_in, (size_t)n * width);
+    ACX_HIP_TRY(hipMemcpyAsync(b + o_in, h + o_in, (size_t)n * width, hipMemcpyHostToDevice, nullptr));
     const unsigned grid = (unsigned)ceil_div<int64_t>(n, 64);
     if (width <= 64)
         hipLaunchKernelGGL(k_simplify_rows<64>, dim3(grid), dim3(64), 0, nullptr, (const int8_t*)(b + o_in), n, width, cyclical, (int8_t*)(b + o_out), (int32_t*)(b + o_len), b + o_err);
     else
         hipLaunchKernelGGL(k_simplify_rows<256>, dim3(grid), dim3(64), 0, nullptr, (const int8_t*)(b + o_in), n, width, cyclical, (int8_t*)(b + o_out), (int32_t*)(b + o_len), b + o_err);
     ACX_HIP_TRY(hipGetLastError());
-    ACX_HIP_TRY(hipDeviceSynchronize());
-    ACX_HIP_TRY(hipMemcpy(h_out, b + o_out, n * width, hipMemcpyDeviceToHost));
-    ACX_HIP_TRY(hipMemcpy(h_len, b + o_len, n * 8, hipMemcpyDeviceToHost));
-    ACX_HIP_TRY(hipMemcpy(h_err, b + o_err, n, hipMemcpyDeviceToHost));
+    ACX_HIP_TRY(hipMemcpyAsync(h + o_out, b + o_out, total - o_out, hipMemcpyDeviceToHost, nullptr));
+    ACX_HIP_TRY(hipStreamSynchronize(nullptr));
+    memcpy(h_out, h + o_out, (size_t)n * width);
+    memcpy(h_len, h + o_len, (size_t)n * 8);
+    memcpy(h_err, h + o_err, (size_t)n);
     return ACX_OK;
 }
 
@@ -924,27 +947,43 @@ int acx_env_step(acx_env* e, const void* d_actions, int action_dtype, void* d_ob
 }
 
 int acx_env_step_host(acx_env* e, const int64_t* h_actions, int8_t* h_obs, float* h_reward, uint8_t* h_done, uint8_t* h_trunc,
-                      int8_t* h_final_obs, int autoreset) {
+                      int8_t* h_final_obs, int autoreset, uint8_t* h_err, void* stream) {
     if (!e || !h_actions) return fail(ACX_E_INVAL, "acx_env_step_host: env and actions required");
+    hipStream_t st = (hipStream_t)stream;
     const int64_t n = e->n;
     const size_t row = (size_t)2 * e->L;
     auto up = [&](size_t b) { return (b + 255) / 256 * 256; };
+    // one device block and its pinned mirror: [actions | obs | final obs | reward | done | truncated | err] -- ONE upload, the
+    // kernel(s), ONE read-back of everything behind the actions, ONE synchronisation (round 2: an upload, a device-wide
+    // synchronisation, five read-backs and a second call for the error bytes)
     const size_t o_act = 0, o_obs = up(n * 8), o_fin = o_obs + up(n * row), o_rew = o_fin + up(n * row), o_done = o_rew + up(n * 4),
-                 o_trunc = o_done + up(n), total = o_trunc + up(n);
+                 o_trunc = o_done + up(n), o_err = o_trunc + up(n), total = o_err + up(n);
     Scratch& s = scratch(2);
     int rc = s.ensure(total);
     if (rc) return rc;
     uint8_t* b = (uint8_t*)s.p;
-    ACX_HIP_TRY(hipMemcpy(b + o_act, h_actions, n * 8, hipMemcpyHostToDevice));
+    uint8_t* h = step_staging(total);
+    if (!h) return fail(ACX_E_NOMEM, "acx_env_step_host: hipHostMalloc(%zu) failed", total);
+    memcpy(h + o_act, h_actions, (size_t)n * 8);
+    ACX_HIP_TRY(hipMemcpyAsync(b + o_act, h + o_act, (size_t)n * 8, hipMemcpyHostToDevice, st));
     rc = acx_env_step(e, b + o_act, ACX_I64, b + o_obs, ACX_I8, (float*)(b + o_rew), 0.f, 0.f, b + o_done, b + o_trunc,
-                      h_final_obs ? b + o_fin : nullptr, autoreset, nullptr);
+                      h_final_obs ? b + o_fin : nullptr, autoreset, st);
     if (rc) return rc;
-    ACX_HIP_TRY(hipDeviceSynchronize());
-    if (h_obs) ACX_HIP_TRY(hipMemcpy(h_obs, b + o_obs, n * row, hipMemcpyDeviceToHost));
-    if (h_final_obs) ACX_HIP_TRY(hipMemcpy(h_final_obs, b + o_fin, n * row, hipMemcpyDeviceToHost));
-    if (h_reward) ACX_HIP_TRY(hipMemcpy(h_reward, b + o_rew, n * 4, hipMemcpyDeviceToHost));
-    if (h_done) ACX_HIP_TRY(hipMemcpy(h_done, b + o_done, n, hipMemcpyDeviceToHost));
-    if (h_trunc) ACX_HIP_TRY(hipMemcpy(h_trunc, b + o_trunc, n, hipMemcpyDeviceToHost));
+    if (h_err) {  // the sticky error bytes of this step, cleared on the way (acx_env_get_errors with clear = 1)
+        const unsigned grid = (unsigned)ceil_div<int64_t>(n, 256);
+        ACX_ENV_DISPATCH(e, hipLaunchKernelGGL(k_env_gather<W>, dim3(grid), dim3(256), 0, st, dev, (const int64_t*)nullptr, n, (int8_t*)nullptr,
+                                                            (int32_t*)nullptr, (int32_t*)nullptr, b + o_err, 1));
+        ACX_HIP_TRY(hipGetLastError());
+    }
+    const size_t first = h_obs || h_final_obs ? o_obs : o_rew;
+    ACX_HIP_TRY(hipMemcpyAsync(h + first, b + first, total - first, hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
+    if (h_obs) memcpy(h_obs, h + o_obs, (size_t)n * row);
+    if (h_final_obs) memcpy(h_final_obs, h + o_fin, (size_t)n * row);
+    if (h_reward) memcpy(h_reward, h + o_rew, (size_t)n * 4);
+    if (h_done) memcpy(h_done, h + o_done, (size_t)n);
+    if (h_trunc) memcpy(h_trunc, h + o_trunc, (size_t)n);
+    if (h_err) memcpy(h_err, h + o_err, (size_t)n);
     return ACX_OK;
 }
 

@@ -327,6 +327,33 @@ def extra_env_numbers(dev, pool):
     from ac_solver.envs.vec_env import ACVecEnv
 
     out = {}
+    # the reference's own single-call surface, unchanged user code: ACEnv.step on ONE environment and ACMove on one presentation
+    # (reference in the build container, BASELINE.md: 105 us per step, 34 us per ACMove; the intended route here is ACVecEnv)
+    try:
+        from ac_solver.envs.ac_env import ACEnv, ACEnvConfig
+        from ac_solver.envs.ac_moves import ACMove
+
+        e1 = ACEnv(ACEnvConfig(initial_state=pool[600], horizon_length=HORIZON))
+        acts = np.random.default_rng(0).integers(0, 12, size=400)
+        for a in acts[:50]:
+            e1.step(int(a))
+        t0 = time.perf_counter()
+        for a in acts[50:]:
+            e1.step(int(a))
+        step_us = (time.perf_counter() - t0) / 350 * 1e6
+        st, ln = pool[600].copy(), None
+        for a in acts[:50]:
+            st, ln = ACMove(int(a), st, L, ln)
+        t0 = time.perf_counter()
+        for a in acts[50:]:
+            st, ln = ACMove(int(a), st, L, ln)
+        move_us = (time.perf_counter() - t0) / 350 * 1e6
+        out["single_call_surface"] = {"single_env_step_us": step_us, "acmove_call_us": move_us, "reference_step_us": 105.0, "reference_acmove_us": 34.0,
+                                      "note": "one environment per call: an upload, one launch, one read-back, one synchronisation (acx_env_step_host / "
+                                              "acx_move_batch); reference figures measured in the build container (BASELINE.md)"}
+        del e1
+    except Exception as e:  # noqa: BLE001
+        out["single_call_surface"] = {"error": f"{type(e).__name__}: {e}"}
     n_big, k_big = 1 << 22, 20
     env = ACVecEnv(pool[np.arange(n_big) % len(pool)], horizon_length=HORIZON, record_actions=False, final_info=False)
     tape = torch.randint(0, 12, (k_big, n_big), dtype=torch.uint8, device=dev)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACX_VERSION 201
+#define ACX_VERSION 202
 
 /* return codes */
 #define ACX_OK 0
@@ -108,9 +108,11 @@ int acx_env_step(acx_env *env, const void *d_actions, int action_dtype, void *d_
                  float clip_lo, float clip_hi, uint8_t *d_done, uint8_t *d_trunc, void *d_final_obs, int autoreset,
                  void *stream);
 /* Same step with host buffers (single-env Python surface): h_actions [n] int64, h_obs / h_final_obs
- * [n,2L] int8, h_reward [n] f32 (unclipped), h_done / h_trunc [n] u8.  Synchronous. */
+ * [n,2L] int8, h_reward [n] f32 (unclipped), h_done / h_trunc [n] u8, h_err [n] (nullable) = the per-env error bytes of
+ * this step (what acx_env_get_errors(clear = 1) would return next).  One upload, the kernel, one read-back and one
+ * synchronisation of `stream`. */
 int acx_env_step_host(acx_env *env, const int64_t *h_actions, int8_t *h_obs, float *h_reward, uint8_t *h_done,
-                      uint8_t *h_trunc, int8_t *h_final_obs, int autoreset);
+                      uint8_t *h_trunc, int8_t *h_final_obs, int autoreset, uint8_t *h_err, void *stream);
 /* T fused steps from an action tape d_tape [T,n] u8 with the state resident in registers;
  * d_reward / d_done / d_trunc are [T,n] (nullable).  Same semantics as T calls of acx_env_step. */
 int acx_env_rollout(acx_env *env, const uint8_t *d_tape, int64_t T, float *d_reward, float clip_lo, float clip_hi,
@@ -149,7 +151,8 @@ int acx_search(int kind, const int8_t *h_presentation, int L, int64_t max_nodes,
                int32_t *path_action, int32_t *path_len, int64_t path_cap, int64_t *path_n, acx_search_stats *stats);
 
 /* verbose=True of bfs / greedy_search (breadth_first.py:79-82, greedy.py:85-89: "New minimal length found: l" whenever a child
- * is shorter than everything generated before it): with the switch on, acx_search records those lengths, in the order the
+ * is shorter than everything generated before it): with the switch on (it is per calling thread: searches running on other
+ * threads are not affected), acx_search records those lengths, in the order the
  * reference prints them and up to the child that ends the search; acx_search_last_minima returns the calling thread's last
  * sequence (*n = its length, the first min(*n, cap) entries are written).  greedy_search then runs batch by batch on the
  * host-driven path (same result, slower). */

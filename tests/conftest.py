@@ -90,3 +90,15 @@ def ms_pool_generator_order(ms_pool_json):
         for w in range(1, 8):
             pool += d[str(w)]
     return pool
+
+
+def ms_pool_rows(pool, L):
+    """the Miller-Schupp pool re-embedded at max_relator_length L: [len(pool), 2L] int8 (copy the non-zero
+    prefix of each half)"""
+    rows = np.zeros((len(pool), 2 * L), np.int8)
+    for k, p in enumerate(pool):
+        half = len(p) // 2
+        for h in (0, 1):
+            w = [x for x in p[h * half:(h + 1) * half] if x != 0]
+            rows[k, h * L:h * L + len(w)] = w
+    return rows

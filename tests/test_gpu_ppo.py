@@ -124,3 +124,50 @@ def test_train_ppo_runs_baseline_config5_shape(tmp_path, monkeypatch):
     stats = train_ppo(["--num-envs", "131072", "--num-steps", "8", "--total-timesteps", str(2 * 8 * 131072), "--tile-initial-states", "--fused-policy",
                        "--horizon-length", "200", "--num-minibatches", "4"])
     assert stats["charts/global_step"] == 2 * 8 * 131072 and np.isfinite(stats["losses/value_loss"]) and np.isfinite(stats["losses/policy_loss"])
+    # the update's importance ratio starts at 1 although the rollout sampled through the bf16 kernel: the behaviour
+    # log-probabilities are recomputed with the f32 modules before the first minibatch (reference: training.py:283-291)
+    assert stats["debug/ratio0_maxdev"] < 1e-3
+
+
+def test_fused_policy_rollout_replays_on_the_oracle_and_starts_at_ratio_one(golden_json):
+    """--fused-policy at a small shape with the rollout tensors logged: obs[t + 1] is the oracle's ACEnv.step of (obs[t],
+    actions[t]) (or a curriculum restart), rewards are the clipped reference rewards, and the first minibatch's ratio is 1."""
+    import torch
+    from torch.optim import Adam
+
+    from ac_solver.agents.ppo_agent import Agent
+    from ac_solver.agents.training import ppo_training_loop
+    from ac_solver.envs.vec_env import ACVecEnv
+    from oracle import ac_oracle as O
+
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    L, N, T, H = 18, 256, 24, 12
+    initial_states = [list(p) for p in pool[:340]]  # n = 1, 2: max_relator_length 18
+    args = _args(num_envs=N, num_steps=T, total_timesteps=N * T * 2, horizon_length=H, update_epochs=1, seed=4, num_minibatches=2)
+    args.fused_policy = True
+    device = torch.device("cuda", 0)
+    torch.manual_seed(args.seed)
+    envs = ACVecEnv(np.asarray(initial_states[:N], np.int8), horizon_length=H, obs_dtype="int8", clip_rewards=(args.min_rew, args.max_rew),
+                    record_actions=True, final_info=False, device=device)
+    agent = Agent(envs, args.nodes_counts).to(device)
+    opt = Adam(agent.parameters(), lr=args.learning_rate, eps=args.epsilon)
+    rec = {"solved": set(), "unsolved": set(range(len(initial_states)))}
+    log = []
+    stats = ppo_training_loop(envs, args, device, opt, agent, list(range(N)), rec, {}, set(range(N)), initial_states, progress=False, rollout_log=log)
+    assert stats["debug/ratio0_maxdev"] < 1e-3 and len(log) == 2
+    max_reward = H * L * 2
+    state = np.asarray(initial_states[:N], np.int8).copy()
+    count = np.zeros(N, np.int32)
+    for u, roll in enumerate(log):
+        obs = roll["obs"].astype(np.int8)
+        assert np.array_equal(obs[0], state), u
+        events = {(t, i): s for t, i, s in roll["events"]}
+        for t in range(T):
+            r, d, tr, err = O.env_rollout(state, count, H, roll["actions"][t].astype(np.uint8)[None])
+            assert not err.any()
+            want_r = np.clip(r[0].astype(np.float32), args.min_rew, args.max_rew)
+            assert np.array_equal(roll["rewards"][t], want_r) and np.array_equal(roll["term"][t + 1].astype(np.uint8), d[0]), (u, t)
+            for i in np.flatnonzero(d[0] | tr[0]):
+                state[i], count[i] = np.asarray(initial_states[events[(t, int(i))]], np.int8), 0
+            assert set(i for (tt, i) in events if tt == t) == set(np.flatnonzero(d[0] | tr[0]).tolist())
+            assert np.array_equal(obs[t + 1], state), (u, t)

@@ -15,7 +15,7 @@ act = np.random.default_rng(0).integers(0, 12, size=(T, N)).astype(np.int64)
 obs = np.empty((N, 2 * L), np.int8); rew = np.empty(N, np.float32); done = np.empty(N, np.uint8); trunc = np.empty(N, np.uint8)
 p = _acx.ptr
 def step(t):
-    _acx.check(_acx.lib.acx_env_step_host(env._h.ptr, p(act[t], C.c_int64), p(obs, C.c_int8), p(rew, C.c_float), p(done, C.c_uint8), p(trunc, C.c_uint8), None, 1))
+    _acx.check(_acx.lib.acx_env_step_host(env._h.ptr, p(act[t], C.c_int64), p(obs, C.c_int8), p(rew, C.c_float), p(done, C.c_uint8), p(trunc, C.c_uint8), None, 1, None, None))
 step(0)
 t0 = time.perf_counter()
 for t in range(1, T):
