@@ -92,12 +92,20 @@ SIGNATURES = {
     "acx_search_many": (C.c_int, [C.c_int, _i8p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, _i32p, _i32p, _i32p, C.c_int64, _i64p,
                                C.POINTER(SearchStats), _i32p]),
     "acx_shard_key_words": (C.c_int, [C.c_int]),
-    "acx_shard_create": (_vp, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int]),
-    "acx_shard_seed": (C.c_int, [_vp, _i64p, _vp]),
-    "acx_shard_level_begin": (C.c_int, [_vp, _i64p]),
-    "acx_shard_find": (C.c_int, [_vp, C.c_int64, _i64p, _vp]),
+    "acx_shard_layout": (C.c_int, [C.c_int64, C.c_int, C.c_int, _i64p, _i64p, _i64p]),
+    "acx_shard_create": (_vp, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "acx_shard_destroy": (None, [_vp]),
+    "acx_shard_attach": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
     "acx_shard_root_record": (C.c_int, [_vp, _i8p, _i64p]),
+    "acx_shard_seed": (C.c_int, [_vp, _i64p, _vp]),
+    "acx_shard_chunk_expand": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, _i64p, _i64p, _vp]),
+    "acx_shard_chunk_insert": (C.c_int, [_vp, _vp]),
+    "acx_shard_chunk_commit": (C.c_int, [_vp, C.c_int64, _vp]),
+    "acx_shard_ctl_snapshot": (C.c_int, [_vp, C.c_int, _vp]),
+    "acx_shard_ctl_wait": (C.c_int, [_vp, C.c_int, _i64p]),
+    "acx_shard_fail": (C.c_int, [_vp, _vp]),
+    "acx_shard_find": (C.c_int, [_vp, C.c_int64, _i64p, _vp]),
+    "acx_shard_node_info": (C.c_int, [_vp, C.c_int64, _i64p]),
     "acx_release_cached_memory": (C.c_int, []),
     "acx_policy_sample": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _vp, _vp, C.c_int, C.c_uint64, _vp, _vp, _vp, _vp]),
     "acx_policy_packed_bytes": (C.c_int64, [C.c_int]),
@@ -107,12 +115,6 @@ SIGNATURES = {
     "acx_search_last_digest": (C.c_int, [C.POINTER(C.c_uint64)]),
     "acx_simplex_graph": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, _i64p, _u8p, _i64p, C.POINTER(C.c_uint32), _u8p]),
     "acx_ball_sizes": (C.c_int, [_i8p, C.c_int64, C.c_int, C.c_int, C.c_int, _i64p, C.POINTER(C.c_int32)]),
-    "acx_shard_expand_routed": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp]),
-    "acx_shard_insert": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]),
-    "acx_shard_commit": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, _vp]),
-    "acx_shard_node_info": (C.c_int, [_vp, C.c_int64, _i64p]),
-    "acx_shard_node_count": (C.c_int64, [_vp]),
-    "acx_shard_status": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "acx_search": (C.c_int, [C.c_int, _i8p, C.c_int, C.c_int64, C.c_int, _i32p, _i32p, _i32p, C.c_int64, _i64p, C.POINTER(SearchStats)]),
 }
 for _name, (_res, _args) in SIGNATURES.items():

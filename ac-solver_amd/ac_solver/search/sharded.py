@@ -7,7 +7,8 @@ global frontier positions; for each chunk every rank
   1. expands the frontier nodes it owns (HIP kernel, 12 children per node; a child's tag
      `12 * global_parent_position + action` is the order in which the reference generates it) and writes each
      child record straight into the send region of the owner of the child's key,
-  2. ONE all-to-all (RCCL over xGMI),
+  2. ONE all-to-all with equal splits (RCCL over xGMI): every region starts with a small header -- the number of
+     records in it and the sender's success / error / failure words -- so the exchange needs no count round trip,
   3. deduplicates what it received against its slice of the visited set, minimum tag wins (HIP), and sets bit a of
      a 12-bit mask of parent p for every child (p, a) that is a new state it owns,
   4. all-reduces (sum) those masks -- 4 bytes per PARENT -- so that every rank derives the same global FIFO
@@ -15,13 +16,19 @@ global frontier positions; for each chunk every rank
      the same budget decision ("first parent after which len(tree_nodes) >= max_nodes", breadth_first.py:91-95)
      and the same success decision (smallest tag of a length-2 child, :84-85); no rank ever holds the tags of the
      other ranks' new states,
-  5. turns its new states into nodes, numbered through the masks (no sort); they are its slice of the next level.
-Per chunk the host reads back the send counts and ONE pack of decision scalars.
+  5. takes those decisions ON THE DEVICE and turns its new states into nodes, numbered through the masks (no
+     sort); they are its slice of the next level.
 
-The per-rank work goes through an *engine* (the C ABI `acx_shard_*` of libacx in production; the CPU
-tests plug in a NumPy engine built on the oracle) and the exchange through a *comm* (torch.distributed:
-backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests; an in-process thread communicator lets one GPU
-play several ranks in the GPU tests).
+Round 3: nothing is read back inside a chunk.  The host enqueues chunk after chunk and looks at a snapshot of the
+engine's control block `LAG` chunks late; when the status word has left 0 (solved / budget / error / a failed rank)
+the chunks that were already enqueued are no-ops on the device -- their collectives still pair up, because every rank
+sees the same status at the same chunk -- and the loop ends.  One synchronisation per LEVEL remains (the size of the
+next level).
+
+The per-rank work goes through an *engine* (the C ABI `acx_shard_*` of libacx in production; the CPU tests plug in a
+NumPy engine built on the oracle, tests/shard_helpers.py) and the exchange through a *comm* (torch.distributed:
+backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests; an in-process thread communicator lets one GPU play several
+ranks in the GPU tests).
 """
 import ctypes as C
 import sys
@@ -29,8 +36,16 @@ import sys
 import numpy as np
 
 INF = 1 << 62
+HDR = 4              # int64 header words of a region: records written, success tag, error word, failure code
+LAG = 2              # chunks the host runs ahead of the control block it reads
 _FORCE_EXCHANGE = False  # tests: route through the communicator even when world == 1
 _ID_MASK = (1 << 40) - 1
+# control block words (include/acx.h: ACX_SHARD_CTL_*)
+CTL_WORDS = 16
+CTL_STATUS, CTL_NODES_GLOBAL, CTL_NEXT_COUNT, CTL_EXPANDED, CTL_SOLVED_TAG, CTL_NODES = 0, 1, 2, 3, 4, 5
+CTL_FAIL_LOCAL, CTL_MIN_LEN, CTL_FAIL_SEEN = 8, 9, 10
+ST_RUNNING, ST_SOLVED, ST_BUDGET, ST_MOVE_ERROR, ST_FAILED = 0, 1, 2, 3, 4
+_FAIL_TEXT = {1: "a send region or the record log overflowed", 2: "node capacity exceeded", 3: "visited table full", 4: "engine call failed"}
 
 
 def _torch():
@@ -41,7 +56,8 @@ def _torch():
 
 # ------------------------------------------------------------------------------------------ comms ---
 class TorchDistComm:
-    """torch.distributed communicator (nccl == RCCL on ROCm, gloo on CPU)."""
+    """torch.distributed communicator (nccl == RCCL on ROCm, gloo on CPU).  Both collectives of a chunk are enqueued on the
+    current stream and need no host synchronisation (RCCL); gloo (CPU tensors) blocks, which is what the CPU tests want."""
 
     def __init__(self, device, group=None):
         import torch.distributed as dist
@@ -49,66 +65,51 @@ class TorchDistComm:
         self.dist, self.group, self.device = dist, group, device
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.stats = {"all_to_all_calls": 0, "all_to_all_bytes": 0, "all_reduce_calls": 0, "all_reduce_bytes": 0}
 
-    def all_to_all_regions(self, regions):
-        """regions[d]: the rows [m_d, C] int64 for rank d (views of the engine's send buffer) -> the rows received, grouped by
-        source, in one tensor.  RCCL takes the regions as they lie (grouped send / recv, no staging copy); gloo (CPU tests) gets
-        one contiguous buffer with split sizes."""
-        torch = _torch()
-        counts = [int(r.shape[0]) for r in regions]
-        c_send = torch.tensor(counts, dtype=torch.int64, device=self.device)
-        c_recv = torch.empty_like(c_send)
-        self.dist.all_to_all_single(c_recv, c_send, group=self.group)
-        recv_counts = c_recv.tolist()
-        cols = regions[0].shape[1]
-        recv = torch.empty((sum(recv_counts), cols), dtype=regions[0].dtype, device=self.device)
-        if self.dist.get_backend(self.group) == "nccl":
-            offs = np.concatenate([[0], np.cumsum(recv_counts)])
-            self.dist.all_to_all([recv[offs[k]:offs[k + 1]] for k in range(self.world)], [r.contiguous() for r in regions], group=self.group)
-        else:
-            self.dist.all_to_all_single(recv, torch.cat(regions).contiguous(), output_split_sizes=recv_counts, input_split_sizes=counts, group=self.group)
-        return recv
-
-    def all_gather_var(self, t):
-        """1-D int64 tensors of different lengths -> list of per-rank tensors"""
-        torch = _torch()
-        n = torch.tensor([t.numel()], dtype=torch.int64, device=self.device)
-        sizes = [torch.empty_like(n) for _ in range(self.world)]
-        self.dist.all_gather(sizes, n, group=self.group)
-        sizes = [int(s.item()) for s in sizes]
-        cap = max(max(sizes), 1)
-        pad = torch.zeros(cap, dtype=t.dtype, device=self.device)
-        pad[: t.numel()] = t
-        out = [torch.empty_like(pad) for _ in range(self.world)]
-        self.dist.all_gather(out, pad, group=self.group)
-        return [o[:s] for o, s in zip(out, sizes)]
+    def all_to_all_single(self, recv, send):
+        """equal splits: rank d receives send[d * k : (d + 1) * k] of every rank, k = numel / world"""
+        assert recv.numel() == send.numel() and send.numel() % self.world == 0
+        self.dist.all_to_all_single(recv, send, group=self.group)
+        self.stats["all_to_all_calls"] += 1
+        self.stats["all_to_all_bytes"] += send.numel() * send.element_size()
 
     def all_reduce(self, t, op):
         ops = {"min": self.dist.ReduceOp.MIN, "max": self.dist.ReduceOp.MAX, "sum": self.dist.ReduceOp.SUM}
         self.dist.all_reduce(t, op=ops[op], group=self.group)
+        self.stats["all_reduce_calls"] += 1
+        self.stats["all_reduce_bytes"] += t.numel() * t.element_size()
         return t
 
 
 class SingleComm:
-    """world == 1: no exchange at all."""
+    """world == 1: no exchange at all (the engine expands straight into its receive area)."""
 
     rank, world = 0, 1
 
-    def all_to_all_regions(self, regions):
-        return regions[0]
+    def __init__(self):
+        self.stats = {}
 
-    def all_gather_var(self, t):
-        return [t]
+    def all_to_all_single(self, recv, send):
+        if recv.data_ptr() != send.data_ptr():
+            recv.copy_(send)
 
     def all_reduce(self, t, op):
         return t
 
 
 # ---------------------------------------------------------------------------------------- engines ---
-class HipShardEngine:
-    """Per-rank frontier slice on one GPU: thin wrapper over the acx_shard_* C ABI (include/acx.h)."""
+def chunk_words(lib_layout, n_par, world, KW):
+    S, subcap, rw = lib_layout(n_par, world, KW)
+    return S * world * rw
 
-    def __init__(self, L, cyclical, node_cap, batch_cap, chunk_parents, rank, world, device=None):
+
+class HipShardEngine:
+    """Per-rank frontier slice on one GPU: thin wrapper over the acx_shard_* C ABI (include/acx.h).  The record log, the
+    send buffer and the mask buffer are torch tensors (torch.distributed moves them); the log grows by doubling when the
+    host-side cursor says the next chunk would not fit."""
+
+    def __init__(self, L, cyclical, node_cap, chunk_parents, rank, world, est_parents, device=None):
         from ac_solver import _acx
 
         torch = _torch()
@@ -116,13 +117,21 @@ class HipShardEngine:
         _acx.require_device()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.KW = _acx.lib.acx_shard_key_words(L)
-        self.rank = rank
+        self.RW = self.KW + 1
+        self.rank, self.world = rank, world
+        self.B = int(chunk_parents)
         with torch.cuda.device(self.device):
-            self.h = _acx.lib.acx_shard_create(L, int(bool(cyclical)), int(node_cap), int(batch_cap), int(chunk_parents), rank, world)
-        if not self.h:
-            raise _acx.AcxError(f"acx_shard_create failed: {_acx.last_error()}")
-        self.batch_cap = int(batch_cap)
-        self._keep = None  # the received records stay alive until the commit that reads them
+            self.h = _acx.lib.acx_shard_create(L, int(bool(cyclical)), int(node_cap), self.B, rank, world)
+            if not self.h:
+                raise _acx.AcxError(f"acx_shard_create failed: {_acx.last_error()}")
+            full = self.layout_words(self.B)
+            words = 8 + int(full * (est_parents / self.B + 2))
+            self.log = torch.empty(words, dtype=torch.int64, device=self.device)
+            self.send = torch.empty(full, dtype=torch.int64, device=self.device) if world > 1 else None
+            self.gmask = torch.empty(self.B, dtype=torch.int32, device=self.device)
+            self._attach()
+        self._cursor = 8  # host mirror of the engine's log cursor (deterministic: it advances by the chunk's words)
+        self._ctl = np.zeros(CTL_WORDS, np.int64)
 
     def __del__(self):
         # not during interpreter shutdown: the HIP runtime may already be tearing down (a hipFree then can block forever)
@@ -132,6 +141,19 @@ class HipShardEngine:
 
     def _stream(self):
         return _torch().cuda.current_stream(self.device).cuda_stream
+
+    def _attach(self):
+        self._acx.check(self._acx.lib.acx_shard_attach(self.h, self.log.data_ptr(), self.log.numel(), self.send.data_ptr() if self.send is not None else None,
+                                                       self.send.numel() if self.send is not None else 0, self.gmask.data_ptr()), "acx_shard_attach")
+
+    def layout(self, n_par):
+        s, cap, rw = C.c_int64(), C.c_int64(), C.c_int64()
+        self._acx.check(self._acx.lib.acx_shard_layout(int(n_par), self.world, self.KW, C.byref(s), C.byref(cap), C.byref(rw)), "acx_shard_layout")
+        return s.value, cap.value, rw.value
+
+    def layout_words(self, n_par):
+        s, _, rw = self.layout(n_par)
+        return s * self.world * rw
 
     def root_record(self, presentation):
         rec = np.zeros(self.KW + 2, np.int64)
@@ -146,49 +168,43 @@ class HipShardEngine:
         rec = None if record is None else np.ascontiguousarray(record, np.int64)
         self._acx.check(self._acx.lib.acx_shard_seed(self.h, None if rec is None else self._acx.ptr(rec, C.c_int64), self._stream()), "acx_shard_seed")
 
-    def level_begin(self):
-        n = C.c_int64(0)
-        self._acx.check(self._acx.lib.acx_shard_level_begin(self.h, C.byref(n)), "acx_shard_level_begin")
-        return n.value
-
-    def expand_routed(self, c0, c1, n_local, solved, world):
-        """children of my frontier nodes with global position in [c0, c1): one region of records per destination rank (views)"""
+    def chunk_expand(self, c0, c1, level_first):
+        """-> (send, recv): 1-D int64 views of equal length for the all-to-all (the same view at world 1)"""
         torch = _torch()
-        full = 12 * min(c1 - c0, n_local)  # a region that could take every child
-        # the owner hash spreads a large chunk evenly: regions are sized for 1.25 x the even share and the expansion is simply
-        # repeated with full-size regions in the (never yet seen) case that one overflows -- the kernel only writes records
-        # and min-combines `solved`, so a second run is harmless
-        cap = full if world == 1 else min(full, int(1.25 * full / world) + 4096)
-        for attempt in (0, 1):
-            rec = torch.empty((world * cap, self.KW + 2), dtype=torch.int64, device=self.device)
-            cnt = torch.empty(world, dtype=torch.int64, device=self.device)
-            self._acx.check(self._acx.lib.acx_shard_expand_routed(self.h, int(c0), int(c1), rec.data_ptr() if cap else None, cap, cnt.data_ptr(),
-                                                                  solved.data_ptr(), self._stream()), "acx_shard_expand_routed")
-            if cap == 0:
-                return [rec[:0] for _ in range(world)]
-            counts = cnt.tolist()
-            if max(counts) <= cap:
-                return [rec[o * cap:o * cap + c] for o, c in enumerate(counts)]
-            if cap == full:
-                raise RuntimeError(f"rank {self.rank}: a send region overflowed ({max(counts)} > {cap} records)")
-            cap = full
+        need = self.layout_words(c1 - c0)
+        if self._cursor + need > self.log.numel():  # grow the log (stream ordered: the chunks in flight keep the old block alive)
+            with torch.cuda.device(self.device):
+                bigger = torch.empty(max(2 * self.log.numel(), self._cursor + 2 * need), dtype=torch.int64, device=self.device)
+                bigger[: self._cursor].copy_(self.log[: self._cursor])
+                self.log = bigger
+                self._attach()
+        off, words = C.c_int64(), C.c_int64()
+        self._acx.check(self._acx.lib.acx_shard_chunk_expand(self.h, int(c0), int(c1), int(bool(level_first)), C.byref(off), C.byref(words), self._stream()),
+                        "acx_shard_chunk_expand")
+        assert off.value == self._cursor and words.value == need, (off.value, self._cursor, words.value, need)
+        recv = self.log[off.value: off.value + need]
+        self._cursor += need
+        return (recv if self.send is None else self.send[:need]), recv
 
-    def insert(self, recv, c0, n_parents):
-        """-> int32 [n_parents]: bit a of entry p - c0 set when child (p, a) is a new state of this rank"""
-        torch = _torch()
-        n = recv.shape[0]
-        recv = recv.contiguous()
-        self._keep = recv
-        mask = torch.empty(max(n_parents, 1), dtype=torch.int32, device=self.device)
-        self._acx.check(self._acx.lib.acx_shard_insert(self.h, recv.data_ptr() if n else None, n, int(c0), int(n_parents), mask.data_ptr(), self._stream()),
-                        "acx_shard_insert")
-        return mask[:n_parents]
+    def chunk_insert(self, n_par):
+        self._acx.check(self._acx.lib.acx_shard_chunk_insert(self.h, self._stream()), "acx_shard_chunk_insert")
+        return self.gmask[:n_par]
 
-    def commit(self, cutoff, lmask, lprefix, gmask, gprefix, gpos_base, n_commit):
-        p = lambda t: t.data_ptr() if t is not None and t.numel() else None  # noqa: E731
-        self._acx.check(self._acx.lib.acx_shard_commit(self.h, int(cutoff), p(lmask), p(lprefix), p(gmask), p(gprefix), int(gpos_base), int(n_commit),
-                                                       self._stream()), "acx_shard_commit")
-        self._keep = None
+    def gmask_view(self, n_par):
+        return self.gmask[:n_par]
+
+    def chunk_commit(self, max_nodes):
+        self._acx.check(self._acx.lib.acx_shard_chunk_commit(self.h, int(max_nodes), self._stream()), "acx_shard_chunk_commit")
+
+    def ctl_snapshot(self, slot):
+        self._acx.check(self._acx.lib.acx_shard_ctl_snapshot(self.h, int(slot), self._stream()), "acx_shard_ctl_snapshot")
+
+    def ctl_wait(self, slot):
+        self._acx.check(self._acx.lib.acx_shard_ctl_wait(self.h, int(slot), self._acx.ptr(self._ctl, C.c_int64)), "acx_shard_ctl_wait")
+        return self._ctl.copy()
+
+    def fail_local(self):
+        self._acx.lib.acx_shard_fail(self.h, self._stream())
 
     def find(self, gpos):
         out = C.c_int64(-1)
@@ -200,14 +216,9 @@ class HipShardEngine:
         self._acx.check(self._acx.lib.acx_shard_node_info(self.h, int(node_id), self._acx.ptr(info, C.c_int64)), "acx_shard_node_info")
         return int(info[0]), int(info[1]), int(info[2])
 
-    def status(self):
-        err, ml = C.c_int32(0), C.c_int32(0)
-        self._acx.check(self._acx.lib.acx_shard_status(self.h, C.byref(err), C.byref(ml)), "acx_shard_status")
-        return err.value, ml.value
 
-
-def _default_engine(L, cyclical, node_cap, batch_cap, chunk_parents, rank, world):
-    return HipShardEngine(L, cyclical, node_cap, batch_cap, chunk_parents, rank, world)
+def _default_engine(L, cyclical, node_cap, chunk_parents, rank, world, est_parents):
+    return HipShardEngine(L, cyclical, node_cap, chunk_parents, rank, world, est_parents)
 
 
 # ------------------------------------------------------------------------------------- orchestrator ---
@@ -222,8 +233,10 @@ def owner_of(keys, world):
 
 
 def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False, comm=None,
-                engine_factory=None, batch_parents=1 << 18, want_stats=False):
-    """Same contract as `bfs`: returns (is_search_successful, path or None) [+ stats dict], identical on every rank."""
+                engine_factory=None, batch_parents=1 << 20, want_stats=False, log_fraction=0.5):
+    """Same contract as `bfs`: returns (is_search_successful, path or None) [+ stats dict], identical on every rank.
+    `batch_parents`: global frontier positions per chunk.  `log_fraction`: expected expanded parents / max_nodes, sizes the
+    record log (it grows by doubling if the estimate is short)."""
     from ac_solver.envs.utils import is_array_valid_presentation
 
     torch = _torch()
@@ -233,26 +246,25 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
     max_nodes = int(max_nodes_to_explore)
     comm = SingleComm() if comm is None else comm
     world, rank = comm.world, comm.rank
-    B = int(max(1, min(batch_parents, max(max_nodes, 64))))          # global parents per chunk
-    batch_cap = int(12 * B * (2.0 / world if world > 1 else 1.0)) + 4096  # records one rank may receive per chunk
-    node_cap = (max_nodes + 12 * min(B, max_nodes) if world == 1 else int(2.0 * max_nodes / world)) + 4096
-    engine = (engine_factory or _default_engine)(L, cyclically_reduce_after_moves, node_cap, batch_cap, B, rank, world)
+    B = int(max(1, min(batch_parents, max(max_nodes, 64))))  # global parents per chunk
+    node_cap = (max_nodes + 64 if world == 1 else int(2.0 * max_nodes / world)) + 4096
+    engine = (engine_factory or _default_engine)(L, cyclically_reduce_after_moves, node_cap, B, rank, world, max(1.0, log_fraction * max_nodes))
     dev = getattr(engine, "device", torch.device("cpu"))
     KW = engine.KW
     exchange = world > 1 or _FORCE_EXCHANGE
+    lag = LAG if dev.type == "cuda" else 0
 
     def i64(values):
         return torch.tensor(values, dtype=torch.int64, device=dev)
-
-    pop12 = i64([bin(v).count("1") for v in range(4096)])  # popcount of a 12-bit child mask
 
     # root: node 0 of its owner, global frontier position 0
     root = engine.root_record(p)
     owner_root = int(owner_of(torch.tensor(root[None, :KW], dtype=torch.int64), world)[0])
     engine.seed(root if rank == owner_root else None)
     F = 1
-    nodes_global = 1
-    expanded = levels = 0
+    levels = chunks = 0
+    failure = None
+    ctl = None
 
     def walk(pref, tail):
         """path of the node `pref` (rank << 40 | id) from the root + tail"""
@@ -268,96 +280,80 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
         return rev[::-1] + tail
 
     def finish(ok, path):
-        _, min_len = engine.status()
-        e = i64([0, -min_len])
+        # closing all-reduce: the smallest length any rank generated, and a failure that no later chunk could carry
+        e = i64([int(ctl[CTL_FAIL_LOCAL]) if failure is None else max(int(ctl[CTL_FAIL_LOCAL]), 4), -int(ctl[CTL_MIN_LEN])])
         comm.all_reduce(e, "max")
+        if int(e[0]):
+            raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure or _FAIL_TEXT.get(int(ctl[CTL_FAIL_LOCAL]), 'engine failure')}"
+                               if failure is not None or int(ctl[CTL_FAIL_LOCAL]) else "sharded bfs failed on another rank")
         if want_stats:
-            return ok, path, dict(nodes=nodes_global, expanded=expanded, levels=levels, min_len=2 if ok else -int(e[1]), world=world)
+            st = dict(nodes=int(ctl[CTL_NODES_GLOBAL]), expanded=int(ctl[CTL_EXPANDED]), levels=levels, chunks=chunks, min_len=2 if ok else -int(e[1]), world=world)
+            st.update({"comm_" + k: v for k, v in getattr(comm, "stats", {}).items()})
+            return ok, path, st
         return ok, path
 
     while F > 0:
         levels += 1
-        n_local = engine.level_begin()  # my slice of the level: the nodes I committed while the previous level was expanded
-        next_count = 0
-        c0 = 0
-        while c0 < F:
+        pending = []  # snapshot slots of the chunks whose control block has not been read yet
+        c0 = k = 0
+        ctl = None
+        while c0 < F and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING):
             c1 = min(F, c0 + B)
             n_par = c1 - c0
-            solved = i64([INF, INF])  # [0] smallest tag of a length-2 child, [1] smallest (tag << 8 | code) of a move the reference raises on
-            # Local failures (a capacity of this rank's engine, a HIP error) must not leave the other ranks waiting in a
-            # collective: the rank keeps taking part with empty contributions and reports through the `solved` all-reduce
-            # (-1 beats every tag), so that all ranks raise together.
-            failure = None
-            empty = [torch.empty((0, KW + 2), dtype=torch.int64, device=dev) for _ in range(world)]
-            regions = empty
+            # A failing engine call of this rank (a HIP error, an exhausted allocation) must not leave the other ranks waiting in a
+            # collective: the rank keeps taking part in the chunk's collectives with whatever its buffers hold and marks itself
+            # failed; the flag travels in the headers of its next chunk and every rank then stops at that chunk (status 4).
             try:
-                regions = engine.expand_routed(c0, c1, n_local, solved, world)
+                send, recv = engine.chunk_expand(c0, c1, c0 == 0)
             except Exception as e:  # noqa: BLE001
-                failure, regions = e, empty
-            recv = comm.all_to_all_regions(regions) if exchange else regions[0]
-            lmask = torch.zeros(n_par, dtype=torch.int32, device=dev)
-            try:
-                if failure is None:
-                    if recv.shape[0] > engine.batch_cap:
-                        raise RuntimeError(f"rank {rank}: {recv.shape[0]} records exceed the per-chunk capacity {engine.batch_cap}")
-                    lmask = engine.insert(recv, c0, n_par)   # one 12-bit mask per parent: MY new states
-            except Exception as e:  # noqa: BLE001
-                failure, lmask = e, torch.zeros(n_par, dtype=torch.int32, device=dev)
-            if failure is not None:
-                solved = i64([-1, INF])
-            # every (parent, action) child has exactly one owner, so SUM == OR
-            gmask = lmask.clone()
-            comm.all_reduce(gmask, "sum")
-            comm.all_reduce(solved, "min")
-            lpop, gpop = pop12[lmask.to(torch.int64)], pop12[gmask.to(torch.int64)]
-            lincl, gincl = torch.cumsum(lpop, 0), torch.cumsum(gpop, 0)   # new states up to and including each parent
-            # ONE read-back for every decision of the chunk: the success / error words, the number of new states, the first
-            # parent whose inclusive count reaches what is left of the budget, and the counts a cut at that parent (or at the
-            # first parent) would commit
-            need = max(max_nodes - nodes_global, 0)
-            pb = torch.clamp(torch.searchsorted(gincl, i64([need])), max=n_par - 1)
-            pack = torch.cat([solved, gincl[-1:], pb, gincl[pb], lincl[pb], lincl[-1:], gincl[:1], lincl[:1]]).tolist()
-            solved_tag, err_word, total_new, pb_rel, g_at_pb, l_at_pb, l_total, g_first, l_first = (int(v) for v in pack)
-            if solved_tag < 0:
-                raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure}" if failure is not None else "sharded bfs failed on another rank")
-
-            p_end, budget_hit = c1 - 1, False
-            commit_global, commit_local = total_new, l_total
-            if nodes_global >= max_nodes:          # only the very first parent can see this (budget <= 1)
-                p_end, budget_hit, commit_global, commit_local = c0, True, g_first, l_first
-            elif nodes_global + total_new >= max_nodes:
-                # parent of the new state that reaches the budget = first parent whose inclusive count reaches it
-                p_end, budget_hit, commit_global, commit_local = c0 + pb_rel, True, g_at_pb, l_at_pb
-            is_solved = solved_tag < INF and solved_tag // 12 <= p_end
-            if err_word < INF and (err_word >> 8) // 12 <= p_end and not (is_solved and solved_tag < (err_word >> 8)):
-                # the reference executes this move before it stops: its ACMove raises (every rank sees the same words)
-                raise AssertionError("a move emptied a relator during the search: the reference's ACMove raises here")
-            if is_solved:
-                gp = solved_tag // 12
-                mine = engine.find(gp)
-                pref = i64([(rank << 40) | mine if mine >= 0 else -1])
-                comm.all_reduce(pref, "max")
-                q, a = gp - c0, solved_tag % 12
-                before = int(gincl[q] - gpop[q] + pop12[int(gmask[q]) & ((1 << a) - 1)])  # new states with a smaller tag (global)
-                expanded += gp + 1 - c0
-                nodes_global += before
-                return finish(True, walk(int(pref[0]), [(a, 2)]))
-            # a capacity failure of one rank's commit goes through the same "everybody raises" path as above
-            failure = None
-            try:
-                engine.commit(12 * (p_end + 1), lmask, lincl - lpop, gmask, gincl - gpop, next_count, commit_local)
-            except Exception as e:  # noqa: BLE001
-                failure = e
-            ok_all = i64([0 if failure is None else 1])
+                if not exchange:
+                    raise
+                failure = failure or e
+                engine.fail_local()
+                # empty regions whose headers say "failed": every rank stops at THIS chunk
+                S, _, rw = engine.layout(n_par)
+                send = torch.zeros(S * world * rw, dtype=torch.int64, device=dev)
+                hdr = send.view(S * world, rw)
+                hdr[:, 1], hdr[:, 2], hdr[:, 3] = INF, INF, 4
+                recv = torch.empty_like(send)
             if exchange:
-                comm.all_reduce(ok_all, "max")
-            if int(ok_all[0]):
-                raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure}" if failure is not None else "sharded bfs failed on another rank")
-            next_count += commit_global
-            nodes_global += commit_global
-            expanded += p_end + 1 - c0
-            if budget_hit:
-                return finish(False, None)
-            c0 = c1
-        F = next_count
+                comm.all_to_all_single(recv, send)
+            try:
+                gmask = engine.chunk_insert(n_par)
+            except Exception as e:  # noqa: BLE001
+                failure = failure or e
+                engine.fail_local()
+                gmask = engine.gmask_view(n_par)  # the engine's own buffer: its commit reads the all-reduced masks from there
+                gmask.zero_()
+            if exchange:
+                comm.all_reduce(gmask, "sum")  # every (parent, action) child has exactly one owner, so SUM == OR
+            try:
+                engine.chunk_commit(max_nodes)
+            except Exception as e:  # noqa: BLE001
+                failure = failure or e
+                engine.fail_local()
+            engine.ctl_snapshot(k % (lag + 2))
+            pending.append(k % (lag + 2))
+            chunks += 1
+            if len(pending) > lag:
+                ctl = engine.ctl_wait(pending.pop(0))
+            c0, k = c1, k + 1
+        while pending and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING):  # end of the level: the one synchronisation
+            ctl = engine.ctl_wait(pending.pop(0))
+        status = int(ctl[CTL_STATUS])
+        if status == ST_FAILED:
+            raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure or _FAIL_TEXT.get(int(ctl[CTL_FAIL_LOCAL]), 'engine failure')}"
+                               if failure is not None or int(ctl[CTL_FAIL_LOCAL]) else "sharded bfs failed on another rank")
+        if status == ST_MOVE_ERROR:
+            # the reference executes this move before it stops: its ACMove raises (every rank sees the same words)
+            raise AssertionError("a move emptied a relator during the search: the reference's ACMove raises here")
+        if status == ST_SOLVED:
+            tag = int(ctl[CTL_SOLVED_TAG])
+            mine = engine.find(tag // 12)
+            pref = i64([(rank << 40) | mine if mine >= 0 else -1])
+            comm.all_reduce(pref, "max")
+            return finish(True, walk(int(pref[0]), [(tag % 12, 2)]))
+        if status == ST_BUDGET:
+            return finish(False, None)
+        F = int(ctl[CTL_NEXT_COUNT])
     return finish(False, None)

@@ -1,34 +1,56 @@
 // acx_shard.hip -- per-GPU engine of the sharded BFS frontier (multi-GPU form of bfs, breadth_first.py:15-97) and its
 // C ABI (acx_shard_*).  Orchestration across ranks: ac-solver_amd/ac_solver/search/sharded.py.
 //
-// Round 2: the engine keeps its frontier on the device (the nodes committed during a level ARE the next level, a
-// contiguous id range in global FIFO order), dedups what it receives in an 8-byte stamp table (bucketed probing, one CAS
-// per new state; the keys of occupants are read from the received records / the node arena) and turns winners into nodes
-// through per-parent child masks -- the same 12-bit masks the ranks all-reduce -- so nothing is ever sorted and a chunk
-// costs the host two read-backs (send counts, the decision scalars).
+// Round 3.  States are partitioned by hash(key) mod world.  A level is processed in chunks of consecutive global frontier
+// positions [c0, c1); per chunk a rank runs, WITHOUT any host read-back in between,
+//
+//   k_shard_prep     frontier slice of the chunk, headers of the send regions
+//   k_shard_expand   12 children per local frontier node; a child equal to its parent, a child that undoes the move that made
+//                    its parent (normal-form searches with cyclical = False: that child IS the grandparent) and every
+//                    duplicate inside the workgroup's 1024 children (LDS fold, smallest tag stays) are never sent; the rest
+//                    goes straight into the send region of the rank that owns its key
+//   (all-to-all of fixed-size regions: a header with the record count and the sender's success / error / failure words in
+//    front of every region, so the exchange needs no count round trip and carries the chunk's scalars as well)
+//   k_shard_insert   exact dedup of the received records in the rank's stamp table, minimum tag wins
+//   k_shard_pack     one 12-bit child mask per parent: the new states this rank owns
+//   (all-reduce (sum == or) of the masks: 4 bytes per PARENT)
+//   k_shard_scan / k_shard_decide   prefix counts of the masks, the budget / success / error decision of the reference
+//                    (breadth_first.py:84-95) -- on the device, identical on every rank, written to the control block
+//   k_shard_commit   the new states below the cutoff become nodes, numbered through the masks (no sort)
+//
+// The receive area of a chunk is a slice of the RECORD LOG, which is never recycled: a stamp-table slot names its state by the
+// word offset of the record that claimed it (fingerprint(28) | offset(36)), so a slot is written exactly once per state --
+// round 2 rewrote every winner's slot with its node id at commit time, a random 8-byte store per new state (4.5 of the
+// engine's 22 ms of kernel time at 1e8 nodes).  What the log costs is memory, which an MI355X has: 24 (u64 keys) or 40
+// (u128) bytes per received record.
+//
+// The host never waits inside a level: it enqueues chunk after chunk and reads a snapshot of the control block two chunks
+// late (acx_shard_ctl_snapshot / acx_shard_ctl_wait); once the status word leaves 0 every later kernel returns at once.
 #include "acx_bfs.h"  // search_move: the shorter move code for searches whose root is in normal form
+
+#ifndef ACX_SHARD_SUBREGIONS
+#define ACX_SHARD_SUBREGIONS 16
+#endif
 
 namespace acx {
 
-// =============================================================================================
-// Sharded frontier: one engine per GPU, states partitioned by hash(key) mod world.  The host side
-// (ac_solver/search/sharded.py) moves candidate records between ranks with an RCCL all-to-all and
-// broadcasts winner tags; everything per rank happens in the kernels below.  A record is KW+2 int64:
-// the key words, tag = 12 * global_parent_position + action, parent_ref = rank << 40 | local id.
-// =============================================================================================
+constexpr int kShardHdr = 4;   // int64 words in front of every region: [0] records written (> capacity: overflow), [1] smallest tag of a
+                               // length-2 child the sender generated, [2] smallest (tag << 8 | code) of a move the reference raises on,
+                               // [3] the sender's sticky failure code (0 = healthy)
+constexpr int kShardSub = ACX_SHARD_SUBREGIONS;  // sub-regions per destination: a region's cursor is ONE word and one word takes ~90 returning
+                               // atomics per microsecond; the workgroups of a launch reserve in sub-region blockIdx % kShardSub
+constexpr int kExpandThreads = 256, kExpandItems = 4, kExpandTile = kExpandThreads * kExpandItems;  // children per workgroup
+constexpr int kScanTile = 4096;                    // parents per workgroup of k_shard_scan
+constexpr unsigned long long kShardInf = 1ull << 62;
+
 template <typename W> struct recio;
 template <> struct recio<uint64_t> {
-    static constexpr int KW = 2;
+    static constexpr int KW = 2, RW = 3;
     static ACX_HD void put(int64_t* r, uint64_t k0, uint64_t k1) { r[0] = (int64_t)k0; r[1] = (int64_t)k1; }
-    // the whole 32-byte record as two 16-byte stores (records are 32-byte aligned)
-    static __device__ __forceinline__ void put_all(int64_t* r, uint64_t k0, uint64_t k1, int64_t tag, int64_t pref) {
-        ((ulonglong2*)r)[0] = make_ulonglong2(k0, k1);
-        ((ulonglong2*)r)[1] = make_ulonglong2((unsigned long long)tag, (unsigned long long)pref);
-    }
     static ACX_HD void get(const int64_t* r, uint64_t& k0, uint64_t& k1) { k0 = (uint64_t)r[0]; k1 = (uint64_t)r[1]; }
 };
 template <> struct recio<u128> {
-    static constexpr int KW = 4;
+    static constexpr int KW = 4, RW = 5;
     static ACX_HD void put(int64_t* r, u128 k0, u128 k1) {
         r[0] = (int64_t)(uint64_t)k0; r[1] = (int64_t)(uint64_t)(k0 >> 64);
         r[2] = (int64_t)(uint64_t)k1; r[3] = (int64_t)(uint64_t)(k1 >> 64);
@@ -36,11 +58,6 @@ template <> struct recio<u128> {
     static ACX_HD void get(const int64_t* r, u128& k0, u128& k1) {
         k0 = ((u128)(uint64_t)r[1] << 64) | (uint64_t)r[0];
         k1 = ((u128)(uint64_t)r[3] << 64) | (uint64_t)r[2];
-    }
-    static __device__ __forceinline__ void put_all(int64_t* r, u128 k0, u128 k1, int64_t tag, int64_t pref) {  // 48 bytes, 16-byte aligned
-        ((ulonglong2*)r)[0] = make_ulonglong2((uint64_t)k0, (uint64_t)(k0 >> 64));
-        ((ulonglong2*)r)[1] = make_ulonglong2((uint64_t)k1, (uint64_t)(k1 >> 64));
-        ((ulonglong2*)r)[2] = make_ulonglong2((unsigned long long)tag, (unsigned long long)pref);
     }
 };
 
@@ -59,10 +76,79 @@ ACX_HD uint32_t owner_of_key(u128 k0, u128 k1, uint32_t world) {
     return (uint32_t)((h & 0x7FFFFFFFFFFFFFFFull) % world);
 }
 
+// ---- control block (device, int64 words; include/acx.h: ACX_SHARD_CTL_*) ---------------------------------------------------
+enum : int {
+    C_STATUS = 0,        // 0 running, 1 solved, 2 budget reached, 3 a move raised (AssertionError), 4 a rank failed
+    C_NODES_GLOBAL = 1,  // len(tree_nodes) over all ranks
+    C_NEXT_COUNT = 2,    // new states of the running level so far = size of the next level
+    C_EXPANDED = 3,      // parents expanded
+    C_SOLVED_TAG = 4,    // 12 * global position + action of the child that ended the search
+    C_NODES = 5,         // local nodes
+    C_LVL_LO = 6,        // the local nodes [lvl_lo, lvl_hi) are this rank's slice of the running level, ascending in gpos
+    C_LVL_HI = 7,
+    C_FAIL_LOCAL = 8,    // sticky: this rank's failure code (travels in the headers of its next chunk)
+    C_MIN_LEN = 9,       // smallest total length this rank generated
+    C_FAIL_SEEN = 10,    // failure code received (status 4)
+    C_CHUNKS = 11,       // chunks decided
+    C_WORDS = 16
+};
+enum : int { FAIL_REGION = 1, FAIL_NODES = 2, FAIL_TABLE = 3, FAIL_HOST = 4 };
 
-// ---- local frontier ------------------------------------------------------------------------------------------------------
-// node arena: k0 / k1 (packed key), node_pref (parent_ref), act, tlen, gpos (d.depth: global FIFO position inside its level)
-// The nodes [lvl_lo, lvl_hi) are the current level, ascending in gpos.
+// decision of the running chunk, written by k_shard_decide for k_shard_commit
+struct ChunkDec {
+    uint32_t commit;      // 1: turn the winners below cutoff into nodes
+    uint32_t cutoff;      // relative tag: 12 * (p_end + 1 - c0)
+    uint32_t node_base;   // first local id of this chunk's nodes
+    uint32_t gpos_base;   // global position (inside the next level) of the chunk's first new state
+};
+
+template <typename W> struct ShardDev {
+    W* k0;
+    W* k1;
+    int64_t* pref;       // parent_ref = rank << 40 | local id of the parent; -1 for the root
+    uint32_t* gpos;      // global FIFO position inside the node's level
+    uint8_t* act;
+    uint8_t* tlen;
+    unsigned long long* stab;
+    uint32_t stmask;
+    int64_t* log;        // record log = receive areas of all chunks
+    uint8_t* btook;      // one byte per tag of a chunk: took a slot / was pushed out again (both zero between chunks)
+    uint8_t* brepl;
+    int32_t* lmask;      // [chunk parents] 12-bit masks: new states of this rank
+    int32_t* gmask;      // the same, summed over the ranks by the caller's all-reduce
+    uint32_t* lpre;      // exclusive popcount prefix inside a kScanTile tile
+    uint32_t* gpre;
+    uint32_t* lblk;      // per tile: total, turned into the exclusive prefix over the tiles by k_shard_decide
+    uint32_t* gblk;
+    unsigned long long* ctl;
+    uint32_t* bounds;    // [2] frontier slice of the running chunk
+    ChunkDec* dec;
+    uint32_t cap_nodes;
+    int32_t L, cyclical;
+    uint32_t world, rank;
+};
+
+struct ChunkGeo {
+    int64_t c0;            // first global position of the chunk
+    int64_t log_off;       // word offset of the chunk's receive area in the log
+    uint32_t n_par;        // global parents in the chunk
+    uint32_t subcap;       // records a sub-region can take
+    uint32_t region_words; // kShardHdr + subcap * RW
+};
+
+// the one place that fixes the geometry of a chunk's regions: every rank (and the NumPy test engine, through
+// acx_shard_layout) computes the same numbers from (parents of the chunk, world)
+static inline void shard_layout(int64_t n_par, int world, int RW, int64_t* subcap, int64_t* region_words) {
+    const int64_t n_blocks = (12 * n_par + kExpandTile - 1) / kExpandTile;
+    const int64_t hard = (n_blocks + kShardSub - 1) / kShardSub * kExpandTile;  // every workgroup that reserves in a sub-region sends it all it has
+    int64_t cap = hard;
+    if (world > 1) {  // the owner hash spreads the records evenly: 1.25 x the even share + two workgroups' worth
+        const int64_t even = (12 * n_par + (int64_t)world * world * kShardSub - 1) / ((int64_t)world * world * kShardSub);
+        cap = std::min<int64_t>(hard, even + even / 4 + 2 * kExpandTile);
+    }
+    *subcap = cap;
+    *region_words = kShardHdr + cap * RW;
+}
 
 // first node of [lo, hi) whose gpos is >= c
 __device__ __forceinline__ uint32_t lower_gpos(const uint32_t* __restrict__ gpos, uint32_t lo, uint32_t hi, uint32_t c) {
@@ -74,265 +160,540 @@ __device__ __forceinline__ uint32_t lower_gpos(const uint32_t* __restrict__ gpos
     return lo;
 }
 
-// [lo, hi) = the local frontier nodes with gpos in [c0, c1): found ONCE per chunk by one lane (two binary searches of ~25
-// dependent loads each: done at the top of every workgroup of the expansion they cost it 8 of its 11 ms on a 1e8-node search)
-template <typename W> __global__ void k_shard_bounds(SearchDev<W> d, uint32_t lvl_lo, uint32_t lvl_hi, uint32_t c0, uint32_t c1, uint32_t* __restrict__ out) {
-    ACX_VGPR_PAD("v23");
-    out[0] = lower_gpos(d.depth, lvl_lo, lvl_hi, c0);
-    out[1] = lower_gpos(d.depth, lvl_lo, lvl_hi, c1);
+// Start of a chunk: the level switch (first chunk of a level), the frontier slice [bounds[0], bounds[1]) of the local nodes
+// with gpos in [c0, c0 + n_par) -- found ONCE per chunk by one lane -- and the headers of the send regions.
+template <typename W>
+__global__ void __launch_bounds__(256) k_shard_prep(ShardDev<W> d, ChunkGeo g, int level_first, int64_t* __restrict__ send) {
+    ACX_VGPR_PAD("v31");
+    if (d.ctl[C_STATUS] != 0) return;
+    if (threadIdx.x == 0) {
+        if (level_first) {
+            d.ctl[C_LVL_LO] = d.ctl[C_LVL_HI];
+            d.ctl[C_LVL_HI] = d.ctl[C_NODES];
+            d.ctl[C_NEXT_COUNT] = 0;
+        }
+        const uint32_t lo = (uint32_t)d.ctl[C_LVL_LO], hi = (uint32_t)d.ctl[C_LVL_HI];
+        d.bounds[0] = lower_gpos(d.gpos, lo, hi, (uint32_t)g.c0);
+        d.bounds[1] = lower_gpos(d.gpos, lo, hi, (uint32_t)(g.c0 + g.n_par));
+    }
+    const unsigned long long fail = d.ctl[C_FAIL_LOCAL];
+    for (uint32_t r = threadIdx.x; r < d.world * kShardSub; r += blockDim.x) {
+        int64_t* h = send + (int64_t)r * g.region_words;
+        h[0] = 0;
+        h[1] = (int64_t)kShardInf;
+        h[2] = (int64_t)kShardInf;
+        h[3] = (int64_t)fail;
+    }
 }
 
-// Children of the local frontier nodes with gpos in [c0, c1), each written straight into the send region of the rank
-// that owns its key (region o = rec[o * region_cap ...]), so the all-to-all can leave without a sort by owner.  The order
-// inside a region is arbitrary.  A workgroup expands kRouteItems x 1024 children and reserves its share of every region
-// with ONE atomicAdd per owner: the cursors are single words, and one word takes only ~90 returning atomics per
-// microsecond (a reservation per 1024 children cost 3.7 of the kernel's 8.3 ms on a 1e8-node search).
-#ifndef ACX_ROUTE_ITEMS
-#define ACX_ROUTE_ITEMS 4
-#endif
-constexpr int kRouteItems = ACX_ROUTE_ITEMS;
+// action that undoes action a on a presentation in normal form, cyclical = False (ac_moves.py:165-179: 0 <-> 2, 1 <-> 3 are
+// r_i <- r_i r_j^{+-1}; 4 <-> 8, 5 <-> 9, 6 <-> 10, 7 <-> 11 conjugate by a generator and its inverse)
+__device__ __forceinline__ uint32_t inverse_action(uint32_t a) { return a < 4 ? a ^ 2u : (a < 8 ? a + 4u : a - 4u); }
 
+// Children of the local frontier nodes with gpos in [c0, c1), each written straight into the send region of the rank that
+// owns its key.  Never sent: a child equal to its parent (over-long product, ac_moves.py:64, :126: visited by construction);
+// with MODE == kMoveNf the child of action inverse(act[parent]) (it is the parent's own tree parent: g^-1 (g r g^-1) g = r and
+// (r_i r_j) r_j^-1 = r_i as reduced words, and the result fits because it did before -- checked against the oracle on every
+// node of the CPU suite's searches, tests/test_sharded_cpu.py); every duplicate among the workgroup's 1024 children except
+// the one with the smallest tag (LDS table of tile lanes: tile order IS tag order).  The success and error words are taken
+// BEFORE any of that, as the reference tests a child before it looks it up (breadth_first.py:84).
 template <typename W, int MODE>
-__global__ void __launch_bounds__(1024) k_shard_expand_routed(SearchDev<W> d, const uint32_t* __restrict__ bounds, int64_t pref_hi,
-                                                             uint32_t world, int64_t* __restrict__ rec, int64_t region_cap, unsigned long long* __restrict__ counts,
-                                                             unsigned long long* __restrict__ solved) {
-    ACX_VGPR_PAD_W(W, "v71", "v103");
+__global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, ChunkGeo g, int64_t* __restrict__ send) {
+    __shared__ W s_k0[kExpandTile];
+    __shared__ W s_k1[kExpandTile];
+    __shared__ uint32_t s_slot[2 * kExpandTile];
     __shared__ uint32_t s_cnt[64];
-    __shared__ unsigned long long s_base[64];
-    const uint32_t s_lo = bounds[0], s_hi = bounds[1];
-    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const int64_t np = (int64_t)s_hi - s_lo;
-    const uint32_t lane = threadIdx.x & 63;
-    W k0[kRouteItems], k1[kRouteItems];
-    int64_t tag[kRouteItems];
-    uint32_t owner[kRouteItems], pos_in_block[kRouteItems], ids[kRouteItems];
+    __shared__ uint32_t s_base[64];
+    ACX_VGPR_PAD_W(W, "v63", "v111");  // the code needs 55-56 / 99-100 registers (tools/kernel_resources.py)
+    if (d.ctl[C_STATUS] != 0) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t s_lo = d.bounds[0], s_hi = d.bounds[1];
+    const int64_t m = 12 * ((int64_t)s_hi - s_lo);
+    if ((int64_t)blockIdx.x * kExpandTile >= m) return;
+    if (tid < 64) s_cnt[tid] = 0;
+    for (uint32_t i = tid; i < 2 * kExpandTile; i += kExpandThreads) s_slot[i] = kEmpty;
+    W c0[kExpandItems], c1[kExpandItems];
+    uint32_t x_lo[kExpandItems], x_hi[kExpandItems];  // record word: parent id | relative tag << 32
+    bool send_it[kExpandItems];
+    uint32_t tl_min = 0xFFFFFFFFu;
 #pragma unroll
-    for (int it = 0; it < kRouteItems; it++) {
-        const int64_t t = ((int64_t)blockIdx.x * kRouteItems + it) * 1024 + threadIdx.x;
-        owner[it] = 0xFFFFFFFFu;
-        pos_in_block[it] = 0;
-        k0[it] = k1[it] = 0;
-        tag[it] = 0;
-        ids[it] = 0;
-        if (t < 12 * np) {
-            const int64_t p = t / 12;
-            const int a = (int)(t - 12 * p);
-            const uint32_t id = s_lo + (uint32_t)p;
-            Pres<W> s;
+    for (int it = 0; it < kExpandItems; it++) {
+        const uint32_t lane = it * kExpandThreads + tid;  // position in the tile = order of the tags
+        const int64_t c = (int64_t)blockIdx.x * kExpandTile + lane;
+        send_it[it] = false;
+        c0[it] = c1[it] = 0;
+        x_lo[it] = x_hi[it] = 0;
+        if (c < m) {
+            const uint32_t p = (uint32_t)(c / 12), a = (uint32_t)(c - 12 * (int64_t)p), id = s_lo + p;
             const W pk0 = d.k0[id], pk1 = d.k1[id];
+            const uint32_t gp = d.gpos[id];
+            Pres<W> s;
             key_to_pres<W>(pk0, pk1, s);
-            const int e = search_move<W, MODE>(s, a, d.L, d.cyclical != 0);
-            tag[it] = 12 * (int64_t)d.depth[id] + a;
-            ids[it] = id;
-            if (e) atomicMin(solved + 1, ((unsigned long long)tag[it] << 8) | (unsigned long long)e);  // first erroring move (global tag)
-            k0[it] = keyops<W>::make(s.w0, s.n0);
-            k1[it] = keyops<W>::make(s.w1, s.n1);
-            // a move that leaves the state unchanged (over-long product: ac_moves.py:64, :126) yields the parent itself, which
-            // is in the visited set already: such a child can never be new, so it is not sent at all
-            if (k0[it] != pk0 || k1[it] != pk1) owner[it] = owner_of_key(k0[it], k1[it], world);
-            if (s.n0 + s.n1 == 2) atomicMin(solved, (unsigned long long)tag[it]);
-            if ((uint32_t)(s.n0 + s.n1) < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, (uint32_t)(s.n0 + s.n1));
+            const int e = search_move<W, MODE>(s, (int)a, d.L, d.cyclical != 0);
+            const unsigned long long tag = 12ull * gp + a;  // the reference's generation order inside the level
+            if (e)  // first erroring move: into the header of EVERY region of this workgroup's sub-region (rare)
+                for (uint32_t o = 0; o < d.world; o++)
+                    atomicMin((unsigned long long*)(send + (int64_t)(o * kShardSub + blockIdx.x % kShardSub) * g.region_words + 2), (tag << 8) | (unsigned long long)e);
+            c0[it] = keyops<W>::make(s.w0, s.n0);
+            c1[it] = keyops<W>::make(s.w1, s.n1);
+            const uint32_t tl = (uint32_t)(s.n0 + s.n1);
+            tl_min = min(tl_min, tl);
+            if (tl == 2)
+                for (uint32_t o = 0; o < d.world; o++)
+                    atomicMin((unsigned long long*)(send + (int64_t)(o * kShardSub + blockIdx.x % kShardSub) * g.region_words + 1), tag);
+            send_it[it] = !(c0[it] == pk0 && c1[it] == pk1);
+            if (MODE == kMoveNf && send_it[it]) {
+                const uint32_t pa = d.act[id];  // 0xff for the root
+                if (pa < 12u && a == inverse_action(pa)) send_it[it] = false;
+            }
+            x_lo[it] = id;
+            x_hi[it] = (uint32_t)(tag - 12ull * (unsigned long long)g.c0);
         }
-        // position inside the workgroup's share of the destination region: wave-aggregated LDS counters per owner
-        for (uint32_t o = 0; o < world; o++) {
-            const unsigned long long m = __ballot(owner[it] == o);
-            if (!m) continue;
-            const uint32_t lead = (uint32_t)__builtin_ctzll(m);
-            uint32_t base = 0;
-            if (lane == lead) base = atomicAdd(&s_cnt[o], (uint32_t)__popcll(m));
-            base = (uint32_t)__shfl((int)base, (int)lead);
-            if (owner[it] == o) pos_in_block[it] = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        s_k0[lane] = c0[it];
+        s_k1[lane] = c1[it];
+    }
+    {  // smallest total length: wave minimum, one atomic per wave that lowers it
+        for (int o = 32; o > 0; o >>= 1) tl_min = min(tl_min, (uint32_t)__shfl_xor((int)tl_min, o));
+        if ((tid & 63u) == 0 && (unsigned long long)tl_min < *(volatile unsigned long long*)(d.ctl + C_MIN_LEN)) atomicMin(d.ctl + C_MIN_LEN, (unsigned long long)tl_min);
+    }
+    __syncthreads();
+    // ---- duplicates inside the tile: the smallest tile lane of every key stays ---------------------------------------------
+    uint32_t ls[kExpandItems];
+#pragma unroll
+    for (int it = 0; it < kExpandItems; it++) {
+        const uint32_t lane = it * kExpandThreads + tid;
+        ls[it] = 0;
+        if (!send_it[it]) continue;
+        uint32_t q = (uint32_t)(hash_key<W>(c0[it], c1[it]) >> 40) & (2 * kExpandTile - 1);
+        for (;;) {
+            uint32_t v = s_slot[q];
+            if (v == kEmpty) {
+                v = atomicCAS(&s_slot[q], kEmpty, lane);
+                if (v == kEmpty) break;
+            }
+            if (s_k0[v] == c0[it] && s_k1[v] == c1[it]) {  // any holder of this slot has my key
+                if (v > lane) atomicMin(&s_slot[q], lane);
+                break;
+            }
+            q = (q + 1) & (2 * kExpandTile - 1);
+        }
+        ls[it] = q;
+    }
+    __syncthreads();
+    // ---- route the survivors: position inside the workgroup's share of the destination's sub-region -------------------------
+    uint32_t owner[kExpandItems], pos[kExpandItems];
+#pragma unroll
+    for (int it = 0; it < kExpandItems; it++) {
+        const uint32_t lane = it * kExpandThreads + tid;
+        owner[it] = 0xFFFFFFFFu;
+        pos[it] = 0;
+        if (send_it[it] && s_slot[ls[it]] == lane) {
+            owner[it] = owner_of_key(c0[it], c1[it], d.world);
+            pos[it] = atomicAdd(&s_cnt[owner[it]], 1u);
         }
     }
     __syncthreads();
-    if (threadIdx.x < world && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    const uint32_t sub = blockIdx.x % kShardSub;
+    if (tid < d.world && s_cnt[tid])
+        s_base[tid] = (uint32_t)atomicAdd((unsigned long long*)(send + (int64_t)(tid * kShardSub + sub) * g.region_words), (unsigned long long)s_cnt[tid]);
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < kRouteItems; it++) {
+    for (int it = 0; it < kExpandItems; it++) {
         if (owner[it] == 0xFFFFFFFFu) continue;
-        const int64_t pos = (int64_t)s_base[owner[it]] + pos_in_block[it];
-        if (pos < region_cap)  // an overflow shows in counts[o] > region_cap; the host reports it
-            recio<W>::put_all(rec + ((int64_t)owner[it] * region_cap + pos) * (recio<W>::KW + 2), k0[it], k1[it], tag[it], pref_hi | ids[it]);
+        const uint32_t at = s_base[owner[it]] + pos[it];
+        if (at >= g.subcap) continue;  // overflow: the count in the header says so, the receiver reports it
+        int64_t* r = send + (int64_t)(owner[it] * kShardSub + sub) * g.region_words + kShardHdr + (int64_t)at * recio<W>::RW;
+        recio<W>::put(r, c0[it], c1[it]);
+        r[recio<W>::KW] = (int64_t)(((unsigned long long)x_hi[it] << 32) | x_lo[it]);
     }
 }
 
-// ---- dedup of the received records -----------------------------------------------------------------------------------------
-// Stamp table (cf. acx_bfs.h): 8-byte slots probed four at a time (one 32-byte sector), all ones = free.
-//   fingerprint(27) | provisional(1) | payload(36)
-// provisional: payload = index of a record of the running chunk (key and tag in rec[payload]); committed: payload = local
-// node id (key in the node arena).  Among equal keys the smaller tag takes the slot with a CAS (retried when another
-// record got there first).  Two byte flags per tag of the chunk, both zero on entry: btook[tag - tag0] is set by a record
-// that takes a slot, brepl[tag - tag0] by the record that pushes it out again -- "took and was not replaced" does not
-// depend on the order in which the two stores land.  k_shard_pack folds them into one 12-bit child mask per parent.
-constexpr unsigned long long kShardFree = ~0ull;
-constexpr unsigned long long kShardProv = 1ull << 36;
-constexpr unsigned long long kShardPayload = kShardProv - 1;
+// ---- dedup of the received records ------------------------------------------------------------------------------------------
+// Stamp table: 8-byte slots probed four at a time (one 32-byte sector), all ones = free, else fingerprint(28) | offset(36):
+// the word offset in the log of the record that claimed the slot.  An offset at or behind the running chunk's receive area is a
+// record of this chunk: among equal keys the smaller tag takes the slot with a CAS (retried when another record got there
+// first); an older offset is a state that was seen before.  Two byte flags per tag of the chunk, both zero on entry:
+// btook[tag] is set by a record that takes a slot, brepl[tag] by the record that pushes it out again -- "took and was not
+// replaced" does not depend on the order in which the two stores land.
+constexpr unsigned long long kStampFree = ~0ull;
+constexpr unsigned long long kStampOff = (1ull << 36) - 1;
 
 template <typename W>
-__global__ void __launch_bounds__(256) k_shard_insert(SearchDev<W> d, const int64_t* __restrict__ rec, int64_t n, int64_t tag0, uint32_t* __restrict__ cslot,
-                                                      uint8_t* __restrict__ took_i) {
+__global__ void __launch_bounds__(256) k_shard_insert(ShardDev<W> d, ChunkGeo g) {
     ACX_VGPR_PAD("v63");
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t* r = rec + i * (recio<W>::KW + 2);
+    if (d.ctl[C_STATUS] != 0) return;
+    const uint32_t r = blockIdx.y;
+    const int64_t roff = g.log_off + (int64_t)r * g.region_words;
+    const unsigned long long written = (unsigned long long)d.log[roff];
+    if (written > g.subcap && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(d.ctl + C_FAIL_LOCAL, (unsigned long long)FAIL_REGION);
+    const uint32_t cnt = written > g.subcap ? g.subcap : (uint32_t)written;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const int64_t off = roff + kShardHdr + (int64_t)i * recio<W>::RW;
+    const int64_t* rec = d.log + off;
     W c0, c1;
-    recio<W>::get(r, c0, c1);
-    const int64_t tag = r[recio<W>::KW];
+    recio<W>::get(rec, c0, c1);
+    const uint32_t tag = (uint32_t)((unsigned long long)rec[recio<W>::KW] >> 32);
     const uint64_t hk = hash_key<W>(c0, c1);
-    const unsigned long long fp = hk & ~((1ull << 37) - 1);
-    const unsigned long long me = fp | kShardProv | (unsigned long long)i;
+    const unsigned long long me = (hk & ~kStampOff) | (unsigned long long)off;
     uint32_t base = (uint32_t)hk & d.stmask & ~3u, probes = 0, took = 0;
     bool open = true;
     while (open) {
         const ulonglong2 lo = *(const ulonglong2*)(d.stab + base), hi = *(const ulonglong2*)(d.stab + base + 2);
         const unsigned long long v0 = lo.x, v1 = lo.y, v2 = hi.x, v3 = hi.y;
-        auto hot = [&](unsigned long long v) { return v == kShardFree || (v >> 37) == (me >> 37); };
+        auto hot = [&](unsigned long long v) { return v == kStampFree || (v >> 36) == (me >> 36); };
         uint32_t cand = (hot(v0) ? 1u : 0u) | (hot(v1) ? 2u : 0u) | (hot(v2) ? 4u : 0u) | (hot(v3) ? 8u : 0u);
         while (cand && open) {
             const uint32_t j = (uint32_t)__builtin_ctz(cand);
             cand &= cand - 1;
             unsigned long long st = j == 0 ? v0 : (j == 1 ? v1 : (j == 2 ? v2 : v3));
             unsigned long long* slot = d.stab + base + j;
-            for (;;) {  // until this slot is decided for me (it changes only among records of MY key once it holds my key)
-                if (st == kShardFree) {
-                    const unsigned long long old = atomicCAS(slot, kShardFree, me);
-                    if (old == kShardFree) {
+            for (;;) {  // until this slot is decided for me (once it holds my key it only changes among records of MY key)
+                if (st == kStampFree) {
+                    const unsigned long long old = atomicCAS(slot, kStampFree, me);
+                    if (old == kStampFree) {
                         took = 1;
                         open = false;
                         break;
                     }
                     st = old;
                 }
-                if ((st >> 37) != (me >> 37)) break;  // another key's fingerprint: next slot
+                if ((st >> 36) != (me >> 36)) break;  // another key's fingerprint: next slot
+                const int64_t qoff = (int64_t)(st & kStampOff);
                 W q0, q1;
-                int64_t qtag = -1;  // committed states beat every record
-                if (st & kShardProv) {
-                    const int64_t* h = rec + (int64_t)(st & kShardPayload) * (recio<W>::KW + 2);
-                    recio<W>::get(h, q0, q1);
-                    qtag = h[recio<W>::KW];
-                } else {
-                    const uint32_t id = (uint32_t)(st & kShardPayload);
-                    q0 = d.k0[id];
-                    q1 = d.k1[id];
-                }
+                recio<W>::get(d.log + qoff, q0, q1);
                 if (q0 != c0 || q1 != c1) break;  // same fingerprint, other key: next slot
-                if (qtag < 0 || qtag < tag) {     // seen before, or a record of this chunk with a smaller tag holds it
+                if (qoff < g.log_off) {           // a record of an earlier chunk: seen before
+                    open = false;
+                    break;
+                }
+                const uint32_t qtag = (uint32_t)((unsigned long long)d.log[qoff + recio<W>::KW] >> 32);
+                if (qtag < tag) {  // a record of this chunk with a smaller tag holds it
                     open = false;
                     break;
                 }
                 const unsigned long long old = atomicCAS(slot, st, me);  // push the larger tag out
                 if (old == st) {
                     took = 1;
-                    d.brepl[qtag - tag0] = 1;  // no longer the first discoverer
+                    d.brepl[qtag] = 1;  // no longer the first discoverer
                     open = false;
                     break;
                 }
                 st = old;  // somebody else replaced it meanwhile: look again
             }
-            if (took) cslot[i] = base + j;
         }
         base = (base + 4) & d.stmask;
         if (open && ++probes > d.stmask / 4) {
-            atomicOr(d.err, kErrTableFull);
+            atomicMax(d.ctl + C_FAIL_LOCAL, (unsigned long long)FAIL_TABLE);
             open = false;
         }
     }
-    if (took) d.btook[tag - tag0] = 1;
-    took_i[i] = (uint8_t)took;  // the same flag by record index (coalesced): k_shard_commit skips the records that never took a slot
+    if (took) d.btook[tag] = 1;
 }
 
-// one 12-bit mask per parent of the chunk: bit a set when child (parent, a) is a new state of this rank
-template <typename W> __global__ void __launch_bounds__(256) k_shard_pack(SearchDev<W> d, int64_t n_parents, int32_t* __restrict__ lmask) {
+// one 12-bit mask per parent of the chunk: bit a set when child (parent, a) is a new state of this rank; the flags it read are
+// zeroed again for the next chunk (no memset launches)
+template <typename W> __global__ void __launch_bounds__(256) k_shard_pack(ShardDev<W> d, uint32_t n_par) {
     ACX_VGPR_PAD("v23");
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_parents) return;
-    const uint32_t* t = (const uint32_t*)(d.btook + 12 * p);  // 12 bytes, 4-byte aligned
-    const uint32_t* r = (const uint32_t*)(d.brepl + 12 * p);
+    if (d.ctl[C_STATUS] != 0) return;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_par) return;
+    uint32_t* t = (uint32_t*)(d.btook + 12 * (size_t)p);  // 12 bytes, 4-byte aligned
+    uint32_t* r = (uint32_t*)(d.brepl + 12 * (size_t)p);
     int32_t m = 0;
 #pragma unroll
     for (int w = 0; w < 3; w++) {
-        const uint32_t v = t[w] & ~r[w];  // bytes are 0 / 1
+        const uint32_t tv = t[w], rv = r[w];
+        if (tv) t[w] = 0;
+        if (rv) r[w] = 0;
+        const uint32_t v = tv & ~rv;  // bytes are 0 / 1
         m |= (int32_t)(((v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u)) << (4 * w));
     }
-    lmask[p] = m;
+    d.lmask[p] = m;
+    d.gmask[p] = m;
+}
+
+// exclusive popcount prefixes of the local and the all-reduced masks inside tiles of kScanTile parents + the tiles' totals
+template <typename W> __global__ void __launch_bounds__(1024) k_shard_scan(ShardDev<W> d, uint32_t n_par) {
+    __shared__ uint32_t s_l[16], s_g[16];
+    ACX_VGPR_PAD("v63");
+    if (d.ctl[C_STATUS] != 0) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t p0 = blockIdx.x * kScanTile + tid * 4;
+    uint32_t lm[4], gm[4], lsum = 0, gsum = 0;
+    if (p0 + 4 <= n_par) {
+        const int4 a = *(const int4*)(d.lmask + p0), b = *(const int4*)(d.gmask + p0);
+        lm[0] = a.x, lm[1] = a.y, lm[2] = a.z, lm[3] = a.w;
+        gm[0] = b.x, gm[1] = b.y, gm[2] = b.z, gm[3] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            lm[k] = p0 + k < n_par ? (uint32_t)d.lmask[p0 + k] : 0u;
+            gm[k] = p0 + k < n_par ? (uint32_t)d.gmask[p0 + k] : 0u;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        lsum += (uint32_t)__popc(lm[k]);
+        gsum += (uint32_t)__popc(gm[k]);
+    }
+    uint32_t li = lsum, gi = gsum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a = (uint32_t)__shfl_up((int)li, o), b = (uint32_t)__shfl_up((int)gi, o);
+        if (lane >= (uint32_t)o) li += a, gi += b;
+    }
+    if (lane == 63) s_l[wave] = li, s_g[wave] = gi;
+    __syncthreads();
+    uint32_t lb = 0, gb = 0, lt = 0, gt = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; w++) {
+        if (w < wave) lb += s_l[w], gb += s_g[w];
+        lt += s_l[w], gt += s_g[w];
+    }
+    uint32_t le = lb + li - lsum, ge = gb + gi - gsum;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (p0 + k < n_par) {
+            d.lpre[p0 + k] = le;
+            d.gpre[p0 + k] = ge;
+            le += (uint32_t)__popc(lm[k]);
+            ge += (uint32_t)__popc(gm[k]);
+        }
+    if (tid == 0) d.lblk[blockIdx.x] = lt, d.gblk[blockIdx.x] = gt;
+}
+
+// The reference's decisions for the chunk, from the all-reduced masks and the received headers -- the same numbers on every rank:
+//   budget   "first parent after which len(tree_nodes) >= max_nodes" (breadth_first.py:91-95): the first parent whose inclusive
+//            count of new states reaches what is left of the budget;
+//   success  the smallest tag of a length-2 child, if its parent is expanded at all (:84-85);
+//   error    a move on which the reference's ACMove raises, if the reference gets that far.
+// One workgroup: prefix over the tiles' totals (turned into exclusive prefixes in place), then lane 0 decides.
+template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(ShardDev<W> d, ChunkGeo g, int64_t max_nodes) {
+    __shared__ uint32_t s_l[1024], s_g[1024];
+    __shared__ unsigned long long s_solved, s_err, s_fail;
+    __shared__ uint32_t s_tile, s_pb;
+    ACX_VGPR_PAD("v39");
+    if (d.ctl[C_STATUS] != 0) {  // the search has ended: this chunk commits nothing
+        if (threadIdx.x == 0) d.dec->commit = 0;
+        return;
+    }
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nt = (g.n_par + kScanTile - 1) / kScanTile, per = (nt + 1023) / 1024;
+    if (tid == 0) s_solved = kShardInf, s_err = kShardInf, s_fail = 0, s_tile = 0xFFFFFFFFu, s_pb = 0xFFFFFFFFu;
+    uint32_t lsum = 0, gsum = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t t = tid * per + k;
+        if (t < nt) lsum += d.lblk[t], gsum += d.gblk[t];
+    }
+    s_l[tid] = lsum;
+    s_g[tid] = gsum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {  // Hillis-Steele over the 1024 partial sums
+        const uint32_t a = tid >= o ? s_l[tid - o] : 0u, b = tid >= o ? s_g[tid - o] : 0u;
+        __syncthreads();
+        s_l[tid] += a;
+        s_g[tid] += b;
+        __syncthreads();
+    }
+    const uint32_t l_total = s_l[1023], g_total = s_g[1023];
+    uint32_t le = s_l[tid] - lsum, ge = s_g[tid] - gsum;
+    const unsigned long long nodes_global = d.ctl[C_NODES_GLOBAL];
+    const unsigned long long need = (unsigned long long)max_nodes > nodes_global ? (unsigned long long)max_nodes - nodes_global : 0ull;
+    for (uint32_t k = 0; k < per; k++) {  // exclusive prefixes of the tiles in place; the tile in which the budget is reached
+        const uint32_t t = tid * per + k;
+        if (t < nt) {
+            const uint32_t lt = d.lblk[t], gt = d.gblk[t];
+            d.lblk[t] = le;
+            d.gblk[t] = ge;
+            if (need >= 1 && (unsigned long long)ge < need && (unsigned long long)ge + gt >= need) atomicMin(&s_tile, t);
+            le += lt;
+            ge += gt;
+        }
+    }
+    // the headers of everything this rank received: success / error words and failure codes of all senders
+    unsigned long long sv = kShardInf, ev = kShardInf, fv = 0;
+    for (uint32_t r = tid; r < d.world * kShardSub; r += 1024) {
+        const int64_t* h = d.log + g.log_off + (int64_t)r * g.region_words;
+        sv = min(sv, (unsigned long long)h[1]);
+        ev = min(ev, (unsigned long long)h[2]);
+        fv = max(fv, (unsigned long long)h[3]);
+    }
+    if (sv < kShardInf) atomicMin(&s_solved, sv);
+    if (ev < kShardInf) atomicMin(&s_err, ev);
+    if (fv) atomicMax(&s_fail, fv);
+    __syncthreads();
+    const bool over = nodes_global + g_total >= (unsigned long long)max_nodes && need >= 1;
+    if (over) {  // the parent inside tile s_tile whose inclusive count reaches the budget
+        const uint32_t t = s_tile;
+        for (uint32_t k = tid; k < (uint32_t)kScanTile; k += 1024) {
+            const uint32_t p = t * kScanTile + k;
+            if (p < g.n_par) {
+                const unsigned long long ex = (unsigned long long)d.gblk[t] + d.gpre[p], in = ex + (unsigned long long)__popc((uint32_t)d.gmask[p]);
+                if (ex < need && in >= need) s_pb = p;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    ChunkDec dec = {0, 0, 0, 0};
+    if (s_fail) {  // some rank failed in an earlier chunk: everybody stops here (same chunk on every rank: the headers are the same)
+        d.ctl[C_STATUS] = 4;
+        d.ctl[C_FAIL_SEEN] = s_fail;
+        *d.dec = dec;
+        return;
+    }
+    uint32_t p_end = g.n_par - 1;
+    bool budget_hit = false;
+    unsigned long long commit_global = g_total, commit_local = l_total;
+    if (need < 1) {  // only the very first parent can see this (budget <= 1)
+        p_end = 0;
+        budget_hit = true;
+        commit_global = (unsigned long long)__popc((uint32_t)d.gmask[0]);
+        commit_local = (unsigned long long)__popc((uint32_t)d.lmask[0]);
+    } else if (over) {
+        p_end = s_pb;
+        budget_hit = true;
+        const uint32_t t = p_end / kScanTile;
+        commit_global = (unsigned long long)d.gblk[t] + d.gpre[p_end] + (unsigned long long)__popc((uint32_t)d.gmask[p_end]);
+        commit_local = (unsigned long long)d.lblk[t] + d.lpre[p_end] + (unsigned long long)__popc((uint32_t)d.lmask[p_end]);
+    }
+    const unsigned long long end_pos = (unsigned long long)g.c0 + p_end;
+    const unsigned long long stag = s_solved, eword = s_err;
+    const bool is_solved = stag < kShardInf && stag / 12ull <= end_pos;
+    d.ctl[C_CHUNKS] += 1;
+    if (eword < kShardInf && (eword >> 8) / 12ull <= end_pos && !(is_solved && stag < (eword >> 8))) {
+        d.ctl[C_STATUS] = 3;  // the reference executes this move before it stops: its ACMove raises
+        *d.dec = dec;
+        return;
+    }
+    if (is_solved) {
+        const uint32_t q = (uint32_t)(stag / 12ull - (unsigned long long)g.c0), a = (uint32_t)(stag % 12ull);
+        const unsigned long long before = (unsigned long long)d.gblk[q / kScanTile] + d.gpre[q] + (unsigned long long)__popc((uint32_t)d.gmask[q] & ((1u << a) - 1u));
+        d.ctl[C_EXPANDED] += (unsigned long long)q + 1;
+        d.ctl[C_NODES_GLOBAL] = nodes_global + before;  // new states with a smaller tag
+        d.ctl[C_SOLVED_TAG] = stag;
+        d.ctl[C_STATUS] = 1;
+        *d.dec = dec;
+        return;
+    }
+    const unsigned long long nodes = d.ctl[C_NODES];
+    if (nodes + commit_local > (unsigned long long)d.cap_nodes) {
+        // refused BEFORE anything is written; the other ranks learn it from the headers of the next chunk (and the closing
+        // all-reduce of the orchestrator), so that everybody stops at the same chunk
+        atomicMax(d.ctl + C_FAIL_LOCAL, (unsigned long long)FAIL_NODES);
+    } else {
+        dec.commit = 1;
+        dec.cutoff = 12u * (p_end + 1);
+        dec.node_base = (uint32_t)nodes;
+        dec.gpos_base = (uint32_t)d.ctl[C_NEXT_COUNT];
+        d.ctl[C_NODES] = nodes + commit_local;
+    }
+    d.ctl[C_NEXT_COUNT] += commit_global;
+    d.ctl[C_NODES_GLOBAL] = nodes_global + commit_global;
+    d.ctl[C_EXPANDED] += (unsigned long long)p_end + 1;
+    if (budget_hit) d.ctl[C_STATUS] = 2;
+    *d.dec = dec;
 }
 
 // Winners with a tag below the cutoff become local nodes: id = base + (winners of this rank with a smaller tag), which the
-// per-parent masks give without a sort; gpos likewise from the all-reduced masks.  Their slot is rewritten to the node id.
-template <typename W>
-__global__ void __launch_bounds__(256) k_shard_commit(SearchDev<W> d, const int64_t* __restrict__ rec, int64_t n, int64_t tag0, int64_t cutoff,
-                                                      const int32_t* __restrict__ lmask, const int64_t* __restrict__ lprefix, const int32_t* __restrict__ gmask,
-                                                      const int64_t* __restrict__ gprefix, uint32_t base, int64_t gpos_base, const uint32_t* __restrict__ cslot,
-                                                      const uint8_t* __restrict__ took_i, int64_t* __restrict__ node_pref, uint32_t cap_nodes) {
+// per-parent masks give without a sort; gpos likewise from the all-reduced masks.  The stamp table is not touched.
+template <typename W> __global__ void __launch_bounds__(256) k_shard_commit(ShardDev<W> d, ChunkGeo g) {
     ACX_VGPR_PAD_W(W, "v39", "v47");
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !took_i[i]) return;
-    const int64_t* r = rec + i * (recio<W>::KW + 2);
-    const int64_t tag = r[recio<W>::KW];
-    const int64_t rel = tag - tag0, par = rel / 12;
-    if (tag >= cutoff || d.brepl[rel]) return;
-    const uint32_t below = (1u << (uint32_t)(rel % 12)) - 1u;
-    const uint32_t id = base + (uint32_t)lprefix[par] + (uint32_t)__popc((uint32_t)lmask[par] & below);
-    if (id >= cap_nodes) return;  // the host has refused this commit already (capacity): never reached
+    const ChunkDec dec = *d.dec;
+    if (!dec.commit) return;
+    const uint32_t r = blockIdx.y;
+    const int64_t roff = g.log_off + (int64_t)r * g.region_words;
+    const unsigned long long written = (unsigned long long)d.log[roff];
+    const uint32_t cnt = written > g.subcap ? g.subcap : (uint32_t)written;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const int64_t* rec = d.log + roff + kShardHdr + (int64_t)i * recio<W>::RW;
+    const unsigned long long x = (unsigned long long)rec[recio<W>::KW];
+    const uint32_t tag = (uint32_t)(x >> 32);
+    if (tag >= dec.cutoff) return;
+    const uint32_t par = tag / 12u, a = tag - 12u * par;
+    const uint32_t lm = (uint32_t)d.lmask[par];
+    if (!((lm >> a) & 1u)) return;
+    const uint32_t below = (1u << a) - 1u, tile = par / kScanTile;
+    const uint32_t id = dec.node_base + d.lblk[tile] + d.lpre[par] + (uint32_t)__popc(lm & below);
+    if (id >= d.cap_nodes) return;  // k_shard_decide has refused such a commit already: never reached
     W k0, k1;
-    recio<W>::get(r, k0, k1);
+    recio<W>::get(rec, k0, k1);
     d.k0[id] = k0;
     d.k1[id] = k1;
-    d.act[id] = (uint8_t)(tag % 12);
+    d.act[id] = (uint8_t)a;
     d.tlen[id] = (uint8_t)(keyops<W>::len(k0) + keyops<W>::len(k1));
-    d.depth[id] = (uint32_t)(gpos_base + gprefix[par] + __popc((uint32_t)gmask[par] & below));
-    node_pref[id] = r[recio<W>::KW + 1];
-    const uint64_t hk = hash_key<W>(k0, k1);
-    d.stab[cslot[i]] = (hk & ~((1ull << 37) - 1)) | (unsigned long long)id;
+    d.gpos[id] = dec.gpos_base + d.gblk[tile] + d.gpre[par] + (uint32_t)__popc((uint32_t)d.gmask[par] & below);
+    d.pref[id] = (int64_t)(((unsigned long long)(r / kShardSub) << 40) | (x & 0xFFFFFFFFull));
 }
 
-template <typename W> __global__ void k_shard_seed(SearchDev<W> d, W k0, W k1, int64_t* __restrict__ node_pref) {
+// root: local node 0 of its owner (global position 0 of level 0); its record sits at the start of the log
+template <typename W> __global__ void k_shard_seed(ShardDev<W> d, W k0, W k1) {
     ACX_VGPR_PAD("v23");
     d.k0[0] = k0;
     d.k1[0] = k1;
     d.act[0] = 0xff;
     d.tlen[0] = (uint8_t)(keyops<W>::len(k0) + keyops<W>::len(k1));
-    d.depth[0] = 0;
-    node_pref[0] = -1;
+    d.gpos[0] = 0;
+    d.pref[0] = -1;
+    recio<W>::put(d.log, k0, k1);
+    d.log[recio<W>::KW] = 0;
     const uint64_t hk = hash_key<W>(k0, k1);
-    d.stab[(uint32_t)hk & d.stmask & ~3u] = hk & ~((1ull << 37) - 1);  // committed stamp of node 0, first slot of its bucket
+    d.stab[(uint32_t)hk & d.stmask & ~3u] = hk & ~kStampOff;  // offset 0: first slot of its bucket
+    d.ctl[C_NODES] = 1;
 }
 
-template <typename W> __global__ void k_shard_find(SearchDev<W> d, uint32_t lvl_lo, uint32_t lvl_hi, uint32_t gpos, int64_t* __restrict__ out) {
+template <typename W> __global__ void k_shard_find(ShardDev<W> d, uint32_t gpos, int64_t* __restrict__ out) {
     ACX_VGPR_PAD("v23");
-    const uint32_t k = lower_gpos(d.depth, lvl_lo, lvl_hi, gpos);
-    *out = (k < lvl_hi && d.depth[k] == gpos) ? (int64_t)k : -1;
+    const uint32_t lo = (uint32_t)d.ctl[C_LVL_LO], hi = (uint32_t)d.ctl[C_LVL_HI];
+    const uint32_t k = lower_gpos(d.gpos, lo, hi, gpos);
+    *out = (k < hi && d.gpos[k] == gpos) ? (int64_t)k : -1;
 }
+
+// the engine's failure code, set from the host (an exception on the orchestrator's side of this rank)
+__global__ void k_shard_fail(unsigned long long* ctl, unsigned long long code) {
+    ACX_VGPR_PAD("v15");
+    atomicMax(ctl + C_FAIL_LOCAL, code);
+}
+
+constexpr int kCtlSlots = 4;
 
 template <typename W> struct ShardEngine {
-    SearchDev<W> d;
-    DevBuf nodes_buf, cand_buf, tab_buf, scal_buf;
-    int64_t* node_pref = nullptr;  // [cap] parent_ref of every local node
-    uint32_t* cslot = nullptr;     // [cap_cand] slot a record took
-    uint8_t* took_i = nullptr;     // [cap_cand] "took a slot", by record index
+    ShardDev<W> d;
+    DevBuf nodes_buf, chunk_buf, tab_buf, scal_buf;
     int64_t* d_find = nullptr;
-    uint32_t* d_bounds = nullptr;  // [2] frontier slice of the running chunk
-    uint64_t cap_nodes = 0, cap_cand = 0, n_slots = 0, chunk_tags = 0;
-    uint64_t nodes = 0;            // committed local nodes
-    uint64_t lvl_lo = 0, lvl_hi = 0;
-    int64_t pending = 0;           // records of the last insert (awaiting commit)
-    const int64_t* pending_rec = nullptr;
-    int64_t pending_tag0 = 0;
+    int64_t* d_send = nullptr;  // the caller's send buffer (null when world == 1: the chunk is expanded straight into the log)
+    uint64_t cap_nodes = 0, n_slots = 0, chunk_parents = 0, log_words = 0, send_words = 0;
+    int64_t log_off = 0;        // next free word of the log
+    ChunkGeo geo{};             // the running chunk
+    bool chunk_open = false;
+    uint64_t nodes_host = 0, lvl_lo_host = 0, lvl_hi_host = 0;  // what the last control-block snapshot said
     int rank = 0, world = 1;
     int move_mode = kMoveGeneral;  // acx_bfs.h: set from the root (acx_shard_root_record, which every rank calls)
+    unsigned long long* pinned = nullptr;  // kCtlSlots x C_WORDS
+    hipEvent_t ev[kCtlSlots] = {};
 
-    int init(int L, int cyclical, int64_t node_cap, int64_t batch_cap, int64_t chunk_parents, int rank_, int world_) {
+    ~ShardEngine() {
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
+        if (pinned) (void)hipHostFree(pinned);
+    }
+
+    int init(int L, int cyclical, int64_t node_cap, int64_t chunk_parents_, int rank_, int world_) {
         memset(&d, 0, sizeof(d));
         d.L = L;
         d.cyclical = cyclical;
+        d.world = (uint32_t)world_;
+        d.rank = (uint32_t)rank_;
         rank = rank_;
         world = world_;
         cap_nodes = (uint64_t)node_cap + 64;
-        cap_cand = (uint64_t)std::max<int64_t>(batch_cap, 1024);
-        chunk_tags = 12ull * (uint64_t)std::max<int64_t>(chunk_parents, 1);
+        chunk_parents = (uint64_t)std::max<int64_t>(chunk_parents_, 1);
+        int64_t subcap, region_words;
+        shard_layout((int64_t)chunk_parents, world, recio<W>::RW, &subcap, &region_words);
+        const uint64_t chunk_records = (uint64_t)subcap * kShardSub * (uint64_t)world;
         n_slots = 1024;
-        while (n_slots < 2 * (cap_nodes + cap_cand)) n_slots <<= 1;
+        while (n_slots < 2 * (cap_nodes + chunk_records)) n_slots <<= 1;
         if (n_slots > (1ull << 31) || cap_nodes > (1ull << 31)) return fail(ACX_E_INVAL, "acx_shard: capacity too large for 32-bit node ids");
         size_t o = 0;
         auto take = [&](uint8_t* base, size_t bytes) {
@@ -345,33 +706,46 @@ template <typename W> struct ShardEngine {
             o = 0;
             d.k0 = (W*)take(b, cap_nodes * sizeof(W));
             d.k1 = (W*)take(b, cap_nodes * sizeof(W));
-            node_pref = (int64_t*)take(b, cap_nodes * 8);
-            d.depth = (uint32_t*)take(b, cap_nodes * 4);
+            d.pref = (int64_t*)take(b, cap_nodes * 8);
+            d.gpos = (uint32_t*)take(b, cap_nodes * 4);
             d.act = (uint8_t*)take(b, cap_nodes);
             d.tlen = (uint8_t*)take(b, cap_nodes);
             if (pass == 0 && nodes_buf.alloc(o)) return ACX_E_NOMEM;
         }
+        const uint64_t n_tiles = (chunk_parents + kScanTile - 1) / kScanTile + 1;
+        size_t flag_bytes = 0;
         for (int pass = 0; pass < 2; pass++) {
-            uint8_t* b = (uint8_t*)cand_buf.p;
+            uint8_t* b = (uint8_t*)chunk_buf.p;
             o = 0;
-            cslot = (uint32_t*)take(b, cap_cand * 4);
-            took_i = take(b, cap_cand);
-            d.btook = take(b, chunk_tags);  // one byte per tag of a chunk
-            d.brepl = take(b, chunk_tags);
-            if (pass == 0 && cand_buf.alloc(o)) return ACX_E_NOMEM;
+            d.btook = take(b, 12 * chunk_parents + 16);
+            d.brepl = take(b, 12 * chunk_parents + 16);
+            flag_bytes = o;
+            d.lmask = (int32_t*)take(b, 4 * chunk_parents + 16);
+            d.lpre = (uint32_t*)take(b, 4 * chunk_parents + 16);
+            d.gpre = (uint32_t*)take(b, 4 * chunk_parents + 16);
+            d.lblk = (uint32_t*)take(b, 4 * n_tiles);
+            d.gblk = (uint32_t*)take(b, 4 * n_tiles);
+            if (pass == 0 && chunk_buf.alloc(o)) return ACX_E_NOMEM;
         }
         if (tab_buf.alloc(n_slots * 8)) return ACX_E_NOMEM;
         d.stab = (unsigned long long*)tab_buf.p;
         d.stmask = (uint32_t)(n_slots - 1);
-        if (scal_buf.alloc(256)) return ACX_E_NOMEM;
+        if (scal_buf.alloc(1024)) return ACX_E_NOMEM;
         uint8_t* sc = (uint8_t*)scal_buf.p;
-        d.err = (uint32_t*)(sc + 24);
-        d.min_len = (uint32_t*)(sc + 28);
-        d_find = (int64_t*)(sc + 64);
-        d_bounds = (uint32_t*)(sc + 96);
+        d.ctl = (unsigned long long*)sc;              // C_WORDS x 8 = 128 bytes
+        d.bounds = (uint32_t*)(sc + 256);
+        d.dec = (ChunkDec*)(sc + 320);
+        d_find = (int64_t*)(sc + 384);
+        d.cap_nodes = (uint32_t)cap_nodes;
         ACX_HIP_TRY(hipMemset(d.stab, 0xff, n_slots * 8));
-        ACX_HIP_TRY(hipMemset(scal_buf.p, 0xff, 256));
-        ACX_HIP_TRY(hipMemset(d.err, 0, 4));
+        ACX_HIP_TRY(hipMemset(chunk_buf.p, 0, flag_bytes));
+        ACX_HIP_TRY(hipMemset(scal_buf.p, 0, 1024));
+        const unsigned long long inf = kShardInf;
+        ACX_HIP_TRY(hipMemcpy(d.ctl + C_MIN_LEN, &inf, 8, hipMemcpyHostToDevice));
+        const unsigned long long one = 1;  // len(tree_nodes) counts the root, on every rank
+        ACX_HIP_TRY(hipMemcpy(d.ctl + C_NODES_GLOBAL, &one, 8, hipMemcpyHostToDevice));
+        ACX_HIP_TRY(hipHostMalloc((void**)&pinned, (size_t)kCtlSlots * C_WORDS * 8, hipHostMallocDefault));
+        for (auto& e : ev) ACX_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ACX_HIP_TRY(hipDeviceSynchronize());  // the fills run on the null stream; the engine's calls arrive on the caller's (possibly non-blocking) stream
         return ACX_OK;
     }
@@ -411,94 +785,128 @@ template <typename W> static int shard_root(ShardEngine<W>& E, const int8_t* pre
     return ACX_OK;
 }
 
+template <typename W> static int shard_attach(ShardEngine<W>& E, int64_t* log, int64_t log_words, int64_t* send, int64_t send_words, int32_t* gmask) {
+    if (!log || !gmask || log_words < 64 || (E.world > 1 && !send)) return fail(ACX_E_INVAL, "acx_shard_attach: bad argument");
+    if ((uint64_t)log_words > (1ull << 36)) return fail(ACX_E_INVAL, "acx_shard_attach: the log is limited to 2^36 words");
+    if (!E.d.log) E.log_off = 8;  // first attach; words 0 .. RW - 1: the root's record.  (A later attach hands over a LARGER log with the old content in front.)
+    else if ((uint64_t)log_words < E.log_words) return fail(ACX_E_INVAL, "acx_shard_attach: the log can only grow");
+    E.d.log = log;
+    E.log_words = (uint64_t)log_words;
+    E.d_send = E.world > 1 ? send : nullptr;
+    E.send_words = (uint64_t)send_words;
+    E.d.gmask = gmask;
+    return ACX_OK;
+}
+
 template <typename W> static int shard_seed(ShardEngine<W>& E, const int64_t* rec, hipStream_t st) {
-    if (E.nodes) return fail(ACX_E_INVAL, "acx_shard_seed: the engine already holds nodes");
+    if (!E.d.log) return fail(ACX_E_INVAL, "acx_shard_seed: call acx_shard_attach first");
+    if (E.nodes_host) return fail(ACX_E_INVAL, "acx_shard_seed: the engine already holds nodes");
     if (rec) {
         W k0, k1;
         recio<W>::get(rec, k0, k1);
-        hipLaunchKernelGGL(k_shard_seed<W>, dim3(1), dim3(1), 0, st, E.d, k0, k1, E.node_pref);
+        hipLaunchKernelGGL(k_shard_seed<W>, dim3(1), dim3(1), 0, st, E.d, k0, k1);
         ACX_HIP_TRY(hipGetLastError());
-        E.nodes = 1;
+        E.nodes_host = 1;
     }
     return ACX_OK;
 }
 
 template <typename W>
-static int shard_expand_routed(ShardEngine<W>& E, int64_t c0, int64_t c1, int64_t* rec, int64_t region_cap, int64_t* counts, int64_t* solved, hipStream_t st) {
-    ACX_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)E.world * 8, st));
-    if (E.world > 64) return fail(ACX_E_INVAL, "acx_shard_expand_routed handles world <= 64");
-    const int64_t np_max = std::min<int64_t>(c1 - c0, (int64_t)(E.lvl_hi - E.lvl_lo));
-    if (np_max <= 0) return ACX_OK;
-    const int64_t m = 12 * np_max;
-    hipLaunchKernelGGL(k_shard_bounds<W>, dim3(1), dim3(1), 0, st, E.d, (uint32_t)E.lvl_lo, (uint32_t)E.lvl_hi, (uint32_t)c0, (uint32_t)c1, E.d_bounds);
-    const dim3 grid((unsigned)((m + 1024 * kRouteItems - 1) / (1024 * kRouteItems)));
-#define ACX_SHARD_EXPAND(MODE)                                                                                                                           \
-    hipLaunchKernelGGL((k_shard_expand_routed<W, MODE>), grid, dim3(1024), 0, st, E.d, E.d_bounds, (int64_t)E.rank << 40, (uint32_t)E.world, rec, region_cap, \
-                       (unsigned long long*)counts, (unsigned long long*)solved)
-    if (E.move_mode == kMoveNf) {
-        ACX_SHARD_EXPAND(kMoveNf);
-    } else if (E.move_mode == kMoveNfCyclical) {
-        ACX_SHARD_EXPAND(kMoveNfCyclical);
-    } else {
-        ACX_SHARD_EXPAND(kMoveGeneral);
+static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int level_first, int64_t* recv_off, int64_t* words, hipStream_t st) {
+    if (!E.d.log) return fail(ACX_E_INVAL, "acx_shard_chunk_expand: call acx_shard_attach first");
+    const int64_t n_par = c1 - c0;
+    if (n_par < 1 || (uint64_t)n_par > E.chunk_parents) return fail(ACX_E_CAPACITY, "acx_shard_chunk_expand: a chunk of %lld parents exceeds the engine's %llu", (long long)n_par, (unsigned long long)E.chunk_parents);
+    if (c1 > (int64_t)0xFFFFFFFFll) return fail(ACX_E_INVAL, "acx_shard_chunk_expand: a level is limited to 2^32 - 1 positions");
+    int64_t subcap, region_words;
+    shard_layout(n_par, E.world, recio<W>::RW, &subcap, &region_words);
+    const int64_t total = region_words * kShardSub * E.world;
+    if (level_first) {  // the nodes committed since the previous switch are this rank's slice of the new level (host mirror; the device switches in k_shard_prep)
+        E.lvl_lo_host = E.lvl_hi_host;
+        E.lvl_hi_host = E.nodes_host;
     }
-#undef ACX_SHARD_EXPAND
+    E.geo.c0 = c0;
+    E.geo.n_par = (uint32_t)n_par;
+    E.geo.subcap = (uint32_t)subcap;
+    E.geo.region_words = (uint32_t)region_words;
+    E.geo.log_off = E.log_off;
+    *recv_off = E.log_off;
+    *words = total;
+    E.chunk_open = true;
+    int64_t* send = E.d_send ? E.d_send : E.d.log + E.log_off;
+    if ((uint64_t)(E.log_off + total) > E.log_words || (E.d_send && (uint64_t)total > E.send_words)) {
+        // no room to receive: this rank fails (sticky); the chunk still runs through the collectives with what the buffers hold
+        hipLaunchKernelGGL(k_shard_fail, dim3(1), dim3(1), 0, st, E.d.ctl, (unsigned long long)FAIL_REGION);
+        E.geo.log_off = E.log_off = 8;
+        *recv_off = 8;
+        if ((uint64_t)(8 + total) > E.log_words || (E.d_send && (uint64_t)total > E.send_words)) return fail(ACX_E_CAPACITY, "acx_shard_chunk_expand: the record log cannot take a single chunk");
+        send = E.d_send ? E.d_send : E.d.log + 8;
+    }
+    hipLaunchKernelGGL(k_shard_prep<W>, dim3(1), dim3(256), 0, st, E.d, E.geo, level_first, send);
+    const int64_t np_max = std::min<int64_t>(n_par, (int64_t)(E.lvl_hi_host - E.lvl_lo_host));
+    if (np_max > 0) {
+        const dim3 grid((unsigned)((12 * np_max + kExpandTile - 1) / kExpandTile));
+        if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_expand<W, kMoveNf>), grid, dim3(kExpandThreads), 0, st, E.d, E.geo, send);
+        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_expand<W, kMoveNfCyclical>), grid, dim3(kExpandThreads), 0, st, E.d, E.geo, send);
+        else hipLaunchKernelGGL((k_shard_expand<W, kMoveGeneral>), grid, dim3(kExpandThreads), 0, st, E.d, E.geo, send);
+    }
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
 
-template <typename W> static int shard_insert(ShardEngine<W>& E, const int64_t* rec, int64_t n, int64_t c0, int64_t n_parents, int32_t* lmask, hipStream_t st) {
-    E.pending = n;
-    E.pending_rec = rec;
-    E.pending_tag0 = 12 * c0;
-    if (n_parents < 0 || 12ull * (uint64_t)n_parents > E.chunk_tags)
-        return fail(ACX_E_CAPACITY, "acx_shard_insert: a chunk of %lld parents exceeds the engine's %llu", (long long)n_parents, (unsigned long long)(E.chunk_tags / 12));
-    if ((uint64_t)n > E.cap_cand) return fail(ACX_E_CAPACITY, "acx_shard_insert: %lld records exceed the batch capacity %llu", (long long)n, (unsigned long long)E.cap_cand);
-    if (n_parents <= 0) return ACX_OK;
-    const dim3 block(256);
-    ACX_HIP_TRY(hipMemsetAsync(E.d.btook, 0, (size_t)n_parents * 12, st));
-    ACX_HIP_TRY(hipMemsetAsync(E.d.brepl, 0, (size_t)n_parents * 12, st));
-    if (n > 0) hipLaunchKernelGGL(k_shard_insert<W>, dim3((unsigned)((n + 255) / 256)), block, 0, st, E.d, rec, n, E.pending_tag0, E.cslot, E.took_i);
-    hipLaunchKernelGGL(k_shard_pack<W>, dim3((unsigned)((n_parents + 255) / 256)), block, 0, st, E.d, n_parents, lmask);
+template <typename W> static int shard_chunk_insert(ShardEngine<W>& E, hipStream_t st) {
+    if (!E.chunk_open) return fail(ACX_E_INVAL, "acx_shard_chunk_insert: no chunk is open");
+    const dim3 grid((unsigned)((E.geo.subcap + 255) / 256), (unsigned)(kShardSub * E.world));
+    hipLaunchKernelGGL(k_shard_insert<W>, grid, dim3(256), 0, st, E.d, E.geo);
+    hipLaunchKernelGGL(k_shard_pack<W>, dim3((E.geo.n_par + 255) / 256), dim3(256), 0, st, E.d, E.geo.n_par);
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
 
-template <typename W>
-static int shard_commit(ShardEngine<W>& E, int64_t cutoff, const int32_t* lmask, const int64_t* lprefix, const int32_t* gmask, const int64_t* gprefix,
-                        int64_t gpos_base, int64_t n_commit, hipStream_t st) {
-    const int64_t n = E.pending;
-    E.pending = 0;
-    if (n_commit < 0) return fail(ACX_E_INVAL, "acx_shard_commit: negative count");
-    // checked BEFORE anything is written: an overfull rank must not touch memory behind its node arena
-    if (E.nodes + (uint64_t)n_commit > E.cap_nodes) return fail(ACX_E_CAPACITY, "acx_shard_commit: node capacity exceeded (%llu + %lld > %llu)",
-                                                                (unsigned long long)E.nodes, (long long)n_commit, (unsigned long long)E.cap_nodes);
-    if (n > 0 && n_commit > 0) {
-        hipLaunchKernelGGL(k_shard_commit<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, E.d, E.pending_rec, n, E.pending_tag0, cutoff, lmask, lprefix, gmask,
-                           gprefix, (uint32_t)E.nodes, gpos_base, E.cslot, E.took_i, E.node_pref, (uint32_t)E.cap_nodes);
-        ACX_HIP_TRY(hipGetLastError());
-    }
-    E.nodes += (uint64_t)n_commit;
+template <typename W> static int shard_chunk_commit(ShardEngine<W>& E, int64_t max_nodes, hipStream_t st) {
+    if (!E.chunk_open) return fail(ACX_E_INVAL, "acx_shard_chunk_commit: no chunk is open");
+    E.chunk_open = false;
+    hipLaunchKernelGGL(k_shard_scan<W>, dim3((E.geo.n_par + kScanTile - 1) / kScanTile), dim3(1024), 0, st, E.d, E.geo.n_par);
+    hipLaunchKernelGGL(k_shard_decide<W>, dim3(1), dim3(1024), 0, st, E.d, E.geo, max_nodes);
+    const dim3 grid((unsigned)((E.geo.subcap + 255) / 256), (unsigned)(kShardSub * E.world));
+    hipLaunchKernelGGL(k_shard_commit<W>, grid, dim3(256), 0, st, E.d, E.geo);
+    ACX_HIP_TRY(hipGetLastError());
+    E.log_off = E.geo.log_off + (int64_t)E.geo.region_words * kShardSub * E.world;
+    return ACX_OK;
+}
+
+template <typename W> static int shard_ctl_snapshot(ShardEngine<W>& E, int slot, hipStream_t st) {
+    ACX_HIP_TRY(hipMemcpyAsync(E.pinned + (size_t)slot * C_WORDS, E.d.ctl, C_WORDS * 8, hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipEventRecord(E.ev[slot], st));
+    return ACX_OK;
+}
+
+template <typename W> static int shard_ctl_wait(ShardEngine<W>& E, int slot, int64_t* out) {
+    ACX_HIP_TRY(hipEventSynchronize(E.ev[slot]));
+    const unsigned long long* p = E.pinned + (size_t)slot * C_WORDS;
+    for (int k = 0; k < C_WORDS; k++) out[k] = (int64_t)p[k];
+    E.nodes_host = p[C_NODES];  // (the level bounds of the host mirror follow at the next level switch)
     return ACX_OK;
 }
 
 template <typename W> static int shard_find(ShardEngine<W>& E, int64_t gpos, int64_t* id, hipStream_t st) {
     *id = -1;
-    if (E.lvl_hi == E.lvl_lo || gpos < 0) return ACX_OK;
-    hipLaunchKernelGGL(k_shard_find<W>, dim3(1), dim3(1), 0, st, E.d, (uint32_t)E.lvl_lo, (uint32_t)E.lvl_hi, (uint32_t)gpos, E.d_find);
+    if (gpos < 0 || gpos > (int64_t)0xFFFFFFFFll) return ACX_OK;
+    hipLaunchKernelGGL(k_shard_find<W>, dim3(1), dim3(1), 0, st, E.d, (uint32_t)gpos, E.d_find);
     ACX_HIP_TRY(hipMemcpyAsync(id, E.d_find, 8, hipMemcpyDeviceToHost, st));
     ACX_HIP_TRY(hipStreamSynchronize(st));
     return ACX_OK;
 }
 
 template <typename W> static int shard_node_info(ShardEngine<W>& E, int64_t id, int64_t* info) {
-    if (id < 0 || (uint64_t)id >= E.nodes) return fail(ACX_E_INVAL, "acx_shard_node_info: id out of range");
+    ACX_HIP_TRY(hipDeviceSynchronize());
+    unsigned long long n = 0;
+    ACX_HIP_TRY(hipMemcpy(&n, E.d.ctl + C_NODES, 8, hipMemcpyDeviceToHost));
+    if (id < 0 || (uint64_t)id >= n) return fail(ACX_E_INVAL, "acx_shard_node_info: id out of range");
     uint8_t a = 0, l = 0;
     int64_t pr = 0;
-    ACX_HIP_TRY(hipDeviceSynchronize());
     ACX_HIP_TRY(hipMemcpy(&a, E.d.act + id, 1, hipMemcpyDeviceToHost));
     ACX_HIP_TRY(hipMemcpy(&l, E.d.tlen + id, 1, hipMemcpyDeviceToHost));
-    ACX_HIP_TRY(hipMemcpy(&pr, E.node_pref + id, 8, hipMemcpyDeviceToHost));
+    ACX_HIP_TRY(hipMemcpy(&pr, E.d.pref + id, 8, hipMemcpyDeviceToHost));
     info[0] = pr < 0 ? -1 : (int64_t)a;
     info[1] = l;
     info[2] = pr;
@@ -518,10 +926,17 @@ extern "C" {
 
 int acx_shard_key_words(int L) { return L <= 29 ? 2 : 4; }
 
-acx_shard* acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t batch_cap, int64_t chunk_parents, int rank, int world) {
+int acx_shard_layout(int64_t n_parents, int world, int key_words, int64_t* subregions, int64_t* subcap, int64_t* region_words) {
+    if (n_parents < 1 || world < 1 || (key_words != 2 && key_words != 4) || !subregions || !subcap || !region_words) return fail(ACX_E_INVAL, "acx_shard_layout: bad argument");
+    *subregions = kShardSub;
+    shard_layout(n_parents, world, key_words + 1, subcap, region_words);
+    return ACX_OK;
+}
+
+acx_shard* acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t chunk_parents, int rank, int world) {
     if (!have_device()) return nullptr;
-    if (L < 1 || L > 61 || node_cap < 1 || batch_cap < 1 || chunk_parents < 1 || world < 1 || rank < 0 || rank >= world) {
-        fail(ACX_E_INVAL, "acx_shard_create: bad argument (1 <= L <= 61)");
+    if (L < 1 || L > 61 || node_cap < 1 || chunk_parents < 1 || chunk_parents > (1ll << 27) || world < 1 || world > 64 || rank < 0 || rank >= world) {
+        fail(ACX_E_INVAL, "acx_shard_create: bad argument (1 <= L <= 61, world <= 64, chunk_parents <= 2^27)");
         return nullptr;
     }
     acx_shard* h = new (std::nothrow) acx_shard();
@@ -530,10 +945,10 @@ acx_shard* acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t batch
     int rc;
     if (h->any.wide) {
         h->any.e128 = new ShardEngine<u128>();
-        rc = h->any.e128->init(L, cyclical, node_cap, batch_cap, chunk_parents, rank, world);
+        rc = h->any.e128->init(L, cyclical, node_cap, chunk_parents, rank, world);
     } else {
         h->any.e64 = new ShardEngine<uint64_t>();
-        rc = h->any.e64->init(L, cyclical, node_cap, batch_cap, chunk_parents, rank, world);
+        rc = h->any.e64->init(L, cyclical, node_cap, chunk_parents, rank, world);
     }
     if (rc != ACX_OK) {
         delete h->any.e64;
@@ -551,6 +966,11 @@ void acx_shard_destroy(acx_shard* h) {
     delete h;
 }
 
+int acx_shard_attach(acx_shard* h, int64_t* d_log, int64_t log_words, int64_t* d_send, int64_t send_words, int32_t* d_gmask) {
+    if (!h) return fail(ACX_E_INVAL, "acx_shard_attach: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, return shard_attach<W>(E, d_log, log_words, d_send, send_words, d_gmask));
+}
+
 int acx_shard_root_record(acx_shard* h, const int8_t* h_presentation, int64_t* h_record) {
     if (!h || !h_presentation || !h_record) return fail(ACX_E_INVAL, "acx_shard_root_record: bad argument");
     ACX_SHARD_DISPATCH(&h->any, return shard_root<W>(E, h_presentation, h_record));
@@ -561,32 +981,38 @@ int acx_shard_seed(acx_shard* h, const int64_t* h_record, void* stream) {
     ACX_SHARD_DISPATCH(&h->any, return shard_seed<W>(E, h_record, (hipStream_t)stream));
 }
 
-int acx_shard_level_begin(acx_shard* h, int64_t* n_local) {
-    if (!h) return fail(ACX_E_INVAL, "acx_shard_level_begin: bad argument");
+int acx_shard_chunk_expand(acx_shard* h, int64_t c0, int64_t c1, int level_first, int64_t* recv_off, int64_t* words, void* stream) {
+    if (!h || c0 < 0 || c1 <= c0 || !recv_off || !words) return fail(ACX_E_INVAL, "acx_shard_chunk_expand: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, return shard_chunk_expand<W>(E, c0, c1, level_first, recv_off, words, (hipStream_t)stream));
+}
+
+int acx_shard_chunk_insert(acx_shard* h, void* stream) {
+    if (!h) return fail(ACX_E_INVAL, "acx_shard_chunk_insert: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, return shard_chunk_insert<W>(E, (hipStream_t)stream));
+}
+
+int acx_shard_chunk_commit(acx_shard* h, int64_t max_nodes, void* stream) {
+    if (!h) return fail(ACX_E_INVAL, "acx_shard_chunk_commit: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, return shard_chunk_commit<W>(E, max_nodes, (hipStream_t)stream));
+}
+
+int acx_shard_ctl_snapshot(acx_shard* h, int slot, void* stream) {
+    if (!h || slot < 0 || slot >= kCtlSlots) return fail(ACX_E_INVAL, "acx_shard_ctl_snapshot: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, return shard_ctl_snapshot<W>(E, slot, (hipStream_t)stream));
+}
+
+int acx_shard_ctl_wait(acx_shard* h, int slot, int64_t* h_ctl) {
+    if (!h || slot < 0 || slot >= kCtlSlots || !h_ctl) return fail(ACX_E_INVAL, "acx_shard_ctl_wait: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, return shard_ctl_wait<W>(E, slot, h_ctl));
+}
+
+int acx_shard_fail(acx_shard* h, void* stream) {
+    if (!h) return fail(ACX_E_INVAL, "acx_shard_fail: bad argument");
     ACX_SHARD_DISPATCH(&h->any, {
-        E.lvl_lo = E.lvl_hi;
-        E.lvl_hi = E.nodes;
-        if (n_local) *n_local = (int64_t)(E.lvl_hi - E.lvl_lo);
+        hipLaunchKernelGGL(k_shard_fail, dim3(1), dim3(1), 0, (hipStream_t)stream, E.d.ctl, (unsigned long long)FAIL_HOST);
+        ACX_HIP_TRY(hipGetLastError());
     });
     return ACX_OK;
-}
-
-int acx_shard_expand_routed(acx_shard* h, int64_t c0, int64_t c1, int64_t* d_records, int64_t region_cap, int64_t* d_counts, int64_t* d_solved, void* stream) {
-    if (!h || c0 < 0 || c1 < c0 || region_cap < 0 || !d_counts || !d_solved || (region_cap > 0 && !d_records))
-        return fail(ACX_E_INVAL, "acx_shard_expand_routed: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_expand_routed<W>(E, c0, c1, d_records, region_cap, d_counts, d_solved, (hipStream_t)stream));
-}
-
-int acx_shard_insert(acx_shard* h, const int64_t* d_records, int64_t n, int64_t c0, int64_t n_parents, int32_t* d_child_mask, void* stream) {
-    if (!h || n < 0 || c0 < 0 || (n > 0 && !d_records) || (n_parents > 0 && !d_child_mask)) return fail(ACX_E_INVAL, "acx_shard_insert: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_insert<W>(E, d_records, n, c0, n_parents, d_child_mask, (hipStream_t)stream));
-}
-
-int acx_shard_commit(acx_shard* h, int64_t cutoff_tag, const int32_t* d_local_mask, const int64_t* d_local_prefix, const int32_t* d_global_mask,
-                     const int64_t* d_global_prefix, int64_t gpos_base, int64_t n_commit, void* stream) {
-    if (!h || (n_commit > 0 && (!d_local_mask || !d_local_prefix || !d_global_mask || !d_global_prefix))) return fail(ACX_E_INVAL, "acx_shard_commit: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_commit<W>(E, cutoff_tag, d_local_mask, d_local_prefix, d_global_mask, d_global_prefix, gpos_base, n_commit,
-                                                       (hipStream_t)stream));
 }
 
 int acx_shard_find(acx_shard* h, int64_t gpos, int64_t* id, void* stream) {
@@ -597,21 +1023,6 @@ int acx_shard_find(acx_shard* h, int64_t gpos, int64_t* id, void* stream) {
 int acx_shard_node_info(acx_shard* h, int64_t id, int64_t* h_info3) {
     if (!h || !h_info3) return fail(ACX_E_INVAL, "acx_shard_node_info: bad argument");
     ACX_SHARD_DISPATCH(&h->any, return shard_node_info<W>(E, id, h_info3));
-}
-
-int64_t acx_shard_node_count(acx_shard* h) {
-    if (!h) return 0;
-    return h->any.wide ? (int64_t)h->any.e128->nodes : (int64_t)h->any.e64->nodes;
-}
-
-int acx_shard_status(acx_shard* h, int32_t* err, int32_t* min_len) {
-    if (!h || !err || !min_len) return fail(ACX_E_INVAL, "acx_shard_status: bad argument");
-    uint32_t v[2];
-    ACX_HIP_TRY(hipDeviceSynchronize());
-    ACX_SHARD_DISPATCH(&h->any, ACX_HIP_TRY(hipMemcpy(v, E.d.err, 8, hipMemcpyDeviceToHost)));
-    *err = (int32_t)v[0];
-    *min_len = (int32_t)v[1];
-    return ACX_OK;
 }
 
 }  // extern "C"

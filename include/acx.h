@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACX_VERSION 202
+#define ACX_VERSION 300
 
 /* return codes */
 #define ACX_OK 0
@@ -179,52 +179,70 @@ int acx_search_many(int kind, const int8_t *h_presentations, int64_t n, int L, i
                     int64_t *path_n, acx_search_stats *stats, int32_t *rc_out);
 
 /* ---- sharded BFS frontier (one engine per GPU) ---------------------------------------------------
- * The multi-GPU form of bfs (breadth_first.py:15-97): states are partitioned by hash(key) mod world, the
- * host exchanges candidate records between ranks (RCCL all-to-all) and these calls do the per-rank work.
- * A record is acx_shard_key_words(L) + 2 int64: the packed key, tag = 12 * global_parent_position + action
- * (the order in which the reference generates children), parent_ref = rank << 40 | local node id.
- * The engine keeps its slice of the frontier on the device: the nodes it commits during a level are the next
- * level, in global FIFO order.  A level is processed in chunks of consecutive global positions [c0, c1).
- * Orchestration and the cross-rank numbering live in ac-solver_amd/ac_solver/search/sharded.py. */
+ * The multi-GPU form of bfs (breadth_first.py:15-97): states are partitioned by hash(key) mod world.  A level is processed
+ * in chunks of consecutive global frontier positions [c0, c1); per chunk every rank calls
+ *     acx_shard_chunk_expand  -> all-to-all of the send buffer into the receive area  (RCCL; nothing at world 1)
+ *     acx_shard_chunk_insert  -> all-reduce (sum) of the child masks                   (RCCL; nothing at world 1)
+ *     acx_shard_chunk_commit
+ * and nothing is read back in between: the budget / success / error decisions of the reference (breadth_first.py:84-95) are
+ * taken on the device, identically on every rank, and land in the CONTROL BLOCK, which the host reads a few chunks late
+ * (acx_shard_ctl_snapshot / acx_shard_ctl_wait).  Once its status word leaves 0 every later call is a no-op on the device.
+ * Orchestration: ac-solver_amd/ac_solver/search/sharded.py.
+ *
+ * Buffers (device memory of the CALLER, e.g. torch tensors, handed over once with acx_shard_attach):
+ *   log    int64[log_words]: the record log.  The receive area of a chunk is the slice [recv_off, recv_off + words) that
+ *          acx_shard_chunk_expand returns; it is never recycled (a visited-table slot names its state by the offset of the
+ *          record that claimed it).  At world 1 the chunk is expanded straight into it.
+ *   send   int64[send_words] (world > 1): the chunk's send buffer, `words` long, same layout.
+ *   gmask  int32[chunk_parents]: one 12-bit mask per parent of the chunk -- bit a set when child (parent, a) is a new state
+ *          owned by this rank; the caller all-reduces (sum == or) its first c1 - c0 entries between insert and commit.
+ * Layout of a chunk's `words`: world * S regions (region d * S + s = sub-region s for / from rank d; S, subcap, region_words from
+ * acx_shard_layout), each = 4 header words [records written, smallest tag of a length-2 child, smallest (tag << 8 | code) of a
+ * raising move, the sender's failure code] + subcap records of key_words + 1 int64: the packed key, then
+ * parent's local id | (12 * (global parent position - c0) + action) << 32.  An all-to-all with equal splits of
+ * S * region_words int64 per rank delivers it. */
 typedef struct acx_shard acx_shard;
 int acx_shard_key_words(int L); /* 2 for L <= 29, 4 for L <= 61 */
-/* node_cap: local nodes; batch_cap: records this rank may receive per chunk; chunk_parents: global parents per chunk */
-acx_shard *acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t batch_cap, int64_t chunk_parents, int rank,
-                            int world);
+/* geometry of a chunk of n_parents global parents (pure host arithmetic, no device needed) */
+int acx_shard_layout(int64_t n_parents, int world, int key_words, int64_t *subregions, int64_t *subcap, int64_t *region_words);
+/* node_cap: local nodes; chunk_parents: the largest chunk (global parents) */
+acx_shard *acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t chunk_parents, int rank, int world);
 void acx_shard_destroy(acx_shard *h);
-/* the root as a record (tag 0, parent_ref -1), host buffer of key_words + 2 int64 */
+int acx_shard_attach(acx_shard *h, int64_t *d_log, int64_t log_words, int64_t *d_send, int64_t send_words, int32_t *d_gmask);
+/* the root as a record (tag 0, parent_ref -1), host buffer of key_words + 2 int64; every rank calls it (it also selects
+ * the move code of the search from the root's form) */
 int acx_shard_root_record(acx_shard *h, const int8_t *h_presentation, int64_t *h_record);
 /* the owner of the root passes its record (local node 0, global position 0), every other rank NULL */
 int acx_shard_seed(acx_shard *h, const int64_t *h_record, void *stream);
-/* the nodes committed since the previous call become the current level; *n_local (nullable) = how many */
-int acx_shard_level_begin(acx_shard *h, int64_t *n_local);
-/* children of the local nodes of the current level whose global positions lie in [c0, c1), already routed: a child
- * whose key belongs to rank o (owner = the hash of ac_solver/search/sharded.py:owner_of, mod world) is written to
- * d_records[(o * region_cap + i) * (key_words + 2)], i < d_counts[o] (device int64[world], any order inside a region);
- * d_counts[o] > region_cap reports an overflow.  Children equal to their parent are not sent (visited by construction).
- * d_solved (int64[2]): [0] is min-combined with the tags of children of total length 2, [1] with tag << 8 | code of the
- * moves on which the reference's ACMove raises (a relator emptied): the search raises if such a move precedes its end */
-int acx_shard_expand_routed(acx_shard *h, int64_t c0, int64_t c1, int64_t *d_records, int64_t region_cap,
-                            int64_t *d_counts, int64_t *d_solved, void *stream);
-/* exact dedup of n received records of the chunk starting at global parent c0 (any order) against the visited table and
- * among themselves (minimum tag wins).  d_child_mask (int32[n_parents], written): bit a of entry p - c0 is set when
- * child (p, a) is a new state owned by this rank.  The records must stay valid until acx_shard_commit. */
-int acx_shard_insert(acx_shard *h, const int64_t *d_records, int64_t n, int64_t c0, int64_t n_parents,
-                     int32_t *d_child_mask, void *stream);
-/* the new states with tag < cutoff_tag become local nodes, in tag order.  d_local_mask is what acx_shard_insert wrote,
- * d_global_mask its sum over the ranks; the *_prefix arrays (int64[n_parents]) hold the exclusive running popcounts of
- * the masks; gpos_base = new states of the level before this chunk; n_commit = this rank's new states below the cutoff
- * (the orchestrator knows it from the local mask).  ACX_E_CAPACITY, before anything is written, when they do not fit. */
-int acx_shard_commit(acx_shard *h, int64_t cutoff_tag, const int32_t *d_local_mask, const int64_t *d_local_prefix,
-                     const int32_t *d_global_mask, const int64_t *d_global_prefix, int64_t gpos_base, int64_t n_commit,
-                     void *stream);
-/* local id of the node of the current level at global position gpos, -1 when another rank owns it */
+/* children of the local nodes of the running level whose global positions lie in [c0, c1), routed to their owners (children
+ * equal to their parent, children that undo their parent's move in a normal-form search with cyclical = 0, and duplicates
+ * inside a workgroup are never sent).  level_first != 0 on the first chunk of a level: the nodes committed during the previous
+ * level become the running one. */
+int acx_shard_chunk_expand(acx_shard *h, int64_t c0, int64_t c1, int level_first, int64_t *recv_off, int64_t *words, void *stream);
+/* exact dedup of what the receive area holds against the visited table and among itself (minimum tag wins) -> gmask */
+int acx_shard_chunk_insert(acx_shard *h, void *stream);
+/* decisions + the new states below the cutoff become local nodes, in tag order (max_nodes = max_nodes_to_explore) */
+int acx_shard_chunk_commit(acx_shard *h, int64_t max_nodes, void *stream);
+/* control block: ACX_SHARD_CTL_WORDS int64 */
+#define ACX_SHARD_CTL_WORDS 16
+#define ACX_SHARD_CTL_STATUS 0       /* 0 running, 1 solved, 2 budget reached, 3 a move raised (AssertionError), 4 a rank failed */
+#define ACX_SHARD_CTL_NODES_GLOBAL 1 /* len(tree_nodes) */
+#define ACX_SHARD_CTL_NEXT_COUNT 2   /* new states of the running level so far */
+#define ACX_SHARD_CTL_EXPANDED 3     /* parents expanded */
+#define ACX_SHARD_CTL_SOLVED_TAG 4   /* 12 * global position + action of the child that ended the search */
+#define ACX_SHARD_CTL_NODES 5        /* local nodes */
+#define ACX_SHARD_CTL_FAIL_LOCAL 8   /* this rank's failure code: 1 region / log overflow, 2 node capacity, 3 table full, 4 host */
+#define ACX_SHARD_CTL_MIN_LEN 9      /* smallest total length this rank generated */
+#define ACX_SHARD_CTL_FAIL_SEEN 10   /* failure code received from some rank (status 4) */
+/* queue a copy of the control block into pinned slot `slot` (0..3) behind the work queued so far / wait for it */
+int acx_shard_ctl_snapshot(acx_shard *h, int slot, void *stream);
+int acx_shard_ctl_wait(acx_shard *h, int slot, int64_t *h_ctl);
+/* mark this rank as failed (an exception on the caller's side): travels to every rank with the next chunk's headers */
+int acx_shard_fail(acx_shard *h, void *stream);
+/* local id of the node of the running level at global position gpos, -1 when another rank owns it */
 int acx_shard_find(acx_shard *h, int64_t gpos, int64_t *id, void *stream);
-/* h_info3 = (action, total_length, parent_ref) of a local node; the root has action -1, parent_ref -1 */
+/* h_info3 = (action, total_length, parent_ref = rank << 40 | local id) of a local node; the root has action -1, parent_ref -1 */
 int acx_shard_node_info(acx_shard *h, int64_t id, int64_t *h_info3);
-int64_t acx_shard_node_count(acx_shard *h);
-/* sticky move-error bits (a move emptied a relator: the reference raises) and the smallest total length seen */
-int acx_shard_status(acx_shard *h, int32_t *err, int32_t *min_len);
 
 /* ---- PPO rollout: fused policy inference ---------------------------------------------------------------
  * The agent of ac_solver/agents/ppo_agent.py:11-109 -- actor and critic, each in_dim -> 256 -> 256 -> {n_actions, 1} with

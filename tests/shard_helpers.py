@@ -1,7 +1,8 @@
 """Test infrastructure for the sharded BFS orchestrator (ac_solver/search/sharded.py):
 
-* OracleShardEngine -- the per-rank engine interface implemented with NumPy + the CPU oracle, so that the
-  orchestration (routing, global numbering, budget / success decisions, path walk) can be exercised on CPU
+* OracleShardEngine -- the per-rank engine interface implemented with NumPy + the CPU oracle, in the SAME buffer
+  formats as the HIP engine (fixed-size regions with headers, the record log, the control block), so that the
+  orchestration (equal-split all-to-all, mask all-reduce, lagged control block, path walk) can be exercised on CPU
   with torch.distributed's gloo backend.  Never used by the product.
 * ThreadComm -- an in-process communicator: several ranks run as threads of one process (one GPU can then
   play all ranks of the HIP engine in the GPU tests).
@@ -15,6 +16,20 @@ from oracle import ac_oracle as O
 
 _CODE = {-2: 0, -1: 1, 1: 2, 2: 3}
 _LETTER = {0: -2, 1: -1, 2: 1, 3: 2}
+INF = 1 << 62
+HDR, SUB, TILE = 4, 16, 1024  # header words, sub-regions per destination, children per workgroup (csrc/acx_shard.hip)
+_INVERSE = {0: 2, 2: 0, 1: 3, 3: 1, 4: 8, 8: 4, 5: 9, 9: 5, 6: 10, 10: 6, 7: 11, 11: 7}
+
+
+def layout(n_par, world, KW):
+    """Python mirror of shard_layout (csrc/acx_shard.hip); tests/test_sharded_cpu.py checks it against acx_shard_layout"""
+    n_blocks = -(-12 * n_par // TILE)
+    hard = -(-n_blocks // SUB) * TILE
+    cap = hard
+    if world > 1:
+        even = -(-12 * n_par // (world * world * SUB))
+        cap = min(hard, even + even // 4 + 2 * TILE)
+    return SUB, cap, HDR + cap * (KW + 1)
 
 
 def pack_word(word):
@@ -44,31 +59,52 @@ def state_of_key(k0, k1, L):
     return row
 
 
+def is_normal_form(state, L, cyclical):
+    for h in (0, 1):
+        w = [int(a) for a in state[h * L:(h + 1) * L] if a != 0]
+        if not w or any(w[i] == -w[i + 1] for i in range(len(w) - 1)):
+            return False
+        if cyclical and len(w) >= 2 and w[0] == -w[-1]:
+            return False
+    return True
+
+
 class OracleShardEngine:
-    """The engine interface of ac_solver/search/sharded.py (seed / level_begin / expand_routed / insert / commit / find /
-    node_info / status) on the CPU: NumPy + the C oracle's ACMove.  Test infrastructure only."""
+    """The engine interface of ac_solver/search/sharded.py on the CPU: NumPy + the C oracle's ACMove.  Test infrastructure only."""
 
-    KW = 2
+    KW, RW = 2, 3
 
-    def __init__(self, L, cyclical, node_cap, batch_cap, chunk_parents, rank, world):
+    def __init__(self, L, cyclical, node_cap, chunk_parents, rank, world, est_parents):
         assert L <= 29
         self.L, self.cyc, self.rank, self.world = L, bool(cyclical), rank, world
-        self.batch_cap, self.node_cap = batch_cap, node_cap
+        self.node_cap, self.B = node_cap + 64, chunk_parents
         self.device = torch.device("cpu")
         self.states, self.prefs, self.acts, self.tlens, self.gpos = [], [], [], [], []
-        self.visited = {}
-        self.pending = []
+        self.visited = set()
         self.lvl_lo = self.lvl_hi = 0
-        self.err = 0
-        self.min_len = 1 << 30
+        self.ctl = np.zeros(16, np.int64)
+        self.ctl[9] = INF
+        self.ctl[1] = 1  # len(tree_nodes) counts the root on every rank
+        self.snap = {}
+        self.nf = False
+        self.inverse_dropped = 0
+
+    def layout(self, n_par):
+        return layout(n_par, self.world, self.KW)
+
+    def layout_words(self, n_par):
+        s, _, rw = self.layout(n_par)
+        return s * self.world * rw
 
     def root_record(self, p):
-        k0, k1 = key_of_state(np.asarray(p), self.L)
+        p = np.asarray(p)
+        k0, k1 = key_of_state(p, self.L)
+        self.nf = is_normal_form(p, self.L, self.cyc)  # the HIP engine drops "undo" children only in normal-form searches, cyclical = False
         return np.array([k0, k1, 0, -1], np.int64)
 
     def _add(self, k0, k1, act, pref, gpos):
         st = state_of_key(k0, k1, self.L)
-        self.visited[(k0, k1)] = len(self.states)
+        self.visited.add((k0, k1))
         self.states.append(st)
         self.prefs.append(pref)
         self.acts.append(act)
@@ -77,67 +113,158 @@ class OracleShardEngine:
 
     def seed(self, record):
         if record is not None:
-            self._add(int(record[0]), int(record[1]), 0, -1, 0)
+            self._add(int(record[0]), int(record[1]), 0xff, -1, 0)
+            self.ctl[5] = 1
 
-    def level_begin(self):
-        self.lvl_lo, self.lvl_hi = self.lvl_hi, len(self.states)
-        return self.lvl_hi - self.lvl_lo
-
-    def expand_routed(self, c0, c1, n_local, solved, world):
+    def chunk_expand(self, c0, c1, level_first):
         from ac_solver.search.sharded import owner_of
 
-        rows = []
-        for nid in range(self.lvl_lo, self.lvl_hi):
+        n_par = c1 - c0
+        S, cap, rw = self.layout(n_par)
+        self.geo = (c0, n_par, S, cap, rw)
+        send = torch.zeros(S * self.world * rw, dtype=torch.int64)
+        recv = torch.zeros_like(send) if self.world > 1 else send
+        self.recv = recv
+        if self.ctl[0] != 0:
+            return send, recv
+        if level_first:
+            self.lvl_lo, self.lvl_hi = self.lvl_hi, len(self.states)
+            self.ctl[2] = 0
+        regs = send.view(S * self.world, rw)
+        regs[:, 1] = INF
+        regs[:, 2] = INF
+        regs[:, 3] = int(self.ctl[8])
+        local = [nid for nid in range(self.lvl_lo, self.lvl_hi) if c0 <= self.gpos[nid] < c1]
+        solved = err = INF
+        for li, nid in enumerate(local):
             gp = self.gpos[nid]
-            if not c0 <= gp < c1:
-                continue
             st = np.repeat(self.states[nid][None], 12, axis=0)
-            out, lens, err = O.move_batch(st, np.arange(12, dtype=np.uint8), self.L, cyclical=self.cyc)
+            out, lens, errs = O.move_batch(st, np.arange(12, dtype=np.uint8), self.L, cyclical=self.cyc)
             for a in range(12):
                 tag = 12 * gp + a
-                if err[a]:
-                    solved[1] = min(int(solved[1]), (tag << 8) | int(err[a]))
+                if errs[a]:
+                    err = min(err, (tag << 8) | int(errs[a]))
                 tl = int(lens[a].sum())
-                self.min_len = min(self.min_len, tl)
+                self.ctl[9] = min(int(self.ctl[9]), tl)
                 if tl == 2:
-                    solved[0] = min(int(solved[0]), tag)
+                    solved = min(solved, tag)
                 if np.array_equal(out[a], self.states[nid]):
                     continue  # an unchanged child is its (visited) parent: never sent
+                if self.nf and not self.cyc and self.acts[nid] < 12 and a == _INVERSE[self.acts[nid]]:
+                    # the HIP engine does not send this child: it must be the parent's own tree parent, a visited state
+                    assert key_of_state(out[a], self.L) in self.visited or self._is_parent_of(nid, out[a])
+                    self.inverse_dropped += 1
+                    continue
                 k0, k1 = key_of_state(out[a], self.L)
-                rows.append([k0, k1, tag, (self.rank << 40) | nid])
-        recs = torch.tensor(rows, dtype=torch.int64).reshape(-1, 4)
-        owners = owner_of(recs[:, :2], world) if len(rows) else torch.zeros(0, dtype=torch.int64)
-        return [recs[owners == o].contiguous() for o in range(world)]
+                o = int(owner_of(torch.tensor([[k0, k1]], dtype=torch.int64), self.world)[0])
+                sub = ((12 * li + a) // TILE) % S
+                reg = regs[o * S + sub]
+                n = int(reg[0])
+                assert n < cap
+                reg[HDR + n * 3: HDR + n * 3 + 3] = torch.tensor([k0, k1, ((tag - 12 * c0) << 32) | nid], dtype=torch.int64)
+                reg[0] = n + 1
+        regs[:, 1] = torch.minimum(regs[:, 1], torch.tensor(solved))
+        regs[:, 2] = torch.minimum(regs[:, 2], torch.tensor(err))
+        return send, recv
 
-    def insert(self, recv, c0, n_parents):
-        recs = sorted(recv.tolist(), key=lambda r: r[2])
-        seen, self.pending = set(), []
-        mask = torch.zeros(n_parents, dtype=torch.int32)
-        for k0, k1, tag, pref in recs:
+    def _is_parent_of(self, nid, state):
+        """the tree parent of a local node lives on rank prefs[nid] >> 40; when it is local its state can be compared"""
+        pref = self.prefs[nid]
+        return pref >= 0 and (pref >> 40 != self.rank or np.array_equal(self.states[pref & ((1 << 40) - 1)], state))
+
+    def gmask_view(self, n_par):
+        """the chunk's mask buffer, zeroed (what the orchestrator all-reduces when chunk_insert itself failed)"""
+        self.gmask = torch.zeros(n_par, dtype=torch.int32)
+        self.lmask = torch.zeros(n_par, dtype=torch.int32)
+        self.winners = []
+        return self.gmask
+
+    def chunk_insert(self, n_par):
+        c0, n_par, S, cap, rw = self.geo
+        self.gmask_view(n_par)
+        if self.ctl[0] != 0:
+            return self.gmask
+        regs = self.recv.view(S * self.world, rw)
+        recs = []
+        for r in range(S * self.world):
+            n = int(regs[r, 0])
+            if n > cap:
+                self.ctl[8] = max(int(self.ctl[8]), 1)
+                n = cap
+            for i in range(n):
+                k0, k1, x = (int(v) for v in regs[r, HDR + 3 * i: HDR + 3 * i + 3])
+                recs.append((x >> 32, k0, k1, ((r // S) << 40) | (x & 0xFFFFFFFF)))
+        seen = set()
+        for tag, k0, k1, pref in sorted(recs):
             if (k0, k1) in self.visited or (k0, k1) in seen:
                 continue
             seen.add((k0, k1))
-            self.pending.append((k0, k1, tag, pref))
-            mask[tag // 12 - c0] |= 1 << (tag % 12)
-        self.c0 = c0
-        return mask
+            self.winners.append((tag, k0, k1, pref))
+            self.lmask[tag // 12] |= 1 << (tag % 12)
+        self.gmask.copy_(self.lmask)
+        return self.gmask
 
-    def commit(self, cutoff, lmask, lprefix, gmask, gprefix, gpos_base, n_commit):
-        todo = [r for r in self.pending if r[2] < cutoff]
-        assert len(todo) == n_commit, (len(todo), n_commit)
-        if len(self.states) + n_commit > self.node_cap + 64:
-            raise RuntimeError("engine capacity exceeded")
-        for k0, k1, tag, pref in todo:
-            par, a = tag // 12 - self.c0, tag % 12
-            gp = gpos_base + int(gprefix[par]) + bin(int(gmask[par]) & ((1 << a) - 1)).count("1")
-            lid = len(self.states)
-            assert lid == self._base(lprefix, lmask, par, a, todo)
-            self._add(k0, k1, a, pref, gp)
-        self.pending = []
+    def chunk_commit(self, max_nodes):
+        if self.ctl[0] != 0:
+            return
+        c0, n_par, S, cap, rw = self.geo
+        regs = self.recv.view(S * self.world, rw)
+        fail = int(regs[:, 3].max())
+        if fail:
+            self.ctl[0], self.ctl[10] = 4, fail
+            return
+        solved, err = int(regs[:, 1].min()), int(regs[:, 2].min())
+        pop = lambda v: bin(int(v)).count("1")  # noqa: E731
+        gpop = np.array([pop(v) for v in self.gmask.tolist()], np.int64)
+        lpop = np.array([pop(v) for v in self.lmask.tolist()], np.int64)
+        gincl, lincl = np.cumsum(gpop), np.cumsum(lpop)
+        nodes_global = int(self.ctl[1])
+        need = max(max_nodes - nodes_global, 0)
+        p_end, budget_hit, cg, cl = n_par - 1, False, int(gincl[-1]), int(lincl[-1])
+        if need < 1:
+            p_end, budget_hit, cg, cl = 0, True, int(gincl[0]), int(lincl[0])
+        elif nodes_global + int(gincl[-1]) >= max_nodes:
+            p_end = int(np.searchsorted(gincl, need))
+            budget_hit, cg, cl = True, int(gincl[p_end]), int(lincl[p_end])
+        end_pos = c0 + p_end
+        is_solved = solved < INF and solved // 12 <= end_pos
+        self.ctl[11] += 1
+        if err < INF and (err >> 8) // 12 <= end_pos and not (is_solved and solved < (err >> 8)):
+            self.ctl[0] = 3
+            return
+        if is_solved:
+            q, a = solved // 12 - c0, solved % 12
+            before = int(gincl[q] - gpop[q]) + pop(int(self.gmask[q]) & ((1 << a) - 1))
+            self.ctl[3] += q + 1
+            self.ctl[1] = nodes_global + before
+            self.ctl[4] = solved
+            self.ctl[0] = 1
+            return
+        if len(self.states) + cl > self.node_cap:
+            self.ctl[8] = max(int(self.ctl[8]), 2)
+        else:
+            base = int(self.ctl[2])
+            todo = [w for w in self.winners if w[0] < 12 * (p_end + 1)]
+            assert len(todo) == cl, (len(todo), cl)
+            for tag, k0, k1, pref in todo:
+                par, a = tag // 12, tag % 12
+                gp = base + int(gincl[par] - gpop[par]) + pop(int(self.gmask[par]) & ((1 << a) - 1))
+                self._add(k0, k1, a, pref, gp)
+            self.ctl[5] = len(self.states)
+        self.ctl[2] += cg
+        self.ctl[1] = nodes_global + cg
+        self.ctl[3] += p_end + 1
+        if budget_hit:
+            self.ctl[0] = 2
 
-    def _base(self, lprefix, lmask, par, a, todo):
-        first = len(self.states) - sum(1 for r in todo if (r[0], r[1]) in self.visited)
-        return first + int(lprefix[par]) + bin(int(lmask[par]) & ((1 << a) - 1)).count("1")
+    def ctl_snapshot(self, slot):
+        self.snap[slot] = self.ctl.copy()
+
+    def ctl_wait(self, slot):
+        return self.snap[slot]
+
+    def fail_local(self):
+        self.ctl[8] = max(int(self.ctl[8]), 4)
 
     def find(self, gpos):
         for nid in range(self.lvl_lo, self.lvl_hi):
@@ -147,9 +274,6 @@ class OracleShardEngine:
 
     def node_info(self, nid):
         return (-1 if self.prefs[nid] < 0 else self.acts[nid]), self.tlens[nid], self.prefs[nid]
-
-    def status(self):
-        return self.err, self.min_len
 
 
 class ThreadComm:
@@ -163,6 +287,7 @@ class ThreadComm:
 
     def __init__(self, shared, rank):
         self.s, self.rank, self.world = shared, rank, shared.world
+        self.stats = {"all_to_all_calls": 0, "all_reduce_calls": 0}
 
     def _exchange(self, value):
         self.s.slots[self.rank] = value
@@ -171,18 +296,27 @@ class ThreadComm:
         self.s.barrier.wait()
         return vals
 
-    def all_to_all_regions(self, regions):
-        everyone = self._exchange(list(regions))
-        return torch.cat([everyone[src][self.rank] for src in range(self.world)])
-
-    def all_gather_var(self, t):
-        return self._exchange(t)
+    def all_to_all_single(self, recv, send):
+        assert recv.numel() == send.numel() and send.numel() % self.world == 0
+        if send.is_cuda:
+            torch.cuda.current_stream(send.device).synchronize()  # the other threads read this buffer on THEIR streams
+        everyone = self._exchange(send)
+        k = send.numel() // self.world
+        for src in range(self.world):
+            recv[src * k:(src + 1) * k].copy_(everyone[src][self.rank * k:(self.rank + 1) * k])
+        if send.is_cuda:
+            torch.cuda.current_stream(send.device).synchronize()
+        self._exchange(None)  # nobody rewrites its send buffer before everybody has copied out of it
+        self.stats["all_to_all_calls"] += 1
 
     def all_reduce(self, t, op):
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
         vals = self._exchange(t.clone())
-        st = torch.stack(vals)
+        st = torch.stack([v.to(t.device) for v in vals])
         red = {"min": st.min(0)[0], "max": st.max(0)[0], "sum": st.sum(0)}[op]
         t.copy_(red)
+        self.stats["all_reduce_calls"] += 1
         return t
 
 

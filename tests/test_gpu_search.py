@@ -234,59 +234,73 @@ def test_sharded_bfs_hip_engine_matches_reference(search, golden_json, world):
 
 @pytest.mark.parametrize("L", [25, 36])
 def test_device_routing_matches_owner_of(search, L):
-    """acx_shard_expand_routed groups the children by the same owner function the orchestrator uses (owner_of), both key
-    widths; fed back into ONE engine (as if it owned every key) the engine calls reproduce a plain BFS level by level."""
+    """acx_shard_chunk_expand routes every child to the region of the rank the orchestrator's owner function names (owner_of),
+    both key widths, and sends exactly the children it should: not the unchanged ones, not the ones that undo their parent's
+    move (normal-form root, cyclical = False), and of the duplicates inside a 1024-child workgroup tile only the smallest tag.
+    Fed back into the SAME engine (as if it owned every key) insert + commit reproduce a plain BFS level by level."""
     import torch
 
-    from ac_solver.search.sharded import HipShardEngine, owner_of
+    from ac_solver.search.sharded import CTL_NODES, CTL_NEXT_COUNT, HDR, HipShardEngine, owner_of
     from oracle import ac_oracle as O
 
+    inverse = {0: 2, 2: 0, 1: 3, 3: 1, 4: 8, 8: 4, 5: 9, 9: 5, 6: 10, 10: 6, 7: 11, 11: 7}
     ak3 = np.zeros(2 * L, np.int8)
     ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
     ak3[L:L + 6] = [1, 2, 1, -2, -1, -2]
-    pop12 = torch.tensor([bin(v).count("1") for v in range(4096)], dtype=torch.int64, device="cuda")
     for world in (2, 3, 8):
-        eng = HipShardEngine(L, False, 100000, 200000, 4096, 0, world)
-        KW = eng.KW
+        eng = HipShardEngine(L, False, 100000, 1 << 15, 0, world, 50000)
+        KW, RW = eng.KW, eng.RW
         eng.seed(eng.root_record(ak3))
-        level = [ak3.copy()]          # host mirror of the frontier (oracle moves), in global FIFO order
+        level = [(ak3.copy(), 0xff)]  # host mirror of the frontier (oracle moves) with the action that made each node, global FIFO order
         visited = {tuple(ak3.tolist())}
         first_id = 0                  # local id of the level's first node (this engine commits everything: ids are FIFO order)
-        for _ in range(4):            # a few levels: 12, then up to 144, ... children
+        nodes = 1
+        for lvl in range(5):          # a few levels: 12, then up to 144, ... children
             F = len(level)
-            n_local = eng.level_begin()
-            assert n_local == F
-            solved = torch.tensor([1 << 62, 1 << 62], dtype=torch.int64, device=eng.device)
-            regions = eng.expand_routed(0, F, n_local, solved, world)
-            send, counts = torch.cat(regions), [int(r.shape[0]) for r in regions]
-            # expected children (the unchanged ones are never sent), tag -> state
-            want, nxt = {}, []
-            for gp, st in enumerate(level):
+            send, recv = eng.chunk_expand(0, F, True)
+            S, cap, rw = eng.layout(F)
+            regs = send.view(S * world, rw).cpu()
+            # expected records: tag -> state, tile by tile
+            want, tile_keys = {}, {}
+            for gp, (st, made_by) in enumerate(level):
                 out, lens, err = O.move_batch(np.repeat(st[None], 12, axis=0), np.arange(12, dtype=np.uint8), L, cyclical=False)
                 for a in range(12):
-                    if not np.array_equal(out[a], st):
-                        want[12 * gp + a] = out[a]
-            rows = send.tolist()
-            assert sum(counts) == len(rows) == len(want)
-            assert sorted(r[KW] for r in rows) == sorted(want)
-            owners = owner_of(send[:, :KW].cpu(), world).tolist()
-            off = 0
-            for o, c in enumerate(counts):
-                assert all(w == o for w in owners[off:off + c]), (L, world, o)
-                off += c
-            assert all(r[KW + 1] == (0 << 40) | (first_id + r[KW] // 12) for r in rows)  # parent_ref = rank << 40 | local id
-            lmask = eng.insert(send, 0, F)
-            lpop = pop12[lmask.to(torch.int64)]
-            lincl = torch.cumsum(lpop, 0)
-            n_new = int(lincl[-1])
-            eng.commit(1 << 62, lmask, lincl - lpop, lmask, lincl - lpop, 0, n_new)
+                    if np.array_equal(out[a], st) or (made_by < 12 and a == inverse[made_by]):
+                        continue
+                    key, tile = tuple(out[a].tolist()), (12 * gp + a) // 1024
+                    if key in tile_keys.setdefault(tile, set()):
+                        continue
+                    tile_keys[tile].add(key)
+                    want[12 * gp + a] = out[a]
+            got = {}
+            for r in range(S * world):
+                n = int(regs[r, 0])
+                assert n <= cap and int(regs[r, 1]) == 1 << 62 and int(regs[r, 2]) == 1 << 62 and int(regs[r, 3]) == 0
+                rows = regs[r, HDR:HDR + n * RW].view(n, RW)
+                if n:
+                    assert (owner_of(rows[:, :KW], world) == r // S).all(), (L, world, r)
+                for row in rows.tolist():
+                    tag, pid = row[KW] >> 32, row[KW] & 0xFFFFFFFF
+                    assert pid == first_id + tag // 12  # the parent's local id
+                    got[tag] = row[:KW]
+            assert sorted(got) == sorted(want), (L, world, lvl)
+            recv.copy_(send)  # as if every region came back to this engine
+            lmask = eng.chunk_insert(F).clone()
+            eng.chunk_commit(1 << 40)
+            eng.ctl_snapshot(0)
+            ctl = eng.ctl_wait(0)
+            nxt = []
             for tag in sorted(want):
                 key = tuple(want[tag].tolist())
                 if key not in visited:
                     visited.add(key)
-                    nxt.append(want[tag])
+                    nxt.append((want[tag], tag % 12))
                     assert (int(lmask[tag // 12]) >> (tag % 12)) & 1, tag
-            assert n_new == len(nxt)
+            nodes += len(nxt)
+            assert int(ctl[CTL_NEXT_COUNT]) == len(nxt) and int(ctl[CTL_NODES]) == nodes
+            for k in (0, len(nxt) // 2, len(nxt) - 1):  # committed in tag order: node ids are the FIFO order
+                a, tl, pref = eng.node_info(first_id + F + k)
+                assert a == nxt[k][1] and tl == int(np.count_nonzero(nxt[k][0]))
             first_id += F
             level = nxt
 
@@ -329,7 +343,7 @@ def test_miller_schupp_driver_matches_reference_test_ranges(search, golden_json)
 
 def test_sharded_bfs_over_rccl_process_group(search):
     """The production communicator (torch.distributed, backend nccl == RCCL) with device tensors, world size 1:
-    exercises all_to_all_single with split sizes, padded all_gather and all_reduce on the HIP engine's buffers."""
+    exercises the equal-split all_to_all_single and the all_reduce on the HIP engine's buffers."""
     import socket
 
     import torch
@@ -355,17 +369,18 @@ def test_sharded_bfs_over_rccl_process_group(search):
 
 
 def _bfs_through_comm(bfs_sharded, p, budget, comm):
+    import torch
+
     import ac_solver.search.sharded as sh
 
     class Forced:
         """world-size-1 communicator that still routes every call through torch.distributed"""
         rank, world = 0, 1
 
-        def all_to_all_regions(self, regions):
-            return comm.all_to_all_regions(regions)
-
-        def all_gather_var(self, t):
-            return comm.all_gather_var(t)
+        def all_to_all_single(self, recv, send):
+            out = torch.empty_like(send)  # RCCL rejects aliased buffers: at world 1 the engine's send and receive areas are the same
+            comm.all_to_all_single(out, send)
+            recv.copy_(out)
 
         def all_reduce(self, t, op):
             return comm.all_reduce(t, op)
@@ -418,8 +433,10 @@ def _two_process_worker(rank, world, port, q):
             def __init__(self):
                 super().__init__(torch.device("cpu"))
 
-            def all_to_all_regions(self, regions):
-                return super().all_to_all_regions([r.cpu() for r in regions]).to("cuda")
+            def all_to_all_single(self, recv, send):
+                h = torch.empty(send.shape, dtype=send.dtype)
+                super().all_to_all_single(h, send.cpu())
+                recv.copy_(h)
 
             def all_reduce(self, t, op):
                 h = t.cpu()

@@ -74,15 +74,15 @@ def test_gloo_world2_matches_reference():
 
 
 def test_a_failing_rank_takes_every_rank_down_without_deadlock():
-    """A rank whose engine fails (capacity, device error) keeps taking part in the collectives of the chunk and reports
-    through the `solved` all-reduce, so that every rank raises instead of waiting forever."""
+    """A rank whose engine call fails (a HIP error, an exhausted allocation) keeps taking part in the collectives of the chunk and
+    marks itself failed; the flag travels in the headers of its next chunk, every rank stops at that chunk and raises."""
     from ac_solver.search.sharded import bfs_sharded
 
     class Flaky(OracleShardEngine):
-        def insert(self, recv, c0, n_parents):
+        def chunk_insert(self, n_par):
             if self.rank == 1 and len(self.states) > 20:
                 raise RuntimeError("engine capacity exceeded (simulated)")
-            return super().insert(recv, c0, n_parents)
+            return super().chunk_insert(n_par)
 
     def run(comm):
         try:
@@ -94,3 +94,58 @@ def test_a_failing_rank_takes_every_rank_down_without_deadlock():
     msgs = run_threads(3, run)
     assert all("sharded bfs failed" in m for m in msgs), msgs
     assert "simulated" in msgs[1]
+
+
+def test_a_device_side_capacity_failure_reaches_every_rank():
+    """node capacity exhausted on one rank: refused on that rank before anything is written, carried to the others by the next
+    chunk's headers (or by the closing all-reduce when the search ends first)"""
+    from ac_solver.search.sharded import bfs_sharded
+
+    class Small(OracleShardEngine):
+        def __init__(self, *a):
+            super().__init__(*a)
+            if self.rank == 0:
+                self.node_cap = 30
+
+    def run(comm):
+        try:
+            bfs_sharded(AK2, 100000, comm=comm, engine_factory=Small, batch_parents=16)
+        except RuntimeError as e:
+            return str(e)
+        return "no error"
+
+    msgs = run_threads(2, run)
+    assert "node capacity" in msgs[0] and "another rank" in msgs[1], msgs
+
+
+def test_layout_mirror_matches_the_library():
+    """tests/shard_helpers.py:layout (what the NumPy engine uses) == acx_shard_layout (pure host arithmetic, no GPU needed)"""
+    import ctypes as C
+
+    from ac_solver import _acx
+    from tests.shard_helpers import layout
+
+    s, cap, rw = C.c_int64(), C.c_int64(), C.c_int64()
+    for world in (1, 2, 3, 8, 64):
+        for n_par in (1, 7, 85, 86, 1000, 1365, 1366, 1 << 18, (1 << 21) + 5):
+            for kw in (2, 4):
+                _acx.check(_acx.lib.acx_shard_layout(n_par, world, kw, C.byref(s), C.byref(cap), C.byref(rw)))
+                assert (s.value, cap.value, rw.value) == layout(n_par, world, kw), (world, n_par, kw)
+
+
+def test_undo_children_are_visited_states():
+    """world 1: every child the engines do not send because it undoes its parent's move (normal-form root, cyclical = False) is
+    a visited state -- asserted inside OracleShardEngine.chunk_expand, where the single rank holds the whole visited set"""
+    from ac_solver.search.sharded import SingleComm, bfs_sharded
+
+    made = []
+
+    def factory(*a):
+        made.append(OracleShardEngine(*a))
+        return made[-1]
+
+    for p, L in ((AK2, 7), (MS, 10)):
+        ok, path, st = bfs_sharded(p, 3000, comm=SingleComm(), engine_factory=factory, batch_parents=97, want_stats=True)
+        wok, wpath, wst = O.bfs(p, 3000, stats=True)
+        assert (ok, path, st["nodes"], st["expanded"]) == (wok, wpath, wst["nodes"], wst["expanded"])
+        assert made[-1].inverse_dropped > 100
