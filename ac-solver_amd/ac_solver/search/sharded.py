@@ -172,12 +172,14 @@ class HipShardEngine:
         """-> (send, recv): 1-D int64 views of equal length for the all-to-all (the same view at world 1)"""
         torch = _torch()
         need = self.layout_words(c1 - c0)
-        if self._cursor + need > self.log.numel():  # grow the log (stream ordered: the chunks in flight keep the old block alive)
+        if self._cursor + need > self.log.numel():  # grow the log: rare, so simply behind everything that is in flight on any stream
+            torch.cuda.synchronize(self.device)
             with torch.cuda.device(self.device):
                 bigger = torch.empty(max(2 * self.log.numel(), self._cursor + 2 * need), dtype=torch.int64, device=self.device)
                 bigger[: self._cursor].copy_(self.log[: self._cursor])
                 self.log = bigger
                 self._attach()
+            torch.cuda.synchronize(self.device)  # the copy ran on the calling stream; the other stream's next kernels read the new block
         off, words = C.c_int64(), C.c_int64()
         self._acx.check(self._acx.lib.acx_shard_chunk_expand(self.h, int(c0), int(c1), int(bool(level_first)), C.byref(off), C.byref(words), self._stream()),
                         "acx_shard_chunk_expand")
@@ -233,7 +235,7 @@ def owner_of(keys, world):
 
 
 def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False, comm=None,
-                engine_factory=None, batch_parents=1 << 20, want_stats=False, log_fraction=0.5):
+                engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5):
     """Same contract as `bfs`: returns (is_search_successful, path or None) [+ stats dict], identical on every rank.
     `batch_parents`: global frontier positions per chunk.  `log_fraction`: expected expanded parents / max_nodes, sizes the
     record log (it grows by doubling if the estimate is short)."""
@@ -292,17 +294,32 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             return ok, path, st
         return ok, path
 
-    while F > 0:
-        levels += 1
-        pending = []  # snapshot slots of the chunks whose control block has not been read yet
-        c0 = k = 0
-        ctl = None
-        while c0 < F and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING):
-            c1 = min(F, c0 + B)
-            n_par = c1 - c0
+    # Two streams on a GPU: `side` runs the expansion of chunk k + 1 and its all-to-all while the main stream deduplicates and
+    # commits chunk k (expansion is arithmetic + streaming stores, the dedup random memory access, the exchange xGMI: three
+    # different resources).  Inside a level chunk k + 1 needs nothing from chunk k: its parents were committed during the
+    # previous level and it has its own slice of the record log; only the send buffer is shared, and that is reused in `side`'s
+    # own order.  The CPU engines of the tests run everything in program order.
+    on_gpu = dev.type == "cuda"
+    main = torch.cuda.current_stream(dev) if on_gpu else None
+    side = torch.cuda.Stream(dev) if on_gpu else None
+
+    class _on_side:
+        def __enter__(self):
+            if on_gpu:
+                self.ctx = torch.cuda.stream(side)
+                self.ctx.__enter__()
+
+        def __exit__(self, *a):
+            if on_gpu:
+                self.ctx.__exit__(*a)
+
+    def produce(c0, c1):
+        """expansion + exchange of one chunk on the side stream -> (n_par, event after which its receive area is complete)"""
+        nonlocal failure
+        n_par = c1 - c0
+        with _on_side():
             # A failing engine call of this rank (a HIP error, an exhausted allocation) must not leave the other ranks waiting in a
-            # collective: the rank keeps taking part in the chunk's collectives with whatever its buffers hold and marks itself
-            # failed; the flag travels in the headers of its next chunk and every rank then stops at that chunk (status 4).
+            # collective: the rank sends empty regions whose headers say "failed" and every rank stops at that chunk (status 4).
             try:
                 send, recv = engine.chunk_expand(c0, c1, c0 == 0)
             except Exception as e:  # noqa: BLE001
@@ -310,7 +327,6 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
                     raise
                 failure = failure or e
                 engine.fail_local()
-                # empty regions whose headers say "failed": every rank stops at THIS chunk
                 S, _, rw = engine.layout(n_par)
                 send = torch.zeros(S * world * rw, dtype=torch.int64, device=dev)
                 hdr = send.view(S * world, rw)
@@ -318,6 +334,27 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
                 recv = torch.empty_like(send)
             if exchange:
                 comm.all_to_all_single(recv, send)
+            ev = None
+            if on_gpu:
+                ev = torch.cuda.Event()
+                ev.record(side)
+        return n_par, ev
+
+    while F > 0:
+        levels += 1
+        pending = []  # snapshot slots of the chunks whose control block has not been read yet
+        k = 0
+        ctl = None
+        if on_gpu:
+            side.wait_stream(main)  # the level's parents are the nodes the main stream committed during the previous level
+        bounds = [(c0, min(F, c0 + B)) for c0 in range(0, F, B)]
+        ready = produce(*bounds[0])
+        while k < len(bounds) and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING):
+            n_par, ev = ready
+            if k + 1 < len(bounds):
+                ready = produce(*bounds[k + 1])  # runs beside this chunk's dedup and commit
+            if ev is not None:
+                main.wait_event(ev)
             try:
                 gmask = engine.chunk_insert(n_par)
             except Exception as e:  # noqa: BLE001
@@ -337,7 +374,9 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             chunks += 1
             if len(pending) > lag:
                 ctl = engine.ctl_wait(pending.pop(0))
-            c0, k = c1, k + 1
+            k += 1
+        if on_gpu:
+            main.wait_stream(side)  # (a chunk that was produced but never consumed: the search ended)
         while pending and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING):  # end of the level: the one synchronisation
             ctl = engine.ctl_wait(pending.pop(0))
         status = int(ctl[CTL_STATUS])

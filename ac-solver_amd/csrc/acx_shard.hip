@@ -164,6 +164,7 @@ __device__ __forceinline__ uint32_t lower_gpos(const uint32_t* __restrict__ gpos
 // with gpos in [c0, c0 + n_par) -- found ONCE per chunk by one lane -- and the headers of the send regions.
 template <typename W>
 __global__ void __launch_bounds__(256) k_shard_prep(ShardDev<W> d, ChunkGeo g, int level_first, int64_t* __restrict__ send) {
+    __shared__ uint32_t s_lo[2], s_hi[2];
     ACX_VGPR_PAD("v31");
     if (d.ctl[C_STATUS] != 0) return;
     if (threadIdx.x == 0) {
@@ -172,9 +173,35 @@ __global__ void __launch_bounds__(256) k_shard_prep(ShardDev<W> d, ChunkGeo g, i
             d.ctl[C_LVL_HI] = d.ctl[C_NODES];
             d.ctl[C_NEXT_COUNT] = 0;
         }
-        const uint32_t lo = (uint32_t)d.ctl[C_LVL_LO], hi = (uint32_t)d.ctl[C_LVL_HI];
-        d.bounds[0] = lower_gpos(d.gpos, lo, hi, (uint32_t)g.c0);
-        d.bounds[1] = lower_gpos(d.gpos, lo, hi, (uint32_t)(g.c0 + g.n_par));
+        s_lo[0] = s_lo[1] = (uint32_t)d.ctl[C_LVL_LO];
+        s_hi[0] = s_hi[1] = (uint32_t)d.ctl[C_LVL_HI];
+    }
+    __syncthreads();
+    // both lower bounds by a 128-ary search (threads 0..127 the first, 128..255 the second): every round one load per thread
+    // instead of the ~25 dependent loads per bound of a one-lane binary search (16 us per chunk in round 3's first profile)
+    const uint32_t which = threadIdx.x >> 7, t = threadIdx.x & 127u;
+    const uint32_t target = which ? (uint32_t)(g.c0 + g.n_par) : (uint32_t)g.c0;
+    for (;;) {
+        const uint32_t lo = s_lo[which], hi = s_hi[which], n = hi - lo;
+        __syncthreads();
+        if (s_hi[0] - s_lo[0] == 0 && s_hi[1] - s_lo[1] == 0) break;  // (uniform: both ranges are read by everybody)
+        if (n) {
+            // probe t looks at position lo + t * step: the answer lies behind the last probe whose gpos is < target
+            const uint32_t step = (n + 127u) / 128u, pos = lo + t * step;
+            const bool below = pos < hi && d.gpos[pos] < target;
+            const bool next_below = pos + step < hi && t + 1 < 128u && d.gpos[pos + step] < target;
+            if (t == 0 && !below) s_hi[which] = lo;                       // the very first element is >= target: the bound is lo
+            if (below && !next_below) {                                    // the last probe below the target
+                s_lo[which] = pos + 1;
+                s_hi[which] = min(hi, pos + step);
+                if (step == 1) s_hi[which] = pos + 1;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        d.bounds[0] = s_lo[0];
+        d.bounds[1] = s_lo[1];
     }
     const unsigned long long fail = d.ctl[C_FAIL_LOCAL];
     for (uint32_t r = threadIdx.x; r < d.world * kShardSub; r += blockDim.x) {
@@ -665,8 +692,12 @@ template <typename W> struct ShardEngine {
     int64_t* d_send = nullptr;  // the caller's send buffer (null when world == 1: the chunk is expanded straight into the log)
     uint64_t cap_nodes = 0, n_slots = 0, chunk_parents = 0, log_words = 0, send_words = 0;
     int64_t log_off = 0;        // next free word of the log
-    ChunkGeo geo{};             // the running chunk
-    bool chunk_open = false;
+    // chunks between acx_shard_chunk_expand and acx_shard_chunk_commit, oldest first: the orchestrator expands chunk k + 1 (on a side
+    // stream) before it inserts and commits chunk k
+    static constexpr int kGeoRing = 4;
+    ChunkGeo geos[kGeoRing] = {};
+    int geo_head = 0, geo_count = 0;   // ring of open chunks
+    int geo_inserted = 0;              // how many of them have been through acx_shard_chunk_insert
     uint64_t nodes_host = 0, lvl_lo_host = 0, lvl_hi_host = 0;  // what the last control-block snapshot said
     int rank = 0, world = 1;
     int move_mode = kMoveGeneral;  // acx_bfs.h: set from the root (acx_shard_root_record, which every rank calls)
@@ -820,57 +851,60 @@ static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int lev
     int64_t subcap, region_words;
     shard_layout(n_par, E.world, recio<W>::RW, &subcap, &region_words);
     const int64_t total = region_words * kShardSub * E.world;
+    if (E.geo_count == ShardEngine<W>::kGeoRing) return fail(ACX_E_INVAL, "acx_shard_chunk_expand: too many chunks in flight (commit the oldest first)");
+    ChunkGeo geo{};
+    geo.c0 = c0;
+    geo.n_par = (uint32_t)n_par;
+    geo.subcap = (uint32_t)subcap;
+    geo.region_words = (uint32_t)region_words;
+    geo.log_off = E.log_off;
+    int64_t* send = E.d_send ? E.d_send : E.d.log + E.log_off;
+    if ((uint64_t)(E.log_off + total) > E.log_words || (E.d_send && (uint64_t)total > E.send_words))
+        return fail(ACX_E_CAPACITY, "acx_shard_chunk_expand: the record log (%llu words, %lld used) cannot take a chunk of %lld words: attach a larger one",
+                    (unsigned long long)E.log_words, (long long)E.log_off, (long long)total);
     if (level_first) {  // the nodes committed since the previous switch are this rank's slice of the new level (host mirror; the device switches in k_shard_prep)
         E.lvl_lo_host = E.lvl_hi_host;
         E.lvl_hi_host = E.nodes_host;
     }
-    E.geo.c0 = c0;
-    E.geo.n_par = (uint32_t)n_par;
-    E.geo.subcap = (uint32_t)subcap;
-    E.geo.region_words = (uint32_t)region_words;
-    E.geo.log_off = E.log_off;
     *recv_off = E.log_off;
     *words = total;
-    E.chunk_open = true;
-    int64_t* send = E.d_send ? E.d_send : E.d.log + E.log_off;
-    if ((uint64_t)(E.log_off + total) > E.log_words || (E.d_send && (uint64_t)total > E.send_words)) {
-        // no room to receive: this rank fails (sticky); the chunk still runs through the collectives with what the buffers hold
-        hipLaunchKernelGGL(k_shard_fail, dim3(1), dim3(1), 0, st, E.d.ctl, (unsigned long long)FAIL_REGION);
-        E.geo.log_off = E.log_off = 8;
-        *recv_off = 8;
-        if ((uint64_t)(8 + total) > E.log_words || (E.d_send && (uint64_t)total > E.send_words)) return fail(ACX_E_CAPACITY, "acx_shard_chunk_expand: the record log cannot take a single chunk");
-        send = E.d_send ? E.d_send : E.d.log + 8;
-    }
-    hipLaunchKernelGGL(k_shard_prep<W>, dim3(1), dim3(256), 0, st, E.d, E.geo, level_first, send);
+    E.log_off += total;
+    E.geos[(E.geo_head + E.geo_count) % ShardEngine<W>::kGeoRing] = geo;
+    E.geo_count++;
+    hipLaunchKernelGGL(k_shard_prep<W>, dim3(1), dim3(256), 0, st, E.d, geo, level_first, send);
     const int64_t np_max = std::min<int64_t>(n_par, (int64_t)(E.lvl_hi_host - E.lvl_lo_host));
     if (np_max > 0) {
         const dim3 grid((unsigned)((12 * np_max + kExpandTile - 1) / kExpandTile));
-        if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_expand<W, kMoveNf>), grid, dim3(kExpandThreads), 0, st, E.d, E.geo, send);
-        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_expand<W, kMoveNfCyclical>), grid, dim3(kExpandThreads), 0, st, E.d, E.geo, send);
-        else hipLaunchKernelGGL((k_shard_expand<W, kMoveGeneral>), grid, dim3(kExpandThreads), 0, st, E.d, E.geo, send);
+        if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_expand<W, kMoveNf>), grid, dim3(kExpandThreads), 0, st, E.d, geo, send);
+        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_expand<W, kMoveNfCyclical>), grid, dim3(kExpandThreads), 0, st, E.d, geo, send);
+        else hipLaunchKernelGGL((k_shard_expand<W, kMoveGeneral>), grid, dim3(kExpandThreads), 0, st, E.d, geo, send);
     }
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
 
 template <typename W> static int shard_chunk_insert(ShardEngine<W>& E, hipStream_t st) {
-    if (!E.chunk_open) return fail(ACX_E_INVAL, "acx_shard_chunk_insert: no chunk is open");
-    const dim3 grid((unsigned)((E.geo.subcap + 255) / 256), (unsigned)(kShardSub * E.world));
-    hipLaunchKernelGGL(k_shard_insert<W>, grid, dim3(256), 0, st, E.d, E.geo);
-    hipLaunchKernelGGL(k_shard_pack<W>, dim3((E.geo.n_par + 255) / 256), dim3(256), 0, st, E.d, E.geo.n_par);
+    if (E.geo_inserted >= E.geo_count) return fail(ACX_E_INVAL, "acx_shard_chunk_insert: no expanded chunk is waiting");
+    const ChunkGeo& geo = E.geos[(E.geo_head + E.geo_inserted) % ShardEngine<W>::kGeoRing];
+    E.geo_inserted++;
+    const dim3 grid((unsigned)((geo.subcap + 255) / 256), (unsigned)(kShardSub * E.world));
+    hipLaunchKernelGGL(k_shard_insert<W>, grid, dim3(256), 0, st, E.d, geo);
+    hipLaunchKernelGGL(k_shard_pack<W>, dim3((geo.n_par + 255) / 256), dim3(256), 0, st, E.d, geo.n_par);
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
 
 template <typename W> static int shard_chunk_commit(ShardEngine<W>& E, int64_t max_nodes, hipStream_t st) {
-    if (!E.chunk_open) return fail(ACX_E_INVAL, "acx_shard_chunk_commit: no chunk is open");
-    E.chunk_open = false;
-    hipLaunchKernelGGL(k_shard_scan<W>, dim3((E.geo.n_par + kScanTile - 1) / kScanTile), dim3(1024), 0, st, E.d, E.geo.n_par);
-    hipLaunchKernelGGL(k_shard_decide<W>, dim3(1), dim3(1024), 0, st, E.d, E.geo, max_nodes);
-    const dim3 grid((unsigned)((E.geo.subcap + 255) / 256), (unsigned)(kShardSub * E.world));
-    hipLaunchKernelGGL(k_shard_commit<W>, grid, dim3(256), 0, st, E.d, E.geo);
+    if (E.geo_inserted < 1) return fail(ACX_E_INVAL, "acx_shard_chunk_commit: no inserted chunk is waiting");
+    const ChunkGeo geo = E.geos[E.geo_head];
+    E.geo_head = (E.geo_head + 1) % ShardEngine<W>::kGeoRing;
+    E.geo_count--;
+    E.geo_inserted--;
+    hipLaunchKernelGGL(k_shard_scan<W>, dim3((geo.n_par + kScanTile - 1) / kScanTile), dim3(1024), 0, st, E.d, geo.n_par);
+    hipLaunchKernelGGL(k_shard_decide<W>, dim3(1), dim3(1024), 0, st, E.d, geo, max_nodes);
+    const dim3 grid((unsigned)((geo.subcap + 255) / 256), (unsigned)(kShardSub * E.world));
+    hipLaunchKernelGGL(k_shard_commit<W>, grid, dim3(256), 0, st, E.d, geo);
     ACX_HIP_TRY(hipGetLastError());
-    E.log_off = E.geo.log_off + (int64_t)E.geo.region_words * kShardSub * E.world;
     return ACX_OK;
 }
 

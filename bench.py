@@ -173,14 +173,14 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
     p = ak3_at_L()
     comm = TorchDistComm(dev) if use_dist else SingleComm()
     t0 = time.perf_counter()
-    bfs_sharded(p, budget, comm=comm, batch_parents=1 << 22)  # warm-up at full size: allocator (GBs of first-time hipMalloc), kernels, communicator
+    bfs_sharded(p, budget, comm=comm, batch_parents=1 << 21)  # warm-up at full size: allocator (GBs of first-time hipMalloc), kernels, communicator
     torch.cuda.synchronize()
     first_call = time.perf_counter() - t0
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
-    ok, path, st = bfs_sharded(p, budget, comm=comm, batch_parents=1 << 22, want_stats=True)
+    ok, path, st = bfs_sharded(p, budget, comm=comm, batch_parents=1 << 21, want_stats=True)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -195,11 +195,11 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
         # the same frontier with the budget grown with the number of GPUs (weak scaling: 1e8 nodes per GPU)
         try:
             wb = budget * world
-            bfs_sharded(p, wb, comm=comm, batch_parents=1 << 22)
+            bfs_sharded(p, wb, comm=comm, batch_parents=1 << 21)
             torch.cuda.synchronize()
             dist.barrier()
             t0 = time.perf_counter()
-            _, _, stw = bfs_sharded(p, wb, comm=comm, batch_parents=1 << 22, want_stats=True)
+            _, _, stw = bfs_sharded(p, wb, comm=comm, batch_parents=1 << 21, want_stats=True)
             torch.cuda.synchronize()
             dist.barrier()
             dtw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)

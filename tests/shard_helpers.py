@@ -88,6 +88,7 @@ class OracleShardEngine:
         self.snap = {}
         self.nf = False
         self.inverse_dropped = 0
+        self.open, self.inserted = [], 0
 
     def layout(self, n_par):
         return layout(n_par, self.world, self.KW)
@@ -121,10 +122,9 @@ class OracleShardEngine:
 
         n_par = c1 - c0
         S, cap, rw = self.layout(n_par)
-        self.geo = (c0, n_par, S, cap, rw)
         send = torch.zeros(S * self.world * rw, dtype=torch.int64)
         recv = torch.zeros_like(send) if self.world > 1 else send
-        self.recv = recv
+        self.open.append(((c0, n_par, S, cap, rw), recv))  # the orchestrator expands chunk k + 1 before it inserts chunk k
         if self.ctl[0] != 0:
             return send, recv
         if level_first:
@@ -180,6 +180,8 @@ class OracleShardEngine:
         return self.gmask
 
     def chunk_insert(self, n_par):
+        self.geo, self.recv = self.open[self.inserted]
+        self.inserted += 1
         c0, n_par, S, cap, rw = self.geo
         self.gmask_view(n_par)
         if self.ctl[0] != 0:
@@ -205,6 +207,8 @@ class OracleShardEngine:
         return self.gmask
 
     def chunk_commit(self, max_nodes):
+        self.geo, self.recv = self.open.pop(0)
+        self.inserted = max(self.inserted - 1, 0)
         if self.ctl[0] != 0:
             return
         c0, n_par, S, cap, rw = self.geo

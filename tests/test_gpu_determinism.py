@@ -81,7 +81,7 @@ def test_bfs_at_the_bench_budget_repeats_and_agrees_with_the_sharded_engine(dige
     assert len({(r[0], str(r[1]), r[2], r[3], r[4]) for r in runs}) == 1, [(r[2], r[3], hex(r[4])) for r in runs]
     ok, path, nodes, expanded, _ = runs[0]
     assert not ok and nodes == 10**8 + 1
-    sok, spath, st = bfs_sharded(_ak3(), 10**8, batch_parents=1 << 22, want_stats=True)
+    sok, spath, st = bfs_sharded(_ak3(), 10**8, batch_parents=1 << 21, want_stats=True)
     assert (sok, spath) == (ok, path) and st["nodes"] == nodes and st["expanded"] == expanded
 
 
