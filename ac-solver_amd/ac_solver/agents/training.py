@@ -63,6 +63,47 @@ def choose_next_state(states_processed, n_states, success_record, round1_complet
     return random.choice(list(success_record["solved"])), round1_complete
 
 
+class Curriculum:
+    """`choose_next_state` for a whole run, with the same decisions and the same draws from `random` as calling that function
+    once per finished episode (training.py:199-221 of the reference) -- but without its per-call O(n_states) work: the
+    reference takes max(states_processed) over the whole set and builds list(unsolved) / list(solved) for every episode, which
+    at 131 072 environments (hundreds of finished episodes per rollout step) was most of an update's wall time.  Here the
+    maximum is kept as a number and the two lists are rebuilt only when their set changed (list(set) of an unchanged set is
+    the same list, so random.choice picks the same element).  The caller's sets stay the containers that are updated."""
+
+    def __init__(self, states_processed, n_states, success_record, repeat_solved_prob, stride=1):
+        self.processed, self.n_states, self.rec, self.p, self.stride = states_processed, n_states, success_record, repeat_solved_prob, stride
+        self.max_processed = max(states_processed)
+        self.round1_complete = False
+        self._lists = {"solved": None, "unsolved": None}
+        self._sizes = {"solved": -1, "unsolved": -1}
+
+    def _list(self, which):
+        st = self.rec[which]
+        if self._lists[which] is None or self._sizes[which] != len(st):  # (a state only ever moves unsolved -> solved: sizes tell)
+            self._lists[which], self._sizes[which] = list(st), len(st)
+        return self._lists[which]
+
+    def mark_solved(self, s):
+        if s in self.rec["unsolved"]:
+            self.rec["unsolved"].remove(s)
+            self.rec["solved"].add(s)
+            self._lists["solved"] = self._lists["unsolved"] = None
+
+    def next_state(self):
+        self.round1_complete = self.round1_complete or self.max_processed + self.stride > self.n_states - 1
+        if not self.round1_complete:
+            nxt = self.max_processed + self.stride
+        elif len(self.rec["solved"]) == 0 or (self.rec["unsolved"] and random.uniform(0, 1) > self.p):
+            nxt = random.choice(self._list("unsolved"))
+        else:
+            nxt = random.choice(self._list("solved"))
+        self.processed.add(nxt)
+        if nxt > self.max_processed:
+            self.max_processed = nxt
+        return nxt
+
+
 class RunningReturnNormalizer:
     """Per-environment reward normalisation as gymnasium 0.28.1's `NormalizeReward` wrapper does it around every single
     env (environment.py:44-46 of the reference): a discounted return is accumulated, its running variance is tracked
@@ -169,6 +210,7 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
     # data parallel: the Miller-Schupp states are dealt rank::world (get_env), so the first curriculum round of a rank
     # walks its own residue class; a single fixed initial state has nothing to deal
     stride = world if dist_on and world > 1 and len(initial_states) > 1 else 1
+    curriculum = Curriculum(states_processed, len(initial_states), success_record, args.repeat_solved_prob, stride)
 
     run_name = f"{args.exp_name}_ppo-ffn-nodes_{args.nodes_counts}_{uuid.uuid4()}"
     out_dir = f"out/{run_name}"
@@ -231,20 +273,17 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             for k, i in enumerate(idx_h):
                 s = curr_states[i]
                 if done_h[k]:
-                    if s in success_record["unsolved"]:
-                        success_record["unsolved"].remove(s)
-                        success_record["solved"].add(s)
+                    curriculum.mark_solved(s)
                     moves = envs.get_actions(i, finished=True)
                     if s not in ACMoves_hist or len(moves) < len(ACMoves_hist[s]):
                         ACMoves_hist[s] = moves
-                returns_queue.append(ret_h[k])
-                lengths_queue.append(len_h[k])
-                episode += 1
-                curr_states[i], round1_complete = choose_next_state(states_processed, len(initial_states), success_record,
-                                                                    round1_complete, args.repeat_solved_prob, stride=stride)
-                states_processed.add(curr_states[i])
+                curr_states[i] = curriculum.next_state()
                 new_states.append(curr_states[i])
                 events.append((step, i, curr_states[i]))
+            returns_queue.extend(ret_h)
+            lengths_queue.extend(len_h)
+            episode += len(idx_h)
+            round1_complete = curriculum.round1_complete
             ep_return[idx] = 0
             ep_length[idx] = 0
             # the finished envs restart from their next curriculum state (envs.envs[i].reset(options={"starting_state": ...}))

@@ -134,6 +134,18 @@ __global__ void __launch_bounds__(kBfsBlock, (sizeof(W) == 8 && MODE != kMoveGen
         if (d.first_len && tl < d.min_len_start) atomicMin(&d.first_len[tl], (unsigned long long)t);  // a candidate for "New minimal length found"
         if (tl == 2) atomicMin(d.solved_tag, (unsigned long long)t);  // breadth_first.py:84: tested before the dedup
         probe = !(c0 == pk0 && c1 == pk1);                            // unchanged state = its (visited) parent
+#ifndef ACX_BFS_NO_UNDO_DROP
+        // Normal-form search with cyclical = False: the child of action inverse(act[parent]) IS the parent's own tree parent
+        // (g^-1 (g r g^-1) g = r and (r_i r_j) r_j^-1 = r_i as reduced words, and the result fits because it did before) -- a
+        // visited state, 8 % of all children: no probe.  One byte per parent, no dependent load (round 2's grandparent test
+        // compared keys: two dependent loads in front of the barrier, slower than the probes it saved).  Checked on the
+        // oracle for every node of the CPU suite's sharded searches (tests/test_sharded_cpu.py) and by the searches' own
+        // node-for-node comparisons with the oracle.
+        if (MODE == kMoveNf && probe) {
+            const uint32_t pa = d.act[pid];  // 0xff for the root
+            if (pa < 12u && a == (pa < 4u ? (pa ^ 2u) : (pa < 8u ? pa + 4u : pa - 4u))) probe = false;
+        }
+#endif
 #ifdef ACX_BFS_GRANDPARENT
         // 8 % of all children undo the move that made their parent.  Testing for it here (two dependent loads in front of the
         // barrier, for every lane) measured 0.4 ms SLOWER per 1e8-node search than letting those children find the

@@ -347,6 +347,15 @@ __device__ __forceinline__ void wave_lds_handoff() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifdef ACX_STEP_STAMP
+// DIAGNOSTIC build only (tools/step_stamps.py, -DACX_STEP_STAMP through tools/build_variant.sh; in the shipped library no stamp
+// executes): every wave of k_env_step logs when it started and when its last store was issued, on the 100 MHz constant
+// clock (s_memrealtime).  The log is read by nothing else in the kernel and no output is computed from it.
+constexpr unsigned int kStampCap = 1u << 21;
+__device__ unsigned long long g_stamp_log[2 * kStampCap];
+__device__ unsigned int g_stamp_cursor;
+#endif
+
 template <typename W, bool SAFE, typename OBS, int LC, bool SUPER = false>
 __global__ void __launch_bounds__(256, SUPER ? 5 : ACX_STEP_WAVES) k_env_step(W* __restrict__ sw0, W* __restrict__ sw1, uint64_t* __restrict__ smeta,
                                                   const void* __restrict__ act, int64_t n_envs, int adt, EnvDev<W> e, OBS* __restrict__ obs,
@@ -361,6 +370,9 @@ __global__ void __launch_bounds__(256, SUPER ? 5 : ACX_STEP_WAVES) k_env_step(W*
     // accesses need: with -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave, so the
     // state loads issue without waiting for a kernarg fetch (this kernel is latency bound at 65 536 envs).
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+#ifdef ACX_STEP_STAMP
+    const unsigned long long stamp_begin = __builtin_amdgcn_s_memrealtime();
+#endif
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int L = LC > 0 ? LC : e.L;
     const int RB = 2 * L * (int)sizeof(OBS);
@@ -401,6 +413,17 @@ __global__ void __launch_bounds__(256, SUPER ? 5 : ACX_STEP_WAVES) k_env_step(W*
         wave_lds_handoff();
         if (rows > 0) wave_copy<ACX_OBS_NT != 0>((uint8_t*)final_obs + row0 * RB, tile, rows * RB, lane, vec != 0);
     }
+#ifdef ACX_STEP_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's stores have left (the real kernel simply ends here)
+    const unsigned long long stamp_end = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+        const unsigned int k = atomicAdd(&g_stamp_cursor, 1u);
+        if (k < kStampCap) {
+            g_stamp_log[2 * k] = stamp_begin;
+            g_stamp_log[2 * k + 1] = stamp_end;
+        }
+    }
+#endif
 }
 
 // Small batches (one wave per SIMD: the per-wave instruction chain is what the kernel time consists of): a TEAM of four
@@ -986,6 +1009,24 @@ int acx_env_step_host(acx_env* e, const int64_t* h_actions, int8_t* h_obs, float
     if (h_err) memcpy(h_err, h + o_err, (size_t)n);
     return ACX_OK;
 }
+
+#ifdef ACX_STEP_STAMP
+// diagnostic build only: the wave stamps of k_env_step since the last reset, as (begin, end) pairs of 10 ns ticks
+int acx_debug_stamps(unsigned long long* h_out, int64_t cap_pairs, int64_t* n_pairs, int reset) {
+    unsigned int n = 0;
+    ACX_HIP_TRY(hipDeviceSynchronize());
+    ACX_HIP_TRY(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_stamp_cursor), 4));
+    if (n > kStampCap) n = kStampCap;
+    *n_pairs = n;
+    const int64_t m = n < cap_pairs ? n : cap_pairs;
+    if (h_out && m > 0) ACX_HIP_TRY(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_stamp_log), (size_t)m * 16));
+    if (reset) {
+        const unsigned int zero = 0;
+        ACX_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_cursor), &zero, 4));
+    }
+    return ACX_OK;
+}
+#endif
 
 int acx_env_rollout(acx_env* e, const uint8_t* d_tape, int64_t T, float* d_reward, float clip_lo, float clip_hi, uint8_t* d_done,
                     uint8_t* d_trunc, int autoreset, void* stream) {

@@ -187,10 +187,27 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    out = {"bfs_sharded": {"nodes_per_s": st["nodes"] / float(dt[0]), "nodes": st["nodes"], "seconds": float(dt[0]), "first_call_seconds": first_call,
-                           "levels": st["levels"],
+    # SURVEY 8(d)'s formula for the frontier ((64 + 72 f) B per generated child) + the xGMI term (n - 1) / n x 32 B per child; the
+    # children are 12 per expanded parent
+    children = 12 * st["expanded"]
+    f_new = st["nodes"] / max(children, 1)
+    algo = (64.0 + 72.0 * f_new) * children
+    secs = float(dt[0])
+    out = {"bfs_sharded": {"nodes_per_s": st["nodes"] / secs, "nodes": st["nodes"], "seconds": secs, "first_call_seconds": first_call,
+                           "levels": st["levels"], "chunks": st["chunks"], "expanded": st["expanded"],
                            "n_gpus": world, "budget": budget, "input": "AK(3) at max_relator_len=25, cyclical=False", "scaling": "strong",
-                           "exchange": "per chunk: all-to-all of child records + all-reduce of one 12-bit child mask per parent (RCCL)" if world > 1 else "none"}}
+                           "exchange": ("per chunk: ONE equal-split all-to-all of child-record regions (headers carry counts and the success / error words) + "
+                                        "ONE all-reduce of a 12-bit child mask per parent (RCCL); expansion + all-to-all of chunk k+1 run on a side stream "
+                                        "beside the dedup + commit of chunk k") if world > 1 else "none (world 1: the chunk is expanded straight into its receive area)",
+                           # self-diagnosis of the first real multi-GPU run: how many ranks the communicator saw and what it moved
+                           "rccl_ranks_seen": world if use_dist else 0,
+                           "backend": dist.get_backend() if use_dist else None,
+                           "collectives": {k[5:]: v for k, v in st.items() if k.startswith("comm_")},
+                           "exchange_bytes_per_chunk_per_rank": (st.get("comm_all_to_all_bytes", 0) / max(st.get("comm_all_to_all_calls", 1), 1)),
+                           "roofline": {"bound": "hbm", "achieved": algo / secs / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                                        "frac": algo / secs / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
+                                        "kernel": "k_shard_insert<u64> + k_shard_expand<u64> + k_shard_commit<u64> (whole search, wall time)",
+                                        "algorithmic_bytes": algo, "bytes_per_child": 64.0 + 72.0 * f_new, "children": children}}}
     if world > 1:
         # the same frontier with the budget grown with the number of GPUs (weak scaling: 1e8 nodes per GPU)
         try:

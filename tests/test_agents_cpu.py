@@ -169,3 +169,36 @@ def test_fused_policy_fragments_decode_back_to_the_layer():
         if hidden:  # every k-step of a hidden-fed layer contracts 16 distinct hidden units, all 256 exactly once
             seen = sorted(32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3) for ks in range(nks) for h in range(2) for j in range(8))
             assert seen == list(range(256))
+
+
+def test_curriculum_object_equals_per_episode_choose_next_state():
+    """training.Curriculum (no per-episode O(n_states) work) takes the same decisions and the same draws from `random` as
+    calling choose_next_state once per finished episode, as the reference's loop does (training.py:199-221)."""
+    import random
+
+    from ac_solver.agents.training import Curriculum
+
+    for stride in (1, 3):
+        proc_a = set(range(0, 8 * stride, stride))
+        rec_a = {"solved": set(), "unsolved": set(range(60))}
+        proc_b, rec_b = set(proc_a), {"solved": set(), "unsolved": set(range(60))}
+        cur = Curriculum(proc_b, 60, rec_b, 0.3, stride)
+        ev = random.Random(1)
+        events = [(ev.random() < 0.2, ev.randrange(60)) for _ in range(3000)]
+        random.seed(5)
+        start = random.getstate()
+        out_a, r1 = [], False
+        for done, s in events:
+            if done and s in rec_a["unsolved"]:
+                rec_a["unsolved"].remove(s)
+                rec_a["solved"].add(s)
+            nxt, r1 = choose_next_state(proc_a, 60, rec_a, r1, 0.3, stride=stride)
+            proc_a.add(nxt)
+            out_a.append(nxt)
+        random.setstate(start)
+        out_b = []
+        for done, s in events:
+            if done:
+                cur.mark_solved(s)
+            out_b.append(cur.next_state())
+        assert out_a == out_b and proc_a == proc_b and rec_a == rec_b and r1 == cur.round1_complete
