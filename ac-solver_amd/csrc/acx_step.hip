@@ -351,9 +351,11 @@ __device__ __forceinline__ void wave_lds_handoff() {
 // DIAGNOSTIC build only (tools/step_stamps.py, -DACX_STEP_STAMP through tools/build_variant.sh; in the shipped library no stamp
 // executes): every wave of k_env_step logs when it started and when its last store was issued, on the 100 MHz constant
 // clock (s_memrealtime).  The log is read by nothing else in the kernel and no output is computed from it.
-constexpr unsigned int kStampCap = 1u << 21;
+// No shared cursor (1024 waves adding to ONE word take ~11 us): wave w of a launch owns the slots w, w + waves, w + 2 waves ...
+// and keeps its own launch count in g_stamp_seq[w]; the bookkeeping runs BEHIND the end stamp.
+constexpr unsigned int kStampCap = 1u << 21, kStampWaves = 1u << 16;
 __device__ unsigned long long g_stamp_log[2 * kStampCap];
-__device__ unsigned int g_stamp_cursor;
+__device__ unsigned int g_stamp_seq[kStampWaves];
 #endif
 
 template <typename W, bool SAFE, typename OBS, int LC, bool SUPER = false>
@@ -417,10 +419,15 @@ __global__ void __launch_bounds__(256, SUPER ? 5 : ACX_STEP_WAVES) k_env_step(W*
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's stores have left (the real kernel simply ends here)
     const unsigned long long stamp_end = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
-        const unsigned int k = atomicAdd(&g_stamp_cursor, 1u);
-        if (k < kStampCap) {
-            g_stamp_log[2 * k] = stamp_begin;
-            g_stamp_log[2 * k + 1] = stamp_end;
+        const unsigned int w = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+        if (w < kStampWaves) {
+            const unsigned int seq = g_stamp_seq[w];
+            const unsigned long long k = (unsigned long long)seq * nw + w;
+            if (k < kStampCap) {
+                g_stamp_log[2 * k] = stamp_begin;
+                g_stamp_log[2 * k + 1] = stamp_end;
+            }
+            g_stamp_seq[w] = seq + 1;
         }
     }
 #endif
@@ -1012,17 +1019,19 @@ int acx_env_step_host(acx_env* e, const int64_t* h_actions, int8_t* h_obs, float
 
 #ifdef ACX_STEP_STAMP
 // diagnostic build only: the wave stamps of k_env_step since the last reset, as (begin, end) pairs of 10 ns ticks
-int acx_debug_stamps(unsigned long long* h_out, int64_t cap_pairs, int64_t* n_pairs, int reset) {
-    unsigned int n = 0;
+// h_out: [launches][waves] (begin, end) pairs; *n_launches = launches of `waves` waves logged since the last reset
+int acx_debug_stamps(unsigned long long* h_out, int64_t cap_pairs, int64_t waves, int64_t* n_launches, int reset) {
+    unsigned int seq = 0;
     ACX_HIP_TRY(hipDeviceSynchronize());
-    ACX_HIP_TRY(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_stamp_cursor), 4));
-    if (n > kStampCap) n = kStampCap;
-    *n_pairs = n;
-    const int64_t m = n < cap_pairs ? n : cap_pairs;
+    ACX_HIP_TRY(hipMemcpyFromSymbol(&seq, HIP_SYMBOL(g_stamp_seq), 4));  // wave 0's count
+    int64_t n = seq;
+    if (waves > 0 && n * waves > (int64_t)kStampCap) n = kStampCap / waves;
+    *n_launches = n;
+    const int64_t m = n * waves < cap_pairs ? n * waves : cap_pairs;
     if (h_out && m > 0) ACX_HIP_TRY(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_stamp_log), (size_t)m * 16));
     if (reset) {
-        const unsigned int zero = 0;
-        ACX_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_cursor), &zero, 4));
+        static unsigned int zeros[kStampWaves];
+        ACX_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_seq), zeros, sizeof(zeros)));
     }
     return ACX_OK;
 }

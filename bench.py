@@ -371,34 +371,52 @@ def extra_env_numbers(dev, pool):
         del e1
     except Exception as e:  # noqa: BLE001
         out["single_call_surface"] = {"error": f"{type(e).__name__}: {e}"}
-    n_big, k_big = 1 << 22, 20
-    env = ACVecEnv(pool[np.arange(n_big) % len(pool)], horizon_length=HORIZON, record_actions=False, final_info=False)
-    tape = torch.randint(0, 12, (k_big, n_big), dtype=torch.uint8, device=dev)
-    obs = torch.empty((2, n_big, 2 * L), dtype=torch.int8, device=dev)
-    rew = torch.empty((2, n_big), dtype=torch.float32, device=dev)
-    done = torch.empty((2, n_big), dtype=torch.bool, device=dev)
-    trunc = torch.empty((2, n_big), dtype=torch.bool, device=dev)
-
-    def step(k):
-        _acx.check(_acx.lib.acx_env_step(env._h.ptr, tape[k].data_ptr(), _acx.U8, obs[k & 1].data_ptr(), _acx.I8, rew[k & 1].data_ptr(), 0.0, 0.0,
-                                         done[k & 1].data_ptr(), trunc[k & 1].data_ptr(), None, 1, env._stream()))
-
-    for k in range(4):
-        step(k)
+    # The same kernel where launch overhead is < 5 % of a launch: 2^20 and 4 Mi envs, eager launches back to back, outputs rotating
+    # over 8 rollout rows.  profiles/r3_env_step_roofline.json holds the rocprofv3 --kernel-trace average and the FETCH_SIZE /
+    # WRITE_SIZE passes of the same command (tools/profile_env_r3.sh): trace and HIP events agree to 1-4 % at these sizes.
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for k in range(4, k_big):
-        step(k)
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / (k_big - 4)
-    out["throughput_regime"] = {"envs": n_big, "us_per_step_launch": us, "env_steps_per_s": n_big / us * 1e6,
-                                "achieved_GBps_algorithmic": ALGO_BYTES_PER_STEP * n_big / us / 1e3,
-                                "frac_of_hbm_peak": ALGO_BYTES_PER_STEP * n_big / us / 1e3 / HBM_PEAK_GBS,
-                                "note": "by SURVEY 8(d)'s ALGORITHMIC bytes (int8 row in + observation row out + action, reward, flags = 107 B per env-step); "
-                                        "the kernel's own packed state (24 B read + 24 B written per env-step, 100 MB in all) stays in the 256 MB Infinity "
-                                        "Cache at this size, what goes to HBM is the 56-B observation / reward / flag stream"}
-    del env, obs, tape
+    regimes = {}
+    for n_big in (1 << 20, 1 << 22):
+        rows, k_big = 8, 44
+        env = ACVecEnv(pool[np.arange(n_big) % len(pool)], horizon_length=HORIZON, record_actions=False, final_info=False)
+        tape = torch.randint(0, 12, (k_big, n_big), dtype=torch.uint8, device=dev)
+        obs = torch.empty((rows, n_big, 2 * L), dtype=torch.int8, device=dev)
+        rew = torch.empty((rows, n_big), dtype=torch.float32, device=dev)
+        done = torch.empty((rows, n_big), dtype=torch.bool, device=dev)
+        trunc = torch.empty((rows, n_big), dtype=torch.bool, device=dev)
+
+        def step(k):
+            r = k % rows
+            _acx.check(_acx.lib.acx_env_step(env._h.ptr, tape[k].data_ptr(), _acx.U8, obs[r].data_ptr(), _acx.I8, rew[r].data_ptr(), 0.0, 0.0,
+                                             done[r].data_ptr(), trunc[r].data_ptr(), None, 1, env._stream()))
+
+        for k in range(4):
+            step(k)
+        e0.record()
+        for k in range(4, k_big):
+            step(k)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / (k_big - 4)
+        # What of a launch's bytes can be served by the 256 MiB Infinity Cache (MI355X_MICROARCH.md: a buffer stays resident only while
+        # it plus every byte moved between two uses of it fits): the packed state (48 B per env-step, reused every launch) does while
+        # one launch moves < 256 MiB in all; the action / observation / reward / flag streams (57 B) never do (a row comes back
+        # after 8 launches).  The FETCH_SIZE / WRITE_SIZE counters cannot tell the two apart (they count Infinity-Cache hits).
+        per_launch = (ALGO_BYTES_PER_STEP - 2) * n_big  # bytes the kernel really moves: 24 + 24 + 1 + 50 + 4 + 1 + 1 = 105 B per env
+        state_resident = per_launch < (256 << 20)
+        beyond = (57 if state_resident else 105) * n_big
+        regimes[str(n_big)] = {"envs": n_big, "us_per_step_launch": us, "env_steps_per_s": n_big / us * 1e6,
+                               "achieved_GBps_algorithmic": ALGO_BYTES_PER_STEP * n_big / us / 1e3,
+                               "frac_of_hbm_peak_algorithmic": ALGO_BYTES_PER_STEP * n_big / us / 1e3 / HBM_PEAK_GBS,
+                               "hbm_bytes_beyond_mall_per_launch": beyond, "frac_of_hbm_peak_beyond_mall": beyond / us / 1e3 / HBM_PEAK_GBS,
+                               "state_stays_in_infinity_cache": state_resident}
+        del env, obs, tape, rew, done, trunc
+    out["throughput_regime"] = regimes["4194304"]
+    out["throughput_regime"]["note"] = ("4 Mi envs: one launch moves 440 MB, more than the 256 MiB Infinity Cache, so state and streams all come from / go to HBM; "
+                                        "algorithmic = SURVEY 8(d)'s 107 B per env-step (the kernel moves 105: its state is 2 x 24 B packed, not 2 x 25)")
+    out["throughput_regime_1Mi"] = regimes["1048576"]
+    out["throughput_regime_1Mi"]["note"] = ("2^20 envs: one launch moves 110 MB; the 50 MB of packed state stay in the Infinity Cache, the 57 B per env-step of "
+                                            "action / observation / reward / flag streams are what reaches HBM")
     n, T = N_ENVS, 1000
     env = ACVecEnv(pool[np.arange(n) % len(pool)], horizon_length=HORIZON, record_actions=False, final_info=False)
     tape = torch.randint(0, 12, (T, n), dtype=torch.uint8, device=dev)
@@ -662,16 +680,32 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/env_step_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and batch)"
         # the same kernel under rocprofv3 --kernel-trace: the profiler stamps every dispatch of the replayed graph begin-to-end
         # (launch latency included, no overlap with its neighbours), which is longer than the back-to-back launch period timed here
-        prof = os.path.join(ROOT, "profiles", "r2_bench_graph_kernel_stats.csv")
-        if os.path.exists(prof) and N == N_ENVS:
-            import csv
-
-            with open(prof) as f:
-                for row in csv.DictReader(f):
-                    if "k_env_step<" in row["Name"]:
-                        us = float(row["AverageNs"]) * 1e-3
-                        out["roofline"]["rocprof"] = {"avg_kernel_us": us, "calls": int(row["Calls"]), "source": "profiles/r2_bench_graph_kernel_stats.csv",
-                                                      "frac_by_kernel_duration": ALGO_BYTES_PER_STEP * N / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        # At this batch size the K rollout rows + the state (K x 3.7 MB + 1.6 MB) sit in the 256 MiB Infinity Cache whenever K <= ~60:
+        # nothing of a launch HAS to reach HBM before the next one starts -- the launch is bound by latency (kernel boundary + one
+        # dependent memory round trip + instruction issue), and `frac` says how far that is from the HBM roofline, not which
+        # resource is saturated.
+        working_set = K * (2 * L + 6) * N + 24 * N
+        out["roofline"]["hbm_bytes_beyond_mall"] = 0 if working_set < (256 << 20) else (ALGO_BYTES_PER_STEP - 50) * N
+        out["roofline"]["working_set_bytes"] = working_set
+        ev = os.path.join(ROOT, "profiles", "r3_env_step_roofline.json")
+        if os.path.exists(ev) and N == N_ENVS:
+            with open(ev) as f:
+                r3 = json.load(f)
+            kt, stp = r3.get(str(N), {}).get("rocprof_kernel_trace"), r3.get("stamps_65536")
+            if kt:  # isolated dispatches (eager launches ~10 us apart): the kernel's begin-to-end LATENCY, not the back-to-back period timed here
+                out["roofline"]["rocprof"] = {"avg_kernel_us": kt["avg_us"], "min_kernel_us": kt["min_us"], "calls": kt["calls"],
+                                              "source": "profiles/r3_env_step_65536_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 tools/env_roofline.py 65536 400)",
+                                              "frac_by_kernel_duration": ALGO_BYTES_PER_STEP * N / (kt["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            if stp:  # in-kernel stamps of the diagnostic build under the same graph replay: where the period goes
+                out["roofline"]["stamps"] = {"active_us": stp["active_us_median"], "launch_boundary_us": stp["gap_us_median"], "one_wave_us": stp["one_wave_us_median"],
+                                             "wave_start_spread_us": stp["wave_start_spread_us_median"], "frac_by_active_time": stp["frac_of_8TBps_by_active_time"],
+                                             "source": "profiles/r3_env_step_roofline.json: tools/step_stamps.py on the -DACX_STEP_STAMP build (s_memrealtime per wave)"}
+            big = r3.get("1048576", {})
+            if big.get("rocprof_kernel_trace"):  # where trace and HIP events agree (launch overhead < 5 %): the kernel against the roofline
+                out["roofline"]["at_1Mi_envs"] = {"hip_event_us": big["hip_event"]["hip_event_us_per_launch"], "rocprof_avg_us": big["rocprof_kernel_trace"]["avg_us"],
+                                                  "frac_by_hip_events": big["frac_of_8TBps_by_hip_events"], "frac_by_rocprof_avg": big["frac_of_8TBps_by_rocprof_avg"],
+                                                  "traffic_bytes_per_launch": big.get("traffic_bytes_per_launch"), "algorithmic_bytes_per_launch": big["algorithmic_bytes_per_launch"],
+                                                  "source": "profiles/r3_env_step_1048576_kernel_stats.csv + r3_env_step_roofline.json"}
         if extras is not None:
             out["env_context"] = extras
         if search is not None:
