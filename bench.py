@@ -676,7 +676,7 @@ def main():
         if os.path.exists(traffic_file) and N == N_ENVS:  # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
             with open(traffic_file) as f:
                 out["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
-            # not measured in this run: counters need their own rocprofv3 passes (tools/pmc_env.py; 2 x FETCH_SIZE + WRITE_SIZE)
+            # not measured in this run: counters need their own rocprofv3 passes (tools/profile_env_r3.sh; 2 x FETCH_SIZE + WRITE_SIZE)
             out["roofline"]["traffic_source"] = "profiles/env_step_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and batch)"
         # the same kernel under rocprofv3 --kernel-trace: the profiler stamps every dispatch of the replayed graph begin-to-end
         # (launch latency included, no overlap with its neighbours), which is longer than the back-to-back launch period timed here

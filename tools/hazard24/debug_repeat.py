@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Repeat one bfs and print its stats each time: python tools/debug_repeat.py pool_index budget cyclical repeats"""
+"""Repeat one bfs and print its stats each time: python tools/hazard24/debug_repeat.py pool_index budget cyclical repeats"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "ac-solver_amd"), ROOT]
 import numpy as np
 from ac_solver import _acx

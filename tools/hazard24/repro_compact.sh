@@ -11,6 +11,6 @@ ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$ROOT"
 [ -f ac-solver_amd/lib/var_hazard.so ] || bash tools/build_search_variant.sh hazard -DACX_HAZARD_REPRO -DACX_COMPACT_ITEMS=8
 echo "== shipped library"
-python3 tools/debug_repeat.py 145 1e6 1 5
+python3 tools/hazard24/debug_repeat.py 145 1e6 1 5
 echo "== k_bfs_compact as in commit 57c6f83: exactly its 32 registers declared"
-ACX_LIB=ac-solver_amd/lib/var_hazard.so python3 tools/debug_repeat.py 145 1e6 1 5
+ACX_LIB=ac-solver_amd/lib/var_hazard.so python3 tools/hazard24/debug_repeat.py 145 1e6 1 5
