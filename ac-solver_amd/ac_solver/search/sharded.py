@@ -235,13 +235,16 @@ def owner_of(keys, world):
 
 
 def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False, comm=None,
-                engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5):
+                engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None):
     """Same contract as `bfs`: returns (is_search_successful, path or None) [+ stats dict], identical on every rank.
     `batch_parents`: global frontier positions per chunk.  `log_fraction`: expected expanded parents / max_nodes, sizes the
-    record log (it grows by doubling if the estimate is short)."""
+    record log (it grows by doubling if the estimate is short).  `overlap`: expansion + exchange of chunk k + 1 on a side stream beside the dedup + commit of chunk k (default: when there is an exchange, i.e. world > 1)."""
     from ac_solver.envs.utils import is_array_valid_presentation
 
+    import time
+
     torch = _torch()
+    t_begin = time.perf_counter()
     assert is_array_valid_presentation(presentation), f"{presentation} is not a valid presentation"
     p = np.array(presentation, dtype=np.int8)
     L = len(p) // 2
@@ -267,6 +270,7 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
     levels = chunks = 0
     failure = None
     ctl = None
+    t_ready = time.perf_counter()  # engine built (device allocations, table fill), root seeded
 
     def walk(pref, tail):
         """path of the node `pref` (rank << 40 | id) from the root + tail"""
@@ -291,6 +295,7 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
         if want_stats:
             st = dict(nodes=int(ctl[CTL_NODES_GLOBAL]), expanded=int(ctl[CTL_EXPANDED]), levels=levels, chunks=chunks, min_len=2 if ok else -int(e[1]), world=world)
             st.update({"comm_" + k: v for k, v in getattr(comm, "stats", {}).items()})
+            st.update(setup_seconds=t_ready - t_begin, loop_seconds=time.perf_counter() - t_ready)
             return ok, path, st
         return ok, path
 
@@ -299,9 +304,14 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
     # different resources).  Inside a level chunk k + 1 needs nothing from chunk k: its parents were committed during the
     # previous level and it has its own slice of the record log; only the send buffer is shared, and that is reused in `side`'s
     # own order.  The CPU engines of the tests run everything in program order.
+    # At world 1 there is no exchange to hide and the two streams gain 3 % at best -- and LOSE 40 % in some process states (a
+    # freshly started process: 20 ms against 15 ms at 1e8 nodes; inside bench.py after its graph capture: 31 ms), so the side
+    # stream is the default only where it has an all-to-all to carry.
+    if overlap is None:
+        overlap = exchange
     on_gpu = dev.type == "cuda"
     main = torch.cuda.current_stream(dev) if on_gpu else None
-    side = torch.cuda.Stream(dev) if on_gpu else None
+    side = (torch.cuda.Stream(dev) if overlap else main) if on_gpu else None
 
     class _on_side:
         def __enter__(self):

@@ -18,18 +18,26 @@ MS = [-1, 2, 1, -2, -2, 0, 0, 0, 0, 0, -1, 2, 1, 2, 0, 0, 0, 0, 0, 0]
 CASES = [(AK2, 100000, False), (AK2, 10, False), (AK2, 500, False), (AK2, 1, False), (AK2, 3000, True), (MS, 2000, False), (MS, 40, True)]
 
 
-def _run(comm, batch):
+SMALL = [(AK2, 4000, False), (AK2, 10, False), (AK2, 500, False), (AK2, 1, False), (AK2, 1500, True), (MS, 2000, False), (MS, 40, True)]
+
+
+def _strip(results):
+    """(ok, path, stats without the wall-clock fields)"""
+    return [(ok, path, {k: v for k, v in st.items() if not k.endswith("_seconds")}) for ok, path, st in results]
+
+
+def _run(comm, batch, cases=None):
     from ac_solver.search.sharded import bfs_sharded
 
     res = []
-    for p, budget, cyc in CASES:
+    for p, budget, cyc in cases or CASES:
         res.append(bfs_sharded(p, budget, cyclically_reduce_after_moves=cyc, comm=comm, engine_factory=OracleShardEngine,
                                batch_parents=batch, want_stats=True))
     return res
 
 
-def _check(results):
-    for (p, budget, cyc), (ok, path, st) in zip(CASES, results):
+def _check(results, cases=None):
+    for (p, budget, cyc), (ok, path, st) in zip(cases or CASES, results):
         wok, wpath, wst = O.bfs(p, budget, cyclically_reduce_after_moves=cyc, stats=True)
         assert (ok, path) == (wok, wpath), (budget, cyc)
         assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (budget, cyc, st, wst)
@@ -42,8 +50,9 @@ def test_thread_ranks_match_reference(world, batch):
     if world == 1:
         _check(_run(SingleComm(), batch))
         return
-    for res in run_threads(world, lambda comm: _run(comm, batch)):
-        _check(res)
+    cases = CASES if batch > 1000 else SMALL  # (the NumPy engine is slow: tiny chunks get smaller budgets)
+    for res in run_threads(world, lambda comm: _run(comm, batch, cases)):
+        _check(res, cases)
 
 
 def _gloo_worker(rank, world, port, q):
@@ -70,7 +79,7 @@ def test_gloo_world2_matches_reference():
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     _check(got[0])
-    assert got[0] == got[1]  # every rank returns the same answer
+    assert _strip(got[0]) == _strip(got[1])  # every rank returns the same answer
 
 
 def test_a_failing_rank_takes_every_rank_down_without_deadlock():
