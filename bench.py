@@ -208,6 +208,13 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
                                         "frac": algo / secs / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
                                         "kernel": "k_shard_insert<u64> + k_shard_expand<u64> + k_shard_commit<u64> (whole search, wall time)",
                                         "algorithmic_bytes": algo, "bytes_per_child": 64.0 + 72.0 * f_new, "children": children}}}
+    tf = os.path.join(ROOT, "profiles", "search_traffic.json")
+    if world == 1 and os.path.exists(tf):  # HBM bytes of the same search from rocprofv3 --pmc passes (profiles/README.md)
+        with open(tf) as fh:
+            t = json.load(fh).get("bfs_sharded_ak3_1e8")
+        if t and t.get("children") == children:
+            out["bfs_sharded"]["roofline"]["traffic"] = t["hbm_bytes"]
+            out["bfs_sharded"]["roofline"]["traffic_source"] = t["source"]
     if world > 1:
         # the same frontier with the budget grown with the number of GPUs (weak scaling: 1e8 nodes per GPU)
         try:
