@@ -84,7 +84,7 @@ template <typename W> __global__ void k_bfs_root(SearchDev<W> d, W k0, W k1, uin
 // larger tag of the same key); brepl[tag] = 1 is set for a holder that was replaced (brepl is zero on entry:
 // cleared once per search, k_bfs_compact zeroes what a batch set).
 template <typename W, int MODE>
-__global__ void __launch_bounds__(kBfsBlock, (sizeof(W) == 8 && MODE != kMoveGeneral) ? 8 : 4) k_bfs_expand_insert(SearchDev<W> d, uint32_t pbegin, uint32_t np) {
+__global__ void __launch_bounds__(kBfsBlock, (sizeof(W) == 8 && MODE != kMoveGeneral) ? 8 : 4) k_bfs_expand_insert(SearchDev<W> d, uint32_t pbegin, uint32_t np, const BfsCursor* __restrict__ cur = nullptr) {
     __shared__ W s_k0[kBfsBlock];
     __shared__ W s_k1[kBfsBlock];
     __shared__ uint32_t s_slot[kBfsLdsSlots];
@@ -93,9 +93,16 @@ __global__ void __launch_bounds__(kBfsBlock, (sizeof(W) == 8 && MODE != kMoveGen
     } else {
         ACX_VGPR_PAD_W(W, "v63", "v95");
     }
+    if (cur) {  // run-ahead mode: the batch is whatever the cursor says (np arrives as the batch capacity)
+        if (cur->status) return;
+        pbegin = cur->head;
+        const uint32_t avail = cur->nodes - pbegin;
+        np = avail < np ? avail : np;
+    }
     const uint32_t tid = threadIdx.x;
     const uint32_t t = blockIdx.x * kBfsBlock + tid;
     const uint32_t m = 12u * np;
+    if (blockIdx.x * kBfsBlock >= m) return;  // (a full-size grid over a short batch)
     s_slot[tid] = kEmpty;
     s_slot[tid + kBfsBlock] = kEmpty;
     W c0 = 0, c1 = 0;
@@ -238,7 +245,8 @@ __global__ void __launch_bounds__(kBfsBlock, (sizeof(W) == 8 && MODE != kMoveGen
 // Winners -> nodes in one pass: k_compact_tab (acx_frontier.h) with the winners' keys recomputed from their parents.
 template <typename W, int MODE>
 __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pbegin, uint32_t m, uint32_t base, uint32_t cap_nodes, uint32_t epoch,
-                                                     unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t* __restrict__ total_out) {
+                                                     unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t* __restrict__ total_out,
+                                                     const BfsCursor* __restrict__ cur = nullptr) {
     __shared__ uint32_t s_tile, s_prefix, s_wsum[4];
     __shared__ uint16_t s_list[kCompactTile];
 #ifdef ACX_HAZARD_REPRO  // tools/hazard24/repro_compact.sh: the kernel as it was when it corrupted (exactly the 32 registers it uses)
@@ -246,6 +254,15 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
 #else
     ACX_VGPR_PAD_W(W, "v47", "v63");
 #endif
+    if (cur) {  // run-ahead mode (m arrives as the capacity 12 * bmax)
+        if (cur->status) return;
+        pbegin = cur->head;
+        const uint32_t avail = 12u * (cur->nodes - pbegin);
+        m = avail < m ? avail : m;
+        base = cur->nodes;
+        epoch = cur->batches + 1;
+    }
+    if (blockIdx.x >= (m + kCompactTile - 1) / kCompactTile) return;  // a full-size grid over a short batch: only the batch's tiles take tickets
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();

@@ -513,10 +513,57 @@ __global__ void __launch_bounds__(256) k_compact_tab(SearchDev<W> d, uint32_t pb
 
 // k_decide for the one-pass BFS commit: the winners of the batch are nodes base .. base + total - 1 in tag order, so
 // "winners before tag T" is a binary search over their (parent, action) and the budget-crossing candidate is winner need - 1.
+// Device-resident batch cursor of the fused BFS (round 3).  Once the frontier holds a full batch the host stops reading every
+// batch's decision back (a 25 us round trip per batch, 33 per 1e8-node search): it enqueues batch after batch with full-size
+// grids, the kernels take "which parents, how many nodes" from this block, k_decide_tab advances it, and the host looks at a
+// pinned snapshot two batches late.  A batch that ENDS the search (success, budget, a raising move, a full table) is not applied:
+// its decision is parked in `term` and the host finishes it exactly as it finishes a batch it read back synchronously.
+struct BfsCursor {
+    uint32_t head, nodes;     // next FIFO position to expand / len(tree_nodes)
+    uint32_t status;          // 0 running, 1 the batch described by term* ended the search (not applied), 3 queue exhausted (applied)
+    uint32_t batches;
+    unsigned long long expanded;
+    uint32_t min_len, term_pbegin, term_np, pad_;
+    Decision term;
+};
+
+__device__ __forceinline__ bool cursor_begin(const BfsCursor* cur, uint32_t& m, uint32_t& np, uint32_t& pbegin, uint32_t& base) {
+    if (cur->status) return false;
+    pbegin = cur->head;
+    const uint32_t avail = cur->nodes - pbegin;
+    np = avail < np ? avail : np;
+    m = 12u * np;
+    base = cur->nodes;
+    return true;
+}
+__device__ __forceinline__ void cursor_advance(BfsCursor* cur, const Decision& dec, uint32_t pbegin, uint32_t np, uint32_t base) {
+    cur->batches += 1;
+    if (dec.min_len < cur->min_len) cur->min_len = dec.min_len;
+    // (the status word is stored LAST, behind a fence: the host's snapshot copies may run while this kernel does, and whatever they
+    // see with a non-zero status must be complete)
+    if (dec.solved || dec.budget_hit || dec.err) {  // this batch ends the search: the host finishes it
+        cur->term = dec;
+        cur->term_pbegin = pbegin;
+        cur->term_np = np;
+        __threadfence();
+        cur->status = 1;
+    } else {
+        const uint32_t head = pbegin + dec.p_end + 1, nodes = base + dec.committed;
+        cur->head = head;
+        cur->nodes = nodes;
+        cur->expanded += (unsigned long long)dec.p_end + 1;
+        if (head >= nodes) {  // queue exhausted (breadth_first.py:61)
+            __threadfence();
+            cur->status = 3;
+        }
+    }
+}
+
 template <typename W>
 __global__ void k_decide_tab(SearchDev<W> d, uint32_t m, uint32_t np, uint32_t pbegin, uint32_t base, uint32_t cap_nodes, long long max_nodes,
-                             const uint32_t* __restrict__ total_in, Decision* __restrict__ out, int reset_tags = 0) {
+                             const uint32_t* __restrict__ total_in, Decision* __restrict__ out, int reset_tags = 0, BfsCursor* cur = nullptr) {
     ACX_VGPR_PAD("v23");
+    if (cur && !cursor_begin(cur, m, np, pbegin, base)) return;  // run-ahead mode (acx_bfs.h): the batch is what the cursor says
     const uint32_t total = *total_in;
     const unsigned long long nodes = base;
     uint32_t p_end = np - 1, budget_hit = 0;
@@ -565,6 +612,7 @@ __global__ void k_decide_tab(SearchDev<W> d, uint32_t m, uint32_t np, uint32_t p
         *d.shorter_tag = kNoTag;
         *d.err_tag = kNoTag;
     }
+    if (cur) cursor_advance(cur, *out, pbegin, np, base);
 }
 
 // root node: id 0

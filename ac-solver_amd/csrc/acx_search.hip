@@ -85,9 +85,14 @@ template <typename W, typename KEYS> static int node_digest(KEYS keys, const uin
     return ACX_OK;
 }
 
+constexpr int kRunAheadSlots = 4, kRunAheadLag = 2;  // pinned snapshots of the BFS cursor / how many batches the host runs ahead of the one it reads
+
 template <typename W> struct Searcher {
     SearchDev<W> d;
-    DevBuf arena_nodes, arena_cand, arena_tab, arena_btab, arena_scal, arena_tmp, arena_list, arena_path, arena_status, arena_first;
+    DevBuf arena_nodes, arena_cand, arena_tab, arena_btab, arena_scal, arena_tmp, arena_list, arena_path, arena_status, arena_first, arena_cursor;
+    uint8_t* h_cursor = nullptr;  // pinned: kRunAheadSlots x BfsCursor (behind the Decision staging)
+    hipEvent_t ev_cursor[kRunAheadSlots] = {}, ev_batch[kRunAheadSlots] = {};
+    hipStream_t st_copy = nullptr;  // the cursor snapshots travel on a stream of their own: a copy queued on `st` sits between two batches (10 us)
     unsigned long long h_first[kFirstLen];
     unsigned long long* d_status = nullptr;  // one-pass BFS commit: per-tile look-back words
     uint32_t* d_ticket = nullptr;
@@ -100,6 +105,11 @@ template <typename W> struct Searcher {
     size_t h_pin_bytes = 0;
 
     ~Searcher() {
+        for (auto& e : ev_cursor)
+            if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_batch)
+            if (e) (void)hipEventDestroy(e);
+        if (st_copy) (void)hipStreamDestroy(st_copy);
         if (st) (void)hipStreamDestroy(st);
     }
 
@@ -178,9 +188,17 @@ template <typename W> struct Searcher {
         if (arena_scal.alloc(256)) return ACX_E_NOMEM;
         uint8_t* sc = (uint8_t*)arena_scal.p;
         d_dec = (Decision*)(sc + 64);
-        h_pin_bytes = sizeof(Decision) + 64 + cap_cand;
+        const size_t cursor_off = (sizeof(Decision) + 64 + cap_cand + 255) / 256 * 256;
+        h_pin_bytes = cursor_off + (stamp_tab ? kRunAheadSlots * sizeof(BfsCursor) : 0);
         h_pin = pinned_staging(h_pin_bytes);
         if (!h_pin) return fail(ACX_E_NOMEM, "hipHostMalloc(%zu) failed", h_pin_bytes);
+        if (stamp_tab) {  // run-ahead batches of the fused BFS (acx_frontier.h: BfsCursor)
+            h_cursor = h_pin + cursor_off;
+            if (arena_cursor.alloc(sizeof(BfsCursor))) return ACX_E_NOMEM;
+            for (auto& e : ev_cursor) ACX_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto& e : ev_batch) ACX_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ACX_HIP_TRY(hipStreamCreateWithFlags(&st_copy, hipStreamNonBlocking));
+        }
         d.solved_tag = (unsigned long long*)(sc + 0);
         d.shorter_tag = (unsigned long long*)(sc + 8);
         d.err_tag = (unsigned long long*)(sc + 16);  // reset with the other batch scalars
@@ -773,6 +791,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
     std::vector<uint32_t> hlist;
     std::vector<uint8_t> hlen;
     const bool debug = getenv("ACX_DEBUG") != nullptr;
+    const bool no_runahead = getenv("ACX_BFS_NO_RUNAHEAD") != nullptr;  // A/B: every batch's decision read back, as in round 2
     const bool classic_commit = getenv("ACX_BFS_CLASSIC_COMMIT") != nullptr;  // A/B: mark + scan + decide + commit as four launches
     uint32_t adaptive = 64;  // greedy batch size: grows while buckets are consumed without a cut
     uint32_t printed_min = tl0;  // verbose mode: the minimum the reference has printed so far
@@ -785,10 +804,70 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         uint32_t pbegin = 0;
         int bucket_len = -1;
         uint32_t bucket_depth = 0;
+        bool have_dec = false;  // the batch's decision is already in *dec (it came out of the run-ahead phase below)
+        Decision* dec = (Decision*)S.h_pin;
         if (!greedy) {
             if (bfs_head >= nodes) break;  // queue exhausted (breadth_first.py:61)
-            np = (uint32_t)std::min<uint64_t>(nodes - bfs_head, bmax);
-            pbegin = bfs_head;
+            if (stamp && !d.first_len && !debug && !no_runahead && nodes - bfs_head >= bmax) {
+                // ---- run-ahead (acx_frontier.h: BfsCursor): the frontier holds a full batch, so from here on the batches are enqueued
+                // back to back with full-size grids and the host reads the cursor two batches late instead of every decision
+                BfsCursor hc;
+                memset(&hc, 0, sizeof(hc));
+                hc.head = bfs_head;
+                hc.nodes = (uint32_t)nodes;
+                hc.batches = (uint32_t)batches;
+                hc.expanded = expanded;
+                hc.min_len = min_len;
+                BfsCursor* dcur = (BfsCursor*)S.arena_cursor.p;
+                BfsCursor* snap = (BfsCursor*)S.h_cursor;  // pinned, kRunAheadSlots entries
+                ACX_HIP_TRY(hipMemcpyAsync(dcur, &hc, sizeof(hc), hipMemcpyHostToDevice, st));
+                const uint32_t mcap = 12u * bmax;
+                const dim3 egrid((mcap + kBfsBlock - 1) / kBfsBlock), eblock(kBfsBlock), cgrid((mcap + kCompactTile - 1) / kCompactTile), cblock(256);
+                const BfsCursor* fin = nullptr;
+                for (uint64_t k = 0; !fin; k++) {
+                    if (batches + k + 1 >= (1ull << 30)) return fail(ACX_E_CAPACITY, "acx_search: more than 2^30 batches (the look-back words carry a 30-bit batch number)");
+#define ACX_BFS_AHEAD(MODE)                                                                                                                              \
+    hipLaunchKernelGGL((k_bfs_expand_insert<W, MODE>), egrid, eblock, 0, st, d, 0u, bmax, dcur);                                                        \
+    hipLaunchKernelGGL((k_bfs_compact<W, MODE>), cgrid, cblock, 0, st, d, 0u, mcap, 0u, (uint32_t)S.cap_nodes, 0u, S.d_status, S.d_ticket, S.d_total, dcur)
+                    if (move_mode == kMoveNf) {
+                        ACX_BFS_AHEAD(kMoveNf);
+                    } else if (move_mode == kMoveNfCyclical) {
+                        ACX_BFS_AHEAD(kMoveNfCyclical);
+                    } else {
+                        ACX_BFS_AHEAD(kMoveGeneral);
+                    }
+#undef ACX_BFS_AHEAD
+                    hipLaunchKernelGGL(k_decide_tab<W>, dim3(1), dim3(1), 0, st, d, mcap, bmax, 0u, 0u, (uint32_t)S.cap_nodes, (long long)max_nodes, S.d_total, S.d_dec, 1, dcur);
+                    ACX_HIP_TRY(hipGetLastError());
+                    const int slot = (int)(k % kRunAheadSlots);
+                    // snapshot of the cursor as this batch leaves it: copied on the side stream, behind an event of the main one.  (The
+                    // next batch may have advanced the cursor by the time the copy runs: a snapshot is then one batch FRESHER, which
+                    // is fine -- a status once set never changes, and the counters of a non-zero status are final.)
+                    ACX_HIP_TRY(hipEventRecord(S.ev_batch[slot], st));
+                    ACX_HIP_TRY(hipStreamWaitEvent(S.st_copy, S.ev_batch[slot], 0));
+                    ACX_HIP_TRY(hipMemcpyAsync(&snap[slot], dcur, sizeof(BfsCursor), hipMemcpyDeviceToHost, S.st_copy));
+                    ACX_HIP_TRY(hipEventRecord(S.ev_cursor[slot], S.st_copy));
+                    if (k >= kRunAheadLag) {
+                        const int old = (int)((k - kRunAheadLag) % kRunAheadSlots);
+                        ACX_HIP_TRY(hipEventSynchronize(S.ev_cursor[old]));
+                        if (snap[old].status) fin = &snap[old];  // (the batches enqueued behind it returned at once and left the cursor alone)
+                    }
+                }
+                bfs_head = fin->head;
+                nodes = fin->nodes;
+                batches = fin->batches;
+                expanded = fin->expanded;
+                min_len = std::min<uint32_t>(min_len, fin->min_len);
+                if (fin->status == 3) continue;  // the queue ran empty: the check at the top of the loop ends the search
+                // the batch that ends the search: finished below exactly like a batch whose decision was read back
+                pbegin = fin->term_pbegin;
+                np = fin->term_np;
+                *dec = fin->term;
+                have_dec = true;
+            } else {
+                np = (uint32_t)std::min<uint64_t>(nodes - bfs_head, bmax);
+                pbegin = bfs_head;
+            }
         } else {
             if (buckets.empty()) break;  // heap exhausted (greedy.py:71)
             auto it = buckets.begin();
@@ -823,6 +902,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         }
         const uint32_t m = 12u * np;
         const dim3 grid((m + 255) / 256), block(256);
+        if (!have_dec) {
         batches++;
         if (debug) fprintf(stderr, "[acx_search] batch %llu: np=%u nodes=%llu bucket=(%d,%u) buckets=%zu\n", (unsigned long long)batches, np,
                            (unsigned long long)nodes, bucket_len, bucket_depth, buckets.size());
@@ -885,12 +965,12 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         }
         ACX_HIP_TRY(hipGetLastError());
         // one read-back: the decision and (greedy) the total lengths of the nodes this batch may have created
-        Decision* dec = (Decision*)S.h_pin;
-        uint8_t* hl = S.h_pin + sizeof(Decision) + 64 - (sizeof(Decision) % 64);
         ACX_HIP_TRY(hipMemcpyAsync(dec, S.d_dec, sizeof(Decision), hipMemcpyDeviceToHost, st));
         if (d.first_len) ACX_HIP_TRY(hipMemcpyAsync(S.h_first, d.first_len, kFirstLen * 8, hipMemcpyDeviceToHost, st));
-        if (greedy) ACX_HIP_TRY(hipMemcpyAsync(hl, d.tlen + nodes, std::min<uint64_t>(m, S.cap_nodes - nodes), hipMemcpyDeviceToHost, st));
+        if (greedy) ACX_HIP_TRY(hipMemcpyAsync(S.h_pin + sizeof(Decision) + 64 - (sizeof(Decision) % 64), d.tlen + nodes, std::min<uint64_t>(m, S.cap_nodes - nodes), hipMemcpyDeviceToHost, st));
         ACX_HIP_TRY(hipStreamSynchronize(st));
+        }  // !have_dec
+        uint8_t* hl = S.h_pin + sizeof(Decision) + 64 - (sizeof(Decision) % 64);
         if (dec->err == 0xFE) return fail(ACX_E_CAPACITY, "acx_search: a probe sequence ran through the whole visited table (table full or damaged)");
         if (dec->err) return err_to_rc(dec->err);
         if (debug) fprintf(stderr, "[acx_search]   total=%u p_end=%u committed=%u solved=%u budget_hit=%u\n", dec->total, dec->p_end, dec->committed, dec->solved, dec->budget_hit);
