@@ -39,7 +39,10 @@ constexpr int kShardHdr = 4;   // int64 words in front of every region: [0] reco
                                // [3] the sender's sticky failure code (0 = healthy)
 constexpr int kShardSub = ACX_SHARD_SUBREGIONS;  // sub-regions per destination: a region's cursor is ONE word and one word takes ~90 returning
                                // atomics per microsecond; the workgroups of a launch reserve in sub-region blockIdx % kShardSub
-constexpr int kExpandThreads = 256, kExpandItems = 4, kExpandTile = kExpandThreads * kExpandItems;  // children per workgroup
+#ifndef ACX_SHARD_EXPAND_ITEMS
+#define ACX_SHARD_EXPAND_ITEMS 4  // (A/B: 2 -> 15.6 ms, 8 -> see DESIGN.md; tests/shard_helpers.py mirrors the tile of 1024)
+#endif
+constexpr int kExpandThreads = 256, kExpandItems = ACX_SHARD_EXPAND_ITEMS, kExpandTile = kExpandThreads * kExpandItems;  // children per workgroup
 constexpr int kScanTile = 4096;                    // parents per workgroup of k_shard_scan
 constexpr unsigned long long kShardInf = 1ull << 62;
 

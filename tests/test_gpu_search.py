@@ -129,6 +129,43 @@ def test_full_size_config3_ak3_budget_1e7_against_oracle(search, algo):
     assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (st, wst)
 
 
+@pytest.mark.timeout(600)
+def test_bfs_run_ahead_batches_equal_read_back_batches_and_the_oracle(search, golden_json, monkeypatch):
+    """Round 3: once the frontier holds a full batch the fused bfs enqueues its batches back to back against a device-resident
+    cursor and reads it two batches late (acx_frontier.h: BfsCursor); ACX_BFS_NO_RUNAHEAD=1 reads every batch's decision back as
+    round 2 did.  Both must give the oracle's (solved, path) and counts: searches that END inside the run-ahead phase by success
+    (Miller-Schupp presentations bfs solves late), by budget (at several offsets inside a batch) and by exhaustion of nothing
+    (budget far beyond the last saturated batch), both cyclical values, both key widths."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search
+    from oracle import ac_oracle as O
+
+    g = golden_json("ms_pool.json")
+    pool = ms_pool_generator_order(g)
+    ak3 = np.zeros(50, np.int8)
+    ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+    ak3[25:31] = [1, 2, 1, -2, -1, -2]
+    # the Miller-Schupp presentations that bfs (cyclical, budget 1e6) solves LAST: 0.66-0.96e6 nodes with 0.4-0.5e6 of them queued,
+    # i.e. well inside the run-ahead phase (a batch is 250 000 parents at this budget); 900, 630 and 730 have 128-bit keys
+    late = [pool[k] for k in (325, 334, 494, 900, 49, 185, 235, 630, 25, 730)]
+    cases = [(p, 10**6, True) for p in late] + [(p, 10**6, False) for p in late[:4]]
+    cases += [(ak3, b, False) for b in (2 * 10**6, 2 * 10**6 + 1, 2999999, 3 * 10**6, 4194304, 4194305)] + [(ak3, 3 * 10**6, True)]
+    n_solved = 0
+    for p, budget, cyc in cases:
+        monkeypatch.delenv("ACX_BFS_NO_RUNAHEAD", raising=False)
+        ahead = run_search(_acx.SEARCH_BFS, p, budget, cyc)
+        monkeypatch.setenv("ACX_BFS_NO_RUNAHEAD", "1")
+        back = run_search(_acx.SEARCH_BFS, p, budget, cyc)
+        monkeypatch.delenv("ACX_BFS_NO_RUNAHEAD", raising=False)
+        wok, wpath, wst = O.bfs(p, budget, cyclically_reduce_after_moves=cyc, stats=True)
+        for ok, path, st in (ahead, back):
+            assert (ok, path) == (wok, wpath), (budget, cyc)
+            assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (budget, cyc, st, wst)
+        assert ahead[2]["levels"] == back[2]["levels"]  # the same batches
+        n_solved += ok
+    assert n_solved >= 10
+
+
 def test_greedy_batch_per_launch_path_equals_device_frontier(search, golden_json, monkeypatch):
     """greedy_search runs on the persistent one-workgroup frontier (acx_greedy.h); the batch-per-launch path it falls
     back to when a capacity is exceeded (ACX_GREEDY_HOST=1 forces it) must return the same thing."""
