@@ -478,14 +478,21 @@ def extra_env_numbers(dev, pool):
 
         tape8 = torch.randint(0, 12, (T, n), dtype=torch.uint8, device=dev)
         res = {}
+        def timed(fn, *a, reps=5):
+            """median of `reps` timed passes behind a warm-up pass (one 32-step window is a few ms: a single pass is noisy)"""
+            fn(*a)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                e0.record()
+                fn(*a)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            return sorted(ts)[len(ts) // 2]
+
         for name in ("fused", "torch", "none"):
-            rollout(name)
-            torch.cuda.synchronize()
-            e0.record()
-            rollout(name)
-            e1.record()
-            torch.cuda.synchronize()
-            res[name] = n * T / e0.elapsed_time(e1) * 1e3
+            res[name] = n * T / timed(rollout, name, reps=3 if name == "torch" else 5) * 1e3
         # the same rollout with int8 observation rows (a quarter of the bytes the env kernel writes and the policy kernel reads;
         # the update would widen a minibatch to f32 when it needs it)
         env8 = ACVecEnv(pool[np.arange(n) % len(pool)], horizon_length=HORIZON, obs_dtype="int8", clip_rewards=(-10, 1000), record_actions=False,
@@ -498,19 +505,14 @@ def extra_env_numbers(dev, pool):
                 fused.sample(obs8[t], act[t], logp[t], val[t])
                 env8.step(act[t], out=(obs8[t + 1], rew[t], term[t + 1], trunc), check_errors=False)
 
-        rollout8()
-        torch.cuda.synchronize()
-        e0.record()
-        rollout8()
-        e1.record()
-        torch.cuda.synchronize()
-        res["fused_i8"] = n * T / e0.elapsed_time(e1) * 1e3
+        res["fused_i8"] = n * T / timed(rollout8) * 1e3
         flop = 2.0 * ((2 * L) * 256 + 256 * 256 + 256 * 12) + 2.0 * ((2 * L) * 256 + 256 * 256 + 256)  # actor + critic, per environment
         out["ppo_rollout"] = {"envs": n, "steps": T, "env_steps_per_s": res["fused"], "env_steps_per_s_torch_f32_policy": res["torch"],
                               "env_steps_per_s_env_kernel_only": res["none"], "env_steps_per_s_int8_obs": res["fused_i8"],
                               "policy": "50-256-256-12 / 50-256-256-1 tanh MLPs; fused = acx_policy_sample (v_mfma_f32_32x32x16_bf16, f32 accumulation, "
                                         "Gumbel-max draw in the kernel), torch = the reference's f32 modules",
                               "policy_tflops_fused": flop * n / max(n / res["fused"] - n / res["none"], 1e-9) / 1e12,
+                              "timing": "median of 5 passes of 32 steps behind a warm-up pass (3 for the torch policy)",
                               "obs": "float32 [T+1, N, 50] written by the env kernel", "algorithmic_GBps_env_only": (12 * L + 10) * res["none"] / 1e9}
     except Exception as e:
         out["ppo_rollout"] = {"error": f"{type(e).__name__}: {e}"}

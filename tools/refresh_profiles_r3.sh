@@ -20,3 +20,8 @@ python3 $R/tools/pmc_sum.py $O/bfs_pmc > $O/bfs_pmc_summary.txt 2>&1
 find $O -name "*.csv" -size +8M -delete
 find $O -name "*kernel_trace.csv" -delete
 ls -la $O
+# the Miller-Schupp sweeps (BASELINE config 4 shape on one GPU): k_bfs_multi / k_greedy_multi
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/sweep_bfs_kt -- python3 $R/tools/ms_sweep.py bfs 1e6 16 1 together > $O/sweep_bfs.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/sweep_greedy_kt -- python3 $R/tools/ms_sweep.py greedy 1e6 16 0 together > $O/sweep_greedy.log 2>&1
+find $O -name "*kernel_trace.csv" -delete
