@@ -11,7 +11,7 @@ global frontier positions; for each chunk every rank
      records in it and the sender's success / error / failure words -- so the exchange needs no count round trip,
   3. deduplicates what it received against its slice of the visited set, minimum tag wins (HIP), and sets bit a of
      a 12-bit mask of parent p for every child (p, a) that is a new state it owns,
-  4. all-reduces (sum) those masks -- 4 bytes per PARENT -- so that every rank derives the same global FIFO
+  4. all-reduces (sum) those masks -- 2 bytes per PARENT, two masks to a word -- so that every rank derives the same global FIFO
      numbering (position of a new state = new states of earlier parents + earlier set bits of its own parent),
      the same budget decision ("first parent after which len(tree_nodes) >= max_nodes", breadth_first.py:91-95)
      and the same success decision (smallest tag of a length-2 child, :84-85); no rank ever holds the tags of the
@@ -128,7 +128,7 @@ class HipShardEngine:
             words = 8 + int(full * (est_parents / self.B + 2))
             self.log = torch.empty(words, dtype=torch.int64, device=self.device)
             self.send = torch.empty(full, dtype=torch.int64, device=self.device) if world > 1 else None
-            self.gmask = torch.empty(self.B, dtype=torch.int32, device=self.device)
+            self.gmask = torch.empty((self.B + 1) // 2, dtype=torch.int32, device=self.device)  # two parents' 12-bit masks per word
             self._attach()
         self._cursor = 8  # host mirror of the engine's log cursor (deterministic: it advances by the chunk's words)
         self._ctl = np.zeros(CTL_WORDS, np.int64)
@@ -189,11 +189,12 @@ class HipShardEngine:
         return (recv if self.send is None else self.send[:need]), recv
 
     def chunk_insert(self, n_par):
+        """-> the chunk's child masks, two parents per int32 word (parent p: bits 16 (p & 1) .. + 11 of word p >> 1), to be summed over the ranks"""
         self._acx.check(self._acx.lib.acx_shard_chunk_insert(self.h, self._stream()), "acx_shard_chunk_insert")
-        return self.gmask[:n_par]
+        return self.gmask[:(n_par + 1) // 2]
 
     def gmask_view(self, n_par):
-        return self.gmask[:n_par]
+        return self.gmask[:(n_par + 1) // 2]
 
     def chunk_commit(self, max_nodes):
         self._acx.check(self._acx.lib.acx_shard_chunk_commit(self.h, int(max_nodes), self._stream()), "acx_shard_chunk_commit")

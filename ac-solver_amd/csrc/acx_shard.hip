@@ -118,7 +118,8 @@ template <typename W> struct ShardDev {
     uint8_t* btook;      // one byte per tag of a chunk: took a slot / was pushed out again (both zero between chunks)
     uint8_t* brepl;
     int32_t* lmask;      // [chunk parents] 12-bit masks: new states of this rank
-    int32_t* gmask;      // the same, summed over the ranks by the caller's all-reduce
+    int32_t* gmask;      // the same for all ranks after the caller's all-reduce, TWO parents per word (parent p: bits 16 (p & 1) .. + 11 of word
+                         // p >> 1): every (parent, action) child has one owner, so the sum of the ranks' words is their union and no field carries
     uint32_t* lpre;      // exclusive popcount prefix inside a kScanTile tile
     uint32_t* gpre;
     uint32_t* lblk;      // per tile: total, turned into the exclusive prefix over the tiles by k_shard_decide
@@ -138,6 +139,8 @@ struct ChunkGeo {
     uint32_t subcap;       // records a sub-region can take
     uint32_t region_words; // kShardHdr + subcap * RW
 };
+
+__device__ __forceinline__ uint32_t gmask_of(const int32_t* __restrict__ gmask, uint32_t p) { return ((uint32_t)gmask[p >> 1] >> (16u * (p & 1u))) & 0xFFFu; }
 
 // the one place that fixes the geometry of a chunk's regions: every rank (and the NumPy test engine, through
 // acx_shard_layout) computes the same numbers from (parents of the chunk, world)
@@ -422,25 +425,32 @@ __global__ void __launch_bounds__(256) k_shard_insert(ShardDev<W> d, ChunkGeo g)
 }
 
 // one 12-bit mask per parent of the chunk: bit a set when child (parent, a) is a new state of this rank; the flags it read are
-// zeroed again for the next chunk (no memset launches)
+// zeroed again for the next chunk (no memset launches).  A lane serves two parents: their masks share a word of gmask.
 template <typename W> __global__ void __launch_bounds__(256) k_shard_pack(ShardDev<W> d, uint32_t n_par) {
-    ACX_VGPR_PAD("v23");
+    ACX_VGPR_PAD("v31");
     if (d.ctl[C_STATUS] != 0) return;
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_par) return;
-    uint32_t* t = (uint32_t*)(d.btook + 12 * (size_t)p);  // 12 bytes, 4-byte aligned
-    uint32_t* r = (uint32_t*)(d.brepl + 12 * (size_t)p);
-    int32_t m = 0;
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * q >= n_par) return;
+    uint32_t both = 0;
 #pragma unroll
-    for (int w = 0; w < 3; w++) {
-        const uint32_t tv = t[w], rv = r[w];
-        if (tv) t[w] = 0;
-        if (rv) r[w] = 0;
-        const uint32_t v = tv & ~rv;  // bytes are 0 / 1
-        m |= (int32_t)(((v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u)) << (4 * w));
+    for (uint32_t h = 0; h < 2; h++) {
+        const uint32_t p = 2 * q + h;
+        if (p >= n_par) break;
+        uint32_t* t = (uint32_t*)(d.btook + 12 * (size_t)p);  // 12 bytes, 4-byte aligned
+        uint32_t* r = (uint32_t*)(d.brepl + 12 * (size_t)p);
+        uint32_t m = 0;
+#pragma unroll
+        for (int w = 0; w < 3; w++) {
+            const uint32_t tv = t[w], rv = r[w];
+            if (tv) t[w] = 0;
+            if (rv) r[w] = 0;
+            const uint32_t v = tv & ~rv;  // bytes are 0 / 1
+            m |= ((v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u)) << (4 * w);
+        }
+        d.lmask[p] = (int32_t)m;
+        both |= m << (16u * h);
     }
-    d.lmask[p] = m;
-    d.gmask[p] = m;
+    d.gmask[q] = (int32_t)both;
 }
 
 // exclusive popcount prefixes of the local and the all-reduced masks inside tiles of kScanTile parents + the tiles' totals
@@ -452,14 +462,15 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_scan(Shard
     const uint32_t p0 = blockIdx.x * kScanTile + tid * 4;
     uint32_t lm[4], gm[4], lsum = 0, gsum = 0;
     if (p0 + 4 <= n_par) {
-        const int4 a = *(const int4*)(d.lmask + p0), b = *(const int4*)(d.gmask + p0);
+        const int4 a = *(const int4*)(d.lmask + p0);
+        const int2 b = *(const int2*)(d.gmask + (p0 >> 1));  // four parents = two words
         lm[0] = a.x, lm[1] = a.y, lm[2] = a.z, lm[3] = a.w;
-        gm[0] = b.x, gm[1] = b.y, gm[2] = b.z, gm[3] = b.w;
+        gm[0] = (uint32_t)b.x & 0xFFFu, gm[1] = ((uint32_t)b.x >> 16) & 0xFFFu, gm[2] = (uint32_t)b.y & 0xFFFu, gm[3] = ((uint32_t)b.y >> 16) & 0xFFFu;
     } else {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             lm[k] = p0 + k < n_par ? (uint32_t)d.lmask[p0 + k] : 0u;
-            gm[k] = p0 + k < n_par ? (uint32_t)d.gmask[p0 + k] : 0u;
+            gm[k] = p0 + k < n_par ? gmask_of(d.gmask, p0 + k) : 0u;
         }
     }
 #pragma unroll
@@ -558,7 +569,7 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(Sha
         for (uint32_t k = tid; k < (uint32_t)kScanTile; k += 1024) {
             const uint32_t p = t * kScanTile + k;
             if (p < g.n_par) {
-                const unsigned long long ex = (unsigned long long)d.gblk[t] + d.gpre[p], in = ex + (unsigned long long)__popc((uint32_t)d.gmask[p]);
+                const unsigned long long ex = (unsigned long long)d.gblk[t] + d.gpre[p], in = ex + (unsigned long long)__popc(gmask_of(d.gmask, p));
                 if (ex < need && in >= need) s_pb = p;
             }
         }
@@ -578,13 +589,13 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(Sha
     if (need < 1) {  // only the very first parent can see this (budget <= 1)
         p_end = 0;
         budget_hit = true;
-        commit_global = (unsigned long long)__popc((uint32_t)d.gmask[0]);
+        commit_global = (unsigned long long)__popc(gmask_of(d.gmask, 0));
         commit_local = (unsigned long long)__popc((uint32_t)d.lmask[0]);
     } else if (over) {
         p_end = s_pb;
         budget_hit = true;
         const uint32_t t = p_end / kScanTile;
-        commit_global = (unsigned long long)d.gblk[t] + d.gpre[p_end] + (unsigned long long)__popc((uint32_t)d.gmask[p_end]);
+        commit_global = (unsigned long long)d.gblk[t] + d.gpre[p_end] + (unsigned long long)__popc(gmask_of(d.gmask, p_end));
         commit_local = (unsigned long long)d.lblk[t] + d.lpre[p_end] + (unsigned long long)__popc((uint32_t)d.lmask[p_end]);
     }
     const unsigned long long end_pos = (unsigned long long)g.c0 + p_end;
@@ -598,7 +609,7 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(Sha
     }
     if (is_solved) {
         const uint32_t q = (uint32_t)(stag / 12ull - (unsigned long long)g.c0), a = (uint32_t)(stag % 12ull);
-        const unsigned long long before = (unsigned long long)d.gblk[q / kScanTile] + d.gpre[q] + (unsigned long long)__popc((uint32_t)d.gmask[q] & ((1u << a) - 1u));
+        const unsigned long long before = (unsigned long long)d.gblk[q / kScanTile] + d.gpre[q] + (unsigned long long)__popc(gmask_of(d.gmask, q) & ((1u << a) - 1u));
         d.ctl[C_EXPANDED] += (unsigned long long)q + 1;
         d.ctl[C_NODES_GLOBAL] = nodes_global + before;  // new states with a smaller tag
         d.ctl[C_SOLVED_TAG] = stag;
@@ -653,7 +664,7 @@ template <typename W> __global__ void __launch_bounds__(256) k_shard_commit(Shar
     d.k1[id] = k1;
     d.act[id] = (uint8_t)a;
     d.tlen[id] = (uint8_t)(keyops<W>::len(k0) + keyops<W>::len(k1));
-    d.gpos[id] = dec.gpos_base + d.gblk[tile] + d.gpre[par] + (uint32_t)__popc((uint32_t)d.gmask[par] & below);
+    d.gpos[id] = dec.gpos_base + d.gblk[tile] + d.gpre[par] + (uint32_t)__popc(gmask_of(d.gmask, par) & below);
     d.pref[id] = (int64_t)(((unsigned long long)(r / kShardSub) << 40) | (x & 0xFFFFFFFFull));
 }
 
@@ -892,7 +903,7 @@ template <typename W> static int shard_chunk_insert(ShardEngine<W>& E, hipStream
     E.geo_inserted++;
     const dim3 grid((unsigned)((geo.subcap + 255) / 256), (unsigned)(kShardSub * E.world));
     hipLaunchKernelGGL(k_shard_insert<W>, grid, dim3(256), 0, st, E.d, geo);
-    hipLaunchKernelGGL(k_shard_pack<W>, dim3((geo.n_par + 255) / 256), dim3(256), 0, st, E.d, geo.n_par);
+    hipLaunchKernelGGL(k_shard_pack<W>, dim3(((geo.n_par + 1) / 2 + 255) / 256), dim3(256), 0, st, E.d, geo.n_par);
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }

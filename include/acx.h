@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACX_VERSION 300
+#define ACX_VERSION 301
 
 /* return codes */
 #define ACX_OK 0
@@ -194,8 +194,10 @@ int acx_search_many(int kind, const int8_t *h_presentations, int64_t n, int L, i
  *          acx_shard_chunk_expand returns; it is never recycled (a visited-table slot names its state by the offset of the
  *          record that claimed it).  At world 1 the chunk is expanded straight into it.
  *   send   int64[send_words] (world > 1): the chunk's send buffer, `words` long, same layout.
- *   gmask  int32[chunk_parents]: one 12-bit mask per parent of the chunk -- bit a set when child (parent, a) is a new state
- *          owned by this rank; the caller all-reduces (sum == or) its first c1 - c0 entries between insert and commit.
+ *   gmask  int32[(chunk_parents + 1) / 2]: one 12-bit mask per parent of the chunk -- bit a set when child (parent, a) is a new
+ *          state owned by this rank --, two parents per word (parent p: bits 16 (p & 1) .. + 11 of word p >> 1); the caller
+ *          all-reduces (sum == or: a child has one owner, no field carries) its first (c1 - c0 + 1) / 2 words between insert and
+ *          commit.
  * Layout of a chunk's `words`: world * S regions (region d * S + s = sub-region s for / from rank d; S, subcap, region_words from
  * acx_shard_layout), each = 4 header words [records written, smallest tag of a length-2 child, smallest (tag << 8 | code) of a
  * raising move, the sender's failure code] + subcap records of key_words + 1 int64: the packed key, then

@@ -173,11 +173,16 @@ class OracleShardEngine:
         return pref >= 0 and (pref >> 40 != self.rank or np.array_equal(self.states[pref & ((1 << 40) - 1)], state))
 
     def gmask_view(self, n_par):
-        """the chunk's mask buffer, zeroed (what the orchestrator all-reduces when chunk_insert itself failed)"""
-        self.gmask = torch.zeros(n_par, dtype=torch.int32)
+        """the chunk's mask buffer, zeroed (what the orchestrator all-reduces when chunk_insert itself failed): two parents per word"""
+        self.packed = torch.zeros((n_par + 1) // 2, dtype=torch.int32)
         self.lmask = torch.zeros(n_par, dtype=torch.int32)
         self.winners = []
-        return self.gmask
+        return self.packed
+
+    def _unpack(self, n_par):
+        w = self.packed.to(torch.int64)
+        both = torch.stack([w & 0xFFF, (w >> 16) & 0xFFF], dim=1).reshape(-1)
+        return both[:n_par].to(torch.int32)
 
     def chunk_insert(self, n_par):
         self.geo, self.recv = self.open[self.inserted]
@@ -185,7 +190,7 @@ class OracleShardEngine:
         c0, n_par, S, cap, rw = self.geo
         self.gmask_view(n_par)
         if self.ctl[0] != 0:
-            return self.gmask
+            return self.packed
         regs = self.recv.view(S * self.world, rw)
         recs = []
         for r in range(S * self.world):
@@ -203,8 +208,9 @@ class OracleShardEngine:
             seen.add((k0, k1))
             self.winners.append((tag, k0, k1, pref))
             self.lmask[tag // 12] |= 1 << (tag % 12)
-        self.gmask.copy_(self.lmask)
-        return self.gmask
+        lm = torch.cat([self.lmask.to(torch.int64), torch.zeros(n_par % 2, dtype=torch.int64)]).view(-1, 2)
+        self.packed.copy_((lm[:, 0] | (lm[:, 1] << 16)).to(torch.int32))
+        return self.packed
 
     def chunk_commit(self, max_nodes):
         self.geo, self.recv = self.open.pop(0)
@@ -218,6 +224,7 @@ class OracleShardEngine:
             self.ctl[0], self.ctl[10] = 4, fail
             return
         solved, err = int(regs[:, 1].min()), int(regs[:, 2].min())
+        self.gmask = self._unpack(n_par)  # (the orchestrator has all-reduced self.packed in place)
         pop = lambda v: bin(int(v)).count("1")  # noqa: E731
         gpop = np.array([pop(v) for v in self.gmask.tolist()], np.int64)
         lpop = np.array([pop(v) for v in self.lmask.tolist()], np.int64)

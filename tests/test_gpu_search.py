@@ -324,7 +324,8 @@ def test_device_routing_matches_owner_of(search, L):
                     got[tag] = row[:KW]
             assert sorted(got) == sorted(want), (L, world, lvl)
             recv.copy_(send)  # as if every region came back to this engine
-            lmask = eng.chunk_insert(F).clone()
+            packed = eng.chunk_insert(F).clone().to(torch.int64)  # two parents per word
+            lmask = torch.stack([packed & 0xFFF, (packed >> 16) & 0xFFF], dim=1).reshape(-1)[:F]
             eng.chunk_commit(1 << 40)
             eng.ctl_snapshot(0)
             ctl = eng.ctl_wait(0)
