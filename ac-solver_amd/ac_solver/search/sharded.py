@@ -36,7 +36,7 @@ import sys
 import numpy as np
 
 INF = 1 << 62
-HDR = 4              # int64 header words of a region: records written, success tag, error word, failure code
+HDR = 4              # int64 header words of a region: records written, success tag, error word, failure code (tests parse regions with it)
 LAG = 2              # chunks the host runs ahead of the control block it reads
 _FORCE_EXCHANGE = False  # tests: route through the communicator even when world == 1
 _ID_MASK = (1 << 40) - 1
@@ -99,11 +99,6 @@ class SingleComm:
 
 
 # ---------------------------------------------------------------------------------------- engines ---
-def chunk_words(lib_layout, n_par, world, KW):
-    S, subcap, rw = lib_layout(n_par, world, KW)
-    return S * world * rw
-
-
 class HipShardEngine:
     """Per-rank frontier slice on one GPU: thin wrapper over the acx_shard_* C ABI (include/acx.h).  The record log, the
     send buffer and the mask buffer are torch tensors (torch.distributed moves them); the log grows by doubling when the

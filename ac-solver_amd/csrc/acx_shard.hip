@@ -167,7 +167,7 @@ __device__ __forceinline__ uint32_t lower_gpos(const uint32_t* __restrict__ gpos
 }
 
 // Start of a chunk: the level switch (first chunk of a level), the frontier slice [bounds[0], bounds[1]) of the local nodes
-// with gpos in [c0, c0 + n_par) -- found ONCE per chunk by one lane -- and the headers of the send regions.
+// with gpos in [c0, c0 + n_par) -- found ONCE per chunk, not per workgroup of the expansion -- and the headers of the send regions.
 template <typename W>
 __global__ void __launch_bounds__(256) k_shard_prep(ShardDev<W> d, ChunkGeo g, int level_first, int64_t* __restrict__ send) {
     __shared__ uint32_t s_lo[2], s_hi[2];
@@ -189,8 +189,9 @@ __global__ void __launch_bounds__(256) k_shard_prep(ShardDev<W> d, ChunkGeo g, i
     const uint32_t target = which ? (uint32_t)(g.c0 + g.n_par) : (uint32_t)g.c0;
     for (;;) {
         const uint32_t lo = s_lo[which], hi = s_hi[which], n = hi - lo;
+        const bool finished = s_hi[0] == s_lo[0] && s_hi[1] == s_lo[1];  // both ranges, read by everybody BEFORE anybody narrows them
         __syncthreads();
-        if (s_hi[0] - s_lo[0] == 0 && s_hi[1] - s_lo[1] == 0) break;  // (uniform: both ranges are read by everybody)
+        if (finished) break;
         if (n) {
             // probe t looks at position lo + t * step: the answer lies behind the last probe whose gpos is < target
             const uint32_t step = (n + 127u) / 128u, pos = lo + t * step;
