@@ -41,7 +41,7 @@ class Agent(nn.Module):
 
     def get_action_and_value(self, x, action=None):
         """-> (action, log-probability of the action, entropy of the policy, value)"""
-        dist = Categorical(logits=self.actor(x))
+        dist = Categorical(logits=self.actor(x), validate_args=False)  # (the validation reads the logits back: a device synchronisation per call)
         if action is None:
             action = dist.sample()
         return action, dist.log_prob(action), dist.entropy(), self.critic(x)
