@@ -271,6 +271,36 @@ def test_sharded_bfs_hip_engine_matches_reference(search, golden_json, world):
             assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (world, b, c, st, wst)
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [4, 8])
+def test_sharded_bfs_mid_size_thread_ranks_equal_the_fused_search(search, golden_json, world):
+    """Several ranks of the HIP engine on one GPU at sizes where every rank runs many full workgroups per chunk, several chunks per
+    level and the two-stream pipeline: 3e6 nodes on AK(3) with 64-bit keys, 1e6 on a Miller-Schupp presentation with 128-bit keys
+    (max_relator_length 36), 2e6 with cyclic reduction.  Every rank must return the fused search's node and expansion counts
+    (itself checked against the oracle at 1e7, test_full_size_config3...) and the same (solved, path)."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search
+    from ac_solver.search.sharded import bfs_sharded
+    from tests.shard_helpers import run_threads
+
+    ak3 = np.zeros(50, np.int8)
+    ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+    ak3[25:31] = [1, 2, 1, -2, -1, -2]
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    cases = [(ak3, 3 * 10**6, False, 1 << 16), (np.array(pool[1100], np.int8), 10**6, False, 1 << 15), (ak3, 2 * 10**6, True, 1 << 17),
+             (np.array(pool[630], np.int8), 10**6, True, 1 << 14)]  # (630: solved after 0.78e6 nodes with cyclic reduction)
+    want = [run_search(_acx.SEARCH_BFS, p, b, c) for p, b, c, _ in cases]
+
+    def run(comm):
+        return [bfs_sharded(p, b, cyclically_reduce_after_moves=c, comm=comm, batch_parents=bp, want_stats=True) for p, b, c, bp in cases]
+
+    for res in run_threads(world, run):
+        for (ok, path, st), (wok, wpath, wst) in zip(res, want):
+            assert (ok, path) == (wok, wpath)
+            assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (world, st, wst)
+    assert want[3][0] and not want[0][0]
+
+
 @pytest.mark.parametrize("L", [25, 36])
 def test_device_routing_matches_owner_of(search, L):
     """acx_shard_chunk_expand routes every child to the region of the rank the orchestrator's owner function names (owner_of),
