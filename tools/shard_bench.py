@@ -36,3 +36,22 @@ for bp in bps:
     flag = "" if (s2["nodes"], s2["expanded"]) == want else "  MISMATCH"
     print(f"bfs_sharded world 1, 2^{bp} parents per chunk: {best * 1e3:.2f} ms, {s2['nodes'] / best:.3e} nodes/s, chunks {s2['chunks']} levels {s2['levels']} "
           f"nodes {s2['nodes']} expanded {s2['expanded']}{flag}", flush=True)
+
+# thread ranks sharing the one GPU (tests/shard_helpers.py: ThreadComm): what the orchestration costs per rank when the
+# kernels of all ranks run on the same device (no hardware scaling number: a box has one GPU)
+if os.environ.get("ACX_SHARD_THREADS"):
+    from tests.shard_helpers import run_threads
+
+    for world in [int(x) for x in os.environ["ACX_SHARD_THREADS"].split(",")]:
+        def work(comm):
+            bfs_sharded(ak3, budget, comm=comm, batch_parents=1 << 21)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ok, path, st = bfs_sharded(ak3, budget, comm=comm, batch_parents=1 << 21, want_stats=True)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, st
+        res = run_threads(world, work)
+        dt = max(r[0] for r in res)
+        st = res[0][1]
+        flag = "" if (st["nodes"], st["expanded"]) == want else "  MISMATCH"
+        print(f"bfs_sharded, {world} thread ranks on one GPU: {dt * 1e3:.1f} ms, nodes {st['nodes']} expanded {st['expanded']} chunks {st['chunks']}{flag}", flush=True)
