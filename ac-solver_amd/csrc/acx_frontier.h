@@ -99,13 +99,14 @@ template <typename W> struct SearchDev {
     int32_t cyclical;
 };
 
-// Shift flavour of the moves in the search kernels.  Search keys cap max_relator_length at 29 (u64) / 61 (u128), so the plain
-// hardware shifts (SAFE = false in acx_word.h) would be enough -- but the k_expand that hipcc builds from them (exactly 24
-// VGPRs) returned corrupted children on MI355X whenever more than one wave per SIMD was resident; the identical code object
-// with 32 VGPRs declared, or at one wave per SIMD, is correct (tools/_build experiments, DESIGN.md "known hazards").  The
-// range-checked shifts cost a few instructions per move and have been bit-exact in every run, so they stay.
+// Shift flavour of the moves in the search kernels.  Search keys cap max_relator_length at 29 (u64) / 61 (u128), so every shift
+// count stays below the word width and the plain hardware shifts (SAFE = false in acx_word.h) are enough.  Rounds 1 and 2 ran
+// the range-checked shifts here: round 1's k_expand built from the plain ones (exactly 24 VGPRs) returned corrupted children,
+// and the checked flavour happened to allocate differently.  Round 3 found the actual cause -- a 64-bit shift whose amount sits
+// in the LAST allocated VGPR -- which tools/check_shift64.py now excludes for every kernel at build time,
+// so the search kernels are back on the plain shifts: 3 % off the 1e8-node bfs (fused and sharded) and off greedy_search.
 #ifndef ACX_SEARCH_SAFE
-#define ACX_SEARCH_SAFE 1
+#define ACX_SEARCH_SAFE 0
 #endif
 constexpr bool kSearchSafe = ACX_SEARCH_SAFE != 0;
 
