@@ -39,10 +39,14 @@ constexpr int kShardHdr = 4;   // int64 words in front of every region: [0] reco
                                // [3] the sender's sticky failure code (0 = healthy)
 constexpr int kShardSub = ACX_SHARD_SUBREGIONS;  // sub-regions per destination: a region's cursor is ONE word and one word takes ~90 returning
                                // atomics per microsecond; the workgroups of a launch reserve in sub-region blockIdx % kShardSub
-#ifndef ACX_SHARD_EXPAND_ITEMS
-#define ACX_SHARD_EXPAND_ITEMS 4  // (A/B: 2 -> 15.6 ms, 8 -> see DESIGN.md; tests/shard_helpers.py mirrors the tile of 1024)
+#ifndef ACX_SHARD_EXPAND_PARENTS
+#define ACX_SHARD_EXPAND_PARENTS 128  // parents per workgroup of k_shard_expand: 64 (4 waves) or 128 (8 waves)
 #endif
-constexpr int kExpandThreads = 256, kExpandItems = ACX_SHARD_EXPAND_ITEMS, kExpandTile = kExpandThreads * kExpandItems;  // children per workgroup
+// a workgroup of k_shard_expand: kExpandParents parents x 12 actions; four waves x three actions per group of 64 parents
+constexpr int kExpandParents = ACX_SHARD_EXPAND_PARENTS, kExpandItems = 3, kExpandThreads = kExpandParents * 4, kExpandTile = kExpandParents * 12;
+constexpr int kFoldSlots = kExpandParents <= 64 ? 2048 : 4096;  // LDS fold table of a tile (a power of two >= 2 x the tile)
+constexpr int kTileBits = kExpandParents <= 64 ? 10 : 11;        // bits of a tile slot / of a tag inside the tile
+static_assert((kExpandParents == 64 || kExpandParents == 128) && kExpandTile <= (1 << kTileBits), "tile slots and tags fit kTileBits");
 constexpr int kScanTile = 4096;                    // parents per workgroup of k_shard_scan
 constexpr unsigned long long kShardInf = 1ull << 62;
 
@@ -228,117 +232,155 @@ __device__ __forceinline__ uint32_t inverse_action(uint32_t a) { return a < 4 ? 
 // owns its key.  Never sent: a child equal to its parent (over-long product, ac_moves.py:64, :126: visited by construction);
 // with MODE == kMoveNf the child of action inverse(act[parent]) (it is the parent's own tree parent: g^-1 (g r g^-1) g = r and
 // (r_i r_j) r_j^-1 = r_i as reduced words, and the result fits because it did before -- checked against the oracle on every
-// node of the CPU suite's searches, tests/test_sharded_cpu.py); every duplicate among the workgroup's 1024 children except
-// the one with the smallest tag (LDS table of tile lanes: tile order IS tag order).  The success and error words are taken
-// BEFORE any of that, as the reference tests a child before it looks it up (breadth_first.py:84).
+// node of the CPU suite's searches, tests/test_sharded_cpu.py); every duplicate among the workgroup's children except the one
+// with the smallest tag (LDS table).  The success and error words are taken BEFORE any of that, as the reference tests a child
+// before it looks it up (breadth_first.py:84).
+//
+// A workgroup serves 128 parents x 12 actions (8 waves; 64 x 12 with 4): wave w of a group of four, item it computes action
+// 3 w + it for the group's 64 parents, ONE ACTION PER WAVE-INSTRUCTION.  The kernel is bound by vector issue (6 waves per SIMD, 27 % of the wave cycles issuing:
+// profiles/r3_shard_1e8_pmc_summary.txt), and with a lane per (parent, action) in tag order -- the first version, as the fused
+// k_bfs_expand_insert has it -- the twelve actions of a parent sit in adjacent lanes, so every wave ran the concatenation AND
+// the conjugation path of the move for every child.  With the action uniform across the wave only the taken path issues.
 template <typename W, int MODE>
 __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, ChunkGeo g, int64_t* __restrict__ send) {
     __shared__ W s_k0[kExpandTile];
     __shared__ W s_k1[kExpandTile];
-    __shared__ uint32_t s_slot[2 * kExpandTile];
+    __shared__ uint32_t s_slot[kFoldSlots];
     __shared__ uint32_t s_cnt[64];
     __shared__ uint32_t s_base[64];
-    ACX_VGPR_PAD_W(W, "v63", "v111");  // the code needs 55-56 / 99-100 registers (tools/kernel_resources.py)
+    extern __shared__ uint32_t s_bits[];  // [world][64]: bits 0..11 the surviving actions of lane l's parent that go to owner o; later | their prefix << 16
+    ACX_VGPR_PAD_W(W, "v55", "v87");  // the code needs 46-47 / 71-79 registers (tools/kernel_resources.py)
     if (d.ctl[C_STATUS] != 0) return;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, l = (tid & 63u) + 64u * (tid >> 8), w = (tid >> 6) & 3u;  // parent slot in the workgroup; wave inside its group of four
     const uint32_t s_lo = d.bounds[0], s_hi = d.bounds[1];
-    const int64_t m = 12 * ((int64_t)s_hi - s_lo);
-    if ((int64_t)blockIdx.x * kExpandTile >= m) return;
+    const uint32_t np = s_hi - s_lo;
+    if (blockIdx.x * kExpandParents >= np) return;
     if (tid < 64) s_cnt[tid] = 0;
-    for (uint32_t i = tid; i < 2 * kExpandTile; i += kExpandThreads) s_slot[i] = kEmpty;
+    for (uint32_t i = tid; i < (uint32_t)kFoldSlots; i += kExpandThreads) s_slot[i] = kEmpty;
+    for (uint32_t i = tid; i < d.world * (uint32_t)kExpandParents; i += kExpandThreads) s_bits[i] = 0;
+    // this lane's parent (the same for its three actions)
+    const uint32_t p = blockIdx.x * kExpandParents + l, id = s_lo + p;
+    const bool live = p < np;
+    W pk0 = 0, pk1 = 0;
+    uint32_t gp = 0, pa = 0xffu;
+    if (live) {
+        pk0 = d.k0[id];
+        pk1 = d.k1[id];
+        gp = d.gpos[id];
+        pa = d.act[id];  // 0xff for the root
+    }
     W c0[kExpandItems], c1[kExpandItems];
-    uint32_t x_lo[kExpandItems], x_hi[kExpandItems];  // record word: parent id | relative tag << 32
     bool send_it[kExpandItems];
     uint32_t tl_min = 0xFFFFFFFFu;
+    const uint32_t hsub = blockIdx.x % kShardSub;
 #pragma unroll
     for (int it = 0; it < kExpandItems; it++) {
-        const uint32_t lane = it * kExpandThreads + tid;  // position in the tile = order of the tags
-        const int64_t c = (int64_t)blockIdx.x * kExpandTile + lane;
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w * kExpandItems + it));  // uniform across the wave
+        const uint32_t j = a * (uint32_t)kExpandParents + l;  // the child's slot in the tile (action major: conflict-free LDS rows)
         send_it[it] = false;
         c0[it] = c1[it] = 0;
-        x_lo[it] = x_hi[it] = 0;
-        if (c < m) {
-            const uint32_t p = (uint32_t)(c / 12), a = (uint32_t)(c - 12 * (int64_t)p), id = s_lo + p;
-            const W pk0 = d.k0[id], pk1 = d.k1[id];
-            const uint32_t gp = d.gpos[id];
+        if (live) {
             Pres<W> s;
             key_to_pres<W>(pk0, pk1, s);
             const int e = search_move<W, MODE>(s, (int)a, d.L, d.cyclical != 0);
             const unsigned long long tag = 12ull * gp + a;  // the reference's generation order inside the level
             if (e)  // first erroring move: into the header of EVERY region of this workgroup's sub-region (rare)
                 for (uint32_t o = 0; o < d.world; o++)
-                    atomicMin((unsigned long long*)(send + (int64_t)(o * kShardSub + blockIdx.x % kShardSub) * g.region_words + 2), (tag << 8) | (unsigned long long)e);
+                    atomicMin((unsigned long long*)(send + (int64_t)(o * kShardSub + hsub) * g.region_words + 2), (tag << 8) | (unsigned long long)e);
             c0[it] = keyops<W>::make(s.w0, s.n0);
             c1[it] = keyops<W>::make(s.w1, s.n1);
             const uint32_t tl = (uint32_t)(s.n0 + s.n1);
             tl_min = min(tl_min, tl);
             if (tl == 2)
                 for (uint32_t o = 0; o < d.world; o++)
-                    atomicMin((unsigned long long*)(send + (int64_t)(o * kShardSub + blockIdx.x % kShardSub) * g.region_words + 1), tag);
+                    atomicMin((unsigned long long*)(send + (int64_t)(o * kShardSub + hsub) * g.region_words + 1), tag);
             send_it[it] = !(c0[it] == pk0 && c1[it] == pk1);
-            if (MODE == kMoveNf && send_it[it]) {
-                const uint32_t pa = d.act[id];  // 0xff for the root
-                if (pa < 12u && a == inverse_action(pa)) send_it[it] = false;
-            }
-            x_lo[it] = id;
-            x_hi[it] = (uint32_t)(tag - 12ull * (unsigned long long)g.c0);
+            if (MODE == kMoveNf && pa < 12u && a == inverse_action(pa)) send_it[it] = false;
         }
-        s_k0[lane] = c0[it];
-        s_k1[lane] = c1[it];
+        s_k0[j] = c0[it];
+        s_k1[j] = c1[it];
     }
     {  // smallest total length: wave minimum, one atomic per wave that lowers it
         for (int o = 32; o > 0; o >>= 1) tl_min = min(tl_min, (uint32_t)__shfl_xor((int)tl_min, o));
         if ((tid & 63u) == 0 && (unsigned long long)tl_min < *(volatile unsigned long long*)(d.ctl + C_MIN_LEN)) atomicMin(d.ctl + C_MIN_LEN, (unsigned long long)tl_min);
     }
     __syncthreads();
-    // ---- duplicates inside the tile: the smallest tile lane of every key stays ---------------------------------------------
-    uint32_t ls[kExpandItems];
+    // ---- duplicates inside the tile: of equal keys the smallest tag stays.  A table entry is (tag inside the tile) << 10 | slot j:
+    // ordered by the tag (12 * lane + action), so atomicMin keeps the first discoverer -------------------------------------
+    uint32_t ls[kExpandItems], me[kExpandItems];
 #pragma unroll
     for (int it = 0; it < kExpandItems; it++) {
-        const uint32_t lane = it * kExpandThreads + tid;
+        const uint32_t a = w * kExpandItems + it, j = a * (uint32_t)kExpandParents + l;
+        me[it] = ((12u * l + a) << kTileBits) | j;
         ls[it] = 0;
         if (!send_it[it]) continue;
-        uint32_t q = (uint32_t)(hash_key<W>(c0[it], c1[it]) >> 40) & (2 * kExpandTile - 1);
+        uint32_t q = (uint32_t)(hash_key<W>(c0[it], c1[it]) >> 40) & (kFoldSlots - 1);
         for (;;) {
             uint32_t v = s_slot[q];
             if (v == kEmpty) {
-                v = atomicCAS(&s_slot[q], kEmpty, lane);
+                v = atomicCAS(&s_slot[q], kEmpty, me[it]);
                 if (v == kEmpty) break;
             }
-            if (s_k0[v] == c0[it] && s_k1[v] == c1[it]) {  // any holder of this slot has my key
-                if (v > lane) atomicMin(&s_slot[q], lane);
+            if (s_k0[v & ((1u << kTileBits) - 1u)] == c0[it] && s_k1[v & ((1u << kTileBits) - 1u)] == c1[it]) {  // any holder of this slot has my key
+                if (v > me[it]) atomicMin(&s_slot[q], me[it]);
                 break;
             }
-            q = (q + 1) & (2 * kExpandTile - 1);
+            q = (q + 1) & (kFoldSlots - 1);
         }
         ls[it] = q;
     }
     __syncthreads();
-    // ---- route the survivors: position inside the workgroup's share of the destination's sub-region -------------------------
+    // ---- route the survivors.  Inside the workgroup's share of a destination's sub-region the records stand in TAG order (parent,
+    // then action), although the lanes hold them action-major: the receiver's commit numbers the nodes in tag order, and its
+    // stores coalesce only when consecutive records are consecutive tags (with the arrival order of an LDS counter the commit
+    // took 2.7 instead of 2.0 ms per 1e8-node search).  Per owner: a 12-bit survivor mask per parent, a wave scan over the 64
+    // parents, position = survivors of earlier parents + earlier actions of the own parent ------------------------------------
     uint32_t owner[kExpandItems], pos[kExpandItems];
 #pragma unroll
     for (int it = 0; it < kExpandItems; it++) {
-        const uint32_t lane = it * kExpandThreads + tid;
         owner[it] = 0xFFFFFFFFu;
         pos[it] = 0;
-        if (send_it[it] && s_slot[ls[it]] == lane) {
+        if (send_it[it] && s_slot[ls[it]] == me[it]) {
             owner[it] = owner_of_key(c0[it], c1[it], d.world);
-            pos[it] = atomicAdd(&s_cnt[owner[it]], 1u);
+            atomicOr(&s_bits[owner[it] * (uint32_t)kExpandParents + l], 1u << (w * kExpandItems + it));
         }
     }
     __syncthreads();
-    const uint32_t sub = blockIdx.x % kShardSub;
+    for (uint32_t o = tid >> 6; o < d.world; o += kExpandThreads / 64) {  // every wave scans some of the owners: survivors per parent, prefix over the parents
+        uint32_t run = 0;
+        for (uint32_t g0 = 0; g0 < (uint32_t)kExpandParents; g0 += 64) {
+            const uint32_t at = o * (uint32_t)kExpandParents + g0 + (tid & 63u);
+            const uint32_t bits = s_bits[at], c = (uint32_t)__popc(bits);
+            uint32_t incl = c;
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, sft);
+                if ((tid & 63u) >= (uint32_t)sft) incl += v;
+            }
+            s_bits[at] = bits | ((run + incl - c) << 16);
+            run += (uint32_t)__shfl((int)incl, 63);
+        }
+        if ((tid & 63u) == 0) s_cnt[o] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kExpandItems; it++)
+        if (owner[it] != 0xFFFFFFFFu) {
+            const uint32_t e = s_bits[owner[it] * (uint32_t)kExpandParents + l], a = w * kExpandItems + it;
+            pos[it] = (e >> 16) + (uint32_t)__popc(e & ((1u << a) - 1u));
+        }
     if (tid < d.world && s_cnt[tid])
-        s_base[tid] = (uint32_t)atomicAdd((unsigned long long*)(send + (int64_t)(tid * kShardSub + sub) * g.region_words), (unsigned long long)s_cnt[tid]);
+        s_base[tid] = (uint32_t)atomicAdd((unsigned long long*)(send + (int64_t)(tid * kShardSub + hsub) * g.region_words), (unsigned long long)s_cnt[tid]);
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < kExpandItems; it++) {
         if (owner[it] == 0xFFFFFFFFu) continue;
         const uint32_t at = s_base[owner[it]] + pos[it];
         if (at >= g.subcap) continue;  // overflow: the count in the header says so, the receiver reports it
-        int64_t* r = send + (int64_t)(owner[it] * kShardSub + sub) * g.region_words + kShardHdr + (int64_t)at * recio<W>::RW;
+        const uint32_t a = w * kExpandItems + it;
+        int64_t* r = send + (int64_t)(owner[it] * kShardSub + hsub) * g.region_words + kShardHdr + (int64_t)at * recio<W>::RW;
         recio<W>::put(r, c0[it], c1[it]);
-        r[recio<W>::KW] = (int64_t)(((unsigned long long)x_hi[it] << 32) | x_lo[it]);
+        // record word: parent's local id | (tag relative to the chunk) << 32
+        r[recio<W>::KW] = (int64_t)(((unsigned long long)(uint32_t)(12ull * gp + a - 12ull * (unsigned long long)g.c0) << 32) | id);
     }
 }
 
@@ -889,10 +931,11 @@ static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int lev
     hipLaunchKernelGGL(k_shard_prep<W>, dim3(1), dim3(256), 0, st, E.d, geo, level_first, send);
     const int64_t np_max = std::min<int64_t>(n_par, (int64_t)(E.lvl_hi_host - E.lvl_lo_host));
     if (np_max > 0) {
-        const dim3 grid((unsigned)((12 * np_max + kExpandTile - 1) / kExpandTile));
-        if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_expand<W, kMoveNf>), grid, dim3(kExpandThreads), 0, st, E.d, geo, send);
-        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_expand<W, kMoveNfCyclical>), grid, dim3(kExpandThreads), 0, st, E.d, geo, send);
-        else hipLaunchKernelGGL((k_shard_expand<W, kMoveGeneral>), grid, dim3(kExpandThreads), 0, st, E.d, geo, send);
+        const dim3 grid((unsigned)((np_max + kExpandParents - 1) / kExpandParents));
+        const size_t lds = (size_t)E.world * kExpandParents * 4;  // s_bits
+        if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_expand<W, kMoveNf>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
+        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_expand<W, kMoveNfCyclical>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
+        else hipLaunchKernelGGL((k_shard_expand<W, kMoveGeneral>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
     }
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;

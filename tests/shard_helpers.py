@@ -17,7 +17,7 @@ from oracle import ac_oracle as O
 _CODE = {-2: 0, -1: 1, 1: 2, 2: 3}
 _LETTER = {0: -2, 1: -1, 2: 1, 3: 2}
 INF = 1 << 62
-HDR, SUB, TILE = 4, 16, 1024  # header words, sub-regions per destination, children per workgroup (csrc/acx_shard.hip)
+HDR, SUB, TILE = 4, 16, 1536  # header words, sub-regions per destination, children per workgroup = 128 parents x 12 (csrc/acx_shard.hip)
 _INVERSE = {0: 2, 2: 0, 1: 3, 3: 1, 4: 8, 8: 4, 5: 9, 9: 5, 6: 10, 10: 6, 7: 11, 11: 7}
 
 

@@ -305,7 +305,7 @@ def test_sharded_bfs_mid_size_thread_ranks_equal_the_fused_search(search, golden
 def test_device_routing_matches_owner_of(search, L):
     """acx_shard_chunk_expand routes every child to the region of the rank the orchestrator's owner function names (owner_of),
     both key widths, and sends exactly the children it should: not the unchanged ones, not the ones that undo their parent's
-    move (normal-form root, cyclical = False), and of the duplicates inside a 1024-child workgroup tile only the smallest tag.
+    move (normal-form root, cyclical = False), and of the duplicates inside a workgroup tile (128 parents) only the smallest tag.
     Fed back into the SAME engine (as if it owned every key) insert + commit reproduce a plain BFS level by level."""
     import torch
 
@@ -336,7 +336,7 @@ def test_device_routing_matches_owner_of(search, L):
                 for a in range(12):
                     if np.array_equal(out[a], st) or (made_by < 12 and a == inverse[made_by]):
                         continue
-                    key, tile = tuple(out[a].tolist()), (12 * gp + a) // 1024
+                    key, tile = tuple(out[a].tolist()), gp // 128  # a workgroup = 128 consecutive local parents x 12 actions
                     if key in tile_keys.setdefault(tile, set()):
                         continue
                     tile_keys[tile].add(key)
