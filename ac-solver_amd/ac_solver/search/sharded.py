@@ -221,20 +221,36 @@ def _default_engine(L, cyclical, node_cap, chunk_parents, rank, world, est_paren
 
 # ------------------------------------------------------------------------------------- orchestrator ---
 def owner_of(keys, world):
-    """Deterministic owner rank of each packed key [m, KW] int64 (same arithmetic on CPU and GPU tensors)."""
+    """Deterministic owner rank of each packed key [m, KW] int64 (same arithmetic on CPU and GPU tensors, and in
+    csrc/acx_shard.hip: shard_hash / owner_of_hash -- one multiply-xorshift round per key word, then the 32 bits from bit 20
+    of the hash scaled to [0, world): no division)."""
     torch = _torch()
     h = torch.zeros(keys.shape[0], dtype=torch.int64, device=keys.device)
     for j in range(keys.shape[1]):
         h = (h ^ keys[:, j]) * -7046029254386353131  # 0x9E3779B97F4A7C15 as int64, wraps
         h = h ^ ((h >> 29) & 0x7FFFFFFFF)
-    return (h & 0x7FFFFFFFFFFFFFFF) % world
+    return (((h >> 20) & 0xFFFFFFFF) * int(world)) >> 32
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """ONE side stream per device for the life of the process.  `torch.cuda.Stream()` hands out the 32 streams of torch's pool in
+    turn, and the first submission to each of them pays for a hardware queue: a search that took a new stream per call ran
+    20 ms instead of 15 ms at 1e8 nodes."""
+    torch = _torch()
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(dev)
+    return _SIDE_STREAMS[key]
 
 
 def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False, comm=None,
                 engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None):
     """Same contract as `bfs`: returns (is_search_successful, path or None) [+ stats dict], identical on every rank.
     `batch_parents`: global frontier positions per chunk.  `log_fraction`: expected expanded parents / max_nodes, sizes the
-    record log (it grows by doubling if the estimate is short).  `overlap`: expansion + exchange of chunk k + 1 on a side stream beside the dedup + commit of chunk k (default: when there is an exchange, i.e. world > 1)."""
+    record log (it grows by doubling if the estimate is short).  `overlap`: expansion + exchange of chunk k + 1 on a side stream, started beside the dedup of chunk k ("insert": the default when there is an exchange, i.e. world > 1) or beside its commit ("commit": the default without one); False: one stream."""
     from ac_solver.envs.utils import is_array_valid_presentation
 
     import time
@@ -295,19 +311,23 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             return ok, path, st
         return ok, path
 
-    # Two streams on a GPU: `side` runs the expansion of chunk k + 1 and its all-to-all while the main stream deduplicates and
-    # commits chunk k (expansion is arithmetic + streaming stores, the dedup random memory access, the exchange xGMI: three
-    # different resources).  Inside a level chunk k + 1 needs nothing from chunk k: its parents were committed during the
-    # previous level and it has its own slice of the record log; only the send buffer is shared, and that is reused in `side`'s
-    # own order.  The CPU engines of the tests run everything in program order.
-    # At world 1 there is no exchange to hide and the two streams gain 3 % at best -- and LOSE 40 % in some process states (a
-    # freshly started process: 20 ms against 15 ms at 1e8 nodes; inside bench.py after its graph capture: 31 ms), so the side
-    # stream is the default only where it has an all-to-all to carry.
-    if overlap is None:
-        overlap = exchange
+    # Two streams on a GPU: `side` runs the expansion of chunk k + 1 and its all-to-all beside the main stream's work on chunk k.
+    # Inside a level chunk k + 1 needs nothing from chunk k: its parents were committed during the previous level and it has its
+    # own slice of the record log; only the send buffer is shared, and that is reused in `side`'s own order.  The CPU engines of
+    # the tests run everything in program order.  WHERE the expansion may start (measured, tools/scratch/trace_timeline.py):
+    #   * beside k_shard_insert it does not pay on one GPU: the dedup keeps ~2.6e5 table atomics queued at the memory side, the
+    #     expansion's region reservations (one returning atomic per workgroup) wait ~14 us each behind them, and the expansion
+    #     runs 3.5 x slower than alone (0.24 -> 0.75-0.9 ms per 2^21-parent chunk) while the dedup slows by a third;
+    #   * beside pack / scan / decide / commit (streaming kernels, no table atomics) it is nearly free.
+    # So with no exchange to hide the side stream is held back until the chunk's dedup is through (`overlap="commit"`); with an
+    # exchange the expansion + all-to-all start at once (`overlap="insert"`): there the per-rank kernels shrink with the world
+    # size and the collectives are what has to be hidden.  `overlap=False`: one stream.
+    if overlap is None or overlap is True:
+        overlap = "insert" if exchange else "commit"
+    assert overlap in (False, "insert", "commit"), overlap
     on_gpu = dev.type == "cuda"
     main = torch.cuda.current_stream(dev) if on_gpu else None
-    side = (torch.cuda.Stream(dev) if overlap else main) if on_gpu else None
+    side = (_side_stream(dev) if overlap else main) if on_gpu else None
 
     class _on_side:
         def __enter__(self):
@@ -357,7 +377,7 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
         ready = produce(*bounds[0])
         while k < len(bounds) and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING):
             n_par, ev = ready
-            if k + 1 < len(bounds):
+            if k + 1 < len(bounds) and overlap != "commit":
                 ready = produce(*bounds[k + 1])  # runs beside this chunk's dedup and commit
             if ev is not None:
                 main.wait_event(ev)
@@ -368,6 +388,10 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
                 engine.fail_local()
                 gmask = engine.gmask_view(n_par)  # the engine's own buffer: its commit reads the all-reduced masks from there
                 gmask.zero_()
+            if k + 1 < len(bounds) and overlap == "commit":
+                if on_gpu:
+                    side.wait_stream(main)  # not before this chunk's dedup is through
+                ready = produce(*bounds[k + 1])  # runs beside this chunk's mask all-reduce and commit
             if exchange:
                 comm.all_reduce(gmask, "sum")  # every (parent, action) child has exactly one owner, so SUM == OR
             try:

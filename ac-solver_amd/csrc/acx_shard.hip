@@ -44,7 +44,10 @@ constexpr int kShardSub = ACX_SHARD_SUBREGIONS;  // sub-regions per destination:
 #endif
 // a workgroup of k_shard_expand: kExpandParents parents x 12 actions; four waves x three actions per group of 64 parents
 constexpr int kExpandParents = ACX_SHARD_EXPAND_PARENTS, kExpandItems = 3, kExpandThreads = kExpandParents * 4, kExpandTile = kExpandParents * 12;
-constexpr int kFoldSlots = kExpandParents <= 64 ? 2048 : 4096;  // LDS fold table of a tile (a power of two >= 2 x the tile)
+#ifndef ACX_SHARD_FOLD_SLOTS
+#define ACX_SHARD_FOLD_SLOTS (ACX_SHARD_EXPAND_PARENTS <= 64 ? 2048 : 4096)
+#endif
+constexpr int kFoldSlots = ACX_SHARD_FOLD_SLOTS;  // LDS fold table of a tile (a power of two >= 2 x the tile)
 constexpr int kTileBits = kExpandParents <= 64 ? 10 : 11;        // bits of a tile slot / of a tag inside the tile
 static_assert((kExpandParents == 64 || kExpandParents == 128) && kExpandTile <= (1 << kTileBits), "tile slots and tags fit kTileBits");
 constexpr int kScanTile = 4096;                    // parents per workgroup of k_shard_scan
@@ -68,20 +71,23 @@ template <> struct recio<u128> {
     }
 };
 
-// Owner rank of a packed key: the arithmetic of ac_solver/search/sharded.py:owner_of on the key's int64 words.
-ACX_HD uint64_t owner_mix(uint64_t h, uint64_t w) {
+// The hash of the sharded engine: ONE value per key serves the owner rank, the LDS fold slot of the expansion, the stamp-table
+// bucket and the 28-bit fingerprint.  k_shard_expand is bound by vector issue, and the hash of the fused search (hash_key:
+// five 64-bit multiplies, i.e. fifteen quarter-rate 32-bit multiplies per child) plus a second hash and a 64-bit modulo for
+// the owner were ~40 % of its vector cycles; this one is one multiply-xorshift round per key word.  Bits: table bucket =
+// low bits, fold slot = bits 40.., fingerprint = bits 36..63, owner = the 32 bits from bit 20 scaled to [0, world)
+// (ac_solver/search/sharded.py:owner_of does the same arithmetic on the key's int64 words).
+ACX_HD uint64_t shard_mix(uint64_t h, uint64_t w) {
     h = (h ^ w) * 0x9E3779B97F4A7C15ull;
     return h ^ (h >> 29);
 }
-ACX_HD uint32_t owner_of_key(uint64_t k0, uint64_t k1, uint32_t world) {
-    const uint64_t h = owner_mix(owner_mix(0, k0), k1);
-    return (uint32_t)((h & 0x7FFFFFFFFFFFFFFFull) % world);
+ACX_HD uint64_t shard_hash(uint64_t k0, uint64_t k1) { return shard_mix(shard_mix(0, k0), k1); }
+ACX_HD uint64_t shard_hash(u128 k0, u128 k1) {
+    uint64_t h = shard_mix(shard_mix(0, (uint64_t)k0), (uint64_t)(k0 >> 64));
+    return shard_mix(shard_mix(h, (uint64_t)k1), (uint64_t)(k1 >> 64));
 }
-ACX_HD uint32_t owner_of_key(u128 k0, u128 k1, uint32_t world) {
-    uint64_t h = owner_mix(owner_mix(0, (uint64_t)k0), (uint64_t)(k0 >> 64));
-    h = owner_mix(owner_mix(h, (uint64_t)k1), (uint64_t)(k1 >> 64));
-    return (uint32_t)((h & 0x7FFFFFFFFFFFFFFFull) % world);
-}
+ACX_HD uint32_t owner_of_hash(uint64_t h, uint32_t world) { return (uint32_t)(((uint64_t)(uint32_t)(h >> 20) * world) >> 32); }
+template <typename W> ACX_HD uint32_t owner_of_key(W k0, W k1, uint32_t world) { return owner_of_hash(shard_hash(k0, k1), world); }
 
 // ---- control block (device, int64 words; include/acx.h: ACX_SHARD_CTL_*) ---------------------------------------------------
 enum : int {
@@ -308,13 +314,16 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
     // ---- duplicates inside the tile: of equal keys the smallest tag stays.  A table entry is (tag inside the tile) << 10 | slot j:
     // ordered by the tag (12 * lane + action), so atomicMin keeps the first discoverer -------------------------------------
     uint32_t ls[kExpandItems], me[kExpandItems];
+    uint64_t hk[kExpandItems];
 #pragma unroll
     for (int it = 0; it < kExpandItems; it++) {
         const uint32_t a = w * kExpandItems + it, j = a * (uint32_t)kExpandParents + l;
         me[it] = ((12u * l + a) << kTileBits) | j;
         ls[it] = 0;
+        hk[it] = 0;
         if (!send_it[it]) continue;
-        uint32_t q = (uint32_t)(hash_key<W>(c0[it], c1[it]) >> 40) & (kFoldSlots - 1);
+        hk[it] = shard_hash(c0[it], c1[it]);
+        uint32_t q = (uint32_t)(hk[it] >> 40) & (kFoldSlots - 1);
         for (;;) {
             uint32_t v = s_slot[q];
             if (v == kEmpty) {
@@ -341,7 +350,7 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
         owner[it] = 0xFFFFFFFFu;
         pos[it] = 0;
         if (send_it[it] && s_slot[ls[it]] == me[it]) {
-            owner[it] = owner_of_key(c0[it], c1[it], d.world);
+            owner[it] = owner_of_hash(hk[it], d.world);
             atomicOr(&s_bits[owner[it] * (uint32_t)kExpandParents + l], 1u << (w * kExpandItems + it));
         }
     }
@@ -394,23 +403,19 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
 constexpr unsigned long long kStampFree = ~0ull;
 constexpr unsigned long long kStampOff = (1ull << 36) - 1;
 
-template <typename W>
-__global__ void __launch_bounds__(256) k_shard_insert(ShardDev<W> d, ChunkGeo g) {
-    ACX_VGPR_PAD("v63");
-    if (d.ctl[C_STATUS] != 0) return;
-    const uint32_t r = blockIdx.y;
+template <typename W> __device__ __forceinline__ void shard_insert_tile(const ShardDev<W>& d, const ChunkGeo& g, uint32_t r, uint32_t bx) {
     const int64_t roff = g.log_off + (int64_t)r * g.region_words;
     const unsigned long long written = (unsigned long long)d.log[roff];
-    if (written > g.subcap && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(d.ctl + C_FAIL_LOCAL, (unsigned long long)FAIL_REGION);
+    if (written > g.subcap && bx == 0 && threadIdx.x == 0) atomicMax(d.ctl + C_FAIL_LOCAL, (unsigned long long)FAIL_REGION);
     const uint32_t cnt = written > g.subcap ? g.subcap : (uint32_t)written;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = bx * blockDim.x + threadIdx.x;
     if (i >= cnt) return;
     const int64_t off = roff + kShardHdr + (int64_t)i * recio<W>::RW;
     const int64_t* rec = d.log + off;
     W c0, c1;
     recio<W>::get(rec, c0, c1);
     const uint32_t tag = (uint32_t)((unsigned long long)rec[recio<W>::KW] >> 32);
-    const uint64_t hk = hash_key<W>(c0, c1);
+    const uint64_t hk = shard_hash(c0, c1);
     const unsigned long long me = (hk & ~kStampOff) | (unsigned long long)off;
     uint32_t base = (uint32_t)hk & d.stmask & ~3u, probes = 0, took = 0;
     bool open = true;
@@ -465,6 +470,15 @@ __global__ void __launch_bounds__(256) k_shard_insert(ShardDev<W> d, ChunkGeo g)
         }
     }
     if (took) d.btook[tag] = 1;
+}
+
+// grid (x, regions): x = tiles per region, or FEWER -- then a workgroup walks the tiles of its region x, x + gridDim.x, ...: a
+// bounded number of resident workgroups, so that an expansion on the side stream finds room beside them (ShardEngine::insert_wgs).
+template <typename W>
+__global__ void __launch_bounds__(256) k_shard_insert(ShardDev<W> d, ChunkGeo g, uint32_t tiles) {
+    ACX_VGPR_PAD("v63");
+    if (d.ctl[C_STATUS] != 0) return;
+    for (uint32_t bx = blockIdx.x; bx < tiles; bx += gridDim.x) shard_insert_tile<W>(d, g, blockIdx.y, bx);
 }
 
 // one 12-bit mask per parent of the chunk: bit a set when child (parent, a) is a new state of this rank; the flags it read are
@@ -689,26 +703,28 @@ template <typename W> __global__ void __launch_bounds__(256) k_shard_commit(Shar
     const int64_t roff = g.log_off + (int64_t)r * g.region_words;
     const unsigned long long written = (unsigned long long)d.log[roff];
     const uint32_t cnt = written > g.subcap ? g.subcap : (uint32_t)written;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cnt) return;
-    const int64_t* rec = d.log + roff + kShardHdr + (int64_t)i * recio<W>::RW;
-    const unsigned long long x = (unsigned long long)rec[recio<W>::KW];
-    const uint32_t tag = (uint32_t)(x >> 32);
-    if (tag >= dec.cutoff) return;
-    const uint32_t par = tag / 12u, a = tag - 12u * par;
-    const uint32_t lm = (uint32_t)d.lmask[par];
-    if (!((lm >> a) & 1u)) return;
-    const uint32_t below = (1u << a) - 1u, tile = par / kScanTile;
-    const uint32_t id = dec.node_base + d.lblk[tile] + d.lpre[par] + (uint32_t)__popc(lm & below);
-    if (id >= d.cap_nodes) return;  // k_shard_decide has refused such a commit already: never reached
-    W k0, k1;
-    recio<W>::get(rec, k0, k1);
-    d.k0[id] = k0;
-    d.k1[id] = k1;
-    d.act[id] = (uint8_t)a;
-    d.tlen[id] = (uint8_t)(keyops<W>::len(k0) + keyops<W>::len(k1));
-    d.gpos[id] = dec.gpos_base + d.gblk[tile] + d.gpre[par] + (uint32_t)__popc(gmask_of(d.gmask, par) & below);
-    d.pref[id] = (int64_t)(((unsigned long long)(r / kShardSub) << 40) | (x & 0xFFFFFFFFull));
+    // gridDim.x workgroups walk the region's records (a region is rarely full: a workgroup per 256 record SLOTS spent two
+    // thirds of its launches on workgroups that found nothing to do)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+        const int64_t* rec = d.log + roff + kShardHdr + (int64_t)i * recio<W>::RW;
+        const unsigned long long x = (unsigned long long)rec[recio<W>::KW];
+        const uint32_t tag = (uint32_t)(x >> 32);
+        if (tag >= dec.cutoff) continue;
+        const uint32_t par = tag / 12u, a = tag - 12u * par;
+        const uint32_t lm = (uint32_t)d.lmask[par];
+        if (!((lm >> a) & 1u)) continue;
+        const uint32_t below = (1u << a) - 1u, tile = par / kScanTile;
+        const uint32_t id = dec.node_base + d.lblk[tile] + d.lpre[par] + (uint32_t)__popc(lm & below);
+        if (id >= d.cap_nodes) continue;  // k_shard_decide has refused such a commit already: never reached
+        W k0, k1;
+        recio<W>::get(rec, k0, k1);
+        d.k0[id] = k0;
+        d.k1[id] = k1;
+        d.act[id] = (uint8_t)a;
+        d.tlen[id] = (uint8_t)(keyops<W>::len(k0) + keyops<W>::len(k1));
+        d.gpos[id] = dec.gpos_base + d.gblk[tile] + d.gpre[par] + (uint32_t)__popc(gmask_of(d.gmask, par) & below);
+        d.pref[id] = (int64_t)(((unsigned long long)(r / kShardSub) << 40) | (x & 0xFFFFFFFFull));
+    }
 }
 
 // root: local node 0 of its owner (global position 0 of level 0); its record sits at the start of the log
@@ -722,7 +738,7 @@ template <typename W> __global__ void k_shard_seed(ShardDev<W> d, W k0, W k1) {
     d.pref[0] = -1;
     recio<W>::put(d.log, k0, k1);
     d.log[recio<W>::KW] = 0;
-    const uint64_t hk = hash_key<W>(k0, k1);
+    const uint64_t hk = shard_hash(k0, k1);
     d.stab[(uint32_t)hk & d.stmask & ~3u] = hk & ~kStampOff;  // offset 0: first slot of its bucket
     d.ctl[C_NODES] = 1;
 }
@@ -757,6 +773,12 @@ template <typename W> struct ShardEngine {
     int geo_inserted = 0;              // how many of them have been through acx_shard_chunk_insert
     uint64_t nodes_host = 0, lvl_lo_host = 0, lvl_hi_host = 0;  // what the last control-block snapshot said
     int rank = 0, world = 1;
+    // k_shard_insert and k_shard_commit run as a bounded number of workgroups that walk their region's records (0 = a
+    // workgroup per 256 record slots).  Regions are sized for the worst case and are usually less than half full, so two
+    // thirds of the per-slot workgroups found nothing to do, and the dedup gains nothing from more than ~4 workgroups per
+    // compute unit in flight: the memory-side atomic units are saturated by then and a deeper queue is only more latency.
+    // Measured at 1e8 nodes (tools/scratch/shard_env_sweep.py): insert 545 -> 528 us per 2^21-parent chunk, commit 158 -> ~125.
+    unsigned insert_wgs = 0, commit_wgs = 0;
     int move_mode = kMoveGeneral;  // acx_bfs.h: set from the root (acx_shard_root_record, which every rank calls)
     unsigned long long* pinned = nullptr;  // kCtlSlots x C_WORDS
     hipEvent_t ev[kCtlSlots] = {};
@@ -775,6 +797,14 @@ template <typename W> struct ShardEngine {
         d.rank = (uint32_t)rank_;
         rank = rank_;
         world = world_;
+        {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            insert_wgs = 4u * (unsigned)cus;
+            commit_wgs = 8u * (unsigned)cus;
+        }
+        if (const char* e = getenv("ACX_SHARD_INSERT_WGS")) insert_wgs = (unsigned)atoi(e);  // (tuning: tools/scratch/shard_env_sweep.py)
+        if (const char* e = getenv("ACX_SHARD_COMMIT_WGS")) commit_wgs = (unsigned)atoi(e);
         cap_nodes = (uint64_t)node_cap + 64;
         chunk_parents = (uint64_t)std::max<int64_t>(chunk_parents_, 1);
         int64_t subcap, region_words;
@@ -945,8 +975,10 @@ template <typename W> static int shard_chunk_insert(ShardEngine<W>& E, hipStream
     if (E.geo_inserted >= E.geo_count) return fail(ACX_E_INVAL, "acx_shard_chunk_insert: no expanded chunk is waiting");
     const ChunkGeo& geo = E.geos[(E.geo_head + E.geo_inserted) % ShardEngine<W>::kGeoRing];
     E.geo_inserted++;
-    const dim3 grid((unsigned)((geo.subcap + 255) / 256), (unsigned)(kShardSub * E.world));
-    hipLaunchKernelGGL(k_shard_insert<W>, grid, dim3(256), 0, st, E.d, geo);
+    const unsigned tiles = (unsigned)((geo.subcap + 255) / 256), regions = (unsigned)(kShardSub * E.world);
+    unsigned gx = tiles;
+    if (E.insert_wgs) gx = std::min(tiles, std::max(1u, E.insert_wgs / regions));
+    hipLaunchKernelGGL(k_shard_insert<W>, dim3(gx, regions), dim3(256), 0, st, E.d, geo, tiles);
     hipLaunchKernelGGL(k_shard_pack<W>, dim3(((geo.n_par + 1) / 2 + 255) / 256), dim3(256), 0, st, E.d, geo.n_par);
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
@@ -960,8 +992,10 @@ template <typename W> static int shard_chunk_commit(ShardEngine<W>& E, int64_t m
     E.geo_inserted--;
     hipLaunchKernelGGL(k_shard_scan<W>, dim3((geo.n_par + kScanTile - 1) / kScanTile), dim3(1024), 0, st, E.d, geo.n_par);
     hipLaunchKernelGGL(k_shard_decide<W>, dim3(1), dim3(1024), 0, st, E.d, geo, max_nodes);
-    const dim3 grid((unsigned)((geo.subcap + 255) / 256), (unsigned)(kShardSub * E.world));
-    hipLaunchKernelGGL(k_shard_commit<W>, grid, dim3(256), 0, st, E.d, geo);
+    const unsigned tiles = (unsigned)((geo.subcap + 255) / 256), regions = (unsigned)(kShardSub * E.world);
+    unsigned gx = tiles;
+    if (E.commit_wgs) gx = std::min(tiles, std::max(1u, E.commit_wgs / regions));
+    hipLaunchKernelGGL(k_shard_commit<W>, dim3(gx, regions), dim3(256), 0, st, E.d, geo);
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }

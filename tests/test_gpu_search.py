@@ -259,8 +259,8 @@ def test_sharded_bfs_hip_engine_matches_reference(search, golden_json, world):
              (ak3, 10**5, False, 1 << 14), (ak3, 5000, True, 333), (pool[1100], 20000, False, 1 << 12), (pool[600], 3000, False, 50)]
 
     def run(comm):
-        # (world 1 runs in stream order by default: every other case also goes through the two-stream pipeline of the multi-rank runs)
-        return [bfs_sharded(p, b, cyclically_reduce_after_moves=c, comm=comm, batch_parents=bp, want_stats=True, overlap=True if k % 2 else None)
+        # (the three schedules of the side stream in turn: whatever the world size defaults to, every rank count sees all of them)
+        return [bfs_sharded(p, b, cyclically_reduce_after_moves=c, comm=comm, batch_parents=bp, want_stats=True, overlap=("insert", "commit", False, None)[k % 4])
                 for k, (p, b, c, bp) in enumerate(cases)]
 
     results = [run(SingleComm())] if world == 1 else run_threads(world, run)
