@@ -250,7 +250,7 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
                 engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None):
     """Same contract as `bfs`: returns (is_search_successful, path or None) [+ stats dict], identical on every rank.
     `batch_parents`: global frontier positions per chunk.  `log_fraction`: expected expanded parents / max_nodes, sizes the
-    record log (it grows by doubling if the estimate is short).  `overlap`: expansion + exchange of chunk k + 1 on a side stream, started beside the dedup of chunk k ("insert": the default when there is an exchange, i.e. world > 1) or beside its commit ("commit": the default without one); False: one stream."""
+    record log (it grows by doubling if the estimate is short).  `overlap`: expansion + exchange of chunk k + 1 on a side stream, started beside the dedup of chunk k ("insert": the default when there is an exchange, i.e. world > 1) or beside its commit ("commit"); False: one stream, the default without an exchange."""
     from ac_solver.envs.utils import is_array_valid_presentation
 
     import time
@@ -314,16 +314,18 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
     # Two streams on a GPU: `side` runs the expansion of chunk k + 1 and its all-to-all beside the main stream's work on chunk k.
     # Inside a level chunk k + 1 needs nothing from chunk k: its parents were committed during the previous level and it has its
     # own slice of the record log; only the send buffer is shared, and that is reused in `side`'s own order.  The CPU engines of
-    # the tests run everything in program order.  WHERE the expansion may start (measured, tools/scratch/trace_timeline.py):
-    #   * beside k_shard_insert it does not pay on one GPU: the dedup keeps ~2.6e5 table atomics queued at the memory side, the
-    #     expansion's region reservations (one returning atomic per workgroup) wait ~14 us each behind them, and the expansion
-    #     runs 3.5 x slower than alone (0.24 -> 0.75-0.9 ms per 2^21-parent chunk) while the dedup slows by a third;
-    #   * beside pack / scan / decide / commit (streaming kernels, no table atomics) it is nearly free.
-    # So with no exchange to hide the side stream is held back until the chunk's dedup is through (`overlap="commit"`); with an
-    # exchange the expansion + all-to-all start at once (`overlap="insert"`): there the per-rank kernels shrink with the world
-    # size and the collectives are what has to be hidden.  `overlap=False`: one stream.
+    # the tests run everything in program order.  What running two of the engine's kernels side by side is worth on ONE GPU
+    # (measured, tools/scratch/trace_timeline.py on rocprofv3 kernel traces of 1e8-node searches):
+    #   * expansion beside k_shard_insert: the dedup keeps ~2.6e5 table atomics queued at the memory side, the expansion's
+    #     region reservations (one returning atomic per workgroup) wait ~14 us each behind them and it loses its share of the
+    #     compute units: 0.21 -> 0.75-0.9 ms per 2^21-parent chunk, the dedup slows by a third, the chunk period stays;
+    #   * expansion beside pack / scan / decide / commit ("commit"): 0.21 -> 0.33 ms, the commit slows too: no gain either;
+    #   * k_shard_commit of chunk k beside the dedup of chunk k + 1 (tried with a third stream): no gain.
+    # The kernels are bound by vector issue (expansion) or by the memory system (the rest); what shortens the search is
+    # shortening them.  So without an exchange everything runs in stream order; with one, expansion + all-to-all start at once
+    # on the side stream ("insert"): the per-rank kernels shrink with the world size and the collectives are what has to be hidden.
     if overlap is None or overlap is True:
-        overlap = "insert" if exchange else "commit"
+        overlap = "insert" if exchange else False
     assert overlap in (False, "insert", "commit"), overlap
     on_gpu = dev.type == "cuda"
     main = torch.cuda.current_stream(dev) if on_gpu else None
@@ -366,6 +368,31 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
                 ev.record(side)
         return n_par, ev
 
+    # Chunk sizes.  A chunk is expanded and deduplicated as a whole even when the budget runs out at its first parents, so near
+    # the end of the budget the chunks shrink to what the remaining budget is expected to need: new states per parent so far in
+    # this level (at its start: of the previous level) x the parents already in flight, from the lagged control block -- the
+    # same integers on every rank, so every rank cuts the same chunks.  An estimate that falls short only costs another small
+    # chunk.  (1e8-node search: the last 2^21-parent chunk was needed for a fraction of its parents.)
+    min_chunk = min(B, 1 << 16)
+    F_prev = 0  # parents of the previous level
+    nodes_seen = 1
+
+    def next_size(c0, sizes, n_read, new_read):
+        n = min(B, F - c0)
+        if n_read > 0:
+            num, den = new_read, sum(sizes[:n_read])  # new states per parent, this level
+        elif F_prev > 0:
+            num, den = F, F_prev
+        else:
+            return n
+        if num <= 0:
+            return n
+        in_flight = sum(sizes[n_read:])
+        remaining = max_nodes - nodes_seen - (in_flight * num + den - 1) // den
+        want = max(min_chunk, -(-(max(remaining, 0) * den * 9) // (num * 8)))
+        want = (want + 2047) // 2048 * 2048
+        return min(n, want)
+
     while F > 0:
         levels += 1
         pending = []  # snapshot slots of the chunks whose control block has not been read yet
@@ -373,12 +400,21 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
         ctl = None
         if on_gpu:
             side.wait_stream(main)  # the level's parents are the nodes the main stream committed during the previous level
-        bounds = [(c0, min(F, c0 + B)) for c0 in range(0, F, B)]
-        ready = produce(*bounds[0])
-        while k < len(bounds) and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING):
+        sizes, n_read, new_read, c_next = [], 0, 0, 0
+
+        def produce_next():
+            nonlocal c_next
+            n = next_size(c_next, sizes, n_read, new_read)
+            sizes.append(n)
+            c_next += n
+            return produce(c_next - n, c_next)
+
+        ready = produce_next()
+        while ready is not None and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING):
             n_par, ev = ready
-            if k + 1 < len(bounds) and overlap != "commit":
-                ready = produce(*bounds[k + 1])  # runs beside this chunk's dedup and commit
+            ready = None
+            if c_next < F and overlap != "commit":
+                ready = produce_next()  # runs beside this chunk's dedup and commit
             if ev is not None:
                 main.wait_event(ev)
             try:
@@ -388,10 +424,10 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
                 engine.fail_local()
                 gmask = engine.gmask_view(n_par)  # the engine's own buffer: its commit reads the all-reduced masks from there
                 gmask.zero_()
-            if k + 1 < len(bounds) and overlap == "commit":
+            if c_next < F and overlap == "commit":
                 if on_gpu:
                     side.wait_stream(main)  # not before this chunk's dedup is through
-                ready = produce(*bounds[k + 1])  # runs beside this chunk's mask all-reduce and commit
+                ready = produce_next()  # runs beside this chunk's mask all-reduce and commit
             if exchange:
                 comm.all_reduce(gmask, "sum")  # every (parent, action) child has exactly one owner, so SUM == OR
             try:
@@ -404,6 +440,8 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             chunks += 1
             if len(pending) > lag:
                 ctl = engine.ctl_wait(pending.pop(0))
+                n_read += 1
+                new_read, nodes_seen = int(ctl[CTL_NEXT_COUNT]), int(ctl[CTL_NODES_GLOBAL])
             k += 1
         if on_gpu:
             main.wait_stream(side)  # (a chunk that was produced but never consumed: the search ended)
@@ -424,5 +462,5 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             return finish(True, walk(int(pref[0]), [(tag % 12, 2)]))
         if status == ST_BUDGET:
             return finish(False, None)
-        F = int(ctl[CTL_NEXT_COUNT])
+        F_prev, F, nodes_seen = F, int(ctl[CTL_NEXT_COUNT]), int(ctl[CTL_NODES_GLOBAL])
     return finish(False, None)

@@ -26,6 +26,9 @@
 //
 // The host never waits inside a level: it enqueues chunk after chunk and reads a snapshot of the control block two chunks
 // late (acx_shard_ctl_snapshot / acx_shard_ctl_wait); once the status word leaves 0 every later kernel returns at once.
+#include <mutex>
+#include <vector>
+
 #include "acx_bfs.h"  // search_move: the shorter move code for searches whose root is in normal form
 
 #ifndef ACX_SHARD_SUBREGIONS
@@ -482,32 +485,38 @@ __global__ void __launch_bounds__(256) k_shard_insert(ShardDev<W> d, ChunkGeo g,
 }
 
 // one 12-bit mask per parent of the chunk: bit a set when child (parent, a) is a new state of this rank; the flags it read are
-// zeroed again for the next chunk (no memset launches).  A lane serves two parents: their masks share a word of gmask.
+// zeroed again for the next chunk (no memset launches).  Two parents share a word of gmask.  A workgroup serves kPackParents
+// parents = 3072 flag bytes of each array, read as 192 coalesced 16-byte vectors, squeezed to one bit per flag in LDS, from
+// where every lane takes the 12 bits of its parent (a lane per parent reading its own 12 bytes as three dwords at a 12-byte
+// stride: 42 us per 2^21-parent chunk instead of 26).
+constexpr int kPackParents = 256;
 template <typename W> __global__ void __launch_bounds__(256) k_shard_pack(ShardDev<W> d, uint32_t n_par) {
+    __shared__ uint16_t s_flag[kPackParents * 12 / 16 + 2];
     ACX_VGPR_PAD("v31");
     if (d.ctl[C_STATUS] != 0) return;
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (2 * q >= n_par) return;
-    uint32_t both = 0;
-#pragma unroll
-    for (uint32_t h = 0; h < 2; h++) {
-        const uint32_t p = 2 * q + h;
-        if (p >= n_par) break;
-        uint32_t* t = (uint32_t*)(d.btook + 12 * (size_t)p);  // 12 bytes, 4-byte aligned
-        uint32_t* r = (uint32_t*)(d.brepl + 12 * (size_t)p);
-        uint32_t m = 0;
-#pragma unroll
-        for (int w = 0; w < 3; w++) {
-            const uint32_t tv = t[w], rv = r[w];
-            if (tv) t[w] = 0;
-            if (rv) r[w] = 0;
-            const uint32_t v = tv & ~rv;  // bytes are 0 / 1
-            m |= ((v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u)) << (4 * w);
-        }
-        d.lmask[p] = (int32_t)m;
-        both |= m << (16u * h);
+    const uint32_t tid = threadIdx.x, p0 = blockIdx.x * kPackParents;
+    if (p0 >= n_par) return;
+    constexpr uint32_t kVecs = kPackParents * 12 / 16;
+    if (tid < kVecs) {  // (the arrays are padded by a tile: flags behind the chunk's last parent are zero and stay zero)
+        uint4* t = (uint4*)(d.btook + 12 * (size_t)p0) + tid;
+        uint4* r = (uint4*)(d.brepl + 12 * (size_t)p0) + tid;
+        const uint4 tv = *t, rv = *r;
+        if (tv.x | tv.y | tv.z | tv.w) *t = make_uint4(0, 0, 0, 0);
+        if (rv.x | rv.y | rv.z | rv.w) *r = make_uint4(0, 0, 0, 0);
+        auto squeeze = [](uint32_t v) { return (v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u); };  // bytes are 0 / 1
+        s_flag[tid] = (uint16_t)(squeeze(tv.x & ~rv.x) | (squeeze(tv.y & ~rv.y) << 4) | (squeeze(tv.z & ~rv.z) << 8) | (squeeze(tv.w & ~rv.w) << 12));
+    } else if (tid < kVecs + 2) {
+        s_flag[tid] = 0;
     }
-    d.gmask[q] = (int32_t)both;
+    __syncthreads();
+    const uint32_t p = p0 + tid, bit = 12u * tid;
+    uint32_t m = 0;
+    if (p < n_par) {
+        m = (((uint32_t)s_flag[bit >> 4] | ((uint32_t)s_flag[(bit >> 4) + 1] << 16)) >> (bit & 15u)) & 0xFFFu;
+        d.lmask[p] = (int32_t)m;
+    }
+    const uint32_t other = (uint32_t)__shfl_xor((int)m, 1);
+    if (!(tid & 1u) && p < n_par) d.gmask[p >> 1] = (int32_t)(m | (other << 16));
 }
 
 // exclusive popcount prefixes of the local and the all-reduced masks inside tiles of kScanTile parents + the tiles' totals
@@ -704,7 +713,8 @@ template <typename W> __global__ void __launch_bounds__(256) k_shard_commit(Shar
     const unsigned long long written = (unsigned long long)d.log[roff];
     const uint32_t cnt = written > g.subcap ? g.subcap : (uint32_t)written;
     // gridDim.x workgroups walk the region's records (a region is rarely full: a workgroup per 256 record SLOTS spent two
-    // thirds of its launches on workgroups that found nothing to do)
+    // thirds of its launches on workgroups that found nothing to do).  (Four records per lane and step, to overlap their
+    // chains of dependent loads, changed nothing: 139 us per 2^21-parent chunk either way.)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
         const int64_t* rec = d.log + roff + kShardHdr + (int64_t)i * recio<W>::RW;
         const unsigned long long x = (unsigned long long)rec[recio<W>::KW];
@@ -758,6 +768,39 @@ __global__ void k_shard_fail(unsigned long long* ctl, unsigned long long code) {
 
 constexpr int kCtlSlots = 4;
 
+// The pinned snapshot slots + their events of an engine.  hipHostMalloc / hipHostFree synchronise with the device and cost
+// ~0.15 ms each, which a 13 ms search notices: released sets are kept (per device) and handed to the next engine.
+struct CtlHost {
+    unsigned long long* pinned = nullptr;  // kCtlSlots x C_WORDS
+    hipEvent_t ev[kCtlSlots] = {};
+    int dev = -1;
+};
+static std::mutex g_ctl_mutex;
+static std::vector<CtlHost> g_ctl_free;
+static int ctl_host_take(CtlHost& c) {
+    int dev = 0;
+    ACX_HIP_TRY(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lock(g_ctl_mutex);
+        for (size_t i = 0; i < g_ctl_free.size(); i++)
+            if (g_ctl_free[i].dev == dev) {
+                c = g_ctl_free[i];
+                g_ctl_free.erase(g_ctl_free.begin() + (long)i);
+                return ACX_OK;
+            }
+    }
+    c.dev = dev;
+    ACX_HIP_TRY(hipHostMalloc((void**)&c.pinned, (size_t)kCtlSlots * C_WORDS * 8, hipHostMallocDefault));
+    for (auto& e : c.ev) ACX_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return ACX_OK;
+}
+static void ctl_host_give(CtlHost& c) {
+    if (!c.pinned) return;
+    std::lock_guard<std::mutex> lock(g_ctl_mutex);
+    g_ctl_free.push_back(c);
+    c = CtlHost();
+}
+
 template <typename W> struct ShardEngine {
     ShardDev<W> d;
     DevBuf nodes_buf, chunk_buf, tab_buf, scal_buf;
@@ -780,13 +823,12 @@ template <typename W> struct ShardEngine {
     // Measured at 1e8 nodes (tools/scratch/shard_env_sweep.py): insert 545 -> 528 us per 2^21-parent chunk, commit 158 -> ~125.
     unsigned insert_wgs = 0, commit_wgs = 0;
     int move_mode = kMoveGeneral;  // acx_bfs.h: set from the root (acx_shard_root_record, which every rank calls)
-    unsigned long long* pinned = nullptr;  // kCtlSlots x C_WORDS
-    hipEvent_t ev[kCtlSlots] = {};
+    CtlHost host;  // pinned snapshot slots + events
 
     ~ShardEngine() {
-        for (auto& e : ev)
-            if (e) (void)hipEventDestroy(e);
-        if (pinned) (void)hipHostFree(pinned);
+        for (auto& e : host.ev)
+            if (e) (void)hipEventSynchronize(e);  // (a snapshot still in flight would land in the next owner's slots)
+        ctl_host_give(host);
     }
 
     int init(int L, int cyclical, int64_t node_cap, int64_t chunk_parents_, int rank_, int world_) {
@@ -835,8 +877,8 @@ template <typename W> struct ShardEngine {
         for (int pass = 0; pass < 2; pass++) {
             uint8_t* b = (uint8_t*)chunk_buf.p;
             o = 0;
-            d.btook = take(b, 12 * chunk_parents + 16);
-            d.brepl = take(b, 12 * chunk_parents + 16);
+            d.btook = take(b, 12 * chunk_parents + 12 * kPackParents + 16);  // (+ a tile of k_shard_pack)
+            d.brepl = take(b, 12 * chunk_parents + 12 * kPackParents + 16);
             flag_bytes = o;
             d.lmask = (int32_t*)take(b, 4 * chunk_parents + 16);
             d.lpre = (uint32_t*)take(b, 4 * chunk_parents + 16);
@@ -862,8 +904,7 @@ template <typename W> struct ShardEngine {
         ACX_HIP_TRY(hipMemcpy(d.ctl + C_MIN_LEN, &inf, 8, hipMemcpyHostToDevice));
         const unsigned long long one = 1;  // len(tree_nodes) counts the root, on every rank
         ACX_HIP_TRY(hipMemcpy(d.ctl + C_NODES_GLOBAL, &one, 8, hipMemcpyHostToDevice));
-        ACX_HIP_TRY(hipHostMalloc((void**)&pinned, (size_t)kCtlSlots * C_WORDS * 8, hipHostMallocDefault));
-        for (auto& e : ev) ACX_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (int rc = ctl_host_take(host)) return rc;
         ACX_HIP_TRY(hipDeviceSynchronize());  // the fills run on the null stream; the engine's calls arrive on the caller's (possibly non-blocking) stream
         return ACX_OK;
     }
@@ -979,7 +1020,7 @@ template <typename W> static int shard_chunk_insert(ShardEngine<W>& E, hipStream
     unsigned gx = tiles;
     if (E.insert_wgs) gx = std::min(tiles, std::max(1u, E.insert_wgs / regions));
     hipLaunchKernelGGL(k_shard_insert<W>, dim3(gx, regions), dim3(256), 0, st, E.d, geo, tiles);
-    hipLaunchKernelGGL(k_shard_pack<W>, dim3(((geo.n_par + 1) / 2 + 255) / 256), dim3(256), 0, st, E.d, geo.n_par);
+    hipLaunchKernelGGL(k_shard_pack<W>, dim3((geo.n_par + kPackParents - 1) / kPackParents), dim3(256), 0, st, E.d, geo.n_par);
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
@@ -1001,14 +1042,14 @@ template <typename W> static int shard_chunk_commit(ShardEngine<W>& E, int64_t m
 }
 
 template <typename W> static int shard_ctl_snapshot(ShardEngine<W>& E, int slot, hipStream_t st) {
-    ACX_HIP_TRY(hipMemcpyAsync(E.pinned + (size_t)slot * C_WORDS, E.d.ctl, C_WORDS * 8, hipMemcpyDeviceToHost, st));
-    ACX_HIP_TRY(hipEventRecord(E.ev[slot], st));
+    ACX_HIP_TRY(hipMemcpyAsync(E.host.pinned + (size_t)slot * C_WORDS, E.d.ctl, C_WORDS * 8, hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipEventRecord(E.host.ev[slot], st));
     return ACX_OK;
 }
 
 template <typename W> static int shard_ctl_wait(ShardEngine<W>& E, int slot, int64_t* out) {
-    ACX_HIP_TRY(hipEventSynchronize(E.ev[slot]));
-    const unsigned long long* p = E.pinned + (size_t)slot * C_WORDS;
+    ACX_HIP_TRY(hipEventSynchronize(E.host.ev[slot]));
+    const unsigned long long* p = E.host.pinned + (size_t)slot * C_WORDS;
     for (int k = 0; k < C_WORDS; k++) out[k] = (int64_t)p[k];
     E.nodes_host = p[C_NODES];  // (the level bounds of the host mirror follow at the next level switch)
     return ACX_OK;
