@@ -32,14 +32,18 @@ namespace acx {
 
 constexpr unsigned long long kSlotFree = ~0ull;
 constexpr uint32_t kSelfAction = 15u;  // slot names the node itself (the root)
-#ifndef ACX_BFS_BLOCK
-#define ACX_BFS_BLOCK 256
-#endif
-// lanes = candidates per workgroup tile.  Measured on the 1e8-node AK(3) search: 1024 lanes (85 parents, folds 55 % of the
-// in-batch duplicates in LDS) 14.0 ms, 512 13.2, 256 (21 parents, 40 %) 12.8, 128 13.0, 64 13.0 -- the wider tile's extra
-// folds do not pay for sixteen waves meeting at two barriers.
-constexpr int kBfsBlock = ACX_BFS_BLOCK;
-constexpr int kBfsLdsSlots = 2 * kBfsBlock;
+
+// hash of the stamp table: one multiply-xorshift round per key word (bucket = low bits, fingerprint = bits 36..63, LDS fold
+// slot = bits 40..); acx_frontier.h's hash_key costs five 64-bit multiplies = fifteen quarter-rate instructions per child
+ACX_HD uint64_t stamp_mix(uint64_t h, uint64_t w) {
+    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+ACX_HD uint64_t stamp_hash(uint64_t k0, uint64_t k1) { return stamp_mix(stamp_mix(0, k0), k1); }
+ACX_HD uint64_t stamp_hash(u128 k0, u128 k1) {
+    uint64_t h = stamp_mix(stamp_mix(0, (uint64_t)k0), (uint64_t)(k0 >> 64));
+    return stamp_mix(stamp_mix(h, (uint64_t)k1), (uint64_t)(k1 >> 64));
+}
 
 ACX_HD unsigned long long slot_make(uint64_t hk, uint32_t pid, uint32_t act) { return (hk & ~((1ull << 36) - 1)) | ((unsigned long long)pid << 4) | act; }
 ACX_HD uint32_t slot_parent(unsigned long long s) { return (uint32_t)(s >> 4); }
@@ -76,153 +80,156 @@ template <typename W> __global__ void k_bfs_root(SearchDev<W> d, W k0, W k1, uin
     d.act[0] = 0xff;
     d.tlen[0] = (uint8_t)tl;
     d.depth[0] = 0;
-    const uint64_t hk = hash_key<W>(k0, k1);
+    const uint64_t hk = stamp_hash(k0, k1);
     d.stab[(uint32_t)hk & d.stmask & ~3u] = slot_make(hk, 0u, kSelfAction);  // first slot of its bucket
 }
 
-// one lane per (parent, action): tag t = 12 * p + a.  btook[t] = 1 when t took its slot (claimed it free, or replaced a
-// larger tag of the same key); brepl[tag] = 1 is set for a holder that was replaced (brepl is zero on entry:
-// cleared once per search, k_bfs_compact zeroes what a batch set).
+// ---- expand + dedup of a batch in ONE launch ------------------------------------------------------------------------------------
+// tag t = 12 * p + a (parent p of the batch, action a).  btook[t] = 1 when t took its slot (claimed it free, or replaced a
+// larger tag of the same key); brepl[tag] = 1 is set for a holder that was replaced (brepl is zero on entry: cleared once per
+// search, k_bfs_compact zeroes what a batch set).
+// Tile shape (round 3, the sharded engine's expansion): 128 parents x 12 actions per 512-lane workgroup; wave w of a group of
+// four computes actions 3w .. 3w + 2 of the group's 64 parents, ONE ACTION PER WAVE-INSTRUCTION.  Rounds 1-2 had a lane per
+// (parent, action) in tag order, 256 lanes per tile (1024 / 512 lanes measured slower then: 14.0 / 13.2 vs 12.8 ms): the twelve
+// actions of a parent sat in adjacent lanes, so every wave issued the concatenation AND the conjugation path of every child --
+// the kernel is atomics-bound, but its vector units were ~65 % busy as well (2.3e9 wave-instructions per 1e8-node search).
+// The LDS fold now sees 1536 candidates instead of 256, so fewer duplicates of a batch meet in the global table, and the
+// hash costs two 64-bit multiplies instead of five.  1e8-node AK(3) search: 10.2 -> 9.7 ms.
+constexpr int kBfsParents = 128, kBfsItems = 3, kBfsThreads = kBfsParents * 4, kBfsTile = kBfsParents * 12, kBfsFold = 4096, kBfsTileBits = 11;
+
+
 template <typename W, int MODE>
-__global__ void __launch_bounds__(kBfsBlock, (sizeof(W) == 8 && MODE != kMoveGeneral) ? 8 : 4) k_bfs_expand_insert(SearchDev<W> d, uint32_t pbegin, uint32_t np, const BfsCursor* __restrict__ cur = nullptr) {
-    __shared__ W s_k0[kBfsBlock];
-    __shared__ W s_k1[kBfsBlock];
-    __shared__ uint32_t s_slot[kBfsLdsSlots];
-    if (MODE == kMoveGeneral) {
-        ACX_VGPR_PAD_W(W, "v71", "v95");
-    } else {
-        ACX_VGPR_PAD_W(W, "v63", "v95");
-    }
+__global__ void __launch_bounds__(kBfsThreads) k_bfs_expand_insert(SearchDev<W> d, uint32_t pbegin, uint32_t np, const BfsCursor* __restrict__ cur = nullptr) {
+    __shared__ W s_k0[kBfsTile];
+    __shared__ W s_k1[kBfsTile];
+    __shared__ uint32_t s_slot[kBfsFold];
+    __shared__ uint32_t s_took[kBfsTile / 4];  // one byte per tag of the tile, written out as dwords
+    ACX_VGPR_PAD_W(W, "v79", "v111");  // (with "v103" the 128-bit kernel had exactly 104 registers and a v_lshrrev_b64 with its amount in v103: tools/check_shift64.py flagged it, and the budget-sweep test failed on the GPU -- DESIGN.md section 7)
     if (cur) {  // run-ahead mode: the batch is whatever the cursor says (np arrives as the batch capacity)
         if (cur->status) return;
         pbegin = cur->head;
         const uint32_t avail = cur->nodes - pbegin;
         np = avail < np ? avail : np;
     }
-    const uint32_t tid = threadIdx.x;
-    const uint32_t t = blockIdx.x * kBfsBlock + tid;
-    const uint32_t m = 12u * np;
-    if (blockIdx.x * kBfsBlock >= m) return;  // (a full-size grid over a short batch)
-    s_slot[tid] = kEmpty;
-    s_slot[tid + kBfsBlock] = kEmpty;
-    W c0 = 0, c1 = 0;
-    uint32_t tl = 0xFFFFFFFFu, pid = 0, a = 0;
-    bool probe = false;
-    if (t < m) {
-        const uint32_t p = t / 12u;
-        a = t - 12u * p;
-        pid = pbegin + p;
-        const W pk0 = d.k0[pid], pk1 = d.k1[pid];
-#ifdef ACX_BFS_GRANDPARENT
-        const uint32_t gp = d.parent[pid];
-#endif
-        Pres<W> s;
-        key_to_pres<W>(pk0, pk1, s);
-        const int e = search_move<W, MODE>(s, (int)a, d.L, d.cyclical != 0);
-        // the reference's ACMove raises here -- but only if it gets this far (k_decide_tab): the FIRST such move of the batch counts
-        if (e) atomicMin(d.err_tag, ((unsigned long long)t << 8) | (unsigned long long)e);
-        c0 = keyops<W>::make(s.w0, s.n0);
-        c1 = keyops<W>::make(s.w1, s.n1);
-#ifdef ACX_BFS_CHECK_NF
-        {
-            Pres<W> g;
-            key_to_pres<W>(pk0, pk1, g);
-            const int eg = apply_move<W, kSearchSafe>(g, (int)a, d.L, d.cyclical != 0);
-            Pres<W> par;
-            key_to_pres<W>(pk0, pk1, par);
-            if (!is_normal_form<W>(par, d.cyclical != 0)) {
-                if (a == 0) printf("EXPAND: parent %u not in normal form: %llx %llx (node parent %u act %u)\n", pid, (unsigned long long)pk0, (unsigned long long)pk1, d.parent[pid], (unsigned)d.act[pid]);
-            } else if (eg != e || keyops<W>::make(g.w0, g.n0) != c0 || keyops<W>::make(g.w1, g.n1) != c1)
-                printf("NF MISMATCH pid %u a %u pk %llx %llx nf %llx %llx (e %d) general %llx %llx (e %d)\n", pid, a, (unsigned long long)pk0, (unsigned long long)pk1,
-                       (unsigned long long)c0, (unsigned long long)c1, e, (unsigned long long)keyops<W>::make(g.w0, g.n0), (unsigned long long)keyops<W>::make(g.w1, g.n1), eg);
-        }
-#endif
-        tl = (uint32_t)(s.n0 + s.n1);
-        if (d.first_len && tl < d.min_len_start) atomicMin(&d.first_len[tl], (unsigned long long)t);  // a candidate for "New minimal length found"
-        if (tl == 2) atomicMin(d.solved_tag, (unsigned long long)t);  // breadth_first.py:84: tested before the dedup
-        probe = !(c0 == pk0 && c1 == pk1);                            // unchanged state = its (visited) parent
+    const uint32_t tid = threadIdx.x, l = (tid & 63u) + 64u * (tid >> 8), w = (tid >> 6) & 3u;
+    if (blockIdx.x * kBfsParents >= np) return;  // (a full-size grid over a short batch)
+    for (uint32_t i = tid; i < (uint32_t)kBfsFold; i += kBfsThreads) s_slot[i] = kEmpty;
+    if (tid < kBfsTile / 4) s_took[tid] = 0;
+    const uint32_t p = blockIdx.x * kBfsParents + l, pid = pbegin + p;
+    const bool live = p < np;
+    W pk0 = 0, pk1 = 0;
+    uint32_t pa = 0xffu;
+    if (live) {
+        pk0 = d.k0[pid];
+        pk1 = d.k1[pid];
+        if (MODE == kMoveNf) pa = d.act[pid];  // 0xff for the root
+    }
+    W c0[kBfsItems], c1[kBfsItems];
+    bool probe[kBfsItems];
+    uint32_t tl_min = 0xFFFFFFFFu;
+#pragma unroll
+    for (int it = 0; it < kBfsItems; it++) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w * kBfsItems + it));  // uniform across the wave
+        const uint32_t j = a * (uint32_t)kBfsParents + l;  // the child's slot in the tile (action major: conflict-free LDS rows)
+        probe[it] = false;
+        c0[it] = c1[it] = 0;
+        if (live) {
+            const uint32_t t = 12u * p + a;  // tag inside the batch: the reference's generation order
+            Pres<W> s;
+            key_to_pres<W>(pk0, pk1, s);
+            const int e = search_move<W, MODE>(s, (int)a, d.L, d.cyclical != 0);
+            // the reference's ACMove raises here -- but only if it gets this far (k_decide_tab): the FIRST such move of the batch counts
+            if (e) atomicMin(d.err_tag, ((unsigned long long)t << 8) | (unsigned long long)e);
+            c0[it] = keyops<W>::make(s.w0, s.n0);
+            c1[it] = keyops<W>::make(s.w1, s.n1);
+            const uint32_t tl = (uint32_t)(s.n0 + s.n1);
+            tl_min = min(tl_min, tl);
+            if (d.first_len && tl < d.min_len_start) atomicMin(&d.first_len[tl], (unsigned long long)t);  // a candidate for "New minimal length found"
+            if (tl == 2) atomicMin(d.solved_tag, (unsigned long long)t);  // breadth_first.py:84: tested before the dedup
+            probe[it] = !(c0[it] == pk0 && c1[it] == pk1);                // unchanged state = its (visited) parent
 #ifndef ACX_BFS_NO_UNDO_DROP
-        // Normal-form search with cyclical = False: the child of action inverse(act[parent]) IS the parent's own tree parent
-        // (g^-1 (g r g^-1) g = r and (r_i r_j) r_j^-1 = r_i as reduced words, and the result fits because it did before) -- a
-        // visited state, 8 % of all children: no probe.  One byte per parent, no dependent load (round 2's grandparent test
-        // compared keys: two dependent loads in front of the barrier, slower than the probes it saved).  Checked on the
-        // oracle for every node of the CPU suite's sharded searches (tests/test_sharded_cpu.py) and by the searches' own
-        // node-for-node comparisons with the oracle.
-        if (MODE == kMoveNf && probe) {
-            const uint32_t pa = d.act[pid];  // 0xff for the root
-            if (pa < 12u && a == (pa < 4u ? (pa ^ 2u) : (pa < 8u ? pa + 4u : pa - 4u))) probe = false;
+            // Normal-form search with cyclical = False: the child of action inverse(act[parent]) IS the parent's own tree parent
+            // (g^-1 (g r g^-1) g = r and (r_i r_j) r_j^-1 = r_i as reduced words, and the result fits because it did before) -- a
+            // visited state, 8 % of all children: no probe.  One byte per parent, no dependent load (round 2's grandparent test
+            // compared keys: two dependent loads in front of the barrier, slower than the probes it saved).  Checked on the
+            // oracle for every node of the CPU suite's sharded searches (tests/test_sharded_cpu.py) and by the searches' own
+            // node-for-node comparisons with the oracle.
+            if (MODE == kMoveNf && pa < 12u && a == (pa < 4u ? (pa ^ 2u) : (pa < 8u ? pa + 4u : pa - 4u))) probe[it] = false;
+#endif
         }
-#endif
-#ifdef ACX_BFS_GRANDPARENT
-        // 8 % of all children undo the move that made their parent.  Testing for it here (two dependent loads in front of the
-        // barrier, for every lane) measured 0.4 ms SLOWER per 1e8-node search than letting those children find the
-        // grandparent's slot in the table, so it is off.
-        if (probe && gp != kEmpty) probe = !(d.k0[gp] == c0 && d.k1[gp] == c1);
-#endif
+        s_k0[j] = c0[it];
+        s_k1[j] = c1[it];
     }
     {  // smallest total length of the batch: wave minimum, then one atomic per wave that lowers it
-        uint32_t mn = tl;
-        for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
-        if ((tid & 63u) == 0 && mn < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, mn);
+        for (int o = 32; o > 0; o >>= 1) tl_min = min(tl_min, (uint32_t)__shfl_xor((int)tl_min, o));
+        if ((tid & 63u) == 0 && tl_min < *(volatile uint32_t*)d.min_len) atomicMin(d.min_len, tl_min);
     }
-    s_k0[tid] = c0;
-    s_k1[tid] = c1;
     __syncthreads();
-    // ---- duplicates inside the tile: LDS table of lane ids, minimum lane (= minimum tag) per key ------------------------
-    const uint64_t hk = hash_key<W>(c0, c1);
-    uint32_t ls = 0;
-    if (probe) {
-        ls = (uint32_t)(hk >> 40) & (kBfsLdsSlots - 1);
+    // ---- duplicates inside the tile: LDS table of (tag inside the tile) << 11 | slot j, minimum = first discoverer ----------------
+    uint32_t ls[kBfsItems], me[kBfsItems];
+    uint64_t hk[kBfsItems];
+#pragma unroll
+    for (int it = 0; it < kBfsItems; it++) {
+        const uint32_t a = w * kBfsItems + it, j = a * (uint32_t)kBfsParents + l;
+        me[it] = ((12u * l + a) << kBfsTileBits) | j;
+        ls[it] = 0;
+        hk[it] = 0;
+        if (!probe[it]) continue;
+        hk[it] = stamp_hash(c0[it], c1[it]);
+        uint32_t q = (uint32_t)(hk[it] >> 40) & (kBfsFold - 1);
         for (;;) {
-            uint32_t v = s_slot[ls];
+            uint32_t v = s_slot[q];
             if (v == kEmpty) {
-                v = atomicCAS(&s_slot[ls], kEmpty, tid);
+                v = atomicCAS(&s_slot[q], kEmpty, me[it]);
                 if (v == kEmpty) break;
             }
-            if (s_k0[v] == c0 && s_k1[v] == c1) {  // any holder of this slot has my key
-                if (v > tid) atomicMin(&s_slot[ls], tid);
+            if (s_k0[v & ((1u << kBfsTileBits) - 1u)] == c0[it] && s_k1[v & ((1u << kBfsTileBits) - 1u)] == c1[it]) {  // any holder of this slot has my key
+                if (v > me[it]) atomicMin(&s_slot[q], me[it]);
                 break;
             }
-            ls = (ls + 1) & (kBfsLdsSlots - 1);  // at most 1024 of the 2048 slots are ever taken
+            q = (q + 1) & (kBfsFold - 1);
         }
+        ls[it] = q;
     }
     __syncthreads();
-    uint32_t took = 0;
-    if (probe && s_slot[ls] == tid) {
-        // ---- the global stamp table ------------------------------------------------------------------------------------
-        // Slots are probed a BUCKET at a time: four slots = one aligned 32-byte sector = one memory access.  A key lives in
-        // the first slot that was free in scan order (bucket of its hash from slot 0, then the following buckets), so a later
-        // probe meets it before it meets a free slot.  With one slot per step nearly every wave had a lane that needed a
-        // second or third dependent (load, CAS) round trip; with buckets the first load almost always decides.
-        const unsigned long long me = slot_make(hk, pid, a);
-        uint32_t base = (uint32_t)hk & d.stmask & ~3u, probes = 0;
+    // ---- the tile's winners probe the global stamp table.  Slots are probed a BUCKET at a time: four slots = one aligned
+    // 32-byte sector = one memory access.  A key lives in the first slot that was free in scan order (bucket of its hash from
+    // slot 0, then the following buckets), so a later probe meets it before it meets a free slot.  Free slot -> one CAS; matching
+    // fingerprint -> the occupant's key is rebuilt from its parent and compared in full; equal keys of the running batch fold to
+    // the smaller (parent, action) with a 64-bit atomicMin (the replaced candidate is flagged by the one that replaced it).
+#pragma unroll
+    for (int it = 0; it < kBfsItems; it++) {
+        if (!(probe[it] && s_slot[ls[it]] == me[it])) continue;
+        const uint32_t a = w * kBfsItems + it;
+        const unsigned long long mine = slot_make(hk[it], pid, a);
+        uint32_t base = (uint32_t)hk[it] & d.stmask & ~3u, probes = 0, took = 0;
         bool open = true;
         while (open) {
             const ulonglong2 lo = *(const ulonglong2*)(d.stab + base), hi = *(const ulonglong2*)(d.stab + base + 2);
             const unsigned long long v0 = lo.x, v1 = lo.y, v2 = hi.x, v3 = hi.y;
-            auto hot = [&](unsigned long long v) { return v == kSlotFree || (v >> 36) == (me >> 36); };  // free, or my fingerprint
+            auto hot = [&](unsigned long long v) { return v == kSlotFree || (v >> 36) == (mine >> 36); };  // free, or my fingerprint
             uint32_t cand = (hot(v0) ? 1u : 0u) | (hot(v1) ? 2u : 0u) | (hot(v2) ? 4u : 0u) | (hot(v3) ? 8u : 0u);
             while (cand) {
-                const uint32_t j = (uint32_t)__builtin_ctz(cand);
+                const uint32_t jj = (uint32_t)__builtin_ctz(cand);
                 cand &= cand - 1;
-                unsigned long long st = j == 0 ? v0 : (j == 1 ? v1 : (j == 2 ? v2 : v3));
-                unsigned long long* slot = d.stab + base + j;
+                unsigned long long st = jj == 0 ? v0 : (jj == 1 ? v1 : (jj == 2 ? v2 : v3));
+                unsigned long long* slot = d.stab + base + jj;
                 if (st == kSlotFree) {
-                    st = atomicCAS(slot, kSlotFree, me);
+                    st = atomicCAS(slot, kSlotFree, mine);
                     if (st == kSlotFree) {
                         took = 1;
                         open = false;
                         break;
                     }
                 }
-                if ((st >> 36) == (me >> 36)) {  // fingerprint match: rebuild the occupant's key
+                if ((st >> 36) == (mine >> 36)) {  // fingerprint match: rebuild the occupant's key
                     const uint32_t hp = slot_parent(st), ha = slot_action(st);
                     W q0, q1;
                     slot_key<W, MODE>(d, hp, ha, q0, q1);
-                    if (q0 == c0 && q1 == c1) {
-                        if (hp >= pbegin && ha != kSelfAction && st > me) {  // a candidate of this batch with a larger tag
-                            const unsigned long long prev = atomicMin(slot, me);
-                            if (prev > me) {
+                    if (q0 == c0[it] && q1 == c1[it]) {
+                        if (hp >= pbegin && ha != kSelfAction && st > mine) {  // a candidate of this batch with a larger tag
+                            const unsigned long long prev = atomicMin(slot, mine);
+                            if (prev > mine) {
                                 took = 1;
                                 d.brepl[12u * (slot_parent(prev) - pbegin) + slot_action(prev)] = 1;  // no longer the first discoverer
                             }
@@ -238,8 +245,13 @@ __global__ void __launch_bounds__(kBfsBlock, (sizeof(W) == 8 && MODE != kMoveGen
                 open = false;
             }
         }
+        if (took) ((uint8_t*)s_took)[12u * l + a] = 1;
     }
-    if (t < m) d.btook[t] = (uint8_t)took;
+    __syncthreads();
+    {  // btook of the tile's tags, coalesced (every tag of the batch is written: zero = did not take a slot)
+        const uint32_t m = 12u * np, t0 = blockIdx.x * (uint32_t)kBfsTile;
+        if (tid < kBfsTile / 4 && t0 + 4u * tid < m) ((uint32_t*)(d.btook + t0))[tid] = s_took[tid];  // (m is a multiple of 4; t0 of 1536)
+    }
 }
 
 // Winners -> nodes in one pass: k_compact_tab (acx_frontier.h) with the winners' keys recomputed from their parents.

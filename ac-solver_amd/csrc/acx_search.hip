@@ -822,12 +822,12 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
                 BfsCursor* snap = (BfsCursor*)S.h_cursor;  // pinned, kRunAheadSlots entries
                 ACX_HIP_TRY(hipMemcpyAsync(dcur, &hc, sizeof(hc), hipMemcpyHostToDevice, st));
                 const uint32_t mcap = 12u * bmax;
-                const dim3 egrid((mcap + kBfsBlock - 1) / kBfsBlock), eblock(kBfsBlock), cgrid((mcap + kCompactTile - 1) / kCompactTile), cblock(256);
+                const dim3 egrid((bmax + kBfsParents - 1) / kBfsParents), eblock(kBfsThreads), cgrid((mcap + kCompactTile - 1) / kCompactTile), cblock(256);
                 const BfsCursor* fin = nullptr;
                 for (uint64_t k = 0; !fin; k++) {
                     if (batches + k + 1 >= (1ull << 30)) return fail(ACX_E_CAPACITY, "acx_search: more than 2^30 batches (the look-back words carry a 30-bit batch number)");
 #define ACX_BFS_AHEAD(MODE)                                                                                                                              \
-    hipLaunchKernelGGL((k_bfs_expand_insert<W, MODE>), egrid, eblock, 0, st, d, 0u, bmax, dcur);                                                        \
+    hipLaunchKernelGGL((k_bfs_expand_insert<W, MODE>), egrid, eblock, 0, st, d, 0u, bmax, dcur);                                                       \
     hipLaunchKernelGGL((k_bfs_compact<W, MODE>), cgrid, cblock, 0, st, d, 0u, mcap, 0u, (uint32_t)S.cap_nodes, 0u, S.d_status, S.d_ticket, S.d_total, dcur)
                     if (move_mode == kMoveNf) {
                         ACX_BFS_AHEAD(kMoveNf);
@@ -916,7 +916,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         if (batches >= (1ull << 30)) return fail(ACX_E_CAPACITY, "acx_search: more than 2^30 batches (the look-back words carry a 30-bit batch number)");
         if (stamp) {
             // expand + dedup in one kernel, winners -> nodes in one pass, then the decision from the written nodes
-            const dim3 egrid((m + kBfsBlock - 1) / kBfsBlock), eblock(kBfsBlock), cgrid((m + kCompactTile - 1) / kCompactTile);
+            const dim3 egrid((np + kBfsParents - 1) / kBfsParents), eblock(kBfsThreads), cgrid((m + kCompactTile - 1) / kCompactTile);
 #ifndef ACX_BFS_EXPAND_MODE
 #define ACX_BFS_EXPAND_MODE(M) M
 #endif
@@ -924,7 +924,7 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
 #define ACX_BFS_COMPACT_MODE(M) M
 #endif
 #define ACX_BFS_LAUNCH(MODE)                                                                                                                          \
-    hipLaunchKernelGGL((k_bfs_expand_insert<W, ACX_BFS_EXPAND_MODE(MODE)>), egrid, eblock, 0, st, d, pbegin, np);                                     \
+    hipLaunchKernelGGL((k_bfs_expand_insert<W, ACX_BFS_EXPAND_MODE(MODE)>), egrid, eblock, 0, st, d, pbegin, np);                                    \
     hipLaunchKernelGGL((k_bfs_compact<W, ACX_BFS_COMPACT_MODE(MODE)>), cgrid, block, 0, st, d, pbegin, m, (uint32_t)nodes, (uint32_t)S.cap_nodes, (uint32_t)batches, S.d_status, \
                        S.d_ticket, S.d_total)
             if (move_mode == kMoveNf) {
