@@ -27,6 +27,10 @@ constexpr int kBmT = ACX_BFS_MULTI_THREADS;  // lanes of the workgroup
 // 8-wave workgroups share a CU (the 1190 Miller-Schupp searches: 0.26 s; 1024 x 1, one workgroup per CU: 0.33 s; 512 x 2:
 // 0.28 s; 512 x 4 needs more registers than two workgroups get: 0.33 s).  More children per lane lengthen the chunk (the
 // probes of a lane run one after the other), fewer leave lanes idle.
+// Round 3 tried the lane layout of k_bfs_expand_insert here (lane = parent, one action per wave-instruction, children in
+// registers, the two-multiply hash): 0.24-0.30 s against 0.26-0.28 s -- a sweep is bound by the chain of memory round trips
+// per chunk, not by vector issue, and the 128-bit searches then need more than the 128 registers that let two workgroups
+// share a compute unit.  Not adopted.
 #ifndef ACX_BFS_MULTI_ITEMS
 #define ACX_BFS_MULTI_ITEMS 3
 #endif
@@ -34,7 +38,8 @@ template <typename W> struct bm_cfg {
     static constexpr int kItems = ACX_BFS_MULTI_ITEMS;
     static constexpr int kCand = kBmT * kItems;
     static constexpr int kParents = kCand / 12;
-    static constexpr int kLds = 2 * kCand;  // LDS fold table
+    static constexpr int kLds = kCand <= 1024 ? 2048 : (kCand <= 2048 ? 4096 : 8192);  // LDS fold table: a POWER OF TWO >= 2 x the chunk (2 * kCand = 3072
+                                                                                        // made `& (kLds - 1)` two separate 1024-slot tables)
 };
 constexpr int kBmMaxParents = 170;  // upper bound of the chunk size over the build variants (sizes the node arenas)
 
@@ -59,6 +64,7 @@ struct BfsOut {
     uint32_t status, nodes, min_len, err;
     uint32_t path_n, pad_;
     unsigned long long expanded, batches;
+    unsigned long long t_phase[6];  // -DACX_BFS_MULTI_PROFILE=1: shader-clock cycles of lane 0 in expand, fold, table, number + decide, commit, tail
 };
 
 // node-arena reads bypass the vector L1: the nodes were written by other waves of this workgroup
@@ -68,8 +74,14 @@ __device__ __forceinline__ u128 ld_l2(const u128* p) {
     return ((u128)ld_l2(q + 1) << 64) | ld_l2(q);
 }
 
+#ifndef ACX_BFS_MULTI_PROFILE
+#define ACX_BFS_MULTI_PROFILE 0
+#endif
+#ifndef ACX_BFS_MULTI_WAVES
+#define ACX_BFS_MULTI_WAVES 1
+#endif
 template <typename W, int MODE>
-__global__ void __launch_bounds__(kBmT) k_bfs_multi(const BfsJob<W>* __restrict__ jobs, BfsOut* __restrict__ outs, int32_t* __restrict__ path_act,
+__global__ void __launch_bounds__(kBmT, ACX_BFS_MULTI_WAVES) k_bfs_multi(const BfsJob<W>* __restrict__ jobs, BfsOut* __restrict__ outs, int32_t* __restrict__ path_act,
                                                     int32_t* __restrict__ path_len, long long path_cap) {
     constexpr int kBmItems = bm_cfg<W>::kItems, kBmCand = bm_cfg<W>::kCand, kBmParents = bm_cfg<W>::kParents, kBmLds = bm_cfg<W>::kLds;
     __shared__ W s_k0[kBmCand];
@@ -86,6 +98,12 @@ __global__ void __launch_bounds__(kBmT) k_bfs_multi(const BfsJob<W>* __restrict_
     const BfsJob<W> g = jobs[blockIdx.x];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     unsigned long long expanded = 0, batches = 0;
+#if ACX_BFS_MULTI_PROFILE
+    unsigned long long tph[6] = {}, tc = clock64();
+#define ACX_BM_TICK(k) do { const unsigned long long now__ = clock64(); tph[k] += now__ - tc; tc = now__; } while (0)
+#else
+#define ACX_BM_TICK(k) do { } while (0)
+#endif
     if (tid == 0) {
         g.k0[0] = g.root_k0;
         g.k1[0] = g.root_k1;
@@ -148,6 +166,7 @@ __global__ void __launch_bounds__(kBmT) k_bfs_multi(const BfsJob<W>* __restrict_
         for (int o = 32; o > 0; o >>= 1) tl_min = min(tl_min, (uint32_t)__shfl_xor((int)tl_min, o));
         if (lane == 0 && tl_min < s_min_len) atomicMin(&s_min_len, tl_min);
         __syncthreads();
+        ACX_BM_TICK(0);
         // ---- duplicates inside the chunk: LDS table of candidate numbers, minimum (= first discoverer) per key
         uint32_t ls[kBmItems];
 #pragma unroll
@@ -172,7 +191,12 @@ __global__ void __launch_bounds__(kBmT) k_bfs_multi(const BfsJob<W>* __restrict_
             ls[it] = q;
         }
         __syncthreads();
+        ACX_BM_TICK(1);
         // ---- the chunk's distinct keys against the visited table: seen before, or one CAS ----------------------------------------
+        // (54 % of a chunk's 22 us, -DACX_BFS_MULTI_PROFILE=1.  Taking the first turn of a lane's three candidates together --
+        // bucket loads, then claims, issued before the first result is used -- changed nothing: the phase lasts as long as the
+        // slowest of the workgroup's ~1000 probes, and at a load factor of 0.5 some lane always needs a second bucket or the
+        // key of an occupant.)
         uint32_t win[kBmItems];
 #pragma unroll
         for (int it = 0; it < kBmItems; it++) {
@@ -236,6 +260,7 @@ __global__ void __launch_bounds__(kBmT) k_bfs_multi(const BfsJob<W>* __restrict_
             if (lane == 0) s_wsum[it * (kBmT / 64) + wave] = (uint32_t)__popcll(b);
         }
         __syncthreads();
+        ACX_BM_TICK(2);
         uint32_t total = 0;
         {
             uint32_t before[kBmItems] = {};
@@ -272,6 +297,7 @@ __global__ void __launch_bounds__(kBmT) k_bfs_multi(const BfsJob<W>* __restrict_
         const bool err_hit = et != ~0ull && (uint32_t)((et >> 8) / 12u) <= p_end && !(is_solved && (unsigned long long)stag < (et >> 8));
         if (err_hit) is_solved = false;
         const uint32_t cutoff = is_solved ? stag : 12u * (p_end + 1);
+        ACX_BM_TICK(3);
         // ---- commit the new states below the cutoff --------------------------------------------------------------------------
 #pragma unroll
         for (int it = 0; it < kBmItems; it++) {
@@ -292,6 +318,7 @@ __global__ void __launch_bounds__(kBmT) k_bfs_multi(const BfsJob<W>* __restrict_
         batches++;
         expanded += is_solved ? stag / 12u + 1 : p_end + 1;
         __syncthreads();  // (also: the nodes written above are in L2 before anybody reads them in the next chunk)
+        ACX_BM_TICK(4);
         if (tid == 0) {
             s_nodes = nodes + s_committed;
             s_head = head + p_end + 1;
@@ -310,8 +337,10 @@ __global__ void __launch_bounds__(kBmT) k_bfs_multi(const BfsJob<W>* __restrict_
         }
         if (err_hit) err_code = (uint32_t)(et & 0xff);
         __syncthreads();
+        ACX_BM_TICK(5);
         if (s_status != BFS_RUNNING) break;
     }
+#undef ACX_BM_TICK
     __syncthreads();
     if (tid == 0) {
         BfsOut* out = outs + blockIdx.x;
@@ -321,6 +350,9 @@ __global__ void __launch_bounds__(kBmT) k_bfs_multi(const BfsJob<W>* __restrict_
         out->err = err_code;
         out->expanded = expanded;
         out->batches = batches;
+#if ACX_BFS_MULTI_PROFILE
+        for (int k = 0; k < 6; k++) out->t_phase[k] = tph[k];
+#endif
         out->path_n = 0;
         if (s_status == BFS_SOLVED) {  // path of the parent + (action, 2)
             uint32_t v = solved_parent;

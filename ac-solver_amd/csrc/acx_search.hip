@@ -555,6 +555,18 @@ static int run_bfs_group(const int8_t* rows, int64_t n, int L, int64_t max_nodes
     ACX_HIP_TRY(hipStreamSynchronize(st));
     float ms = 0;
     ACX_HIP_TRY(hipEventElapsedTime(&ms, evs.a, evs.b));
+    if (getenv("ACX_DEBUG")) {  // -DACX_BFS_MULTI_PROFILE=1 builds: where a chunk's time goes, summed over the group's searches
+        unsigned long long tp[6] = {}, tot = 0, chunks = 0;
+        for (int64_t j = 0; j < n; j++) {
+            for (int q = 0; q < 6; q++) tp[q] += o[(size_t)j].t_phase[q];
+            chunks += o[(size_t)j].batches;
+        }
+        for (int q = 0; q < 6; q++) tot += tp[q];
+        if (tot)
+            fprintf(stderr, "[acx_bfs_multi] %lld searches, %llu chunks, %.0f cycles per chunk: expand %.1f %% fold %.1f table %.1f number+decide %.1f commit %.1f tail %.1f; group %.2f ms\n",
+                    (long long)n, chunks, (double)tot / (double)(chunks ? chunks : 1), 100.0 * tp[0] / tot, 100.0 * tp[1] / tot, 100.0 * tp[2] / tot, 100.0 * tp[3] / tot,
+                    100.0 * tp[4] / tot, 100.0 * tp[5] / tot, ms);
+    }
     for (int64_t j = 0; j < n; j++) {
         const int64_t k = slot_of[(size_t)j];
         const BfsOut& r = o[(size_t)j];
