@@ -254,124 +254,125 @@ __global__ void __launch_bounds__(kBfsThreads) k_bfs_expand_insert(SearchDev<W> 
     }
 }
 
-// Winners -> nodes in one pass: k_compact_tab (acx_frontier.h) with the winners' keys recomputed from their parents.
-template <typename W, int MODE>
-__global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pbegin, uint32_t m, uint32_t base, uint32_t cap_nodes, uint32_t epoch,
-                                                     unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t* __restrict__ total_out,
-                                                     const BfsCursor* __restrict__ cur = nullptr) {
-    __shared__ uint32_t s_tile, s_prefix, s_wsum[4];
-    __shared__ uint16_t s_list[kCompactTile];
-#ifdef ACX_HAZARD_REPRO  // tools/hazard24/repro_compact.sh: the kernel as it was when it corrupted (exactly the 32 registers it uses)
-    asm volatile("" ::: "v31");
+// Winners -> nodes, in TWO launches since round 3:
+//   k_bfs_count    a tile of 8192 candidates per workgroup: the took / replaced flags -> one winner bit per candidate (32 per lane,
+//                  kept in `masks`) and the tile's winner count; zeroes the replaced-flags it read
+//   k_bfs_compact  position of a tile's first winner = sum of the counts of ALL earlier tiles (256 at a time, independent loads),
+//                  then the nodes in tag order, the winners' keys recomputed from their parents.
+// Rounds 1-2 did this in one launch (k_compact_tab's scheme: a ticket per tile, decoupled look-back over status words).  Its
+// own clock (-DACX_COMPACT_PROFILE) showed where the 58 us per 2^20-parent batch went: the ~1500 same-address returning
+// atomics of the tickets take 18 us, and every memory access of the kernel crawls while they last (a tile that had its ticket
+// after 1 us saw its 32 KB of flags after 20 us); then 8 us of look-back, then 22 us of node writes at ~3 TB/s.
+#ifdef ACX_COMPACT_PROFILE
+#define ACX_CP_DECL unsigned long long tp[4] = {}, tc0 = clock64()
+#define ACX_CP_TICK(k) do { tp[k] = clock64() - tc0; } while (0)
 #else
-    ACX_VGPR_PAD_W(W, "v47", "v63");
+#define ACX_CP_DECL do { } while (0)
+#define ACX_CP_TICK(k) do { } while (0)
 #endif
+
+template <typename W>
+__global__ void __launch_bounds__(256) k_bfs_count(SearchDev<W> d, uint32_t m, uint32_t* __restrict__ counts, uint32_t* __restrict__ masks, const BfsCursor* __restrict__ cur = nullptr) {
+    __shared__ uint32_t s_wsum[4];
+    ACX_VGPR_PAD("v31");
+    static_assert(kCompactItems == 32, "two 16-candidate halves per lane");
+    if (cur) {  // run-ahead mode (m arrives as the capacity 12 * bmax)
+        if (cur->status) return;
+        const uint32_t avail = 12u * (cur->nodes - cur->head);
+        m = avail < m ? avail : m;
+    }
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tile >= (m + kCompactTile - 1) / kCompactTile) return;  // a full-size grid over a short batch
+    // A lane takes 16 consecutive candidates of each half of the tile (bits 0..15 / 16..31 of fl): its flags are two 16-byte loads
+    // per array and the wave reads 1 KB per instruction.
+    uint32_t fl = 0;  // bit i < 16: candidate 16 tid + i of the tile; bit 16 + i: candidate kCompactTile / 2 + 16 tid + i -- a winner (took its slot and was not replaced)
+#pragma unroll
+    for (uint32_t h = 0; h < 2; h++) {
+        const uint32_t c0 = tile * kCompactTile + h * (kCompactTile / 2) + 16u * tid;
+        if (c0 + 16u <= m) {
+            const uint4 tb = *(const uint4*)(d.btook + c0), rb = *(const uint4*)(d.brepl + c0);
+            if (rb.x | rb.y | rb.z | rb.w) *(uint4*)(d.brepl + c0) = make_uint4(0, 0, 0, 0);  // zero again for the next batch (no memset launch per batch)
+            auto squeeze = [](uint32_t v) { return (v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u); };  // bytes are 0 / 1
+            fl |= (squeeze(tb.x & ~rb.x) | (squeeze(tb.y & ~rb.y) << 4) | (squeeze(tb.z & ~rb.z) << 8) | (squeeze(tb.w & ~rb.w) << 12)) << (16u * h);
+        } else {
+            for (uint32_t i = 0; i < 16u; i++)
+                if (c0 + i < m) {
+                    const uint8_t rb = d.brepl[c0 + i];
+                    if (rb) d.brepl[c0 + i] = 0;
+                    if (d.btook[c0 + i] && !rb) fl |= 1u << (16u * h + i);
+                }
+        }
+    }
+    masks[tile * 256u + tid] = fl;
+    uint32_t cnt = (uint32_t)__popc(fl & 0xFFFFu) | ((uint32_t)__popc(fl >> 16) << 16);  // both halves in one word (<= 4096 each)
+    for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
+    if (lane == 0) s_wsum[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) counts[tile] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+}
+
+template <typename W, int MODE>
+__global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pbegin, uint32_t m, uint32_t base, uint32_t cap_nodes, const uint32_t* __restrict__ counts,
+                                                     const uint32_t* __restrict__ masks, uint32_t* __restrict__ total_out, const BfsCursor* __restrict__ cur = nullptr) {
+    __shared__ uint32_t s_wsum[4], s_psum[4];
+    __shared__ uint16_t s_list[kCompactTile];
+    ACX_VGPR_PAD_W(W, "v47", "v63");
     if (cur) {  // run-ahead mode (m arrives as the capacity 12 * bmax)
         if (cur->status) return;
         pbegin = cur->head;
         const uint32_t avail = 12u * (cur->nodes - pbegin);
         m = avail < m ? avail : m;
         base = cur->nodes;
-        epoch = cur->batches + 1;
     }
-    if (blockIdx.x >= (m + kCompactTile - 1) / kCompactTile) return;  // a full-size grid over a short batch: only the batch's tiles take tickets
+    const uint32_t ntiles = (m + kCompactTile - 1) / kCompactTile, tile = blockIdx.x;
+    if (tile >= ntiles) return;  // a full-size grid over a short batch
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint32_t tile = s_tile, ntiles = (m + kCompactTile - 1) / kCompactTile;
-    const uint32_t t0 = tile * kCompactTile + tid * kCompactItems;
-    uint32_t fl = 0;  // bit i: candidate t0 + i is a winner (took its slot and was not replaced)
-    if (t0 + kCompactItems <= m) {
-#pragma unroll
-        for (uint32_t q = 0; q < kCompactItems / 8; q++) {
-            const unsigned long long tb = *(const unsigned long long*)(d.btook + t0 + 8 * q), rb = *(const unsigned long long*)(d.brepl + t0 + 8 * q);
-            if (rb) *(unsigned long long*)(d.brepl + t0 + 8 * q) = 0;  // zero again for the next batch (no memset launch per batch)
-            const unsigned long long w = tb & ~rb;  // bytes are 0 / 1
-#pragma unroll
-            for (uint32_t i = 0; i < 8; i++) fl |= (uint32_t)((w >> (8u * i)) & 1ull) << (8 * q + i);
-        }
-    } else {
-        for (uint32_t i = 0; i < kCompactItems; i++)
-            if (t0 + i < m) {
-                const uint8_t rb = d.brepl[t0 + i];
-                if (rb) d.brepl[t0 + i] = 0;
-                if (d.btook[t0 + i] && !rb) fl |= 1u << i;
-            }
+    ACX_CP_DECL;
+    const uint32_t fl = masks[tile * 256u + tid];
+    uint32_t part = 0;  // winners of all earlier tiles: their counts, 256 at a time
+    for (uint32_t j = tid; j < tile; j += 256) {
+        const uint32_t c = counts[j];
+        part += (c & 0xFFFFu) + (c >> 16);
     }
-    const uint32_t cnt = (uint32_t)__popc(fl);
+    for (int o = 32; o > 0; o >>= 1) part += (uint32_t)__shfl_xor((int)part, o);
+    // positions in tag order: the first halves of all lanes, then the second halves; both scans in one (counts <= 4096 fit 16 bits)
+    const uint32_t cnt = (uint32_t)__popc(fl & 0xFFFFu) | ((uint32_t)__popc(fl >> 16) << 16);
     uint32_t incl = cnt;
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
         if (lane >= (uint32_t)o) incl += v;
     }
     if (lane == 63) s_wsum[wave] = incl;
+    if (lane == 0) s_psum[wave] = part;
     __syncthreads();
+    ACX_CP_TICK(0);
     uint32_t wbase = 0;
     for (uint32_t w = 0; w < wave; w++) wbase += s_wsum[w];
-    const uint32_t block_total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    const uint32_t both_total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    const uint32_t first_total = both_total & 0xFFFFu, block_total = first_total + (both_total >> 16);
+    const uint32_t excl = s_psum[0] + s_psum[1] + s_psum[2] + s_psum[3];
+    if (tid == 0 && tile == ntiles - 1) *total_out = excl + block_total;
     {
-        uint32_t pos = wbase + incl - cnt, f = fl;
+        const uint32_t before = wbase + incl - cnt;
+        uint32_t pos = before & 0xFFFFu, f = fl & 0xFFFFu;
         while (f) {
             const uint32_t i = (uint32_t)__builtin_ctz(f);
             f &= f - 1;
-            s_list[pos++] = (uint16_t)(tid * kCompactItems + i);
+            s_list[pos++] = (uint16_t)(16u * tid + i);
         }
-    }
-    if (wave == 0) {  // decoupled look-back over the tiles' status words (see k_compact_tab)
-        const unsigned long long tagged = (unsigned long long)epoch << 34;
-        if (lane == 0)
-            __hip_atomic_store(&status[tile], tagged | ((tile == 0 ? kTileIncl : kTileAgg) << 32) | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t excl = 0;
-        long long j0 = (long long)tile - 1;
-        while (j0 >= 0) {
-            const long long j = j0 - (long long)lane;
-            unsigned long long w = tagged | (kTileIncl << 32);
-            for (;;) {
-                if (j >= 0) w = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool ready = (w >> 34) == (unsigned long long)epoch && ((w >> 32) & 3ull) != 0;
-                if (__all(ready)) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            const unsigned long long inc = __ballot(((w >> 32) & 3ull) == kTileIncl);
-            const uint32_t first = inc ? (uint32_t)__builtin_ctzll(inc) : 63u;
-            uint32_t v = lane <= first ? (uint32_t)w : 0u;
-            for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-            excl += v;
-            if (inc) break;
-            j0 -= 64;
-        }
-        if (lane == 0) {
-            if (tile != 0) __hip_atomic_store(&status[tile], tagged | (kTileIncl << 32) | (excl + block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_prefix = excl;
-            if (tile == ntiles - 1) {
-                *total_out = excl + block_total;
-                *ticket = 0;
-            }
+        pos = first_total + (before >> 16);
+        f = fl >> 16;
+        while (f) {
+            const uint32_t i = (uint32_t)__builtin_ctz(f);
+            f &= f - 1;
+            s_list[pos++] = (uint16_t)(kCompactTile / 2 + 16u * tid + i);
         }
     }
     __syncthreads();
-    const uint32_t first_id = base + s_prefix, tbase = tile * kCompactTile;
-#ifdef ACX_HAZARD_REPRO
-    // the write loop of commit 57c6f83 (one winner per lane and round), kept verbatim for the reproducer of DESIGN.md section 7
-    for (uint32_t j = tid; j < block_total; j += 256) {
-        const uint32_t id = first_id + j;
-        if (id >= cap_nodes) break;  // beyond the budget: never read
-        const uint32_t t = tbase + s_list[j];
-        const uint32_t p = t / 12u, pid = pbegin + p, a = t - 12u * p;
-        Pres<W> s;
-        key_to_pres<W>(d.k0[pid], d.k1[pid], s);
-        (void)search_move<W, MODE>(s, (int)a, d.L, d.cyclical != 0);
-        d.k0[id] = keyops<W>::make(s.w0, s.n0);
-        d.k1[id] = keyops<W>::make(s.w1, s.n1);
-        d.parent[id] = pid;
-        d.act[id] = (uint8_t)a;
-        d.tlen[id] = (uint8_t)(s.n0 + s.n1);
-        d.depth[id] = d.depth[pid] + 1;
-    }
-#else
+    ACX_CP_TICK(1);
+    const uint32_t first_id = base + excl, tbase = tile * kCompactTile;
     // kU winners per lane and round: their parent keys and depths are loaded together, then the moves, then the stores
-    // (kU = 4 -- one memory round trip for four nodes -- measured no faster than 1 on the 1e8-node search: the pass is not
-    // bound by this loop's latency; 1 keeps the kernel at 36 registers)
+    // (kU = 4 -- one memory round trip for four nodes -- measured no faster than 1: the writes run at ~3 TB/s either way)
 #ifndef ACX_COMPACT_UNROLL
 #define ACX_COMPACT_UNROLL 1
 #endif
@@ -418,7 +419,13 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
             d.depth[id] = dep[u] + 1;
         }
     }
+#ifdef ACX_COMPACT_PROFILE
+    ACX_CP_TICK(2);
+    if (tid == 0 && ntiles > 1000 && (tile % 300u) == 7u)
+        printf("[compact] tile %u of %u: winners %u; cycles to: prefix + scan %llu, list %llu, nodes written %llu\n", tile, ntiles, block_total, tp[0], tp[1], tp[2]);
 #endif
 }
+#undef ACX_CP_DECL
+#undef ACX_CP_TICK
 
 }  // namespace acx

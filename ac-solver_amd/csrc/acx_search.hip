@@ -95,6 +95,8 @@ template <typename W> struct Searcher {
     hipStream_t st_copy = nullptr;  // the cursor snapshots travel on a stream of their own: a copy queued on `st` sits between two batches (10 us)
     unsigned long long h_first[kFirstLen];
     unsigned long long* d_status = nullptr;  // one-pass BFS commit: per-tile look-back words
+    uint32_t* d_counts = nullptr;            // stamp-table BFS: winners per tile (k_bfs_count -> k_bfs_compact) ...
+    uint32_t* d_masks = nullptr;             // ... and one winner bit per candidate
     uint32_t* d_ticket = nullptr;
     uint32_t* d_total = nullptr;
     size_t tmp_bytes = 0;
@@ -226,9 +228,13 @@ template <typename W> struct Searcher {
         ACX_HIP_TRY(hipMemsetAsync(d_ticket, 0, 8, st));
         if (inline_tab || stamp_tab) {  // status words of k_compact_tab / k_bfs_compact: epoch 0 = never written
             const size_t tiles = cap_cand / kCompactTile + 2;
-            if (arena_status.alloc(tiles * 8)) return ACX_E_NOMEM;
+            if (arena_status.alloc(tiles * 8 + (stamp_tab ? tiles * (4 + 1024) : 0))) return ACX_E_NOMEM;
             d_status = (unsigned long long*)arena_status.p;
             ACX_HIP_TRY(hipMemsetAsync(d_status, 0, tiles * 8, st));
+            if (stamp_tab) {
+                d_counts = (uint32_t*)(d_status + tiles);
+                d_masks = d_counts + tiles;
+            }
         }
         return ACX_OK;
     }
@@ -840,7 +846,8 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
                     if (batches + k + 1 >= (1ull << 30)) return fail(ACX_E_CAPACITY, "acx_search: more than 2^30 batches (the look-back words carry a 30-bit batch number)");
 #define ACX_BFS_AHEAD(MODE)                                                                                                                              \
     hipLaunchKernelGGL((k_bfs_expand_insert<W, MODE>), egrid, eblock, 0, st, d, 0u, bmax, dcur);                                                       \
-    hipLaunchKernelGGL((k_bfs_compact<W, MODE>), cgrid, cblock, 0, st, d, 0u, mcap, 0u, (uint32_t)S.cap_nodes, 0u, S.d_status, S.d_ticket, S.d_total, dcur)
+    hipLaunchKernelGGL(k_bfs_count<W>, cgrid, cblock, 0, st, d, mcap, S.d_counts, S.d_masks, dcur);                                                      \
+    hipLaunchKernelGGL((k_bfs_compact<W, MODE>), cgrid, cblock, 0, st, d, 0u, mcap, 0u, (uint32_t)S.cap_nodes, S.d_counts, S.d_masks, S.d_total, dcur)
                     if (move_mode == kMoveNf) {
                         ACX_BFS_AHEAD(kMoveNf);
                     } else if (move_mode == kMoveNfCyclical) {
@@ -937,8 +944,8 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
 #endif
 #define ACX_BFS_LAUNCH(MODE)                                                                                                                          \
     hipLaunchKernelGGL((k_bfs_expand_insert<W, ACX_BFS_EXPAND_MODE(MODE)>), egrid, eblock, 0, st, d, pbegin, np);                                    \
-    hipLaunchKernelGGL((k_bfs_compact<W, ACX_BFS_COMPACT_MODE(MODE)>), cgrid, block, 0, st, d, pbegin, m, (uint32_t)nodes, (uint32_t)S.cap_nodes, (uint32_t)batches, S.d_status, \
-                       S.d_ticket, S.d_total)
+    hipLaunchKernelGGL(k_bfs_count<W>, cgrid, block, 0, st, d, m, S.d_counts, S.d_masks);                                                             \
+    hipLaunchKernelGGL((k_bfs_compact<W, ACX_BFS_COMPACT_MODE(MODE)>), cgrid, block, 0, st, d, pbegin, m, (uint32_t)nodes, (uint32_t)S.cap_nodes, S.d_counts, S.d_masks, S.d_total)
             if (move_mode == kMoveNf) {
                 ACX_BFS_LAUNCH(kMoveNf);
             } else if (move_mode == kMoveNfCyclical) {
