@@ -92,13 +92,13 @@ SIGNATURES = {
     "acx_search_many": (C.c_int, [C.c_int, _i8p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, _i32p, _i32p, _i32p, C.c_int64, _i64p,
                                C.POINTER(SearchStats), _i32p]),
     "acx_shard_key_words": (C.c_int, [C.c_int]),
-    "acx_shard_layout": (C.c_int, [C.c_int64, C.c_int, C.c_int, _i64p, _i64p, _i64p]),
+    "acx_shard_layout": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, _i64p, _i64p, _i64p]),
     "acx_shard_create": (_vp, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "acx_shard_destroy": (None, [_vp]),
     "acx_shard_attach": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
     "acx_shard_root_record": (C.c_int, [_vp, _i8p, _i64p]),
     "acx_shard_seed": (C.c_int, [_vp, _i64p, _vp]),
-    "acx_shard_chunk_expand": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, _i64p, _i64p, _vp]),
+    "acx_shard_chunk_expand": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, C.c_int, _i64p, _i64p, _vp]),
     "acx_shard_chunk_insert": (C.c_int, [_vp, _vp]),
     "acx_shard_chunk_commit": (C.c_int, [_vp, C.c_int64, _vp]),
     "acx_shard_ctl_snapshot": (C.c_int, [_vp, C.c_int, _vp]),

@@ -43,7 +43,8 @@ _ID_MASK = (1 << 40) - 1
 # control block words (include/acx.h: ACX_SHARD_CTL_*)
 CTL_WORDS = 16
 CTL_STATUS, CTL_NODES_GLOBAL, CTL_NEXT_COUNT, CTL_EXPANDED, CTL_SOLVED_TAG, CTL_NODES = 0, 1, 2, 3, 4, 5
-CTL_FAIL_LOCAL, CTL_MIN_LEN, CTL_FAIL_SEEN = 8, 9, 10
+CTL_FAIL_LOCAL, CTL_MIN_LEN, CTL_FAIL_SEEN, CTL_LEVEL_FILL = 8, 9, 10, 12
+FILL_DEFAULT = 320  # region capacity in 1/256 of the even share of all children: 1.25 x, safe for any input (acx_shard_layout)
 ST_RUNNING, ST_SOLVED, ST_BUDGET, ST_MOVE_ERROR, ST_FAILED = 0, 1, 2, 3, 4
 _FAIL_TEXT = {1: "a send region or the record log overflowed", 2: "node capacity exceeded", 3: "visited table full", 4: "engine call failed"}
 
@@ -141,13 +142,13 @@ class HipShardEngine:
         self._acx.check(self._acx.lib.acx_shard_attach(self.h, self.log.data_ptr(), self.log.numel(), self.send.data_ptr() if self.send is not None else None,
                                                        self.send.numel() if self.send is not None else 0, self.gmask.data_ptr()), "acx_shard_attach")
 
-    def layout(self, n_par):
+    def layout(self, n_par, fill_q8=0):
         s, cap, rw = C.c_int64(), C.c_int64(), C.c_int64()
-        self._acx.check(self._acx.lib.acx_shard_layout(int(n_par), self.world, self.KW, C.byref(s), C.byref(cap), C.byref(rw)), "acx_shard_layout")
+        self._acx.check(self._acx.lib.acx_shard_layout(int(n_par), self.world, self.KW, int(fill_q8), C.byref(s), C.byref(cap), C.byref(rw)), "acx_shard_layout")
         return s.value, cap.value, rw.value
 
-    def layout_words(self, n_par):
-        s, _, rw = self.layout(n_par)
+    def layout_words(self, n_par, fill_q8=0):
+        s, _, rw = self.layout(n_par, fill_q8)
         return s * self.world * rw
 
     def root_record(self, presentation):
@@ -163,10 +164,10 @@ class HipShardEngine:
         rec = None if record is None else np.ascontiguousarray(record, np.int64)
         self._acx.check(self._acx.lib.acx_shard_seed(self.h, None if rec is None else self._acx.ptr(rec, C.c_int64), self._stream()), "acx_shard_seed")
 
-    def chunk_expand(self, c0, c1, level_first):
+    def chunk_expand(self, c0, c1, level_first, fill_q8=0):
         """-> (send, recv): 1-D int64 views of equal length for the all-to-all (the same view at world 1)"""
         torch = _torch()
-        need = self.layout_words(c1 - c0)
+        need = self.layout_words(c1 - c0, fill_q8)
         if self._cursor + need > self.log.numel():  # grow the log: rare, so simply behind everything that is in flight on any stream
             torch.cuda.synchronize(self.device)
             with torch.cuda.device(self.device):
@@ -176,7 +177,7 @@ class HipShardEngine:
                 self._attach()
             torch.cuda.synchronize(self.device)  # the copy ran on the calling stream; the other stream's next kernels read the new block
         off, words = C.c_int64(), C.c_int64()
-        self._acx.check(self._acx.lib.acx_shard_chunk_expand(self.h, int(c0), int(c1), int(bool(level_first)), C.byref(off), C.byref(words), self._stream()),
+        self._acx.check(self._acx.lib.acx_shard_chunk_expand(self.h, int(c0), int(c1), int(bool(level_first)), int(fill_q8), C.byref(off), C.byref(words), self._stream()),
                         "acx_shard_chunk_expand")
         assert off.value == self._cursor and words.value == need, (off.value, self._cursor, words.value, need)
         recv = self.log[off.value: off.value + need]
@@ -246,11 +247,30 @@ def _side_stream(dev):
     return _SIDE_STREAMS[key]
 
 
+class _RegionOverflow(RuntimeError):
+    """a send region overflowed under a capacity tighter than the default: the search is rerun with the default"""
+
+
 def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False, comm=None,
-                engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None):
+                engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None, region_fill=None):
+    """`bfs` with the frontier sharded over the ranks of `comm`: see _bfs_sharded_once.  A search whose adaptive (or given) region
+    capacity turns out too tight fails on every rank at the same chunk and is rerun from scratch with the safe default."""
+    kw = dict(verbose=verbose, cyclically_reduce_after_moves=cyclically_reduce_after_moves, comm=comm, engine_factory=engine_factory,
+              batch_parents=batch_parents, want_stats=want_stats, log_fraction=log_fraction, overlap=overlap)
+    try:
+        return _bfs_sharded_once(presentation, max_nodes_to_explore, region_fill=region_fill, **kw)
+    except _RegionOverflow:
+        out = _bfs_sharded_once(presentation, max_nodes_to_explore, region_fill=FILL_DEFAULT, **kw)
+        if want_stats:
+            out[2]["region_overflow_reruns"] = 1
+        return out
+
+
+def _bfs_sharded_once(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False, comm=None,
+                      engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None, region_fill=None):
     """Same contract as `bfs`: returns (is_search_successful, path or None) [+ stats dict], identical on every rank.
     `batch_parents`: global frontier positions per chunk.  `log_fraction`: expected expanded parents / max_nodes, sizes the
-    record log (it grows by doubling if the estimate is short).  `overlap`: expansion + exchange of chunk k + 1 on a side stream, started beside the dedup of chunk k ("insert": the default when there is an exchange, i.e. world > 1) or beside its commit ("commit"); False: one stream, the default without an exchange."""
+    record log (it grows by doubling if the estimate is short).  `overlap`: expansion + exchange of chunk k + 1 on a side stream, started beside the dedup of chunk k ("insert": the default when there is an exchange, i.e. world > 1) or beside its commit ("commit"); False: one stream, the default without an exchange.  `region_fill`: capacity of the exchanged regions in 1/256 of the even share of all children -- None: adaptive (1.5 x the fullest region of the previous level, at most the default), an int: that value for every chunk, FILL_DEFAULT: the safe 1.25 x; a search whose tighter regions overflow is rerun with the default."""
     from ac_solver.envs.utils import is_array_valid_presentation
 
     import time
@@ -284,6 +304,19 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
     ctl = None
     t_ready = time.perf_counter()  # engine built (device allocations, table fill), root seeded
 
+    # capacity of the exchanged regions (acx_shard_layout): the safe default, a given value, or -- adaptive -- 1.5 x the fullest
+    # region of the previous level (the maximum over the ranks: one scalar all-reduce per level)
+    adaptive = region_fill is None and exchange
+    fill = FILL_DEFAULT if region_fill is None else int(region_fill)
+    fills = []
+
+    def raise_failed(code):
+        """every rank gets here at the same chunk with the same code (the largest any rank reported)"""
+        if code == 1 and failure is None and fill < FILL_DEFAULT:
+            raise _RegionOverflow()
+        raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure or _FAIL_TEXT.get(int(ctl[CTL_FAIL_LOCAL]), 'engine failure')}"
+                           if failure is not None or int(ctl[CTL_FAIL_LOCAL]) else f"sharded bfs failed on another rank: {_FAIL_TEXT.get(code, 'engine failure')}")
+
     def walk(pref, tail):
         """path of the node `pref` (rank << 40 | id) from the root + tail"""
         rev = []
@@ -302,12 +335,11 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
         e = i64([int(ctl[CTL_FAIL_LOCAL]) if failure is None else max(int(ctl[CTL_FAIL_LOCAL]), 4), -int(ctl[CTL_MIN_LEN])])
         comm.all_reduce(e, "max")
         if int(e[0]):
-            raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure or _FAIL_TEXT.get(int(ctl[CTL_FAIL_LOCAL]), 'engine failure')}"
-                               if failure is not None or int(ctl[CTL_FAIL_LOCAL]) else "sharded bfs failed on another rank")
+            raise_failed(int(e[0]))
         if want_stats:
             st = dict(nodes=int(ctl[CTL_NODES_GLOBAL]), expanded=int(ctl[CTL_EXPANDED]), levels=levels, chunks=chunks, min_len=2 if ok else -int(e[1]), world=world)
             st.update({"comm_" + k: v for k, v in getattr(comm, "stats", {}).items()})
-            st.update(setup_seconds=t_ready - t_begin, loop_seconds=time.perf_counter() - t_ready)
+            st.update(setup_seconds=t_ready - t_begin, loop_seconds=time.perf_counter() - t_ready, region_fill_q8=fills[-4:] if adaptive else fill)
             return ok, path, st
         return ok, path
 
@@ -349,13 +381,13 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             # A failing engine call of this rank (a HIP error, an exhausted allocation) must not leave the other ranks waiting in a
             # collective: the rank sends empty regions whose headers say "failed" and every rank stops at that chunk (status 4).
             try:
-                send, recv = engine.chunk_expand(c0, c1, c0 == 0)
+                send, recv = engine.chunk_expand(c0, c1, c0 == 0, fill)
             except Exception as e:  # noqa: BLE001
                 if not exchange:
                     raise
                 failure = failure or e
                 engine.fail_local()
-                S, _, rw = engine.layout(n_par)
+                S, _, rw = engine.layout(n_par, fill)
                 send = torch.zeros(S * world * rw, dtype=torch.int64, device=dev)
                 hdr = send.view(S * world, rw)
                 hdr[:, 1], hdr[:, 2], hdr[:, 3] = INF, INF, 4
@@ -449,8 +481,7 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
             ctl = engine.ctl_wait(pending.pop(0))
         status = int(ctl[CTL_STATUS])
         if status == ST_FAILED:
-            raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure or _FAIL_TEXT.get(int(ctl[CTL_FAIL_LOCAL]), 'engine failure')}"
-                               if failure is not None or int(ctl[CTL_FAIL_LOCAL]) else "sharded bfs failed on another rank")
+            raise_failed(int(ctl[CTL_FAIL_SEEN]))
         if status == ST_MOVE_ERROR:
             # the reference executes this move before it stops: its ACMove raises (every rank sees the same words)
             raise AssertionError("a move emptied a relator during the search: the reference's ACMove raises here")
@@ -463,4 +494,10 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
         if status == ST_BUDGET:
             return finish(False, None)
         F_prev, F, nodes_seen = F, int(ctl[CTL_NEXT_COUNT]), int(ctl[CTL_NODES_GLOBAL])
+        if adaptive:  # the fullest region any rank received in this level (0: no chunk large enough to tell) sizes the next level's regions
+            lf = i64([int(ctl[CTL_LEVEL_FILL])])
+            comm.all_reduce(lf, "max")
+            lf = int(lf[0])
+            fill = FILL_DEFAULT if lf == 0 else min(FILL_DEFAULT, max(64, lf * 3 // 2 + 8))
+            fills.append(fill)
     return finish(False, None)

@@ -106,6 +106,7 @@ enum : int {
     C_MIN_LEN = 9,       // smallest total length this rank generated
     C_FAIL_SEEN = 10,    // failure code received (status 4)
     C_CHUNKS = 11,       // chunks decided
+    C_LEVEL_FILL = 12,   // fullest region this rank received in the running level, in 1/256 of the even share (chunks with an even share >= 2048 records)
     C_WORDS = 16
 };
 enum : int { FAIL_REGION = 1, FAIL_NODES = 2, FAIL_TABLE = 3, FAIL_HOST = 4 };
@@ -151,22 +152,31 @@ struct ChunkGeo {
     uint32_t n_par;        // global parents in the chunk
     uint32_t subcap;       // records a sub-region can take
     uint32_t region_words; // kShardHdr + subcap * RW
+    uint32_t even;         // records of the even share per sub-region (12 n_par / (world^2 * sub-regions)); 0 at world 1
 };
 
 __device__ __forceinline__ uint32_t gmask_of(const int32_t* __restrict__ gmask, uint32_t p) { return ((uint32_t)gmask[p >> 1] >> (16u * (p & 1u))) & 0xFFFu; }
 
 // the one place that fixes the geometry of a chunk's regions: every rank (and the NumPy test engine, through
 // acx_shard_layout) computes the same numbers from (parents of the chunk, world)
-static inline void shard_layout(int64_t n_par, int world, int RW, int64_t* subcap, int64_t* region_words) {
+// Region capacity at world > 1: `fill_q8` / 256 x the even share of ALL children + two workgroups' worth (never more than the
+// hard bound).  The default (fill_q8 <= 0) is 1.25 x: safe whatever the presentation does, but the records that are really
+// sent (the unchanged children, the undo children and the in-tile duplicates stay home) fill ~38 % of that, and the all-to-all
+// moves the whole region.  The orchestrator therefore passes the fullest region of the previous level x 1.5
+// (ctl[C_LEVEL_FILL]); an overflow fails the search (FAIL_REGION) and the orchestrator reruns it with the default.
+constexpr int kShardFillDefault = 320;
+static inline void shard_layout(int64_t n_par, int world, int RW, int fill_q8, int64_t* subcap, int64_t* region_words, int64_t* even_out = nullptr) {
     const int64_t n_blocks = (12 * n_par + kExpandTile - 1) / kExpandTile;
     const int64_t hard = (n_blocks + kShardSub - 1) / kShardSub * kExpandTile;  // every workgroup that reserves in a sub-region sends it all it has
-    int64_t cap = hard;
-    if (world > 1) {  // the owner hash spreads the records evenly: 1.25 x the even share + two workgroups' worth
-        const int64_t even = (12 * n_par + (int64_t)world * world * kShardSub - 1) / ((int64_t)world * world * kShardSub);
-        cap = std::min<int64_t>(hard, even + even / 4 + 2 * kExpandTile);
+    int64_t cap = hard, even = 0;
+    if (world > 1) {  // the owner hash spreads the records evenly
+        if (fill_q8 <= 0 || fill_q8 > kShardFillDefault) fill_q8 = kShardFillDefault;
+        even = (12 * n_par + (int64_t)world * world * kShardSub - 1) / ((int64_t)world * world * kShardSub);
+        cap = std::min<int64_t>(hard, (even * fill_q8 + 255) / 256 + 2 * kExpandTile);
     }
     *subcap = cap;
     *region_words = kShardHdr + cap * RW;
+    if (even_out) *even_out = even;
 }
 
 // first node of [lo, hi) whose gpos is >= c
@@ -191,6 +201,7 @@ __global__ void __launch_bounds__(256) k_shard_prep(ShardDev<W> d, ChunkGeo g, i
             d.ctl[C_LVL_LO] = d.ctl[C_LVL_HI];
             d.ctl[C_LVL_HI] = d.ctl[C_NODES];
             d.ctl[C_NEXT_COUNT] = 0;
+            d.ctl[C_LEVEL_FILL] = 0;
         }
         s_lo[0] = s_lo[1] = (uint32_t)d.ctl[C_LVL_LO];
         s_hi[0] = s_hi[1] = (uint32_t)d.ctl[C_LVL_HI];
@@ -577,7 +588,7 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_scan(Shard
 // One workgroup: prefix over the tiles' totals (turned into exclusive prefixes in place), then lane 0 decides.
 template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(ShardDev<W> d, ChunkGeo g, int64_t max_nodes) {
     __shared__ uint32_t s_l[1024], s_g[1024];
-    __shared__ unsigned long long s_solved, s_err, s_fail;
+    __shared__ unsigned long long s_solved, s_err, s_fail, s_fill;
     __shared__ uint32_t s_tile, s_pb;
     ACX_VGPR_PAD("v39");
     if (d.ctl[C_STATUS] != 0) {  // the search has ended: this chunk commits nothing
@@ -586,7 +597,7 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(Sha
     }
     const uint32_t tid = threadIdx.x;
     const uint32_t nt = (g.n_par + kScanTile - 1) / kScanTile, per = (nt + 1023) / 1024;
-    if (tid == 0) s_solved = kShardInf, s_err = kShardInf, s_fail = 0, s_tile = 0xFFFFFFFFu, s_pb = 0xFFFFFFFFu;
+    if (tid == 0) s_solved = kShardInf, s_err = kShardInf, s_fail = 0, s_fill = 0, s_tile = 0xFFFFFFFFu, s_pb = 0xFFFFFFFFu;
     uint32_t lsum = 0, gsum = 0;
     for (uint32_t k = 0; k < per; k++) {
         const uint32_t t = tid * per + k;
@@ -618,9 +629,10 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(Sha
         }
     }
     // the headers of everything this rank received: success / error words and failure codes of all senders
-    unsigned long long sv = kShardInf, ev = kShardInf, fv = 0;
+    unsigned long long sv = kShardInf, ev = kShardInf, fv = 0, cv = 0;
     for (uint32_t r = tid; r < d.world * kShardSub; r += 1024) {
         const int64_t* h = d.log + g.log_off + (int64_t)r * g.region_words;
+        cv = max(cv, (unsigned long long)h[0]);
         sv = min(sv, (unsigned long long)h[1]);
         ev = min(ev, (unsigned long long)h[2]);
         fv = max(fv, (unsigned long long)h[3]);
@@ -628,6 +640,7 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(Sha
     if (sv < kShardInf) atomicMin(&s_solved, sv);
     if (ev < kShardInf) atomicMin(&s_err, ev);
     if (fv) atomicMax(&s_fail, fv);
+    if (cv) atomicMax(&s_fill, cv);
     __syncthreads();
     const bool over = nodes_global + g_total >= (unsigned long long)max_nodes && need >= 1;
     if (over) {  // the parent inside tile s_tile whose inclusive count reaches the budget
@@ -642,6 +655,10 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(Sha
     }
     __syncthreads();
     if (tid != 0) return;
+    if (g.even >= 2048u) {  // (a small chunk says little about the fill of a large one)
+        const unsigned long long q8 = (s_fill * 256ull + g.even - 1) / g.even;
+        if (q8 > d.ctl[C_LEVEL_FILL]) d.ctl[C_LEVEL_FILL] = q8;
+    }
     ChunkDec dec = {0, 0, 0, 0};
     if (s_fail) {  // some rank failed in an earlier chunk: everybody stops here (same chunk on every rank: the headers are the same)
         d.ctl[C_STATUS] = 4;
@@ -850,7 +867,7 @@ template <typename W> struct ShardEngine {
         cap_nodes = (uint64_t)node_cap + 64;
         chunk_parents = (uint64_t)std::max<int64_t>(chunk_parents_, 1);
         int64_t subcap, region_words;
-        shard_layout((int64_t)chunk_parents, world, recio<W>::RW, &subcap, &region_words);
+        shard_layout((int64_t)chunk_parents, world, recio<W>::RW, 0, &subcap, &region_words);
         const uint64_t chunk_records = (uint64_t)subcap * kShardSub * (uint64_t)world;
         n_slots = 1024;
         while (n_slots < 2 * (cap_nodes + chunk_records)) n_slots <<= 1;
@@ -971,13 +988,13 @@ template <typename W> static int shard_seed(ShardEngine<W>& E, const int64_t* re
 }
 
 template <typename W>
-static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int level_first, int64_t* recv_off, int64_t* words, hipStream_t st) {
+static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int level_first, int fill_q8, int64_t* recv_off, int64_t* words, hipStream_t st) {
     if (!E.d.log) return fail(ACX_E_INVAL, "acx_shard_chunk_expand: call acx_shard_attach first");
     const int64_t n_par = c1 - c0;
     if (n_par < 1 || (uint64_t)n_par > E.chunk_parents) return fail(ACX_E_CAPACITY, "acx_shard_chunk_expand: a chunk of %lld parents exceeds the engine's %llu", (long long)n_par, (unsigned long long)E.chunk_parents);
     if (c1 > (int64_t)0xFFFFFFFFll) return fail(ACX_E_INVAL, "acx_shard_chunk_expand: a level is limited to 2^32 - 1 positions");
-    int64_t subcap, region_words;
-    shard_layout(n_par, E.world, recio<W>::RW, &subcap, &region_words);
+    int64_t subcap, region_words, even;
+    shard_layout(n_par, E.world, recio<W>::RW, fill_q8, &subcap, &region_words, &even);
     const int64_t total = region_words * kShardSub * E.world;
     if (E.geo_count == ShardEngine<W>::kGeoRing) return fail(ACX_E_INVAL, "acx_shard_chunk_expand: too many chunks in flight (commit the oldest first)");
     ChunkGeo geo{};
@@ -985,6 +1002,7 @@ static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int lev
     geo.n_par = (uint32_t)n_par;
     geo.subcap = (uint32_t)subcap;
     geo.region_words = (uint32_t)region_words;
+    geo.even = (uint32_t)even;
     geo.log_off = E.log_off;
     int64_t* send = E.d_send ? E.d_send : E.d.log + E.log_off;
     if ((uint64_t)(E.log_off + total) > E.log_words || (E.d_send && (uint64_t)total > E.send_words))
@@ -1093,10 +1111,10 @@ extern "C" {
 
 int acx_shard_key_words(int L) { return L <= 29 ? 2 : 4; }
 
-int acx_shard_layout(int64_t n_parents, int world, int key_words, int64_t* subregions, int64_t* subcap, int64_t* region_words) {
+int acx_shard_layout(int64_t n_parents, int world, int key_words, int fill_q8, int64_t* subregions, int64_t* subcap, int64_t* region_words) {
     if (n_parents < 1 || world < 1 || (key_words != 2 && key_words != 4) || !subregions || !subcap || !region_words) return fail(ACX_E_INVAL, "acx_shard_layout: bad argument");
     *subregions = kShardSub;
-    shard_layout(n_parents, world, key_words + 1, subcap, region_words);
+    shard_layout(n_parents, world, key_words + 1, fill_q8, subcap, region_words);
     return ACX_OK;
 }
 
@@ -1148,9 +1166,9 @@ int acx_shard_seed(acx_shard* h, const int64_t* h_record, void* stream) {
     ACX_SHARD_DISPATCH(&h->any, return shard_seed<W>(E, h_record, (hipStream_t)stream));
 }
 
-int acx_shard_chunk_expand(acx_shard* h, int64_t c0, int64_t c1, int level_first, int64_t* recv_off, int64_t* words, void* stream) {
+int acx_shard_chunk_expand(acx_shard* h, int64_t c0, int64_t c1, int level_first, int fill_q8, int64_t* recv_off, int64_t* words, void* stream) {
     if (!h || c0 < 0 || c1 <= c0 || !recv_off || !words) return fail(ACX_E_INVAL, "acx_shard_chunk_expand: bad argument");
-    ACX_SHARD_DISPATCH(&h->any, return shard_chunk_expand<W>(E, c0, c1, level_first, recv_off, words, (hipStream_t)stream));
+    ACX_SHARD_DISPATCH(&h->any, return shard_chunk_expand<W>(E, c0, c1, level_first, fill_q8, recv_off, words, (hipStream_t)stream));
 }
 
 int acx_shard_chunk_insert(acx_shard* h, void* stream) {

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACX_VERSION 301
+#define ACX_VERSION 302
 
 /* return codes */
 #define ACX_OK 0
@@ -205,8 +205,12 @@ int acx_search_many(int kind, const int8_t *h_presentations, int64_t n, int L, i
  * S * region_words int64 per rank delivers it. */
 typedef struct acx_shard acx_shard;
 int acx_shard_key_words(int L); /* 2 for L <= 29, 4 for L <= 61 */
-/* geometry of a chunk of n_parents global parents (pure host arithmetic, no device needed) */
-int acx_shard_layout(int64_t n_parents, int world, int key_words, int64_t *subregions, int64_t *subcap, int64_t *region_words);
+/* geometry of a chunk of n_parents global parents (pure host arithmetic, no device needed).  fill_q8: capacity of a region at
+ * world > 1 in 1/256 of the even share of ALL children (+ two workgroups' worth); <= 0 or > 320: the default 320 = 1.25 x,
+ * safe for any input.  The records really sent fill ~38 % of that, and the all-to-all moves whole regions: the orchestrator
+ * passes 1.5 x the fullest region of the previous level (control word ACX_SHARD_CTL_LEVEL_FILL, max over the ranks) and reruns
+ * the search with the default if a region ever overflows (failure code 1). */
+int acx_shard_layout(int64_t n_parents, int world, int key_words, int fill_q8, int64_t *subregions, int64_t *subcap, int64_t *region_words);
 /* node_cap: local nodes; chunk_parents: the largest chunk (global parents) */
 acx_shard *acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t chunk_parents, int rank, int world);
 void acx_shard_destroy(acx_shard *h);
@@ -219,8 +223,8 @@ int acx_shard_seed(acx_shard *h, const int64_t *h_record, void *stream);
 /* children of the local nodes of the running level whose global positions lie in [c0, c1), routed to their owners (children
  * equal to their parent, children that undo their parent's move in a normal-form search with cyclical = 0, and duplicates
  * inside a workgroup are never sent).  level_first != 0 on the first chunk of a level: the nodes committed during the previous
- * level become the running one. */
-int acx_shard_chunk_expand(acx_shard *h, int64_t c0, int64_t c1, int level_first, int64_t *recv_off, int64_t *words, void *stream);
+ * level become the running one.  fill_q8: as in acx_shard_layout (the same value on every rank). */
+int acx_shard_chunk_expand(acx_shard *h, int64_t c0, int64_t c1, int level_first, int fill_q8, int64_t *recv_off, int64_t *words, void *stream);
 /* exact dedup of what the receive area holds against the visited table and among itself (minimum tag wins) -> gmask */
 int acx_shard_chunk_insert(acx_shard *h, void *stream);
 /* decisions + the new states below the cutoff become local nodes, in tag order (max_nodes = max_nodes_to_explore) */
@@ -236,6 +240,7 @@ int acx_shard_chunk_commit(acx_shard *h, int64_t max_nodes, void *stream);
 #define ACX_SHARD_CTL_FAIL_LOCAL 8   /* this rank's failure code: 1 region / log overflow, 2 node capacity, 3 table full, 4 host */
 #define ACX_SHARD_CTL_MIN_LEN 9      /* smallest total length this rank generated */
 #define ACX_SHARD_CTL_FAIL_SEEN 10   /* failure code received from some rank (status 4) */
+#define ACX_SHARD_CTL_LEVEL_FILL 12  /* fullest region this rank received in the running level, in 1/256 of the even share (0: no chunk large enough to tell) */
 /* queue a copy of the control block into pinned slot `slot` (0..3) behind the work queued so far / wait for it */
 int acx_shard_ctl_snapshot(acx_shard *h, int slot, void *stream);
 int acx_shard_ctl_wait(acx_shard *h, int slot, int64_t *h_ctl);

@@ -21,14 +21,23 @@ HDR, SUB, TILE = 4, 16, 1536  # header words, sub-regions per destination, child
 _INVERSE = {0: 2, 2: 0, 1: 3, 3: 1, 4: 8, 8: 4, 5: 9, 9: 5, 6: 10, 10: 6, 7: 11, 11: 7}
 
 
-def layout(n_par, world, KW):
+FILL_DEFAULT = 320
+FILL_MIN_EVEN = 2048  # chunks with a smaller even share do not update the level's fill word (csrc/acx_shard.hip: k_shard_decide)
+
+
+def even_share(n_par, world):
+    return -(-12 * n_par // (world * world * SUB)) if world > 1 else 0
+
+
+def layout(n_par, world, KW, fill_q8=0):
     """Python mirror of shard_layout (csrc/acx_shard.hip); tests/test_sharded_cpu.py checks it against acx_shard_layout"""
     n_blocks = -(-12 * n_par // TILE)
     hard = -(-n_blocks // SUB) * TILE
     cap = hard
     if world > 1:
-        even = -(-12 * n_par // (world * world * SUB))
-        cap = min(hard, even + even // 4 + 2 * TILE)
+        if fill_q8 <= 0 or fill_q8 > FILL_DEFAULT:
+            fill_q8 = FILL_DEFAULT
+        cap = min(hard, -(-even_share(n_par, world) * fill_q8 // 256) + 2 * TILE)
     return SUB, cap, HDR + cap * (KW + 1)
 
 
@@ -89,12 +98,13 @@ class OracleShardEngine:
         self.nf = False
         self.inverse_dropped = 0
         self.open, self.inserted = [], 0
+        self.fill_min_even = FILL_MIN_EVEN
 
-    def layout(self, n_par):
-        return layout(n_par, self.world, self.KW)
+    def layout(self, n_par, fill_q8=0):
+        return layout(n_par, self.world, self.KW, fill_q8)
 
-    def layout_words(self, n_par):
-        s, _, rw = self.layout(n_par)
+    def layout_words(self, n_par, fill_q8=0):
+        s, _, rw = self.layout(n_par, fill_q8)
         return s * self.world * rw
 
     def root_record(self, p):
@@ -117,11 +127,11 @@ class OracleShardEngine:
             self._add(int(record[0]), int(record[1]), 0xff, -1, 0)
             self.ctl[5] = 1
 
-    def chunk_expand(self, c0, c1, level_first):
+    def chunk_expand(self, c0, c1, level_first, fill_q8=0):
         from ac_solver.search.sharded import owner_of
 
         n_par = c1 - c0
-        S, cap, rw = self.layout(n_par)
+        S, cap, rw = self.layout(n_par, fill_q8)
         send = torch.zeros(S * self.world * rw, dtype=torch.int64)
         recv = torch.zeros_like(send) if self.world > 1 else send
         self.open.append(((c0, n_par, S, cap, rw), recv))  # the orchestrator expands chunk k + 1 before it inserts chunk k
@@ -130,6 +140,7 @@ class OracleShardEngine:
         if level_first:
             self.lvl_lo, self.lvl_hi = self.lvl_hi, len(self.states)
             self.ctl[2] = 0
+            self.ctl[12] = 0
         regs = send.view(S * self.world, rw)
         regs[:, 1] = INF
         regs[:, 2] = INF
@@ -219,6 +230,9 @@ class OracleShardEngine:
             return
         c0, n_par, S, cap, rw = self.geo
         regs = self.recv.view(S * self.world, rw)
+        even = even_share(n_par, self.world)
+        if even >= self.fill_min_even:  # the fullest region of the level, in 1/256 of the even share
+            self.ctl[12] = max(int(self.ctl[12]), -(-int(regs[:, 0].max()) * 256 // even))
         fail = int(regs[:, 3].max())
         if fail:
             self.ctl[0], self.ctl[10] = 4, fail

@@ -299,6 +299,19 @@ def test_sharded_bfs_mid_size_thread_ranks_equal_the_fused_search(search, golden
             assert (ok, path) == (wok, wpath)
             assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (world, st, wst)
     assert want[3][0] and not want[0][0]
+    if world == 4:
+        # the regions of the exchange: adaptive capacity really in use (chunks of 2^16 parents: an even share of 3072 records per
+        # sub-region, about half of it sent), and a capacity that cannot hold (1/256 of the even share of 2^18-parent chunks + the
+        # two tiles of slack) overflows, fails every rank at the same chunk and is rerun with the default -- same counts
+        fills = res[0][2]["region_fill_q8"]
+        assert isinstance(fills, list) and fills and min(fills) < 320, fills
+
+        def forced(comm):
+            return bfs_sharded(ak3, 3 * 10**6, comm=comm, batch_parents=1 << 18, want_stats=True, region_fill=1)
+
+        for ok, path, st in run_threads(world, forced):
+            assert (ok, path) == want[0][:2] and st["nodes"] == want[0][2]["nodes"] and st["expanded"] == want[0][2]["expanded"]
+            assert st.get("region_overflow_reruns") == 1, st
 
 
 @pytest.mark.parametrize("L", [25, 36])
@@ -327,7 +340,7 @@ def test_device_routing_matches_owner_of(search, L):
         for lvl in range(5):          # a few levels: 12, then up to 144, ... children
             F = len(level)
             send, recv = eng.chunk_expand(0, F, True)
-            S, cap, rw = eng.layout(F)
+            S, cap, rw = eng.layout(F, 0)
             regs = send.view(S * world, rw).cpu()
             # expected records: tag -> state, tile by tile
             want, tile_keys = {}, {}

@@ -138,8 +138,9 @@ def test_layout_mirror_matches_the_library():
     for world in (1, 2, 3, 8, 64):
         for n_par in (1, 7, 85, 86, 1000, 1365, 1366, 1 << 18, (1 << 21) + 5):
             for kw in (2, 4):
-                _acx.check(_acx.lib.acx_shard_layout(n_par, world, kw, C.byref(s), C.byref(cap), C.byref(rw)))
-                assert (s.value, cap.value, rw.value) == layout(n_par, world, kw), (world, n_par, kw)
+                for fill in (0, 64, 121, 320, 999):
+                    _acx.check(_acx.lib.acx_shard_layout(n_par, world, kw, fill, C.byref(s), C.byref(cap), C.byref(rw)))
+                    assert (s.value, cap.value, rw.value) == layout(n_par, world, kw, fill), (world, n_par, kw, fill)
 
 
 def test_undo_children_are_visited_states():
@@ -158,3 +159,30 @@ def test_undo_children_are_visited_states():
         wok, wpath, wst = O.bfs(p, 3000, stats=True)
         assert (ok, path, st["nodes"], st["expanded"]) == (wok, wpath, wst["nodes"], wst["expanded"])
         assert made[-1].inverse_dropped > 100
+
+
+def test_adaptive_regions_and_the_rerun_after_an_overflow():
+    """world 2-3 thread ranks over the NumPy engine: (a) the adaptive region capacity (the previous level's fullest region x 1.5)
+    leaves the result untouched and is really used (the engine's threshold for "a chunk large enough to tell" is lowered to
+    the sizes of this test); (b) so does a given capacity."""
+    from ac_solver.search.sharded import bfs_sharded
+
+    def factory(*a):
+        eng = OracleShardEngine(*a)
+        eng.fill_min_even = 1
+        return eng
+
+    for world in (2, 3):
+        for (p, budget, cyc) in SMALL[:3]:
+            wok, wpath, wst = O.bfs(p, budget, cyclically_reduce_after_moves=cyc, stats=True)
+
+            def work(comm):
+                a = bfs_sharded(p, budget, cyclically_reduce_after_moves=cyc, comm=comm, engine_factory=factory, batch_parents=64, want_stats=True)
+                b = bfs_sharded(p, budget, cyclically_reduce_after_moves=cyc, comm=comm, engine_factory=factory, batch_parents=64, want_stats=True, region_fill=1)
+                return a, b
+
+            for a, b in run_threads(world, work):
+                for ok, path, st in (a, b):
+                    assert (ok, path) == (wok, wpath) and st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (world, budget, cyc)
+                assert "region_overflow_reruns" not in a[2]  # (chunks this small never exceed the two tiles of slack: the overflow itself is
+                # forced in tests/test_gpu_search.py::test_sharded_bfs_mid_size_thread_ranks_equal_the_fused_search)
