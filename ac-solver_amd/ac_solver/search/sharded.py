@@ -31,6 +31,7 @@ backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests; an in-process thread co
 ranks in the GPU tests).
 """
 import ctypes as C
+import os
 import sys
 
 import numpy as np
@@ -128,6 +129,16 @@ class HipShardEngine:
             self._attach()
         self._cursor = 8  # host mirror of the engine's log cursor (deterministic: it advances by the chunk's words)
         self._ctl = np.zeros(CTL_WORDS, np.int64)
+
+    def close(self):
+        """Give the engine's device memory back NOW (bfs_sharded calls this when it returns) instead of whenever the garbage collector
+        gets to the reference cycle the orchestrator's closures keep the engine in: the next search then finds the 5 GB of a
+        1e8-node engine in the block pool."""
+        if getattr(self, "h", None) and not sys.is_finalizing():
+            _torch().cuda.synchronize(self.device)  # (a chunk that was expanded but never consumed may still be running)
+            self._acx.lib.acx_shard_destroy(self.h)
+            self.h = None
+        self.log = self.send = self.gmask = None
 
     def __del__(self):
         # not during interpreter shutdown: the HIP runtime may already be tearing down (a hipFree then can block forever)
@@ -286,6 +297,26 @@ def _bfs_sharded_once(presentation, max_nodes_to_explore=10000, verbose=False, c
     B = int(max(1, min(batch_parents, max(max_nodes, 64))))  # global parents per chunk
     node_cap = (max_nodes + 64 if world == 1 else int(2.0 * max_nodes / world)) + 4096
     engine = (engine_factory or _default_engine)(L, cyclically_reduce_after_moves, node_cap, B, rank, world, max(1.0, log_fraction * max_nodes))
+    # The orchestrator allocates a few small Python objects per chunk; in a process with a large heap (bench.py) that now and then
+    # triggers a full garbage collection (25-30 ms there) in the middle of a 13 ms search.  No collections while the search runs
+    # (the collector's state is restored on the way out: the collection then happens behind the search).
+    import gc
+
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        return _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, want_stats, overlap, region_fill, t_begin)
+    finally:
+        if hasattr(engine, "close"):
+            engine.close()
+        if gc_was_on:
+            gc.enable()
+
+
+def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, want_stats, overlap, region_fill, t_begin):
+    import time
+
+    torch = _torch()
     dev = getattr(engine, "device", torch.device("cpu"))
     KW = engine.KW
     exchange = world > 1 or _FORCE_EXCHANGE
