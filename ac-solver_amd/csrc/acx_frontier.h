@@ -2,6 +2,7 @@
 // the BFS / greedy frontiers (expand, insert with minimum-tag resolution, mark, commit, decide) and the device
 // block pool.  Included by acx_search.hip (single-GPU searches) and acx_shard.hip (per-GPU engine of the sharded BFS).
 #pragma once
+#include <array>
 #include <string.h>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
@@ -791,14 +792,44 @@ struct DevBuf {
     }
 };
 
-// two timing events that are released on every exit path
+// two timing events, handed back on every exit path; finished pairs are kept for the next search (per device: an event belongs
+// to the device it was created on)
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
+    int dev = -1;
+    struct Pool {
+        std::mutex mu;
+        std::vector<EventPair*> unused;  // (owned copies)
+        std::vector<std::array<void*, 3>> free_;  // a, b, dev
+    };
+    static Pool& pool() {
+        static Pool* p = new Pool();  // never destroyed: no HIP calls at process exit
+        return *p;
+    }
     hipError_t create() {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        {
+            Pool& P = pool();
+            std::lock_guard<std::mutex> lock(P.mu);
+            for (size_t i = 0; i < P.free_.size(); i++)
+                if ((int)(intptr_t)P.free_[i][2] == dev) {
+                    a = (hipEvent_t)P.free_[i][0];
+                    b = (hipEvent_t)P.free_[i][1];
+                    P.free_[i] = P.free_.back();
+                    P.free_.pop_back();
+                    return hipSuccess;
+                }
+        }
         hipError_t e = hipEventCreate(&a);
         return e != hipSuccess ? e : hipEventCreate(&b);
     }
     ~EventPair() {
+        if (a && b) {
+            Pool& P = pool();
+            std::lock_guard<std::mutex> lock(P.mu);
+            P.free_.push_back({(void*)a, (void*)b, (void*)(intptr_t)dev});
+            return;
+        }
         if (a) (void)hipEventDestroy(a);
         if (b) (void)hipEventDestroy(b);
     }

@@ -87,11 +87,52 @@ template <typename W, typename KEYS> static int node_digest(KEYS keys, const uin
 
 constexpr int kRunAheadSlots = 4, kRunAheadLag = 2;  // pinned snapshots of the BFS cursor / how many batches the host runs ahead of the one it reads
 
+// The streams and events of a search.  Creating and destroying two streams and eight events per search cost ~0.7 ms of host
+// time -- of a 9 ms search: finished searches leave theirs here (per device) for the next one.
+struct SearchHandles {
+    hipStream_t st = nullptr, st_copy = nullptr;
+    hipEvent_t ev_cursor[kRunAheadSlots] = {}, ev_batch[kRunAheadSlots] = {};
+    int dev = -1;
+};
+static std::mutex g_handles_mu;
+static std::vector<SearchHandles> g_handles_free;
+static int search_handles_take(SearchHandles& h) {
+    int dev = 0;
+    ACX_HIP_TRY(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lock(g_handles_mu);
+        for (size_t i = 0; i < g_handles_free.size(); i++)
+            if (g_handles_free[i].dev == dev) {
+                h = g_handles_free[i];
+                g_handles_free[i] = g_handles_free.back();
+                g_handles_free.pop_back();
+                return ACX_OK;
+            }
+    }
+    h.dev = dev;
+    // every search owns a stream, so that searches driven from different host threads overlap on the GPU; the cursor snapshots of
+    // the fused BFS travel on a second one (a copy queued on `st` sits between two batches: 10 us)
+    ACX_HIP_TRY(hipStreamCreateWithFlags(&h.st, hipStreamNonBlocking));
+    ACX_HIP_TRY(hipStreamCreateWithFlags(&h.st_copy, hipStreamNonBlocking));
+    for (auto& e : h.ev_cursor) ACX_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : h.ev_batch) ACX_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return ACX_OK;
+}
+static void search_handles_give(SearchHandles& h) {
+    if (!h.st) return;
+    (void)hipStreamSynchronize(h.st_copy);  // (idle when a search ends normally; an error path may have left a copy in flight)
+    (void)hipStreamSynchronize(h.st);
+    std::lock_guard<std::mutex> lock(g_handles_mu);
+    g_handles_free.push_back(h);
+    h = SearchHandles();
+}
+
 template <typename W> struct Searcher {
     SearchDev<W> d;
     DevBuf arena_nodes, arena_cand, arena_tab, arena_btab, arena_scal, arena_tmp, arena_list, arena_path, arena_status, arena_first, arena_cursor;
     uint8_t* h_cursor = nullptr;  // pinned: kRunAheadSlots x BfsCursor (behind the Decision staging)
-    hipEvent_t ev_cursor[kRunAheadSlots] = {}, ev_batch[kRunAheadSlots] = {};
+    SearchHandles handles;
+    hipEvent_t ev_cursor[kRunAheadSlots] = {}, ev_batch[kRunAheadSlots] = {};  // (copies of the handles' events)
     hipStream_t st_copy = nullptr;  // the cursor snapshots travel on a stream of their own: a copy queued on `st` sits between two batches (10 us)
     unsigned long long h_first[kFirstLen];
     unsigned long long* d_status = nullptr;  // one-pass BFS commit: per-tile look-back words
@@ -106,22 +147,17 @@ template <typename W> struct Searcher {
     uint8_t* h_pin = nullptr;    // pinned host staging: Decision followed by the total lengths of the new nodes
     size_t h_pin_bytes = 0;
 
-    ~Searcher() {
-        for (auto& e : ev_cursor)
-            if (e) (void)hipEventDestroy(e);
-        for (auto& e : ev_batch)
-            if (e) (void)hipEventDestroy(e);
-        if (st_copy) (void)hipStreamDestroy(st_copy);
-        if (st) (void)hipStreamDestroy(st);
-    }
+    ~Searcher() { search_handles_give(handles); }
 
     // inline_tab: BFS visited table with inline keys (TabEntry, round 1; kept for A/B runs: ACX_BFS_INLINE_TAB=1);
     // stamp_tab: the 8-byte stamp table of acx_bfs.h (no candidate keys at all); otherwise the id table of the greedy paths
     // lean: no key arrays and no table (the persistent greedy frontier keeps its own: GreedyDev::nkeys / tab)
     int init(int L, int cyclical, int64_t max_nodes, uint32_t batch_parents, bool greedy, bool inline_tab = false, bool lean = false, bool stamp_tab = false) {
         memset(&d, 0, sizeof(d));
-        // every search owns a stream, so that searches driven from different host threads overlap on the GPU
-        ACX_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        if (int rc = search_handles_take(handles)) return rc;
+        st = handles.st;
+        st_copy = handles.st_copy;
+        for (int k = 0; k < kRunAheadSlots; k++) ev_cursor[k] = handles.ev_cursor[k], ev_batch[k] = handles.ev_batch[k];
         d.L = L;
         d.cyclical = cyclical;
         cap_nodes = (uint64_t)max_nodes + 64;
@@ -197,9 +233,6 @@ template <typename W> struct Searcher {
         if (stamp_tab) {  // run-ahead batches of the fused BFS (acx_frontier.h: BfsCursor)
             h_cursor = h_pin + cursor_off;
             if (arena_cursor.alloc(sizeof(BfsCursor))) return ACX_E_NOMEM;
-            for (auto& e : ev_cursor) ACX_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            for (auto& e : ev_batch) ACX_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ACX_HIP_TRY(hipStreamCreateWithFlags(&st_copy, hipStreamNonBlocking));
         }
         d.solved_tag = (unsigned long long*)(sc + 0);
         d.shorter_tag = (unsigned long long*)(sc + 8);
