@@ -37,7 +37,8 @@ namespace acx {
 constexpr int kGT = ACX_GREEDY_THREADS;  // lanes of the persistent workgroup
 constexpr uint32_t kDepthCap = 16384;  // bucket table rows per total length
 
-enum : uint32_t { GREEDY_RUNNING = 0, GREEDY_SOLVED = 1, GREEDY_BUDGET = 2, GREEDY_EXHAUSTED = 3, GREEDY_FALLBACK = 4, GREEDY_MOVE_ERROR = 5, GREEDY_HANDOFF = 6 };
+enum : uint32_t { GREEDY_RUNNING = 0, GREEDY_SOLVED = 1, GREEDY_BUDGET = 2, GREEDY_EXHAUSTED = 3, GREEDY_FALLBACK = 4, GREEDY_MOVE_ERROR = 5, GREEDY_HANDOFF = 6,
+                  GREEDY_MEGA_MORE = 7 };  // a relaunch that found the whole-GPU kernels still at work on the handed-off bucket: nothing done
 
 // What the persistent workgroup keeps in LDS between batches, parked in HBM when a single search hands a big bucket to the
 // whole-GPU kernels of acx_greedy_mega.h (GREEDY_HANDOFF) and read back when it is relaunched (`resume`).
@@ -81,6 +82,9 @@ template <typename W> struct GreedyDev {
     uint32_t root_len;
     uint32_t hand_min;   // 0: never; else a selected bucket with at least this many queued parents ends the kernel with GREEDY_HANDOFF
     GreedyState* state;  // nullable (k_greedy_multi): where the frontier is parked / resumed from
+    const uint32_t* mega_status;  // nullable: {status, cut, remaining} of the whole-GPU kernels (acx_greedy_mega.h: MegaScalars).  The host
+                                  // relaunches this kernel behind every mega-batch WITHOUT waiting for the batch's outcome (one
+                                  // synchronisation per hand-off instead of two); when the bucket is not finished the launch is a no-op
 };
 
 struct GreedyOut {
@@ -220,6 +224,11 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wv = tid >> 6;
+    if (g.mega_status && g.mega_status[0] == GREEDY_RUNNING && g.mega_status[1] == 0 && g.mega_status[2] != 0) {  // more mega-batches to come
+        if (tid == 0) out->status = GREEDY_MEGA_MORE;
+        return;
+    }
+
     const SearchDev<W>& d = g.d;
     const uint32_t nlen = g.nlen;
     const uint32_t gmask = g.tmask & ~1u;  // probe sequences start on a 2-slot (16-byte) pair

@@ -337,6 +337,7 @@ template <typename W> struct GreedySearch {
         g.root_len = (uint32_t)(root.n0 + root.n1);
         g.hand_min = 0;
         g.state = nullptr;
+        g.mega_status = nullptr;
         const uint64_t arena_entries = std::min<uint64_t>(8ull * (uint64_t)std::max<int64_t>(max_nodes, 1) + (1ull << 20), 1ull << 31);
         g.arena_cap = (uint32_t)arena_entries;
         if (nkeys.alloc(S.cap_nodes * sizeof(NodeKey<W>)) || tab.alloc(S.n_slots * 8)) return ACX_E_NOMEM;
@@ -438,6 +439,7 @@ static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_no
         g.root_len = (uint32_t)(root.n0 + root.n1);
         g.hand_min = 0;
         g.state = nullptr;
+        g.mega_status = nullptr;
         g.root_k0 = keyops<W>::make(root.w0, root.n0);
         g.root_k1 = keyops<W>::make(root.w1, root.n1);
     }
@@ -668,8 +670,10 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
             mscal.alloc(sizeof(MegaScalars)))
             return ACX_E_NOMEM;
         ACX_HIP_TRY(hipMemsetAsync(stateb.p, 0, sizeof(GreedyState), st));
+        ACX_HIP_TRY(hipMemsetAsync(mscal.p, 0, sizeof(MegaScalars), st));  // (status RUNNING, cut 0, remaining 0: nothing handed off yet)
         g.hand_min = hand_min;
         g.state = (GreedyState*)stateb.p;
+        g.mega_status = (const uint32_t*)((const uint8_t*)mscal.p + offsetof(MegaScalars, status));
         md.ck0 = (W*)mck0.p;
         md.ck1 = (W*)mck1.p;
         md.clen = (uint8_t*)mclen.p;
@@ -681,7 +685,9 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
     } else {
         g.hand_min = 0;
         g.state = nullptr;
+        g.mega_status = nullptr;
     }
+    static_assert(offsetof(MegaScalars, cut) == offsetof(MegaScalars, status) + 4 && offsetof(MegaScalars, remaining) == offsetof(MegaScalars, status) + 8, "status, cut, remaining are read as three consecutive words");
     md.g = g;
     EventPair evs;
     ACX_HIP_TRY(evs.create());
@@ -689,12 +695,11 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
     ACX_HIP_TRY(hipEventRecord(ev0, st));
     GreedyOut o;
     unsigned long long handoffs = 0;
-    for (;;) {
-        hipLaunchKernelGGL(k_greedy_persistent<W>, dim3(1), dim3(kGT), 0, st, g, (GreedyOut*)outb.p);
-        ACX_HIP_TRY(hipGetLastError());
-        ACX_HIP_TRY(hipMemcpyAsync(&o, outb.p, sizeof(o), hipMemcpyDeviceToHost, st));
-        ACX_HIP_TRY(hipStreamSynchronize(st));
-        if (o.status != GREEDY_HANDOFF) break;
+    hipLaunchKernelGGL(k_greedy_persistent<W>, dim3(1), dim3(kGT), 0, st, g, (GreedyOut*)outb.p);
+    ACX_HIP_TRY(hipGetLastError());
+    ACX_HIP_TRY(hipMemcpyAsync(&o, outb.p, sizeof(o), hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
+    while (o.status == GREEDY_HANDOFF) {
         handoffs++;
         // ---- the selected bucket on the whole GPU: order it, then mega-batches until it is used up, cut, or the search ends ----
         uint32_t live = o.hand_live;
@@ -714,11 +719,18 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
             hipLaunchKernelGGL(k_gm_commit<W>, dim3((m + kMegaTile - 1) / kMegaTile), dim3(kMegaTile), 0, st, md, m);
             hipLaunchKernelGGL(k_gm_file<W>, dim3(1), dim3(256), 0, st, md, np);
             hipLaunchKernelGGL(k_gm_push<W>, dim3((m + 255) / 256), dim3(256), 0, st, md, m);
-            ACX_HIP_TRY(hipGetLastError());
             uint32_t res[3];  // status, cut, remaining (consecutive in MegaScalars)
             ACX_HIP_TRY(hipMemcpyAsync(res, (const uint8_t*)mscal.p + offsetof(MegaScalars, status), sizeof(res), hipMemcpyDeviceToHost, st));
+            // the frontier kernel again, behind the batch and WITHOUT waiting for its outcome: most buckets take one mega-batch,
+            // and when this one needs another the launch finds that in the scalars and does nothing (GREEDY_MEGA_MORE) --
+            // one synchronisation per hand-off instead of two
+            hipLaunchKernelGGL(k_greedy_persistent<W>, dim3(1), dim3(kGT), 0, st, g, (GreedyOut*)outb.p);
+            ACX_HIP_TRY(hipGetLastError());
+            ACX_HIP_TRY(hipMemcpyAsync(&o, outb.p, sizeof(o), hipMemcpyDeviceToHost, st));
             ACX_HIP_TRY(hipStreamSynchronize(st));
-            if (res[0] != GREEDY_RUNNING || res[1] || res[2] == 0) break;
+            const bool more = res[0] == GREEDY_RUNNING && !res[1] && res[2] != 0;
+            if (more != (o.status == GREEDY_MEGA_MORE)) return fail(ACX_E_NODEVICE, "greedy hand-off: the frontier kernel and the host disagree about the bucket (status %u)", o.status);
+            if (!more) break;
             live = res[2];
         }
     }
