@@ -31,6 +31,11 @@ constexpr int kBmT = ACX_BFS_MULTI_THREADS;  // lanes of the workgroup
 // registers, the two-multiply hash): 0.24-0.30 s against 0.26-0.28 s -- a sweep is bound by the chain of memory round trips
 // per chunk, not by vector issue, and the 128-bit searches then need more than the 128 registers that let two workgroups
 // share a compute unit.  Not adopted.
+// The two 128-bit groups of the Miller-Schupp sweep are its critical path (twice the vector instructions of a 64-bit group, one
+// workgroup per compute unit at 133 registers, 340 workgroups for 256 compute units).  Bounding those kernels to 128 registers
+// (__launch_bounds__(512, 4): no spills in the normal-form modes) gave 0.305 -> 0.28 s -- and a v_lshrrev_b64 with its amount in
+// v127 of 128 (tools/check_shift64.py), the gfx950 fault of DESIGN.md section 7, at the architectural limit where no pad can
+// move it.  Not adopted either.
 #ifndef ACX_BFS_MULTI_ITEMS
 #define ACX_BFS_MULTI_ITEMS 3
 #endif
