@@ -778,6 +778,12 @@ template <typename W> __global__ void k_shard_find(ShardDev<W> d, uint32_t gpos,
 }
 
 // the engine's failure code, set from the host (an exception on the orchestrator's side of this rank)
+__global__ void k_shard_ctl_init(unsigned long long* ctl) {
+    ACX_VGPR_PAD("v15");
+    ctl[C_MIN_LEN] = kShardInf;
+    ctl[C_NODES_GLOBAL] = 1;
+}
+
 __global__ void k_shard_fail(unsigned long long* ctl, unsigned long long code) {
     ACX_VGPR_PAD("v15");
     atomicMax(ctl + C_FAIL_LOCAL, code);
@@ -790,6 +796,7 @@ constexpr int kCtlSlots = 4;
 struct CtlHost {
     unsigned long long* pinned = nullptr;  // kCtlSlots x C_WORDS
     hipEvent_t ev[kCtlSlots] = {};
+    hipEvent_t ready = nullptr;  // behind the fills of the engine's set-up (null stream)
     int dev = -1;
 };
 static std::mutex g_ctl_mutex;
@@ -809,6 +816,7 @@ static int ctl_host_take(CtlHost& c) {
     c.dev = dev;
     ACX_HIP_TRY(hipHostMalloc((void**)&c.pinned, (size_t)kCtlSlots * C_WORDS * 8, hipHostMallocDefault));
     for (auto& e : c.ev) ACX_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ACX_HIP_TRY(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
     return ACX_OK;
 }
 static void ctl_host_give(CtlHost& c) {
@@ -845,7 +853,20 @@ template <typename W> struct ShardEngine {
     ~ShardEngine() {
         for (auto& e : host.ev)
             if (e) (void)hipEventSynchronize(e);  // (a snapshot still in flight would land in the next owner's slots)
+        if (host.ready) (void)hipEventSynchronize(host.ready);
         ctl_host_give(host);
+    }
+
+    // The fills of the set-up (2 GB of table for a 1e8-node search: 0.35 ms) run on the null stream and the host does not wait for
+    // them; a caller's other stream waits for them once, in front of its first engine call.
+    std::vector<hipStream_t> ready_streams;
+    int await_ready(hipStream_t st) {
+        if (!st) return ACX_OK;  // the null stream itself
+        for (hipStream_t s : ready_streams)
+            if (s == st) return ACX_OK;
+        ACX_HIP_TRY(hipStreamWaitEvent(st, host.ready, 0));
+        ready_streams.push_back(st);
+        return ACX_OK;
     }
 
     int init(int L, int cyclical, int64_t node_cap, int64_t chunk_parents_, int rank_, int world_) {
@@ -914,15 +935,13 @@ template <typename W> struct ShardEngine {
         d.dec = (ChunkDec*)(sc + 320);
         d_find = (int64_t*)(sc + 384);
         d.cap_nodes = (uint32_t)cap_nodes;
-        ACX_HIP_TRY(hipMemset(d.stab, 0xff, n_slots * 8));
-        ACX_HIP_TRY(hipMemset(chunk_buf.p, 0, flag_bytes));
-        ACX_HIP_TRY(hipMemset(scal_buf.p, 0, 1024));
-        const unsigned long long inf = kShardInf;
-        ACX_HIP_TRY(hipMemcpy(d.ctl + C_MIN_LEN, &inf, 8, hipMemcpyHostToDevice));
-        const unsigned long long one = 1;  // len(tree_nodes) counts the root, on every rank
-        ACX_HIP_TRY(hipMemcpy(d.ctl + C_NODES_GLOBAL, &one, 8, hipMemcpyHostToDevice));
         if (int rc = ctl_host_take(host)) return rc;
-        ACX_HIP_TRY(hipDeviceSynchronize());  // the fills run on the null stream; the engine's calls arrive on the caller's (possibly non-blocking) stream
+        ACX_HIP_TRY(hipMemsetAsync(d.stab, 0xff, n_slots * 8, nullptr));
+        ACX_HIP_TRY(hipMemsetAsync(chunk_buf.p, 0, flag_bytes, nullptr));
+        ACX_HIP_TRY(hipMemsetAsync(scal_buf.p, 0, 1024, nullptr));
+        hipLaunchKernelGGL(k_shard_ctl_init, dim3(1), dim3(1), 0, nullptr, d.ctl);  // smallest length = none yet; len(tree_nodes) counts the root, on every rank
+        ACX_HIP_TRY(hipGetLastError());
+        ACX_HIP_TRY(hipEventRecord(host.ready, nullptr));  // (every entry point: await_ready)
         return ACX_OK;
     }
 };
@@ -975,6 +994,7 @@ template <typename W> static int shard_attach(ShardEngine<W>& E, int64_t* log, i
 }
 
 template <typename W> static int shard_seed(ShardEngine<W>& E, const int64_t* rec, hipStream_t st) {
+    if (int rc = E.await_ready(st)) return rc;
     if (!E.d.log) return fail(ACX_E_INVAL, "acx_shard_seed: call acx_shard_attach first");
     if (E.nodes_host) return fail(ACX_E_INVAL, "acx_shard_seed: the engine already holds nodes");
     if (rec) {
@@ -989,6 +1009,7 @@ template <typename W> static int shard_seed(ShardEngine<W>& E, const int64_t* re
 
 template <typename W>
 static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int level_first, int fill_q8, int64_t* recv_off, int64_t* words, hipStream_t st) {
+    if (int rc = E.await_ready(st)) return rc;
     if (!E.d.log) return fail(ACX_E_INVAL, "acx_shard_chunk_expand: call acx_shard_attach first");
     const int64_t n_par = c1 - c0;
     if (n_par < 1 || (uint64_t)n_par > E.chunk_parents) return fail(ACX_E_CAPACITY, "acx_shard_chunk_expand: a chunk of %lld parents exceeds the engine's %llu", (long long)n_par, (unsigned long long)E.chunk_parents);
@@ -1031,6 +1052,7 @@ static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int lev
 }
 
 template <typename W> static int shard_chunk_insert(ShardEngine<W>& E, hipStream_t st) {
+    if (int rc = E.await_ready(st)) return rc;
     if (E.geo_inserted >= E.geo_count) return fail(ACX_E_INVAL, "acx_shard_chunk_insert: no expanded chunk is waiting");
     const ChunkGeo& geo = E.geos[(E.geo_head + E.geo_inserted) % ShardEngine<W>::kGeoRing];
     E.geo_inserted++;
@@ -1044,6 +1066,7 @@ template <typename W> static int shard_chunk_insert(ShardEngine<W>& E, hipStream
 }
 
 template <typename W> static int shard_chunk_commit(ShardEngine<W>& E, int64_t max_nodes, hipStream_t st) {
+    if (int rc = E.await_ready(st)) return rc;
     if (E.geo_inserted < 1) return fail(ACX_E_INVAL, "acx_shard_chunk_commit: no inserted chunk is waiting");
     const ChunkGeo geo = E.geos[E.geo_head];
     E.geo_head = (E.geo_head + 1) % ShardEngine<W>::kGeoRing;
@@ -1060,6 +1083,7 @@ template <typename W> static int shard_chunk_commit(ShardEngine<W>& E, int64_t m
 }
 
 template <typename W> static int shard_ctl_snapshot(ShardEngine<W>& E, int slot, hipStream_t st) {
+    if (int rc = E.await_ready(st)) return rc;
     ACX_HIP_TRY(hipMemcpyAsync(E.host.pinned + (size_t)slot * C_WORDS, E.d.ctl, C_WORDS * 8, hipMemcpyDeviceToHost, st));
     ACX_HIP_TRY(hipEventRecord(E.host.ev[slot], st));
     return ACX_OK;
@@ -1074,6 +1098,7 @@ template <typename W> static int shard_ctl_wait(ShardEngine<W>& E, int slot, int
 }
 
 template <typename W> static int shard_find(ShardEngine<W>& E, int64_t gpos, int64_t* id, hipStream_t st) {
+    if (int rc = E.await_ready(st)) return rc;
     *id = -1;
     if (gpos < 0 || gpos > (int64_t)0xFFFFFFFFll) return ACX_OK;
     hipLaunchKernelGGL(k_shard_find<W>, dim3(1), dim3(1), 0, st, E.d, (uint32_t)gpos, E.d_find);
@@ -1194,6 +1219,7 @@ int acx_shard_ctl_wait(acx_shard* h, int slot, int64_t* h_ctl) {
 int acx_shard_fail(acx_shard* h, void* stream) {
     if (!h) return fail(ACX_E_INVAL, "acx_shard_fail: bad argument");
     ACX_SHARD_DISPATCH(&h->any, {
+        if (int rc = E.await_ready((hipStream_t)stream)) return rc;
         hipLaunchKernelGGL(k_shard_fail, dim3(1), dim3(1), 0, (hipStream_t)stream, E.d.ctl, (unsigned long long)FAIL_HOST);
         ACX_HIP_TRY(hipGetLastError());
     });
