@@ -83,6 +83,16 @@ def test_bfs_at_the_bench_budget_repeats_and_agrees_with_the_sharded_engine(dige
     assert not ok and nodes == 10**8 + 1
     sok, spath, st = bfs_sharded(_ak3(), 10**8, batch_parents=1 << 21, want_stats=True)
     assert (sok, spath) == (ok, path) and st["nodes"] == nodes and st["expanded"] == expanded
+    # ... and as two ranks (threads on the one GPU) with the exchange at its real sizes: 2^21-parent chunks, regions of ~0.4 M
+    # records, their capacity adapted from level to level
+    from tests.shard_helpers import run_threads
+
+    def two(comm):
+        return bfs_sharded(_ak3(), 10**8, comm=comm, batch_parents=1 << 21, want_stats=True)
+
+    for tok, tpath, tst in run_threads(2, two):
+        assert (tok, tpath) == (ok, path) and tst["nodes"] == nodes and tst["expanded"] == expanded
+        assert isinstance(tst["region_fill_q8"], list) and min(tst["region_fill_q8"]) < 320 and "region_overflow_reruns" not in tst, tst["region_fill_q8"]
 
 
 @pytest.mark.timeout(300)
