@@ -281,7 +281,7 @@ def _bfs_sharded_once(presentation, max_nodes_to_explore=10000, verbose=False, c
                       engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None, region_fill=None):
     """Same contract as `bfs`: returns (is_search_successful, path or None) [+ stats dict], identical on every rank.
     `batch_parents`: global frontier positions per chunk.  `log_fraction`: expected expanded parents / max_nodes, sizes the
-    record log (it grows by doubling if the estimate is short).  `overlap`: expansion + exchange of chunk k + 1 on a side stream, started beside the dedup of chunk k ("insert": the default when there is an exchange, i.e. world > 1) or beside its commit ("commit"); False: one stream, the default without an exchange.  `region_fill`: capacity of the exchanged regions in 1/256 of the even share of all children -- None: adaptive (1.5 x the fullest region of the previous level, at most the default), an int: that value for every chunk, FILL_DEFAULT: the safe 1.25 x; a search whose tighter regions overflow is rerun with the default."""
+    record log (it grows by doubling if the estimate is short).  `overlap`: expansion + exchange of chunk k + 1 on a side stream, started beside the dedup of chunk k ("insert": the default when there is an exchange, i.e. world > 1) or beside its commit ("commit"); False: one stream, the default without an exchange.  `region_fill`: capacity of the exchanged regions in 1/256 of the even share of all children -- None: adaptive (1.3 x the fullest region of the previous level, at most the default), an int: that value for every chunk, FILL_DEFAULT: the safe 1.25 x; a search whose tighter regions overflow is rerun with the default."""
     from ac_solver.envs.utils import is_array_valid_presentation
 
     import time
@@ -335,7 +335,7 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
     ctl = None
     t_ready = time.perf_counter()  # engine built (device allocations, table fill), root seeded
 
-    # capacity of the exchanged regions (acx_shard_layout): the safe default, a given value, or -- adaptive -- 1.5 x the fullest
+    # capacity of the exchanged regions (acx_shard_layout): the safe default, a given value, or -- adaptive -- 1.3 x the fullest
     # region of the previous level (the maximum over the ranks: one scalar all-reduce per level)
     adaptive = region_fill is None and exchange
     fill = FILL_DEFAULT if region_fill is None else int(region_fill)
@@ -370,7 +370,7 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
         if want_stats:
             st = dict(nodes=int(ctl[CTL_NODES_GLOBAL]), expanded=int(ctl[CTL_EXPANDED]), levels=levels, chunks=chunks, min_len=2 if ok else -int(e[1]), world=world)
             st.update({"comm_" + k: v for k, v in getattr(comm, "stats", {}).items()})
-            st.update(setup_seconds=t_ready - t_begin, loop_seconds=time.perf_counter() - t_ready, region_fill_q8=fills[-4:] if adaptive else fill)
+            st.update(setup_seconds=t_ready - t_begin, loop_seconds=time.perf_counter() - t_ready, region_fill_q8=fills[-4:] if adaptive else fill, region_fill_all=list(fills) if adaptive else fill)
             return ok, path, st
         return ok, path
 
@@ -531,6 +531,8 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
             lf = i64([int(ctl[CTL_LEVEL_FILL])])
             comm.all_reduce(lf, "max")
             lf = int(lf[0])
-            fill = FILL_DEFAULT if lf == 0 else min(FILL_DEFAULT, max(64, lf * 3 // 2 + 8))
+            # (measured level by level on five searches, tools/scratch/shard_fill_levels.py: the fullest region is 0.33 (cyclical) to 0.6 of
+            # the even share, falls by up to 25 % from one level to the next and rises by at most 7 %)
+            fill = FILL_DEFAULT if lf == 0 else min(FILL_DEFAULT, max(64, lf * 13 // 10 + 8))
             fills.append(fill)
     return finish(False, None)

@@ -208,7 +208,7 @@ int acx_shard_key_words(int L); /* 2 for L <= 29, 4 for L <= 61 */
 /* geometry of a chunk of n_parents global parents (pure host arithmetic, no device needed).  fill_q8: capacity of a region at
  * world > 1 in 1/256 of the even share of ALL children (+ two workgroups' worth); <= 0 or > 320: the default 320 = 1.25 x,
  * safe for any input.  The records really sent fill ~38 % of that, and the all-to-all moves whole regions: the orchestrator
- * passes 1.5 x the fullest region of the previous level (control word ACX_SHARD_CTL_LEVEL_FILL, max over the ranks) and reruns
+ * passes 1.3 x the fullest region of the previous level (control word ACX_SHARD_CTL_LEVEL_FILL, max over the ranks) and reruns
  * the search with the default if a region ever overflows (failure code 1). */
 int acx_shard_layout(int64_t n_parents, int world, int key_words, int fill_q8, int64_t *subregions, int64_t *subcap, int64_t *region_words);
 /* node_cap: local nodes; chunk_parents: the largest chunk (global parents) */
