@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(kBmT, ACX_BFS_MULTI_WAVES) k_bfs_multi(const B
         g.act[0] = 0xff;
         g.tlen[0] = (uint8_t)(keyops<W>::len(g.root_k0) + keyops<W>::len(g.root_k1));
         g.depth[0] = 0;
-        const uint64_t hk = hash_key<W>(g.root_k0, g.root_k1);
+        const uint64_t hk = stamp_hash(g.root_k0, g.root_k1);
         g.stab[(uint32_t)hk & g.stmask & ~3u] = slot_make(hk, 0u, kSelfAction);
         s_head = 0;
         s_nodes = 1;
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(kBmT, ACX_BFS_MULTI_WAVES) k_bfs_multi(const B
             ls[it] = 0;
             if (!probe[it]) continue;
             const W c0 = s_k0[c], c1 = s_k1[c];
-            uint32_t q = (uint32_t)(hash_key<W>(c0, c1) >> 40) & (kBmLds - 1);
+            uint32_t q = (uint32_t)(stamp_hash(c0, c1) >> 40) & (kBmLds - 1);
             for (;;) {
                 uint32_t v = s_slot[q];
                 if (v == kEmpty) {
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(kBmT, ACX_BFS_MULTI_WAVES) k_bfs_multi(const B
             if (!probe[it] || s_slot[ls[it]] != c) continue;
             const W c0 = s_k0[c], c1 = s_k1[c];
             const uint32_t p = c / 12u, a = c - 12u * p;
-            const uint64_t hk = hash_key<W>(c0, c1);
+            const uint64_t hk = stamp_hash(c0, c1);
             const unsigned long long me = slot_make(hk, head + p, a);
             uint32_t base = (uint32_t)hk & g.stmask & ~3u, probes = 0;
             bool open = true;
