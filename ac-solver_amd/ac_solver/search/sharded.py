@@ -340,10 +340,11 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
     adaptive = region_fill is None and exchange
     fill = FILL_DEFAULT if region_fill is None else int(region_fill)
     fills = []
+    tight_used = False  # some chunk of this search was expanded with less than the default capacity
 
     def raise_failed(code):
         """every rank gets here at the same chunk with the same code (the largest any rank reported)"""
-        if code == 1 and failure is None and fill < FILL_DEFAULT:
+        if code == 1 and failure is None and tight_used:  # (an overflow shows one chunk late: by then `fill` may be the next level's)
             raise _RegionOverflow()
         raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure or _FAIL_TEXT.get(int(ctl[CTL_FAIL_LOCAL]), 'engine failure')}"
                            if failure is not None or int(ctl[CTL_FAIL_LOCAL]) else f"sharded bfs failed on another rank: {_FAIL_TEXT.get(code, 'engine failure')}")
@@ -408,8 +409,9 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
 
     def produce(c0, c1):
         """expansion + exchange of one chunk on the side stream -> (n_par, event after which its receive area is complete)"""
-        nonlocal failure
+        nonlocal failure, tight_used
         n_par = c1 - c0
+        tight_used = tight_used or (exchange and 0 < fill < FILL_DEFAULT)
         with _on_side():
             # A failing engine call of this rank (a HIP error, an exhausted allocation) must not leave the other ranks waiting in a
             # collective: the rank sends empty regions whose headers say "failed" and every rank stops at that chunk (status 4).
