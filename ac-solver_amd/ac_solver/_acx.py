@@ -100,6 +100,7 @@ SIGNATURES = {
     "acx_shard_seed": (C.c_int, [_vp, _i64p, _vp]),
     "acx_shard_chunk_expand": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, C.c_int, _i64p, _i64p, _vp]),
     "acx_shard_chunk_insert": (C.c_int, [_vp, _vp]),
+    "acx_shard_chunk_insert_dead": (C.c_int, [_vp, _vp]),
     "acx_shard_chunk_commit": (C.c_int, [_vp, C.c_int64, _vp]),
     "acx_shard_ctl_snapshot": (C.c_int, [_vp, C.c_int, _vp]),
     "acx_shard_ctl_wait": (C.c_int, [_vp, C.c_int, _i64p]),

@@ -40,6 +40,7 @@ INF = 1 << 62
 HDR = 4              # int64 header words of a region: records written, success tag, error word, failure code (tests parse regions with it)
 LAG = 2              # chunks the host runs ahead of the control block it reads
 _FORCE_EXCHANGE = False  # tests: route through the communicator even when world == 1
+_FORCE_LAG = None        # tests: run the CPU engines with the GPU path's lagged control block
 _ID_MASK = (1 << 40) - 1
 # control block words (include/acx.h: ACX_SHARD_CTL_*)
 CTL_WORDS = 16
@@ -61,17 +62,29 @@ class TorchDistComm:
     """torch.distributed communicator (nccl == RCCL on ROCm, gloo on CPU).  Both collectives of a chunk are enqueued on the
     current stream and need no host synchronisation (RCCL); gloo (CPU tensors) blocks, which is what the CPU tests want."""
 
-    def __init__(self, device, group=None):
+    def __init__(self, device, group=None, mask_group=None):
+        """`mask_group`: the group (communicator) the per-chunk mask all-reduce runs on.  torch's NCCL backend keeps ONE internal
+        stream per communicator and runs that communicator's collectives in issue order; the orchestrator issues the all-to-all of
+        chunk k + 1 (side stream) BEFORE the mask all-reduce of chunk k (main stream), so on one communicator all-reduce(k) queues
+        behind all-to-all(k + 1), which waits for expand(k + 1) -- the commit of chunk k then waits for the exchange it was meant to
+        overlap.  "own" (or a group from dist.new_group) gives the masks their own communicator: the two collectives of a chunk
+        period are then independent.  Same issue order on every rank either way.  None = the same group as everything else."""
         import torch.distributed as dist
 
         self.dist, self.group, self.device = dist, group, device
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.stats = {"all_to_all_calls": 0, "all_to_all_bytes": 0, "all_reduce_calls": 0, "all_reduce_bytes": 0}
+        if isinstance(mask_group, str):
+            assert mask_group in ("own", "shared"), mask_group
+            mask_group = dist.new_group(ranks=list(range(self.world)) if group is None else dist.get_process_group_ranks(group)) if mask_group == "own" else None
+        self.mask_group = mask_group if mask_group is not None else group
+        self.stats = {"all_to_all_calls": 0, "all_to_all_bytes": 0, "all_reduce_calls": 0, "all_reduce_bytes": 0, "mask_all_reduce_calls": 0, "mask_all_reduce_bytes": 0}
 
     def all_to_all_single(self, recv, send):
         """equal splits: rank d receives send[d * k : (d + 1) * k] of every rank, k = numel / world"""
         assert recv.numel() == send.numel() and send.numel() % self.world == 0
+        if recv.data_ptr() == send.data_ptr():  # world 1 (tests, bench.py's forced one-rank run): the engine's send and receive areas are the same, and RCCL rejects aliased buffers
+            send = send.clone()
         self.dist.all_to_all_single(recv, send, group=self.group)
         self.stats["all_to_all_calls"] += 1
         self.stats["all_to_all_bytes"] += send.numel() * send.element_size()
@@ -81,6 +94,13 @@ class TorchDistComm:
         self.dist.all_reduce(t, op=ops[op], group=self.group)
         self.stats["all_reduce_calls"] += 1
         self.stats["all_reduce_bytes"] += t.numel() * t.element_size()
+        return t
+
+    def all_reduce_masks(self, t):
+        """the per-chunk child masks (sum == or: every (parent, action) child has one owner), on `mask_group`"""
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.mask_group)
+        self.stats["mask_all_reduce_calls"] += 1
+        self.stats["mask_all_reduce_bytes"] += t.numel() * t.element_size()
         return t
 
 
@@ -200,6 +220,11 @@ class HipShardEngine:
         self._acx.check(self._acx.lib.acx_shard_chunk_insert(self.h, self._stream()), "acx_shard_chunk_insert")
         return self.gmask[:(n_par + 1) // 2]
 
+    def chunk_insert_dead(self, n_par):
+        """the failure path: the chunk's masks without the dedup (acx_shard_chunk_insert_dead)"""
+        self._acx.check(self._acx.lib.acx_shard_chunk_insert_dead(self.h, self._stream()), "acx_shard_chunk_insert_dead")
+        return self.gmask[:(n_par + 1) // 2]
+
     def gmask_view(self, n_par):
         return self.gmask[:(n_par + 1) // 2]
 
@@ -263,11 +288,11 @@ class _RegionOverflow(RuntimeError):
 
 
 def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False, comm=None,
-                engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None, region_fill=None):
+                engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None, region_fill=None, timeline=False):
     """`bfs` with the frontier sharded over the ranks of `comm`: see _bfs_sharded_once.  A search whose adaptive (or given) region
     capacity turns out too tight fails on every rank at the same chunk and is rerun from scratch with the safe default."""
     kw = dict(verbose=verbose, cyclically_reduce_after_moves=cyclically_reduce_after_moves, comm=comm, engine_factory=engine_factory,
-              batch_parents=batch_parents, want_stats=want_stats, log_fraction=log_fraction, overlap=overlap)
+              batch_parents=batch_parents, want_stats=want_stats, log_fraction=log_fraction, overlap=overlap, timeline=timeline)
     try:
         return _bfs_sharded_once(presentation, max_nodes_to_explore, region_fill=region_fill, **kw)
     except _RegionOverflow:
@@ -278,10 +303,13 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
 
 
 def _bfs_sharded_once(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False, comm=None,
-                      engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None, region_fill=None):
+                      engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None, region_fill=None, timeline=False):
     """Same contract as `bfs`: returns (is_search_successful, path or None) [+ stats dict], identical on every rank.
     `batch_parents`: global frontier positions per chunk.  `log_fraction`: expected expanded parents / max_nodes, sizes the
-    record log (it grows by doubling if the estimate is short).  `overlap`: expansion + exchange of chunk k + 1 on a side stream, started beside the dedup of chunk k ("insert": the default when there is an exchange, i.e. world > 1) or beside its commit ("commit"); False: one stream, the default without an exchange.  `region_fill`: capacity of the exchanged regions in 1/256 of the even share of all children -- None: adaptive (1.3 x the fullest region of the previous level, at most the default), an int: that value for every chunk, FILL_DEFAULT: the safe 1.25 x; a search whose tighter regions overflow is rerun with the default."""
+    record log (it grows by doubling if the estimate is short).  `overlap`: expansion + exchange of chunk k + 1 on a side stream, started beside the dedup of chunk k ("insert": the default when there is an exchange, i.e. world > 1) or beside its commit ("commit"); False: one stream, the default without an exchange.  `region_fill`: capacity of the exchanged regions in 1/256 of the even share of all children -- None: adaptive (1.3 x the fullest region of the previous level, at most the default), an int: that value for every chunk, FILL_DEFAULT: the safe 1.25 x; a search whose tighter regions overflow is rerun with the default.  `timeline` (GPU, with want_stats): HIP events around every stage of every chunk -- stats["timeline"] gives the median device time of
+    expansion, all-to-all, dedup, mask all-reduce and commit per full-size chunk, the chunk period and `overlap_effective` = their
+    sum / the period (1 = the stages run one after the other, > 1 = the side stream hides work).  A diagnostic: the events cost a
+    little, so timed runs leave it off."""
     from ac_solver.envs.utils import is_array_valid_presentation
 
     import time
@@ -305,7 +333,7 @@ def _bfs_sharded_once(presentation, max_nodes_to_explore=10000, verbose=False, c
     gc_was_on = gc.isenabled()
     gc.disable()
     try:
-        return _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, want_stats, overlap, region_fill, t_begin)
+        return _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, want_stats, overlap, region_fill, t_begin, timeline)
     finally:
         if hasattr(engine, "close"):
             engine.close()
@@ -313,7 +341,29 @@ def _bfs_sharded_once(presentation, max_nodes_to_explore=10000, verbose=False, c
             gc.enable()
 
 
-def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, want_stats, overlap, region_fill, t_begin):
+def _timeline_summary(torch, rows, B):
+    """rows: per chunk (n_par, side events e0 e1 e2, main events m0 m1 m2 m3) -> medians over the full-size chunks (all chunks if none is)"""
+    torch.cuda.synchronize()
+    full = [r for r in rows if r[0] == B] or rows
+    med = lambda v: float(sorted(v)[len(v) // 2]) if v else None  # noqa: E731
+    us = lambda a, b: a.elapsed_time(b) * 1e3  # noqa: E731
+    stages = {"expand_us": [us(r[1], r[2]) for r in full], "all_to_all_us": [us(r[2], r[3]) for r in full], "insert_us": [us(r[4], r[5]) for r in full],
+              "mask_all_reduce_us": [us(r[5], r[6]) for r in full], "commit_us": [us(r[6], r[7]) for r in full],
+              "wait_for_exchange_us": [max(0.0, us(r[3], r[4])) for r in full]}
+    # period: from the end of one chunk's commit to the end of the next one's, between consecutive full-size chunks of a level
+    period = [us(a[7], b[7]) for a, b in zip(rows, rows[1:]) if a[0] == B and b[0] == B and a[8] == b[8]]
+    out = {k: med(v) for k, v in stages.items()}
+    out["chunk_period_us"] = med(period)
+    out["chunks_timed"] = len(full)
+    out["chunk_parents"] = full[0][0] if full else 0
+    parts = [out[k] for k in ("expand_us", "all_to_all_us", "insert_us", "mask_all_reduce_us", "commit_us")]
+    if out["chunk_period_us"] and all(v is not None for v in parts):
+        out["stage_sum_us"] = sum(parts)
+        out["overlap_effective"] = sum(parts) / out["chunk_period_us"]
+    return out
+
+
+def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, want_stats, overlap, region_fill, t_begin, timeline=False):
     import time
 
     torch = _torch()
@@ -321,6 +371,9 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
     KW = engine.KW
     exchange = world > 1 or _FORCE_EXCHANGE
     lag = LAG if dev.type == "cuda" else 0
+    if _FORCE_LAG is not None:
+        lag = int(_FORCE_LAG)
+    reduce_masks = getattr(comm, "all_reduce_masks", None) or (lambda t: comm.all_reduce(t, "sum"))
 
     def i64(values):
         return torch.tensor(values, dtype=torch.int64, device=dev)
@@ -331,23 +384,25 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
     engine.seed(root if rank == owner_root else None)
     F = 1
     levels = chunks = 0
-    failure = None
+    failure = None         # the first exception on this rank's host side
+    fail_hdr_chunk = None  # index (inside the running level) of the first chunk this rank sent with "failed" headers
     ctl = None
     t_ready = time.perf_counter()  # engine built (device allocations, table fill), root seeded
 
     # capacity of the exchanged regions (acx_shard_layout): the safe default, a given value, or -- adaptive -- 1.3 x the fullest
-    # region of the previous level (the maximum over the ranks: one scalar all-reduce per level)
+    # region of the previous level (the maximum over the ranks: it rides on the closing all-reduce of the level)
     adaptive = region_fill is None and exchange
     fill = FILL_DEFAULT if region_fill is None else int(region_fill)
     fills = []
     tight_used = False  # some chunk of this search was expanded with less than the default capacity
 
     def raise_failed(code):
-        """every rank gets here at the same chunk with the same code (the largest any rank reported)"""
+        """every rank gets here at the same point with the same code (the largest any rank reported)"""
         if code == 1 and failure is None and tight_used:  # (an overflow shows one chunk late: by then `fill` may be the next level's)
             raise _RegionOverflow()
-        raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure or _FAIL_TEXT.get(int(ctl[CTL_FAIL_LOCAL]), 'engine failure')}"
-                           if failure is not None or int(ctl[CTL_FAIL_LOCAL]) else f"sharded bfs failed on another rank: {_FAIL_TEXT.get(code, 'engine failure')}")
+        mine = failure is not None or (ctl is not None and int(ctl[CTL_FAIL_LOCAL]))
+        raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure or _FAIL_TEXT.get(int(ctl[CTL_FAIL_LOCAL]) if ctl is not None else 4, 'engine failure')}"
+                           if mine else f"sharded bfs failed on another rank: {_FAIL_TEXT.get(code, 'engine failure')}")
 
     def walk(pref, tail):
         """path of the node `pref` (rank << 40 | id) from the root + tail"""
@@ -362,16 +417,15 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
             rev.append((a, tl))
         return rev[::-1] + tail
 
-    def finish(ok, path):
-        # closing all-reduce: the smallest length any rank generated, and a failure that no later chunk could carry
-        e = i64([int(ctl[CTL_FAIL_LOCAL]) if failure is None else max(int(ctl[CTL_FAIL_LOCAL]), 4), -int(ctl[CTL_MIN_LEN])])
-        comm.all_reduce(e, "max")
-        if int(e[0]):
-            raise_failed(int(e[0]))
+    tl_rows = [] if (timeline and dev.type == "cuda") else None
+
+    def finish(ok, path, min_len):
         if want_stats:
-            st = dict(nodes=int(ctl[CTL_NODES_GLOBAL]), expanded=int(ctl[CTL_EXPANDED]), levels=levels, chunks=chunks, min_len=2 if ok else -int(e[1]), world=world)
+            st = dict(nodes=int(ctl[CTL_NODES_GLOBAL]), expanded=int(ctl[CTL_EXPANDED]), levels=levels, chunks=chunks, min_len=2 if ok else min_len, world=world)
             st.update({"comm_" + k: v for k, v in getattr(comm, "stats", {}).items()})
             st.update(setup_seconds=t_ready - t_begin, loop_seconds=time.perf_counter() - t_ready, region_fill_q8=fills[-4:] if adaptive else fill, region_fill_all=list(fills) if adaptive else fill)
+            if tl_rows:
+                st["timeline"] = _timeline_summary(torch, tl_rows, B)
             return ok, path, st
         return ok, path
 
@@ -407,33 +461,66 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
             if on_gpu:
                 self.ctx.__exit__(*a)
 
-    def produce(c0, c1):
-        """expansion + exchange of one chunk on the side stream -> (n_par, event after which its receive area is complete)"""
-        nonlocal failure, tight_used
+    def stamp(stream):
+        if tl_rows is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        return ev
+
+    def set_failed(e):
+        nonlocal failure
+        failure = failure or e
+        try:
+            engine.fail_local()  # sticky on the device: the headers of every later chunk this engine expands say so
+        except Exception:  # noqa: BLE001
+            pass
+
+    # A failure on this rank's HOST side (an engine call that raises: a HIP error, an exhausted allocation) must not leave the
+    # other ranks waiting in a collective, and must not leave THIS rank issuing collectives the others have stopped issuing.
+    #   * From the failure on, every chunk this rank produces is "dead": no engine call, empty regions whose headers carry failure
+    #     code 4.  Every healthy rank's k_shard_decide turns its status to 4 at the first dead chunk (index `fail_hdr_chunk` of the
+    #     level) and leaves the chunk loop once it has read that control block, `lag` chunks later.  This rank cannot see that in
+    #     its own control block (a dead chunk does not go through its engine), so it leaves by the same rule: after the iteration
+    #     of chunk fail_hdr_chunk + lag -- every rank has then issued the same collectives.
+    #   * Chunks that were expanded by the engine before the failure are still dedup'ed and committed through it (a dedup call that
+    #     raised is replaced by `chunk_insert_dead`: masks only), so the engine's ring of open chunks stays in step and its decide
+    #     kernel keeps taking the global decisions (budget / solved / a failure seen) from the all-reduced masks: the control
+    #     blocks this rank reads for chunks before the first dead one are as valid as every other rank's.
+    #   * The level's closing all-reduce carries the failure code: a failure in the last chunk of a level, or one that no header
+    #     carried, ends every rank there, whatever status each of them read.
+    def produce(c0, c1, idx):
+        """expansion + exchange of one chunk on the side stream -> (n_par, event after which its receive area is complete, dead, stamps)"""
+        nonlocal tight_used, fail_hdr_chunk
         n_par = c1 - c0
         tight_used = tight_used or (exchange and 0 < fill < FILL_DEFAULT)
         with _on_side():
-            # A failing engine call of this rank (a HIP error, an exhausted allocation) must not leave the other ranks waiting in a
-            # collective: the rank sends empty regions whose headers say "failed" and every rank stops at that chunk (status 4).
-            try:
-                send, recv = engine.chunk_expand(c0, c1, c0 == 0, fill)
-            except Exception as e:  # noqa: BLE001
-                if not exchange:
-                    raise
-                failure = failure or e
-                engine.fail_local()
+            e0 = stamp(side)
+            dead = failure is not None and exchange
+            if not dead:
+                try:
+                    send, recv = engine.chunk_expand(c0, c1, c0 == 0, fill)
+                except Exception as e:  # noqa: BLE001
+                    if not exchange:
+                        raise
+                    set_failed(e)
+                    dead = True
+            if dead:
                 S, _, rw = engine.layout(n_par, fill)
                 send = torch.zeros(S * world * rw, dtype=torch.int64, device=dev)
                 hdr = send.view(S * world, rw)
                 hdr[:, 1], hdr[:, 2], hdr[:, 3] = INF, INF, 4
                 recv = torch.empty_like(send)
+                if fail_hdr_chunk is None:
+                    fail_hdr_chunk = idx
+            e1 = stamp(side)
             if exchange:
                 comm.all_to_all_single(recv, send)
             ev = None
             if on_gpu:
-                ev = torch.cuda.Event()
+                ev = torch.cuda.Event(enable_timing=tl_rows is not None)
                 ev.record(side)
-        return n_par, ev
+        return n_par, ev, dead, (e0, e1)
 
     # Chunk sizes.  A chunk is expanded and deduplicated as a whole even when the budget runs out at its first parents, so near
     # the end of the budget the chunks shrink to what the remaining budget is expected to need: new states per parent so far in
@@ -460,6 +547,7 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
         want = (want + 2047) // 2048 * 2048
         return min(n, want)
 
+    min_len = INF
     while F > 0:
         levels += 1
         pending = []  # snapshot slots of the chunks whose control block has not been read yet
@@ -474,34 +562,45 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
             n = next_size(c_next, sizes, n_read, new_read)
             sizes.append(n)
             c_next += n
-            return produce(c_next - n, c_next)
+            return produce(c_next - n, c_next, len(sizes) - 1)
 
         ready = produce_next()
-        while ready is not None and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING):
-            n_par, ev = ready
+        while ready is not None and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING) and (fail_hdr_chunk is None or k <= fail_hdr_chunk + lag):
+            n_par, ev, dead, (e0, e1) = ready
             ready = None
             if c_next < F and overlap != "commit":
                 ready = produce_next()  # runs beside this chunk's dedup and commit
             if ev is not None:
                 main.wait_event(ev)
-            try:
-                gmask = engine.chunk_insert(n_par)
-            except Exception as e:  # noqa: BLE001
-                failure = failure or e
-                engine.fail_local()
-                gmask = engine.gmask_view(n_par)  # the engine's own buffer: its commit reads the all-reduced masks from there
-                gmask.zero_()
+            m0 = stamp(main)
+            if dead:  # never went through the engine: nothing to dedup, nothing to commit; the collectives still pair up
+                gmask = torch.zeros((n_par + 1) // 2, dtype=torch.int32, device=dev)
+            else:
+                try:
+                    gmask = engine.chunk_insert(n_par)
+                except Exception as e:  # noqa: BLE001
+                    set_failed(e)
+                    try:  # masks only: the chunk stays in the engine's ring, so its commit (and the decide kernel in it) still runs
+                        gmask = engine.chunk_insert_dead(n_par)
+                    except Exception:  # noqa: BLE001
+                        gmask = engine.gmask_view(n_par)  # the engine's own buffer: its commit reads the all-reduced masks from there
+                        gmask.zero_()
+            m1 = stamp(main)
             if c_next < F and overlap == "commit":
                 if on_gpu:
                     side.wait_stream(main)  # not before this chunk's dedup is through
                 ready = produce_next()  # runs beside this chunk's mask all-reduce and commit
             if exchange:
-                comm.all_reduce(gmask, "sum")  # every (parent, action) child has exactly one owner, so SUM == OR
-            try:
-                engine.chunk_commit(max_nodes)
-            except Exception as e:  # noqa: BLE001
-                failure = failure or e
-                engine.fail_local()
+                reduce_masks(gmask)  # every (parent, action) child has exactly one owner, so SUM == OR
+            m2 = stamp(main)
+            if not dead:
+                try:
+                    engine.chunk_commit(max_nodes)
+                except Exception as e:  # noqa: BLE001
+                    set_failed(e)
+            m3 = stamp(main)
+            if tl_rows is not None:
+                tl_rows.append((n_par, e0, e1, ev, m0, m1, m2, m3, levels))
             engine.ctl_snapshot(k % (lag + 2))
             pending.append(k % (lag + 2))
             chunks += 1
@@ -515,8 +614,22 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
         while pending and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING):  # end of the level: the one synchronisation
             ctl = engine.ctl_wait(pending.pop(0))
         status = int(ctl[CTL_STATUS])
+        # closing all-reduce of the level (max): [failure code, -(smallest total length generated), fullest region received].
+        # Every rank does it here, whatever status it read, so a failure that no header carried (the last chunk of a level; a
+        # region overflow noticed after the search ended; an exception on one rank's host side) ends every rank at the same point.
+        code = int(ctl[CTL_FAIL_LOCAL])
         if status == ST_FAILED:
-            raise_failed(int(ctl[CTL_FAIL_SEEN]))
+            code = max(code, int(ctl[CTL_FAIL_SEEN]))
+        if failure is not None:
+            code = max(code, 4)
+        closing = [code, -int(ctl[CTL_MIN_LEN]), int(ctl[CTL_LEVEL_FILL])]
+        if exchange:
+            e = i64(closing)
+            comm.all_reduce(e, "max")
+            closing = [int(v) for v in e.tolist()]
+        min_len = min(min_len, -closing[1])
+        if closing[0]:
+            raise_failed(closing[0])
         if status == ST_MOVE_ERROR:
             # the reference executes this move before it stops: its ACMove raises (every rank sees the same words)
             raise AssertionError("a move emptied a relator during the search: the reference's ACMove raises here")
@@ -525,16 +638,14 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
             mine = engine.find(tag // 12)
             pref = i64([(rank << 40) | mine if mine >= 0 else -1])
             comm.all_reduce(pref, "max")
-            return finish(True, walk(int(pref[0]), [(tag % 12, 2)]))
+            return finish(True, walk(int(pref[0]), [(tag % 12, 2)]), min_len)
         if status == ST_BUDGET:
-            return finish(False, None)
+            return finish(False, None, min_len)
         F_prev, F, nodes_seen = F, int(ctl[CTL_NEXT_COUNT]), int(ctl[CTL_NODES_GLOBAL])
         if adaptive:  # the fullest region any rank received in this level (0: no chunk large enough to tell) sizes the next level's regions
-            lf = i64([int(ctl[CTL_LEVEL_FILL])])
-            comm.all_reduce(lf, "max")
-            lf = int(lf[0])
+            lf = closing[2]
             # (measured level by level on five searches, tools/scratch/shard_fill_levels.py: the fullest region is 0.33 (cyclical) to 0.6 of
             # the even share, falls by up to 25 % from one level to the next and rises by at most 7 %)
             fill = FILL_DEFAULT if lf == 0 else min(FILL_DEFAULT, max(64, lf * 13 // 10 + 8))
             fills.append(fill)
-    return finish(False, None)
+    return finish(False, None, min_len)

@@ -282,8 +282,8 @@ __global__ void __launch_bounds__(256) k_bfs_count(SearchDev<W> d, uint32_t m, u
     static_assert(kCompactItems == 32, "two 16-candidate halves per lane");
     if (cur) {  // run-ahead mode (m arrives as the capacity 12 * bmax)
         if (cur->status) return;
-        const uint32_t avail = 12u * (cur->nodes - cur->head);
-        m = avail < m ? avail : m;
+        const uint32_t np = cur->nodes - cur->head;  // clamp in PARENTS (as cursor_begin and k_bfs_expand_insert do): 12 x a frontier above 3.6e8 nodes wraps 32 bits
+        if (np < m / 12u) m = 12u * np;
     }
     const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tile >= (m + kCompactTile - 1) / kCompactTile) return;  // a full-size grid over a short batch
@@ -324,8 +324,8 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
     if (cur) {  // run-ahead mode (m arrives as the capacity 12 * bmax)
         if (cur->status) return;
         pbegin = cur->head;
-        const uint32_t avail = 12u * (cur->nodes - pbegin);
-        m = avail < m ? avail : m;
+        const uint32_t np = cur->nodes - pbegin;  // clamp in PARENTS: 12 x a frontier above 3.6e8 nodes wraps 32 bits
+        if (np < m / 12u) m = 12u * np;
         base = cur->nodes;
     }
     const uint32_t ntiles = (m + kCompactTile - 1) / kCompactTile, tile = blockIdx.x;

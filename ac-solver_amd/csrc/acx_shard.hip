@@ -1051,7 +1051,8 @@ static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int lev
     return ACX_OK;
 }
 
-template <typename W> static int shard_chunk_insert(ShardEngine<W>& E, hipStream_t st) {
+// `dedup` false (acx_shard_chunk_insert_dead): the masks only -- the chunk's records are dropped, the chunk stays in the ring
+template <typename W> static int shard_chunk_insert(ShardEngine<W>& E, hipStream_t st, bool dedup = true) {
     if (int rc = E.await_ready(st)) return rc;
     if (E.geo_inserted >= E.geo_count) return fail(ACX_E_INVAL, "acx_shard_chunk_insert: no expanded chunk is waiting");
     const ChunkGeo& geo = E.geos[(E.geo_head + E.geo_inserted) % ShardEngine<W>::kGeoRing];
@@ -1059,7 +1060,7 @@ template <typename W> static int shard_chunk_insert(ShardEngine<W>& E, hipStream
     const unsigned tiles = (unsigned)((geo.subcap + 255) / 256), regions = (unsigned)(kShardSub * E.world);
     unsigned gx = tiles;
     if (E.insert_wgs) gx = std::min(tiles, std::max(1u, E.insert_wgs / regions));
-    hipLaunchKernelGGL(k_shard_insert<W>, dim3(gx, regions), dim3(256), 0, st, E.d, geo, tiles);
+    if (dedup) hipLaunchKernelGGL(k_shard_insert<W>, dim3(gx, regions), dim3(256), 0, st, E.d, geo, tiles);
     hipLaunchKernelGGL(k_shard_pack<W>, dim3((geo.n_par + kPackParents - 1) / kPackParents), dim3(256), 0, st, E.d, geo.n_par);
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
@@ -1199,6 +1200,11 @@ int acx_shard_chunk_expand(acx_shard* h, int64_t c0, int64_t c1, int level_first
 int acx_shard_chunk_insert(acx_shard* h, void* stream) {
     if (!h) return fail(ACX_E_INVAL, "acx_shard_chunk_insert: bad argument");
     ACX_SHARD_DISPATCH(&h->any, return shard_chunk_insert<W>(E, (hipStream_t)stream));
+}
+
+int acx_shard_chunk_insert_dead(acx_shard* h, void* stream) {
+    if (!h) return fail(ACX_E_INVAL, "acx_shard_chunk_insert_dead: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, return shard_chunk_insert<W>(E, (hipStream_t)stream, false));
 }
 
 int acx_shard_chunk_commit(acx_shard* h, int64_t max_nodes, void* stream) {

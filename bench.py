@@ -87,6 +87,9 @@ def ms_pool_at_L(L):
     return np.stack(pool)
 
 
+CPU_SCALE = float(os.environ.get("ACX_BENCH_CPU_SECONDS", "0")) / 12.0 or 1.0  # (tests: shrink the CPU legs)
+
+
 def cpu_baseline(states, seed, budget_s=12.0):
     """Oracle ACEnv.step (1 thread) on a bounded sample of the same workload: 4096-env slices x 64 steps."""
     from oracle import ac_oracle as O
@@ -108,7 +111,7 @@ def cpu_baseline(states, seed, budget_s=12.0):
     dt = time.perf_counter() - t0
     out = {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
            "sample": f"{steps} ACEnv.step calls ({n} envs, MS initial states, L={L}) by oracle/ac_oracle.c in {dt:.1f} s"}
-    out["all_cores"] = cpu_baseline_all_cores(states, seed + 1)
+    out["all_cores"] = cpu_baseline_all_cores(states, seed + 1, budget_s=budget_s / 2)
     return out
 
 
@@ -159,10 +162,15 @@ def ak3_at_L():
     return p
 
 
-def search_numbers(world, rank, dev, budget, use_dist=False):
+STRONG_BUDGET = int(os.environ.get("ACX_BENCH_STRONG_BUDGET", 4 * 10**8))        # the 1 -> 8 GPU strong-scaling search: >= 5e7 nodes per rank at 8 ranks (the 1e8 search keeps 1.25e7: latency-bound by construction)
+
+
+def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
     """BFS nodes/s with the frontier sharded over `world` GPUs (one search, strong scaling) and, on one GPU, the
     fused single-GPU frontier (acx_search) for bfs and greedy_search.  AK(3) at L=25 does not trivialise, so the
-    searches run to the node budget."""
+    searches run to the node budget.  `out` is filled stage by stage (the watchdog of a multi-rank run prints what is there)."""
+    import gc
+
     import torch
     import torch.distributed as dist
 
@@ -170,77 +178,91 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
     from ac_solver.search._common import run_search
     from ac_solver.search.sharded import SingleComm, TorchDistComm, bfs_sharded
 
+    out = {} if out is None else out
     p = ak3_at_L()
-    comm = TorchDistComm(dev) if use_dist else SingleComm()
-    t0 = time.perf_counter()
-    bfs_sharded(p, budget, comm=comm, batch_parents=1 << 21)  # warm-up at full size: allocator (GBs of first-time hipMalloc), kernels, communicator
-    torch.cuda.synchronize()
-    first_call = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    import gc
+    if use_dist and world == 1:  # the forced one-rank run (ACX_BENCH_FORCE_DIST): route through the communicator as a multi-rank run does
+        import ac_solver.search.sharded as _sh
 
-    samples, split = [], []
-    for _ in range(3):  # the median of three timed searches, the garbage collector off while the clock runs (as timeit does: a full
-        # collection of this process's heap takes 25-30 ms and landed in one search out of four)
-        gc.collect()
-        gc.disable()
+        _sh._FORCE_EXCHANGE = True
+    comms = {"shared": TorchDistComm(dev) if use_dist else SingleComm()}
+
+    def timed_sharded(comm, b, reps=3):
+        """median of `reps` timed searches (MAX over the ranks each) behind a full-size warm-up call; no garbage collection while the clock runs
+        (as timeit does: a full collection of this process's heap takes 25-30 ms and landed in one search out of four)"""
         t0 = time.perf_counter()
-        ok, path, st = bfs_sharded(p, budget, comm=comm, batch_parents=1 << 21, want_stats=True)
+        bfs_sharded(p, b, comm=comm, batch_parents=1 << 21)  # warm-up at full size: allocator (GBs of first-time hipMalloc), kernels, communicator
         torch.cuda.synchronize()
+        first_call = time.perf_counter() - t0
         if use_dist:
             dist.barrier()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if use_dist:
-            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        gc.enable()
-        samples.append(float(dt[0]))
-        split.append((round(st.get("setup_seconds", 0.0), 4), round(st.get("loop_seconds", 0.0), 4)))
-    dt = torch.tensor([sorted(samples)[1]], dtype=torch.float64, device=dev)
-    # SURVEY 8(d)'s formula for the frontier ((64 + 72 f) B per generated child) + the xGMI term (n - 1) / n x 32 B per child; the
-    # children are 12 per expanded parent
-    children = 12 * st["expanded"]
-    f_new = st["nodes"] / max(children, 1)
-    algo = (64.0 + 72.0 * f_new) * children
-    secs = float(dt[0])
-    out = {"bfs_sharded": {"nodes_per_s": st["nodes"] / secs, "nodes": st["nodes"], "seconds": secs, "samples_seconds": samples, "samples_setup_loop_seconds": split, "first_call_seconds": first_call,
-                           "levels": st["levels"], "chunks": st["chunks"], "expanded": st["expanded"],
-                           "n_gpus": world, "budget": budget, "input": "AK(3) at max_relator_len=25, cyclical=False", "scaling": "strong",
-                           "exchange": ("per chunk: ONE equal-split all-to-all of child-record regions (headers carry counts and the success / error words) + "
-                                        "ONE all-reduce of a 12-bit child mask per parent (RCCL); expansion + all-to-all of chunk k+1 run on a side stream "
-                                        "beside the dedup + commit of chunk k") if world > 1 else "none (world 1: the chunk is expanded straight into its receive area)",
-                           # self-diagnosis of the first real multi-GPU run: how many ranks the communicator saw and what it moved
-                           "rccl_ranks_seen": world if use_dist else 0,
-                           "backend": dist.get_backend() if use_dist else None,
-                           "collectives": {k[5:]: v for k, v in st.items() if k.startswith("comm_")},
-                           "exchange_bytes_per_chunk_per_rank": (st.get("comm_all_to_all_bytes", 0) / max(st.get("comm_all_to_all_calls", 1), 1)),
-                           "roofline": {"bound": "hbm", "achieved": algo / secs / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
-                                        "frac": algo / secs / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
-                                        "kernel": "k_shard_insert<u64> + k_shard_expand<u64> + k_shard_commit<u64> (whole search, wall time)",
-                                        "algorithmic_bytes": algo, "bytes_per_child": 64.0 + 72.0 * f_new, "children": children}}}
+        samples, split, st = [], [], None
+        for _ in range(reps):
+            gc.collect()
+            gc.disable()
+            t0 = time.perf_counter()
+            ok, path, st = bfs_sharded(p, b, comm=comm, batch_parents=1 << 21, want_stats=True)
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            gc.enable()
+            samples.append(float(dt[0]))
+            split.append((round(st.get("setup_seconds", 0.0), 4), round(st.get("loop_seconds", 0.0), 4)))
+        secs = sorted(samples)[len(samples) // 2]
+        # SURVEY 8(d)'s formula for the frontier ((64 + 72 f) B per generated child); the children are 12 per expanded parent
+        children = 12 * st["expanded"]
+        f_new = st["nodes"] / max(children, 1)
+        algo = (64.0 + 72.0 * f_new) * children
+        return {"nodes_per_s": st["nodes"] / secs, "nodes": st["nodes"], "seconds": secs, "samples_seconds": samples, "samples_setup_loop_seconds": split,
+                "first_call_seconds": first_call, "levels": st["levels"], "chunks": st["chunks"], "expanded": st["expanded"], "n_gpus": world, "budget": b,
+                "input": "AK(3) at max_relator_len=25, cyclical=False", "scaling": "strong",
+                "collectives": {k[5:]: v for k, v in st.items() if k.startswith("comm_")},
+                "exchange_bytes_per_chunk_per_rank": (st.get("comm_all_to_all_bytes", 0) / max(st.get("comm_all_to_all_calls", 1), 1)),
+                "region_fill_q8": st.get("region_fill_q8"), "region_overflow_reruns": st.get("region_overflow_reruns", 0),
+                "roofline": {"bound": "hbm", "achieved": algo / secs / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                             "frac": algo / secs / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
+                             "kernel": "k_shard_insert<u64> + k_shard_expand<u64> + k_shard_commit<u64> (whole search, wall time)",
+                             "algorithmic_bytes": algo, "bytes_per_child": 64.0 + 72.0 * f_new, "children": children}}
+
+    def timeline_of(comm, b):
+        """one more search with HIP events around every stage of every chunk (not a timed sample: the events cost a little)"""
+        try:
+            _, _, st = bfs_sharded(p, b, comm=comm, batch_parents=1 << 21, want_stats=True, timeline=True)
+            return st.get("timeline")
+        except Exception as e:  # noqa: BLE001
+            return {"error": f"{type(e).__name__}: {e}"}
+
+    exchange_text = ("per chunk: ONE equal-split all-to-all of child-record regions (headers carry counts and the success / error words) + "
+                     "ONE all-reduce of a 12-bit child mask per parent (RCCL); expansion + all-to-all of chunk k+1 run on a side stream "
+                     "beside the dedup + commit of chunk k") if world > 1 else "none (world 1: the chunk is expanded straight into its receive area)"
+    one = timed_sharded(comms["shared"], budget)
+    one.update({"exchange": exchange_text, "rccl_ranks_seen": world if use_dist else 0, "backend": dist.get_backend() if use_dist else None,
+                "mask_all_reduce_group": "shared" if use_dist else None})
     tf = os.path.join(ROOT, "profiles", "search_traffic.json")
     if world == 1 and os.path.exists(tf):  # HBM bytes of the same search from rocprofv3 --pmc passes (profiles/README.md)
         with open(tf) as fh:
             t = json.load(fh).get("bfs_sharded_ak3_1e8")
-        if t and t.get("children") == children:
-            out["bfs_sharded"]["roofline"]["traffic"] = t["hbm_bytes"]
-            out["bfs_sharded"]["roofline"]["traffic_source"] = t["source"]
+        if t and t.get("children") == one["roofline"]["children"]:
+            one["roofline"]["traffic"] = t["hbm_bytes"]
+            one["roofline"]["traffic_source"] = t["source"]
+    out["bfs_sharded"] = one
+    # where a chunk period goes: device time of the expansion, the all-to-all, the dedup, the mask all-reduce and the commit per
+    # full-size chunk, and how much of their sum the side stream hides (overlap_effective > 1)
+    one["timeline"] = timeline_of(comms["shared"], budget)
+    # the strong-scaling point of the 1 -> 8 GPU curve: the SAME 4e8-node search at every N
+    try:
+        out["bfs_sharded_strong"] = timed_sharded(comms["shared"], STRONG_BUDGET, reps=3)
+        out["bfs_sharded_strong"]["timeline"] = timeline_of(comms["shared"], STRONG_BUDGET)
+        out["bfs_sharded_strong"]["note"] = "the curve to read across N: one 4e8-node search, >= 5e7 nodes per rank at 8 ranks"
+    except Exception as e:  # noqa: BLE001
+        out["bfs_sharded_strong"] = {"error": f"{type(e).__name__}: {e}"}
     if world > 1:
         # the same frontier with the budget grown with the number of GPUs (weak scaling: 1e8 nodes per GPU)
         try:
-            wb = budget * world
-            bfs_sharded(p, wb, comm=comm, batch_parents=1 << 21)
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
-            _, _, stw = bfs_sharded(p, wb, comm=comm, batch_parents=1 << 21, want_stats=True)
-            torch.cuda.synchronize()
-            dist.barrier()
-            dtw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-            dist.all_reduce(dtw, op=dist.ReduceOp.MAX)
-            out["bfs_sharded_weak"] = {"nodes_per_s": stw["nodes"] / float(dtw[0]), "nodes": stw["nodes"], "seconds": float(dtw[0]), "levels": stw["levels"],
-                                       "n_gpus": world, "budget": wb, "scaling": "weak"}
+            out["bfs_sharded_weak"] = timed_sharded(comms["shared"], budget * world, reps=2)
+            out["bfs_sharded_weak"]["scaling"] = "weak"
         except Exception as e:  # noqa: BLE001
             out["bfs_sharded_weak"] = {"error": f"{type(e).__name__}: {e}"}
     # BASELINE config 4 shape: bfs over the 1190 Miller-Schupp presentations; the searches are independent, so they are dealt
@@ -323,6 +345,27 @@ def search_numbers(world, rank, dev, budget, use_dist=False):
                          "roofline": search_roofline(s1, "k_bfs_expand_insert<u64> (expand + visited-table dedup, one launch per batch)"
                                                      if kind == _acx.SEARCH_BFS else "k_greedy_persistent<u64> (one workgroup)",
                                                      "bfs_ak3_1e8" if kind == _acx.SEARCH_BFS else "greedy_ak3_1e7")}
+    if use_dist:
+        # LAST (everything above is already recorded should this stage hang): the mask all-reduce on a communicator of its own.
+        # torch's NCCL backend runs a communicator's collectives in issue order on one internal stream, and the orchestrator issues
+        # all-to-all(k + 1) before all-reduce(k): on the shared communicator commit(k) waits for the exchange of chunk k + 1.
+        try:
+            comms["own"] = TorchDistComm(dev, mask_group="own")
+            own = {}
+            for name, b in (("bfs_sharded", budget), ("bfs_sharded_strong", STRONG_BUDGET)):
+                own[name] = timed_sharded(comms["own"], b)
+                own[name]["timeline"] = timeline_of(comms["own"], b)
+                own[name]["mask_all_reduce_group"] = "own"
+                shared = out.get(name, {})
+                if "nodes_per_s" in shared:
+                    shared["by_mask_group"] = {"shared": {"seconds": shared["seconds"], "nodes_per_s": shared["nodes_per_s"], "timeline": shared.get("timeline")},
+                                               "own": {"seconds": own[name]["seconds"], "nodes_per_s": own[name]["nodes_per_s"], "timeline": own[name]["timeline"]}}
+                    if own[name]["nodes_per_s"] > shared["nodes_per_s"]:  # the line's figure is the better of the two, and says which
+                        for k in ("nodes_per_s", "seconds", "samples_seconds", "samples_setup_loop_seconds", "roofline", "timeline", "collectives"):
+                            shared[k] = own[name][k]
+                        shared["mask_all_reduce_group"] = "own"
+        except Exception as e:  # noqa: BLE001
+            out["mask_group_own"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
@@ -543,9 +586,80 @@ def extra_env_numbers(dev, pool):
     return out
 
 
+def launch_ranks(n, argv, child=None, env=None, grace_s=20.0):
+    """`python bench.py --gpus N` outside a launcher: start N FRESH rank processes (one per GPU) and relay rank 0's one JSON line.
+
+    This process never imports torch and never touches HIP: it only spawns children -- a process that has initialised the GPU must
+    not be replaced or forked on this pool.  Each child gets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free
+    MASTER_PORT, exactly what `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` (the driver's launcher) would export,
+    and runs this same file with the same arguments.  Rank 0's stdout is passed through; the other ranks' stdout goes to stderr.
+    Returns the exit code: 0 only if EVERY rank exited 0; when one rank fails the others are given `grace_s` seconds (their
+    collectives are gone) and are then terminated by PID.  `child` (tests): the command to run instead of this file."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = list(child) if child is not None else [sys.executable, os.path.abspath(__file__)]
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ACX_BENCH_LAUNCHED="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on these hosts
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd + list(argv), env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    import threading
+
+    lines = []
+
+    def pump():
+        for raw in procs[0].stdout:
+            lines.append(raw.decode("utf-8", "replace"))
+
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    codes = [None] * n
+    failed_at = None
+    while any(c is None for c in codes):
+        for r, pr in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = pr.poll()
+                if codes[r] not in (None, 0) and failed_at is None:
+                    failed_at = time.monotonic()
+                    print(f"[bench] rank {r} exited with code {codes[r]}; waiting {grace_s:.0f} s for the other ranks", file=sys.stderr, flush=True)
+        if failed_at is not None and time.monotonic() - failed_at > grace_s:
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    pr.terminate()  # by PID: the children this call started, nothing else
+                    try:
+                        codes[r] = pr.wait(10)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        codes[r] = pr.wait()
+        time.sleep(0.05)
+    th.join(5)
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    if bad:
+        print(f"[bench] --gpus {n}: rank(s) {', '.join(f'{r} (exit {c})' for r, c in bad)} failed; no result line is relayed", file=sys.stderr, flush=True)
+        return next((c for _, c in bad if c and c > 0), 1)
+    if len(json_lines) != 1:
+        print(f"[bench] --gpus {n}: rank 0 printed {len(json_lines)} JSON lines instead of one", file=sys.stderr, flush=True)
+        return 1
+    got = json.loads(json_lines[0])
+    if got.get("n_gpus") != n:
+        print(f"[bench] --gpus {n}: rank 0 reports n_gpus = {got.get('n_gpus')}", file=sys.stderr, flush=True)
+        return 1
+    sys.stdout.write(json_lines[0] if json_lines[0].endswith("\n") else json_lines[0] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one process per GPU).  Under a launcher (WORLD_SIZE set) it must agree with it; "
+                                                           "without one and N > 1, bench.py starts the N rank processes itself")
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=N_ENVS, help="envs per GPU (default: BASELINE config 2)")
@@ -557,13 +671,24 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the 4 Mi-env and fused-rollout context numbers")
     args = ap.parse_args()
 
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (args.gpus or 1) > 1:
+        # no launcher around us: become one -- BEFORE torch is imported or any HIP call is made in this process
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if env_world is not None and args.gpus is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher exported WORLD_SIZE={env_world}: refusing to report a mislabelled line")
+
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     use_dist = world > 1 or bool(os.environ.get("ACX_BENCH_FORCE_DIST"))  # the env var drives the N > 1 code path on one GPU (testing)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count()  # (counting does not initialise the GPU)
+    if n_dev <= local or n_dev < int(os.environ.get("LOCAL_WORLD_SIZE", "1")):  # (torchrun and launch_ranks both export LOCAL_WORLD_SIZE)
+        # one process per GPU: N ranks need N devices -- never N ranks sharing a device under an `n_gpus: N` label
+        raise SystemExit(f"bench.py: rank {rank} of {world} needs GPU {local}, but this node shows {n_dev} device(s); --gpus {world} cannot be measured here")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the AC hot path only exists as HIP kernels (no CPU fallback)")
     torch.cuda.set_device(local)
@@ -749,13 +874,18 @@ def main():
     # already in hand: if they have not come back after SEARCH_TIMEOUT_S seconds (a rank lost, a collective stuck), rank 0
     # still prints its one JSON line and every rank leaves, instead of the whole job hanging.
     watchdog = None
+    partial, extras_box = {}, [None]
     if use_dist and not args.no_search:
         import threading
 
         def give_up():
+            # the headline and every finished stage of the secondary measurements are printed; the stage that hung is named
             if rank == 0:
-                print(json.dumps(headline(None, {"error": f"secondary measurements did not finish within {SEARCH_TIMEOUT_S} s"})), flush=True)
-            os._exit(3)  # every rank leaves with a failure code: the headline is printed, but the run did hang
+                got = dict(partial)
+                got["error"] = f"secondary measurements did not finish within {SEARCH_TIMEOUT_S} s (finished stages: {sorted(partial)})"
+                print(json.dumps(headline(extras_box[0], got)), flush=True)
+            # exit code: 0 when the sharded search itself was measured (the line is usable and says what is missing), else failure
+            os._exit(0 if "nodes_per_s" in partial.get("bfs_sharded", {}) else 3)
 
         watchdog = threading.Timer(SEARCH_TIMEOUT_S, give_up)
         watchdog.daemon = True
@@ -767,26 +897,29 @@ def main():
             extras = extra_env_numbers(dev, pool)
         except Exception as e:
             extras = {"error": f"{type(e).__name__}: {e}"}
+    extras_box[0] = extras
     search = None
     if not args.no_search:
         try:
-            search = search_numbers(world, rank, dev, args.search_budget, use_dist)
+            search = search_numbers(world, rank, dev, args.search_budget, use_dist, partial)
         except Exception as e:  # the headline line must survive a failure of the secondary measurement
-            search = {"error": f"{type(e).__name__}: {e}"}
+            search = dict(partial)
+            search["error"] = f"{type(e).__name__}: {e}"
     if watchdog is not None:
         watchdog.cancel()
 
-    if rank == 0:
-        out = headline(extras, search)
-        if not args.no_cpu_baseline and world == 1 and not use_dist:
-            out["cpu_baseline"] = cpu_baseline(states, 0)
-            if not args.no_search:
-                out["cpu_baseline"].update(cpu_search_baseline())
-            out["cpu_baseline"]["python_numpy"] = cpu_python_baseline(states)
-        print(json.dumps(out), flush=True)
+    # every rank is through with the GPU: the communicator goes first, so that ranks 1.. can leave while rank 0 times the CPU legs
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        out = headline(extras, search)
+        if not args.no_cpu_baseline:  # on every line, N = 1 or not (rank 0's host cores, after the collectives)
+            out["cpu_baseline"] = cpu_baseline(states, 0, budget_s=12.0 * CPU_SCALE)
+            if not args.no_search:
+                out["cpu_baseline"].update(cpu_search_baseline(10**6 if CPU_SCALE == 1.0 else 10**4))
+            out["cpu_baseline"]["python_numpy"] = cpu_python_baseline(states, budget_s=4.0 * CPU_SCALE)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -227,6 +227,10 @@ int acx_shard_seed(acx_shard *h, const int64_t *h_record, void *stream);
 int acx_shard_chunk_expand(acx_shard *h, int64_t c0, int64_t c1, int level_first, int fill_q8, int64_t *recv_off, int64_t *words, void *stream);
 /* exact dedup of what the receive area holds against the visited table and among itself (minimum tag wins) -> gmask */
 int acx_shard_chunk_insert(acx_shard *h, void *stream);
+/* the failure path of a rank whose dedup call could not run: the oldest expanded chunk's masks WITHOUT the dedup (its records are
+ * dropped), so that the chunk stays in the engine's ring and acx_shard_chunk_commit still takes the global decisions from the
+ * all-reduced masks; the caller has marked the rank failed (acx_shard_fail), every rank stops at the next chunk's headers */
+int acx_shard_chunk_insert_dead(acx_shard *h, void *stream);
 /* decisions + the new states below the cutoff become local nodes, in tag order (max_nodes = max_nodes_to_explore) */
 int acx_shard_chunk_commit(acx_shard *h, int64_t max_nodes, void *stream);
 /* control block: ACX_SHARD_CTL_WORDS int64 */

@@ -223,7 +223,15 @@ class OracleShardEngine:
         self.packed.copy_((lm[:, 0] | (lm[:, 1] << 16)).to(torch.int32))
         return self.packed
 
+    def chunk_insert_dead(self, n_par):
+        """masks only (all zero), the chunk stays in the ring: csrc/acx_shard.hip acx_shard_chunk_insert_dead"""
+        self.geo, self.recv = self.open[self.inserted]
+        self.inserted += 1
+        return self.gmask_view(self.geo[1])
+
     def chunk_commit(self, max_nodes):
+        if not self.open or self.inserted < 1:
+            raise RuntimeError("chunk_commit: no inserted chunk is waiting")
         self.geo, self.recv = self.open.pop(0)
         self.inserted = max(self.inserted - 1, 0)
         if self.ctl[0] != 0:

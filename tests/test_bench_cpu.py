@@ -51,3 +51,93 @@ def test_timed_window_is_at_least_16384_steps_for_any_k():
         p = max(1, min(r, bench.GRAPH_NODES_MAX // k))  # passes captured into one graph; the graph is launched ceil(r / p) times
         g = -(-r // p)
         assert p * k <= max(k, bench.GRAPH_NODES_MAX) and p * g >= r and p * (g - 1) < r
+
+
+# ---- `python bench.py --gpus N` without a launcher: bench.py starts the N rank processes itself ---------------------------------
+_STUB = """
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0 and os.environ["LOCAL_RANK"] == str(rank)
+mode = sys.argv[1]
+if mode == "ok":
+    print("rank %d chatter" % rank)
+    if rank == 0:
+        print(json.dumps({"metric": "m", "n_gpus": world, "argv": sys.argv[2:]}))
+elif mode == "rank1_dies":
+    if rank == 1:
+        sys.exit(5)
+    time.sleep(60)   # the others sit in a collective that will never complete
+elif mode == "mislabelled":
+    if rank == 0:
+        print(json.dumps({"metric": "m", "n_gpus": 1}))
+"""
+
+
+def _stub(tmp_path):
+    import sys
+
+    f = tmp_path / "stub.py"
+    f.write_text(_STUB)
+    return [sys.executable, str(f)]
+
+
+def test_launcher_relays_rank0s_one_json_line(tmp_path, capfd):
+    import json
+
+    import bench
+
+    rc = bench.launch_ranks(3, ["--steps", "7"], child=_stub(tmp_path) + ["ok"])
+    out = capfd.readouterr().out
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert rc == 0 and len(lines) == 1
+    got = json.loads(lines[0])
+    assert got["n_gpus"] == 3 and got["argv"] == ["--steps", "7"]
+    assert "rank 0 chatter" not in out  # only the JSON line reaches stdout
+
+
+def test_launcher_fails_when_any_rank_fails_and_ends_the_others(tmp_path, capfd):
+    import time
+
+    import bench
+
+    t0 = time.time()
+    rc = bench.launch_ranks(3, [], child=_stub(tmp_path) + ["rank1_dies"], grace_s=1.0)
+    io = capfd.readouterr()
+    assert rc == 5 and "{" not in io.out and "rank 1 exited with code 5" in io.err
+    assert time.time() - t0 < 30  # ranks 0 and 2 were terminated, not waited for
+
+
+def test_launcher_refuses_a_mislabelled_line(tmp_path, capfd):
+    import bench
+
+    assert bench.launch_ranks(2, [], child=_stub(tmp_path) + ["mislabelled"]) == 1
+    io = capfd.readouterr()
+    assert "{" not in io.out and "n_gpus = 1" in io.err
+
+
+def test_bench_gpus_2_on_a_box_without_two_gpus_fails_loudly():
+    """the whole path through the real file: `python bench.py --gpus 2` must start two ranks, and where two GPUs are not there it must
+    exit non-zero WITHOUT printing a result line (round 3: it printed `n_gpus: 1`)"""
+    import os
+    import subprocess
+    import sys
+
+    import bench
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    r = subprocess.run([sys.executable, bench.__file__, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-search", "--no-extras", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout, (r.returncode, r.stdout[-300:])
+    assert "device(s)" in r.stderr and "cannot be measured here" in r.stderr, r.stderr[-600:]
+
+
+def test_bench_refuses_a_gpus_flag_that_contradicts_the_launcher():
+    import os
+    import subprocess
+    import sys
+
+    import bench
+
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, bench.__file__, "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and r.stdout.strip() == ""

@@ -442,11 +442,23 @@ def test_sharded_bfs_over_rccl_process_group(search):
         port = s.getsockname()[1]
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        comm = TorchDistComm(torch.device("cuda", 0))
         ak2 = [1, 1, -2, -2, -2, 0, 0, 1, 2, 1, -2, -1, -2, 0]
-        for budget in (10, 5000, 10**6):
-            got = _bfs_through_comm(bfs_sharded, ak2, budget, comm)
-            assert got == O.bfs(ak2, budget)
+        # the mask all-reduce on the communicator everything else uses, and on one of its own (dist.new_group)
+        for comm in (TorchDistComm(torch.device("cuda", 0)), TorchDistComm(torch.device("cuda", 0), mask_group="own")):
+            for budget in (10, 5000, 10**6):
+                got = _bfs_through_comm(bfs_sharded, ak2, budget, comm)
+                assert got == O.bfs(ak2, budget)
+            assert comm.stats["mask_all_reduce_calls"] > 0 and comm.stats["all_to_all_calls"] > 0
+        import ac_solver.search.sharded as sh
+
+        sh._FORCE_EXCHANGE = True
+        try:  # the communicator itself copes with the aliased send / receive areas of world 1; the per-stage timeline comes back
+            ok, path, st = bfs_sharded(ak2, 10**6, comm=comm, want_stats=True, timeline=True, batch_parents=1 << 14)
+        finally:
+            sh._FORCE_EXCHANGE = False
+        assert (ok, path) == O.bfs(ak2, 10**6)
+        tl = st["timeline"]
+        assert tl["chunks_timed"] > 0 and tl["expand_us"] > 0 and tl["insert_us"] > 0 and tl["commit_us"] > 0 and tl["all_to_all_us"] > 0 and tl["mask_all_reduce_us"] > 0
     finally:
         dist.destroy_process_group()
 
@@ -467,6 +479,9 @@ def _bfs_through_comm(bfs_sharded, p, budget, comm):
 
         def all_reduce(self, t, op):
             return comm.all_reduce(t, op)
+
+        def all_reduce_masks(self, t):
+            return comm.all_reduce_masks(t) if hasattr(comm, "all_reduce_masks") else comm.all_reduce(t, "sum")
 
     saved = sh.bfs_sharded.__globals__.get("_FORCE_EXCHANGE")
     sh._FORCE_EXCHANGE = True

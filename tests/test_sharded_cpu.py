@@ -105,6 +105,61 @@ def test_a_failing_rank_takes_every_rank_down_without_deadlock():
     assert "simulated" in msgs[1]
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("lag", [0, 2])
+@pytest.mark.parametrize("where", ["chunk_expand", "chunk_insert", "chunk_commit"])
+@pytest.mark.parametrize("overlap", ["insert", "commit"])
+def test_a_host_side_failure_in_any_engine_call_ends_every_rank_at_the_same_collective(where, lag, overlap):
+    """An engine call that raises on ONE rank (chunk_expand before its chunk exists in the engine, chunk_insert, chunk_commit), with
+    the control block read `lag` chunks late as on the GPU: every rank must issue exactly the same collectives and raise -- a rank
+    left alone in a collective would hang this test (thread ranks meet at barriers).  The failing call is placed in the middle of
+    a level with many chunks, at a level's last chunk and in the search's last chunks."""
+    from ac_solver.search import sharded
+    from ac_solver.search.sharded import bfs_sharded
+
+    for fail_at in (3, 9, 10, 17, 30):
+        calls = {}
+
+        class Flaky(OracleShardEngine):
+            def _maybe(self, name):
+                if name == where and self.rank == 1:
+                    calls[name] = calls.get(name, 0) + 1
+                    if calls[name] == fail_at:
+                        raise RuntimeError("engine call failed (simulated)")
+
+            def chunk_expand(self, *a, **k):
+                self._maybe("chunk_expand")
+                return super().chunk_expand(*a, **k)
+
+            def chunk_insert(self, n_par):
+                self._maybe("chunk_insert")
+                return super().chunk_insert(n_par)
+
+            def chunk_commit(self, max_nodes):
+                self._maybe("chunk_commit")
+                return super().chunk_commit(max_nodes)
+
+        def run(comm):
+            try:
+                bfs_sharded(AK2, 600, comm=comm, engine_factory=Flaky, batch_parents=8, overlap=overlap)
+            except RuntimeError as e:
+                return str(e), dict(comm.stats)
+            return "no error", dict(comm.stats)
+
+        sharded._FORCE_LAG = lag
+        try:
+            out = run_threads(3, run)
+        finally:
+            sharded._FORCE_LAG = None
+        msgs = [m for m, _ in out]
+        if calls.get(where, 0) < fail_at:  # the search ended before the failing call: nothing to see
+            assert all(m == "no error" for m in msgs), (fail_at, msgs)
+            continue
+        assert all("sharded bfs failed" in m for m in msgs), (fail_at, msgs)
+        assert "simulated" in msgs[1], (fail_at, msgs)
+        assert out[0][1] == out[1][1] == out[2][1], (fail_at, [st for _, st in out])  # the same number of each collective on every rank
+
+
 def test_a_device_side_capacity_failure_reaches_every_rank():
     """node capacity exhausted on one rank: refused on that rank before anything is written, carried to the others by the next
     chunk's headers (or by the closing all-reduce when the search ends first)"""

@@ -10,7 +10,8 @@ This tool compiles a translation unit of csrc/ to assembly (device only, no GPU 
 amount register is the last register of its kernel's allocation.  tests/test_abi_cpu.py requires the list to be empty for every
 kernel of libacx.so (the kernels keep it empty by declaring a few registers more than they use: ACX_VGPR_PAD, acx_common.h).
 
-    python3 tools/check_shift64.py [acx_search.hip ...] [-- extra hipcc flags]"""
+    python3 tools/check_shift64.py [acx_search.hip ...] [-- extra hipcc flags]
+    python3 tools/check_shift64.py --asm file.s ...      (csrc/Makefile runs this on the assembly of every object it links: the build fails on a hit)"""
 import os
 import re
 import subprocess
@@ -24,7 +25,7 @@ SHIFT = re.compile(r"^\s*(v_lshlrev_b64|v_lshrrev_b64|v_ashrrev_i64)\s+v\[\d+:\d
 
 
 def scan_asm(text):
-    """-> ({kernel: next_free_vgpr}, [(function, opcode, amount operand)]) for one assembly file"""
+    """-> ({kernel: (next_free_vgpr, accum_offset or None)}, [(function, opcode, amount operand)]) for one assembly file"""
     nfree, sites, cur, in_desc = {}, [], None, None
     for line in text.split("\n"):
         m = re.match(r"^([A-Za-z_][\w$.]*):", line)
@@ -34,32 +35,46 @@ def scan_asm(text):
         m = re.match(r"\s*\.amdhsa_kernel\s+(\S+)", line)
         if m:
             in_desc = m.group(1)
+            nfree[in_desc] = [0, None]
             continue
         if in_desc:
             m = re.match(r"\s*\.amdhsa_next_free_vgpr\s+(\d+)", line)
             if m:
-                nfree[in_desc] = int(m.group(1))
+                nfree[in_desc][0] = int(m.group(1))
+            m = re.match(r"\s*\.amdhsa_accum_offset\s+(\d+)", line)
+            if m:
+                nfree[in_desc][1] = int(m.group(1))
             if ".end_amdhsa_kernel" in line:
                 in_desc = None
             continue
         m = SHIFT.match(line)
         if m and cur:
             sites.append((cur, m.group(1), m.group(2)))
-    return nfree, sites
+    return {k: tuple(v) for k, v in nfree.items()}, sites
 
 
 def risky_sites(text):
-    """the 64-bit shifts whose VGPR amount is the last register of the allocation of the kernel they are in"""
+    """The 64-bit shifts whose VGPR amount is the last register of an allocation block of the kernel they are in: the last register
+    of the whole allocation (next_free_vgpr rounded up to the granule of 8) and, in a kernel that also holds accumulation registers
+    (the unified file of gfx90a+: the architectural VGPRs end at accum_offset, the AGPRs follow), the last architectural one.  A
+    shift with a VGPR amount in a function that is NOT a kernel has no allocation of its own to check against (it runs in its
+    caller's): this library inlines everything, so any such site is reported too."""
     nfree, sites = scan_asm(text)
     bad = []
     for fn, op, amt in sites:
         m = re.fullmatch(r"v(\d+)", amt)
-        if not m or fn not in nfree:
-            continue  # an SGPR / literal amount, or a non-kernel function (everything is inlined in this library)
-        alloc = (nfree[fn] + 7) // 8 * 8
-        if int(m.group(1)) == alloc - 1:
-            bad.append((fn, op, amt, nfree[fn]))
-    return bad, nfree, sites
+        if not m:
+            continue  # an SGPR / literal amount
+        if fn not in nfree:
+            bad.append((fn, op, amt, -1))  # not a kernel: unknown allocation
+            continue
+        nf, acc = nfree[fn]
+        tops = {(nf + 7) // 8 * 8 - 1}
+        if acc is not None and acc < nf:  # AGPRs in use: the architectural registers are v0 .. v(accum_offset - 1)
+            tops.add(acc - 1)
+        if int(m.group(1)) in tops:
+            bad.append((fn, op, amt, nf))
+    return bad, {k: v[0] for k, v in nfree.items()}, sites
 
 
 def compile_to_asm(tu, extra=()):
@@ -71,8 +86,19 @@ def compile_to_asm(tu, extra=()):
         return open(out).read()
 
 
+def report(name, text):
+    bad, nfree, sites = risky_sites(text)
+    demangle = subprocess.run(["c++filt"], input="\n".join(b[0] for b in bad), capture_output=True, text=True).stdout.split("\n")
+    print(f"== {name}: {len(nfree)} kernels, {len(sites)} 64-bit shifts with a register amount checked, {len(bad)} at the top of an allocation")
+    for (fn, op, amt, nf), dn in zip(bad, demangle):
+        print(f"   {op} amount {amt} with next_free_vgpr {nf}: {dn[:140]}" if nf >= 0 else f"   {op} amount {amt} in a non-kernel function (no allocation to check against): {dn[:140]}")
+    return len(bad)
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
+    if args and args[0] == "--asm":  # csrc/Makefile: the device assembly of the object that is about to be linked (-save-temps)
+        sys.exit(1 if sum(report(os.path.basename(f), open(f).read()) for f in args[1:]) else 0)
     extra = []
     if "--" in args:
         k = args.index("--")
@@ -80,10 +106,5 @@ if __name__ == "__main__":
     tus = args or ["acx_step.hip", "acx_search.hip", "acx_shard.hip", "acx_ball.hip", "acx_simplex.hip", "acx_policy.hip"]
     total = 0
     for tu in tus:
-        bad, nfree, sites = risky_sites(compile_to_asm(tu, extra + (["-fno-slp-vectorize"] if tu == "acx_policy.hip" else [])))
-        demangle = subprocess.run(["c++filt"], input="\n".join(b[0] for b in bad), capture_output=True, text=True).stdout.split("\n")
-        print(f"== {tu}: {len(nfree)} kernels, {len(sites)} 64-bit shifts with a register amount checked, {len(bad)} at the top of an allocation")
-        for (fn, op, amt, nf), name in zip(bad, demangle):
-            print(f"   {op} amount {amt} with next_free_vgpr {nf}: {name[:140]}")
-        total += len(bad)
+        total += report(tu, compile_to_asm(tu, extra + (["-fno-slp-vectorize"] if tu == "acx_policy.hip" else [])))
     sys.exit(1 if total else 0)
