@@ -344,14 +344,15 @@ def _bfs_sharded_once(presentation, max_nodes_to_explore=10000, verbose=False, c
 def _timeline_summary(torch, rows, B):
     """rows: per chunk (n_par, side events e0 e1 e2, main events m0 m1 m2 m3) -> medians over the full-size chunks (all chunks if none is)"""
     torch.cuda.synchronize()
-    full = [r for r in rows if r[0] == B] or rows
+    any_full = any(r[0] == B for r in rows)
+    full = [r for r in rows if r[0] == B] if any_full else rows
     med = lambda v: float(sorted(v)[len(v) // 2]) if v else None  # noqa: E731
     us = lambda a, b: a.elapsed_time(b) * 1e3  # noqa: E731
     stages = {"expand_us": [us(r[1], r[2]) for r in full], "all_to_all_us": [us(r[2], r[3]) for r in full], "insert_us": [us(r[4], r[5]) for r in full],
               "mask_all_reduce_us": [us(r[5], r[6]) for r in full], "commit_us": [us(r[6], r[7]) for r in full],
               "wait_for_exchange_us": [max(0.0, us(r[3], r[4])) for r in full]}
     # period: from the end of one chunk's commit to the end of the next one's, between consecutive full-size chunks of a level
-    period = [us(a[7], b[7]) for a, b in zip(rows, rows[1:]) if a[0] == B and b[0] == B and a[8] == b[8]]
+    period = [us(a[7], b[7]) for a, b in zip(rows, rows[1:]) if (not any_full or (a[0] == B and b[0] == B)) and a[8] == b[8]]
     out = {k: med(v) for k, v in stages.items()}
     out["chunk_period_us"] = med(period)
     out["chunks_timed"] = len(full)
@@ -495,6 +496,10 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
         n_par = c1 - c0
         tight_used = tight_used or (exchange and 0 < fill < FILL_DEFAULT)
         with _on_side():
+            # the expansion runs at most ONE chunk ahead of the dedup: the children a rank owns itself claim their table slots from
+            # the expansion kernel, and the engine tells the claims of two chunks in flight apart by the chunk's parity
+            if on_gpu and side is not main and done:
+                side.wait_event(done[-1])  # chunk idx - 2 is committed (the last chunk consumed so far; chunk idx - 1 is the one being dedup'ed)
             e0 = stamp(side)
             dead = failure is not None and exchange
             if not dead:
@@ -556,6 +561,7 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
         if on_gpu:
             side.wait_stream(main)  # the level's parents are the nodes the main stream committed during the previous level
         sizes, n_read, new_read, c_next = [], 0, 0, 0
+        done = []  # per consumed chunk of this level: event behind its commit on the main stream
 
         def produce_next():
             nonlocal c_next
@@ -599,6 +605,10 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
                 except Exception as e:  # noqa: BLE001
                     set_failed(e)
             m3 = stamp(main)
+            if on_gpu and side is not main:
+                ev_done = torch.cuda.Event()
+                ev_done.record(main)
+                done.append(ev_done)
             if tl_rows is not None:
                 tl_rows.append((n_par, e0, e1, ev, m0, m1, m2, m3, levels))
             engine.ctl_snapshot(k % (lag + 2))

@@ -24,6 +24,17 @@
 // engine's 22 ms of kernel time at 1e8 nodes).  What the log costs is memory, which an MI355X has: 24 (u64 keys) or 40
 // (u128) bytes per received record.
 //
+// Round 4: BORN stamps.  A child whose key this rank owns and whose parent is a local node never leaves the expansion kernel: it
+// claims its table slot right there, with a stamp that names it as "child `action` of local node `parent`" (the fused search's
+// stamp, acx_bfs.h) instead of the offset of a record -- no record is written, none is read back by the dedup, none by the commit:
+// k_shard_commit_born rebuilds the winners' keys from their parents.  At world 1 that is every child (the record log shrinks to
+// the regions' headers and k_shard_insert has nothing to do); at world N it is 1/N of them.  A slot's type bit tells the two
+// kinds of stamp apart, and both kinds of occupant are compared by their tags, so records and born children of one chunk fold
+// to the first discoverer as before.  The expansion of chunk k + 1 may run (side stream) beside the dedup of chunk k: its born
+// children carry larger tags than anything in chunk k, so a record of chunk k that meets one pushes it out (and flags it in the
+// flag set of chunk k + 1: the byte flags are double-buffered by chunk parity), and a born child that meets a record is "seen".
+// The orchestrator keeps the expansion at most ONE chunk ahead of the dedup (an event, no host wait).
+//
 // The host never waits inside a level: it enqueues chunk after chunk and reads a snapshot of the control block two chunks
 // late (acx_shard_ctl_snapshot / acx_shard_ctl_wait); once the status word leaves 0 every later kernel returns at once.
 #include <mutex>
@@ -129,8 +140,10 @@ template <typename W> struct ShardDev {
     unsigned long long* stab;
     uint32_t stmask;
     int64_t* log;        // record log = receive areas of all chunks
-    uint8_t* btook;      // one byte per tag of a chunk: took a slot / was pushed out again (both zero between chunks)
-    uint8_t* brepl;
+    uint8_t* btook;      // one byte per tag of a chunk: took a slot / was pushed out again (both zero between chunks); TWO sets, `flag_stride`
+    uint8_t* brepl;      // bytes apart, indexed by the chunk's parity (ChunkGeo::par): the expansion of chunk k + 1 claims beside the dedup of chunk k
+    size_t flag_stride;
+    uint32_t born;       // 1: locally owned children of local parents claim their slot in k_shard_expand (BORN stamps); 0: everything travels as a record
     int32_t* lmask;      // [chunk parents] 12-bit masks: new states of this rank
     int32_t* gmask;      // the same for all ranks after the caller's all-reduce, TWO parents per word (parent p: bits 16 (p & 1) .. + 11 of word
                          // p >> 1): every (parent, action) child has one owner, so the sum of the ranks' words is their union and no field carries
@@ -139,7 +152,7 @@ template <typename W> struct ShardDev {
     uint32_t* lblk;      // per tile: total, turned into the exclusive prefix over the tiles by k_shard_decide
     uint32_t* gblk;
     unsigned long long* ctl;
-    uint32_t* bounds;    // [2] frontier slice of the running chunk
+    uint32_t* bounds;    // [2][2] frontier slice (local node ids [lo, hi)) of the chunk of either parity
     ChunkDec* dec;
     uint32_t cap_nodes;
     int32_t L, cyclical;
@@ -153,6 +166,7 @@ struct ChunkGeo {
     uint32_t subcap;       // records a sub-region can take
     uint32_t region_words; // kShardHdr + subcap * RW
     uint32_t even;         // records of the even share per sub-region (12 n_par / (world^2 * sub-regions)); 0 at world 1
+    uint32_t par;          // parity of the chunk inside its level: which set of byte flags and which bounds pair it uses
 };
 
 __device__ __forceinline__ uint32_t gmask_of(const int32_t* __restrict__ gmask, uint32_t p) { return ((uint32_t)gmask[p >> 1] >> (16u * (p & 1u))) & 0xFFFu; }
@@ -165,10 +179,19 @@ __device__ __forceinline__ uint32_t gmask_of(const int32_t* __restrict__ gmask, 
 // moves the whole region.  The orchestrator therefore passes the fullest region of the previous level x 1.3
 // (ctl[C_LEVEL_FILL]); an overflow fails the search (FAIL_REGION) and the orchestrator reruns it with the default.
 constexpr int kShardFillDefault = 320;
+// ACX_SHARD_BORN=0 switches the born stamps off (A/B measurements; every child then travels as a record, round 3's data path)
+static inline bool shard_born_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("ACX_SHARD_BORN");
+        return !e || atoi(e) != 0;
+    }();
+    return on;
+}
 static inline void shard_layout(int64_t n_par, int world, int RW, int fill_q8, int64_t* subcap, int64_t* region_words, int64_t* even_out = nullptr) {
     const int64_t n_blocks = (12 * n_par + kExpandTile - 1) / kExpandTile;
     const int64_t hard = (n_blocks + kShardSub - 1) / kShardSub * kExpandTile;  // every workgroup that reserves in a sub-region sends it all it has
     int64_t cap = hard, even = 0;
+    if (world == 1 && shard_born_enabled()) cap = 0;  // every child is born where it is owned: a region is its header
     if (world > 1) {  // the owner hash spreads the records evenly
         if (fill_q8 <= 0 || fill_q8 > kShardFillDefault) fill_q8 = kShardFillDefault;
         even = (12 * n_par + (int64_t)world * world * kShardSub - 1) / ((int64_t)world * world * kShardSub);
@@ -231,8 +254,8 @@ __global__ void __launch_bounds__(256) k_shard_prep(ShardDev<W> d, ChunkGeo g, i
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        d.bounds[0] = s_lo[0];
-        d.bounds[1] = s_lo[1];
+        d.bounds[2 * g.par] = s_lo[0];
+        d.bounds[2 * g.par + 1] = s_lo[1];
     }
     const unsigned long long fail = d.ctl[C_FAIL_LOCAL];
     for (uint32_t r = threadIdx.x; r < d.world * kShardSub; r += blockDim.x) {
@@ -241,6 +264,33 @@ __global__ void __launch_bounds__(256) k_shard_prep(ShardDev<W> d, ChunkGeo g, i
         h[1] = (int64_t)kShardInf;
         h[2] = (int64_t)kShardInf;
         h[3] = (int64_t)fail;
+    }
+}
+
+// ---- stamps -----------------------------------------------------------------------------------------------------------------
+// 8-byte slots, all ones = free, else fingerprint(27, bits 37..63 of the key's hash) | type(1) | payload(36):
+//   type 0 (REC)   payload = word offset, in this rank's record log, of the record that claimed the slot
+//   type 1 (BORN)  payload = local id of the parent node << 4 | action: the state is that child of that node; its key is rebuilt
+//                  from the parent's key in the node arena (written by the commit of an earlier level) and one move
+// A slot only ever moves free -> first claimer of key K -> a claimer of K with a smaller (chunk, tag), so whatever a (possibly
+// stale) plain load shows, an occupant that beats me stays beaten, and every change goes through a device-scope CAS.
+constexpr unsigned long long kStampFree = ~0ull;
+constexpr unsigned long long kStampOff = (1ull << 36) - 1;   // payload
+constexpr unsigned long long kStampBorn = 1ull << 36;        // type bit
+constexpr unsigned long long kStampFpMask = ~((1ull << 37) - 1);
+__device__ __forceinline__ bool stamp_fp_eq(unsigned long long a, unsigned long long b) { return (a >> 37) == (b >> 37); }
+__device__ __forceinline__ uint32_t born_parent(unsigned long long st) { return (uint32_t)((st & kStampOff) >> 4); }
+__device__ __forceinline__ uint32_t born_action(unsigned long long st) { return (uint32_t)st & 15u; }
+template <typename W, int MODE> __device__ __forceinline__ void stamp_key(const ShardDev<W>& d, unsigned long long st, W& q0, W& q1) {
+    if (st & kStampBorn) {
+        const uint32_t hp = born_parent(st);
+        Pres<W> s;
+        key_to_pres<W>(d.k0[hp], d.k1[hp], s);
+        (void)search_move<W, MODE>(s, (int)born_action(st), d.L, d.cyclical != 0);
+        q0 = keyops<W>::make(s.w0, s.n0);
+        q1 = keyops<W>::make(s.w1, s.n1);
+    } else {
+        recio<W>::get(d.log + (int64_t)(st & kStampOff), q0, q1);
     }
 }
 
@@ -272,7 +322,7 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
     ACX_VGPR_PAD_W(W, "v55", "v87");  // the code needs 46-47 / 71-79 registers (tools/kernel_resources.py)
     if (d.ctl[C_STATUS] != 0) return;
     const uint32_t tid = threadIdx.x, l = (tid & 63u) + 64u * (tid >> 8), w = (tid >> 6) & 3u;  // parent slot in the workgroup; wave inside its group of four
-    const uint32_t s_lo = d.bounds[0], s_hi = d.bounds[1];
+    const uint32_t s_lo = d.bounds[2 * g.par], s_hi = d.bounds[2 * g.par + 1];
     const uint32_t np = s_hi - s_lo;
     if (blockIdx.x * kExpandParents >= np) return;
     if (tid < 64) s_cnt[tid] = 0;
@@ -359,13 +409,20 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
     // took 2.7 instead of 2.0 ms per 1e8-node search).  Per owner: a 12-bit survivor mask per parent, a wave scan over the 64
     // parents, position = survivors of earlier parents + earlier actions of the own parent ------------------------------------
     uint32_t owner[kExpandItems], pos[kExpandItems];
+    bool born[kExpandItems];
 #pragma unroll
     for (int it = 0; it < kExpandItems; it++) {
         owner[it] = 0xFFFFFFFFu;
         pos[it] = 0;
+        born[it] = false;
         if (send_it[it] && s_slot[ls[it]] == me[it]) {
             owner[it] = owner_of_hash(hk[it], d.world);
-            atomicOr(&s_bits[owner[it] * (uint32_t)kExpandParents + l], 1u << (w * kExpandItems + it));
+            if (d.born && owner[it] == d.rank) {  // stays home: claims its slot below, no record
+                born[it] = true;
+                owner[it] = 0xFFFFFFFFu;
+            } else {
+                atomicOr(&s_bits[owner[it] * (uint32_t)kExpandParents + l], 1u << (w * kExpandItems + it));
+            }
         }
     }
     __syncthreads();
@@ -405,6 +462,64 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
         // record word: parent's local id | (tag relative to the chunk) << 32
         r[recio<W>::KW] = (int64_t)(((unsigned long long)(uint32_t)(12ull * gp + a - 12ull * (unsigned long long)g.c0) << 32) | id);
     }
+    // ---- the children this rank owns itself claim their slots here (BORN stamps): the probe loop of the fused search
+    // (acx_bfs.h: k_bfs_expand_insert), a bucket of four slots = one 32-byte sector per step.  Occupants: a record (a chunk that
+    // was dedup'ed before this kernel started, or -- on the main stream, beside this kernel -- the chunk before mine: smaller tags
+    // either way) or a born child; a born child of MY chunk (its parent is one of this chunk's local parents: id >= s_lo) folds
+    // with me by (parent, action), which IS the tag order; every other occupant with my key has been seen before me.
+    uint8_t* __restrict__ btook = d.btook + g.par * d.flag_stride;
+    uint8_t* __restrict__ brepl = d.brepl + g.par * d.flag_stride;
+#pragma unroll
+    for (int it = 0; it < kExpandItems; it++) {
+        if (!born[it]) continue;
+        const uint32_t a = w * kExpandItems + it;
+        const unsigned long long mine = (hk[it] & kStampFpMask) | kStampBorn | ((unsigned long long)id << 4) | a;
+        uint32_t base = (uint32_t)hk[it] & d.stmask & ~3u, probes = 0;
+        bool open = true, took = false;
+        while (open) {
+            const ulonglong2 lo = *(const ulonglong2*)(d.stab + base), hi = *(const ulonglong2*)(d.stab + base + 2);
+            const unsigned long long v0 = lo.x, v1 = lo.y, v2 = hi.x, v3 = hi.y;
+            auto hot = [&](unsigned long long v) { return v == kStampFree || stamp_fp_eq(v, mine); };
+            uint32_t cand = (hot(v0) ? 1u : 0u) | (hot(v1) ? 2u : 0u) | (hot(v2) ? 4u : 0u) | (hot(v3) ? 8u : 0u);
+            while (cand && open) {
+                const uint32_t jj = (uint32_t)__builtin_ctz(cand);
+                cand &= cand - 1;
+                unsigned long long st = jj == 0 ? v0 : (jj == 1 ? v1 : (jj == 2 ? v2 : v3));
+                unsigned long long* slot = d.stab + base + jj;
+                for (;;) {  // until this slot is decided for me (once it holds my key it only changes among holders of MY key)
+                    if (st == kStampFree) {
+                        const unsigned long long old = atomicCAS(slot, kStampFree, mine);
+                        if (old == kStampFree) {
+                            took = true;
+                            open = false;
+                            break;
+                        }
+                        st = old;
+                    }
+                    if (!stamp_fp_eq(st, mine)) break;  // another key's fingerprint: next slot
+                    W q0, q1;
+                    stamp_key<W, MODE>(d, st, q0, q1);
+                    if (q0 != c0[it] || q1 != c1[it]) break;  // same fingerprint, other key: next slot
+                    open = false;
+                    if (!(st & kStampBorn) || born_parent(st) < s_lo || st < mine) break;  // seen before me, or a smaller tag of my chunk holds it
+                    const unsigned long long old = atomicCAS(slot, st, mine);  // push the larger tag of my chunk out
+                    if (old == st) {
+                        took = true;
+                        brepl[12u * (d.gpos[born_parent(st)] - (uint32_t)g.c0) + born_action(st)] = 1;  // no longer the first discoverer
+                        break;
+                    }
+                    st = old;  // somebody else replaced it meanwhile: look again
+                    open = true;
+                }
+            }
+            base = (base + 4) & d.stmask;
+            if (open && ++probes > d.stmask / 4) {
+                atomicMax(d.ctl + C_FAIL_LOCAL, (unsigned long long)FAIL_TABLE);
+                open = false;
+            }
+        }
+        if (took) btook[12u * (gp - (uint32_t)g.c0) + a] = 1;
+    }
 }
 
 // ---- dedup of the received records ------------------------------------------------------------------------------------------
@@ -414,10 +529,7 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
 // first); an older offset is a state that was seen before.  Two byte flags per tag of the chunk, both zero on entry:
 // btook[tag] is set by a record that takes a slot, brepl[tag] by the record that pushes it out again -- "took and was not
 // replaced" does not depend on the order in which the two stores land.
-constexpr unsigned long long kStampFree = ~0ull;
-constexpr unsigned long long kStampOff = (1ull << 36) - 1;
-
-template <typename W> __device__ __forceinline__ void shard_insert_tile(const ShardDev<W>& d, const ChunkGeo& g, uint32_t r, uint32_t bx) {
+template <typename W, int MODE> __device__ __forceinline__ void shard_insert_tile(const ShardDev<W>& d, const ChunkGeo& g, uint32_t r, uint32_t bx) {
     const int64_t roff = g.log_off + (int64_t)r * g.region_words;
     const unsigned long long written = (unsigned long long)d.log[roff];
     if (written > g.subcap && bx == 0 && threadIdx.x == 0) atomicMax(d.ctl + C_FAIL_LOCAL, (unsigned long long)FAIL_REGION);
@@ -430,20 +542,24 @@ template <typename W> __device__ __forceinline__ void shard_insert_tile(const Sh
     recio<W>::get(rec, c0, c1);
     const uint32_t tag = (uint32_t)((unsigned long long)rec[recio<W>::KW] >> 32);
     const uint64_t hk = shard_hash(c0, c1);
-    const unsigned long long me = (hk & ~kStampOff) | (unsigned long long)off;
+    const unsigned long long me = (hk & kStampFpMask) | (unsigned long long)off;
+    uint8_t* __restrict__ btook = d.btook + g.par * d.flag_stride;
+    uint8_t* __restrict__ brepl = d.brepl + g.par * d.flag_stride;
+    uint8_t* __restrict__ brepl_next = d.brepl + (g.par ^ 1u) * d.flag_stride;
+    const uint32_t b0 = d.bounds[2 * g.par], b1 = d.bounds[2 * g.par + 1];  // this chunk's local parents
     uint32_t base = (uint32_t)hk & d.stmask & ~3u, probes = 0, took = 0;
     bool open = true;
     while (open) {
         const ulonglong2 lo = *(const ulonglong2*)(d.stab + base), hi = *(const ulonglong2*)(d.stab + base + 2);
         const unsigned long long v0 = lo.x, v1 = lo.y, v2 = hi.x, v3 = hi.y;
-        auto hot = [&](unsigned long long v) { return v == kStampFree || (v >> 36) == (me >> 36); };
+        auto hot = [&](unsigned long long v) { return v == kStampFree || stamp_fp_eq(v, me); };
         uint32_t cand = (hot(v0) ? 1u : 0u) | (hot(v1) ? 2u : 0u) | (hot(v2) ? 4u : 0u) | (hot(v3) ? 8u : 0u);
         while (cand && open) {
             const uint32_t j = (uint32_t)__builtin_ctz(cand);
             cand &= cand - 1;
             unsigned long long st = j == 0 ? v0 : (j == 1 ? v1 : (j == 2 ? v2 : v3));
             unsigned long long* slot = d.stab + base + j;
-            for (;;) {  // until this slot is decided for me (once it holds my key it only changes among records of MY key)
+            for (;;) {  // until this slot is decided for me (once it holds my key it only changes among holders of MY key)
                 if (st == kStampFree) {
                     const unsigned long long old = atomicCAS(slot, kStampFree, me);
                     if (old == kStampFree) {
@@ -453,28 +569,38 @@ template <typename W> __device__ __forceinline__ void shard_insert_tile(const Sh
                     }
                     st = old;
                 }
-                if ((st >> 36) != (me >> 36)) break;  // another key's fingerprint: next slot
-                const int64_t qoff = (int64_t)(st & kStampOff);
+                if (!stamp_fp_eq(st, me)) break;  // another key's fingerprint: next slot
                 W q0, q1;
-                recio<W>::get(d.log + qoff, q0, q1);
+                stamp_key<W, MODE>(d, st, q0, q1);
                 if (q0 != c0 || q1 != c1) break;  // same fingerprint, other key: next slot
-                if (qoff < g.log_off) {           // a record of an earlier chunk: seen before
-                    open = false;
-                    break;
-                }
-                const uint32_t qtag = (uint32_t)((unsigned long long)d.log[qoff + recio<W>::KW] >> 32);
-                if (qtag < tag) {  // a record of this chunk with a smaller tag holds it
-                    open = false;
-                    break;
+                open = false;
+                uint8_t* flag;  // where the holder is flagged when I push it out
+                if (st & kStampBorn) {
+                    const uint32_t hp = born_parent(st);
+                    if (hp < b0) break;  // a child of an earlier chunk or level: seen before
+                    const uint32_t ogp = d.gpos[hp];
+                    if (hp < b1) {  // a born child of THIS chunk
+                        const uint32_t otag = 12u * (ogp - (uint32_t)g.c0) + born_action(st);
+                        if (otag < tag) break;
+                        flag = brepl + otag;
+                    } else {  // of the NEXT chunk (its expansion runs beside me on the side stream): every tag of mine is smaller
+                        flag = brepl_next + 12u * (ogp - (uint32_t)g.c0 - g.n_par) + born_action(st);
+                    }
+                } else {
+                    const int64_t qoff = (int64_t)(st & kStampOff);
+                    if (qoff < g.log_off) break;  // a record of an earlier chunk: seen before
+                    const uint32_t qtag = (uint32_t)((unsigned long long)d.log[qoff + recio<W>::KW] >> 32);
+                    if (qtag < tag) break;  // a record of this chunk with a smaller tag holds it
+                    flag = brepl + qtag;
                 }
                 const unsigned long long old = atomicCAS(slot, st, me);  // push the larger tag out
                 if (old == st) {
                     took = 1;
-                    d.brepl[qtag] = 1;  // no longer the first discoverer
-                    open = false;
+                    *flag = 1;  // no longer the first discoverer
                     break;
                 }
                 st = old;  // somebody else replaced it meanwhile: look again
+                open = true;
             }
         }
         base = (base + 4) & d.stmask;
@@ -483,16 +609,16 @@ template <typename W> __device__ __forceinline__ void shard_insert_tile(const Sh
             open = false;
         }
     }
-    if (took) d.btook[tag] = 1;
+    if (took) btook[tag] = 1;
 }
 
 // grid (x, regions): x = tiles per region, or FEWER -- then a workgroup walks the tiles of its region x, x + gridDim.x, ...: a
 // bounded number of resident workgroups, so that an expansion on the side stream finds room beside them (ShardEngine::insert_wgs).
-template <typename W>
+template <typename W, int MODE>
 __global__ void __launch_bounds__(256) k_shard_insert(ShardDev<W> d, ChunkGeo g, uint32_t tiles) {
-    ACX_VGPR_PAD("v63");
+    ACX_VGPR_PAD_W(W, "v63", "v95");
     if (d.ctl[C_STATUS] != 0) return;
-    for (uint32_t bx = blockIdx.x; bx < tiles; bx += gridDim.x) shard_insert_tile<W>(d, g, blockIdx.y, bx);
+    for (uint32_t bx = blockIdx.x; bx < tiles; bx += gridDim.x) shard_insert_tile<W, MODE>(d, g, blockIdx.y, bx);
 }
 
 // one 12-bit mask per parent of the chunk: bit a set when child (parent, a) is a new state of this rank; the flags it read are
@@ -501,7 +627,7 @@ __global__ void __launch_bounds__(256) k_shard_insert(ShardDev<W> d, ChunkGeo g,
 // where every lane takes the 12 bits of its parent (a lane per parent reading its own 12 bytes as three dwords at a 12-byte
 // stride: 42 us per 2^21-parent chunk instead of 26).
 constexpr int kPackParents = 256;
-template <typename W> __global__ void __launch_bounds__(256) k_shard_pack(ShardDev<W> d, uint32_t n_par) {
+template <typename W> __global__ void __launch_bounds__(256) k_shard_pack(ShardDev<W> d, uint32_t n_par, uint32_t par) {
     __shared__ uint16_t s_flag[kPackParents * 12 / 16 + 2];
     ACX_VGPR_PAD("v31");
     if (d.ctl[C_STATUS] != 0) return;
@@ -509,8 +635,8 @@ template <typename W> __global__ void __launch_bounds__(256) k_shard_pack(ShardD
     if (p0 >= n_par) return;
     constexpr uint32_t kVecs = kPackParents * 12 / 16;
     if (tid < kVecs) {  // (the arrays are padded by a tile: flags behind the chunk's last parent are zero and stay zero)
-        uint4* t = (uint4*)(d.btook + 12 * (size_t)p0) + tid;
-        uint4* r = (uint4*)(d.brepl + 12 * (size_t)p0) + tid;
+        uint4* t = (uint4*)(d.btook + par * d.flag_stride + 12 * (size_t)p0) + tid;
+        uint4* r = (uint4*)(d.brepl + par * d.flag_stride + 12 * (size_t)p0) + tid;
         const uint4 tv = *t, rv = *r;
         if (tv.x | tv.y | tv.z | tv.w) *t = make_uint4(0, 0, 0, 0);
         if (rv.x | rv.y | rv.z | rv.w) *r = make_uint4(0, 0, 0, 0);
@@ -754,6 +880,72 @@ template <typename W> __global__ void __launch_bounds__(256) k_shard_commit(Shar
     }
 }
 
+// The born winners of a chunk become nodes: for a LOCAL parent every set bit of its mask is a child that was born here (a child of
+// a local parent that another rank owns is flagged on that rank; a record this rank received has a parent on another rank), so the
+// kernel walks the chunk's local parents, not records.  Numbering as in k_shard_commit (one sequence over both kinds of winner, in
+// tag order); the keys are rebuilt from the parents (one move per new node, as k_bfs_compact does).  A workgroup takes 256
+// consecutive local parents, lists their winners below the cutoff in LDS in tag order and hands them out one per lane, so that
+// the node stores of a wave are consecutive ids (all of them at world 1, where every winner is born).
+constexpr int kBornParents = 256;
+template <typename W, int MODE> __global__ void __launch_bounds__(kBornParents) k_shard_commit_born(ShardDev<W> d, ChunkGeo g) {
+    __shared__ W s_pk0[kBornParents];
+    __shared__ W s_pk1[kBornParents];
+    __shared__ uint32_t s_q[kBornParents], s_lm[kBornParents], s_idb[kBornParents], s_gpb[kBornParents], s_gm[kBornParents];
+    __shared__ uint16_t s_list[kBornParents * 12];
+    __shared__ uint32_t s_wsum[kBornParents / 64];
+    ACX_VGPR_PAD_W(W, "v47", "v63");
+    const ChunkDec dec = *d.dec;
+    if (!dec.commit) return;
+    const uint32_t b0 = d.bounds[2 * g.par], b1 = d.bounds[2 * g.par + 1];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t first = b0 + blockIdx.x * (uint32_t)kBornParents;
+    if (first >= b1) return;
+    const uint32_t i = first + tid;
+    uint32_t lm = 0;
+    if (i < b1) {
+        const uint32_t q = d.gpos[i] - (uint32_t)g.c0, tile = q / kScanTile;
+        const uint32_t full = (uint32_t)d.lmask[q];
+        const uint32_t t0 = 12u * q;  // bits a with t0 + a < cutoff
+        lm = t0 + 12u <= dec.cutoff ? full : (t0 >= dec.cutoff ? 0u : full & ((1u << (dec.cutoff - t0)) - 1u));
+        s_q[tid] = q;
+        s_lm[tid] = full;
+        s_gm[tid] = gmask_of(d.gmask, q);
+        s_idb[tid] = dec.node_base + d.lblk[tile] + d.lpre[q];
+        s_gpb[tid] = dec.gpos_base + d.gblk[tile] + d.gpre[q];
+        s_pk0[tid] = d.k0[i];
+        s_pk1[tid] = d.k1[i];
+    }
+    const uint32_t cnt = (uint32_t)__popc(lm);
+    uint32_t incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= (uint32_t)o) incl += v;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t off = incl - cnt, total = 0;
+    for (uint32_t w2 = 0; w2 < (uint32_t)kBornParents / 64; w2++) {
+        if (w2 < wave) off += s_wsum[w2];
+        total += s_wsum[w2];
+    }
+    for (uint32_t f = lm; f; f &= f - 1) s_list[off++] = (uint16_t)((tid << 4) | (uint32_t)__builtin_ctz(f));
+    __syncthreads();
+    for (uint32_t j = tid; j < total; j += (uint32_t)kBornParents) {
+        const uint32_t e = s_list[j], pl = e >> 4, a = e & 15u, below = (1u << a) - 1u;
+        const uint32_t id = s_idb[pl] + (uint32_t)__popc(s_lm[pl] & below);
+        if (id >= d.cap_nodes) continue;  // k_shard_decide has refused such a commit already: never reached
+        Pres<W> s;
+        key_to_pres<W>(s_pk0[pl], s_pk1[pl], s);
+        (void)search_move<W, MODE>(s, (int)a, d.L, d.cyclical != 0);
+        d.k0[id] = keyops<W>::make(s.w0, s.n0);
+        d.k1[id] = keyops<W>::make(s.w1, s.n1);
+        d.act[id] = (uint8_t)a;
+        d.tlen[id] = (uint8_t)(s.n0 + s.n1);
+        d.gpos[id] = s_gpb[pl] + (uint32_t)__popc(s_gm[pl] & below);
+        d.pref[id] = (int64_t)(((unsigned long long)d.rank << 40) | (unsigned long long)(first + pl));
+    }
+}
+
 // root: local node 0 of its owner (global position 0 of level 0); its record sits at the start of the log
 template <typename W> __global__ void k_shard_seed(ShardDev<W> d, W k0, W k1) {
     ACX_VGPR_PAD("v23");
@@ -766,7 +958,7 @@ template <typename W> __global__ void k_shard_seed(ShardDev<W> d, W k0, W k1) {
     recio<W>::put(d.log, k0, k1);
     d.log[recio<W>::KW] = 0;
     const uint64_t hk = shard_hash(k0, k1);
-    d.stab[(uint32_t)hk & d.stmask & ~3u] = hk & ~kStampOff;  // offset 0: first slot of its bucket
+    d.stab[(uint32_t)hk & d.stmask & ~3u] = hk & kStampFpMask;  // a record stamp with offset 0: first slot of its bucket
     d.ctl[C_NODES] = 1;
 }
 
@@ -838,6 +1030,7 @@ template <typename W> struct ShardEngine {
     static constexpr int kGeoRing = 4;
     ChunkGeo geos[kGeoRing] = {};
     int geo_head = 0, geo_count = 0;   // ring of open chunks
+    uint32_t chunk_seq = 0;            // chunks expanded so far: its low bit is the chunk's parity (flag set, bounds pair)
     int geo_inserted = 0;              // how many of them have been through acx_shard_chunk_insert
     uint64_t nodes_host = 0, lvl_lo_host = 0, lvl_hi_host = 0;  // what the last control-block snapshot said
     int rank = 0, world = 1;
@@ -875,6 +1068,7 @@ template <typename W> struct ShardEngine {
         d.cyclical = cyclical;
         d.world = (uint32_t)world_;
         d.rank = (uint32_t)rank_;
+        d.born = shard_born_enabled() ? 1u : 0u;
         rank = rank_;
         world = world_;
         {
@@ -889,7 +1083,9 @@ template <typename W> struct ShardEngine {
         chunk_parents = (uint64_t)std::max<int64_t>(chunk_parents_, 1);
         int64_t subcap, region_words;
         shard_layout((int64_t)chunk_parents, world, recio<W>::RW, 0, &subcap, &region_words);
-        const uint64_t chunk_records = (uint64_t)subcap * kShardSub * (uint64_t)world;
+        // what a chunk can put into the table beyond the nodes it commits: the records it receives + the children born here, of
+        // the chunk being dedup'ed and of the one whose expansion runs ahead of it
+        const uint64_t chunk_records = (uint64_t)subcap * kShardSub * (uint64_t)world + (d.born ? 2 * (12 * chunk_parents / (uint64_t)world + kExpandTile) : 0);
         n_slots = 1024;
         while (n_slots < 2 * (cap_nodes + chunk_records)) n_slots <<= 1;
         if (n_slots > (1ull << 31) || cap_nodes > (1ull << 31)) return fail(ACX_E_INVAL, "acx_shard: capacity too large for 32-bit node ids");
@@ -915,8 +1111,10 @@ template <typename W> struct ShardEngine {
         for (int pass = 0; pass < 2; pass++) {
             uint8_t* b = (uint8_t*)chunk_buf.p;
             o = 0;
-            d.btook = take(b, 12 * chunk_parents + 12 * kPackParents + 16);  // (+ a tile of k_shard_pack)
-            d.brepl = take(b, 12 * chunk_parents + 12 * kPackParents + 16);
+            const size_t one_set = (12 * chunk_parents + 12 * kPackParents + 16 + 255) / 256 * 256;  // (+ a tile of k_shard_pack)
+            d.btook = take(b, 2 * one_set);  // two sets, by chunk parity
+            d.brepl = take(b, 2 * one_set);
+            d.flag_stride = one_set;
             flag_bytes = o;
             d.lmask = (int32_t*)take(b, 4 * chunk_parents + 16);
             d.lpre = (uint32_t*)take(b, 4 * chunk_parents + 16);
@@ -1024,6 +1222,7 @@ static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int lev
     geo.subcap = (uint32_t)subcap;
     geo.region_words = (uint32_t)region_words;
     geo.even = (uint32_t)even;
+    geo.par = E.chunk_seq++ & 1u;
     geo.log_off = E.log_off;
     int64_t* send = E.d_send ? E.d_send : E.d.log + E.log_off;
     if ((uint64_t)(E.log_off + total) > E.log_words || (E.d_send && (uint64_t)total > E.send_words))
@@ -1060,8 +1259,12 @@ template <typename W> static int shard_chunk_insert(ShardEngine<W>& E, hipStream
     const unsigned tiles = (unsigned)((geo.subcap + 255) / 256), regions = (unsigned)(kShardSub * E.world);
     unsigned gx = tiles;
     if (E.insert_wgs) gx = std::min(tiles, std::max(1u, E.insert_wgs / regions));
-    if (dedup) hipLaunchKernelGGL(k_shard_insert<W>, dim3(gx, regions), dim3(256), 0, st, E.d, geo, tiles);
-    hipLaunchKernelGGL(k_shard_pack<W>, dim3((geo.n_par + kPackParents - 1) / kPackParents), dim3(256), 0, st, E.d, geo.n_par);
+    if (dedup && tiles) {  // (no tiles: world 1 with born stamps -- no record ever arrives)
+        if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_insert<W, kMoveNf>), dim3(gx, regions), dim3(256), 0, st, E.d, geo, tiles);
+        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_insert<W, kMoveNfCyclical>), dim3(gx, regions), dim3(256), 0, st, E.d, geo, tiles);
+        else hipLaunchKernelGGL((k_shard_insert<W, kMoveGeneral>), dim3(gx, regions), dim3(256), 0, st, E.d, geo, tiles);
+    }
+    hipLaunchKernelGGL(k_shard_pack<W>, dim3((geo.n_par + kPackParents - 1) / kPackParents), dim3(256), 0, st, E.d, geo.n_par, geo.par);
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
@@ -1078,7 +1281,14 @@ template <typename W> static int shard_chunk_commit(ShardEngine<W>& E, int64_t m
     const unsigned tiles = (unsigned)((geo.subcap + 255) / 256), regions = (unsigned)(kShardSub * E.world);
     unsigned gx = tiles;
     if (E.commit_wgs) gx = std::min(tiles, std::max(1u, E.commit_wgs / regions));
-    hipLaunchKernelGGL(k_shard_commit<W>, dim3(gx, regions), dim3(256), 0, st, E.d, geo);
+    if (tiles) hipLaunchKernelGGL(k_shard_commit<W>, dim3(gx, regions), dim3(256), 0, st, E.d, geo);
+    const int64_t np_max = std::min<int64_t>((int64_t)geo.n_par, (int64_t)(E.lvl_hi_host - E.lvl_lo_host));  // this rank's share of the chunk's parents, at most
+    if (E.d.born && np_max > 0) {
+        const dim3 grid((unsigned)((np_max + kBornParents - 1) / kBornParents));
+        if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_commit_born<W, kMoveNf>), grid, dim3(kBornParents), 0, st, E.d, geo);
+        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_commit_born<W, kMoveNfCyclical>), grid, dim3(kBornParents), 0, st, E.d, geo);
+        else hipLaunchKernelGGL((k_shard_commit_born<W, kMoveGeneral>), grid, dim3(kBornParents), 0, st, E.d, geo);
+    }
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }

@@ -223,7 +223,7 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
                 "region_fill_q8": st.get("region_fill_q8"), "region_overflow_reruns": st.get("region_overflow_reruns", 0),
                 "roofline": {"bound": "hbm", "achieved": algo / secs / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
                              "frac": algo / secs / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
-                             "kernel": "k_shard_insert<u64> + k_shard_expand<u64> + k_shard_commit<u64> (whole search, wall time)",
+                             "kernel": "k_shard_expand<u64> (expansion + the claims of the children born on their owner) + k_shard_insert<u64> (received records) + k_shard_commit_born / k_shard_commit<u64> (whole search, wall time)",
                              "algorithmic_bytes": algo, "bytes_per_child": 64.0 + 72.0 * f_new, "children": children}}
 
     def timeline_of(comm, b):
@@ -236,7 +236,7 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
 
     exchange_text = ("per chunk: ONE equal-split all-to-all of child-record regions (headers carry counts and the success / error words) + "
                      "ONE all-reduce of a 12-bit child mask per parent (RCCL); expansion + all-to-all of chunk k+1 run on a side stream "
-                     "beside the dedup + commit of chunk k") if world > 1 else "none (world 1: the chunk is expanded straight into its receive area)"
+                     "beside the dedup + commit of chunk k") if world > 1 else "none (world 1: every child is owned by the one rank and claims its table slot from the expansion kernel; no record is written)"
     one = timed_sharded(comms["shared"], budget)
     one.update({"exchange": exchange_text, "rccl_ranks_seen": world if use_dist else 0, "backend": dist.get_backend() if use_dist else None,
                 "mask_all_reduce_group": "shared" if use_dist else None})
@@ -279,10 +279,10 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
         groups.append(np.array([q for w in range(1, 8) for q in d[w]], dtype=np.int8)[rank::world])
     n_mine = sum(len(g) for g in groups)
 
-    def sweep(kind, cyclical, published, entry):
+    def sweep(kind, cyclical, published, entry, kernel, traffic_key):
         if use_dist:
             dist.barrier()
-        n_solved = n_nodes = 0
+        n_solved = n_nodes = n_children = 0
         sweep_err = None
         try:
             run_search_groups(kind, groups, 10**6, cyclical)  # first call: pays for the device allocations (kept by the block pool)
@@ -294,7 +294,7 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
 
         times = []
         for _ in range(3):  # the median of three timed sweeps (a sweep is 0.3-0.5 s and single samples scatter by +-25 %), no garbage collection while the clock runs
-            n_solved = n_nodes = 0
+            n_solved = n_nodes = n_children = 0
             gc.collect()
             gc.disable()
             t0 = time.perf_counter()
@@ -304,6 +304,7 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
                         for ok, _, s1 in res:
                             n_solved += ok
                             n_nodes += s1["nodes"]
+                            n_children += s1["children"]
             except Exception as e:  # noqa: BLE001
                 sweep_err = e
             tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
@@ -311,23 +312,31 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
             if use_dist:
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             times.append(float(tmax[0]))
-        tot = torch.tensor([n_solved, n_nodes, n_mine, 0.0 if sweep_err is None else 1.0], dtype=torch.float64, device=dev)
+        tot = torch.tensor([n_solved, n_nodes, n_mine, 0.0 if sweep_err is None else 1.0, n_children], dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(tot)
         dt1 = sorted(times)[1]
         if float(tot[3]) > 0:
             return {"error": f"{type(sweep_err).__name__}: {sweep_err}" if sweep_err is not None else "failed on another rank"}
+        # (64 + 72 f) B per generated child over the whole sweep (the seven widths together), per GPU; wall time of the
+        # sweep (the searches of a group run inside ONE launch, so there is no per-search device time to sum)
+        roof = search_roofline({"children": int(tot[4]), "nodes": int(tot[1]), "seconds": dt1 * world}, kernel, traffic_key)
+        roof["unit"] = "GB/s per GPU"
+        roof["timed"] = "wall clock of the whole sweep (median of three), host-side result handling included"
         return {"searches": int(tot[2]), "budget": 10**6, "cyclical": cyclical, "solved": int(tot[0]), "published_solved": published,
-                "nodes": int(tot[1]), "seconds": dt1, "samples_seconds": times, "nodes_per_s": float(tot[1]) / dt1, "searches_per_s": float(tot[2]) / dt1,
-                "n_gpus": world, "scaling": "strong", "entry": entry}
+                "nodes": int(tot[1]), "children": int(tot[4]), "seconds": dt1, "samples_seconds": times, "nodes_per_s": float(tot[1]) / dt1,
+                "children_per_s": float(tot[4]) / dt1, "searches_per_s": float(tot[2]) / dt1,
+                "n_gpus": world, "scaling": "strong", "entry": entry, "roofline": roof}
 
     out["bfs_ms_sweep"] = sweep(_acx.SEARCH_BFS, True, 278,
                                 "acx_search_many per rank: one persistent workgroup per search (k_bfs_multi), the seven max_relator_lengths in "
-                                "flight together; searches dealt round-robin to the ranks")
+                                "flight together; searches dealt round-robin to the ranks",
+                                "k_bfs_multi<u64> / <u128> (one persistent workgroup per search)", "bfs_ms_sweep_1e6")
     # the reference's other published experiment: greedy_search, budget 1e6, on the same 1190 (533 solved)
     out["greedy_ms_sweep"] = sweep(_acx.SEARCH_GREEDY, False, 533,
                                    "acx_search_many per rank: one persistent workgroup per search (k_greedy_multi), the seven "
-                                   "max_relator_lengths in flight together; searches dealt round-robin to the ranks")
+                                   "max_relator_lengths in flight together; searches dealt round-robin to the ranks",
+                                   "k_greedy_multi<u64> / <u128> (one persistent workgroup per search)", "greedy_ms_sweep_1e6")
     if world == 1 and not use_dist:
         for kind, name in ((_acx.SEARCH_BFS, "bfs"), (_acx.SEARCH_GREEDY, "greedy_search")):
             b = budget if kind == _acx.SEARCH_BFS else min(budget, 10**7)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACX_VERSION 302
+#define ACX_VERSION 400  /* history: INTEGRATION.md, "ACX_VERSION history" */
 
 /* return codes */
 #define ACX_OK 0
@@ -170,10 +170,15 @@ int acx_search_last_digest(uint64_t *digest);
 int acx_release_cached_memory(void);
 
 /* n independent searches of the same kind / budget (the batch driver trivialize_miller_schupp_through_search,
- * miller_schupp.py:95-177, runs them one after another): `n_threads` host threads, each search on its own HIP
- * stream, so the small kernels of different searches overlap on the GPU.  Row k of every output belongs to
- * presentation k ([n, path_cap] for the paths); rc_out[k] is that search's return code (ACX_E_CAPACITY when its
- * path needs more than path_cap entries: path_n[k] then holds the required size). */
+ * miller_schupp.py:95-177, runs them one after another).  Both kinds run as GROUPS of searches in ONE launch, one persistent
+ * workgroup per search with its own visited table and node arena (bfs: k_bfs_multi, acx_bfs_multi.h, two workgroups per compute
+ * unit; greedy_search: k_greedy_multi, acx_greedy.h); a group is as many searches as fit the free device memory, and a greedy
+ * search that outgrows a capacity of its workgroup is rerun alone through acx_search.  `n_threads` only matters on the fallback
+ * path (n == 1, L > 61 never reaches it, the diagnostic switches ACX_GREEDY_HOST / ACX_BFS_MANY_STREAMS, `verbose` minima or the
+ * digest hook on): there that many host threads run one acx_search each, every search on its own HIP stream; 1..64, clamped.
+ * Row k of every output belongs to presentation k ([n, path_cap] for the paths); rc_out[k] is that search's return code
+ * (ACX_E_CAPACITY when its path needs more than path_cap entries: path_n[k] then holds the required size).  Results are
+ * identical to n calls of acx_search. */
 int acx_search_many(int kind, const int8_t *h_presentations, int64_t n, int L, int64_t max_nodes, int cyclical,
                     int n_threads, int32_t *solved, int32_t *path_action, int32_t *path_len, int64_t path_cap,
                     int64_t *path_n, acx_search_stats *stats, int32_t *rc_out);

@@ -33,7 +33,7 @@ def layout(n_par, world, KW, fill_q8=0):
     """Python mirror of shard_layout (csrc/acx_shard.hip); tests/test_sharded_cpu.py checks it against acx_shard_layout"""
     n_blocks = -(-12 * n_par // TILE)
     hard = -(-n_blocks // SUB) * TILE
-    cap = hard
+    cap = 0 if world == 1 else hard  # world 1: every child is born where it is owned (no record), a region is its header
     if world > 1:
         if fill_q8 <= 0 or fill_q8 > FILL_DEFAULT:
             fill_q8 = FILL_DEFAULT
@@ -134,7 +134,8 @@ class OracleShardEngine:
         S, cap, rw = self.layout(n_par, fill_q8)
         send = torch.zeros(S * self.world * rw, dtype=torch.int64)
         recv = torch.zeros_like(send) if self.world > 1 else send
-        self.open.append(((c0, n_par, S, cap, rw), recv))  # the orchestrator expands chunk k + 1 before it inserts chunk k
+        born = []  # children of local parents that this rank owns itself: they never travel (the HIP engine: BORN stamps)
+        self.open.append(((c0, n_par, S, cap, rw), recv, born))  # the orchestrator expands chunk k + 1 before it inserts chunk k
         if self.ctl[0] != 0:
             return send, recv
         if level_first:
@@ -168,6 +169,9 @@ class OracleShardEngine:
                     continue
                 k0, k1 = key_of_state(out[a], self.L)
                 o = int(owner_of(torch.tensor([[k0, k1]], dtype=torch.int64), self.world)[0])
+                if o == self.rank:
+                    born.append((tag - 12 * c0, k0, k1, (self.rank << 40) | nid))
+                    continue
                 sub = ((12 * li + a) // TILE) % S
                 reg = regs[o * S + sub]
                 n = int(reg[0])
@@ -196,14 +200,14 @@ class OracleShardEngine:
         return both[:n_par].to(torch.int32)
 
     def chunk_insert(self, n_par):
-        self.geo, self.recv = self.open[self.inserted]
+        self.geo, self.recv, born = self.open[self.inserted]
         self.inserted += 1
         c0, n_par, S, cap, rw = self.geo
         self.gmask_view(n_par)
         if self.ctl[0] != 0:
             return self.packed
         regs = self.recv.view(S * self.world, rw)
-        recs = []
+        recs = list(born)
         for r in range(S * self.world):
             n = int(regs[r, 0])
             if n > cap:
@@ -225,14 +229,14 @@ class OracleShardEngine:
 
     def chunk_insert_dead(self, n_par):
         """masks only (all zero), the chunk stays in the ring: csrc/acx_shard.hip acx_shard_chunk_insert_dead"""
-        self.geo, self.recv = self.open[self.inserted]
+        self.geo, self.recv, _ = self.open[self.inserted]
         self.inserted += 1
         return self.gmask_view(self.geo[1])
 
     def chunk_commit(self, max_nodes):
         if not self.open or self.inserted < 1:
             raise RuntimeError("chunk_commit: no inserted chunk is waiting")
-        self.geo, self.recv = self.open.pop(0)
+        self.geo, self.recv, _ = self.open.pop(0)
         self.inserted = max(self.inserted - 1, 0)
         if self.ctl[0] != 0:
             return

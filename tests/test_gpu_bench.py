@@ -35,7 +35,7 @@ def test_the_multi_rank_code_path_runs_on_one_gpu_and_reports_its_diagnostics():
     a communicator of its own for the masks, per-stage device times of a chunk, cpu_baseline on the line although the run is
     'distributed'."""
     r = subprocess.run([sys.executable, BENCH, "--steps", "20", "--warmup", "5", "--no-extras", "--search-budget", "3000000"],
-                       env=_env(ACX_BENCH_FORCE_DIST="1", ACX_BENCH_STRONG_BUDGET="6000000", ACX_BENCH_CPU_SECONDS="1", MASTER_PORT="29533"),
+                       env=_env(ACX_BENCH_FORCE_DIST="1", ACX_BENCH_STRONG_BUDGET="30000000", ACX_BENCH_CPU_SECONDS="1", MASTER_PORT="29533"),
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -45,11 +45,13 @@ def test_the_multi_rank_code_path_runs_on_one_gpu_and_reports_its_diagnostics():
     s = out["search"]
     assert "error" not in s, s.get("error")
     one = s["bfs_sharded"]
-    assert one["nodes"] == 3000001 and one["rccl_ranks_seen"] == 1 and one["backend"] == "nccl"
+    assert 3000000 <= one["nodes"] < 3000012 and one["rccl_ranks_seen"] == 1 and one["backend"] == "nccl"
     tl = one["timeline"]
-    for k in ("expand_us", "all_to_all_us", "insert_us", "mask_all_reduce_us", "commit_us", "chunk_period_us", "overlap_effective"):
+    for k in ("expand_us", "all_to_all_us", "insert_us", "mask_all_reduce_us", "commit_us"):
         assert tl[k] is not None and tl[k] >= 0, (k, tl)
+    tl4 = s["bfs_sharded_strong"]["timeline"]  # (enough chunks per level for a period)
+    assert tl4["chunk_period_us"] > 0 and tl4["overlap_effective"] > 0, tl4
     assert set(one["by_mask_group"]) == {"shared", "own"} and one["mask_all_reduce_group"] in ("shared", "own")
     assert one["collectives"]["all_to_all_calls"] > 0 and one["collectives"]["mask_all_reduce_calls"] > 0
-    assert s["bfs_sharded_strong"]["nodes"] == 6000001 and s["bfs_sharded_strong"]["budget"] == 6000000
+    assert 30000000 <= s["bfs_sharded_strong"]["nodes"] < 30000012 and s["bfs_sharded_strong"]["budget"] == 30000000
     assert s["bfs_ms_sweep"]["solved"] == 278 and s["greedy_ms_sweep"]["solved"] == 533

@@ -314,6 +314,81 @@ def test_sharded_bfs_mid_size_thread_ranks_equal_the_fused_search(search, golden
             assert st.get("region_overflow_reruns") == 1, st
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("where", ["chunk_expand", "chunk_insert", "chunk_commit"])
+def test_a_host_side_failure_of_the_hip_engine_ends_every_thread_rank_together(search, where):
+    """An engine call of ONE rank raises on the host side (before the C call: what an exhausted allocation or a HIP error looks like
+    to the orchestrator) in the middle of a level of many chunks, with the control block read two chunks late and the expansion
+    running ahead on the side stream.  Every rank must issue the same collectives and raise; a rank left alone in a collective
+    would hang the thread barrier (and this test).  The engine of the failing rank keeps its ring of open chunks in step
+    (acx_shard_chunk_insert_dead), so a second search on fresh engines afterwards is exact."""
+    from ac_solver.search import sharded
+    from ac_solver.search.sharded import HipShardEngine, bfs_sharded
+    from oracle import ac_oracle as O
+    from tests.shard_helpers import run_threads
+
+    ak3 = np.zeros(50, np.int8)
+    ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+    ak3[25:31] = [1, 2, 1, -2, -1, -2]
+    for fail_at in (2, 9, 23):
+        calls = {"n": 0}
+
+        class Flaky(HipShardEngine):
+            def _maybe(self, name):
+                if name == where and self.rank == 1:
+                    calls["n"] += 1
+                    if calls["n"] == fail_at:
+                        raise RuntimeError("engine call failed (simulated)")
+
+            def chunk_expand(self, *a, **k):
+                self._maybe("chunk_expand")
+                return super().chunk_expand(*a, **k)
+
+            def chunk_insert(self, n_par):
+                self._maybe("chunk_insert")
+                return super().chunk_insert(n_par)
+
+            def chunk_commit(self, max_nodes):
+                self._maybe("chunk_commit")
+                return super().chunk_commit(max_nodes)
+
+        def run(comm):
+            try:
+                bfs_sharded(ak3, 200000, comm=comm, engine_factory=Flaky, batch_parents=1 << 10)
+            except RuntimeError as e:
+                return str(e), dict(comm.stats)
+            return "no error", dict(comm.stats)
+
+        out = run_threads(2, run)
+        assert calls["n"] >= fail_at, "the search ended before the failing call"
+        assert all("sharded bfs failed" in m for m, _ in out) and "simulated" in out[1][0], [m for m, _ in out]
+        assert out[0][1] == out[1][1], [st for _, st in out]
+
+    def clean(comm):
+        return bfs_sharded(ak3, 200000, comm=comm, batch_parents=1 << 10)
+
+    assert all(r == O.bfs(ak3, 200000) for r in run_threads(2, clean))
+
+
+def _key_words(state, L, KW):
+    """the packed key of a state as the engine's int64 words (2-bit letters, length in the top six bits of each relator's word)"""
+    code = {-2: 0, -1: 1, 1: 2, 2: 3}
+    words = []
+    for h in (0, 1):
+        w = [int(a) for a in state[h * L:(h + 1) * L] if a != 0]
+        k = 0
+        for i, a in enumerate(w):
+            k |= code[a] << (2 * i)
+        if KW == 2:
+            k |= len(w) << 58
+            words.append(k - (1 << 64) if k >= (1 << 63) else k)
+        else:
+            k |= len(w) << 122
+            for part in (k & ((1 << 64) - 1), k >> 64):
+                words.append(part - (1 << 64) if part >= (1 << 63) else part)
+    return words
+
+
 @pytest.mark.parametrize("L", [25, 36])
 def test_device_routing_matches_owner_of(search, L):
     """acx_shard_chunk_expand routes every child to the region of the rank the orchestrator's owner function names (owner_of),
@@ -337,6 +412,7 @@ def test_device_routing_matches_owner_of(search, L):
         visited = {tuple(ak3.tolist())}
         first_id = 0                  # local id of the level's first node (this engine commits everything: ids are FIFO order)
         nodes = 1
+        n_born = 0
         for lvl in range(5):          # a few levels: 12, then up to 144, ... children
             F = len(level)
             send, recv = eng.chunk_expand(0, F, True)
@@ -365,8 +441,11 @@ def test_device_routing_matches_owner_of(search, L):
                     tag, pid = row[KW] >> 32, row[KW] & 0xFFFFFFFF
                     assert pid == first_id + tag // 12  # the parent's local id
                     got[tag] = row[:KW]
-            assert sorted(got) == sorted(want), (L, world, lvl)
-            recv.copy_(send)  # as if every region came back to this engine
+            # the children this engine (rank 0) owns itself are BORN in the expansion kernel: no record, their slots are claimed there
+            own = {t for t, st in want.items() if int(owner_of(torch.tensor([[int(v) for v in _key_words(st, L, KW)]], dtype=torch.int64), world)[0]) == 0}
+            assert sorted(got) == sorted(set(want) - own), (L, world, lvl)
+            n_born += len(own)
+            recv.copy_(send)  # as if every region came back to this engine: records and born children of one chunk fold together
             packed = eng.chunk_insert(F).clone().to(torch.int64)  # two parents per word
             lmask = torch.stack([packed & 0xFFF, (packed >> 16) & 0xFFF], dim=1).reshape(-1)[:F]
             eng.chunk_commit(1 << 40)
@@ -386,6 +465,7 @@ def test_device_routing_matches_owner_of(search, L):
                 assert a == nxt[k][1] and tl == int(np.count_nonzero(nxt[k][0]))
             first_id += F
             level = nxt
+        assert n_born > 0  # some children were born on this rank (no record) and still came out as nodes in the right places
 
 
 def test_many_searches_overlapped_equal_single(search, golden_json):
