@@ -160,13 +160,48 @@ def _share_success_record(success_record, n_states, device):
     success_record["unsolved"] -= solved
 
 
+class _Phases:
+    """ACX_PPO_PHASES=1: wall time per phase of an update (a device synchronisation at every phase edge, so the run itself is
+    slower), printed by rank 0 at the end of the training loop; off: no-ops."""
+
+    def __init__(self, device):
+        import os
+
+        self.on = bool(os.environ.get("ACX_PPO_PHASES")) and torch.cuda.is_available() and str(device).startswith("cuda")
+        self.acc, self.t = {}, None
+
+    def start(self):
+        if self.on:
+            import time
+
+            torch.cuda.synchronize()
+            self.t = time.perf_counter()
+
+    def lap(self, name):
+        if self.on:
+            import time
+
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            self.acc[name] = self.acc.get(name, 0.0) + now - self.t
+            self.t = now
+
+    def report(self, updates):
+        if self.on and updates:
+            tot = sum(self.acc.values())
+            print("[ppo phases] per update: " + ", ".join(f"{k} {v / updates * 1e3:.1f} ms" for k, v in self.acc.items()) + f"; sum {tot / updates * 1e3:.1f} ms")
+
+
 def refresh_behaviour_stats(agent, obs, actions, logprobs, values):
     """logprobs[t], values[t] <- the f32 agent's log pi(actions[t] | obs[t]) and V(obs[t]) for every rollout row t (in place)."""
+    T, N = actions.shape
+    rows = max(1, min(T, (1 << 20) // max(N, 1)))  # ~1 Mi samples per forward pass: 32 passes of 131 072 rows cost 25 ms at BASELINE config 5's shape, 4 of 1 Mi cost less (fewer, fuller GEMMs)
     with torch.no_grad():
-        for t in range(actions.shape[0]):
-            _, lp, _, v = agent.get_action_and_value(obs[t].float(), actions[t])
-            logprobs[t].copy_(lp)
-            values[t].copy_(v.flatten())
+        for t0 in range(0, T, rows):
+            t1 = min(T, t0 + rows)
+            _, lp, _, v = agent.get_action_and_value(obs[t0:t1].reshape((-1,) + obs.shape[2:]).float(), actions[t0:t1].reshape(-1))
+            logprobs[t0:t1].copy_(lp.view(t1 - t0, N))
+            values[t0:t1].copy_(v.view(t1 - t0, N))
 
 
 def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success_record, ACMoves_hist, states_processed,
@@ -230,8 +265,11 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
         except ImportError:  # pragma: no cover
             pass
     stats = {}
+    ph = _Phases(device)
+    n_updates_done = 0
 
     for update in updates:
+        ph.start()
         random.seed(args.seed + update)
         np.random.seed(args.seed + update)
         torch.manual_seed(args.seed + update)
@@ -255,6 +293,7 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
                 logprobs[step] = logprob
                 values[step] = value.flatten()
             envs.step(action, out=(obs[step + 1], rewards[step], term[step + 1], trunc), check_errors=False)
+            ph.lap("policy+env")
             if normalizer is not None:  # NormalizeReward, then TransformReward(clip) as make_env stacks them
                 rewards[step] = normalizer(rewards[step], term[step + 1])
                 if args.clip_rewards:
@@ -263,6 +302,7 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             ep_length += 1
             fin = term[step + 1] | trunc
             if not bool(fin.any()):
+                ph.lap("episode bookkeeping")
                 continue
             # ---- episodes ended: bookkeeping of the reference (training.py:167-224) on the finished envs only ----
             idx = torch.nonzero(fin).flatten()
@@ -289,6 +329,7 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             # the finished envs restart from their next curriculum state (envs.envs[i].reset(options={"starting_state": ...}))
             envs.reset_envs(idx_h, init_rows[new_states])
             obs[step + 1].index_copy_(0, idx, init_table[torch.as_tensor(new_states, device=device)])
+            ph.lap("episode bookkeeping")
         envs._raise_on_errors()
         if rollout_log is not None:
             rollout_log.append({"obs": obs.cpu().numpy().copy(), "actions": actions.cpu().numpy().copy(), "rewards": rewards.cpu().numpy().copy(),
@@ -308,11 +349,14 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             # against log-probabilities of THAT policy (training.py:283-291): so the behaviour statistics the update uses are
             # recomputed here with one f32 forward over the batch -- the ratio of the first minibatch of the first epoch is then
             # exactly 1, as in the reference.  One row of the rollout at a time keeps the temporaries at [N, 256].
+            ph.lap("rollout tail")
             refresh_behaviour_stats(agent, obs, actions, logprobs, values)
+            ph.lap("behaviour stats (f32)")
         with torch.no_grad():
             next_value = agent.get_value(obs[T].float()).reshape(-1)
             advantages, returns = compute_gae(rewards, values, dones[:T], next_value, dones[T], args.gamma, args.gae_lambda)
 
+        ph.lap("gae")
         b_obs = obs[:T].reshape((-1,) + obs_shape)
         b_logprobs, b_actions = logprobs.reshape(-1), actions.reshape(-1)
         b_advantages, b_returns, b_values = advantages.reshape(-1), returns.reshape(-1), values.reshape(-1)
@@ -361,6 +405,7 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
                     break
             else:
                 beta = beta / 2 if approx_kl < args.target_kl / 1.5 else (beta * 2 if approx_kl > args.target_kl * 1.5 else beta)
+        ph.lap("update (f32 torch)")
         if dist_on and world > 1:
             _share_success_record(success_record, len(initial_states), device)
 
@@ -368,9 +413,10 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
         obs[0].copy_(obs[T])
         term[0].copy_(term[T])
 
-        y_pred, y_true = b_values.cpu().numpy(), b_returns.cpu().numpy()
-        var_y = np.var(y_true)
-        explained_var = np.nan if var_y == 0 else 1 - np.var(y_true - y_pred) / var_y
+        # explained variance on the device (np.var's population variance, as the reference computes it on host copies: two 16 MB
+        # read-backs per update at BASELINE config 5's shape, 20 ms)
+        var_y = float(b_returns.var(unbiased=False))
+        explained_var = np.nan if var_y == 0 else 1 - float((b_returns - b_values).var(unbiased=False)) / var_y
         stats = {
             "charts/global_step": global_step, "charts/episode": episode,
             "charts/normalized_returns_mean": float(normalized_returns.mean()), "charts/normalized_lengths_mean": float(normalized_lengths.mean()),
@@ -404,4 +450,8 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             }
             print(f"saving checkpoint to {out_dir}")
             torch.save(checkpoint, join(out_dir, "ckpt.pt"))
+        ph.lap("stats + tail")
+        n_updates_done += 1
+    if rank == 0:
+        ph.report(n_updates_done)
     return stats

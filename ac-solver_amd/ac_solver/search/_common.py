@@ -1,5 +1,7 @@
 """Shared driver for bfs / greedy_search: hands the presentation to libacx's device frontier."""
 import ctypes as C
+import os
+import time
 
 import numpy as np
 
@@ -83,9 +85,19 @@ def run_search_groups(kind, groups, max_nodes_to_explore, cyclical, n_threads=16
 
     if len(groups) <= 1:
         return [run_search_many(kind, g, max_nodes_to_explore, cyclical, n_threads, path_cap) for g in groups]
+    # Longest first: the widest presentations (128-bit keys from max_relator_length 30) are the slowest searches, and a search that
+    # starts late runs its tail alone on an otherwise idle GPU.  Their launches go out first (the other batches follow a moment
+    # later), so the hardware hands their workgroups compute units before the shorter ones.
+    order = sorted(range(len(groups)), key=lambda k: -np.asarray(groups[k]).shape[-1])
+    stagger = os.environ.get("ACX_SWEEP_STAGGER_MS", "0")  # (a pause between the wide and the narrow batches: measured no better than none)
+    wide = [k for k in order if np.asarray(groups[k]).shape[-1] // 2 > 29]
     with ThreadPoolExecutor(max_workers=len(groups)) as ex:
-        futs = [ex.submit(run_search_many, kind, g, max_nodes_to_explore, cyclical, n_threads, path_cap) for g in groups]
-        return [f.result() for f in futs]
+        futs = {}
+        for pos, k in enumerate(order):
+            if wide and pos == len(wide) and float(stagger) > 0:
+                time.sleep(float(stagger) * 1e-3)
+            futs[k] = ex.submit(run_search_many, kind, groups[k], max_nodes_to_explore, cyclical, n_threads, path_cap)
+        return [futs[k].result() for k in range(len(groups))]
 
 
 def self_check(search_fn, budget=10**6):

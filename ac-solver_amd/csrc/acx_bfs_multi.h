@@ -39,8 +39,16 @@ constexpr int kBmT = ACX_BFS_MULTI_THREADS;  // lanes of the workgroup
 #ifndef ACX_BFS_MULTI_ITEMS
 #define ACX_BFS_MULTI_ITEMS 3
 #endif
+// 128-bit keys (max_relator_length 30 .. 61): TWO children per lane.  With three the kernel needs 133 registers, i.e. one workgroup
+// per compute unit, and the two 128-bit groups of the Miller-Schupp sweep (n = 6, 7) were its critical path: 130 ms per group
+// against 113 ms for a 64-bit one.  With two it fits the 128 registers at which two workgroups share a compute unit (no spills; the
+// 64-bit-shift check of the Makefile passes): the sweep 0.30-0.32 -> 0.26-0.27 s.  (Three 64-bit workgroups per compute unit at 80
+// registers -- ACX_BFS_MULTI_WAVES=6 -- spill 68 bytes per lane and lose: 0.32-0.33 s.)
+#ifndef ACX_BFS_MULTI_ITEMS_128
+#define ACX_BFS_MULTI_ITEMS_128 2
+#endif
 template <typename W> struct bm_cfg {
-    static constexpr int kItems = ACX_BFS_MULTI_ITEMS;
+    static constexpr int kItems = sizeof(W) > 8 ? ACX_BFS_MULTI_ITEMS_128 : ACX_BFS_MULTI_ITEMS;
     static constexpr int kCand = kBmT * kItems;
     static constexpr int kParents = kCand / 12;
     static constexpr int kLds = kCand <= 1024 ? 2048 : (kCand <= 2048 ? 4096 : 8192);  // LDS fold table: a POWER OF TWO >= 2 x the chunk (2 * kCand = 3072
@@ -95,11 +103,19 @@ __global__ void __launch_bounds__(kBmT, ACX_BFS_MULTI_WAVES) k_bfs_multi(const B
     __shared__ uint32_t s_wsum[kBmItems * kBmT / 64];
     __shared__ unsigned long long s_err_tag;
     __shared__ uint32_t s_solved_tag, s_min_len, s_pb, s_committed, s_head, s_nodes, s_status, s_full;
+#if ACX_BFS_MULTI_WAVES >= 6  // three 64-bit workgroups per compute unit: 80 registers (experiment)
+    if (MODE == kMoveGeneral) {
+        ACX_VGPR_PAD_W(W, "v143", "v151");
+    } else {
+        ACX_VGPR_PAD_W(W, "v79", "v127");
+    }
+#else
     if (MODE == kMoveGeneral) {
         ACX_VGPR_PAD_W(W, "v143", "v151");
     } else {
         ACX_VGPR_PAD_W(W, "v119", "v127");
     }
+#endif
     const BfsJob<W> g = jobs[blockIdx.x];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     unsigned long long expanded = 0, batches = 0;

@@ -47,7 +47,7 @@ struct GreedyState {
     uint32_t arena_top, nodes, status, reason, err, seen_min, np_cap, last_parent, solved_pid, last_child_len, solved_action, max_bucket;
     uint32_t cur_len, cur_depth, resume, pad_;
     unsigned long long expanded, batches, sorts, big_sorts, mega_batches, mega_parents;
-    unsigned long long t_phase[12];  // ACX_GREEDY_PROFILE
+    unsigned long long t_phase[24];  // ACX_GREEDY_PROFILE
 };
 
 struct BucketRec {
@@ -97,7 +97,7 @@ struct GreedyOut {
     unsigned long long sorts, big_sorts;
     uint32_t hist_sort[16];  // sorts by log2(bucket size)
     uint32_t hist_np[16];    // batches by log2(parents)
-    unsigned long long t_phase[12];  // [8] global probe rounds (cycles), [9] probe rounds of wave 0 (count)  // shader-clock cycles per phase (thread 0): select, sort, expand, probe, scan+decide, commit, file, tail
+    unsigned long long t_phase[24];  // [12..15] inside commit: stores + ballots, per-length positions, seen + CAS issue, barrier; [16..23] the phases 0..7 over the batches of <= 21 parents only; [8] global probe rounds (cycles), [9] probe rounds of wave 0 (count)  // shader-clock cycles per phase (thread 0): select, sort, expand, probe, scan+decide, commit, file, tail
 };
 
 template <typename W> struct greedy_cfg;
@@ -215,11 +215,14 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         s_reason, s_max_bucket, s_np_cap, s_last_child_len, s_solved_action, s_sorted_in_lds;
     __shared__ unsigned long long s_expanded, s_batches, s_sorts, s_big_sorts, s_err_tag;
     __shared__ uint32_t s_hist[32];
-    __shared__ unsigned long long s_tph[12], s_tc;  // phase clock, kept by thread 0
+    __shared__ unsigned long long s_tph[24], s_tc;  // phase clock, kept by thread 0
+    __shared__ uint32_t s_small;  // (profile) the running bucket holds <= 21 parents
 #if ACX_GREEDY_PROFILE
-#define ACX_TICK(k) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); s_tph[k] += now__ - s_tc; s_tc = now__; } } while (0)
+#define ACX_TICK(k) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); s_tph[k] += now__ - s_tc; if ((k) < 8 && s_small) s_tph[16 + (k)] += now__ - s_tc; s_tc = now__; } } while (0)
+#define ACX_SUBTICK(k) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); s_tph[k] += now__ - s_tc2; s_tc2 = now__; } } while (0)
 #else
 #define ACX_TICK(k) do { } while (0)
+#define ACX_SUBTICK(k) do { } while (0)
 #endif
 
     const uint32_t tid = threadIdx.x;
@@ -238,7 +241,8 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         s_hint[tid] = kDepthCap;
     }
     if (tid < 32) s_hist[tid] = 0;
-    if (tid < 12) s_tph[tid] = 0;
+    if (tid < 24) s_tph[tid] = 0;
+    if (tid == 0) s_small = 0;
 #if ACX_GREEDY_PROFILE
     if (tid == 0) s_tc = clock64();
 #else
@@ -253,7 +257,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
             s_hint[tid] = ps->hint[tid];
         }
         if (tid < 32) s_hist[tid] = ps->hist[tid];
-        if (tid < 12) s_tph[tid] = ps->t_phase[tid];
+        if (tid < 24) s_tph[tid] = ps->t_phase[tid];
         if (tid == 0) {
             s_arena_top = ps->arena_top;
             s_nodes = ps->nodes;
@@ -361,8 +365,12 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                 }
             }
             __syncthreads();
-            ACX_TICK(0);
             const uint32_t n = s_rec.cnt - s_rec.head;
+#if ACX_GREEDY_PROFILE
+            if (tid == 0) s_small = n <= 21u ? 1u : 0u;
+            __syncthreads();
+#endif
+            ACX_TICK(0);
             if (g.hand_min && n >= g.hand_min) {
                 // a big bucket: park the frontier; the host runs this bucket on the whole GPU and relaunches this kernel
                 // (every bucket record goes back to HBM: the selected one is there already, the cached depth follows)
@@ -727,6 +735,9 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         ACX_TICK(4);
         const uint32_t cutoff = s_cutoff, p_end = s_p_end;
         const bool is_solved = s_is_solved != 0;
+#if ACX_GREEDY_PROFILE
+        unsigned long long s_tc2 = clock64();
+#endif
         uint32_t pos[R];
         uint32_t seen = 0xFFFFFFFFu;
 #pragma unroll
@@ -751,6 +762,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
             }
             // LDS atomics are aggregated per wave (thousands of lanes on one address would serialise):
             unsigned long long cb = __ballot(cm);
+            ACX_SUBTICK(12);
             if (cb && lane == 63u - (uint32_t)__builtin_clzll(cb)) atomicMax(&s_committed, cpos[r] + 1);  // cpos grows with the lane
             while (cb) {  // position inside the target bucket: one atomicAdd per (wave, total length)
                 const uint32_t lead = (uint32_t)__builtin_ctzll(cb);
@@ -763,6 +775,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                 cb &= ~same;
             }
         }
+        ACX_SUBTICK(13);
         for (int o = 32; o > 0; o >>= 1) seen = min(seen, (uint32_t)__shfl_xor((int)seen, o));
         if (lane == 0 && seen != 0xFFFFFFFFu) atomicMin(&s_seen_min, seen);
         // visited-table insertion: the keys are pairwise distinct and absent; the CAS goes to the empty slot the probe
@@ -771,7 +784,9 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
 #pragma unroll
         for (int r = 0; r < R; r++)
             cas_old[r] = (fl[r] & 8u) ? atomicCAS(&g.tab[hv[r]], kTabEmpty, (unsigned long long)(nodes + cpos[r]) | ((unsigned long long)fpv[r] << 32)) : kTabEmpty;
+        ACX_SUBTICK(14);
         lds_barrier();
+        ACX_SUBTICK(15);
         ACX_TICK(5);
         // ---- file the new nodes into their buckets (total length, depth + 1): one owner lane per length ----
         if (tid < nlen && s_lcnt[tid] > 0 && !is_solved) {
@@ -869,7 +884,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
             ps->hint[tid] = s_hint[tid];
         }
         if (tid < 32) ps->hist[tid] = s_hist[tid];
-        if (tid < 12) ps->t_phase[tid] = s_tph[tid];
+        if (tid < 24) ps->t_phase[tid] = s_tph[tid];
         if (tid == 0) {
             ps->arena_top = s_arena_top;
             ps->nodes = s_nodes;
@@ -911,7 +926,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         out->max_bucket = s_max_bucket;
         out->sorts = s_sorts;
         out->big_sorts = s_big_sorts;
-        for (int k = 0; k < 12; k++) out->t_phase[k] = s_tph[k];
+        for (int k = 0; k < 24; k++) out->t_phase[k] = s_tph[k];
         for (int k = 0; k < 16; k++) out->hist_sort[k] = s_hist[k], out->hist_np[k] = s_hist[16 + k];
         out->path_n = 0;
         if (path_act && (s_status == GREEDY_SOLVED || s_status == GREEDY_BUDGET || s_status == GREEDY_EXHAUSTED)) {

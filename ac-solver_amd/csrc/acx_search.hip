@@ -756,6 +756,15 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
         if (tot) fprintf(stderr, "[acx_greedy] sort cycles: %.1f%% of all in buckets > LDS, %.1f%% in 256 < n <= LDS\n", 100.0 * o.t_phase[10] / tot, 100.0 * o.t_phase[11] / tot);
         if (tot) fprintf(stderr, "[acx_greedy] probe: %.1f%% of the cycles in the table rounds, %.2f rounds per batch (wave 0)\n", 100.0 * o.t_phase[8] / (tot + o.t_phase[8]),
                          (double)o.t_phase[9] / (double)o.batches);
+        if (tot) {
+            unsigned long long ts = 0;
+            for (int k = 16; k < 24; k++) ts += o.t_phase[k];
+            fprintf(stderr, "[acx_greedy] buckets of <= 21 parents: %.1f%% of all cycles; their cycles%%: select %.1f sort %.1f expand %.1f probe %.1f scan %.1f commit %.1f file %.1f tail %.1f\n",
+                    100.0 * ts / tot, 100.0 * o.t_phase[16] / ts, 100.0 * o.t_phase[17] / ts, 100.0 * o.t_phase[18] / ts, 100.0 * o.t_phase[19] / ts, 100.0 * o.t_phase[20] / ts,
+                    100.0 * o.t_phase[21] / ts, 100.0 * o.t_phase[22] / ts, 100.0 * o.t_phase[23] / ts);
+            fprintf(stderr, "[acx_greedy] inside commit (%% of all cycles): stores + ballots %.1f, per-length positions %.1f, seen + CAS issue %.1f, barrier %.1f\n",
+                    100.0 * o.t_phase[12] / tot, 100.0 * o.t_phase[13] / tot, 100.0 * o.t_phase[14] / tot, 100.0 * o.t_phase[15] / tot);
+        }
         if (tot) fprintf(stderr, "[acx_greedy] cycles%%: select %.1f sort %.1f expand %.1f probe %.1f scan %.1f commit %.1f file %.1f tail %.1f (total %.3e cycles)\n",
                 100.0 * o.t_phase[0] / tot, 100.0 * o.t_phase[1] / tot, 100.0 * o.t_phase[2] / tot, 100.0 * o.t_phase[3] / tot, 100.0 * o.t_phase[4] / tot,
                 100.0 * o.t_phase[5] / tot, 100.0 * o.t_phase[6] / tot, 100.0 * o.t_phase[7] / tot, (double)tot);

@@ -311,8 +311,12 @@ __device__ __forceinline__ uint32_t inverse_action(uint32_t a) { return a < 4 ? 
 // profiles/r3_shard_1e8_pmc_summary.txt), and with a lane per (parent, action) in tag order -- the first version, as the fused
 // k_bfs_expand_insert has it -- the twelve actions of a parent sit in adjacent lanes, so every wave ran the concatenation AND
 // the conjugation path of the move for every child.  With the action uniform across the wave only the taken path issues.
-template <typename W, int MODE>
+// SOLO (world 1 with born stamps): every child is owned here and born here -- no owner masks, no region reservation, no record;
+// the tile's took-flags leave through LDS as coalesced dwords (the chunk's local parents are ALL its parents, so the tile's tags
+// are 1536 consecutive bytes), as in the fused search.
+template <typename W, int MODE, bool SOLO>
 __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, ChunkGeo g, int64_t* __restrict__ send) {
+    __shared__ uint32_t s_took[SOLO ? kExpandTile / 4 : 1];  // one byte per tag of the tile
     __shared__ W s_k0[kExpandTile];
     __shared__ W s_k1[kExpandTile];
     __shared__ uint32_t s_slot[kFoldSlots];
@@ -327,7 +331,9 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
     if (blockIdx.x * kExpandParents >= np) return;
     if (tid < 64) s_cnt[tid] = 0;
     for (uint32_t i = tid; i < (uint32_t)kFoldSlots; i += kExpandThreads) s_slot[i] = kEmpty;
-    for (uint32_t i = tid; i < d.world * (uint32_t)kExpandParents; i += kExpandThreads) s_bits[i] = 0;
+    if (!SOLO)
+        for (uint32_t i = tid; i < d.world * (uint32_t)kExpandParents; i += kExpandThreads) s_bits[i] = 0;
+    if (SOLO && tid < (uint32_t)kExpandTile / 4) s_took[tid] = 0;
     // this lane's parent (the same for its three actions)
     const uint32_t p = blockIdx.x * kExpandParents + l, id = s_lo + p;
     const bool live = p < np;
@@ -415,7 +421,9 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
         owner[it] = 0xFFFFFFFFu;
         pos[it] = 0;
         born[it] = false;
-        if (send_it[it] && s_slot[ls[it]] == me[it]) {
+        if (SOLO) {
+            born[it] = send_it[it] && s_slot[ls[it]] == me[it];
+        } else if (send_it[it] && s_slot[ls[it]] == me[it]) {
             owner[it] = owner_of_hash(hk[it], d.world);
             if (d.born && owner[it] == d.rank) {  // stays home: claims its slot below, no record
                 born[it] = true;
@@ -425,6 +433,7 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
             }
         }
     }
+    if (!SOLO) {
     __syncthreads();
     for (uint32_t o = tid >> 6; o < d.world; o += kExpandThreads / 64) {  // every wave scans some of the owners: survivors per parent, prefix over the parents
         uint32_t run = 0;
@@ -462,6 +471,7 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
         // record word: parent's local id | (tag relative to the chunk) << 32
         r[recio<W>::KW] = (int64_t)(((unsigned long long)(uint32_t)(12ull * gp + a - 12ull * (unsigned long long)g.c0) << 32) | id);
     }
+    }  // !SOLO
     // ---- the children this rank owns itself claim their slots here (BORN stamps): the probe loop of the fused search
     // (acx_bfs.h: k_bfs_expand_insert), a bucket of four slots = one 32-byte sector per step.  Occupants: a record (a chunk that
     // was dedup'ed before this kernel started, or -- on the main stream, beside this kernel -- the chunk before mine: smaller tags
@@ -518,7 +528,15 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
                 open = false;
             }
         }
-        if (took) btook[12u * (gp - (uint32_t)g.c0) + a] = 1;
+        if (took) {
+            if (SOLO) ((uint8_t*)s_took)[12u * l + a] = 1;
+            else btook[12u * (gp - (uint32_t)g.c0) + a] = 1;
+        }
+    }
+    if (SOLO) {  // btook of the tile's tags, coalesced (zero = did not take a slot)
+        __syncthreads();
+        const uint32_t t0 = 12u * (s_lo - d.bounds[2 * g.par] + blockIdx.x * (uint32_t)kExpandParents);  // the tile's first parent is local parent blockIdx.x * 128 = position c0 + that
+        if (tid < (uint32_t)kExpandTile / 4 && t0 + 4u * tid < 12u * np) ((uint32_t*)(btook + t0))[tid] = s_took[tid];
     }
 }
 
@@ -1242,9 +1260,13 @@ static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int lev
     if (np_max > 0) {
         const dim3 grid((unsigned)((np_max + kExpandParents - 1) / kExpandParents));
         const size_t lds = (size_t)E.world * kExpandParents * 4;  // s_bits
-        if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_expand<W, kMoveNf>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
-        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_expand<W, kMoveNfCyclical>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
-        else hipLaunchKernelGGL((k_shard_expand<W, kMoveGeneral>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
+        if (E.world == 1 && E.d.born) {
+            if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_expand<W, kMoveNf, true>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
+            else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_expand<W, kMoveNfCyclical, true>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
+            else hipLaunchKernelGGL((k_shard_expand<W, kMoveGeneral, true>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
+        } else if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_expand<W, kMoveNf, false>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
+        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_expand<W, kMoveNfCyclical, false>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
+        else hipLaunchKernelGGL((k_shard_expand<W, kMoveGeneral, false>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
     }
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
