@@ -45,7 +45,7 @@ enum : uint32_t { GREEDY_RUNNING = 0, GREEDY_SOLVED = 1, GREEDY_BUDGET = 2, GREE
 struct GreedyState {
     uint32_t len_count[132], hint[132], hist[32];
     uint32_t arena_top, nodes, status, reason, err, seen_min, np_cap, last_parent, solved_pid, last_child_len, solved_action, max_bucket;
-    uint32_t cur_len, cur_depth, resume, pad_;
+    uint32_t cur_len, cur_depth, resume, depth_hi;  // depth_hi: the largest depth any node has (buckets of deeper depths still hold the zeroes of the set-up)
     unsigned long long expanded, batches, sorts, big_sorts, mega_batches, mega_parents;
     unsigned long long t_phase[24];  // ACX_GREEDY_PROFILE
 };
@@ -80,6 +80,8 @@ template <typename W> struct GreedyDev {
     uint32_t nlen;      // 2L + 1 total lengths
     long long max_nodes;
     uint32_t root_len;
+    uint32_t nf;         // 1: the root is in normal form (freely -- with `cyclical`, cyclically -- reduced, both relators non-empty), so every node is: the
+                         // kernels instantiated for that run the shorter move code apply_move_nf (acx_word.h; what the BFS kernels call kMoveNf)
     uint32_t hand_min;   // 0: never; else a selected bucket with at least this many queued parents ends the kernel with GREEDY_HANDOFF
     GreedyState* state;  // nullable (k_greedy_multi): where the frontier is parked / resumed from
     const uint32_t* mega_status;  // nullable: {status, cut, remaining} of the whole-GPU kernels (acx_greedy_mega.h: MegaScalars).  The host
@@ -114,6 +116,19 @@ constexpr uint32_t kGreedyMultiThreads = ACX_GREEDY_MULTI_THREADS;
 #endif
 template <> struct greedy_cfg<uint64_t> { static constexpr uint32_t kSortCap = ACX_GREEDY_MULTI_R * kGreedyMultiThreads; };
 template <> struct greedy_cfg<u128> { static constexpr uint32_t kSortCap = 2 * kGreedyMultiThreads; };
+
+// The hash of the greedy frontier's tables (visited table: slot = low bits, 32-bit fingerprint = high half; in-batch tables: low bits /
+// bits 40..): one multiply-xorshift round per key word, as the BFS stamp tables use (acx_bfs.h: stamp_hash).  Rounds 1-3 used
+// acx_frontier.h's hash_key -- five 64-bit multiplies, fifteen quarter-rate instructions on the critical path of every batch.
+ACX_HD uint64_t greedy_mix(uint64_t h, uint64_t w) {
+    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+ACX_HD uint64_t greedy_hash(uint64_t k0, uint64_t k1) { return greedy_mix(greedy_mix(0, k0), k1); }
+ACX_HD uint64_t greedy_hash(u128 k0, u128 k1) {
+    const uint64_t h = greedy_mix(greedy_mix(0, (uint64_t)k0), (uint64_t)(k0 >> 64));
+    return greedy_mix(greedy_mix(h, (uint64_t)k1), (uint64_t)(k1 >> 64));
+}
 
 template <typename W> __device__ __forceinline__ bool key_less(W a0, W a1, W b0, W b1) {
     Pres<W> a, b;
@@ -189,13 +204,14 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, ui
 
 // The whole search, executed by one 1024-lane workgroup.  path_act / path_len (nullable, `path_cap` entries): the
 // reference's return path, (-1, len0), (action, length) ... , written by lane 0 at the end; out->path_n is its length.
-template <typename W, uint32_t SC, uint32_t kGT>  // SC candidates per batch, kGT lanes (shadows the namespace constant: the single search's workgroup)
+template <typename W, uint32_t SC, uint32_t kGT, bool NF>  // SC candidates per batch, kGT lanes (shadows the namespace constant: the single search's workgroup), NF: normal-form search
 __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __restrict__ out, int32_t* __restrict__ path_act,
                                            int32_t* __restrict__ path_len, long long path_cap) {
     constexpr int R = (int)(SC / kGT);                     // children per lane in a full batch
     constexpr uint32_t kPmax = (uint32_t)(R * kGT) / 12u;  // parents in a full batch
     constexpr uint32_t kBT = 2 * SC;                       // in-batch dedup table (LDS)
     constexpr uint32_t kNW = (uint32_t)R * (kGT / 64);     // wave-level winner counts per batch (<= 64)
+    constexpr uint32_t kDirectPos = 192;                   // batches with at most this many new states take their bucket positions with one LDS atomic per lane
     __shared__ W sk0[SC];  // sort keys; double as the candidate keys of a batch (indexed by tag)
     __shared__ W sk1[SC];
     __shared__ uint32_t sid[SC];
@@ -209,14 +225,24 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
     __shared__ uint32_t s_wcnt[64], s_woff[64];
     __shared__ BucketRec s_rec;
     __shared__ BucketRec s_frec[132];  // records of the buckets (length, s_fdepth): the depth the running batches file into
+    // Fresh buckets (round 4, batches of one candidate per lane): a bucket that was EMPTY before the last batch filed into it consists
+    // of that batch's children, and those are still in LDS (candidate keys sk0 / sk1 by tag, their ids and bucket positions in
+    // s_keep).  When such a bucket is selected next -- the usual case behind a cut, and behind a bucket that one batch used up -- it
+    // is ordered and staged from there: no arena load, no key load (two dependent trips of the sort, two of the staging).
+    constexpr bool kFresh = R == 1;
+    __shared__ uint32_t s_keep[kFresh ? kGT : 1];  // per candidate of the last batch: bit 31 committed, bits 11..21 position in its bucket, bits 0..10 rank among the batch's new nodes
+    __shared__ uint32_t s_keep_n;                  // candidates of the last batch that s_keep / sk0 / sk1 / s_clen describe (0: none)
+    __shared__ uint8_t s_fresh[132];               // bucket (length, filing depth) held nothing before the last batch
+    __shared__ uint32_t s_keep_nodes;              // id of the last batch's first new node
     __shared__ uint32_t s_fdepth;
     __shared__ uint32_t s_minlen, s_mindepth, s_solved, s_shorter, s_lo, s_err, s_seen_min, s_njobs, s_arena_top, s_committed, s_flag, s_total;
     __shared__ uint32_t s_p_end, s_cutoff, s_budget_hit, s_is_solved, s_last_parent, s_solved_pid, s_cur_len, s_cur_depth, s_nodes, s_status,
-        s_reason, s_max_bucket, s_np_cap, s_last_child_len, s_solved_action, s_sorted_in_lds;
+        s_reason, s_max_bucket, s_np_cap, s_last_child_len, s_solved_action, s_sorted_in_lds, s_depth_hi;
     __shared__ unsigned long long s_expanded, s_batches, s_sorts, s_big_sorts, s_err_tag;
     __shared__ uint32_t s_hist[32];
     __shared__ unsigned long long s_tph[24], s_tc;  // phase clock, kept by thread 0
     __shared__ uint32_t s_small;  // (profile) the running bucket holds <= 21 parents
+    (void)s_small;
 #if ACX_GREEDY_PROFILE
 #define ACX_TICK(k) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); s_tph[k] += now__ - s_tc; if ((k) < 8 && s_small) s_tph[16 + (k)] += now__ - s_tc; s_tc = now__; } } while (0)
 #define ACX_SUBTICK(k) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); s_tph[k] += now__ - s_tc2; s_tc2 = now__; } } while (0)
@@ -241,6 +267,8 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         s_hint[tid] = kDepthCap;
     }
     if (tid < 32) s_hist[tid] = 0;
+    if (tid < 132) s_fresh[tid] = 0;
+    if (tid == 0) s_keep_n = 0;
     if (tid < 24) s_tph[tid] = 0;
     if (tid == 0) s_small = 0;
 #if ACX_GREEDY_PROFILE
@@ -275,6 +303,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
             s_last_child_len = ps->last_child_len;
             s_solved_action = ps->solved_action;
             s_np_cap = ps->np_cap;
+            s_depth_hi = ps->depth_hi;
             s_flag = 0;
             s_sorted_in_lds = 0;
             s_fdepth = 0xFFFFFFFFu;
@@ -287,7 +316,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         d.act[0] = 0xff;
         d.tlen[0] = (uint8_t)g.root_len;
         d.depth[0] = 0;
-        const uint64_t h = hash_key<W>(g.root_k0, g.root_k1);
+        const uint64_t h = greedy_hash(g.root_k0, g.root_k1);
         g.tab[(uint32_t)h & gmask] = (h >> 32) << 32;  // node 0 with its fingerprint
         BucketRec r = {0u, 16u, 0u, 1u, 1u, {0u, 0u, 0u}};
         g.arena[0] = 0;
@@ -311,6 +340,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         s_last_child_len = 0;
         s_solved_action = 0;
         s_np_cap = kGT / 12;
+        s_depth_hi = 0;
         s_flag = 0;  // 1: the current bucket record in s_rec is valid
         s_sorted_in_lds = 0;
         s_fdepth = 0xFFFFFFFFu;
@@ -333,23 +363,38 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                 __syncthreads();
                 break;
             }
-            {
+            // Shortcut (round 4): when the bucket of length l at the CACHED depth holds every queued entry of that length, it is the
+            // minimum-depth bucket of l -- no bitmap load, no record load: the two dependent trips of this phase (2.1 us of a
+            // 10 us small batch).  That is the common case: a batch that was cut by a new shorter child is followed by the bucket
+            // it has just created, and a bucket that was used up by the one its children went to.
+            const uint32_t fd0 = s_fdepth;
+            const bool whole = fd0 != 0xFFFFFFFFu && s_frec[l].cnt - s_frec[l].head == s_len_count[l];  // (uniform: nobody writes these here)
+#if ACX_GREEDY_PROFILE
+            if (tid == 0) {
+                s_hist[28]++;
+                if (whole) s_hist[29]++;
+                if (kFresh && whole && s_fresh[l] != 0) s_hist[30]++;
+            }
+#endif
+            if (!whole) {
                 const uint32_t w = s_hint[l] / 32 + tid;
                 if (w < kDepthCap / 32) {
                     const uint32_t bits = g.bitmap[(size_t)l * (kDepthCap / 32) + w];
                     if (bits) atomicMin(&s_mindepth, w * 32 + (uint32_t)__builtin_ctz(bits));
                 }
+                __syncthreads();
             }
-            __syncthreads();
             {
                 // the selected bucket's record comes from the LDS cache when it is a bucket of the cached depth; the cache
-                // then moves to depth + 1 (the children's depth): old records out, new records in, one trip together
-                const uint32_t D = s_mindepth, fd = s_fdepth;
+                // then moves to depth + 1 (the children's depth): old records out, new records in, one trip together -- and no
+                // trip at all for a depth that no node has reached yet (its records are still the zeroes of the set-up)
+                const uint32_t D = whole ? fd0 : s_mindepth, fd = fd0;
                 BucketRec cur, nxt;
                 if (tid == 0) cur = D == fd ? s_frec[l] : g.bk[(size_t)l * kDepthCap + D];
                 const bool move = fd != D + 1 && D + 1 < kDepthCap && tid < nlen;
                 if (move) {
-                    nxt = g.bk[(size_t)tid * kDepthCap + D + 1];
+                    if (D + 1 > s_depth_hi) nxt = BucketRec{0u, 0u, 0u, 0u, 0u, {0u, 0u, 0u}};
+                    else nxt = g.bk[(size_t)tid * kDepthCap + D + 1];
                     if (fd != 0xFFFFFFFFu) g.bk[(size_t)tid * kDepthCap + fd] = s_frec[tid];
                 }
                 __syncthreads();  // (tid 0 read s_frec[l] before it is replaced)
@@ -379,6 +424,27 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                 __syncthreads();
                 break;
             }
+            const bool fresh_sel = whole && s_keep_n != 0 && s_fresh[l] != 0;  // (uniform) the bucket is made of the last batch's children
+            // ---- a fresh bucket: its entries are the last batch's children, still in LDS ---------------------------------
+            const bool fast = kFresh && fresh_sel && n <= SC;  // (uniform)
+            if (fast) {
+                const uint32_t kp = tid < s_keep_n ? s_keep[kFresh ? tid : 0] : 0u;
+                const bool mine = (kp >> 31) != 0 && (uint32_t)s_clen[tid] == l;  // candidate tid of the last batch (one per lane)
+                W key0 = 0, key1 = 0;
+                if (mine) {
+                    key0 = sk0[tid];
+                    key1 = sk1[tid];
+                }
+                __syncthreads();  // every candidate key is read before the sort arrays overwrite them
+                if (mine) {
+                    const uint32_t at = (kp >> 11) & 0x7FFu;
+                    sk0[at] = key0;
+                    sk1[at] = key1;
+                    sid[at] = s_keep_nodes + (kp & 0x7FFu);
+                }
+                if (tid == 0 && n == 1) s_sorted_in_lds = 1;  // nothing to order: the staging below takes it from here
+                __syncthreads();
+            }
             // ---- order the bucket by the signed state tuple if it has an unsorted tail ----------------------
             if (s_rec.sorted_end < s_rec.cnt && n > 1) {
                 const uint32_t base = s_rec.off + s_rec.head;
@@ -392,12 +458,18 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                     uint32_t myid = 0;
                     W m0 = 0, m1 = 0;
                     if (tid < n) {
-                        myid = g.arena[base + tid];
-                        const NodeKey<W> nk = g.nkeys[myid];
-                        m0 = nk.k0;
-                        m1 = nk.k1;
-                        sk0[tid] = m0;
-                        sk1[tid] = m1;
+                        if (fast) {
+                            myid = sid[tid];
+                            m0 = sk0[tid];
+                            m1 = sk1[tid];
+                        } else {
+                            myid = g.arena[base + tid];
+                            const NodeKey<W> nk = g.nkeys[myid];
+                            m0 = nk.k0;
+                            m1 = nk.k1;
+                            sk0[tid] = m0;
+                            sk1[tid] = m1;
+                        }
                         s_btab[tid] = 0;  // rank
                     }
                     __syncthreads();
@@ -422,13 +494,14 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                     }
                     if (tid == 0) s_sorted_in_lds = 1;
                 } else if (n <= SC) {
-                    for (uint32_t i = tid; i < n; i += kGT) {
-                        const uint32_t id = g.arena[base + i];
-                        sid[i] = id;
-                        const NodeKey<W> nk = g.nkeys[id];
-                        sk0[i] = nk.k0;
-                        sk1[i] = nk.k1;
-                    }
+                    if (!fast)
+                        for (uint32_t i = tid; i < n; i += kGT) {
+                            const uint32_t id = g.arena[base + i];
+                            sid[i] = id;
+                            const NodeKey<W> nk = g.nkeys[id];
+                            sk0[i] = nk.k0;
+                            sk1[i] = nk.k1;
+                        }
                     lds_sort<W, kGT>(sk0, sk1, sid, n, tid);
                     for (uint32_t i = tid; i < n; i += kGT) g.arena[base + i] = sid[i];
                     if (tid == 0) s_sorted_in_lds = 1;
@@ -572,14 +645,14 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                 const uint32_t p = t / 12u;
                 Pres<W> s;
                 key_to_pres<W>(sp_k0[p], sp_k1[p], s);
-                const int e = apply_move<W, kSearchSafe>(s, (int)(t - 12u * p), d.L, d.cyclical != 0);
+                const int e = NF ? apply_move_nf<W, kSearchSafe>(s, (int)(t - 12u * p), d.L, d.cyclical != 0) : apply_move<W, kSearchSafe>(s, (int)(t - 12u * p), d.L, d.cyclical != 0);
                 if (e) atomicMin(&s_err_tag, ((unsigned long long)t << 8) | (unsigned long long)e);  // counts only if the reference gets this far
                 const W c0 = keyops<W>::make(s.w0, s.n0), c1 = keyops<W>::make(s.w1, s.n1);
                 const uint32_t tl = (uint32_t)(s.n0 + s.n1);
                 sk0[t] = c0;
                 sk1[t] = c1;
                 s_clen[t] = (uint8_t)tl;
-                const uint64_t h = hash_key<W>(c0, c1);
+                const uint64_t h = greedy_hash(c0, c1);
                 hv[r] = (uint32_t)h & gmask;
                 hb[r] = (uint32_t)h & (bt - 1);
                 fl[r] = 1u;
@@ -764,6 +837,14 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
             unsigned long long cb = __ballot(cm);
             ACX_SUBTICK(12);
             if (cb && lane == 63u - (uint32_t)__builtin_clzll(cb)) atomicMax(&s_committed, cpos[r] + 1);  // cpos grows with the lane
+            if (total <= kDirectPos) {
+                // A small batch (most are: 8-15 parents): one returning LDS atomic per committed lane.  The aggregation below is a chain
+                // of four dependent LDS operations per distinct length and wave (2300 cycles of a 21 000-cycle batch in the kernel's
+                // own clock); a few dozen lanes on a handful of counters serialise for far less.  (The order of a bucket's entries
+                // does not matter: a bucket is sorted by state before it is popped.)
+                if (cm) pos[r] = atomicAdd(&s_lcnt[tl], 1u);
+                cb = 0;
+            }
             while (cb) {  // position inside the target bucket: one atomicAdd per (wave, total length)
                 const uint32_t lead = (uint32_t)__builtin_ctzll(cb);
                 const uint32_t v = (uint32_t)__shfl((int)tl, (int)lead);
@@ -774,6 +855,11 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                 if (cm && tl == v) pos[r] = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
                 cb &= ~same;
             }
+            if (kFresh) s_keep[kFresh ? tid : 0] = cm ? (0x80000000u | (pos[r] << 11) | cpos[r]) : 0u;
+        }
+        if (tid == 0) {
+            s_keep_nodes = nodes;
+            s_keep_n = kFresh ? (uint32_t)kGT : 0u;
         }
         ACX_SUBTICK(13);
         for (int o = 32; o > 0; o >>= 1) seen = min(seen, (uint32_t)__shfl_xor((int)seen, o));
@@ -789,6 +875,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         ACX_SUBTICK(15);
         ACX_TICK(5);
         // ---- file the new nodes into their buckets (total length, depth + 1): one owner lane per length ----
+        if (tid < 132) s_fresh[tid] = 0;
         if (tid < nlen && s_lcnt[tid] > 0 && !is_solved) {
             const uint32_t k = s_lcnt[tid];
             if (D1 >= kDepthCap) {
@@ -821,6 +908,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                 r.cnt += k;
                 if (s_status == GREEDY_RUNNING) {
                     s_frec[tid] = r;
+                    if (lv == 0) s_fresh[tid] = 1;
                     if (lv == 0) atomicOr(&g.bitmap[(size_t)tid * (kDepthCap / 32) + D1 / 32], 1u << (D1 & 31));
                     s_len_count[tid] += k;
                     if (D1 < s_hint[tid]) s_hint[tid] = D1;
@@ -830,9 +918,14 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         lds_barrier();
         ACX_TICK(6);
         if (s_status != GREEDY_RUNNING) break;
+        // The value every CAS is compared with, made opaque HERE: without this the compiler compares (and so waits for) the result
+        // right behind the atomic -- `global_atomic_cmpswap_x2; s_waitcnt vmcnt(0)` in front of the filing phase, the whole round
+        // trip exposed (7 % of the kernel's cycles by its own clock) -- instead of here, behind it.
+        unsigned long long tab_empty = kTabEmpty;
+        asm volatile("" : "+v"(tab_empty));
 #pragma unroll
         for (int r = 0; r < R; r++) {  // settle the table insertions (a failed CAS: another new key took the slot in this batch, rare)
-            if (!(fl[r] & 8u) || cas_old[r] == kTabEmpty) continue;
+            if (!(fl[r] & 8u) || cas_old[r] == tab_empty) continue;
             const unsigned long long mine = (unsigned long long)(nodes + cpos[r]) | ((unsigned long long)fpv[r] << 32);
             do hv[r] = (hv[r] + 1) & g.tmask;
             while (atomicCAS(&g.tab[hv[r]], kTabEmpty, mine) != kTabEmpty);
@@ -849,6 +942,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
             s_batches++;
             s_expanded += popped;
             s_nodes = nodes + s_committed;
+            if (s_committed && !is_solved && D1 > s_depth_hi) s_depth_hi = D1;
             if (s_err) {
                 s_status = GREEDY_MOVE_ERROR;
             } else if (is_solved) {
@@ -902,6 +996,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
             ps->last_child_len = s_last_child_len;
             ps->solved_action = s_solved_action;
             ps->np_cap = s_np_cap;
+            ps->depth_hi = s_depth_hi;
             ps->cur_len = s_cur_len;
             ps->cur_depth = s_cur_depth;
             ps->resume = 1;
@@ -960,18 +1055,18 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
 #define ACX_GREEDY_SINGLE_SC 1024  // 0: as the many-search kernel
 #endif
 template <typename W> constexpr uint32_t kSingleSortCap = ACX_GREEDY_SINGLE_SC ? (uint32_t)ACX_GREEDY_SINGLE_SC : greedy_cfg<W>::kSortCap;
-template <typename W>
+template <typename W, bool NF>
 __global__ void __launch_bounds__(kGT) k_greedy_persistent(GreedyDev<W> g, GreedyOut* __restrict__ out) {
-    greedy_run<W, kSingleSortCap<W>, (uint32_t)kGT>(g, out, nullptr, nullptr, 0);
+    greedy_run<W, kSingleSortCap<W>, (uint32_t)kGT, NF>(g, out, nullptr, nullptr, 0);
 }
 
 // One search per workgroup: acx_search_many runs a whole group of independent greedy searches in ONE launch (a
 // stream per search is limited by the few hardware queues a process gets; here every CU can carry a search).
-template <typename W>
+template <typename W, bool NF>
 __global__ void __launch_bounds__(kGreedyMultiThreads) k_greedy_multi(const GreedyDev<W>* __restrict__ gs, GreedyOut* __restrict__ outs, int32_t* __restrict__ path_act,
                                                       int32_t* __restrict__ path_len, long long path_cap) {
     const GreedyDev<W> g = gs[blockIdx.x];
-    greedy_run<W, greedy_cfg<W>::kSortCap, kGreedyMultiThreads>(g, outs + blockIdx.x, path_act + (size_t)blockIdx.x * path_cap, path_len + (size_t)blockIdx.x * path_cap, path_cap);
+    greedy_run<W, greedy_cfg<W>::kSortCap, kGreedyMultiThreads, NF>(g, outs + blockIdx.x, path_act + (size_t)blockIdx.x * path_cap, path_len + (size_t)blockIdx.x * path_cap, path_cap);
 }
 
 }  // namespace acx

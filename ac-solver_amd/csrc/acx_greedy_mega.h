@@ -151,7 +151,7 @@ template <typename W> __device__ __forceinline__ void gm_child(const MegaDev<W>&
     p1 = nk.k1;
     Pres<W> s;
     key_to_pres<W>(p0, p1, s);
-    e = apply_move<W, kSearchSafe>(s, (int)(t - 12u * p), g.d.L, g.d.cyclical != 0);
+    e = g.nf ? apply_move_nf<W, kSearchSafe>(s, (int)(t - 12u * p), g.d.L, g.d.cyclical != 0) : apply_move<W, kSearchSafe>(s, (int)(t - 12u * p), g.d.L, g.d.cyclical != 0);
     c0 = keyops<W>::make(s.w0, s.n0);
     c1 = keyops<W>::make(s.w1, s.n1);
     tl = (uint32_t)(s.n0 + s.n1);
@@ -173,7 +173,7 @@ template <typename W> __global__ void __launch_bounds__(256) k_gm_expand(MegaDev
     md.ck0[t] = c0;
     md.ck1[t] = c1;
     md.clen[t] = (uint8_t)tl;
-    const uint64_t h = hash_key<W>(c0, c1);
+    const uint64_t h = greedy_hash(c0, c1);
     bool known = c0 == p0 && c1 == p1;  // an over-long product leaves the parent, which is in the visited set
     if (!known) {  // read-only probe of the visited table: pairs of 8-byte slots (node id | 32-bit fingerprint << 32)
         const uint32_t fp = (uint32_t)(h >> 32);
@@ -374,7 +374,7 @@ template <typename W> __global__ void __launch_bounds__(kMegaTile) k_gm_commit(M
         d.tlen[id] = (uint8_t)tl;
         d.depth[id] = sc->cur_depth + 1;
         // visited table: the keys of a batch's winners are pairwise distinct and absent; first free slot of the probe sequence
-        const uint64_t h = hash_key<W>(nk.k0, nk.k1);
+        const uint64_t h = greedy_hash(nk.k0, nk.k1);
         const unsigned long long mine = (unsigned long long)id | ((h >> 32) << 32);
         uint32_t hv = (uint32_t)h & g.tmask & ~1u;
         while (atomicCAS(&g.tab[hv], kTabEmpty, mine) != kTabEmpty) hv = (hv + 1) & g.tmask;
@@ -487,6 +487,7 @@ template <typename W> __global__ void __launch_bounds__(256) k_gm_file(MegaDev<W
             ps->batches++;
             ps->expanded += popped;
             ps->nodes = sc->nodes0 + sc->committed;
+            if (sc->committed && !is_solved && D1 > ps->depth_hi) ps->depth_hi = D1;
             ps->last_parent = sc->last_parent;
             ps->last_child_len = sc->last_child_len;
             ps->hist[16 + 31 - __builtin_clz(np)]++;

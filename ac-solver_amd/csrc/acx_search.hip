@@ -335,6 +335,7 @@ template <typename W> struct GreedySearch {
         g.nlen = (uint32_t)(2 * L + 1);
         g.max_nodes = (long long)max_nodes;
         g.root_len = (uint32_t)(root.n0 + root.n1);
+        g.nf = is_normal_form<W>(root, cyclical != 0) ? 1u : 0u;
         g.hand_min = 0;
         g.state = nullptr;
         g.mega_status = nullptr;
@@ -393,6 +394,7 @@ static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_no
     uint8_t* p_bm = p_bk + (uint64_t)n * b_bk;
     uint8_t* p_rest = p_bm + (uint64_t)n * b_bm;
     std::vector<GreedyDev<W>> hdev((size_t)n);
+    bool all_nf = true;  // every root of the group in normal form: the launch runs the shorter move code
     hipStream_t st = nullptr;
     ACX_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     struct StreamGuard {
@@ -437,6 +439,8 @@ static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_no
         g.nlen = nlen;
         g.max_nodes = (long long)max_nodes;
         g.root_len = (uint32_t)(root.n0 + root.n1);
+        g.nf = is_normal_form<W>(root, cyclical != 0) ? 1u : 0u;
+        all_nf = all_nf && g.nf != 0;
         g.hand_min = 0;
         g.state = nullptr;
         g.mega_status = nullptr;
@@ -453,8 +457,12 @@ static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_no
     ACX_HIP_TRY(evs.create());
     hipEvent_t ev0 = evs.a, ev1 = evs.b;
     ACX_HIP_TRY(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(k_greedy_multi<W>, dim3((unsigned)n), dim3(kGreedyMultiThreads), 0, st, (const GreedyDev<W>*)ddev.p, (GreedyOut*)douts.p, (int32_t*)dpa.p, (int32_t*)dpl.p,
-                       (long long)pc);
+    if (all_nf)
+        hipLaunchKernelGGL((k_greedy_multi<W, true>), dim3((unsigned)n), dim3(kGreedyMultiThreads), 0, st, (const GreedyDev<W>*)ddev.p, (GreedyOut*)douts.p, (int32_t*)dpa.p,
+                           (int32_t*)dpl.p, (long long)pc);
+    else
+        hipLaunchKernelGGL((k_greedy_multi<W, false>), dim3((unsigned)n), dim3(kGreedyMultiThreads), 0, st, (const GreedyDev<W>*)ddev.p, (GreedyOut*)douts.p, (int32_t*)dpa.p,
+                           (int32_t*)dpl.p, (long long)pc);
     ACX_HIP_TRY(hipGetLastError());
     ACX_HIP_TRY(hipEventRecord(ev1, st));
     std::vector<GreedyOut> o((size_t)n);
@@ -643,6 +651,11 @@ static int run_bfs_group(const int8_t* rows, int64_t n, int L, int64_t max_nodes
     return ACX_OK;
 }
 
+template <typename W> static void launch_greedy_persistent(const GreedyDev<W>& g, GreedyOut* out, hipStream_t st) {
+    if (g.nf) hipLaunchKernelGGL((k_greedy_persistent<W, true>), dim3(1), dim3(kGT), 0, st, g, out);
+    else hipLaunchKernelGGL((k_greedy_persistent<W, false>), dim3(1), dim3(kGT), 0, st, g, out);
+}
+
 // greedy_search on the device-resident priority frontier (acx_greedy.h).  *handled = false when the persistent
 // kernel ran out of one of its capacities: the caller then reruns the search on the batch-per-launch path.
 template <typename W>
@@ -695,7 +708,7 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
     ACX_HIP_TRY(hipEventRecord(ev0, st));
     GreedyOut o;
     unsigned long long handoffs = 0;
-    hipLaunchKernelGGL(k_greedy_persistent<W>, dim3(1), dim3(kGT), 0, st, g, (GreedyOut*)outb.p);
+    launch_greedy_persistent<W>(g, (GreedyOut*)outb.p, st);
     ACX_HIP_TRY(hipGetLastError());
     ACX_HIP_TRY(hipMemcpyAsync(&o, outb.p, sizeof(o), hipMemcpyDeviceToHost, st));
     ACX_HIP_TRY(hipStreamSynchronize(st));
@@ -724,7 +737,7 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
             // the frontier kernel again, behind the batch and WITHOUT waiting for its outcome: most buckets take one mega-batch,
             // and when this one needs another the launch finds that in the scalars and does nothing (GREEDY_MEGA_MORE) --
             // one synchronisation per hand-off instead of two
-            hipLaunchKernelGGL(k_greedy_persistent<W>, dim3(1), dim3(kGT), 0, st, g, (GreedyOut*)outb.p);
+            launch_greedy_persistent<W>(g, (GreedyOut*)outb.p, st);
             ACX_HIP_TRY(hipGetLastError());
             ACX_HIP_TRY(hipMemcpyAsync(&o, outb.p, sizeof(o), hipMemcpyDeviceToHost, st));
             ACX_HIP_TRY(hipStreamSynchronize(st));
@@ -751,6 +764,7 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
         fprintf(stderr, "\n[acx_greedy] batches by log2(parents):");
         for (int k = 0; k < 10; k++) fprintf(stderr, " %u", o.hist_np[k]);
         fprintf(stderr, "\n");
+        if (o.hist_np[12]) fprintf(stderr, "[acx_greedy] selects %u, of them from the cached depth without a load %u, fresh buckets ordered from LDS %u\n", o.hist_np[12], o.hist_np[13], o.hist_np[14]);
         unsigned long long tot = 0;
         for (int k = 0; k < 8; k++) tot += o.t_phase[k];
         if (tot) fprintf(stderr, "[acx_greedy] sort cycles: %.1f%% of all in buckets > LDS, %.1f%% in 256 < n <= LDS\n", 100.0 * o.t_phase[10] / tot, 100.0 * o.t_phase[11] / tot);

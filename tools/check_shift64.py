@@ -53,27 +53,73 @@ def scan_asm(text):
     return {k: tuple(v) for k, v in nfree.items()}, sites
 
 
+def function_bodies(text):
+    """{symbol: body text} of every function of an assembly file (kernels and the functions they call)"""
+    bodies, cur, buf = {}, None, []
+    for line in text.split("\n"):
+        m = re.match(r"^([A-Za-z_][\w$.]*):", line)
+        if m and not line.startswith(".L"):
+            if cur:
+                bodies[cur] = "\n".join(buf)
+            cur, buf = m.group(1), []
+            continue
+        if cur:
+            buf.append(line)
+    if cur:
+        bodies[cur] = "\n".join(buf)
+    return bodies
+
+
 def risky_sites(text):
     """The 64-bit shifts whose VGPR amount is the last register of an allocation block of the kernel they are in: the last register
     of the whole allocation (next_free_vgpr rounded up to the granule of 8) and, in a kernel that also holds accumulation registers
     (the unified file of gfx90a+: the architectural VGPRs end at accum_offset, the AGPRs follow), the last architectural one.  A
-    shift with a VGPR amount in a function that is NOT a kernel has no allocation of its own to check against (it runs in its
-    caller's): this library inlines everything, so any such site is reported too."""
+    shift with a VGPR amount in a function that is NOT a kernel (the micro-batch of acx_greedy.h) runs inside the allocation of
+    the kernel that calls it: it is checked against the allocation of EVERY kernel whose code mentions the function's symbol,
+    directly or through another such function; a function nobody seems to call is held to the rule that covers any caller (the
+    amount must not be the last register of a granule of 8)."""
     nfree, sites = scan_asm(text)
+
+    def tops_of(kernel):
+        nf, acc = nfree[kernel]
+        tops = {(nf + 7) // 8 * 8 - 1}
+        if acc is not None and acc < nf:  # AGPRs in use: the architectural registers are v0 .. v(accum_offset - 1)
+            tops.add(acc - 1)
+        return tops
+
+    callee_sites = [s for s in sites if s[0] not in nfree and re.fullmatch(r"v(\d+)", s[2])]
+    callers = {}
+    if callee_sites:
+        bodies = function_bodies(text)
+        callees = {s[0] for s in callee_sites}
+        mentions = {f: {g for g, body in bodies.items() if g != f and f in body} for f in callees}
+        for f in callees:
+            seen, todo, ks = set(), [f], set()
+            while todo:
+                x = todo.pop()
+                for g in mentions.get(x, {h for h, body in bodies.items() if h != x and x in body}):
+                    if g in nfree:
+                        ks.add(g)
+                    elif g not in seen:
+                        seen.add(g)
+                        todo.append(g)
+            callers[f] = ks
     bad = []
     for fn, op, amt in sites:
         m = re.fullmatch(r"v(\d+)", amt)
         if not m:
             continue  # an SGPR / literal amount
-        if fn not in nfree:
-            bad.append((fn, op, amt, -1))  # not a kernel: unknown allocation
-            continue
-        nf, acc = nfree[fn]
-        tops = {(nf + 7) // 8 * 8 - 1}
-        if acc is not None and acc < nf:  # AGPRs in use: the architectural registers are v0 .. v(accum_offset - 1)
-            tops.add(acc - 1)
-        if int(m.group(1)) in tops:
-            bad.append((fn, op, amt, nf))
+        idx = int(m.group(1))
+        if fn in nfree:
+            if idx in tops_of(fn):
+                bad.append((fn, op, amt, nfree[fn][0]))
+        elif callers.get(fn):
+            for k in callers[fn]:
+                if idx in tops_of(k):
+                    bad.append((fn, op, amt, nfree[k][0]))
+                    break
+        elif idx % 8 == 7:
+            bad.append((fn, op, amt, -1))
     return bad, {k: v[0] for k, v in nfree.items()}, sites
 
 
@@ -91,7 +137,7 @@ def report(name, text):
     demangle = subprocess.run(["c++filt"], input="\n".join(b[0] for b in bad), capture_output=True, text=True).stdout.split("\n")
     print(f"== {name}: {len(nfree)} kernels, {len(sites)} 64-bit shifts with a register amount checked, {len(bad)} at the top of an allocation")
     for (fn, op, amt, nf), dn in zip(bad, demangle):
-        print(f"   {op} amount {amt} with next_free_vgpr {nf}: {dn[:140]}" if nf >= 0 else f"   {op} amount {amt} in a non-kernel function (no allocation to check against): {dn[:140]}")
+        print(f"   {op} amount {amt} with next_free_vgpr {nf}: {dn[:140]}" if nf >= 0 else f"   {op} amount {amt} in a non-kernel function, in the last register of a granule of 8 (could be the last of its caller's allocation): {dn[:140]}")
     return len(bad)
 
 
