@@ -563,9 +563,16 @@ __device__ __forceinline__ void cursor_advance(BfsCursor* cur, const Decision& d
 
 template <typename W>
 __global__ void k_decide_tab(SearchDev<W> d, uint32_t m, uint32_t np, uint32_t pbegin, uint32_t base, uint32_t cap_nodes, long long max_nodes,
-                             const uint32_t* __restrict__ total_in, Decision* __restrict__ out, int reset_tags = 0, BfsCursor* cur = nullptr) {
+                             const uint32_t* __restrict__ total_in, Decision* __restrict__ out, int reset_tags = 0, BfsCursor* cur = nullptr,
+                             BfsCursor* __restrict__ snap = nullptr) {
     ACX_VGPR_PAD("v23");
-    if (cur && !cursor_begin(cur, m, np, pbegin, base)) return;  // run-ahead mode (acx_bfs.h): the batch is what the cursor says
+    // run-ahead mode (acx_bfs.h): the batch is what the cursor says.  `snap`: this batch's own snapshot slot -- the cursor as this
+    // kernel leaves it, written by this kernel alone and not touched again before the host has read it (the host copies the SLOT,
+    // never the live cursor, which the next batch's kernels may be changing while the copy runs: no torn snapshot)
+    if (cur && !cursor_begin(cur, m, np, pbegin, base)) {
+        if (snap) *snap = *cur;  // the search has ended in an earlier batch: the final cursor, once more
+        return;
+    }
     const uint32_t total = *total_in;
     const unsigned long long nodes = base;
     uint32_t p_end = np - 1, budget_hit = 0;
@@ -614,7 +621,10 @@ __global__ void k_decide_tab(SearchDev<W> d, uint32_t m, uint32_t np, uint32_t p
         *d.shorter_tag = kNoTag;
         *d.err_tag = kNoTag;
     }
-    if (cur) cursor_advance(cur, *out, pbegin, np, base);
+    if (cur) {
+        cursor_advance(cur, *out, pbegin, np, base);
+        if (snap) *snap = *cur;
+    }
 }
 
 // root node: id 0

@@ -232,7 +232,7 @@ template <typename W> struct Searcher {
         if (!h_pin) return fail(ACX_E_NOMEM, "hipHostMalloc(%zu) failed", h_pin_bytes);
         if (stamp_tab) {  // run-ahead batches of the fused BFS (acx_frontier.h: BfsCursor)
             h_cursor = h_pin + cursor_off;
-            if (arena_cursor.alloc(sizeof(BfsCursor))) return ACX_E_NOMEM;
+            if (arena_cursor.alloc((1 + kRunAheadSlots) * sizeof(BfsCursor))) return ACX_E_NOMEM;  // the live cursor + one snapshot slot per batch in flight
         }
         d.solved_tag = (unsigned long long*)(sc + 0);
         d.shorter_tag = (unsigned long long*)(sc + 8);
@@ -924,15 +924,18 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
                         ACX_BFS_AHEAD(kMoveGeneral);
                     }
 #undef ACX_BFS_AHEAD
-                    hipLaunchKernelGGL(k_decide_tab<W>, dim3(1), dim3(1), 0, st, d, mcap, bmax, 0u, 0u, (uint32_t)S.cap_nodes, (long long)max_nodes, S.d_total, S.d_dec, 1, dcur);
-                    ACX_HIP_TRY(hipGetLastError());
                     const int slot = (int)(k % kRunAheadSlots);
-                    // snapshot of the cursor as this batch leaves it: copied on the side stream, behind an event of the main one.  (The
-                    // next batch may have advanced the cursor by the time the copy runs: a snapshot is then one batch FRESHER, which
-                    // is fine -- a status once set never changes, and the counters of a non-zero status are final.)
+                    hipLaunchKernelGGL(k_decide_tab<W>, dim3(1), dim3(1), 0, st, d, mcap, bmax, 0u, 0u, (uint32_t)S.cap_nodes, (long long)max_nodes, S.d_total, S.d_dec, 1, dcur,
+                                       dcur + 1 + slot);
+                    ACX_HIP_TRY(hipGetLastError());
+                    // snapshot of the cursor as this batch leaves it: k_decide_tab wrote it into the batch's own device slot, which
+                    // nothing touches again until the host has read it (the slot is reused by batch k + kRunAheadSlots, which is only
+                    // enqueued after the host has waited for the copy of batch k + kRunAheadSlots - 1 - kRunAheadLag >= k, and the
+                    // copies complete in order); copied on the side stream, behind an event of the main one -- never from the live
+                    // cursor, which the next batch's kernels may be advancing while the copy runs
                     ACX_HIP_TRY(hipEventRecord(S.ev_batch[slot], st));
                     ACX_HIP_TRY(hipStreamWaitEvent(S.st_copy, S.ev_batch[slot], 0));
-                    ACX_HIP_TRY(hipMemcpyAsync(&snap[slot], dcur, sizeof(BfsCursor), hipMemcpyDeviceToHost, S.st_copy));
+                    ACX_HIP_TRY(hipMemcpyAsync(&snap[slot], dcur + 1 + slot, sizeof(BfsCursor), hipMemcpyDeviceToHost, S.st_copy));
                     ACX_HIP_TRY(hipEventRecord(S.ev_cursor[slot], S.st_copy));
                     if (k >= kRunAheadLag) {
                         const int old = (int)((k - kRunAheadLag) % kRunAheadSlots);

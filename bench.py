@@ -293,7 +293,7 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
         import gc
 
         times = []
-        for _ in range(3):  # the median of three timed sweeps (a sweep is 0.3-0.5 s and single samples scatter by +-25 %), no garbage collection while the clock runs
+        for _ in range(5):  # the median of five timed sweeps (a sweep is 0.3-0.5 s; the first one behind the sharded searches runs up to 40 % longer), no garbage collection while the clock runs
             n_solved = n_nodes = n_children = 0
             gc.collect()
             gc.disable()
@@ -315,14 +315,14 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
         tot = torch.tensor([n_solved, n_nodes, n_mine, 0.0 if sweep_err is None else 1.0, n_children], dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(tot)
-        dt1 = sorted(times)[1]
+        dt1 = sorted(times)[len(times) // 2]
         if float(tot[3]) > 0:
             return {"error": f"{type(sweep_err).__name__}: {sweep_err}" if sweep_err is not None else "failed on another rank"}
         # (64 + 72 f) B per generated child over the whole sweep (the seven widths together), per GPU; wall time of the
         # sweep (the searches of a group run inside ONE launch, so there is no per-search device time to sum)
         roof = search_roofline({"children": int(tot[4]), "nodes": int(tot[1]), "seconds": dt1 * world}, kernel, traffic_key)
         roof["unit"] = "GB/s per GPU"
-        roof["timed"] = "wall clock of the whole sweep (median of three), host-side result handling included"
+        roof["timed"] = "wall clock of the whole sweep (median of five), host-side result handling included"
         return {"searches": int(tot[2]), "budget": 10**6, "cyclical": cyclical, "solved": int(tot[0]), "published_solved": published,
                 "nodes": int(tot[1]), "children": int(tot[4]), "seconds": dt1, "samples_seconds": times, "nodes_per_s": float(tot[1]) / dt1,
                 "children_per_s": float(tot[4]) / dt1, "searches_per_s": float(tot[2]) / dt1,
