@@ -320,6 +320,12 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
                                                      const uint32_t* __restrict__ masks, uint32_t* __restrict__ total_out, const BfsCursor* __restrict__ cur = nullptr) {
     __shared__ uint32_t s_wsum[4], s_psum[4];
     __shared__ uint16_t s_list[kCompactTile];
+    // the tile's parents (its 8192 candidates belong to at most 684 consecutive parents), loaded once, coalesced: every parent has
+    // ~3.6 winners, and a gather of its key per winner (rounds 2-3) read it that many times
+    constexpr uint32_t kTileParents = kCompactTile / 12 + 2;
+    __shared__ W s_pk0[kTileParents];
+    __shared__ W s_pk1[kTileParents];
+    __shared__ uint32_t s_pdep[kTileParents];
     ACX_VGPR_PAD_W(W, "v47", "v63");
     if (cur) {  // run-ahead mode (m arrives as the capacity 12 * bmax)
         if (cur->status) return;
@@ -333,6 +339,16 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     ACX_CP_DECL;
     const uint32_t fl = masks[tile * 256u + tid];
+    const uint32_t p_first = (tile * kCompactTile) / 12u;
+    {
+        const uint32_t m_end = min(m, (tile + 1) * kCompactTile), p_end = (m_end + 11u) / 12u;  // parents p_first .. p_end - 1 touch this tile
+        for (uint32_t i = tid; p_first + i < p_end; i += 256) {
+            const uint32_t pid = pbegin + p_first + i;
+            s_pk0[i] = d.k0[pid];
+            s_pk1[i] = d.k1[pid];
+            s_pdep[i] = d.depth[pid];
+        }
+    }
     uint32_t part = 0;  // winners of all earlier tiles: their counts, 256 at a time
     for (uint32_t j = tid; j < tile; j += 256) {
         const uint32_t c = counts[j];
@@ -393,9 +409,9 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
             const uint32_t p = t / 12u;
             pid[u] = pbegin + p;
             act[u] = t - 12u * p;
-            pk0[u] = on[u] ? d.k0[pid[u]] : (W)0;
-            pk1[u] = on[u] ? d.k1[pid[u]] : (W)0;
-            dep[u] = on[u] ? d.depth[pid[u]] : 0u;
+            pk0[u] = on[u] ? s_pk0[p - p_first] : (W)0;
+            pk1[u] = on[u] ? s_pk1[p - p_first] : (W)0;
+            dep[u] = on[u] ? s_pdep[p - p_first] : 0u;
         }
 #pragma unroll
         for (uint32_t u = 0; u < kU; u++) {
