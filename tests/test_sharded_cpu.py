@@ -62,7 +62,11 @@ def _gloo_worker(rank, world, port, q):
         from ac_solver.search.sharded import TorchDistComm
 
         res = _run(TorchDistComm(torch.device("cpu")), 50)
-        q.put((rank, res))
+        # the mask all-reduce on a communicator of its own (dist.new_group): what bench.py times next to the shared one on N > 1 GPUs
+        own = TorchDistComm(torch.device("cpu"), mask_group="own")
+        res_own = _run(own, 50, SMALL)
+        assert own.stats["mask_all_reduce_calls"] > 0 and own.mask_group is not own.group
+        q.put((rank, res, res_own))
     finally:
         dist.destroy_process_group()
 
@@ -75,11 +79,16 @@ def test_gloo_world2_matches_reference():
     q = ctx.Queue()
     procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in procs]
-    got = dict(q.get(timeout=240) for _ in range(2))
+    rows = [q.get(timeout=400) for _ in range(2)]
+    got = {r: a for r, a, _ in rows}
+    got_own = {r: b for r, _, b in rows}
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     _check(got[0])
     assert _strip(got[0]) == _strip(got[1])  # every rank returns the same answer
+    _check(got_own[0], SMALL)
+    strip_comm = lambda res: [(ok, path, {k: v for k, v in st.items() if not k.startswith("comm_")}) for ok, path, st in _strip(res)]  # noqa: E731
+    assert strip_comm(got_own[0]) == strip_comm(got_own[1])
 
 
 def test_a_failing_rank_takes_every_rank_down_without_deadlock():
