@@ -231,9 +231,12 @@ __global__ void __launch_bounds__(kBmT, ACX_BFS_MULTI_WAVES) k_bfs_multi(const B
             uint32_t base = (uint32_t)hk & g.stmask & ~3u, probes = 0;
             bool open = true;
             while (open) {
-                unsigned long long v[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) v[j] = ld_l2(g.stab + base + j);
+                // the bucket as TWO 16-byte loads (rounds 2-3: four 8-byte agent-scope loads, i.e. four L2 requests per probing lane --
+                // three quarters of the sweep's 8.2e9 L2 requests).  Plain loads may be served by a stale line of the vector L1; that is
+                // harmless here as in the fused kernel: a slot only ever moves free -> stamp of key K, so a stale "free" costs one
+                // failed CAS whose return value is then looked at, and a stale stamp is the stamp
+                const ulonglong2 lo = *(const ulonglong2*)(g.stab + base), hi = *(const ulonglong2*)(g.stab + base + 2);
+                const unsigned long long v[4] = {lo.x, lo.y, hi.x, hi.y};
                 uint32_t cand = 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) cand |= (v[j] == kSlotFree || (v[j] >> 36) == (me >> 36)) ? 1u << j : 0u;
