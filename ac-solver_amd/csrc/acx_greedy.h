@@ -229,8 +229,12 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
     // of that batch's children, and those are still in LDS (candidate keys sk0 / sk1 by tag, their ids and bucket positions in
     // s_keep).  When such a bucket is selected next -- the usual case behind a cut, and behind a bucket that one batch used up -- it
     // is ordered and staged from there: no arena load, no key load (two dependent trips of the sort, two of the staging).
-    constexpr bool kFresh = R == 1;
-    __shared__ uint32_t s_keep[kFresh ? kGT : 1];  // per candidate of the last batch: bit 31 committed, bits 11..21 position in its bucket, bits 0..10 rank among the batch's new nodes
+#ifndef ACX_GREEDY_FRESH_MULTI
+#define ACX_GREEDY_FRESH_MULTI 0  // 1: the many-search kernel (four candidates per lane) orders fresh buckets from LDS too -- measured on the 1190-search sweep: 0.42-0.44 s with it, 0.38-0.43 s without (16 KB more LDS, more registers in the selection), so only the single search does
+#endif
+    constexpr bool kFresh = R == 1 || ACX_GREEDY_FRESH_MULTI != 0;
+    __shared__ uint32_t s_keep[kFresh ? SC : 1];  // per candidate of the last batch: bit 31 committed, bits 12..23 position in its bucket, bits 0..11 rank among the batch's new nodes
+    static_assert(SC <= 4096, "positions and ranks of a batch's candidates take 12 bits each in s_keep");
     __shared__ uint32_t s_keep_n;                  // candidates of the last batch that s_keep / sk0 / sk1 / s_clen describe (0: none)
     __shared__ uint8_t s_fresh[132];               // bucket (length, filing depth) held nothing before the last batch
     __shared__ uint32_t s_keep_nodes;              // id of the last batch's first new node
@@ -428,20 +432,28 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
             // ---- a fresh bucket: its entries are the last batch's children, still in LDS ---------------------------------
             const bool fast = kFresh && fresh_sel && n <= SC;  // (uniform)
             if (fast) {
-                const uint32_t kp = tid < s_keep_n ? s_keep[kFresh ? tid : 0] : 0u;
-                const bool mine = (kp >> 31) != 0 && (uint32_t)s_clen[tid] == l;  // candidate tid of the last batch (one per lane)
-                W key0 = 0, key1 = 0;
-                if (mine) {
-                    key0 = sk0[tid];
-                    key1 = sk1[tid];
+                uint32_t kp[R];
+                W key0[R], key1[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) {  // candidate t = r * lanes + tid of the last batch
+                    const uint32_t t = (uint32_t)r * kGT + tid;
+                    kp[r] = t < s_keep_n ? s_keep[kFresh ? t : 0] : 0u;
+                    if ((uint32_t)s_clen[t] != l) kp[r] = 0;
+                    key0[r] = key1[r] = 0;
+                    if (kp[r] >> 31) {
+                        key0[r] = sk0[t];
+                        key1[r] = sk1[t];
+                    }
                 }
                 __syncthreads();  // every candidate key is read before the sort arrays overwrite them
-                if (mine) {
-                    const uint32_t at = (kp >> 11) & 0x7FFu;
-                    sk0[at] = key0;
-                    sk1[at] = key1;
-                    sid[at] = s_keep_nodes + (kp & 0x7FFu);
-                }
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    if (kp[r] >> 31) {
+                        const uint32_t at = (kp[r] >> 12) & 0xFFFu;
+                        sk0[at] = key0[r];
+                        sk1[at] = key1[r];
+                        sid[at] = s_keep_nodes + (kp[r] & 0xFFFu);
+                    }
                 if (tid == 0 && n == 1) s_sorted_in_lds = 1;  // nothing to order: the staging below takes it from here
                 __syncthreads();
             }
@@ -855,11 +867,11 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                 if (cm && tl == v) pos[r] = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
                 cb &= ~same;
             }
-            if (kFresh) s_keep[kFresh ? tid : 0] = cm ? (0x80000000u | (pos[r] << 11) | cpos[r]) : 0u;
+            if (kFresh) s_keep[kFresh ? (uint32_t)r * kGT + tid : 0] = cm ? (0x80000000u | (pos[r] << 12) | cpos[r]) : 0u;
         }
         if (tid == 0) {
             s_keep_nodes = nodes;
-            s_keep_n = kFresh ? (uint32_t)kGT : 0u;
+            s_keep_n = kFresh ? SC : 0u;
         }
         ACX_SUBTICK(13);
         for (int o = 32; o > 0; o >>= 1) seen = min(seen, (uint32_t)__shfl_xor((int)seen, o));
