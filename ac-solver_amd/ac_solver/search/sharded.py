@@ -25,6 +25,13 @@ the chunks that were already enqueued are no-ops on the device -- their collecti
 sees the same status at the same chunk -- and the loop ends.  One synchronisation per LEVEL remains (the size of the
 next level).
 
+Round 4: a child whose key is owned by the rank that generates it claims its table slot inside the expansion kernel and never
+becomes a record (all children at world 1; 1/world of them otherwise), so step 1 writes the visited table -- the orchestrator
+therefore keeps the expansion at most ONE chunk ahead of the dedup (an event behind each commit).  Every level ends with one small
+all-reduce (max) of [failure code, smallest length generated, fullest region]: a failure that no header carried ends every rank at
+the same point.  `TorchDistComm(mask_group="own")` puts step 4 on a communicator of its own; `timeline=True` returns the device
+time of every stage of a chunk.
+
 The per-rank work goes through an *engine* (the C ABI `acx_shard_*` of libacx in production; the CPU tests plug in a
 NumPy engine built on the oracle, tests/shard_helpers.py) and the exchange through a *comm* (torch.distributed:
 backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests; an in-process thread communicator lets one GPU play several
