@@ -8,6 +8,43 @@ from torch import nn
 from torch.distributions import Categorical
 
 
+class _LinearSplitK(torch.autograd.Function):
+    """y = x W^T + b with a SPLIT-K weight gradient.  The update of BASELINE config 5 pushes minibatches of 1 Mi samples through
+    256-wide layers: dW = dY^T X contracts over those 1 Mi rows into a 256 x 256 (or 256 x 50, 12 x 256, 1 x 256) output, and the
+    library's single GEMM for that shape runs at 4-60 TFLOP/s in small-tile kernels -- 48 of the update's 100 ms of device time
+    (torch's kernel table, tools/update_probe.py), five to ten times the time it takes to read the two operands once.  Here the rows are cut
+    into chunks, one batched GEMM forms a partial product per chunk and a sum folds them: the same numbers up to f32 summation
+    order.  Forward and data gradient are the library's GEMMs (they run at the f32 matrix peak)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        n = x.shape[0]
+        chunks = 1
+        while chunks < 512 and n % (2 * chunks) == 0 and n // (2 * chunks) >= 2048:
+            chunks *= 2
+        gw = torch.bmm(gy.view(chunks, n // chunks, -1).transpose(1, 2), x.reshape(chunks, n // chunks, -1)).sum(0)
+        return gx, gw, gy.sum(0)
+
+
+class Linear(nn.Linear):
+    """nn.Linear (same parameters, same state_dict keys) whose large-batch training passes on the GPU take the split-K weight gradient."""
+
+    SPLIT_K_ROWS = 1 << 16
+
+    def forward(self, x):
+        if x.is_cuda and x.dim() == 2 and x.shape[0] >= self.SPLIT_K_ROWS and torch.is_grad_enabled() and self.weight.requires_grad and self.bias is not None:
+            return _LinearSplitK.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 def initialize_layer(layer, std=math.sqrt(2), bias_const=0.0):
     nn.init.orthogonal_(layer.weight, std)
     nn.init.constant_(layer.bias, bias_const)
@@ -20,7 +57,7 @@ def build_network(nodes_counts, std=0.01):
     layers = []
     last = len(nodes_counts) - 2
     for k in range(last + 1):
-        lin = nn.Linear(int(nodes_counts[k]), int(nodes_counts[k + 1]))
+        lin = Linear(int(nodes_counts[k]), int(nodes_counts[k + 1]))
         layers.append(initialize_layer(lin, std) if k == last else initialize_layer(lin))
         if k != last:
             layers.append(nn.Tanh())

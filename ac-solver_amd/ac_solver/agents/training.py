@@ -160,6 +160,60 @@ def _share_success_record(success_record, n_states, device):
     success_record["unsolved"] -= solved
 
 
+class _MinibatchOrder:
+    """The minibatch permutations of the updates, computed ahead of time.  The reference shuffles np.arange(batch_size) once per epoch
+    with the global NumPy generator it seeded at the top of the update (training.py:121, 273-275: np.random.seed(seed + update) ...
+    np.random.shuffle(b_inds)); nothing draws from that generator in between, so the permutations are a function of the seed alone.
+    At BASELINE config 5's shape a shuffle of 4 Mi indices takes ~100 ms of host time, and each minibatch's slice went to the device
+    through a synchronous copy -- with the GPU idle meanwhile (60 of an update's 123 ms).  Here a thread computes them through libacx
+    (acx_np_shuffle_epochs: NumPy's legacy algorithm restated, pinned against numpy in tests/test_agents_cpu.py, and -- unlike
+    np.random.shuffle, which holds the GIL for all of its run -- off the interpreter lock), ONE UPDATE AHEAD: the permutations of
+    update u + 1 are started at the top of update u (two pinned buffers take turns), go to the device in one copy, and a minibatch
+    is a slice of that."""
+
+    def __init__(self, batch_size, epochs, device):
+        self.batch_size, self.epochs, self.device = batch_size, epochs, device
+        self.on_gpu = str(device).startswith("cuda") and torch.cuda.is_available()
+        self.host = [torch.empty((epochs, batch_size), dtype=torch.int64, pin_memory=self.on_gpu) for _ in range(2)]
+        self.dev = torch.empty((epochs, batch_size), dtype=torch.int64, device=device) if self.on_gpu else None
+        self.jobs = {}       # seed -> (thread, buffer index)
+        self.copied = [None, None]  # per buffer: event behind the last copy out of it
+
+    def prefetch(self, seed):
+        import threading
+
+        if seed in self.jobs:
+            return
+        busy = {k for _, k in self.jobs.values()}
+        k = 0 if 0 not in busy else 1
+        assert k not in busy, "more than two updates' permutations in flight"
+        if self.copied[k] is not None:
+            self.copied[k].synchronize()  # the permutations this buffer held have left it
+
+        def work(out=self.host[k].numpy()):
+            import ctypes as C
+
+            from ac_solver import _acx
+
+            _acx.check(_acx.lib.acx_np_shuffle_epochs(int(seed) & 0xFFFFFFFF, self.batch_size, self.epochs, _acx.ptr(out, C.c_int64)), "acx_np_shuffle_epochs")
+
+        th = threading.Thread(target=work)
+        th.start()
+        self.jobs[seed] = (th, k)
+
+    def get(self, seed):
+        """-> [epochs, batch_size] int64 on the training device: the permutations of the update seeded with `seed`"""
+        self.prefetch(seed)
+        th, k = self.jobs.pop(seed)
+        th.join()
+        if not self.on_gpu:
+            return self.host[k]
+        self.dev.copy_(self.host[k], non_blocking=True)
+        self.copied[k] = torch.cuda.Event()
+        self.copied[k].record()
+        return self.dev
+
+
 class _Phases:
     """ACX_PPO_PHASES=1: wall time per phase of an update (a device synchronisation at every phase edge, so the run itself is
     slower), printed by rank 0 at the end of the training loop; off: no-ops."""
@@ -265,6 +319,7 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
         except ImportError:  # pragma: no cover
             pass
     stats = {}
+    order = _MinibatchOrder(args.batch_size, args.update_epochs, device)
     ph = _Phases(device)
     n_updates_done = 0
 
@@ -272,6 +327,9 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
         ph.start()
         random.seed(args.seed + update)
         np.random.seed(args.seed + update)
+        order.prefetch(args.seed + update)  # this update's minibatch permutations (under way since the previous update, except for the first) ...
+        if update < num_updates:
+            order.prefetch(args.seed + update + 1)  # ... and the next one's: a whole update to hide their ~100 ms of host time in
         torch.manual_seed(args.seed + update)
         if args.anneal_lr:
             optimizer.param_groups[0]["lr"] = get_curr_lr(update, args.lr_decay, args.warmup_period, args.learning_rate,
@@ -362,12 +420,11 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
         b_advantages, b_returns, b_values = advantages.reshape(-1), returns.reshape(-1), values.reshape(-1)
 
         # ---------------------------------------------------------------- policy / value update ----
-        b_inds = np.arange(args.batch_size)
+        perms = order.get(args.seed + update)
         clipfracs = []
         for epoch in range(args.update_epochs):
-            np.random.shuffle(b_inds)
             for start in range(0, args.batch_size, args.minibatch_size):
-                mb = torch.as_tensor(b_inds[start:start + args.minibatch_size], device=device)
+                mb = perms[epoch, start:start + args.minibatch_size]
                 _, newlogprob, entropy, newvalue = agent.get_action_and_value(b_obs[mb].float(), b_actions[mb])
                 logratio = newlogprob - b_logprobs[mb]
                 ratio = logratio.exp()

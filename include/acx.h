@@ -157,6 +157,12 @@ int acx_search(int kind, const int8_t *h_presentation, int L, int64_t max_nodes,
  * sequence (*n = its length, the first min(*n, cap) entries are written).  greedy_search then runs batch by batch on the
  * host-driven path (same result, slower). */
 int acx_search_minima_enable(int on);
+/* Host utility of the PPO driver (no device work): the permutations np.random.seed(seed); for e in range(epochs): np.random.shuffle(b_inds)
+ * leaves in b_inds = np.arange(n) -- what the update loop of agents/training.py:121, 273-275 draws its minibatches from -- written to
+ * h_out [epochs, n].  NumPy's legacy MT19937 / shuffle algorithm restated (a third-party dependency of the reference); runs without
+ * the interpreter lock, so the driver computes it on a thread beside the rollout.  n < 2^32. */
+int acx_np_shuffle_epochs(uint32_t seed, int64_t n, int epochs, int64_t *h_out);
+
 int acx_search_last_minima(int32_t *lengths, int64_t cap, int64_t *n);
 
 /* Test hook (repeat-determinism tests): with the switch on, every acx_search of the process ends with one extra pass that

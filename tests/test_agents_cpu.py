@@ -202,3 +202,77 @@ def test_curriculum_object_equals_per_episode_choose_next_state():
                 cur.mark_solved(s)
             out_b.append(cur.next_state())
         assert out_a == out_b and proc_a == proc_b and rec_a == rec_b and r1 == cur.round1_complete
+
+
+def test_split_k_linear_has_the_gradients_of_nn_linear():
+    """agents/ppo_agent.py: the large-batch Linear forms its weight gradient as a sum of per-chunk products (split-K); output and all
+    three gradients must be those of torch's linear (float64: equal up to summation order).  The layers are nn.Linear subclasses with
+    the same state_dict keys, and below the row threshold (or on the CPU) they ARE nn.Linear."""
+    import torch
+
+    from ac_solver.agents.ppo_agent import Linear, _LinearSplitK
+
+    torch.manual_seed(0)
+    for rows, fin, fout in ((8192 * 4, 50, 256), (4096 * 8, 256, 12), (2048 * 3, 256, 1)):
+        x = torch.randn(rows, fin, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(fout, fin, dtype=torch.float64, requires_grad=True)
+        b = torch.randn(fout, dtype=torch.float64, requires_grad=True)
+        y = _LinearSplitK.apply(x, w, b)
+        g = torch.randn_like(y)
+        y.backward(g)
+        got = (y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+        x.grad = w.grad = b.grad = None
+        y2 = torch.nn.functional.linear(x, w, b)
+        y2.backward(g)
+        for a, c in zip(got, (y2.detach(), x.grad, w.grad, b.grad)):
+            assert torch.allclose(a, c, rtol=1e-12, atol=1e-10)
+    lin = Linear(4, 3)
+    assert isinstance(lin, torch.nn.Linear) and set(lin.state_dict()) == {"weight", "bias"}
+    xs = torch.randn(5, 4)
+    assert torch.equal(lin(xs), torch.nn.functional.linear(xs, lin.weight, lin.bias))
+
+
+def test_minibatch_order_is_the_references_shuffle_sequence():
+    """training._MinibatchOrder: the permutations a thread computes beside the rollout are exactly what the reference's loop produces
+    with the global generator it seeded at the top of the update (np.random.seed(s); np.random.shuffle(b_inds) once per epoch)."""
+    import numpy as np
+    import torch
+
+    from ac_solver.agents.training import _MinibatchOrder
+
+    for seed, batch, epochs in ((3, 1000, 1), (11, 4096, 3)):
+        order = _MinibatchOrder(batch, epochs, torch.device("cpu"))
+        order.prefetch(seed)
+        order.prefetch(seed + 1)  # (the next update's, one ahead, in the other buffer)
+        got = order.get(seed).numpy().copy()
+        nxt = order.get(seed + 1).numpy()
+        np.random.seed(seed + 1)
+        b_next = np.arange(batch)
+        np.random.shuffle(b_next)
+        assert np.array_equal(nxt[0], b_next)
+        np.random.seed(seed)
+        b_inds = np.arange(batch)
+        for e in range(epochs):
+            np.random.shuffle(b_inds)
+            assert np.array_equal(got[e], b_inds)
+
+
+def test_libacx_shuffle_is_numpys_legacy_shuffle():
+    """acx_np_shuffle_epochs (csrc/acx_step.hip, a host utility without device work): np.random.seed(s) followed by one
+    np.random.shuffle of the same array per epoch, bit for bit -- MT19937 seeded by an integer, Fisher-Yates from the top with
+    masked rejection sampling.  Pinned against numpy itself, including seeds above 2^31 and sizes around powers of two."""
+    import ctypes as C
+
+    import numpy as np
+
+    from ac_solver import _acx
+
+    for seed, n, epochs in ((1, 10, 1), (7, 1000, 3), (123456, 100003, 2), (2**31 + 5, 4096, 1), (3, 1, 2), (42, 2, 4), (0, 65537, 1), (2**32 - 1, 65535, 2)):
+        out = np.empty((epochs, n), np.int64)
+        assert _acx.lib.acx_np_shuffle_epochs(seed, n, epochs, _acx.ptr(out, C.c_int64)) == 0
+        np.random.seed(seed)
+        a = np.arange(n)
+        for e in range(epochs):
+            np.random.shuffle(a)
+            assert np.array_equal(out[e], a), (seed, n, e)
+    assert _acx.lib.acx_np_shuffle_epochs(1, 0, 1, _acx.ptr(np.empty(1, np.int64), C.c_int64)) == _acx.E_INVAL
