@@ -614,7 +614,47 @@ def extra_env_numbers(dev, pool):
                               "obs": "float32 [T+1, N, 50] written by the env kernel", "algorithmic_GBps_env_only": (12 * L + 10) * res["none"] / 1e9}
     except Exception as e:
         out["ppo_rollout"] = {"error": f"{type(e).__name__}: {e}"}
+    # PPO training end to end at the same shape: rollout of 32 steps x 131 072 envs with the fused policy kernel,
+    # curriculum bookkeeping, f32 behaviour statistics, GAE and the f32 torch update (4 minibatches of 1 Mi samples) per update
+    if not os.environ.get("WORLD_SIZE"):  # (train_ppo brings its own process group up under a launcher)
+        try:
+            out["ppo_train"] = ppo_train_number()
+        except BaseException as e:  # noqa: BLE001  (SystemExit included: the line must survive)
+            out["ppo_train"] = {"error": f"{type(e).__name__}: {e}"}
     return out
+
+
+def ppo_train_number(n=1 << 17, T=32, updates=8):
+    """ms per PPO update of ac_solver.agents.ppo.train_ppo at BASELINE config 5's per-GPU shape: the difference of a run of 2 + `updates`
+    updates and a run of 2 (the smaller of two samples each: a call's fixed cost -- files, allocations -- varies), behind a warm-up run"""
+    import contextlib
+    import tempfile
+
+    import torch
+
+    from ac_solver.agents.ppo import train_ppo
+
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp())
+    try:
+        def run(u):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(sys.stderr):  # (stdout carries exactly one JSON line)
+                train_ppo(["--num-envs", str(n), "--num-steps", str(T), "--total-timesteps", str(u * T * n), "--tile-initial-states", "--fused-policy",
+                           "--horizon-length", "200", "--num-minibatches", "4"])
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+
+        run(2)
+        a, b = min(run(2), run(2)), min(run(2 + updates), run(2 + updates))
+        per = (b - a) / updates
+        return {"envs": n, "steps_per_update": T, "ms_per_update": per * 1e3, "env_steps_per_s": n * T / per, "updates_timed": updates,
+                "what": "rollout with acx_policy_sample on int8 observation rows + curriculum bookkeeping + f32 behaviour statistics + GAE + the f32 torch "
+                        "update (4 minibatches of 1 Mi samples, split-K weight gradients), one GPU",
+                "round3": {"ms_per_update": 212.0}}
+    finally:
+        os.chdir(cwd)
 
 
 def launch_ranks(n, argv, child=None, env=None, grace_s=20.0):
