@@ -1,9 +1,11 @@
 """GPU parity of bfs / greedy_search (device frontier through acx_search) against the reference's
 golden results and the oracle: identical (solved, path), budget-exhaustion returns included."""
+import os
+
 import numpy as np
 import pytest
 
-from tests.conftest import ms_pool_generator_order
+from tests.conftest import PKG, ROOT, ms_pool_generator_order
 
 pytestmark = pytest.mark.gpu
 
@@ -387,6 +389,33 @@ def _key_words(state, L, KW):
             for part in (k & ((1 << 64) - 1), k >> 64):
                 words.append(part - (1 << 64) if part >= (1 << 63) else part)
     return words
+
+
+@pytest.mark.timeout(600)
+def test_sharded_bfs_with_every_child_as_a_record_still_matches(search):
+    """ACX_SHARD_BORN=0 (the A/B switch of DESIGN.md section 4: every child travels as a record, round 3's data path) is read once per
+    process, so a fresh interpreter runs it: world 1 and two thread ranks against the oracle, both key widths."""
+    import subprocess
+    import sys
+
+    code = """
+import sys, numpy as np
+sys.path[:0] = [%r, %r]
+from ac_solver.search.sharded import bfs_sharded
+from oracle import ac_oracle as O
+from tests.shard_helpers import run_threads
+ak3 = np.zeros(50, np.int8); ak3[:7] = [1, 1, 1, -2, -2, -2, -2]; ak3[25:31] = [1, 2, 1, -2, -1, -2]
+wide = np.zeros(72, np.int8); wide[:7] = [1, 1, 1, -2, -2, -2, -2]; wide[36:42] = [1, 2, 1, -2, -1, -2]
+for p, b, c in ((ak3, 300000, False), (ak3, 20000, True), (wide, 100000, False)):
+    want = O.bfs(p, b, cyclically_reduce_after_moves=c, stats=True)
+    got = bfs_sharded(p, b, cyclically_reduce_after_moves=c, batch_parents=1 << 12, want_stats=True)
+    assert got[:2] == want[:2] and got[2]["nodes"] == want[2]["nodes"] and got[2]["expanded"] == want[2]["expanded"], (b, c)
+    for r in run_threads(2, lambda comm: bfs_sharded(p, b, cyclically_reduce_after_moves=c, comm=comm, batch_parents=1 << 12, want_stats=True)):
+        assert r[:2] == want[:2] and r[2]["nodes"] == want[2]["nodes"], (b, c)
+print("ok")
+""" % (PKG, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ACX_SHARD_BORN="0"), capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]
 
 
 @pytest.mark.parametrize("L", [25, 36])
