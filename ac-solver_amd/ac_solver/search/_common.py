@@ -91,7 +91,11 @@ def run_search_groups(kind, groups, max_nodes_to_explore, cyclical, n_threads=16
     order = sorted(range(len(groups)), key=lambda k: -np.asarray(groups[k]).shape[-1])
     stagger = os.environ.get("ACX_SWEEP_STAGGER_MS", "0")  # (a pause between the wide and the narrow batches: measured no better than none)
     wide = [k for k in order if np.asarray(groups[k]).shape[-1] // 2 > 29]
-    with ThreadPoolExecutor(max_workers=len(groups)) as ex:
+    # bfs: a batch of searches fills the GPU on its own (acx_bfs_many.h: a tile of every search's frontier per workgroup), and batches in
+    # flight together only evict each other's tables from the caches -- measured: the seven widths one after another 144 ms, all at once
+    # 190-250 ms.  greedy: one workgroup per search, so the batches must overlap to fill the compute units.
+    workers = int(os.environ.get("ACX_SWEEP_WORKERS", "0")) or (1 if kind == _acx.SEARCH_BFS and os.environ.get("ACX_BFS_MANY") != "multi" else len(groups))
+    with ThreadPoolExecutor(max_workers=workers) as ex:
         futs = {}
         for pos, k in enumerate(order):
             if wide and pos == len(wide) and float(stagger) > 0:

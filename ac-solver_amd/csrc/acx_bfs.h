@@ -98,8 +98,9 @@ template <typename W> __global__ void k_bfs_root(SearchDev<W> d, W k0, W k1, uin
 constexpr int kBfsParents = 128, kBfsItems = 3, kBfsThreads = kBfsParents * 4, kBfsTile = kBfsParents * 12, kBfsFold = 4096, kBfsTileBits = 11;
 
 
+// (the kernels' bodies are functions of the tile index `bx`: k_bfs_*_many run them for MANY searches in one launch, a search per blockIdx.y)
 template <typename W, int MODE>
-__global__ void __launch_bounds__(kBfsThreads) k_bfs_expand_insert(SearchDev<W> d, uint32_t pbegin, uint32_t np, const BfsCursor* __restrict__ cur = nullptr) {
+__device__ __forceinline__ void bfs_expand_insert_body(const SearchDev<W>& d, uint32_t pbegin, uint32_t np, const BfsCursor* __restrict__ cur, const uint32_t bx) {
     __shared__ W s_k0[kBfsTile];
     __shared__ W s_k1[kBfsTile];
     __shared__ uint32_t s_slot[kBfsFold];
@@ -112,10 +113,10 @@ __global__ void __launch_bounds__(kBfsThreads) k_bfs_expand_insert(SearchDev<W> 
         np = avail < np ? avail : np;
     }
     const uint32_t tid = threadIdx.x, l = (tid & 63u) + 64u * (tid >> 8), w = (tid >> 6) & 3u;
-    if (blockIdx.x * kBfsParents >= np) return;  // (a full-size grid over a short batch)
+    if (bx * kBfsParents >= np) return;  // (a full-size grid over a short batch)
     for (uint32_t i = tid; i < (uint32_t)kBfsFold; i += kBfsThreads) s_slot[i] = kEmpty;
     if (tid < kBfsTile / 4) s_took[tid] = 0;
-    const uint32_t p = blockIdx.x * kBfsParents + l, pid = pbegin + p;
+    const uint32_t p = bx * kBfsParents + l, pid = pbegin + p;
     const bool live = p < np;
     W pk0 = 0, pk1 = 0;
     uint32_t pa = 0xffu;
@@ -253,9 +254,14 @@ __global__ void __launch_bounds__(kBfsThreads) k_bfs_expand_insert(SearchDev<W> 
     }
     __syncthreads();
     {  // btook of the tile's tags, coalesced (every tag of the batch is written: zero = did not take a slot)
-        const uint32_t m = 12u * np, t0 = blockIdx.x * (uint32_t)kBfsTile;
+        const uint32_t m = 12u * np, t0 = bx * (uint32_t)kBfsTile;
         if (tid < kBfsTile / 4 && t0 + 4u * tid < m) ((uint32_t*)(d.btook + t0))[tid] = s_took[tid];  // (m is a multiple of 4; t0 of 1536)
     }
+}
+
+template <typename W, int MODE>
+__global__ void __launch_bounds__(kBfsThreads) k_bfs_expand_insert(SearchDev<W> d, uint32_t pbegin, uint32_t np, const BfsCursor* __restrict__ cur = nullptr) {
+    bfs_expand_insert_body<W, MODE>(d, pbegin, np, cur, blockIdx.x);
 }
 
 // Winners -> nodes, in TWO launches since round 3:
@@ -276,7 +282,7 @@ __global__ void __launch_bounds__(kBfsThreads) k_bfs_expand_insert(SearchDev<W> 
 #endif
 
 template <typename W>
-__global__ void __launch_bounds__(256) k_bfs_count(SearchDev<W> d, uint32_t m, uint32_t* __restrict__ counts, uint32_t* __restrict__ masks, const BfsCursor* __restrict__ cur = nullptr) {
+__device__ __forceinline__ void bfs_count_body(const SearchDev<W>& d, uint32_t m, uint32_t* __restrict__ counts, uint32_t* __restrict__ masks, const BfsCursor* __restrict__ cur, const uint32_t bx) {
     __shared__ uint32_t s_wsum[4];
     ACX_VGPR_PAD("v31");
     static_assert(kCompactItems == 32, "two 16-candidate halves per lane");
@@ -285,7 +291,7 @@ __global__ void __launch_bounds__(256) k_bfs_count(SearchDev<W> d, uint32_t m, u
         const uint32_t np = cur->nodes - cur->head;  // clamp in PARENTS (as cursor_begin and k_bfs_expand_insert do): 12 x a frontier above 3.6e8 nodes wraps 32 bits
         if (np < m / 12u) m = 12u * np;
     }
-    const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tile = bx, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tile >= (m + kCompactTile - 1) / kCompactTile) return;  // a full-size grid over a short batch
     // A lane takes 16 consecutive candidates of each half of the tile (bits 0..15 / 16..31 of fl): its flags are two 16-byte loads
     // per array and the wave reads 1 KB per instruction.
@@ -315,9 +321,14 @@ __global__ void __launch_bounds__(256) k_bfs_count(SearchDev<W> d, uint32_t m, u
     if (tid == 0) counts[tile] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
 }
 
+template <typename W>
+__global__ void __launch_bounds__(256) k_bfs_count(SearchDev<W> d, uint32_t m, uint32_t* __restrict__ counts, uint32_t* __restrict__ masks, const BfsCursor* __restrict__ cur = nullptr) {
+    bfs_count_body<W>(d, m, counts, masks, cur, blockIdx.x);
+}
+
 template <typename W, int MODE>
-__global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pbegin, uint32_t m, uint32_t base, uint32_t cap_nodes, const uint32_t* __restrict__ counts,
-                                                     const uint32_t* __restrict__ masks, uint32_t* __restrict__ total_out, const BfsCursor* __restrict__ cur = nullptr) {
+__device__ __forceinline__ void bfs_compact_body(const SearchDev<W>& d, uint32_t pbegin, uint32_t m, uint32_t base, uint32_t cap_nodes, const uint32_t* __restrict__ counts,
+                                                 const uint32_t* __restrict__ masks, uint32_t* __restrict__ total_out, const BfsCursor* __restrict__ cur, const uint32_t bx) {
     __shared__ uint32_t s_wsum[4], s_psum[4];
     __shared__ uint16_t s_list[kCompactTile];
     // the tile's parents (its 8192 candidates belong to at most 684 consecutive parents), loaded once, coalesced: every parent has
@@ -334,7 +345,7 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
         if (np < m / 12u) m = 12u * np;
         base = cur->nodes;
     }
-    const uint32_t ntiles = (m + kCompactTile - 1) / kCompactTile, tile = blockIdx.x;
+    const uint32_t ntiles = (m + kCompactTile - 1) / kCompactTile, tile = bx;
     if (tile >= ntiles) return;  // a full-size grid over a short batch
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     ACX_CP_DECL;
@@ -445,6 +456,12 @@ __global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pb
         printf("[compact] tile %u of %u: winners %u; cycles to: prefix + scan %llu, list %llu, nodes written %llu\n", tile, ntiles, block_total, tp[0], tp[1], tp[2]);
 #endif
 }
+template <typename W, int MODE>
+__global__ void __launch_bounds__(256) k_bfs_compact(SearchDev<W> d, uint32_t pbegin, uint32_t m, uint32_t base, uint32_t cap_nodes, const uint32_t* __restrict__ counts,
+                                                     const uint32_t* __restrict__ masks, uint32_t* __restrict__ total_out, const BfsCursor* __restrict__ cur = nullptr) {
+    bfs_compact_body<W, MODE>(d, pbegin, m, base, cap_nodes, counts, masks, total_out, cur, blockIdx.x);
+}
+
 #undef ACX_CP_DECL
 #undef ACX_CP_TICK
 

@@ -562,10 +562,8 @@ __device__ __forceinline__ void cursor_advance(BfsCursor* cur, const Decision& d
 }
 
 template <typename W>
-__global__ void k_decide_tab(SearchDev<W> d, uint32_t m, uint32_t np, uint32_t pbegin, uint32_t base, uint32_t cap_nodes, long long max_nodes,
-                             const uint32_t* __restrict__ total_in, Decision* __restrict__ out, int reset_tags = 0, BfsCursor* cur = nullptr,
-                             BfsCursor* __restrict__ snap = nullptr) {
-    ACX_VGPR_PAD("v23");
+__device__ __forceinline__ void decide_tab_body(const SearchDev<W>& d, uint32_t m, uint32_t np, uint32_t pbegin, uint32_t base, uint32_t cap_nodes, long long max_nodes,
+                                                const uint32_t* __restrict__ total_in, Decision* __restrict__ out, int reset_tags, BfsCursor* cur, BfsCursor* __restrict__ snap) {
     // run-ahead mode (acx_bfs.h): the batch is what the cursor says.  `snap`: this batch's own snapshot slot -- the cursor as this
     // kernel leaves it, written by this kernel alone and not touched again before the host has read it (the host copies the SLOT,
     // never the live cursor, which the next batch's kernels may be changing while the copy runs: no torn snapshot)
@@ -625,6 +623,13 @@ __global__ void k_decide_tab(SearchDev<W> d, uint32_t m, uint32_t np, uint32_t p
         cursor_advance(cur, *out, pbegin, np, base);
         if (snap) *snap = *cur;
     }
+}
+template <typename W>
+__global__ void k_decide_tab(SearchDev<W> d, uint32_t m, uint32_t np, uint32_t pbegin, uint32_t base, uint32_t cap_nodes, long long max_nodes,
+                             const uint32_t* __restrict__ total_in, Decision* __restrict__ out, int reset_tags = 0, BfsCursor* cur = nullptr,
+                             BfsCursor* __restrict__ snap = nullptr) {
+    ACX_VGPR_PAD("v23");
+    decide_tab_body<W>(d, m, np, pbegin, base, cap_nodes, max_nodes, total_in, out, reset_tags, cur, snap);
 }
 
 // root node: id 0

@@ -26,6 +26,7 @@
 #include "acx_frontier.h"
 #include "acx_bfs.h"
 #include "acx_bfs_multi.h"
+#include "acx_bfs_many.h"
 #include "acx_greedy.h"
 #include "acx_greedy_mega.h"
 
@@ -651,6 +652,242 @@ static int run_bfs_group(const int8_t* rows, int64_t n, int L, int64_t max_nodes
     return ACX_OK;
 }
 
+// A group of independent breadth-first searches, level-synchronous on the kernels of the fused single search (acx_bfs_many.h): one
+// round of launches advances every running search by one batch of at most `bmax` parents.  Same contract as run_bfs_group.
+static uint32_t bfs_many_bmax() {
+    const char* e = getenv("ACX_BFS_MANY_BMAX");
+    const long v = e ? atol(e) : 0;
+    return v >= 128 ? (uint32_t)std::min<long>(v, 1l << 22) : (1u << 15);
+}
+template <typename W>
+static int run_bfs_group_fused(const int8_t* rows, int64_t n, int L, int64_t max_nodes, int cyclical, int32_t* solved, int32_t* path_action, int32_t* path_len,
+                               int64_t path_cap, int64_t* path_n, acx_search_stats* stats, int32_t* rc_out) {
+    if (n <= 0) return ACX_OK;
+    const uint32_t bmax = (uint32_t)std::min<int64_t>(std::max<int64_t>(max_nodes / 4, 1024), bfs_many_bmax());
+    const uint64_t cap_nodes = (uint64_t)std::max<int64_t>(max_nodes, 0) + 64, cap_cand = 12ull * bmax;
+    uint64_t n_slots = 1024;
+    static const double load = getenv("ACX_BFS_MANY_LOAD") ? atof(getenv("ACX_BFS_MANY_LOAD")) : 2.0;  // slots per stamp the table may ever hold
+    while ((double)n_slots < load * (double)(cap_nodes + cap_cand)) n_slots <<= 1;
+    if (n_slots > (1ull << 31)) return fail(ACX_E_INVAL, "acx_search_many: budget too large for 32-bit node ids");
+    auto up = [](uint64_t b) { return (b + 255) / 256 * 256; };
+    const uint64_t tiles = cap_cand / kCompactTile + 2;
+    const uint64_t b_tab = up(n_slots * 8), b_key = up(cap_nodes * sizeof(W)), b_u32 = up(cap_nodes * 4), b_u8 = up(cap_nodes), b_flag = up(cap_cand + 8);
+    const uint64_t b_counts = up(tiles * 4), b_masks = up(tiles * 1024), b_scal = 256;
+    const uint64_t per_rest = 2 * b_key + 2 * b_u32 + 2 * b_u8 + b_flag + b_counts + b_masks + b_scal;
+    // [tables of all searches][replaced-flags of all searches] (one memset each), then the rest search by search
+    DevBuf big;
+    if (big.alloc((uint64_t)n * (b_tab + b_flag + per_rest))) return ACX_E_NOMEM;
+    uint8_t* p_tab = (uint8_t*)big.p;
+    uint8_t* p_repl = p_tab + (uint64_t)n * b_tab;
+    uint8_t* p_rest = p_repl + (uint64_t)n * b_flag;
+    SearchHandles H;
+    if (int rc = search_handles_take(H)) return rc;
+    struct Give {
+        SearchHandles& h;
+        ~Give() { search_handles_give(h); }
+    } give{H};
+    hipStream_t st = H.st;
+    ACX_HIP_TRY(hipMemsetAsync(p_tab, 0xff, (uint64_t)n * b_tab, st));
+    ACX_HIP_TRY(hipMemsetAsync(p_repl, 0, (uint64_t)n * b_flag, st));  // once: k_bfs_count zeroes what a batch sets
+    std::vector<int64_t> order[2];  // [0] general move code, [1] normal form (a root in normal form keeps its whole search there)
+    std::vector<Pres<W>> roots((size_t)n);
+    for (int64_t k = 0; k < n; k++) {
+        rc_out[k] = ACX_OK;
+        solved[k] = 0;
+        path_n[k] = 0;
+        Pres<W>& root = roots[(size_t)k];
+        bool ok = pack_relator<W>(rows + k * 2 * L, L, root.w0, root.n0);
+        ok = pack_relator<W>(rows + k * 2 * L + L, L, root.w1, root.n1) && ok;
+        if (!ok) return fail(ACX_E_ROWERR, "acx_search_many: presentation %lld is not a zero-padded word pair over {+-1,+-2}", (long long)k);
+        order[is_normal_form<W>(root, cyclical != 0) && !getenv("ACX_BFS_GENERAL_MOVE") ? 1 : 0].push_back(k);
+    }
+    DevBuf dcur;  // the searches' cursors, contiguous: one copy brings them all back
+    if (dcur.alloc((size_t)n * sizeof(BfsCursor))) return ACX_E_NOMEM;
+    std::vector<BfsMany<W>> hq;
+    std::vector<W> hroots;
+    std::vector<int64_t> slot_of;  // launch slot -> search index: [general ...][normal form ...]
+    for (int mode = 0; mode < 2; mode++)
+        for (int64_t k : order[mode]) {
+            const size_t j = slot_of.size();
+            slot_of.push_back(k);
+            BfsMany<W> e;
+            memset(&e, 0, sizeof(e));
+            uint8_t* q = p_rest + (uint64_t)j * per_rest;
+            auto take = [&](uint64_t bytes) {
+                uint8_t* r = q;
+                q += bytes;
+                return r;
+            };
+            SearchDev<W>& d = e.d;
+            d.L = L;
+            d.cyclical = cyclical;
+            d.stab = (unsigned long long*)(p_tab + (uint64_t)j * b_tab);
+            d.stmask = (uint32_t)(n_slots - 1);
+            d.brepl = p_repl + (uint64_t)j * b_flag;
+            d.k0 = (W*)take(b_key);
+            d.k1 = (W*)take(b_key);
+            d.parent = (uint32_t*)take(b_u32);
+            d.depth = (uint32_t*)take(b_u32);
+            d.act = take(b_u8);
+            d.tlen = take(b_u8);
+            d.btook = take(b_flag);
+            e.counts = (uint32_t*)take(b_counts);
+            e.masks = (uint32_t*)take(b_masks);
+            uint8_t* sc = take(b_scal);
+            d.solved_tag = (unsigned long long*)(sc + 0);
+            d.shorter_tag = (unsigned long long*)(sc + 8);
+            d.err_tag = (unsigned long long*)(sc + 16);
+            d.err = (uint32_t*)(sc + 24);
+            d.min_len = (uint32_t*)(sc + 28);
+            e.dec = (Decision*)(sc + 64);
+            e.total = (uint32_t*)(sc + 132);
+            e.cur = (BfsCursor*)dcur.p + j;
+            hq.push_back(e);
+            hroots.push_back(keyops<W>::make(roots[(size_t)k].w0, roots[(size_t)k].n0));
+            hroots.push_back(keyops<W>::make(roots[(size_t)k].w1, roots[(size_t)k].n1));
+        }
+    const int64_t pc = std::max<int64_t>(path_cap, 1);
+    const uint32_t un = (uint32_t)n;
+    DevBuf dq, droots, dstatus, dwant, dpa, dpl, dpn;
+    if (dq.alloc((size_t)n * sizeof(BfsMany<W>)) || droots.alloc((size_t)n * 2 * sizeof(W)) || dstatus.alloc((size_t)n * 4 * kRunAheadSlots) || dwant.alloc((size_t)n * 4) ||
+        dpa.alloc((size_t)n * pc * 4) || dpl.alloc((size_t)n * pc * 4) || dpn.alloc((size_t)n * 4))
+        return ACX_E_NOMEM;
+    const size_t cur_off = up((size_t)n * 4 * kRunAheadSlots);
+    uint8_t* pin = pinned_staging(cur_off + (size_t)n * sizeof(BfsCursor));
+    if (!pin) return fail(ACX_E_NOMEM, "hipHostMalloc failed");
+    uint32_t* h_status = (uint32_t*)pin;
+    ACX_HIP_TRY(hipMemcpyAsync(dq.p, hq.data(), (size_t)n * sizeof(BfsMany<W>), hipMemcpyHostToDevice, st));
+    ACX_HIP_TRY(hipMemcpyAsync(droots.p, hroots.data(), (size_t)n * 2 * sizeof(W), hipMemcpyHostToDevice, st));
+    EventPair evs;
+    ACX_HIP_TRY(evs.create());
+    ACX_HIP_TRY(hipEventRecord(evs.a, st));
+    const BfsMany<W>* q = (const BfsMany<W>*)dq.p;
+    const uint32_t n_gen = (uint32_t)order[0].size(), n_nf = (uint32_t)order[1].size();
+    const dim3 sgrid((un + 63) / 64), sblock(64);
+    hipLaunchKernelGGL(k_bfs_root_many<W>, sgrid, sblock, 0, st, q, (const W*)droots.p, un);
+    const uint32_t mcap = 12u * bmax;
+    uint64_t bound = 1;  // no search has more than `bound` parents queued in this round (a batch multiplies the nodes by at most 13)
+    uint64_t rounds = 0;
+    for (uint64_t k = 0;; k++) {
+        if (k + 1 >= (1ull << 30)) return fail(ACX_E_CAPACITY, "acx_search_many: more than 2^30 batches");
+        const uint32_t bp = (uint32_t)std::min<uint64_t>(bound, bmax);
+        const unsigned ex = (bp + kBfsParents - 1) / kBfsParents, cx = (12u * bp + kCompactTile - 1) / kCompactTile;
+        if (n_gen) hipLaunchKernelGGL((k_bfs_expand_insert_many<W, kMoveGeneral>), dim3(ex, n_gen), dim3(kBfsThreads), 0, st, q, bmax);
+        if (n_nf) {
+            if (cyclical) hipLaunchKernelGGL((k_bfs_expand_insert_many<W, kMoveNfCyclical>), dim3(ex, n_nf), dim3(kBfsThreads), 0, st, q + n_gen, bmax);
+            else hipLaunchKernelGGL((k_bfs_expand_insert_many<W, kMoveNf>), dim3(ex, n_nf), dim3(kBfsThreads), 0, st, q + n_gen, bmax);
+        }
+        hipLaunchKernelGGL(k_bfs_count_many<W>, dim3(cx, un), dim3(256), 0, st, q, mcap);
+        if (n_gen) hipLaunchKernelGGL((k_bfs_compact_many<W, kMoveGeneral>), dim3(cx, n_gen), dim3(256), 0, st, q, mcap, (uint32_t)cap_nodes);
+        if (n_nf) {
+            if (cyclical) hipLaunchKernelGGL((k_bfs_compact_many<W, kMoveNfCyclical>), dim3(cx, n_nf), dim3(256), 0, st, q + n_gen, mcap, (uint32_t)cap_nodes);
+            else hipLaunchKernelGGL((k_bfs_compact_many<W, kMoveNf>), dim3(cx, n_nf), dim3(256), 0, st, q + n_gen, mcap, (uint32_t)cap_nodes);
+        }
+        const int slot = (int)(k % kRunAheadSlots);
+        uint32_t* dst = (uint32_t*)dstatus.p + (size_t)slot * n;
+        hipLaunchKernelGGL(k_decide_tab_many<W>, sgrid, sblock, 0, st, q, un, mcap, bmax, (uint32_t)cap_nodes, (long long)max_nodes, dst);
+        ACX_HIP_TRY(hipGetLastError());
+        // the round's status words, copied on the side stream behind an event of the main one (the slot is reused four rounds later, which
+        // is only enqueued after the host has waited for this copy)
+        ACX_HIP_TRY(hipEventRecord(H.ev_batch[slot], st));
+        ACX_HIP_TRY(hipStreamWaitEvent(H.st_copy, H.ev_batch[slot], 0));
+        ACX_HIP_TRY(hipMemcpyAsync(h_status + (size_t)slot * n, dst, (size_t)n * 4, hipMemcpyDeviceToHost, H.st_copy));
+        ACX_HIP_TRY(hipEventRecord(H.ev_cursor[slot], H.st_copy));
+        bound = std::min<uint64_t>(bound * 13, 1ull << 40);
+        rounds = k + 1;
+        if (k >= kRunAheadLag) {
+            const int old = (int)((k - kRunAheadLag) % kRunAheadSlots);
+            ACX_HIP_TRY(hipEventSynchronize(H.ev_cursor[old]));
+            bool all = true;
+            for (int64_t j = 0; j < n && all; j++) all = h_status[(size_t)old * n + j] != 0;
+            if (all) break;  // (the rounds enqueued behind it found every cursor ended and left them alone)
+        }
+    }
+    // every search has ended: its cursor says how (status 3: the queue ran empty; 1: `term` is the batch that ended it, not applied)
+    BfsCursor* hc = (BfsCursor*)(pin + cur_off);
+    ACX_HIP_TRY(hipMemcpyAsync(hc, dcur.p, (size_t)n * sizeof(BfsCursor), hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
+    std::vector<uint32_t> want((size_t)n, kEmpty);
+    bool any_path = false;
+    for (int64_t j = 0; j < n; j++) {
+        const BfsCursor& c = hc[j];
+        if (c.status == 1 && c.term.solved && !c.term.err) {
+            want[(size_t)j] = c.term_pbegin + c.term.solved_tag / 12;
+            any_path = true;
+        }
+    }
+    std::vector<int32_t> pa, pl;
+    std::vector<uint32_t> pn((size_t)n, 0);
+    if (any_path) {
+        pa.resize((size_t)n * pc);
+        pl.resize((size_t)n * pc);
+        ACX_HIP_TRY(hipMemcpyAsync(dwant.p, want.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_paths_many<W>, sgrid, sblock, 0, st, q, un, (const uint32_t*)dwant.p, (int32_t*)dpa.p, (int32_t*)dpl.p, (uint32_t*)dpn.p, (long long)pc);
+        ACX_HIP_TRY(hipGetLastError());
+        ACX_HIP_TRY(hipMemcpyAsync(pn.data(), dpn.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipMemcpyAsync(pa.data(), dpa.p, (size_t)n * pc * 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipMemcpyAsync(pl.data(), dpl.p, (size_t)n * pc * 4, hipMemcpyDeviceToHost, st));
+    }
+    ACX_HIP_TRY(hipEventRecord(evs.b, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    ACX_HIP_TRY(hipEventElapsedTime(&ms, evs.a, evs.b));
+    if (getenv("ACX_DEBUG")) fprintf(stderr, "[acx_bfs_many] %lld searches (%u general), %llu rounds of <= %u parents, group %.2f ms\n", (long long)n, n_gen, (unsigned long long)rounds, bmax, ms);
+    for (int64_t j = 0; j < n; j++) {
+        const int64_t k = slot_of[(size_t)j];
+        const BfsCursor& c = hc[j];
+        uint64_t nodes = c.nodes, expanded = c.expanded;
+        uint32_t min_len = c.min_len;
+        if (c.status == 1) {
+            const Decision& dec = c.term;
+            if (dec.err == 0xFE) {
+                rc_out[k] = fail(ACX_E_CAPACITY, "acx_search_many: a probe sequence ran through the whole visited table of search %lld", (long long)k);
+                continue;
+            }
+            if (dec.err) {
+                rc_out[k] = err_to_rc(dec.err);
+                continue;
+            }
+            min_len = std::min<uint32_t>(min_len, dec.min_len);
+            nodes += dec.committed;
+            if (dec.solved) {  // success: path of the parent + (action, 2); checked before dedup and before the budget test
+                const uint32_t ps = dec.solved_tag / 12, as = dec.solved_tag % 12;
+                const int64_t len = (int64_t)pn[(size_t)j];
+                if (path_action && path_len) {
+                    const int64_t w = std::min<int64_t>(len, path_cap);
+                    if (w > 0) {
+                        memcpy(path_action + k * path_cap, pa.data() + j * pc, (size_t)w * 4);
+                        memcpy(path_len + k * path_cap, pl.data() + j * pc, (size_t)w * 4);
+                    }
+                    if (len < path_cap) {
+                        path_action[k * path_cap + len] = (int32_t)as;
+                        path_len[k * path_cap + len] = 2;
+                    }
+                }
+                path_n[k] = len + 1;
+                solved[k] = 1;
+                expanded += ps + 1;
+                min_len = 2;
+                if (path_n[k] > path_cap) rc_out[k] = fail(ACX_E_CAPACITY, "path has %lld entries, buffer holds %lld", (long long)path_n[k], (long long)path_cap);
+            } else {
+                expanded += (uint64_t)dec.p_end + 1;
+            }
+        } else if (c.status != 3) {
+            rc_out[k] = fail(ACX_E_NODEVICE, "bfs cursor of search %lld ended in state %u", (long long)k, c.status);
+            continue;
+        }
+        if (stats) {
+            stats[k].nodes = (int64_t)nodes;
+            stats[k].expanded = (int64_t)expanded;
+            stats[k].children = (int64_t)expanded * 12;
+            stats[k].levels = (int64_t)c.batches;
+            stats[k].min_len = (int32_t)min_len;
+            stats[k].seconds = ms * 1e-3;  // of the whole group
+        }
+    }
+    return ACX_OK;
+}
+
 template <typename W> static void launch_greedy_persistent(const GreedyDev<W>& g, GreedyOut* out, hipStream_t st) {
     if (g.nf) hipLaunchKernelGGL((k_greedy_persistent<W, true>), dim3(1), dim3(kGT), 0, st, g, out);
     else hipLaunchKernelGGL((k_greedy_persistent<W, false>), dim3(1), dim3(kGT), 0, st, g, out);
@@ -1227,17 +1464,25 @@ extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t 
         return ACX_OK;
     }
     if (kind == ACX_SEARCH_BFS && n > 1 && L >= 1 && L <= 61 && !getenv("ACX_BFS_MANY_STREAMS") && !t_minima_on && !g_digest_on.load()) {
-        // bfs: groups of searches in ONE launch, one persistent workgroup per search (acx_bfs_multi.h)
+        // bfs: groups of searches sharing the launches of the fused single search, a batch of every search per round (acx_bfs_many.h);
+        // ACX_BFS_MANY=multi: round 3's one persistent workgroup per search in ONE launch (acx_bfs_multi.h), kept for A/B runs
         if (max_nodes < 0) max_nodes = 0;
-        const double per_search = (L <= 29 ? 26.0 : 42.0) * (double)std::max<int64_t>(max_nodes, 1) + 16.0 * 2.0 * (double)std::max<int64_t>(max_nodes, 1) + 4e6;
+        const char* many_env = getenv("ACX_BFS_MANY");
+        const bool fused = !(many_env && !strcmp(many_env, "multi"));
+        const double nn = (double)std::max<int64_t>(max_nodes, 1);
+        const double per_search = fused ? (L <= 29 ? 26.0 : 42.0) * nn + 32.0 * (nn + 12.0 * bfs_many_bmax()) + 64.0 * bfs_many_bmax() + 1e6
+                                        : (L <= 29 ? 26.0 : 42.0) * nn + 16.0 * 2.0 * nn + 4e6;
         const int64_t group = (int64_t)std::max(1.0, std::min(4096.0, group_byte_budget(48e9) / per_search));
         for (int64_t k0 = 0; k0 < n; k0 += group) {
             const int64_t m = std::min<int64_t>(group, n - k0);
             int32_t* pa = path_action ? path_action + k0 * path_cap : nullptr;
             int32_t* pl = path_len ? path_len + k0 * path_cap : nullptr;
             acx_search_stats* ps = stats ? stats + k0 : nullptr;
-            const int rc = L <= 29 ? run_bfs_group<uint64_t>(h_presentations + k0 * 2 * L, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0)
-                                   : run_bfs_group<u128>(h_presentations + k0 * 2 * L, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0);
+            const int8_t* pr = h_presentations + k0 * 2 * L;
+            const int rc = fused ? (L <= 29 ? run_bfs_group_fused<uint64_t>(pr, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0)
+                                            : run_bfs_group_fused<u128>(pr, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0))
+                                 : (L <= 29 ? run_bfs_group<uint64_t>(pr, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0)
+                                            : run_bfs_group<u128>(pr, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0));
             if (rc != ACX_OK) return rc;
         }
         for (int64_t k = 0; k < n; k++)

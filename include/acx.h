@@ -140,7 +140,7 @@ typedef struct {
     int64_t expanded;  /* parents expanded */
     int64_t children;  /* ACMove evaluations */
     int64_t levels;    /* BFS levels / greedy batches processed */
-    int32_t min_len;   /* smallest total length generated */
+    int32_t min_len;   /* smallest total length generated (in whole batches: an unsolved search may count children of its last batch that the reference would not have generated any more) */
     double seconds;    /* device time of the search loop */
 } acx_search_stats;
 

@@ -510,6 +510,70 @@ def test_many_searches_overlapped_equal_single(search, golden_json):
             assert (ok, path) == many[k][:2] and st["nodes"] == many[k][2]["nodes"]
 
 
+def _pad(rel0, rel1, L):
+    row = np.zeros(2 * L, np.int8)
+    row[: len(rel0)] = rel0
+    row[L: L + len(rel1)] = rel1
+    return row
+
+
+@pytest.mark.parametrize("L", [9, 33])
+def test_many_bfs_searches_share_their_launches_and_equal_single_ones(search, L, monkeypatch):
+    """acx_search_many(bfs) = acx_bfs_many.h: one round of launches advances every search of the group by a batch.  Groups that mix
+    roots in and out of normal form (two move codes), searches that end by success, by budget at every small budget and by an empty
+    queue, batches of 128 / 1024 / 32768 parents: (solved, path, nodes, expanded) equal the single search's, which the other
+    tests hold against the oracle -- and round 3's one-workgroup-per-search kernel (ACX_BFS_MANY=multi) says the same."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search, run_search_many
+
+    rows = np.stack([
+        _pad([1, 1, -2, -2, -2], [1, 2, 1, -2, -1, -2], L),          # AK(2): solved after 7e4 nodes
+        _pad([1, 1, 1, -2, -2, -2, -2], [1, 2, 1, -2, -1, -2], L),   # AK(3): never solved here
+        _pad([1, 2, -2, 1], [2, 1, -1, 2, 2], L),                    # not freely reduced: the general move code
+        _pad([2, 1, -2], [1, 2, -1, -1], L),                         # not cyclically reduced
+        _pad([1], [2], L),                                           # trivial already: the first child ends the search
+        _pad([1, 1], [2, 2], L),
+        _pad([1, 2], [2, 1, 1], L),
+    ])
+    for cyc in (False, True):
+        single = {}
+        for bmax in (128, 1024, 32768):
+            monkeypatch.setenv("ACX_BFS_MANY_BMAX", str(bmax))
+            for budget in list(range(0, 30)) + [157, 1537, 1538, 20000, 120000]:
+                if bmax != 128 and budget < 30 and budget % 7:
+                    continue
+                many = run_search_many(_acx.SEARCH_BFS, rows, budget, cyc)
+                for k, (ok, path, st) in enumerate(many):
+                    if (k, budget) not in single:
+                        single[(k, budget)] = run_search(_acx.SEARCH_BFS, rows[k], budget, cyc)
+                    wok, wpath, wst = single[(k, budget)]
+                    assert (ok, path) == (wok, wpath), (cyc, bmax, budget, k)
+                    # (min_len also counts the children of the last batch behind the one that ended the search: it depends on the batch size)
+                    assert [st[f] for f in ("nodes", "expanded", "children")] == [wst[f] for f in ("nodes", "expanded", "children")], (cyc, bmax, budget, k, st, wst)
+                    assert st["min_len"] == wst["min_len"] or not ok
+        monkeypatch.delenv("ACX_BFS_MANY_BMAX")
+        monkeypatch.setenv("ACX_BFS_MANY", "multi")
+        for budget in (13, 1537, 120000):
+            for k, (ok, path, st) in enumerate(run_search_many(_acx.SEARCH_BFS, rows, budget, cyc)):
+                wok, wpath, wst = single[(k, budget)]
+                assert (ok, path, st["nodes"], st["expanded"]) == (wok, wpath, wst["nodes"], wst["expanded"]), ("multi", cyc, budget, k)
+        monkeypatch.delenv("ACX_BFS_MANY")
+    # a finite state space: the queue runs empty (breadth_first.py:61) in every search of the group, after different numbers of batches
+    tiny = np.stack([_pad([1, 1], [2, 2], 3), _pad([1, 1], [2, 1], 3), _pad([1, 1], [2], 3), _pad([1, 2, 1], [2, 2], 3), _pad([2, 2], [1, -2], 3)])
+    monkeypatch.setenv("ACX_BFS_MANY_BMAX", "128")
+    got = run_search_many(_acx.SEARCH_BFS, tiny, 10**5, False)
+    assert [(ok, path, st["nodes"], st["expanded"]) for ok, path, st in got] == [(False, None, n, n) for n in (1, 48, 108, 60, 48)]  # (the C oracle's counts)
+    for k, (ok, path, st) in enumerate(got):
+        wok, wpath, wst = run_search(_acx.SEARCH_BFS, tiny[k], 10**5, False)
+        assert (ok, path, st["nodes"], st["expanded"]) == (wok, wpath, wst["nodes"], wst["expanded"])
+    # a move on which the reference's ACMove raises, in ONE search of a group: the call raises as the single search does
+    bad = np.stack([_pad([1, 1], [2, 2], 2), _pad([1, 2], [2, 1], 2)])
+    with pytest.raises(AssertionError):
+        run_search(_acx.SEARCH_BFS, bad[1], 100, False)
+    with pytest.raises(AssertionError):
+        run_search_many(_acx.SEARCH_BFS, bad, 100, False)
+
+
 def test_miller_schupp_driver_matches_reference_test_ranges(search, golden_json):
     """tests/search/miller_schupp/test_miller_schupp.py of the reference: n, w in {1, 2} (greedy 1e6, bfs 1e4) and {3, 4} (greedy 1e4)"""
     from ac_solver.search.miller_schupp.miller_schupp import trivialize_miller_schupp_through_search
