@@ -78,9 +78,10 @@ def run_search_many(kind, presentations, max_nodes_to_explore, cyclical, n_threa
 
 
 def run_search_groups(kind, groups, max_nodes_to_explore, cyclical, n_threads=16, path_cap=4096):
-    """`run_search_many` on several batches of presentations of DIFFERENT widths at once (the Miller-Schupp presentations of each
-    n have their own max_relator_length): one host thread per batch, so that their launches share the GPU -- a batch of 170
-    one-workgroup searches fills 170 of the 256 compute units.  -> list (per batch) of lists of (solved, path, stats)."""
+    """`run_search_many` on several batches of presentations of DIFFERENT widths (the Miller-Schupp presentations of each n have
+    their own max_relator_length).  greedy_search: one host thread per batch, so that their launches share the GPU -- a batch of
+    170 one-workgroup searches fills 170 of the 256 compute units.  bfs: one batch after the other (see below).
+    -> list (per batch) of lists of (solved, path, stats)."""
     from concurrent.futures import ThreadPoolExecutor
 
     if len(groups) <= 1:

@@ -293,7 +293,7 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
         import gc
 
         times = []
-        for _ in range(5):  # the median of five timed sweeps (a sweep is 0.3-0.5 s; the first one behind the sharded searches runs up to 40 % longer), no garbage collection while the clock runs
+        for _ in range(5):  # the median of five timed sweeps (a sweep is 0.15-0.45 s; the first one behind the sharded searches runs up to 40 % longer), no garbage collection while the clock runs
             n_solved = n_nodes = n_children = 0
             gc.collect()
             gc.disable()
@@ -329,9 +329,11 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
                 "n_gpus": world, "scaling": "strong", "entry": entry, "roofline": roof}
 
     out["bfs_ms_sweep"] = sweep(_acx.SEARCH_BFS, True, 278,
-                                "acx_search_many per rank: one persistent workgroup per search (k_bfs_multi), the seven max_relator_lengths in "
-                                "flight together; searches dealt round-robin to the ranks",
-                                "k_bfs_multi<u64> / <u128> (one persistent workgroup per search)", "bfs_ms_sweep_1e6")
+                                "acx_search_many per rank: the 170 searches of a max_relator_length share the launches of the fused single search "
+                                "(acx_bfs_many.h: a batch of every running search per round of four launches), the seven lengths one after "
+                                "another; searches dealt round-robin to the ranks",
+                                "k_bfs_expand_insert_many<u64> / <u128> + k_bfs_count_many + k_bfs_compact_many (a tile of one search's batch per workgroup)",
+                                "bfs_ms_sweep_1e6")
     # the reference's other published experiment: greedy_search, budget 1e6, on the same 1190 (533 solved)
     out["greedy_ms_sweep"] = sweep(_acx.SEARCH_GREEDY, False, 533,
                                    "acx_search_many per rank: one persistent workgroup per search (k_greedy_multi), the seven "

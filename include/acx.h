@@ -176,9 +176,11 @@ int acx_search_last_digest(uint64_t *digest);
 int acx_release_cached_memory(void);
 
 /* n independent searches of the same kind / budget (the batch driver trivialize_miller_schupp_through_search,
- * miller_schupp.py:95-177, runs them one after another).  Both kinds run as GROUPS of searches in ONE launch, one persistent
- * workgroup per search with its own visited table and node arena (bfs: k_bfs_multi, acx_bfs_multi.h, two workgroups per compute
- * unit; greedy_search: k_greedy_multi, acx_greedy.h); a group is as many searches as fit the free device memory, and a greedy
+ * miller_schupp.py:95-177, runs them one after another).  Both kinds run as GROUPS of searches, each search with its own visited
+ * table and node arena.  bfs: the searches of a group share the launches of the fused single search (acx_bfs_many.h: a tile of one
+ * search's batch per workgroup, a batch of every running search per round of four launches; ACX_BFS_MANY=multi selects the
+ * earlier one-persistent-workgroup-per-search kernel k_bfs_multi for A/B runs).  greedy_search: ONE launch, one persistent
+ * workgroup per search (k_greedy_multi, acx_greedy.h).  A group is as many searches as fit the free device memory, and a greedy
  * search that outgrows a capacity of its workgroup is rerun alone through acx_search.  `n_threads` only matters on the fallback
  * path (n == 1, L > 61 never reaches it, the diagnostic switches ACX_GREEDY_HOST / ACX_BFS_MANY_STREAMS, `verbose` minima or the
  * digest hook on): there that many host threads run one acx_search each, every search on its own HIP stream; 1..64, clamped.
