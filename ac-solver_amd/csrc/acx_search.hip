@@ -675,7 +675,8 @@ static int run_bfs_group_fused(const int8_t* rows, int64_t n, int L, int64_t max
     const uint64_t b_counts = up(tiles * 4), b_masks = up(tiles * 1024), b_scal = 256;
     const uint64_t per_rest = 2 * b_key + 2 * b_u32 + 2 * b_u8 + b_flag + b_counts + b_masks + b_scal;
     // [tables of all searches][replaced-flags of all searches] (one memset each), then the rest search by search
-    DevBuf big;
+    // (every device block is declared before the stream guard below: an error return first waits for the streams, then frees)
+    DevBuf big, dcur, dq, droots, dstatus, dwant, dpa, dpl, dpn;
     if (big.alloc((uint64_t)n * (b_tab + b_flag + per_rest))) return ACX_E_NOMEM;
     uint8_t* p_tab = (uint8_t*)big.p;
     uint8_t* p_repl = p_tab + (uint64_t)n * b_tab;
@@ -701,8 +702,7 @@ static int run_bfs_group_fused(const int8_t* rows, int64_t n, int L, int64_t max
         if (!ok) return fail(ACX_E_ROWERR, "acx_search_many: presentation %lld is not a zero-padded word pair over {+-1,+-2}", (long long)k);
         order[is_normal_form<W>(root, cyclical != 0) && !getenv("ACX_BFS_GENERAL_MOVE") ? 1 : 0].push_back(k);
     }
-    DevBuf dcur;  // the searches' cursors, contiguous: one copy brings them all back
-    if (dcur.alloc((size_t)n * sizeof(BfsCursor))) return ACX_E_NOMEM;
+    if (dcur.alloc((size_t)n * sizeof(BfsCursor))) return ACX_E_NOMEM;  // the searches' cursors, contiguous: one copy brings them all back
     std::vector<BfsMany<W>> hq;
     std::vector<W> hroots;
     std::vector<int64_t> slot_of;  // launch slot -> search index: [general ...][normal form ...]
@@ -748,7 +748,6 @@ static int run_bfs_group_fused(const int8_t* rows, int64_t n, int L, int64_t max
         }
     const int64_t pc = std::max<int64_t>(path_cap, 1);
     const uint32_t un = (uint32_t)n;
-    DevBuf dq, droots, dstatus, dwant, dpa, dpl, dpn;
     if (dq.alloc((size_t)n * sizeof(BfsMany<W>)) || droots.alloc((size_t)n * 2 * sizeof(W)) || dstatus.alloc((size_t)n * 4 * kRunAheadSlots) || dwant.alloc((size_t)n * 4) ||
         dpa.alloc((size_t)n * pc * 4) || dpl.alloc((size_t)n * pc * 4) || dpn.alloc((size_t)n * 4))
         return ACX_E_NOMEM;
