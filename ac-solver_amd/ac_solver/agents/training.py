@@ -103,6 +103,74 @@ class Curriculum:
             self.max_processed = nxt
         return nxt
 
+    # ---- a rollout step's finished episodes at once ------------------------------------------------------------------------------
+    _C_MIN = 48  # below this many draws Python's own generator is cheaper than moving its state to libacx and back
+
+    def _draws(self, n):
+        """next_state() n times after the first round, with both lists fixed: the same draws from `random`, taken in libacx
+        (acx_py_curriculum_draws restates CPython's Random.random / choice) on the state of the global generator, which is put back
+        advanced.  -> states [n]"""
+        if n < self._C_MIN:
+            return [self.next_state() for _ in range(n)]
+        import ctypes as C
+
+        from ac_solver import _acx
+
+        ver, internal, gauss = random.getstate()
+        mt = np.array(internal[:624], dtype=np.uint32)
+        pos = C.c_int32(internal[624])
+        which, index = np.empty(n, np.uint8), np.empty(n, np.int64)
+        solved, unsolved = self._list("solved"), self._list("unsolved")
+        _acx.check(_acx.lib.acx_py_curriculum_draws(mt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), n, len(solved), len(unsolved), float(self.p),
+                                                    _acx.ptr(which, C.c_uint8), _acx.ptr(index, C.c_int64)), "acx_py_curriculum_draws")
+        random.setstate((ver, tuple(mt.tolist()) + (pos.value,), gauss))
+        key = ("arrays", len(solved), len(unsolved))
+        if getattr(self, "_arr_key", None) != key:  # (a state only ever moves unsolved -> solved: the sizes tell)
+            self._arr = (np.asarray(unsolved, np.int64), np.asarray(solved, np.int64))
+            self._arr_key = key
+        un, so = self._arr
+        out = np.where(which == 0, un[np.minimum(index, max(len(un) - 1, 0))] if len(un) else 0, so[np.minimum(index, max(len(so) - 1, 0))] if len(so) else 0)
+        nxt = out.tolist()
+        self.processed.update(nxt)
+        self.max_processed = max(self.max_processed, max(nxt))
+        return nxt
+
+    def finish_episodes(self, current, done, on_done):
+        """The reference's bookkeeping (training.py:172-224) for the episodes a rollout step ended, in environment order: `current`
+        [k] the curriculum states those environments ran, `done` [k] whether the episode reached the trivial presentation; for every
+        such episode `on_done(position, state)` is called (the shortest-path record) after the state has been marked solved.
+        -> the next state of each environment [k].  Same decisions, same draws from `random`, as mark_solved / next_state called
+        episode by episode; the episodes between two changes of the solved set take their draws in one call of libacx."""
+        k = len(current)
+        out = []
+        done_pos = np.flatnonzero(done).tolist()
+        a = 0
+        for pos in done_pos + [k]:
+            # episodes a .. pos - 1 draw with the lists as they are; episode pos (if any) first changes them
+            if pos < k:
+                s = current[pos]
+                changes = s in self.rec["unsolved"]
+                if not changes:
+                    on_done(pos, s)  # (solved before: only the path record may change, the lists do not)
+                    continue
+            n = pos - a
+            if n > 0:
+                if not self.round1_complete:
+                    # first round: the states in order, `stride` apart, while they last (then the rule flips for good)
+                    self.round1_complete = self.max_processed + self.stride > self.n_states - 1
+                while n > 0 and not self.round1_complete:
+                    out.append(self.next_state())
+                    n -= 1
+                    self.round1_complete = self.round1_complete or self.max_processed + self.stride > self.n_states - 1
+                if n > 0:
+                    out.extend(self._draws(n))
+            a = pos
+            if pos < k:
+                self.mark_solved(current[pos])
+                on_done(pos, current[pos])
+        # (every `continue` above left its episodes in the pending range a .. : they were drawn with the segment that followed)
+        return out
+
 
 class RunningReturnNormalizer:
     """Per-environment reward normalisation as gymnasium 0.28.1's `NormalizeReward` wrapper does it around every single
@@ -359,25 +427,32 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             ep_return += rewards[step]
             ep_length += 1
             fin = term[step + 1] | trunc
-            if not bool(fin.any()):
+            # ---- episodes ended: bookkeeping of the reference (training.py:167-224) on the finished envs only ----
+            # two read-backs per step: how many (the size of `idx`), then index, done flag, return and length of each in one block
+            idx = torch.nonzero(fin).flatten()
+            if idx.numel() == 0:
                 ph.lap("episode bookkeeping")
                 continue
-            # ---- episodes ended: bookkeeping of the reference (training.py:167-224) on the finished envs only ----
-            idx = torch.nonzero(fin).flatten()
-            idx_h = idx.tolist()
-            done_h = term[step + 1][idx].tolist()
-            ret_h, len_h = ep_return[idx].tolist(), ep_length[idx].tolist()
-            new_states = []
-            for k, i in enumerate(idx_h):
-                s = curr_states[i]
-                if done_h[k]:
-                    curriculum.mark_solved(s)
-                    moves = envs.get_actions(i, finished=True)
+            packed = torch.stack((idx.double(), term[step + 1][idx].double(), ep_return[idx].double(), ep_length[idx].double())).cpu().numpy()
+            idx_h = packed[0].astype(np.int64).tolist()
+            done_np = packed[1] != 0
+            ret_h, len_h = packed[2].tolist(), packed[3].tolist()  # (float32 values, exact in float64: what .tolist() of the tensors gives)
+            current = [curr_states[i] for i in idx_h]
+
+            def on_done(k, s):  # the shortest action sequence seen for state s (strictly shorter replaces; the first of a length stays)
+                # an episode's action list is as long as the episode: only a record-setting one is read back from the device
+                if s not in ACMoves_hist or int(len_h[k]) < len(ACMoves_hist[s]):
+                    moves = envs.get_actions(idx_h[k], finished=True)
+                    if len(moves) != int(len_h[k]):
+                        raise RuntimeError(f"env {idx_h[k]}: an episode of {int(len_h[k])} steps with {len(moves)} recorded actions")
                     if s not in ACMoves_hist or len(moves) < len(ACMoves_hist[s]):
                         ACMoves_hist[s] = moves
-                curr_states[i] = curriculum.next_state()
-                new_states.append(curr_states[i])
-                events.append((step, i, curr_states[i]))
+
+            new_states = curriculum.finish_episodes(current, done_np, on_done)
+            for i, nxt in zip(idx_h, new_states):
+                curr_states[i] = nxt
+            if rollout_log is not None:
+                events.extend((step, i, nxt) for i, nxt in zip(idx_h, new_states))
             returns_queue.extend(ret_h)
             lengths_queue.extend(len_h)
             episode += len(idx_h)

@@ -723,6 +723,40 @@ int acx_np_shuffle_epochs(uint32_t seed, int64_t n, int epochs, int64_t* out) {
     return ACX_OK;
 }
 
+// CPython's random.Random restated for the curriculum draws of the PPO driver (agents/training.py: choose_next_state, reference
+// training.py:199-221): the generator is the same MT19937; random() = (a >> 5, b >> 6) of two outputs as a 53-bit fraction;
+// uniform(0, 1) = 0 + (1 - 0) * random(); choice(seq) = seq[_randbelow(len(seq))], _randbelow(n) = getrandbits(n.bit_length())
+// redrawn until < n, getrandbits(k <= 32) = output >> (32 - k)  (Lib/random.py, Modules/_randommodule.c of CPython 3.10).
+int acx_py_curriculum_draws(uint32_t* mt_state, int32_t* mt_pos, int64_t n, int64_t n_solved, int64_t n_unsolved, double repeat_solved_prob,
+                            uint8_t* which, int64_t* index) {
+    if (!mt_state || !mt_pos || n < 0 || (n && (!which || !index)) || n_solved < 0 || n_unsolved < 0 || (n && n_solved + n_unsolved == 0) ||
+        n_solved > 0xffffffffll || n_unsolved > 0xffffffffll || *mt_pos < 0 || *mt_pos > 624)
+        return fail(ACX_E_INVAL, "acx_py_curriculum_draws: bad argument");
+    Mt19937 rng(0u);
+    memcpy(rng.key, mt_state, sizeof(rng.key));
+    rng.pos = *mt_pos;
+    auto randbelow = [&](uint64_t m) {
+        int k = 0;
+        while ((m >> k) != 0) k++;  // m.bit_length()
+        uint32_t r;
+        do r = rng.next() >> (32 - k);
+        while (r >= m);
+        return (int64_t)r;
+    };
+    for (int64_t i = 0; i < n; i++) {
+        bool unsolved = n_solved == 0;
+        if (!unsolved && n_unsolved > 0) {  // (`unsolved and uniform(0, 1) > p`: no draw when nothing is unsolved)
+            const uint32_t a = rng.next() >> 5, b = rng.next() >> 6;
+            unsolved = ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0) > repeat_solved_prob;
+        }
+        which[i] = unsolved ? 0 : 1;
+        index[i] = randbelow((uint64_t)(unsolved ? n_unsolved : n_solved));
+    }
+    memcpy(mt_state, rng.key, sizeof(rng.key));
+    *mt_pos = rng.pos;
+    return ACX_OK;
+}
+
 int acx_version(void) { return ACX_VERSION; }
 const char* acx_last_error(void) { return last_error_buf(); }
 int acx_device_count(void) {

@@ -162,6 +162,14 @@ int acx_search_minima_enable(int on);
  * h_out [epochs, n].  NumPy's legacy MT19937 / shuffle algorithm restated (a third-party dependency of the reference); runs without
  * the interpreter lock, so the driver computes it on a thread beside the rollout.  n < 2^32. */
 int acx_np_shuffle_epochs(uint32_t seed, int64_t n, int epochs, int64_t *h_out);
+/* Host utility of the PPO driver (no device work): the draws of n consecutive curriculum decisions (training.py:199-221 of the
+ * reference, after its first round: `len(solved) == 0 or (unsolved and random.uniform(0, 1) > repeat_solved_prob)` ->
+ * random.choice(list(unsolved)), else random.choice(list(solved))) for FIXED sizes of the two lists.  mt_state [624] / *mt_pos: the
+ * state of Python's global `random` generator as random.getstate()[1] holds it, advanced in place exactly as n calls of the
+ * Python code advance it (CPython's Random restated: a third-party dependency of the reference).  which[i] = 0: element index[i] of
+ * the unsolved list, 1: of the solved list.  The caller splits a rollout step's finished episodes where a list changes. */
+int acx_py_curriculum_draws(uint32_t *mt_state, int32_t *mt_pos, int64_t n, int64_t n_solved, int64_t n_unsolved,
+                            double repeat_solved_prob, uint8_t *which, int64_t *index);
 
 int acx_search_last_minima(int32_t *lengths, int64_t cap, int64_t *n);
 

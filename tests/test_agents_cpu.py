@@ -204,6 +204,81 @@ def test_curriculum_object_equals_per_episode_choose_next_state():
         assert out_a == out_b and proc_a == proc_b and rec_a == rec_b and r1 == cur.round1_complete
 
 
+def test_py_curriculum_draws_are_pythons_own():
+    """acx_py_curriculum_draws (csrc/acx_step.hip, host only): CPython's random.uniform / random.choice restated on the state of the
+    global generator -- the same decisions as the Python expression of choose_next_state, and the same generator state afterwards."""
+    import ctypes as C
+    import random
+
+    from ac_solver import _acx
+
+    for seed, n_solved, n_unsolved, p, n in ((1, 0, 17, 0.25, 300), (2, 5, 0, 0.25, 300), (3, 1, 1, 0.5, 500), (4, 640, 550, 0.25, 4000),
+                                             (5, 3, 1190, 0.0, 1000), (6, 1189, 1, 1.0, 1000), (7, 2 ** 20 + 1, 2 ** 31, 0.3, 2000)):
+        random.seed(seed)
+        for _ in range(seed * 37):  # (a generator in mid-block)
+            random.random()
+        ver, internal, gauss = random.getstate()
+        want = []
+        for _ in range(n):
+            if n_solved == 0 or (n_unsolved and random.uniform(0, 1) > p):
+                want.append((0, random.choice(range(n_unsolved))))
+            else:
+                want.append((1, random.choice(range(n_solved))))
+        after = random.getstate()
+        mt = np.array(internal[:624], dtype=np.uint32)
+        pos = C.c_int32(internal[624])
+        which, index = np.empty(n, np.uint8), np.empty(n, np.int64)
+        assert _acx.lib.acx_py_curriculum_draws(mt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), n, n_solved, n_unsolved, p,
+                                                _acx.ptr(which, C.c_uint8), _acx.ptr(index, C.c_int64)) == 0
+        assert list(zip(which.tolist(), index.tolist())) == want
+        assert (ver, tuple(mt.tolist()) + (pos.value,), gauss) == after
+    mt = np.zeros(624, np.uint32)
+    pos = C.c_int32(624)
+    one = np.empty(1, np.uint8), np.empty(1, np.int64)
+    assert _acx.lib.acx_py_curriculum_draws(mt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), 1, 0, 0, 0.5, _acx.ptr(one[0], C.c_uint8),
+                                            _acx.ptr(one[1], C.c_int64)) == _acx.E_INVAL
+
+
+def test_finished_episodes_of_a_step_at_once_equal_one_by_one():
+    """Curriculum.finish_episodes (a rollout step's finished episodes in one call; the draws between two changes of the solved set in
+    libacx) = mark_solved / next_state episode by episode: next states, the sets, the shortest-path callbacks in order, and the state
+    of `random` afterwards.  Steps of 1 .. 3000 finished episodes, through the first round and past it, with and without new solves."""
+    import random
+
+    from ac_solver.agents.training import Curriculum
+
+    for stride, n_states, p in ((1, 1190, 0.25), (2, 400, 0.6), (1, 60, 0.0)):
+        ev = random.Random(11 + stride)
+        steps = []
+        for t in range(40):
+            k = ev.choice((1, 3, 40, 47, 48, 49, 300, 3000))
+            steps.append([(ev.random() < (0.3 if t % 3 else 0.002), ev.randrange(n_states)) for _ in range(k)])
+
+        def run(batched):
+            proc = set(range(0, 8 * stride, stride))
+            rec = {"solved": set(), "unsolved": set(range(n_states))}
+            cur = Curriculum(proc, n_states, rec, p, stride)
+            random.seed(3)
+            outs, calls = [], []
+            for step in steps:
+                current, done = [s for _, s in step], np.array([d for d, _ in step])
+                if batched:
+                    outs.append(cur.finish_episodes(current, done, lambda k, s: calls.append((len(outs), k, s))))
+                else:
+                    nxt = []
+                    for k, (d, s) in enumerate(step):
+                        if d:
+                            cur.mark_solved(s)
+                            calls.append((len(outs), k, s))
+                        nxt.append(cur.next_state())
+                    outs.append(nxt)
+            return outs, calls, proc, rec, cur.round1_complete, cur.max_processed, random.getstate()
+
+        a, b = run(False), run(True)
+        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[3] == b[3] and a[4:] == b[4:]
+        assert a[4] and len(a[3]["solved"]) > 5
+
+
 def test_split_k_linear_has_the_gradients_of_nn_linear():
     """agents/ppo_agent.py: the large-batch Linear forms its weight gradient as a sum of per-chunk products (split-K); output and all
     three gradients must be those of torch's linear (float64: equal up to summation order).  The layers are nn.Linear subclasses with
