@@ -45,6 +45,7 @@ enum : uint32_t { GREEDY_RUNNING = 0, GREEDY_SOLVED = 1, GREEDY_BUDGET = 2, GREE
 struct GreedyState {
     uint32_t len_count[132], hint[132], hist[32];
     uint32_t arena_top, nodes, status, reason, err, seen_min, np_cap, last_parent, solved_pid, last_child_len, solved_action, max_bucket;
+    uint32_t reported;  // the frontier kernel has written the search's final GreedyOut (chained launches behind it return at once)
     uint32_t cur_len, cur_depth, resume, depth_hi;  // depth_hi: the largest depth any node has (buckets of deeper depths still hold the zeroes of the set-up)
     unsigned long long expanded, batches, sorts, big_sorts, mega_batches, mega_parents;
     unsigned long long t_phase[24];  // ACX_GREEDY_PROFILE
@@ -87,6 +88,8 @@ template <typename W> struct GreedyDev {
     const uint32_t* mega_status;  // nullable: {status, cut, remaining} of the whole-GPU kernels (acx_greedy_mega.h: MegaScalars).  The host
                                   // relaunches this kernel behind every mega-batch WITHOUT waiting for the batch's outcome (one
                                   // synchronisation per hand-off instead of two); when the bucket is not finished the launch is a no-op
+    uint32_t* hand_ctl;  // nullable: {pending, queued parents, 1 = unsorted tail} of MegaScalars -- chained mode (acx_greedy_mega.h): the hand-off
+                         // is read by the whole-GPU kernels the host has ALREADY enqueued behind this one, not by the host
 };
 
 struct GreedyOut {
@@ -257,6 +260,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wv = tid >> 6;
+    if (g.hand_ctl && g.state->resume && g.state->reported) return;  // chained launches behind the end of the search
     if (g.mega_status && g.mega_status[0] == GREEDY_RUNNING && g.mega_status[1] == 0 && g.mega_status[2] != 0) {  // more mega-batches to come
         if (tid == 0) out->status = GREEDY_MEGA_MORE;
         return;
@@ -1012,7 +1016,13 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
             ps->cur_len = s_cur_len;
             ps->cur_depth = s_cur_depth;
             ps->resume = 1;
+            ps->reported = s_status != GREEDY_HANDOFF && s_status != GREEDY_RUNNING ? 1u : 0u;
         }
+    }
+    if (tid == 0 && g.hand_ctl) {
+        g.hand_ctl[1] = s_status == GREEDY_HANDOFF ? s_rec.cnt - s_rec.head : 0u;
+        g.hand_ctl[2] = s_status == GREEDY_HANDOFF && s_rec.sorted_end < s_rec.cnt ? 1u : 0u;
+        g.hand_ctl[0] = s_status == GREEDY_HANDOFF ? 1u : 0u;
     }
     if (tid == 0) {
         out->hand_len = s_cur_len;

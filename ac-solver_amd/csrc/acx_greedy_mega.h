@@ -38,6 +38,10 @@ struct MegaScalars {
     // the decision (k_gm_decide) and the outcome (k_gm_file)
     uint32_t cutoff, p_end, is_solved, budget_hit, err, last_parent, last_child_len, solved_pid, solved_action;
     uint32_t status, cut, remaining, nodes0, base, cur_len, cur_depth;
+    // chained mode (round 4; the host enqueues frontier kernel -> sort -> mega-batch -> frontier kernel ... without reading anything
+    // in between): h_* is written by the frontier kernel when it hands a bucket off (pending, its queued parents, 1 = unsorted tail)
+    // and kept up to date by k_gm_file; b_* is this mega-batch as k_gm_begin froze it (0 / np / 12 np)
+    uint32_t h_pending, h_live, h_sort, b_active, b_np, b_m;
     uint32_t tbase[kMegaTiles + 1], tcnt[kMegaTiles + 1];
 };
 
@@ -58,41 +62,52 @@ template <typename W> struct MegaDev {
 // an entry is its index in its own run plus, for every other run, the number of that run's keys that precede it (a binary
 // search: the keys of a bucket are pairwise distinct).
 constexpr uint32_t kMegaRun = 1024;  // short runs: the bitonic network's depth grows with log^2 of the run, the merge only with the number of runs
-template <typename W> __global__ void __launch_bounds__(kGT) k_gm_runsort(MegaDev<W> md, uint32_t n) {
+template <typename W> __global__ void __launch_bounds__(kGT) k_gm_runsort(MegaDev<W> md, uint32_t n, uint32_t chained) {
     constexpr uint32_t SC = kMegaRun;
     __shared__ W sk0[SC];
     __shared__ W sk1[SC];
     __shared__ uint32_t sid[SC];
     ACX_VGPR_PAD_W(W, "v47", "v63");
     const GreedyDev<W>& g = md.g;
+    if (chained) {  // (the grid is a fixed one: runs are dealt round-robin to its workgroups)
+        if (!md.sc->h_pending || !md.sc->h_sort) return;
+        n = md.sc->h_live;
+    }
     const GreedyState* ps = g.state;
     const BucketRec r = g.bk[(size_t)ps->cur_len * kDepthCap + ps->cur_depth];
-    const uint32_t tid = threadIdx.x, i0 = blockIdx.x * SC, cnt = min(SC, n - i0);
-    for (uint32_t i = tid; i < cnt; i += kGT) {
-        const uint32_t id = g.arena[r.off + r.head + i0 + i];
-        const NodeKey<W> nk = g.nkeys[id];
-        sid[i] = id;
-        sk0[i] = nk.k0;
-        sk1[i] = nk.k1;
-    }
-    __syncthreads();
-    lds_sort<W, (uint32_t)kGT>(sk0, sk1, sid, cnt, tid);
-    for (uint32_t i = tid; i < cnt; i += kGT) {
-        g.gid[i0 + i] = sid[i];
-        g.gk0[i0 + i] = sk0[i];
-        g.gk1[i0 + i] = sk1[i];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i0 = blockIdx.x * SC; i0 < n; i0 += gridDim.x * SC) {
+        const uint32_t cnt = min(SC, n - i0);
+        for (uint32_t i = tid; i < cnt; i += kGT) {
+            const uint32_t id = g.arena[r.off + r.head + i0 + i];
+            const NodeKey<W> nk = g.nkeys[id];
+            sid[i] = id;
+            sk0[i] = nk.k0;
+            sk1[i] = nk.k1;
+        }
+        __syncthreads();
+        lds_sort<W, (uint32_t)kGT>(sk0, sk1, sid, cnt, tid);
+        for (uint32_t i = tid; i < cnt; i += kGT) {
+            g.gid[i0 + i] = sid[i];
+            g.gk0[i0 + i] = sk0[i];
+            g.gk1[i0 + i] = sk1[i];
+        }
+        __syncthreads();
     }
 }
 
-template <typename W> __global__ void __launch_bounds__(256) k_gm_merge(MegaDev<W> md, uint32_t n) {
+template <typename W> __global__ void __launch_bounds__(256) k_gm_merge(MegaDev<W> md, uint32_t n, uint32_t chained) {
     constexpr uint32_t SC = kMegaRun;
     ACX_VGPR_PAD_W(W, "v47", "v63");
     const GreedyDev<W>& g = md.g;
+    if (chained) {
+        if (!md.sc->h_pending || !md.sc->h_sort) return;
+        n = md.sc->h_live;
+    }
     GreedyState* ps = g.state;
     BucketRec* rp = g.bk + (size_t)ps->cur_len * kDepthCap + ps->cur_depth;
     const BucketRec r = *rp;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const W m0 = g.gk0[i], m1 = g.gk1[i];
         const uint32_t mine = i / SC;
         uint32_t rank = i - mine * SC;
@@ -108,7 +123,8 @@ template <typename W> __global__ void __launch_bounds__(256) k_gm_merge(MegaDev<
         }
         g.arena[r.off + r.head + rank] = g.gid[i];
     }
-    if (i == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // (sorted_end is read above by every workgroup through the copy `r` only for off / head: writing it here races with nothing)
         rp->sorted_end = r.cnt;
         ps->sorts++;
         if (n > greedy_cfg<W>::kSortCap) ps->big_sorts++;
@@ -118,9 +134,21 @@ template <typename W> __global__ void __launch_bounds__(256) k_gm_merge(MegaDev<
 }
 
 // ---- one mega-batch -----------------------------------------------------------------------------------------------------------
-template <typename W> __global__ void __launch_bounds__(256) k_gm_begin(MegaDev<W> md, uint32_t slots) {
+template <typename W> __global__ void __launch_bounds__(256) k_gm_begin(MegaDev<W> md, uint32_t slots, uint32_t chained) {
     ACX_VGPR_PAD("v23");
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (chained) {  // the batch is what the frontier kernel handed off / what the last batch left of it; nothing pending: every kernel of the batch returns
+        const uint32_t pending = md.sc->h_pending, np = min(md.sc->h_live, kMegaParents);
+        if (i == 0) {
+            md.sc->b_active = pending && np ? 1u : 0u;
+            md.sc->b_np = np;
+            md.sc->b_m = 12u * np;
+            md.sc->h_sort = 0;  // (the sort kernels in front of this batch have run)
+        }
+        if (!pending || !np) return;
+        slots = 1024;
+        while (slots < 24u * np) slots <<= 1;
+    }
     for (uint32_t k = i; k < slots; k += gridDim.x * blockDim.x) md.mtab[k] = kNone;
     MegaScalars* sc = md.sc;
     if (i < 132) {
@@ -157,10 +185,17 @@ template <typename W> __device__ __forceinline__ void gm_child(const MegaDev<W>&
     tl = (uint32_t)(s.n0 + s.n1);
 }
 
-template <typename W> __global__ void __launch_bounds__(256) k_gm_expand(MegaDev<W> md, uint32_t m, uint32_t smask) {
+template <typename W> __global__ void __launch_bounds__(256) k_gm_expand(MegaDev<W> md, uint32_t m, uint32_t smask, uint32_t chained) {
     ACX_VGPR_PAD_W(W, "v71", "v103");
     const GreedyDev<W>& g = md.g;
     MegaScalars* sc = md.sc;
+    if (chained) {
+        if (!sc->b_active) return;
+        m = sc->b_m;
+        uint32_t slots = 1024;
+        while (slots < 2u * m) slots <<= 1;
+        smask = slots - 1;
+    }
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     const uint32_t base = sc->base;
@@ -219,10 +254,15 @@ template <typename W> __global__ void __launch_bounds__(256) k_gm_expand(MegaDev
     md.info[t] = 1u | (known ? 2u : 0u) | (hs << 4);
 }
 
-template <typename W> __global__ void __launch_bounds__(kMegaTile) k_gm_mark(MegaDev<W> md, uint32_t m) {
+template <typename W> __global__ void __launch_bounds__(kMegaTile) k_gm_mark(MegaDev<W> md, uint32_t m, uint32_t chained) {
     ACX_VGPR_PAD("v23");
     __shared__ uint32_t s_cnt;
     MegaScalars* sc = md.sc;
+    if (chained) {
+        if (!sc->b_active) return;
+        m = sc->b_m;
+        if (blockIdx.x * kMegaTile >= m) return;  // (a full-size grid over a short batch)
+    }
     const uint32_t t = blockIdx.x * kMegaTile + threadIdx.x, lane = threadIdx.x & 63u;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
@@ -244,12 +284,17 @@ template <typename W> __global__ void __launch_bounds__(kMegaTile) k_gm_mark(Meg
 }
 
 // one workgroup: prefix of the tile counts, the winner that reaches the budget, the decision of greedy.py:71-119 for this batch
-template <typename W> __global__ void __launch_bounds__(256) k_gm_decide(MegaDev<W> md, uint32_t np, uint32_t m) {
+template <typename W> __global__ void __launch_bounds__(256) k_gm_decide(MegaDev<W> md, uint32_t np, uint32_t m, uint32_t chained) {
     ACX_VGPR_PAD("v31");
     __shared__ uint32_t s_x[256];
     __shared__ uint32_t s_lo, s_tile, s_tile_base;
     const GreedyDev<W>& g = md.g;
     MegaScalars* sc = md.sc;
+    if (chained) {
+        if (!sc->b_active) return;
+        np = sc->b_np;
+        m = sc->b_m;
+    }
     const uint32_t tid = threadIdx.x;
     const uint32_t tiles = (m + kMegaTile - 1) / kMegaTile;
     const uint32_t mine = tid < tiles ? sc->tcnt[tid] : 0u;
@@ -338,7 +383,7 @@ template <typename W> __global__ void __launch_bounds__(256) k_gm_decide(MegaDev
     }
 }
 
-template <typename W> __global__ void __launch_bounds__(kMegaTile) k_gm_commit(MegaDev<W> md, uint32_t m) {
+template <typename W> __global__ void __launch_bounds__(kMegaTile) k_gm_commit(MegaDev<W> md, uint32_t m, uint32_t chained) {
     ACX_VGPR_PAD_W(W, "v31", "v39");
     __shared__ uint32_t s_w[kMegaTile / 64];
     __shared__ uint32_t s_l[132], s_lb[132];
@@ -346,6 +391,11 @@ template <typename W> __global__ void __launch_bounds__(kMegaTile) k_gm_commit(M
     const GreedyDev<W>& g = md.g;
     const SearchDev<W>& d = g.d;
     MegaScalars* sc = md.sc;
+    if (chained) {
+        if (!sc->b_active) return;
+        m = sc->b_m;
+        if (blockIdx.x * kMegaTile >= m) return;
+    }
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t t = blockIdx.x * kMegaTile + tid;
     const uint32_t cutoff = sc->cutoff, p_end = sc->p_end, nodes = sc->nodes0, base = sc->base;
@@ -408,13 +458,17 @@ template <typename W> __global__ void __launch_bounds__(kMegaTile) k_gm_commit(M
 }
 
 // one workgroup: what the persistent kernel does between "commit" and the next batch (filing, tail)
-template <typename W> __global__ void __launch_bounds__(256) k_gm_file(MegaDev<W> md, uint32_t np) {
+template <typename W> __global__ void __launch_bounds__(256) k_gm_file(MegaDev<W> md, uint32_t np, uint32_t chained) {
     ACX_VGPR_PAD("v31");
     __shared__ uint32_t s_job[132 * 3];
     __shared__ uint32_t s_lc[132], s_hint[132];
     __shared__ uint32_t s_njobs, s_top, s_status, s_reason;
     const GreedyDev<W>& g = md.g;
     MegaScalars* sc = md.sc;
+    if (chained) {
+        if (!sc->b_active) return;
+        np = sc->b_np;
+    }
     GreedyState* ps = g.state;
     const uint32_t tid = threadIdx.x, nlen = g.nlen;
     if (tid < 132) {
@@ -518,6 +572,11 @@ template <typename W> __global__ void __launch_bounds__(256) k_gm_file(MegaDev<W
         }
         ps->status = status;
         sc->status = status;
+        if (chained) {  // another mega-batch of this bucket (what the frontier kernel reads as GREEDY_MEGA_MORE), or the bucket is done with
+            const bool more = status == GREEDY_RUNNING && !sc->cut && sc->remaining != 0;
+            sc->h_live = more ? sc->remaining : 0u;
+            if (!more) sc->h_pending = 0;
+        }
     }
     __syncthreads();
     if (tid < 132) {
@@ -526,9 +585,13 @@ template <typename W> __global__ void __launch_bounds__(256) k_gm_file(MegaDev<W
     }
 }
 
-template <typename W> __global__ void __launch_bounds__(256) k_gm_push(MegaDev<W> md, uint32_t m) {
+template <typename W> __global__ void __launch_bounds__(256) k_gm_push(MegaDev<W> md, uint32_t m, uint32_t chained) {
     ACX_VGPR_PAD("v23");
     const MegaScalars* sc = md.sc;
+    if (chained) {
+        if (!sc->b_active) return;
+        m = sc->b_m;
+    }
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m || sc->is_solved || sc->status == GREEDY_FALLBACK) return;
     const uint32_t id = md.idv[t];

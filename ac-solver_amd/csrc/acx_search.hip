@@ -340,6 +340,7 @@ template <typename W> struct GreedySearch {
         g.hand_min = 0;
         g.state = nullptr;
         g.mega_status = nullptr;
+        g.hand_ctl = nullptr;
         const uint64_t arena_entries = std::min<uint64_t>(8ull * (uint64_t)std::max<int64_t>(max_nodes, 1) + (1ull << 20), 1ull << 31);
         g.arena_cap = (uint32_t)arena_entries;
         if (nkeys.alloc(S.cap_nodes * sizeof(NodeKey<W>)) || tab.alloc(S.n_slots * 8)) return ACX_E_NOMEM;
@@ -445,6 +446,7 @@ static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_no
         g.hand_min = 0;
         g.state = nullptr;
         g.mega_status = nullptr;
+        g.hand_ctl = nullptr;
         g.root_k0 = keyops<W>::make(root.w0, root.n0);
         g.root_k1 = keyops<W>::make(root.w1, root.n1);
     }
@@ -908,7 +910,8 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
     if (outb.alloc(sizeof(GreedyOut))) return ACX_E_NOMEM;
     ACX_HIP_TRY(hipMemsetAsync(outb.p, 0, sizeof(GreedyOut), st));
     // big buckets go to the whole-GPU kernels of acx_greedy_mega.h (0: the persistent workgroup does everything)
-    uint32_t hand_min = 1024;
+    // (chained hand-offs cost ~95 us a cycle instead of ~120: buckets from 512 parents pay; measured 256 .. 1024: 179.9 / 177.8 / 177.3 / 177.5 / 179.8 ms)
+    uint32_t hand_min = getenv("ACX_GREEDY_NO_CHAIN") ? 1024 : 512;
     if (const char* hm = getenv("ACX_GREEDY_HAND_MIN")) hand_min = (uint32_t)strtoul(hm, nullptr, 10);
     DevBuf stateb, mck0, mck1, mclen, minfo, midv, mposv, mtab, mscal;
     MegaDev<W> md;
@@ -921,6 +924,7 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
         ACX_HIP_TRY(hipMemsetAsync(stateb.p, 0, sizeof(GreedyState), st));
         ACX_HIP_TRY(hipMemsetAsync(mscal.p, 0, sizeof(MegaScalars), st));  // (status RUNNING, cut 0, remaining 0: nothing handed off yet)
         g.hand_min = hand_min;
+        g.hand_ctl = nullptr;
         g.state = (GreedyState*)stateb.p;
         g.mega_status = (const uint32_t*)((const uint8_t*)mscal.p + offsetof(MegaScalars, status));
         md.ck0 = (W*)mck0.p;
@@ -935,7 +939,14 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
         g.hand_min = 0;
         g.state = nullptr;
         g.mega_status = nullptr;
+        g.hand_ctl = nullptr;
     }
+    // chained (round 4): frontier kernel -> sort -> mega-batch -> frontier kernel ... enqueued back to back with fixed grids; every kernel
+    // finds in MegaScalars whether and on what it has to work, the host reads the frontier kernel's status word two cycles late.
+    // ACX_GREEDY_NO_CHAIN=1: round 3's form, one synchronisation per hand-off (A/B runs)
+    const bool chain = hand_min && !getenv("ACX_GREEDY_NO_CHAIN");
+    if (chain) g.hand_ctl = (uint32_t*)((uint8_t*)mscal.p + offsetof(MegaScalars, h_pending));
+    static_assert(offsetof(MegaScalars, h_live) == offsetof(MegaScalars, h_pending) + 4 && offsetof(MegaScalars, h_sort) == offsetof(MegaScalars, h_pending) + 8, "pending, live, sort are written as three consecutive words");
     static_assert(offsetof(MegaScalars, cut) == offsetof(MegaScalars, status) + 4 && offsetof(MegaScalars, remaining) == offsetof(MegaScalars, status) + 8, "status, cut, remaining are read as three consecutive words");
     md.g = g;
     EventPair evs;
@@ -946,6 +957,33 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
     unsigned long long handoffs = 0;
     launch_greedy_persistent<W>(g, (GreedyOut*)outb.p, st);
     ACX_HIP_TRY(hipGetLastError());
+    if (chain) {
+        uint32_t* hst = (uint32_t*)S.h_pin;  // pinned: the frontier kernel's status word after every cycle, kRunAheadSlots entries
+        for (uint64_t k = 0;; k++) {
+            hipLaunchKernelGGL(k_gm_runsort<W>, dim3(32), dim3(kGT), 0, st, md, 0u, 1u);
+            hipLaunchKernelGGL(k_gm_merge<W>, dim3(128), dim3(256), 0, st, md, 0u, 1u);
+            hipLaunchKernelGGL(k_gm_begin<W>, dim3(kMegaSlots / 1024), dim3(256), 0, st, md, 0u, 1u);
+            hipLaunchKernelGGL(k_gm_expand<W>, dim3(kMegaTags / 256), dim3(256), 0, st, md, 0u, 0u, 1u);
+            hipLaunchKernelGGL(k_gm_mark<W>, dim3(kMegaTiles), dim3(kMegaTile), 0, st, md, 0u, 1u);
+            hipLaunchKernelGGL(k_gm_decide<W>, dim3(1), dim3(256), 0, st, md, 0u, 0u, 1u);
+            hipLaunchKernelGGL(k_gm_commit<W>, dim3(kMegaTiles), dim3(kMegaTile), 0, st, md, 0u, 1u);
+            hipLaunchKernelGGL(k_gm_file<W>, dim3(1), dim3(256), 0, st, md, 0u, 1u);
+            hipLaunchKernelGGL(k_gm_push<W>, dim3(kMegaTags / 256), dim3(256), 0, st, md, 0u, 1u);
+            launch_greedy_persistent<W>(g, (GreedyOut*)outb.p, st);
+            ACX_HIP_TRY(hipGetLastError());
+            handoffs++;
+            const int slot = (int)(k % kRunAheadSlots);
+            ACX_HIP_TRY(hipEventRecord(S.ev_batch[slot], st));
+            ACX_HIP_TRY(hipStreamWaitEvent(S.st_copy, S.ev_batch[slot], 0));
+            ACX_HIP_TRY(hipMemcpyAsync(&hst[slot], (const uint8_t*)outb.p + offsetof(GreedyOut, status), 4, hipMemcpyDeviceToHost, S.st_copy));
+            ACX_HIP_TRY(hipEventRecord(S.ev_cursor[slot], S.st_copy));
+            if (k >= kRunAheadLag) {
+                const int old = (int)((k - kRunAheadLag) % kRunAheadSlots);
+                ACX_HIP_TRY(hipEventSynchronize(S.ev_cursor[old]));
+                if (hst[old] != GREEDY_HANDOFF && hst[old] != GREEDY_MEGA_MORE) break;  // (the cycles enqueued behind it found nothing to do)
+            }
+        }
+    }
     ACX_HIP_TRY(hipMemcpyAsync(&o, outb.p, sizeof(o), hipMemcpyDeviceToHost, st));
     ACX_HIP_TRY(hipStreamSynchronize(st));
     while (o.status == GREEDY_HANDOFF) {
@@ -954,20 +992,20 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
         uint32_t live = o.hand_live;
         if (o.hand_sort) {
             const uint32_t n = live, SC = kMegaRun;
-            hipLaunchKernelGGL(k_gm_runsort<W>, dim3((n + SC - 1) / SC), dim3(kGT), 0, st, md, n);
-            hipLaunchKernelGGL(k_gm_merge<W>, dim3((n + 255) / 256), dim3(256), 0, st, md, n);
+            hipLaunchKernelGGL(k_gm_runsort<W>, dim3((n + SC - 1) / SC), dim3(kGT), 0, st, md, n, 0u);
+            hipLaunchKernelGGL(k_gm_merge<W>, dim3((n + 255) / 256), dim3(256), 0, st, md, n, 0u);
         }
         for (;;) {
             const uint32_t np = std::min<uint32_t>(live, kMegaParents), m = 12u * np;
             uint32_t slots = 1024;
             while (slots < 2 * m) slots <<= 1;
-            hipLaunchKernelGGL(k_gm_begin<W>, dim3(std::max<uint32_t>(1, slots / 1024)), dim3(256), 0, st, md, slots);
-            hipLaunchKernelGGL(k_gm_expand<W>, dim3((m + 255) / 256), dim3(256), 0, st, md, m, slots - 1);
-            hipLaunchKernelGGL(k_gm_mark<W>, dim3((m + kMegaTile - 1) / kMegaTile), dim3(kMegaTile), 0, st, md, m);
-            hipLaunchKernelGGL(k_gm_decide<W>, dim3(1), dim3(256), 0, st, md, np, m);
-            hipLaunchKernelGGL(k_gm_commit<W>, dim3((m + kMegaTile - 1) / kMegaTile), dim3(kMegaTile), 0, st, md, m);
-            hipLaunchKernelGGL(k_gm_file<W>, dim3(1), dim3(256), 0, st, md, np);
-            hipLaunchKernelGGL(k_gm_push<W>, dim3((m + 255) / 256), dim3(256), 0, st, md, m);
+            hipLaunchKernelGGL(k_gm_begin<W>, dim3(std::max<uint32_t>(1, slots / 1024)), dim3(256), 0, st, md, slots, 0u);
+            hipLaunchKernelGGL(k_gm_expand<W>, dim3((m + 255) / 256), dim3(256), 0, st, md, m, slots - 1, 0u);
+            hipLaunchKernelGGL(k_gm_mark<W>, dim3((m + kMegaTile - 1) / kMegaTile), dim3(kMegaTile), 0, st, md, m, 0u);
+            hipLaunchKernelGGL(k_gm_decide<W>, dim3(1), dim3(256), 0, st, md, np, m, 0u);
+            hipLaunchKernelGGL(k_gm_commit<W>, dim3((m + kMegaTile - 1) / kMegaTile), dim3(kMegaTile), 0, st, md, m, 0u);
+            hipLaunchKernelGGL(k_gm_file<W>, dim3(1), dim3(256), 0, st, md, np, 0u);
+            hipLaunchKernelGGL(k_gm_push<W>, dim3((m + 255) / 256), dim3(256), 0, st, md, m, 0u);
             uint32_t res[3];  // status, cut, remaining (consecutive in MegaScalars)
             ACX_HIP_TRY(hipMemcpyAsync(res, (const uint8_t*)mscal.p + offsetof(MegaScalars, status), sizeof(res), hipMemcpyDeviceToHost, st));
             // the frontier kernel again, behind the batch and WITHOUT waiting for its outcome: most buckets take one mega-batch,
