@@ -88,6 +88,7 @@ template <typename W> struct GreedyDev {
     const uint32_t* mega_status;  // nullable: {status, cut, remaining} of the whole-GPU kernels (acx_greedy_mega.h: MegaScalars).  The host
                                   // relaunches this kernel behind every mega-batch WITHOUT waiting for the batch's outcome (one
                                   // synchronisation per hand-off instead of two); when the bucket is not finished the launch is a no-op
+    uint32_t rank_max;   // chained mode: a handed-off bucket of more entries is ordered by the frontier kernel itself first (kMegaRankMax)
     uint32_t* hand_ctl;  // nullable: {pending, queued parents, 1 = unsorted tail} of MegaScalars -- chained mode (acx_greedy_mega.h): the hand-off
                          // is read by the whole-GPU kernels the host has ALREADY enqueued behind this one, not by the host
 };
@@ -104,6 +105,10 @@ struct GreedyOut {
     uint32_t hist_np[16];    // batches by log2(parents)
     unsigned long long t_phase[24];  // [12..15] inside commit: stores + ballots, per-length positions, seen + CAS issue, barrier; [16..23] the phases 0..7 over the batches of <= 21 parents only; [8] global probe rounds (cycles), [9] probe rounds of wave 0 (count)  // shader-clock cycles per phase (thread 0): select, sort, expand, probe, scan+decide, commit, file, tail
 };
+
+// Handed-off buckets of at most this many entries are ordered by the whole-GPU counting sort of acx_greedy_mega.h (k_gm_rank); in
+// chained mode a larger one is ordered by the frontier kernel itself (its bitonic network through HBM) BEFORE it is handed off.
+constexpr uint32_t kMegaRankMax = 16384;  // GreedyDev::rank_max unless ACX_MEGA_RANK_MAX says otherwise (tests: a small value sends AK(3) through the own-sort path)
 
 template <typename W> struct greedy_cfg;
 // k_greedy_multi (one search per workgroup, many searches per launch): lanes and candidates per batch.  Measured on the 1190
@@ -424,7 +429,9 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
             __syncthreads();
 #endif
             ACX_TICK(0);
-            if (g.hand_min && n >= g.hand_min) {
+            const bool hand = g.hand_min && n >= g.hand_min;  // (uniform)
+            const bool own_sort = hand && g.hand_ctl && n > g.rank_max && s_rec.sorted_end < s_rec.cnt;  // chained: too large for the counting sort
+            if (hand && !own_sort) {
                 // a big bucket: park the frontier; the host runs this bucket on the whole GPU and relaunches this kernel
                 // (every bucket record goes back to HBM: the selected one is there already, the cached depth follows)
                 if (tid < nlen && s_fdepth != 0xFFFFFFFFu) g.bk[(size_t)tid * kDepthCap + s_fdepth] = s_frec[tid];
@@ -603,6 +610,15 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
             }
 #endif
             ACX_TICK(1);
+            if (own_sort) {  // ordered here: now it goes to the whole-GPU kernels (its record, with the new sorted_end, back to HBM first)
+                if (tid < nlen && s_fdepth != 0xFFFFFFFFu) g.bk[(size_t)tid * kDepthCap + s_fdepth] = s_frec[tid];
+                if (tid == 0) {
+                    g.bk[(size_t)s_cur_len * kDepthCap + s_cur_depth] = s_rec;
+                    s_status = GREEDY_HANDOFF;
+                }
+                __syncthreads();
+                break;
+            }
         }
 
         // ================================================================= one batch =====================

@@ -54,6 +54,7 @@ template <typename W> struct MegaDev {
     uint32_t* idv;   // [kMegaTags] node id of a committed winner (kNone otherwise)
     uint32_t* posv;  // [kMegaTags] its position among this batch's new nodes of the same total length
     uint32_t* mtab;  // [kMegaSlots] minimum tag per key
+    uint32_t* rank;  // [g.rank_max] k_gm_rank: entries of the bucket that precede entry i (zero between sorts)
     MegaScalars* sc;
 };
 
@@ -61,6 +62,54 @@ template <typename W> struct MegaDev {
 // Runs of kMegaRun entries are sorted in LDS, one workgroup each (the bitonic network of acx_greedy.h); the final position of
 // an entry is its index in its own run plus, for every other run, the number of that run's keys that precede it (a binary
 // search: the keys of a bucket are pairwise distinct).
+// Buckets of at most kMegaRankMax entries (round 4) are ordered by COUNTING instead: the keys of a bucket are pairwise distinct, so the
+// final position of an entry is the number of entries that precede it.  k_gm_rank spreads the n x n comparisons over the whole chip --
+// a work item is 256 entries against a tile of 128, an LDS broadcast per comparison -- and k_gm_begin, the first kernel of the
+// mega-batch behind it, writes the ids to their places: ~15 us for the average handed-off bucket (3 200 entries) where the sorted runs + rank merge took 41 + 15 us with three or
+// four workgroups busy.  The work grows with n^2: beyond kMegaRankMax entries the runs are cheaper again.
+constexpr uint32_t kRankTile = 128;
+template <typename W> __global__ void __launch_bounds__(256) k_gm_rank(MegaDev<W> md, uint32_t n, uint32_t chained) {
+    __shared__ W sj0[kRankTile];
+    __shared__ W sj1[kRankTile];
+    ACX_VGPR_PAD_W(W, "v47", "v63");
+    const GreedyDev<W>& g = md.g;
+    if (chained) {
+        if (!md.sc->h_pending || !md.sc->h_sort) return;
+        n = md.sc->h_live;
+    }
+    if (n > g.rank_max) return;
+    const GreedyState* ps = g.state;
+    const BucketRec r = g.bk[(size_t)ps->cur_len * kDepthCap + ps->cur_depth];
+    const uint32_t base = r.off + r.head, tid = threadIdx.x;
+    const uint32_t eb = (n + 255u) / 256u, jt_n = (n + kRankTile - 1u) / kRankTile;
+    for (uint32_t w = blockIdx.x; w < eb * jt_n; w += gridDim.x) {
+        const uint32_t ei = w / jt_n, jt = w - ei * jt_n;
+        const uint32_t i = ei * 256u + tid, j = jt * kRankTile + tid;
+        uint32_t id = 0;
+        W m0 = 0, m1 = 0;
+        if (i < n) {
+            id = g.arena[base + i];
+            const NodeKey<W> nk = g.nkeys[id];
+            m0 = nk.k0;
+            m1 = nk.k1;
+        }
+        if (tid < kRankTile && j < n) {
+            const NodeKey<W> nk = g.nkeys[g.arena[base + j]];
+            sj0[tid] = nk.k0;
+            sj1[tid] = nk.k1;
+        }
+        __syncthreads();
+        if (i < n) {
+            const uint32_t jn = min(kRankTile, n - jt * kRankTile);
+            uint32_t c = 0;
+            for (uint32_t q = 0; q < jn; q++) c += key_less<W>(sj0[q], sj1[q], m0, m1) ? 1u : 0u;
+            if (c) atomicAdd(&md.rank[i], c);
+            if (jt == 0) g.gid[i] = id;
+        }
+        __syncthreads();
+    }
+}
+
 constexpr uint32_t kMegaRun = 1024;  // short runs: the bitonic network's depth grows with log^2 of the run, the merge only with the number of runs
 template <typename W> __global__ void __launch_bounds__(kGT) k_gm_runsort(MegaDev<W> md, uint32_t n, uint32_t chained) {
     constexpr uint32_t SC = kMegaRun;
@@ -134,20 +183,39 @@ template <typename W> __global__ void __launch_bounds__(256) k_gm_merge(MegaDev<
 }
 
 // ---- one mega-batch -----------------------------------------------------------------------------------------------------------
-template <typename W> __global__ void __launch_bounds__(256) k_gm_begin(MegaDev<W> md, uint32_t slots, uint32_t chained) {
+// `sort_n`: the bucket has just been counted by k_gm_rank (sort_n entries; 0: no): the ids go to their places first
+template <typename W> __global__ void __launch_bounds__(256) k_gm_begin(MegaDev<W> md, uint32_t slots, uint32_t sort_n, uint32_t chained) {
     ACX_VGPR_PAD("v23");
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (chained) {  // the batch is what the frontier kernel handed off / what the last batch left of it; nothing pending: every kernel of the batch returns
-        const uint32_t pending = md.sc->h_pending, np = min(md.sc->h_live, kMegaParents);
+        const uint32_t pending = md.sc->h_pending, live = md.sc->h_live, np = min(live, kMegaParents);
+        sort_n = pending && md.sc->h_sort ? live : 0u;  // (k_gm_file clears h_sort: only the first batch of a hand-off finds it set)
         if (i == 0) {
             md.sc->b_active = pending && np ? 1u : 0u;
             md.sc->b_np = np;
             md.sc->b_m = 12u * np;
-            md.sc->h_sort = 0;  // (the sort kernels in front of this batch have run)
         }
         if (!pending || !np) return;
         slots = 1024;
         while (slots < 24u * np) slots <<= 1;
+    }
+    if (sort_n) {
+        const GreedyDev<W>& g = md.g;
+        GreedyState* ps = g.state;
+        BucketRec* rp = g.bk + (size_t)ps->cur_len * kDepthCap + ps->cur_depth;
+        const BucketRec r = *rp;
+        for (uint32_t k = i; k < sort_n; k += gridDim.x * blockDim.x) {
+            const uint32_t rk = md.rank[k];
+            md.rank[k] = 0;  // (zero again for the next bucket)
+            g.arena[r.off + r.head + rk] = g.gid[k];
+        }
+        if (i == 0) {
+            rp->sorted_end = r.cnt;
+            ps->sorts++;
+            if (sort_n > greedy_cfg<W>::kSortCap) ps->big_sorts++;
+            ps->hist[min(15, 31 - __builtin_clz(sort_n))]++;
+            if (sort_n > ps->max_bucket) ps->max_bucket = sort_n;
+        }
     }
     for (uint32_t k = i; k < slots; k += gridDim.x * blockDim.x) md.mtab[k] = kNone;
     MegaScalars* sc = md.sc;
@@ -575,6 +643,7 @@ template <typename W> __global__ void __launch_bounds__(256) k_gm_file(MegaDev<W
         if (chained) {  // another mega-batch of this bucket (what the frontier kernel reads as GREEDY_MEGA_MORE), or the bucket is done with
             const bool more = status == GREEDY_RUNNING && !sc->cut && sc->remaining != 0;
             sc->h_live = more ? sc->remaining : 0u;
+            sc->h_sort = 0;
             if (!more) sc->h_pending = 0;
         }
     }

@@ -341,6 +341,7 @@ template <typename W> struct GreedySearch {
         g.state = nullptr;
         g.mega_status = nullptr;
         g.hand_ctl = nullptr;
+        g.rank_max = 0;
         const uint64_t arena_entries = std::min<uint64_t>(8ull * (uint64_t)std::max<int64_t>(max_nodes, 1) + (1ull << 20), 1ull << 31);
         g.arena_cap = (uint32_t)arena_entries;
         if (nkeys.alloc(S.cap_nodes * sizeof(NodeKey<W>)) || tab.alloc(S.n_slots * 8)) return ACX_E_NOMEM;
@@ -447,6 +448,7 @@ static int run_greedy_group(const int8_t* rows, int64_t n, int L, int64_t max_no
         g.state = nullptr;
         g.mega_status = nullptr;
         g.hand_ctl = nullptr;
+        g.rank_max = 0;
         g.root_k0 = keyops<W>::make(root.w0, root.n0);
         g.root_k1 = keyops<W>::make(root.w1, root.n1);
     }
@@ -913,18 +915,22 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
     // (chained hand-offs cost ~95 us a cycle instead of ~120: buckets from 512 parents pay; measured 256 .. 1024: 179.9 / 177.8 / 177.3 / 177.5 / 179.8 ms)
     uint32_t hand_min = getenv("ACX_GREEDY_NO_CHAIN") ? 1024 : 512;
     if (const char* hm = getenv("ACX_GREEDY_HAND_MIN")) hand_min = (uint32_t)strtoul(hm, nullptr, 10);
-    DevBuf stateb, mck0, mck1, mclen, minfo, midv, mposv, mtab, mscal;
+    uint32_t rank_max = kMegaRankMax;  // handed-off buckets up to this size are ordered by counting (k_gm_rank)
+    if (const char* rm = getenv("ACX_MEGA_RANK_MAX")) rank_max = std::max<uint32_t>(256, (uint32_t)strtoul(rm, nullptr, 10));
+    DevBuf stateb, mck0, mck1, mclen, minfo, midv, mposv, mtab, mscal, mrank;
     MegaDev<W> md;
     GreedyState hstate;
     if (hand_min) {
         if (stateb.alloc(sizeof(GreedyState)) || mck0.alloc((size_t)kMegaTags * sizeof(W)) || mck1.alloc((size_t)kMegaTags * sizeof(W)) || mclen.alloc(kMegaTags) ||
             minfo.alloc((size_t)kMegaTags * 4) || midv.alloc((size_t)kMegaTags * 4) || mposv.alloc((size_t)kMegaTags * 4) || mtab.alloc((size_t)kMegaSlots * 4) ||
-            mscal.alloc(sizeof(MegaScalars)))
+            mscal.alloc(sizeof(MegaScalars)) || mrank.alloc((size_t)rank_max * 4))
             return ACX_E_NOMEM;
+        ACX_HIP_TRY(hipMemsetAsync(mrank.p, 0, (size_t)rank_max * 4, st));
         ACX_HIP_TRY(hipMemsetAsync(stateb.p, 0, sizeof(GreedyState), st));
         ACX_HIP_TRY(hipMemsetAsync(mscal.p, 0, sizeof(MegaScalars), st));  // (status RUNNING, cut 0, remaining 0: nothing handed off yet)
         g.hand_min = hand_min;
         g.hand_ctl = nullptr;
+        g.rank_max = rank_max;
         g.state = (GreedyState*)stateb.p;
         g.mega_status = (const uint32_t*)((const uint8_t*)mscal.p + offsetof(MegaScalars, status));
         md.ck0 = (W*)mck0.p;
@@ -934,12 +940,14 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
         md.idv = (uint32_t*)midv.p;
         md.posv = (uint32_t*)mposv.p;
         md.mtab = (uint32_t*)mtab.p;
+        md.rank = (uint32_t*)mrank.p;
         md.sc = (MegaScalars*)mscal.p;
     } else {
         g.hand_min = 0;
         g.state = nullptr;
         g.mega_status = nullptr;
         g.hand_ctl = nullptr;
+        g.rank_max = 0;
     }
     // chained (round 4): frontier kernel -> sort -> mega-batch -> frontier kernel ... enqueued back to back with fixed grids; every kernel
     // finds in MegaScalars whether and on what it has to work, the host reads the frontier kernel's status word two cycles late.
@@ -960,9 +968,8 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
     if (chain) {
         uint32_t* hst = (uint32_t*)S.h_pin;  // pinned: the frontier kernel's status word after every cycle, kRunAheadSlots entries
         for (uint64_t k = 0;; k++) {
-            hipLaunchKernelGGL(k_gm_runsort<W>, dim3(32), dim3(kGT), 0, st, md, 0u, 1u);
-            hipLaunchKernelGGL(k_gm_merge<W>, dim3(128), dim3(256), 0, st, md, 0u, 1u);
-            hipLaunchKernelGGL(k_gm_begin<W>, dim3(kMegaSlots / 1024), dim3(256), 0, st, md, 0u, 1u);
+            hipLaunchKernelGGL(k_gm_rank<W>, dim3(1024), dim3(256), 0, st, md, 0u, 1u);
+            hipLaunchKernelGGL(k_gm_begin<W>, dim3(kMegaSlots / 1024), dim3(256), 0, st, md, 0u, 0u, 1u);
             hipLaunchKernelGGL(k_gm_expand<W>, dim3(kMegaTags / 256), dim3(256), 0, st, md, 0u, 0u, 1u);
             hipLaunchKernelGGL(k_gm_mark<W>, dim3(kMegaTiles), dim3(kMegaTile), 0, st, md, 0u, 1u);
             hipLaunchKernelGGL(k_gm_decide<W>, dim3(1), dim3(256), 0, st, md, 0u, 0u, 1u);
@@ -989,17 +996,23 @@ static int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int 
     while (o.status == GREEDY_HANDOFF) {
         handoffs++;
         // ---- the selected bucket on the whole GPU: order it, then mega-batches until it is used up, cut, or the search ends ----
-        uint32_t live = o.hand_live;
+        uint32_t live = o.hand_live, counted = 0;  // counted: k_gm_rank has run, the first k_gm_begin places the ids
         if (o.hand_sort) {
             const uint32_t n = live, SC = kMegaRun;
-            hipLaunchKernelGGL(k_gm_runsort<W>, dim3((n + SC - 1) / SC), dim3(kGT), 0, st, md, n, 0u);
-            hipLaunchKernelGGL(k_gm_merge<W>, dim3((n + 255) / 256), dim3(256), 0, st, md, n, 0u);
+            if (n <= rank_max) {
+                hipLaunchKernelGGL(k_gm_rank<W>, dim3(std::min<uint32_t>(1024, ((n + 255) / 256) * ((n + kRankTile - 1) / kRankTile))), dim3(256), 0, st, md, n, 0u);
+                counted = n;
+            } else {
+                hipLaunchKernelGGL(k_gm_runsort<W>, dim3((n + SC - 1) / SC), dim3(kGT), 0, st, md, n, 0u);
+                hipLaunchKernelGGL(k_gm_merge<W>, dim3((n + 255) / 256), dim3(256), 0, st, md, n, 0u);
+            }
         }
         for (;;) {
             const uint32_t np = std::min<uint32_t>(live, kMegaParents), m = 12u * np;
             uint32_t slots = 1024;
             while (slots < 2 * m) slots <<= 1;
-            hipLaunchKernelGGL(k_gm_begin<W>, dim3(std::max<uint32_t>(1, slots / 1024)), dim3(256), 0, st, md, slots, 0u);
+            hipLaunchKernelGGL(k_gm_begin<W>, dim3(std::max<uint32_t>(1, slots / 1024)), dim3(256), 0, st, md, slots, counted, 0u);
+            counted = 0;
             hipLaunchKernelGGL(k_gm_expand<W>, dim3((m + 255) / 256), dim3(256), 0, st, md, m, slots - 1, 0u);
             hipLaunchKernelGGL(k_gm_mark<W>, dim3((m + kMegaTile - 1) / kMegaTile), dim3(kMegaTile), 0, st, md, m, 0u);
             hipLaunchKernelGGL(k_gm_decide<W>, dim3(1), dim3(256), 0, st, md, np, m, 0u);

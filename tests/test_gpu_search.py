@@ -236,6 +236,32 @@ def test_greedy_buckets_larger_than_one_whole_gpu_batch(search):
         assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (budget, cyc, st, wst)
 
 
+@pytest.mark.parametrize("env", [{}, {"ACX_GREEDY_NO_CHAIN": "1"}, {"ACX_MEGA_RANK_MAX": "256"}, {"ACX_MEGA_RANK_MAX": "256", "ACX_GREEDY_HAND_MIN": "64"},
+                                 {"ACX_GREEDY_NO_CHAIN": "1", "ACX_MEGA_RANK_MAX": "700"}])
+def test_greedy_hand_off_protocols_agree_with_the_oracle(search, monkeypatch, env):
+    """The hand-off cycle of a single greedy_search: chained on the stream (default: every kernel reads its work from device scalars,
+    the host looks two cycles late) or with one synchronisation per hand-off (ACX_GREEDY_NO_CHAIN); the handed-off bucket ordered by the
+    whole-GPU counting sort, by sorted runs + rank merge (unchained, above ACX_MEGA_RANK_MAX) or by the frontier kernel itself before
+    the hand-off (chained, above ACX_MEGA_RANK_MAX).  AK(3), 64- and 128-bit keys: result, path and counts as the oracle's."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search
+    from oracle import ac_oracle as O
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ak3 = np.zeros(50, np.int8)
+    ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+    ak3[25:31] = [1, 2, 1, -2, -1, -2]
+    wide = np.zeros(72, np.int8)
+    wide[:7] = ak3[:7]
+    wide[36:42] = ak3[25:31]
+    for pres, budget, cyc in ((ak3, 10**6, False), (ak3, 3 * 10**5, True), (wide, 3 * 10**5, False)):
+        ok, path, st = run_search(_acx.SEARCH_GREEDY, pres, budget, cyc)
+        wok, wpath, wst = O.greedy_search(pres, budget, cyclically_reduce_after_moves=cyc, stats=True)
+        assert (ok, path) == (wok, wpath), (env, budget, cyc)
+        assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (env, budget, cyc, st, wst)
+
+
 def test_greedy_paths_file_sample(search, golden_json):
     """data/greedy_search_paths.txt (budget 1e6): a sample through the device frontier at native L (up to 36 -> 128-bit keys)"""
     pool = ms_pool_generator_order(golden_json("ms_pool.json"))
