@@ -354,7 +354,7 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
             out[name] = {"nodes_per_s": s1["nodes"] / dt1, "nodes": s1["nodes"], "seconds": dt1, "device_seconds": s1["seconds"],
                          "first_call_seconds": first, "batches": s1["levels"], "entry": "acx_search",
                          "roofline": search_roofline(s1, "k_bfs_expand_insert<u64> (expand + visited-table dedup, one launch per batch)"
-                                                     if kind == _acx.SEARCH_BFS else "k_greedy_persistent<u64> (one workgroup)",
+                                                     if kind == _acx.SEARCH_BFS else "k_greedy_persistent<u64> (one workgroup) + the whole-GPU k_gm_* cycle for buckets of >= 512 parents, chained on the stream",
                                                      "bfs_ak3_1e8" if kind == _acx.SEARCH_BFS else "greedy_ak3_1e7")}
     if use_dist:
         # LAST (everything above is already recorded should this stage hang): the mask all-reduce on a communicator of its own.
