@@ -8,6 +8,7 @@ policy samples on the GPU, and the host only sees the indices of environments th
 With torch.distributed initialised (one process per GPU) gradients are averaged over the ranks (data parallel).
 """
 import math
+import os
 import random
 import uuid
 from collections import deque
@@ -314,6 +315,39 @@ class _Phases:
             print("[ppo phases] per update: " + ", ".join(f"{k} {v / updates * 1e3:.1f} ms" for k, v in self.acc.items()) + f"; sum {tot / updates * 1e3:.1f} ms")
 
 
+class _StatsStream:
+    """refresh_behaviour_stats WHILE the rollout runs: the f32 forward over rollout rows t0 .. t1 - 1 is enqueued on a second stream as
+    soon as those rows are final (behind an event of the rollout's stream), so the ~23 ms of GEMMs per update at BASELINE config 5's
+    shape fill the GPU time the rollout leaves idle -- its own kernels are 5 ms, the rest of its ~20 ms is the host's episode
+    bookkeeping.  Groups of `group` rows: fewer, fuller GEMMs and an eighth of the launches of a row at a time."""
+
+    def __init__(self, agent, device, group=4):
+        self.agent, self.group = agent, max(1, int(group))
+        self.side = torch.cuda.Stream(device) if device.type == "cuda" else None
+        self.t0 = 0
+
+    def rows_final(self, t1, obs, actions, logprobs, values, last=False):
+        """rows self.t0 .. t1 - 1 of obs / actions are final on the current stream (and the sampling kernel has written its logprobs /
+        values for them): recompute those of a full group (or, with `last`, of what is left) in f32, in place."""
+        if t1 - self.t0 < self.group and not (last and t1 > self.t0):
+            return
+        t0, self.t0 = self.t0, t1
+        if self.side is None:
+            refresh_behaviour_stats(self.agent, obs[t0:t1], actions[t0:t1], logprobs[t0:t1], values[t0:t1])
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            refresh_behaviour_stats(self.agent, obs[t0:t1], actions[t0:t1], logprobs[t0:t1], values[t0:t1])
+
+    def join(self):
+        """the current stream waits for everything enqueued so far; the next rollout starts at row 0"""
+        self.t0 = 0
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
 def refresh_behaviour_stats(agent, obs, actions, logprobs, values):
     """logprobs[t], values[t] <- the f32 agent's log pi(actions[t] | obs[t]) and V(obs[t]) for every rollout row t (in place)."""
     T, N = actions.shape
@@ -387,6 +421,7 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
         except ImportError:  # pragma: no cover
             pass
     stats = {}
+    stats_stream = _StatsStream(agent, device, int(os.environ.get("ACX_PPO_STATS_GROUP", "4"))) if fused_on and os.environ.get("ACX_PPO_STATS_STREAM", "1") != "0" else None
     order = _MinibatchOrder(args.batch_size, args.update_epochs, device)
     ph = _Phases(device)
     n_updates_done = 0
@@ -412,6 +447,8 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             if fused is not None:
                 fused.sample(obs[step], actions[step], logprobs[step], values[step])
                 action = actions[step]
+                if stats_stream is not None:  # rows up to `step` are final: their f32 behaviour statistics start on the second stream
+                    stats_stream.rows_final(step + 1, obs, actions, logprobs, values, last=step == T - 1)
             else:
                 with torch.no_grad():
                     action, logprob, _, value = agent.get_action_and_value(obs[step])
@@ -482,8 +519,12 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             # against log-probabilities of THAT policy (training.py:283-291): so the behaviour statistics the update uses are
             # recomputed here with one f32 forward over the batch -- the ratio of the first minibatch of the first epoch is then
             # exactly 1, as in the reference.  One row of the rollout at a time keeps the temporaries at [N, 256].
+            # Since round 4 that forward runs on a second stream beside the rollout (_StatsStream); here only its tail is waited for.
             ph.lap("rollout tail")
-            refresh_behaviour_stats(agent, obs, actions, logprobs, values)
+            if stats_stream is not None:
+                stats_stream.join()
+            else:
+                refresh_behaviour_stats(agent, obs, actions, logprobs, values)
             ph.lap("behaviour stats (f32)")
         with torch.no_grad():
             next_value = agent.get_value(obs[T].float()).reshape(-1)
