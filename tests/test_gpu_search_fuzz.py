@@ -62,6 +62,47 @@ def test_random_presentations_against_oracle(L):
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("L", [6, 25, 33])
+def test_random_presentation_groups_through_search_many(L, monkeypatch):
+    """acx_search_many on groups of random presentations (roots in and out of normal form in one group, so both move codes; small
+    batches per round so that the searches of a group are many rounds apart): every search as the oracle's, for bfs (the searches
+    share their launches, acx_bfs_many.h) and greedy_search (one workgroup per search); a group with a search in which the
+    reference raises makes the call raise."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search_many
+    from oracle import ac_oracle as O
+
+    _acx.require_device()
+    rng = np.random.default_rng(500 + L + 1000 * SEED)
+    monkeypatch.setenv("ACX_BFS_MANY_BMAX", str(int(rng.choice([128, 512, 32768]))))
+    for budget, cyc in ((int(rng.choice([1, 7, 60])), False), (500, True), (4000, False), (30000, True)):
+        rows = []
+        for _ in range(40):
+            row = np.zeros(2 * L, np.int8)
+            for h in (0, 1):
+                w = _random_word(rng, int(rng.integers(1, min(L, 9) + 1)))
+                if rng.random() < 0.15 and len(w) + 2 <= L:  # not freely reduced: the general move code
+                    w = w[:1] + [1, -1] + w[1:]
+                row[h * L:h * L + len(w)] = w
+            rows.append(row)
+        for kind, ofn in ((_acx.SEARCH_BFS, O.bfs), (_acx.SEARCH_GREEDY, O.greedy_search)):
+            want, good, bad = [], [], []
+            for row in rows:
+                try:
+                    want.append(ofn(row, budget, cyclically_reduce_after_moves=cyc, stats=True))
+                    good.append(row)
+                except (AssertionError, IndexError):
+                    bad.append(row)
+            got = run_search_many(kind, np.stack(good), budget, cyc)
+            for k, ((ok, path, st), (wok, wpath, wst)) in enumerate(zip(got, want)):
+                assert (ok, path) == (wok, wpath), (L, kind, budget, cyc, good[k].tolist())
+                assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (L, kind, budget, cyc, good[k].tolist(), st, wst)
+            if bad:
+                with pytest.raises(AssertionError):
+                    run_search_many(kind, np.stack(good[:3] + bad[:1] + good[3:6]), budget, cyc)
+
+
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("world", [1, 3])
 def test_random_presentations_sharded_bfs(world):
     """the same comparison through the sharded frontier (HIP engine; thread ranks share the GPU when world > 1)"""
