@@ -64,10 +64,15 @@ template <typename W> struct MegaDev {
 // search: the keys of a bucket are pairwise distinct).
 // Buckets of at most kMegaRankMax entries (round 4) are ordered by COUNTING instead: the keys of a bucket are pairwise distinct, so the
 // final position of an entry is the number of entries that precede it.  k_gm_rank spreads the n x n comparisons over the whole chip --
-// a work item is 256 entries against a tile of 128, an LDS broadcast per comparison -- and k_gm_begin, the first kernel of the
+// a work item is 256 entries against a tile of 32, an LDS broadcast per comparison -- and k_gm_begin, the first kernel of the
 // mega-batch behind it, writes the ids to their places: ~15 us for the average handed-off bucket (3 200 entries) where the sorted runs + rank merge took 41 + 15 us with three or
 // four workgroups busy.  The work grows with n^2: beyond kMegaRankMax entries the runs are cheaper again.
-constexpr uint32_t kRankTile = 128;
+// (a work item's tile: 128 entries 176.5-177.4 ms per 1e7-node search, 64: 173.4-174.1, 32: 171.1-172.5, 16: 171.4-172.2, 8: 173.1-174.2, 256: 183.2-184.0 --
+// the bucket is a few thousand entries, so the chip runs about one wave per SIMD and a work item's length is instruction LATENCY)
+#ifndef ACX_RANK_TILE
+#define ACX_RANK_TILE 32
+#endif
+constexpr uint32_t kRankTile = ACX_RANK_TILE;
 template <typename W> __global__ void __launch_bounds__(256) k_gm_rank(MegaDev<W> md, uint32_t n, uint32_t chained) {
     __shared__ W sj0[kRankTile];
     __shared__ W sj1[kRankTile];
