@@ -82,6 +82,7 @@ SIGNATURES = {
     "acx_env_destroy": (None, [_vp]),
     "acx_env_set_initial": (C.c_int, [_vp, _i8p, _i64p, C.c_int64, _vp]),
     "acx_env_reset": (C.c_int, [_vp, _i8p, _i64p, C.c_int64, _vp]),
+    "acx_env_reset_device": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp]),
     "acx_env_set_supermoves": (C.c_int, [_vp, _u8p, _i32p, C.c_int, _vp]),
     "acx_env_step": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_float, C.c_float, _vp, _vp, _vp, C.c_int, _vp]),
     "acx_env_step_host": (C.c_int, [_vp, _i64p, _i8p, _f32p, _u8p, _u8p, _i8p, C.c_int, _u8p, _vp]),

@@ -107,24 +107,42 @@ class Curriculum:
     # ---- a rollout step's finished episodes at once ------------------------------------------------------------------------------
     _C_MIN = 48  # below this many draws Python's own generator is cheaper than moving its state to libacx and back
 
+    # The state of Python's global generator while libacx draws from it: taken out once (begin_borrow: 625 words, ~60 us with the
+    # conversions), advanced in place by every acx_py_curriculum_draws call, put back by end_borrow -- the training loop borrows it
+    # for a whole rollout (nothing else draws from `random` in there); on its own, finish_episodes borrows per call.
+    _borrowed = None
+
+    def begin_borrow(self):
+        import ctypes as C
+
+        ver, internal, gauss = random.getstate()
+        self._borrowed = (ver, gauss, np.array(internal[:624], dtype=np.uint32), C.c_int32(internal[624]))
+
+    def end_borrow(self):
+        if self._borrowed is not None:
+            ver, gauss, mt, pos = self._borrowed
+            self._borrowed = None
+            random.setstate((ver, tuple(mt.tolist()) + (pos.value,), gauss))
+
     def _draws(self, n):
         """next_state() n times after the first round, with both lists fixed: the same draws from `random`, taken in libacx
-        (acx_py_curriculum_draws restates CPython's Random.random / choice) on the state of the global generator, which is put back
-        advanced.  -> states [n]"""
-        if n < self._C_MIN:
+        (acx_py_curriculum_draws restates CPython's Random.random / choice) on the state of the global generator.  -> states [n]"""
+        if n < self._C_MIN and self._borrowed is None:
             return [self.next_state() for _ in range(n)]
         import ctypes as C
 
         from ac_solver import _acx
 
-        ver, internal, gauss = random.getstate()
-        mt = np.array(internal[:624], dtype=np.uint32)
-        pos = C.c_int32(internal[624])
+        mine = self._borrowed is None
+        if mine:
+            self.begin_borrow()
+        _, _, mt, pos = self._borrowed
         which, index = np.empty(n, np.uint8), np.empty(n, np.int64)
         solved, unsolved = self._list("solved"), self._list("unsolved")
         _acx.check(_acx.lib.acx_py_curriculum_draws(mt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), n, len(solved), len(unsolved), float(self.p),
                                                     _acx.ptr(which, C.c_uint8), _acx.ptr(index, C.c_int64)), "acx_py_curriculum_draws")
-        random.setstate((ver, tuple(mt.tolist()) + (pos.value,), gauss))
+        if mine:
+            self.end_borrow()
         key = ("arrays", len(solved), len(unsolved))
         if getattr(self, "_arr_key", None) != key:  # (a state only ever moves unsolved -> solved: the sizes tell)
             self._arr = (np.asarray(unsolved, np.int64), np.asarray(solved, np.int64))
@@ -381,6 +399,8 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
     values = torch.zeros((T, N), device=device)
     init_rows = np.asarray(initial_states, np.int8)
     init_table = torch.as_tensor(init_rows, device=device).to(obs_dtype)  # [n_states, 2L]
+    init_rows_dev = torch.as_tensor(init_rows, device=device)  # int8 rows for ACVecEnv.reset_envs_device
+    ns_pin = torch.empty(N, dtype=torch.int64).pin_memory() if device.type == "cuda" else None
     ep_return = torch.zeros(N, device=device)
     ep_length = torch.zeros(N, device=device)
 
@@ -438,6 +458,8 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             optimizer.param_groups[0]["lr"] = get_curr_lr(update, args.lr_decay, args.warmup_period, args.learning_rate,
                                                           args.learning_rate * args.min_lr_frac, num_updates)
         events = []  # (step, env, next curriculum state) of this rollout
+        reset_err_any = None
+        curriculum.begin_borrow()  # the rollout's curriculum draws advance the generator's state inside libacx; back in `random` after the rollout
         if fused is not None:
             fused.refresh()  # the weights of the last update
 
@@ -496,10 +518,22 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
             round1_complete = curriculum.round1_complete
             ep_return[idx] = 0
             ep_length[idx] = 0
-            # the finished envs restart from their next curriculum state (envs.envs[i].reset(options={"starting_state": ...}))
-            envs.reset_envs(idx_h, init_rows[new_states])
-            obs[step + 1].index_copy_(0, idx, init_table[torch.as_tensor(new_states, device=device)])
+            # the finished envs restart from their next curriculum state (envs.envs[i].reset(options={"starting_state": ...})): one
+            # upload (the states' numbers, through a pinned buffer), rows gathered and environments reset on the device
+            if device.type == "cuda":
+                k = len(new_states)
+                ns_pin[:k].copy_(torch.from_numpy(np.asarray(new_states, np.int64)))
+                ns_dev = ns_pin[:k].to(device, non_blocking=True)
+                reset_err = envs.reset_envs_device(idx, init_rows_dev.index_select(0, ns_dev))
+                reset_err_any = reset_err.any() if reset_err_any is None else reset_err_any | reset_err.any()
+            else:
+                ns_dev = torch.as_tensor(new_states, device=device)
+                envs.reset_envs(idx_h, init_rows[new_states])
+            obs[step + 1].index_copy_(0, idx, init_table.index_select(0, ns_dev))
             ph.lap("episode bookkeeping")
+        curriculum.end_borrow()
+        if reset_err_any is not None and bool(reset_err_any):  # (cannot happen: the rows are the validated initial states)
+            raise ValueError("a curriculum state is not a valid presentation (ACEnv.reset)")
         envs._raise_on_errors()
         if rollout_log is not None:
             rollout_log.append({"obs": obs.cpu().numpy().copy(), "actions": actions.cpu().numpy().copy(), "rewards": rewards.cpu().numpy().copy(),

@@ -214,6 +214,21 @@ class ACVecEnv:
         _acx.check(_acx.lib.acx_env_reset(self._h.ptr, None if rows is None else _acx.ptr(rows, C.c_int8), _acx.ptr(idx, C.c_int64), len(idx),
                                           self._stream()), "acx_env_reset")
 
+    def reset_envs_device(self, indices, states, rowerr=None):
+        """reset_envs from device tensors, queued on the current stream without a copy or a synchronisation: `indices` int64 [k]
+        (in range -- not checked), `states` int8 [k, 2L] rows (or None -> initial state).  -> the uint8 [k] tensor that will hold a
+        non-zero byte for every row that is not a presentation over {+-1, +-2} (such an env keeps its state)."""
+        torch = _torch()
+        assert indices.dtype == torch.int64 and indices.is_contiguous()
+        k = indices.numel()
+        if states is not None:
+            assert states.dtype == torch.int8 and states.is_contiguous() and tuple(states.shape) == (k, 2 * self.max_relator_length)
+        if rowerr is None:
+            rowerr = torch.empty(max(k, 1), dtype=torch.uint8, device=indices.device)
+        _acx.check(_acx.lib.acx_env_reset_device(self._h.ptr, None if states is None else states.data_ptr(), indices.data_ptr(), k, rowerr.data_ptr(),
+                                                 self._stream()), "acx_env_reset_device")
+        return rowerr[:k]
+
     def _get(self, indices):
         idx = np.ascontiguousarray(np.arange(self.num_envs) if indices is None else indices, np.int64)
         st = np.empty((len(idx), 2 * self.max_relator_length), np.int8)

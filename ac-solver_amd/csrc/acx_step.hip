@@ -1031,6 +1031,16 @@ int acx_env_reset(acx_env* e, const int8_t* h_states, const int64_t* h_idx, int6
     return env_load_rows(e, h_states, h_idx, n_idx, 0, (hipStream_t)stream);
 }
 
+int acx_env_reset_device(acx_env* e, const int8_t* d_states, const int64_t* d_idx, int64_t n_idx, uint8_t* d_rowerr, void* stream) {
+    if (!e || n_idx < 0 || !d_idx || !d_rowerr) return fail(ACX_E_INVAL, "acx_env_reset_device: env, indices and the row-error bytes are required");
+    if (n_idx == 0) return ACX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)ceil_div<int64_t>(n_idx, 256);
+    ACX_ENV_DISPATCH(e, hipLaunchKernelGGL(k_env_load<W>, dim3(grid), dim3(256), 0, st, dev, d_states, d_idx, n_idx, 0, d_rowerr));
+    ACX_HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
 int acx_env_step(acx_env* e, const void* d_actions, int action_dtype, void* d_obs, int obs_dtype, float* d_reward, float clip_lo,
                  float clip_hi, uint8_t* d_done, uint8_t* d_trunc, void* d_final_obs, int autoreset, void* stream) {
     if (!e || !d_actions) return fail(ACX_E_INVAL, "acx_env_step: env and actions required");

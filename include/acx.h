@@ -92,6 +92,12 @@ int acx_env_set_initial(acx_env *env, const int8_t *h_states, const int64_t *h_i
 /* ACEnv.reset (ac_env.py:115-131): h_states NULL -> back to the initial state, else
  * options={"starting_state": row}.  Zeroes count_steps and the action history of those envs. */
 int acx_env_reset(acx_env *env, const int8_t *h_states, const int64_t *h_idx, int64_t n_idx, void *stream);
+/* The same from DEVICE buffers (the PPO driver restarts the finished environments of a rollout step from rows it gathers on the
+ * device): d_states [n_idx, 2L] int8 or NULL (-> initial state), d_idx [n_idx] (required; every index in [0, n) -- not checked),
+ * d_rowerr [n_idx] receives 0 or ACX_ERR_UNPACKABLE per row (an env whose row is flagged keeps its state).  Only queues the kernel:
+ * no copy, no synchronisation; ordered with the steps on `stream`. */
+int acx_env_reset_device(acx_env *env, const int8_t *d_states, const int64_t *d_idx, int64_t n_idx, uint8_t *d_rowerr,
+                         void *stream);
 /* Supermoves.  The reference declares `use_supermoves` (envs/ac_env.py:20, agents/args.py:107-114) and raises
  * NotImplementedError when it is set (ac_env.py:62-65); there is no reference behaviour to reproduce.  Opt-in here: action
  * 12 + s runs the base moves h_moves[h_offsets[s] .. h_offsets[s + 1]) (each 0..11) as ONE environment step -- state = the

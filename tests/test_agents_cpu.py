@@ -254,13 +254,16 @@ def test_finished_episodes_of_a_step_at_once_equal_one_by_one():
             k = ev.choice((1, 3, 40, 47, 48, 49, 300, 3000))
             steps.append([(ev.random() < (0.3 if t % 3 else 0.002), ev.randrange(n_states)) for _ in range(k)])
 
-        def run(batched):
+        def run(batched, borrow=False):
             proc = set(range(0, 8 * stride, stride))
             rec = {"solved": set(), "unsolved": set(range(n_states))}
             cur = Curriculum(proc, n_states, rec, p, stride)
             random.seed(3)
             outs, calls = [], []
-            for step in steps:
+            for t, step in enumerate(steps):
+                if borrow and t % 8 == 0:  # (the training loop: the generator's state stays in libacx for a whole rollout)
+                    cur.end_borrow()
+                    cur.begin_borrow()
                 current, done = [s for _, s in step], np.array([d for d, _ in step])
                 if batched:
                     outs.append(cur.finish_episodes(current, done, lambda k, s: calls.append((len(outs), k, s))))
@@ -272,10 +275,12 @@ def test_finished_episodes_of_a_step_at_once_equal_one_by_one():
                             calls.append((len(outs), k, s))
                         nxt.append(cur.next_state())
                     outs.append(nxt)
+            cur.end_borrow()
             return outs, calls, proc, rec, cur.round1_complete, cur.max_processed, random.getstate()
 
-        a, b = run(False), run(True)
+        a, b, c = run(False), run(True), run(True, borrow=True)
         assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[3] == b[3] and a[4:] == b[4:]
+        assert a[0] == c[0] and a[1] == c[1] and a[2] == c[2] and a[3] == c[3] and a[4:] == c[4:]
         assert a[4] and len(a[3]["solved"]) > 5
 
 
