@@ -94,6 +94,8 @@ SIGNATURES = {
     "acx_env_max_reward": (C.c_int64, [_vp]),
     "acx_search_many": (C.c_int, [C.c_int, _i8p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, _i32p, _i32p, _i32p, C.c_int64, _i64p,
                                C.POINTER(SearchStats), _i32p]),
+    "acx_search_groups": (C.c_int, [C.c_int, C.c_int, C.POINTER(_i8p), _i64p, _i32p, C.c_int64, C.c_int, _i32p, _i32p, _i32p, C.c_int64, _i64p,
+                                 C.POINTER(SearchStats), _i32p]),
     "acx_shard_key_words": (C.c_int, [C.c_int]),
     "acx_shard_layout": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, _i64p, _i64p, _i64p]),
     "acx_shard_create": (_vp, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int]),

@@ -1,7 +1,6 @@
 """Shared driver for bfs / greedy_search: hands the presentation to libacx's device frontier."""
 import ctypes as C
 import os
-import time
 
 import numpy as np
 
@@ -78,31 +77,56 @@ def run_search_many(kind, presentations, max_nodes_to_explore, cyclical, n_threa
 
 
 def run_search_groups(kind, groups, max_nodes_to_explore, cyclical, n_threads=16, path_cap=4096):
-    """`run_search_many` on several batches of presentations of DIFFERENT widths (the Miller-Schupp presentations of each n have
-    their own max_relator_length).  greedy_search: one host thread per batch, so that their launches share the GPU -- a batch of
-    170 one-workgroup searches fills 170 of the 256 compute units.  bfs: one batch after the other (see below).
-    -> list (per batch) of lists of (solved, path, stats)."""
-    from concurrent.futures import ThreadPoolExecutor
+    """Searches on several batches of presentations of DIFFERENT widths (the Miller-Schupp presentations of each n have their own
+    max_relator_length) in one call of acx_search_groups.  greedy_search: all searches of all batches are jobs of one launch per
+    key width, taken by a fixed set of workgroups one after the other.  bfs: one batch after the other -- a batch fills the GPU on
+    its own (acx_bfs_many.h: a tile of every search's frontier per workgroup), and batches in flight together only evict each
+    other's tables from the caches (measured: the seven widths one after another 144 ms, all at once 190-250 ms).
+    ACX_SWEEP_WORKERS=k: the earlier form, k host threads with one acx_search_many call per batch (A/B runs).
+    -> list (per batch) of lists of (solved, path, stats), each identical to what run_search returns."""
+    workers = int(os.environ.get("ACX_SWEEP_WORKERS", "0"))
+    if workers > 0 and len(groups) > 1:
+        from concurrent.futures import ThreadPoolExecutor
 
-    if len(groups) <= 1:
-        return [run_search_many(kind, g, max_nodes_to_explore, cyclical, n_threads, path_cap) for g in groups]
-    # Longest first: the widest presentations (128-bit keys from max_relator_length 30) are the slowest searches, and a search that
-    # starts late runs its tail alone on an otherwise idle GPU.  Their launches go out first (the other batches follow a moment
-    # later), so the hardware hands their workgroups compute units before the shorter ones.
-    order = sorted(range(len(groups)), key=lambda k: -np.asarray(groups[k]).shape[-1])
-    stagger = os.environ.get("ACX_SWEEP_STAGGER_MS", "0")  # (a pause between the wide and the narrow batches: measured no better than none)
-    wide = [k for k in order if np.asarray(groups[k]).shape[-1] // 2 > 29]
-    # bfs: a batch of searches fills the GPU on its own (acx_bfs_many.h: a tile of every search's frontier per workgroup), and batches in
-    # flight together only evict each other's tables from the caches -- measured: the seven widths one after another 144 ms, all at once
-    # 190-250 ms.  greedy: one workgroup per search, so the batches must overlap to fill the compute units.
-    workers = int(os.environ.get("ACX_SWEEP_WORKERS", "0")) or (1 if kind == _acx.SEARCH_BFS and os.environ.get("ACX_BFS_MANY") != "multi" else len(groups))
-    with ThreadPoolExecutor(max_workers=workers) as ex:
-        futs = {}
-        for pos, k in enumerate(order):
-            if wide and pos == len(wide) and float(stagger) > 0:
-                time.sleep(float(stagger) * 1e-3)
-            futs[k] = ex.submit(run_search_many, kind, groups[k], max_nodes_to_explore, cyclical, n_threads, path_cap)
-        return [futs[k].result() for k in range(len(groups))]
+        order = sorted(range(len(groups)), key=lambda k: -np.asarray(groups[k]).shape[-1])  # widest first
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            futs = {k: ex.submit(run_search_many, kind, groups[k], max_nodes_to_explore, cyclical, n_threads, path_cap) for k in order}
+            return [futs[k].result() for k in range(len(groups))]
+    _acx.require_device()
+    rows = [_acx.as_i8_rows(np.asarray(g)) for g in groups]
+    ng = len(rows)
+    if ng == 0:
+        return []
+    counts = np.array([r.shape[0] for r in rows], np.int64)
+    widths = np.array([r.shape[1] // 2 for r in rows], np.int32)
+    n = int(counts.sum())
+    ptrs = (C.POINTER(C.c_int8) * ng)(*[_acx.ptr(r, C.c_int8) for r in rows])
+    solved = np.zeros(n, np.int32)
+    pa = np.empty((n, path_cap), np.int32)
+    pl = np.empty((n, path_cap), np.int32)
+    pn = np.zeros(n, np.int64)
+    rcs = np.zeros(n, np.int32)
+    stats = (_acx.SearchStats * n)()
+    rc = _acx.lib.acx_search_groups(kind, ng, ptrs, _acx.ptr(counts, C.c_int64), _acx.ptr(widths, C.c_int32), int(max_nodes_to_explore), int(bool(cyclical)),
+                                    _acx.ptr(solved, C.c_int32), _acx.ptr(pa, C.c_int32), _acx.ptr(pl, C.c_int32), path_cap, _acx.ptr(pn, C.c_int64), stats,
+                                    _acx.ptr(rcs, C.c_int32))
+    if rc == _acx.E_ROWERR and (rcs == _acx.E_ROWERR).any():
+        raise AssertionError(_acx.last_error())
+    _acx.check(rc, "acx_search_groups")
+    out, k = [], 0
+    for g in range(ng):
+        res = []
+        for i in range(int(counts[g])):
+            if rcs[k] == _acx.E_CAPACITY:  # rare: a path longer than path_cap -> redo that search alone
+                res.append(run_search(kind, rows[g][i], max_nodes_to_explore, cyclical))
+            else:
+                st = stats[k]
+                path = [(int(a), int(l)) for a, l in zip(pa[k, : pn[k]], pl[k, : pn[k]])] if pn[k] else None
+                res.append((bool(solved[k]), path, dict(nodes=st.nodes, expanded=st.expanded, children=st.children, levels=st.levels, min_len=st.min_len,
+                                                        seconds=st.seconds)))
+            k += 1
+        out.append(res)
+    return out
 
 
 def self_check(search_fn, budget=10**6):

@@ -214,7 +214,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, ui
 // reference's return path, (-1, len0), (action, length) ... , written by lane 0 at the end; out->path_n is its length.
 template <typename W, uint32_t SC, uint32_t kGT, bool NF>  // SC candidates per batch, kGT lanes (shadows the namespace constant: the single search's workgroup), NF: normal-form search
 __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __restrict__ out, int32_t* __restrict__ path_act,
-                                           int32_t* __restrict__ path_len, long long path_cap) {
+                                           int32_t* __restrict__ path_len, long long path_cap, uint32_t* depth_hi_out = nullptr) {
     constexpr int R = (int)(SC / kGT);                     // children per lane in a full batch
     constexpr uint32_t kPmax = (uint32_t)(R * kGT) / 12u;  // parents in a full batch
     constexpr uint32_t kBT = 2 * SC;                       // in-batch dedup table (LDS)
@@ -1080,6 +1080,10 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
             }
         }
     }
+    if (depth_hi_out) {  // (k_greedy_sched: the deepest bucket row this search can have written, for the slot's clean-up; every lane its own copy)
+        __syncthreads();
+        *depth_hi_out = s_depth_hi;
+    }
 }
 
 // No register pad here (ACX_VGPR_PAD, acx_common.h): a 1024-lane workgroup may use at most 128 registers per lane and the
@@ -1105,6 +1109,64 @@ __global__ void __launch_bounds__(kGreedyMultiThreads) k_greedy_multi(const Gree
                                                       int32_t* __restrict__ path_len, long long path_cap) {
     const GreedyDev<W> g = gs[blockIdx.x];
     greedy_run<W, greedy_cfg<W>::kSortCap, kGreedyMultiThreads, NF>(g, outs + blockIdx.x, path_act + (size_t)blockIdx.x * path_cap, path_len + (size_t)blockIdx.x * path_cap, path_cap);
+}
+
+// ---- many searches on a FIXED number of workgroups (round 4) -----------------------------------------------------------------------
+// k_greedy_multi gives every search of a launch its own workgroup and its own memory, so a launch is as many searches as fit the
+// memory budget (46 at 1e6 nodes), a batch of 170 is four launches one after the other, and every launch waits for its slowest
+// search while the compute units of the finished ones stand idle -- with the seven batches of a Miller-Schupp sweep on seven
+// streams (which share four hardware queues by default) the chip ran at a quarter of the workgroup time it was given
+// (5.5e10 workgroup cycles = 103 ms x 256 compute units in a 400 ms sweep).  Here a launch is a fixed set of SLOTS -- a workgroup
+// with the memory of one search -- and the searches are JOBS the workgroups take from a counter, one after the other: a slot is
+// cleaned between two jobs by the workgroup itself (the visited table, the rows of the bucket table the last job can have
+// touched).  Searches of different max_relator_length share a launch (a job carries its L), so a whole sweep is one launch per
+// key width and move code.
+template <typename W> struct GreedyJob {
+    W root_k0, root_k1;
+    uint32_t root_len, nlen;
+    int32_t L, pad_;
+};
+template <typename W, bool NF>
+__global__ void __launch_bounds__(kGreedyMultiThreads) k_greedy_sched(const GreedyDev<W>* __restrict__ slots, const GreedyJob<W>* __restrict__ jobs, uint32_t n_jobs,
+                                                      uint32_t* __restrict__ counter, GreedyOut* __restrict__ outs, int32_t* __restrict__ path_act,
+                                                      int32_t* __restrict__ path_len, long long path_cap) {
+    __shared__ uint32_t s_job;
+    const uint32_t tid = threadIdx.x;
+    uint32_t used = 0, prev_hi = 0, prev_nlen = 0;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_job = atomicAdd(counter, 1u);
+        __syncthreads();
+        const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_job);  // (uniform: the slot and the job arrive through scalar loads)
+        if (j >= n_jobs) break;
+        GreedyDev<W> g = slots[blockIdx.x];
+        const uint32_t nlen_cap = g.nlen;  // the slot's bucket table has rows for this many total lengths
+        const GreedyJob<W> jb = jobs[j];
+        if (used) {  // the slot as the host set it up: table free, bucket records and bitmap zero (only rows 0 .. depth_hi + 2 can be anything else)
+            ulonglong2* t2 = (ulonglong2*)g.tab;
+            const uint32_t n2 = (g.tmask + 1u) / 2u;
+            for (uint32_t i = tid; i < n2; i += kGreedyMultiThreads) t2[i] = make_ulonglong2(kTabEmpty, kTabEmpty);
+            const uint32_t rows = min(prev_hi + 3u, kDepthCap), words = (rows + 31u) / 32u;
+            for (uint32_t l = 0; l < prev_nlen; l++) {
+                uint4* r4 = (uint4*)(g.bk + (size_t)l * kDepthCap);  // a record is two uint4
+                for (uint32_t i = tid; i < 2u * rows; i += kGreedyMultiThreads) r4[i] = make_uint4(0, 0, 0, 0);
+                for (uint32_t i = tid; i < words; i += kGreedyMultiThreads) g.bitmap[(size_t)l * (kDepthCap / 32) + i] = 0;
+            }
+        }
+        // the vector L1 may hold lines of the slot as the LAST job left them (a kernel starts with an empty L1, a job does not): an
+        // agent-scope fence writes the clean-up through and invalidates them
+        __threadfence();
+        g.root_k0 = jb.root_k0;
+        g.root_k1 = jb.root_k1;
+        g.root_len = jb.root_len;
+        g.nlen = min(jb.nlen, nlen_cap);
+        g.d.L = jb.L;
+        uint32_t hi = 0;
+        greedy_run<W, greedy_cfg<W>::kSortCap, kGreedyMultiThreads, NF>(g, outs + j, path_act + (size_t)j * path_cap, path_len + (size_t)j * path_cap, path_cap, &hi);
+        used = 1;
+        prev_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
+        prev_nlen = g.nlen;
+    }
 }
 
 }  // namespace acx

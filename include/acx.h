@@ -193,14 +193,24 @@ int acx_release_cached_memory(void);
  * miller_schupp.py:95-177, runs them one after another).  Both kinds run as GROUPS of searches, each search with its own visited
  * table and node arena.  bfs: the searches of a group share the launches of the fused single search (acx_bfs_many.h: a tile of one
  * search's batch per workgroup, a batch of every running search per round of four launches; ACX_BFS_MANY=multi selects the
- * earlier one-persistent-workgroup-per-search kernel k_bfs_multi for A/B runs).  greedy_search: ONE launch, one persistent
- * workgroup per search (k_greedy_multi, acx_greedy.h).  A group is as many searches as fit the free device memory, and a greedy
- * search that outgrows a capacity of its workgroup is rerun alone through acx_search.  `n_threads` only matters on the fallback
+ * earlier one-persistent-workgroup-per-search kernel k_bfs_multi for A/B runs).  greedy_search: ONE launch of up to 192 persistent
+ * workgroups, each with the memory of one search, which take the searches from a counter one after the other (k_greedy_sched,
+ * acx_greedy.h; ACX_GREEDY_MULTI_STATIC=1: round 3's one workgroup per search, as many searches per launch as fit the memory
+ * budget).  A greedy search that outgrows a capacity of its workgroup is rerun alone through acx_search.  `n_threads` only matters on the fallback
  * path (n == 1, L > 61 never reaches it, the diagnostic switches ACX_GREEDY_HOST / ACX_BFS_MANY_STREAMS, `verbose` minima or the
  * digest hook on): there that many host threads run one acx_search each, every search on its own HIP stream; 1..64, clamped.
  * Row k of every output belongs to presentation k ([n, path_cap] for the paths); rc_out[k] is that search's return code
  * (ACX_E_CAPACITY when its path needs more than path_cap entries: path_n[k] then holds the required size).  Results are
  * identical to n calls of acx_search. */
+/* Several batches of searches in one call: batch g has n[g] presentations of max_relator_length L[g] (h_presentations[g]:
+ * [n[g], 2 L[g]]) -- the Miller-Schupp presentations of each n have their own max_relator_length, and the reference's driver walks
+ * through all of them (miller_schupp.py:140-158).  Outputs as acx_search_many's, the batches one behind the other in batch order
+ * (sum of n[g] rows).  greedy_search: ALL searches are jobs of one launch per key width (k_greedy_sched, acx_greedy.h): a fixed set of
+ * workgroups, each with the memory of one search, takes them from a counter one after the other -- no launch waits for its slowest
+ * search, no batch for another.  bfs: the batches one after the other through acx_search_many (a batch fills the GPU by itself). */
+int acx_search_groups(int kind, int n_groups, const int8_t *const *h_presentations, const int64_t *n, const int32_t *L,
+                      int64_t max_nodes, int cyclical, int32_t *solved, int32_t *path_action, int32_t *path_len,
+                      int64_t path_cap, int64_t *path_n, acx_search_stats *stats, int32_t *rc_out);
 int acx_search_many(int kind, const int8_t *h_presentations, int64_t n, int L, int64_t max_nodes, int cyclical,
                     int n_threads, int32_t *solved, int32_t *path_action, int32_t *path_len, int64_t path_cap,
                     int64_t *path_n, acx_search_stats *stats, int32_t *rc_out);

@@ -600,6 +600,47 @@ def test_many_bfs_searches_share_their_launches_and_equal_single_ones(search, L,
         run_search_many(_acx.SEARCH_BFS, bad, 100, False)
 
 
+@pytest.mark.parametrize("slots", ["2", "5", "256"])
+def test_greedy_searches_as_jobs_on_a_few_workgroup_slots(search, golden_json, monkeypatch, slots):
+    """acx_search_groups / acx_search_many(greedy) = k_greedy_sched: a fixed set of workgroups, each with the memory of ONE search,
+    takes the searches from a counter and cleans its slot (visited table, bucket rows, the vector L1) between two of them.  With 2 or 5
+    slots every workgroup runs dozens of searches one after the other -- of different max_relator_length, solved after a handful
+    of nodes or cut off by the budget at depth > 100, 64- and 128-bit keys, roots in and out of normal form: each (solved, path,
+    nodes, expanded) as the single search's, which the other tests hold against the oracle."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search, run_search_groups, run_search_many
+
+    monkeypatch.setenv("ACX_GREEDY_SLOTS", slots)
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    rng = np.random.default_rng(17)
+    groups = []
+    for n0 in (0, 2, 4, 5, 6):  # max_relator_length 18, 20, 28 (64-bit keys), 32, 36 (128-bit keys)
+        pick = np.sort(rng.choice(170, size=14, replace=False)) + 170 * n0
+        groups.append(np.array([pool[int(k)] for k in pick], dtype=np.int8))
+    extra = np.stack([_pad([1, 2, -2, 1], [2, 1, -1, 2, 2], 12), _pad([2, 1, -2], [1, 2, -1, -1], 12), _pad([1], [2], 12), _pad([1, 1, 1, -2, -2, -2, -2], [1, 2, 1, -2, -1, -2], 12)])
+    groups.append(extra)  # not in normal form: the general move code, a launch of its own
+    for budget, cyc in ((3000, False), (40000, True)):
+        got = run_search_groups(_acx.SEARCH_GREEDY, groups, budget, cyc)
+        assert [len(r) for r in got] == [len(g) for g in groups]
+        for g, res in zip(groups, got):
+            for row, (ok, path, st) in zip(g, res):
+                wok, wpath, wst = run_search(_acx.SEARCH_GREEDY, row, budget, cyc)
+                assert (ok, path) == (wok, wpath), (slots, budget, cyc, row.tolist())
+                assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (slots, budget, cyc, row.tolist(), st, wst)
+        one = run_search_many(_acx.SEARCH_GREEDY, groups[1], budget, cyc)  # a single batch takes the same route
+        assert [(ok, path, st["nodes"]) for ok, path, st in one] == [(ok, path, st["nodes"]) for ok, path, st in got[1]]
+    # bfs through the same entry: the batches one after the other
+    got = run_search_groups(_acx.SEARCH_BFS, groups[:3], 2000, True)
+    for g, res in zip(groups[:3], got):
+        for row, (ok, path, st) in zip(g, res):
+            wok, wpath, wst = run_search(_acx.SEARCH_BFS, row, 2000, True)
+            assert (ok, path, st["nodes"], st["expanded"]) == (wok, wpath, wst["nodes"], wst["expanded"])
+    # a search in which the reference raises makes the call raise
+    bad = np.stack([_pad([1, 1], [2, 2], 2), _pad([1, 2], [2, 1], 2)])
+    with pytest.raises(AssertionError):
+        run_search_groups(_acx.SEARCH_GREEDY, [groups[0], bad], 100, False)
+
+
 def test_miller_schupp_driver_matches_reference_test_ranges(search, golden_json):
     """tests/search/miller_schupp/test_miller_schupp.py of the reference: n, w in {1, 2} (greedy 1e6, bfs 1e4) and {3, 4} (greedy 1e4)"""
     from ac_solver.search.miller_schupp.miller_schupp import trivialize_miller_schupp_through_search
