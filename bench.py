@@ -336,9 +336,10 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
                                 "bfs_ms_sweep_1e6")
     # the reference's other published experiment: greedy_search, budget 1e6, on the same 1190 (533 solved)
     out["greedy_ms_sweep"] = sweep(_acx.SEARCH_GREEDY, False, 533,
-                                   "acx_search_many per rank: one persistent workgroup per search (k_greedy_multi), the seven "
-                                   "max_relator_lengths in flight together; searches dealt round-robin to the ranks",
-                                   "k_greedy_multi<u64> / <u128> (one persistent workgroup per search)", "greedy_ms_sweep_1e6")
+                                   "acx_search_groups per rank: the searches of all seven max_relator_lengths are jobs that a fixed set of persistent "
+                                   "workgroups (one per compute unit, shared out between the 64- and the 128-bit launch) takes from a counter "
+                                   "(k_greedy_sched); searches dealt round-robin to the ranks",
+                                   "k_greedy_sched<u64> / <u128> (persistent workgroups, one search after the other)", "greedy_ms_sweep_1e6")
     if world == 1 and not use_dist:
         for kind, name in ((_acx.SEARCH_BFS, "bfs"), (_acx.SEARCH_GREEDY, "greedy_search")):
             b = budget if kind == _acx.SEARCH_BFS else min(budget, 10**7)
