@@ -614,9 +614,13 @@ static int run_greedy_sched(const std::vector<SearchGroupIn>& groups, int64_t ma
         where[code].swap(ws);
     }
     const uint32_t n_most = (uint32_t)std::max(jobs[0].size(), jobs[1].size());
-    const uint32_t R = (uint32_t)std::max<double>(1.0, std::min<double>(std::min<uint32_t>(n_most, std::max<uint32_t>(slots_cap, 1u)), budget / (double)per_slot));
+    uint32_t R = (uint32_t)std::max<double>(1.0, std::min<double>(std::min<uint32_t>(n_most, std::max<uint32_t>(slots_cap, 1u)), budget / (double)per_slot));
     DevBuf big, dslots, djobs, dcounter, douts, dpa, dpl;
-    if (big.alloc((uint64_t)R * per_slot)) return ACX_E_NOMEM;
+    while (big.alloc((uint64_t)R * per_slot)) {  // (the estimate of the free memory was too good: fewer slots -- the jobs just take longer)
+        if (R == 1) return ACX_E_NOMEM;
+        (void)hipGetLastError();  // (the failed hipMalloc's error must not meet the launch check below)
+        R = (R + 1) / 2;
+    }
     uint8_t* p_slots = (uint8_t*)big.p;
     uint8_t* p_bk = p_slots + (uint64_t)R * b_slots;
     uint8_t* p_bm = p_bk + (uint64_t)R * b_bk;
