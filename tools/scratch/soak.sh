@@ -1,22 +1,5 @@
-#!/bin/bash
-# soak.sh N LIMIT_SECONDS OUTDIR -- pytest args...   : N plain runs of the GPU suite; a run that exceeds LIMIT is examined
-# (faulthandler's Python stacks are in its log; GPU use and the threads' kernel wait channels are appended) and then killed.
-n=$1; limit=$2; out=$3; shift 3
-mkdir -p "$out"
-for i in $(seq 1 "$n"); do
-  log="$out/run_$i.log"
-  python -X faulthandler -m pytest "$@" -o faulthandler_timeout=$((limit - 30)) > "$log" 2>&1 &
-  pid=$!
-  t=0
-  while kill -0 "$pid" 2>/dev/null && [ "$t" -lt "$limit" ]; do sleep 2; t=$((t + 2)); done
-  if kill -0 "$pid" 2>/dev/null; then
-    { echo "==== STALLED after $t s ===="; /opt/rocm/bin/rocm-smi --showuse --showmemuse 2>&1 | tail -12;
-      for task in /proc/$pid/task/*; do echo "$(basename $task) $(cat $task/comm 2>/dev/null) wchan=$(cat $task/wchan 2>/dev/null) state=$(grep State $task/status 2>/dev/null | tr -s '\t ' ' ')"; done; } >> "$log"
-    kill "$pid"; sleep 3; kill -9 "$pid" 2>/dev/null
-    echo "iter $i: STALLED (see $log)"
-    break
-  fi
-  wait "$pid"; rc=$?
-  echo "iter $i rc=$rc $(grep -E 'passed|failed' "$log" | tail -1)"
-  [ "$rc" -eq 0 ] && rm -f "$log"
-done
+mkdir -p gpurun_out/soak
+for seed in 12 13 14 15 16 17 18 19 20 21 22 23; do ACX_FUZZ_SEED=$seed timeout 900 python -m pytest tests/test_gpu_search_fuzz.py -m gpu -x -q 2>&1 | tail -1; done
+for sl in 1 3 7 33; do ACX_GREEDY_SLOTS=$sl timeout 900 python -m pytest tests/test_gpu_search.py tests/test_gpu_sweeps.py -m gpu -x -q -k "many or greedy_sweep or paths_file or groups" 2>&1 | tail -1; done
+python tools/scratch/greedy_soak.py 5 40 2>&1 | tail -1
+timeout 900 python -m ac_solver.agents.ppo --num-envs 8192 --tile-initial-states --fused-policy --num-steps 32 --total-timesteps 10485760 --horizon-length 200 2>&1 | tail -2
