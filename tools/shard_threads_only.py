@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bfs_sharded on AK(3) with W thread ranks sharing the one GPU of a box (tests/shard_helpers.py: ThreadComm), nothing else: for
 `rocprofv3 --kernel-trace --stats`, whose k_shard_* totals / (searches) are the device work of ALL ranks of one search at world W.
-    python3 tools/shard_threads_only.py W [budget] [searches]"""
+    python3 tools/shard_threads_only.py W [budget] [searches] [log2 of the global parents per chunk]"""
 import os
 import sys
 import time
@@ -17,6 +17,7 @@ from tests.shard_helpers import run_threads
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 budget = int(float(sys.argv[2])) if len(sys.argv) > 2 else 10**8
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+bp = 1 << (int(sys.argv[4]) if len(sys.argv) > 4 else 21)
 ak3 = np.zeros(50, np.int8)
 ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
 ak3[25:31] = [1, 2, 1, -2, -1, -2]
@@ -27,7 +28,7 @@ def work(comm):
     for _ in range(reps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ok, path, st = bfs_sharded(ak3, budget, comm=comm, batch_parents=1 << 21, want_stats=True)
+        ok, path, st = bfs_sharded(ak3, budget, comm=comm, batch_parents=bp, want_stats=True)
         torch.cuda.synchronize()
         out.append((time.perf_counter() - t0, st["nodes"], st["expanded"]))
     return out
