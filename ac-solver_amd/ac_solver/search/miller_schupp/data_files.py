@@ -70,7 +70,7 @@ def make_data_files(max_nodes_to_explore=10**6, out_dir=None, verbose=True):
         by_len = generate_miller_schupp_presentations(n, 7)
         all_rows.append([p for lenw in range(1, 8) for p in by_len.get(lenw, [])])
     arrs = [np.array(rows, dtype=np.int8) for rows in all_rows]
-    greedy_all = run_search_groups(_acx.SEARCH_GREEDY, arrs, max_nodes_to_explore, False)  # the seven widths in flight together
+    greedy_all = run_search_groups(_acx.SEARCH_GREEDY, arrs, max_nodes_to_explore, False)  # all seven widths in one call (acx_search_groups)
     bfs_all = run_search_groups(_acx.SEARCH_BFS, arrs, max_nodes_to_explore, True)
     for n in range(1, 8):
         rows, greedy, bfs = all_rows[n - 1], greedy_all[n - 1], bfs_all[n - 1]
