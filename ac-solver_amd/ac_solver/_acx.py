@@ -103,6 +103,8 @@ SIGNATURES = {
     "acx_shard_attach": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
     "acx_shard_root_record": (C.c_int, [_vp, _i8p, _i64p]),
     "acx_shard_seed": (C.c_int, [_vp, _i64p, _vp]),
+    "acx_shard_owner": (C.c_int, [C.c_int, _i64p, C.c_int]),
+    "acx_shard_check_owners": (C.c_int, [_vp, _i64p, _vp]),
     "acx_shard_chunk_expand": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, C.c_int, _i64p, _i64p, _vp]),
     "acx_shard_chunk_insert": (C.c_int, [_vp, _vp]),
     "acx_shard_chunk_insert_dead": (C.c_int, [_vp, _vp]),

@@ -48,12 +48,14 @@ HDR = 4              # int64 header words of a region: records written, success 
 LAG = 2              # chunks the host runs ahead of the control block it reads
 _FORCE_EXCHANGE = False  # tests: route through the communicator even when world == 1
 _FORCE_LAG = None        # tests: run the CPU engines with the GPU path's lagged control block
+_CHECK_OWNERS = False    # tests: stats["owner_mismatches"] = nodes of this rank's engine that do not live on their owner (acx_shard_check_owners)
 _ID_MASK = (1 << 40) - 1
 # control block words (include/acx.h: ACX_SHARD_CTL_*)
 CTL_WORDS = 16
 CTL_STATUS, CTL_NODES_GLOBAL, CTL_NEXT_COUNT, CTL_EXPANDED, CTL_SOLVED_TAG, CTL_NODES = 0, 1, 2, 3, 4, 5
 CTL_FAIL_LOCAL, CTL_MIN_LEN, CTL_FAIL_SEEN, CTL_LEVEL_FILL = 8, 9, 10, 12
-FILL_DEFAULT = 320  # region capacity in 1/256 of the even share of all children: 1.25 x, safe for any input (acx_shard_layout)
+FILL_DEFAULT = 320  # region capacity in 1/256 of the even share of all children: 1.25 x (acx_shard_layout)
+FILL_HARD = 1 << 20  # the hard bound: every workgroup sends a region all it has -- cannot overflow, world^2 x the even share
 ST_RUNNING, ST_SOLVED, ST_BUDGET, ST_MOVE_ERROR, ST_FAILED = 0, 1, 2, 3, 4
 _FAIL_TEXT = {1: "a send region or the record log overflowed", 2: "node capacity exceeded", 3: "visited table full", 4: "engine call failed"}
 
@@ -142,7 +144,7 @@ class HipShardEngine:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.KW = _acx.lib.acx_shard_key_words(L)
         self.RW = self.KW + 1
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.L = rank, world, int(L)
         self.B = int(chunk_parents)
         with torch.cuda.device(self.device):
             self.h = _acx.lib.acx_shard_create(L, int(bool(cyclical)), int(node_cap), self.B, rank, world)
@@ -198,6 +200,19 @@ class HipShardEngine:
         self._acx.check(rc, "acx_shard_root_record")
         return rec
 
+    def root_owner(self, record):
+        """rank that owns the root (csrc/acx_owner.h through acx_shard_owner: host arithmetic)"""
+        rec = np.ascontiguousarray(record, np.int64)
+        o = self._acx.lib.acx_shard_owner(self.L, self._acx.ptr(rec, C.c_int64), self.world)
+        self._acx.check(min(o, 0), "acx_shard_owner")
+        return o
+
+    def check_owners(self):
+        """test hook: local nodes that are not where acx_shard_owner says (must be 0)"""
+        bad = C.c_int64(-1)
+        self._acx.check(self._acx.lib.acx_shard_check_owners(self.h, C.byref(bad), self._stream()), "acx_shard_check_owners")
+        return bad.value
+
     def seed(self, record):
         rec = None if record is None else np.ascontiguousarray(record, np.int64)
         self._acx.check(self._acx.lib.acx_shard_seed(self.h, None if rec is None else self._acx.ptr(rec, C.c_int64), self._stream()), "acx_shard_seed")
@@ -214,6 +229,11 @@ class HipShardEngine:
                 self.log = bigger
                 self._attach()
             torch.cuda.synchronize(self.device)  # the copy ran on the calling stream; the other stream's next kernels read the new block
+        if self.send is not None and need > self.send.numel():  # (only under a capacity above the default: the hard bound of the last resort)
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.device(self.device):
+                self.send = torch.empty(need, dtype=torch.int64, device=self.device)
+                self._attach()
         off, words = C.c_int64(), C.c_int64()
         self._acx.check(self._acx.lib.acx_shard_chunk_expand(self.h, int(c0), int(c1), int(bool(level_first)), int(fill_q8), C.byref(off), C.byref(words), self._stream()),
                         "acx_shard_chunk_expand")
@@ -264,16 +284,68 @@ def _default_engine(L, cyclical, node_cap, chunk_parents, rank, world, est_paren
 
 
 # ------------------------------------------------------------------------------------- orchestrator ---
+_CLASS_K = (0x85EBCA6B, 0xC2B2AE35, 0x27D4EB2F, 0x165667B1, 0xD3A2646D, 0xFD7046C5, 0xB55A4F09, 0x9E3779B9,
+            0x7F4A7C15, 0x94D049BB, 0xBF58476D, 0x1CE4E5B9, 0x2545F491, 0x4F6CDD1D, 0x6C62272F, 0x07BB0143)
+
+
+def conj_prefix(codes):
+    """letters the cyclic reduction strips from each end (acx_word.h:cyclic_reduce): p = letters on which the word and its inverse
+    agree from the front -- for a freely reduced word r = u c u^-1 that is |u| and stops before the middle --, 0 when that would
+    eat the whole word"""
+    n = len(codes)
+    p = 0
+    while p < n and codes[p] == (codes[n - 1 - p] ^ 3):
+        p += 1
+    return 0 if (p == n or 2 * p >= n) else p
+
+
+def inner_letter(codes):
+    """csrc/acx_owner.h: 0 when u is empty (r = u c u^-1), else 1 + the code of u's last letter.  A conjugation of r by a generator
+    adds or removes a letter at the FRONT of u: this only changes while |u| <= 1."""
+    p = conj_prefix(codes)
+    return 1 + codes[p - 1] if p else 0
+
+
+def class_hash(codes):
+    """csrc/acx_owner.h: class_hash on the 2-bit letter codes of one relator (-2, -1, +1, +2 -> 0, 1, 2, 3; inverse = code ^ 3).
+    A function of the word's cyclic reduction read as a CYCLIC word -- its length and the multiset of (letter, cyclic successor)
+    pairs -- so the eight conjugation moves of ACMove (ac_moves.py:192-229) do not change it."""
+    p = conj_prefix(codes)
+    c = codes[p:len(codes) - p]
+    n = len(c)
+    if n == 0:
+        return 0
+    h = (n * 0x9E3779B1) & 0xFFFFFFFF
+    for i in range(n):
+        x, y = c[i], c[(i + 1) % n]
+        if x ^ y != 3:
+            h = (h + _CLASS_K[4 * x + y]) & 0xFFFFFFFF
+    return h
+
+
 def owner_of(keys, world):
-    """Deterministic owner rank of each packed key [m, KW] int64 (same arithmetic on CPU and GPU tensors, and in
-    csrc/acx_shard.hip: shard_hash / owner_of_hash -- one multiply-xorshift round per key word, then the 32 bits from bit 20
-    of the hash scaled to [0, world): no division)."""
-    torch = _torch()
-    h = torch.zeros(keys.shape[0], dtype=torch.int64, device=keys.device)
-    for j in range(keys.shape[1]):
-        h = (h ^ keys[:, j]) * -7046029254386353131  # 0x9E3779B97F4A7C15 as int64, wraps
-        h = h ^ ((h >> 29) & 0x7FFFFFFFF)
-    return (((h >> 20) & 0xFFFFFFFF) * int(world)) >> 32
+    """Owner rank of each packed key (rows of KW int64 words: 2 for L <= 29 -- word | length << 58 per relator --, 4 for L <= 61:
+    two words per relator, the length in the top 6 bits of the second).  The same arithmetic as csrc/acx_owner.h, which
+    `acx_shard_owner` exposes (tests/test_sharded_cpu.py compares the two):
+    scale(mix(class_hash(r_0) + class_hash(r_1) + K0 inner_letter(r_0) + K1 inner_letter(r_1)), world).
+    A rank therefore owns most conjugation children of its own nodes, and most children never cross the exchange."""
+    rows = np.asarray(keys.cpu() if hasattr(keys, "cpu") else keys, dtype=np.int64).reshape(len(keys), -1)
+    half = rows.shape[1] // 2
+    bits = 64 * half
+    out = np.zeros(len(rows), np.int64)
+    for i, row in enumerate(rows):
+        csum = 0
+        for r in range(2):
+            k = 0
+            for j in range(half):
+                k |= (int(row[r * half + j]) & 0xFFFFFFFFFFFFFFFF) << (64 * j)
+            n = k >> (bits - 6)
+            codes = [(k >> (2 * t)) & 3 for t in range(n)]
+            csum += class_hash(codes) + inner_letter(codes) * (0x85EBCA77 if r else 0x9E3779B1)
+        h = ((csum & 0xFFFFFFFF) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        h ^= h >> 29
+        out[i] = (((h >> 20) & 0xFFFFFFFF) * int(world)) >> 32
+    return out
 
 
 _SIDE_STREAMS = {}
@@ -295,25 +367,35 @@ class _RegionOverflow(RuntimeError):
 
 
 def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False, comm=None,
-                engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None, region_fill=None, timeline=False):
+                engine_factory=None, batch_parents=None, want_stats=False, log_fraction=0.5, overlap=None, region_fill=None, timeline=False):
     """`bfs` with the frontier sharded over the ranks of `comm`: see _bfs_sharded_once.  A search whose adaptive (or given) region
     capacity turns out too tight fails on every rank at the same chunk and is rerun from scratch with the safe default."""
     kw = dict(verbose=verbose, cyclically_reduce_after_moves=cyclically_reduce_after_moves, comm=comm, engine_factory=engine_factory,
-              batch_parents=batch_parents, want_stats=want_stats, log_fraction=log_fraction, overlap=overlap, timeline=timeline)
-    try:
-        return _bfs_sharded_once(presentation, max_nodes_to_explore, region_fill=region_fill, **kw)
-    except _RegionOverflow:
-        out = _bfs_sharded_once(presentation, max_nodes_to_explore, region_fill=FILL_DEFAULT, **kw)
-        if want_stats:
-            out[2]["region_overflow_reruns"] = 1
+              want_stats=want_stats, log_fraction=log_fraction, overlap=overlap, timeline=timeline)
+    # (the owner function keeps families of states on one rank -- csrc/acx_owner.h --, so no capacity below the hard bound is safe
+    # for EVERY input: the third attempt uses it, with small chunks, since a region then has room for every child of its senders)
+    if batch_parents is None:
+        # a chunk's fixed costs (eight launches per rank) against the memory of its flag arrays: 2^21 global parents, 2^22 from 8 ranks
+        # on, where a rank's share of a chunk is small (profiles/r5_shard_thread_ranks_device_work.txt: 3.7 -> 3.4 ms per rank at 8)
+        batch_parents = 1 << (22 if (comm is not None and comm.world >= 8) else 21)
+    reruns = 0
+    for fill, bp in ((region_fill, batch_parents), (FILL_DEFAULT, batch_parents), (FILL_HARD, min(batch_parents, 1 << 17))):
+        try:
+            out = _bfs_sharded_once(presentation, max_nodes_to_explore, region_fill=fill, **dict(kw, batch_parents=bp))
+        except _RegionOverflow:
+            reruns += 1
+            continue
+        if want_stats and reruns:
+            out[2]["region_overflow_reruns"] = reruns
         return out
+    raise RuntimeError("sharded bfs: a region overflowed under the hard capacity bound")  # (cannot happen: acx_shard_layout)
 
 
 def _bfs_sharded_once(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False, comm=None,
                       engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None, region_fill=None, timeline=False):
     """Same contract as `bfs`: returns (is_search_successful, path or None) [+ stats dict], identical on every rank.
     `batch_parents`: global frontier positions per chunk.  `log_fraction`: expected expanded parents / max_nodes, sizes the
-    record log (it grows by doubling if the estimate is short).  `overlap`: expansion + exchange of chunk k + 1 on a side stream, started beside the dedup of chunk k ("insert": the default when there is an exchange, i.e. world > 1) or beside its commit ("commit"); False: one stream, the default without an exchange.  `region_fill`: capacity of the exchanged regions in 1/256 of the even share of all children -- None: adaptive (1.3 x the fullest region of the previous level, at most the default), an int: that value for every chunk, FILL_DEFAULT: the safe 1.25 x; a search whose tighter regions overflow is rerun with the default.  `timeline` (GPU, with want_stats): HIP events around every stage of every chunk -- stats["timeline"] gives the median device time of
+    record log (it grows by doubling if the estimate is short).  `overlap`: expansion + exchange of chunk k + 1 on a side stream, started beside the dedup of chunk k ("insert": the default when there is an exchange, i.e. world > 1) or beside its commit ("commit"); False: one stream, the default without an exchange.  `region_fill`: capacity of the exchanged regions in 1/256 of the even share of all children -- None: adaptive (1.25 x the fullest region of the previous level, at most the default), an int: that value for every chunk, FILL_DEFAULT: 1.25 x the even share of all children, FILL_HARD: the bound that cannot overflow; a search whose regions overflow is rerun with the default, then with the hard bound.  `timeline` (GPU, with want_stats): HIP events around every stage of every chunk -- stats["timeline"] gives the median device time of
     expansion, all-to-all, dedup, mask all-reduce and commit per full-size chunk, the chunk period and `overlap_effective` = their
     sum / the period (1 = the stages run one after the other, > 1 = the side stream hides work).  A diagnostic: the events cost a
     little, so timed runs leave it off."""
@@ -388,7 +470,7 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
 
     # root: node 0 of its owner, global frontier position 0
     root = engine.root_record(p)
-    owner_root = int(owner_of(torch.tensor(root[None, :KW], dtype=torch.int64), world)[0])
+    owner_root = int(engine.root_owner(root) if hasattr(engine, "root_owner") else owner_of(root[None, :KW], world)[0])
     engine.seed(root if rank == owner_root else None)
     F = 1
     levels = chunks = 0
@@ -434,6 +516,9 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
             st.update(setup_seconds=t_ready - t_begin, loop_seconds=time.perf_counter() - t_ready, region_fill_q8=fills[-4:] if adaptive else fill, region_fill_all=list(fills) if adaptive else fill)
             if tl_rows:
                 st["timeline"] = _timeline_summary(torch, tl_rows, B)
+            st["local_nodes"] = int(ctl[CTL_NODES])
+            if _CHECK_OWNERS and hasattr(engine, "check_owners"):
+                st["owner_mismatches"] = engine.check_owners()
             return ok, path, st
         return ok, path
 
@@ -501,7 +586,7 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
         """expansion + exchange of one chunk on the side stream -> (n_par, event after which its receive area is complete, dead, stamps)"""
         nonlocal tight_used, fail_hdr_chunk
         n_par = c1 - c0
-        tight_used = tight_used or (exchange and 0 < fill < FILL_DEFAULT)
+        tight_used = tight_used or (exchange and 0 < fill < FILL_HARD)
         with _on_side():
             # the expansion runs at most ONE chunk ahead of the dedup: the children a rank owns itself claim their table slots from
             # the expansion kernel, and the engine tells the claims of two chunks in flight apart by the chunk's parity
@@ -661,8 +746,10 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
         F_prev, F, nodes_seen = F, int(ctl[CTL_NEXT_COUNT]), int(ctl[CTL_NODES_GLOBAL])
         if adaptive:  # the fullest region any rank received in this level (0: no chunk large enough to tell) sizes the next level's regions
             lf = closing[2]
-            # (measured level by level on five searches, tools/scratch/shard_fill_levels.py: the fullest region is 0.33 (cyclical) to 0.6 of
-            # the even share, falls by up to 25 % from one level to the next and rises by at most 7 %)
-            fill = FILL_DEFAULT if lf == 0 else min(FILL_DEFAULT, max(64, lf * 13 // 10 + 8))
+            # (round 3, owner = hash of the whole key, measured level by level on five searches: the fullest region falls by up to 25 % from
+            # one level to the next and rises by at most 7 %.  Round 5's owner function sends a quarter of the children: on AK(3) the
+            # fullest region of a level is 0.58 / 0.44 / 0.36 / 0.34 of the even share of ALL children at 8 ranks, falling as the
+            # conjugators grow.  An overflow only costs a rerun.)
+            fill = FILL_DEFAULT if lf == 0 else min(FILL_DEFAULT, max(24, lf * 5 // 4 + 12))
             fills.append(fill)
     return finish(False, None, min_len)

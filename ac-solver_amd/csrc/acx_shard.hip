@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "acx_bfs.h"  // search_move: the shorter move code for searches whose root is in normal form
+#include "acx_owner.h"  // class_hash, inner_letter, owner_of_sum: which rank owns a state
 
 #ifndef ACX_SHARD_SUBREGIONS
 #define ACX_SHARD_SUBREGIONS 16
@@ -85,23 +86,47 @@ template <> struct recio<u128> {
     }
 };
 
-// The hash of the sharded engine: ONE value per key serves the owner rank, the LDS fold slot of the expansion, the stamp-table
-// bucket and the 28-bit fingerprint.  k_shard_expand is bound by vector issue, and the hash of the fused search (hash_key:
-// five 64-bit multiplies, i.e. fifteen quarter-rate 32-bit multiplies per child) plus a second hash and a 64-bit modulo for
-// the owner were ~40 % of its vector cycles; this one is one multiply-xorshift round per key word.  Bits: table bucket =
-// low bits, fold slot = bits 40.., fingerprint = bits 36..63, owner = the 32 bits from bit 20 scaled to [0, world)
-// (ac_solver/search/sharded.py:owner_of does the same arithmetic on the key's int64 words).
-ACX_HD uint64_t shard_mix(uint64_t h, uint64_t w) {
-    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
-    return h ^ (h >> 29);
-}
+// The key hash of the sharded engine: ONE value per key serves the LDS fold slot of the expansion, the stamp-table bucket and the
+// 27-bit fingerprint.  k_shard_expand is bound by vector issue, and the hash of the fused search (hash_key: five 64-bit
+// multiplies, i.e. fifteen quarter-rate 32-bit multiplies per child) was ~30 % of its vector cycles; this one is one
+// multiply-xorshift round per key word (acx_owner.h: shard_mix).  Bits: table bucket = low bits, fold slot = bits 40..,
+// fingerprint = bits 37..63.  The OWNER of a key is a different function (acx_owner.h): it only looks at the conjugacy classes of
+// the two relators, so that most children are owned by the rank that makes them.
 ACX_HD uint64_t shard_hash(uint64_t k0, uint64_t k1) { return shard_mix(shard_mix(0, k0), k1); }
 ACX_HD uint64_t shard_hash(u128 k0, u128 k1) {
     uint64_t h = shard_mix(shard_mix(0, (uint64_t)k0), (uint64_t)(k0 >> 64));
     return shard_mix(shard_mix(h, (uint64_t)k1), (uint64_t)(k1 >> 64));
 }
-ACX_HD uint32_t owner_of_hash(uint64_t h, uint32_t world) { return (uint32_t)(((uint64_t)(uint32_t)(h >> 20) * world) >> 32); }
-template <typename W> ACX_HD uint32_t owner_of_key(W k0, W k1, uint32_t world) { return owner_of_hash(shard_hash(k0, k1), world); }
+// what names the owner of a state (acx_owner.h): the class hashes of its two relators and their inner letters.  Every node of a
+// multi-rank engine carries them (ShardDev::cls, ::inn): a child inherits what its move does not change.
+struct OwnerParts {
+    uint32_t c0, c1, in0, in1;
+    ACX_HD uint32_t sum() const { return owner_sum(c0, c1, in0, in1); }
+};
+template <typename W> ACX_HD OwnerParts owner_parts_of_key(W k0, W k1) {
+    OwnerParts o;
+    o.c0 = class_hash<W, kSearchSafe>(keyops<W>::word(k0), keyops<W>::len(k0));
+    o.c1 = class_hash<W, kSearchSafe>(keyops<W>::word(k1), keyops<W>::len(k1));
+    o.in0 = inner_letter<W, kSearchSafe>(keyops<W>::word(k0), keyops<W>::len(k0));
+    o.in1 = inner_letter<W, kSearchSafe>(keyops<W>::word(k1), keyops<W>::len(k1));
+    return o;
+}
+template <typename W> ACX_HD uint32_t owner_of_key(W k0, W k1, uint32_t world) { return owner_of_sum(owner_parts_of_key<W>(k0, k1).sum(), world); }
+// the parts of the child that move `a` made of a node with parts `o`, in a normal-form search: the move rewrote ONE relator (even
+// action ids r_1, ac_moves.py:192-206), a conjugation (a >= 4) kept its class, and only its inner letter has to be looked up again
+template <typename W> ACX_HD OwnerParts owner_parts_of_child(OwnerParts o, uint32_t a, const Pres<W>& s) {
+    if (a & 1u) {
+        if (a < 4u) o.c0 = class_hash<W, kSearchSafe>(s.w0, s.n0);
+        o.in0 = inner_letter<W, kSearchSafe>(s.w0, s.n0);
+    } else {
+        if (a < 4u) o.c1 = class_hash<W, kSearchSafe>(s.w1, s.n1);
+        o.in1 = inner_letter<W, kSearchSafe>(s.w1, s.n1);
+    }
+    return o;
+}
+template <typename W> ACX_HD OwnerParts owner_parts_of_pres(const Pres<W>& s) {
+    return owner_parts_of_key<W>(keyops<W>::make(s.w0, s.n0), keyops<W>::make(s.w1, s.n1));
+}
 
 // ---- control block (device, int64 words; include/acx.h: ACX_SHARD_CTL_*) ---------------------------------------------------
 enum : int {
@@ -137,13 +162,14 @@ template <typename W> struct ShardDev {
     uint32_t* gpos;      // global FIFO position inside the node's level
     uint8_t* act;
     uint8_t* tlen;
+    uint2* cls;          // world > 1: class hashes of the node's two relators (acx_owner.h) -- a child made by a conjugation inherits them
+    uint8_t* inn;        // world > 1: inner letters of the two relators, in0 | in1 << 4
     unsigned long long* stab;
     uint32_t stmask;
     int64_t* log;        // record log = receive areas of all chunks
     uint8_t* btook;      // one byte per tag of a chunk: took a slot / was pushed out again (both zero between chunks); TWO sets, `flag_stride`
     uint8_t* brepl;      // bytes apart, indexed by the chunk's parity (ChunkGeo::par): the expansion of chunk k + 1 claims beside the dedup of chunk k
     size_t flag_stride;
-    uint32_t born;       // 1: locally owned children of local parents claim their slot in k_shard_expand (BORN stamps); 0: everything travels as a record
     int32_t* lmask;      // [chunk parents] 12-bit masks: new states of this rank
     int32_t* gmask;      // the same for all ranks after the caller's all-reduce, TWO parents per word (parent p: bits 16 (p & 1) .. + 11 of word
                          // p >> 1): every (parent, action) child has one owner, so the sum of the ranks' words is their union and no field carries
@@ -179,20 +205,13 @@ __device__ __forceinline__ uint32_t gmask_of(const int32_t* __restrict__ gmask, 
 // moves the whole region.  The orchestrator therefore passes the fullest region of the previous level x 1.3
 // (ctl[C_LEVEL_FILL]); an overflow fails the search (FAIL_REGION) and the orchestrator reruns it with the default.
 constexpr int kShardFillDefault = 320;
-// ACX_SHARD_BORN=0 switches the born stamps off (A/B measurements; every child then travels as a record, round 3's data path)
-static inline bool shard_born_enabled() {
-    static const bool on = [] {
-        const char* e = getenv("ACX_SHARD_BORN");
-        return !e || atoi(e) != 0;
-    }();
-    return on;
-}
+constexpr int kShardFillHard = 1 << 20;  // fill_q8 at or above this: the hard bound itself (the orchestrator's last resort after two overflows)
 static inline void shard_layout(int64_t n_par, int world, int RW, int fill_q8, int64_t* subcap, int64_t* region_words, int64_t* even_out = nullptr) {
     const int64_t n_blocks = (12 * n_par + kExpandTile - 1) / kExpandTile;
     const int64_t hard = (n_blocks + kShardSub - 1) / kShardSub * kExpandTile;  // every workgroup that reserves in a sub-region sends it all it has
     int64_t cap = hard, even = 0;
-    if (world == 1 && shard_born_enabled()) cap = 0;  // every child is born where it is owned: a region is its header
-    if (world > 1) {  // the owner hash spreads the records evenly
+    if (world == 1) cap = 0;  // every child is born where it is owned: a region is its header
+    if (world > 1 && fill_q8 < kShardFillHard) {
         if (fill_q8 <= 0 || fill_q8 > kShardFillDefault) fill_q8 = kShardFillDefault;
         even = (12 * n_par + (int64_t)world * world * kShardSub - 1) / ((int64_t)world * world * kShardSub);
         cap = std::min<int64_t>(hard, (even * fill_q8 + 255) / 256 + 2 * kExpandTile);
@@ -294,6 +313,10 @@ template <typename W, int MODE> __device__ __forceinline__ void stamp_key(const 
     }
 }
 
+// the action of item `it` (0 .. 2) of wave `w` (0 .. 3) of a group of four in k_shard_expand: one of the four concatenations
+// (it == 0: actions 0 .. 3) and two of the eight conjugations per wave
+__device__ __forceinline__ uint32_t expand_action(uint32_t w, int it) { return w + 4u * (uint32_t)it; }
+
 // action that undoes action a on a presentation in normal form, cyclical = False (ac_moves.py:165-179: 0 <-> 2, 1 <-> 3 are
 // r_i <- r_i r_j^{+-1}; 4 <-> 8, 5 <-> 9, 6 <-> 10, 7 <-> 11 conjugate by a generator and its inverse)
 __device__ __forceinline__ uint32_t inverse_action(uint32_t a) { return a < 4 ? a ^ 2u : (a < 8 ? a + 4u : a - 4u); }
@@ -307,7 +330,8 @@ __device__ __forceinline__ uint32_t inverse_action(uint32_t a) { return a < 4 ? 
 // before it looks it up (breadth_first.py:84).
 //
 // A workgroup serves 128 parents x 12 actions (8 waves; 64 x 12 with 4): wave w of a group of four, item it computes action
-// 3 w + it for the group's 64 parents, ONE ACTION PER WAVE-INSTRUCTION.  The kernel is bound by vector issue (6 waves per SIMD, 27 % of the wave cycles issuing:
+// w + 4 it for the group's 64 parents (round 5; 3 w + it before: every wave now has ONE concatenation, it = 0, and two
+// conjugations -- the concatenation children are the ones whose owner has to be computed), ONE ACTION PER WAVE-INSTRUCTION.  The kernel is bound by vector issue (6 waves per SIMD, 27 % of the wave cycles issuing:
 // profiles/r3_shard_1e8_pmc_summary.txt), and with a lane per (parent, action) in tag order -- the first version, as the fused
 // k_bfs_expand_insert has it -- the twelve actions of a parent sit in adjacent lanes, so every wave ran the concatenation AND
 // the conjugation path of the move for every child.  With the action uniform across the wave only the taken path issues.
@@ -339,22 +363,31 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
     const bool live = p < np;
     W pk0 = 0, pk1 = 0;
     uint32_t gp = 0, pa = 0xffu;
+    OwnerParts po = {0u, 0u, 0u, 0u};  // class hashes and inner letters of the parent's relators (acx_owner.h)
     if (live) {
         pk0 = d.k0[id];
         pk1 = d.k1[id];
         gp = d.gpos[id];
         pa = d.act[id];  // 0xff for the root
+        if (!SOLO) {
+            const uint2 c = d.cls[id];
+            const uint32_t in = d.inn[id];
+            po = OwnerParts{c.x, c.y, in & 15u, in >> 4};
+        }
     }
     W c0[kExpandItems], c1[kExpandItems];
     bool send_it[kExpandItems];
+    uint32_t csum[kExpandItems];  // owner_sum of the child: names its owner
     uint32_t tl_min = 0xFFFFFFFFu;
     const uint32_t hsub = blockIdx.x % kShardSub;
 #pragma unroll
     for (int it = 0; it < kExpandItems; it++) {
-        const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w * kExpandItems + it));  // uniform across the wave
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)expand_action(w, it));  // uniform across the wave
+        __builtin_assume(it == 0 ? a < 4u : a >= 4u);  // the item fixes the kind of move: no branch between concatenation and conjugation
         const uint32_t j = a * (uint32_t)kExpandParents + l;  // the child's slot in the tile (action major: conflict-free LDS rows)
         send_it[it] = false;
         c0[it] = c1[it] = 0;
+        csum[it] = 0;
         if (live) {
             Pres<W> s;
             key_to_pres<W>(pk0, pk1, s);
@@ -372,6 +405,13 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
                     atomicMin((unsigned long long*)(send + (int64_t)(o * kShardSub + hsub) * g.region_words + 1), tag);
             send_it[it] = !(c0[it] == pk0 && c1[it] == pk1);
             if (MODE == kMoveNf && pa < 12u && a == inverse_action(pa)) send_it[it] = false;
+            if (!SOLO && send_it[it]) {
+                // what names the child's owner.  In a normal-form search a move leaves the other relator alone and a conjugation (a >= 4)
+                // keeps the class of the one it rewrites: only a concatenation (it == 0) has a class hash to compute, the others look
+                // up one inner letter.  A search whose root is not in normal form (its first level simplifies BOTH relators) computes
+                // everything, for every child.
+                csum[it] = (MODE == kMoveGeneral ? owner_parts_of_pres<W>(s) : owner_parts_of_child<W>(po, a, s)).sum();
+            }
         }
         s_k0[j] = c0[it];
         s_k1[j] = c1[it];
@@ -387,7 +427,7 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
     uint64_t hk[kExpandItems];
 #pragma unroll
     for (int it = 0; it < kExpandItems; it++) {
-        const uint32_t a = w * kExpandItems + it, j = a * (uint32_t)kExpandParents + l;
+        const uint32_t a = expand_action(w, it), j = a * (uint32_t)kExpandParents + l;
         me[it] = ((12u * l + a) << kTileBits) | j;
         ls[it] = 0;
         hk[it] = 0;
@@ -424,12 +464,12 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
         if (SOLO) {
             born[it] = send_it[it] && s_slot[ls[it]] == me[it];
         } else if (send_it[it] && s_slot[ls[it]] == me[it]) {
-            owner[it] = owner_of_hash(hk[it], d.world);
-            if (d.born && owner[it] == d.rank) {  // stays home: claims its slot below, no record
+            owner[it] = owner_of_sum(csum[it], d.world);
+            if (owner[it] == d.rank) {  // stays home: claims its slot below, no record
                 born[it] = true;
                 owner[it] = 0xFFFFFFFFu;
             } else {
-                atomicOr(&s_bits[owner[it] * (uint32_t)kExpandParents + l], 1u << (w * kExpandItems + it));
+                atomicOr(&s_bits[owner[it] * (uint32_t)kExpandParents + l], 1u << expand_action(w, it));
             }
         }
     }
@@ -454,7 +494,7 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
 #pragma unroll
     for (int it = 0; it < kExpandItems; it++)
         if (owner[it] != 0xFFFFFFFFu) {
-            const uint32_t e = s_bits[owner[it] * (uint32_t)kExpandParents + l], a = w * kExpandItems + it;
+            const uint32_t e = s_bits[owner[it] * (uint32_t)kExpandParents + l], a = expand_action(w, it);
             pos[it] = (e >> 16) + (uint32_t)__popc(e & ((1u << a) - 1u));
         }
     if (tid < d.world && s_cnt[tid])
@@ -465,7 +505,7 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
         if (owner[it] == 0xFFFFFFFFu) continue;
         const uint32_t at = s_base[owner[it]] + pos[it];
         if (at >= g.subcap) continue;  // overflow: the count in the header says so, the receiver reports it
-        const uint32_t a = w * kExpandItems + it;
+        const uint32_t a = expand_action(w, it);
         int64_t* r = send + (int64_t)(owner[it] * kShardSub + hsub) * g.region_words + kShardHdr + (int64_t)at * recio<W>::RW;
         recio<W>::put(r, c0[it], c1[it]);
         // record word: parent's local id | (tag relative to the chunk) << 32
@@ -482,7 +522,7 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
 #pragma unroll
     for (int it = 0; it < kExpandItems; it++) {
         if (!born[it]) continue;
-        const uint32_t a = w * kExpandItems + it;
+        const uint32_t a = expand_action(w, it);
         const unsigned long long mine = (hk[it] & kStampFpMask) | kStampBorn | ((unsigned long long)id << 4) | a;
         uint32_t base = (uint32_t)hk[it] & d.stmask & ~3u, probes = 0;
         bool open = true, took = false;
@@ -895,6 +935,9 @@ template <typename W> __global__ void __launch_bounds__(256) k_shard_commit(Shar
         d.tlen[id] = (uint8_t)(keyops<W>::len(k0) + keyops<W>::len(k1));
         d.gpos[id] = dec.gpos_base + d.gblk[tile] + d.gpre[par] + (uint32_t)__popc(gmask_of(d.gmask, par) & below);
         d.pref[id] = (int64_t)(((unsigned long long)(r / kShardSub) << 40) | (x & 0xFFFFFFFFull));
+        const OwnerParts o = owner_parts_of_key<W>(k0, k1);  // (a record only exists at world > 1, and most children never become one: acx_owner.h)
+        d.cls[id] = make_uint2(o.c0, o.c1);
+        d.inn[id] = (uint8_t)(o.in0 | (o.in1 << 4));
     }
 }
 
@@ -911,6 +954,8 @@ template <typename W, int MODE> __global__ void __launch_bounds__(kBornParents) 
     __shared__ uint32_t s_q[kBornParents], s_lm[kBornParents], s_idb[kBornParents], s_gpb[kBornParents], s_gm[kBornParents];
     __shared__ uint16_t s_list[kBornParents * 12];
     __shared__ uint32_t s_wsum[kBornParents / 64];
+    __shared__ uint2 s_cls[kBornParents];
+    __shared__ uint8_t s_inn[kBornParents];
     ACX_VGPR_PAD_W(W, "v47", "v63");
     const ChunkDec dec = *d.dec;
     if (!dec.commit) return;
@@ -932,6 +977,10 @@ template <typename W, int MODE> __global__ void __launch_bounds__(kBornParents) 
         s_gpb[tid] = dec.gpos_base + d.gblk[tile] + d.gpre[q];
         s_pk0[tid] = d.k0[i];
         s_pk1[tid] = d.k1[i];
+        if (d.cls) {
+            s_cls[tid] = d.cls[i];
+            s_inn[tid] = d.inn[i];
+        }
     }
     const uint32_t cnt = (uint32_t)__popc(lm);
     uint32_t incl = cnt;
@@ -961,6 +1010,11 @@ template <typename W, int MODE> __global__ void __launch_bounds__(kBornParents) 
         d.tlen[id] = (uint8_t)(s.n0 + s.n1);
         d.gpos[id] = s_gpb[pl] + (uint32_t)__popc(s_gm[pl] & below);
         d.pref[id] = (int64_t)(((unsigned long long)d.rank << 40) | (unsigned long long)(first + pl));
+        if (d.cls) {  // world > 1: what names the node's owner -- its parent's parts, except for what the move rewrote (as k_shard_expand)
+            const OwnerParts o = MODE == kMoveGeneral ? owner_parts_of_pres<W>(s) : owner_parts_of_child<W>(OwnerParts{s_cls[pl].x, s_cls[pl].y, s_inn[pl] & 15u, (uint32_t)s_inn[pl] >> 4}, a, s);
+            d.cls[id] = make_uint2(o.c0, o.c1);
+            d.inn[id] = (uint8_t)(o.in0 | (o.in1 << 4));
+        }
     }
 }
 
@@ -973,11 +1027,28 @@ template <typename W> __global__ void k_shard_seed(ShardDev<W> d, W k0, W k1) {
     d.tlen[0] = (uint8_t)(keyops<W>::len(k0) + keyops<W>::len(k1));
     d.gpos[0] = 0;
     d.pref[0] = -1;
+    if (d.cls) {
+        const OwnerParts o = owner_parts_of_key<W>(k0, k1);
+        d.cls[0] = make_uint2(o.c0, o.c1);
+        d.inn[0] = (uint8_t)(o.in0 | (o.in1 << 4));
+    }
     recio<W>::put(d.log, k0, k1);
     d.log[recio<W>::KW] = 0;
     const uint64_t hk = shard_hash(k0, k1);
     d.stab[(uint32_t)hk & d.stmask & ~3u] = hk & kStampFpMask;  // a record stamp with offset 0: first slot of its bucket
     d.ctl[C_NODES] = 1;
+}
+
+// test hook (acx_shard_check_owners): every local node must live on the rank that owns its key, and the class hashes it carries
+// (inherited along conjugations) must be the ones its key gives
+template <typename W> __global__ void __launch_bounds__(256) k_shard_check_owners(ShardDev<W> d, unsigned long long* __restrict__ bad) {
+    ACX_VGPR_PAD_W(W, "v63", "v95");
+    const uint32_t n = (uint32_t)d.ctl[C_NODES];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const OwnerParts o = owner_parts_of_key<W>(d.k0[i], d.k1[i]);
+        const bool ok = owner_of_sum(o.sum(), d.world) == d.rank && (!d.cls || (d.cls[i].x == o.c0 && d.cls[i].y == o.c1 && d.inn[i] == (uint8_t)(o.in0 | (o.in1 << 4))));
+        if (!ok) atomicAdd(bad, 1ull);
+    }
 }
 
 template <typename W> __global__ void k_shard_find(ShardDev<W> d, uint32_t gpos, int64_t* __restrict__ out) {
@@ -1086,7 +1157,6 @@ template <typename W> struct ShardEngine {
         d.cyclical = cyclical;
         d.world = (uint32_t)world_;
         d.rank = (uint32_t)rank_;
-        d.born = shard_born_enabled() ? 1u : 0u;
         rank = rank_;
         world = world_;
         {
@@ -1103,7 +1173,10 @@ template <typename W> struct ShardEngine {
         shard_layout((int64_t)chunk_parents, world, recio<W>::RW, 0, &subcap, &region_words);
         // what a chunk can put into the table beyond the nodes it commits: the records it receives + the children born here, of
         // the chunk being dedup'ed and of the one whose expansion runs ahead of it
-        const uint64_t chunk_records = (uint64_t)subcap * kShardSub * (uint64_t)world + (d.born ? 2 * (12 * chunk_parents / (uint64_t)world + kExpandTile) : 0);
+        // (a rank's share of a chunk's parents: the owner function keeps families of states together, so a chunk of consecutive frontier
+        // positions is shared out less evenly than the nodes as a whole -- 1.1-1.4 x the even share at 8 ranks, tools/owner_balance.cpp)
+        const uint64_t local_parents = world == 1 ? chunk_parents : std::min<uint64_t>(chunk_parents, 2 * chunk_parents / (uint64_t)world);
+        const uint64_t chunk_records = (uint64_t)subcap * kShardSub * (uint64_t)world + 2 * (12 * local_parents + kExpandTile);
         n_slots = 1024;
         while (n_slots < 2 * (cap_nodes + chunk_records)) n_slots <<= 1;
         if (n_slots > (1ull << 31) || cap_nodes > (1ull << 31)) return fail(ACX_E_INVAL, "acx_shard: capacity too large for 32-bit node ids");
@@ -1122,6 +1195,8 @@ template <typename W> struct ShardEngine {
             d.gpos = (uint32_t*)take(b, cap_nodes * 4);
             d.act = (uint8_t*)take(b, cap_nodes);
             d.tlen = (uint8_t*)take(b, cap_nodes);
+            d.cls = world > 1 ? (uint2*)take(b, cap_nodes * 8) : nullptr;
+            d.inn = world > 1 ? (uint8_t*)take(b, cap_nodes) : nullptr;
             if (pass == 0 && nodes_buf.alloc(o)) return ACX_E_NOMEM;
         }
         const uint64_t n_tiles = (chunk_parents + kScanTile - 1) / kScanTile + 1;
@@ -1260,7 +1335,7 @@ static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int lev
     if (np_max > 0) {
         const dim3 grid((unsigned)((np_max + kExpandParents - 1) / kExpandParents));
         const size_t lds = (size_t)E.world * kExpandParents * 4;  // s_bits
-        if (E.world == 1 && E.d.born) {
+        if (E.world == 1) {
             if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_expand<W, kMoveNf, true>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
             else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_expand<W, kMoveNfCyclical, true>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
             else hipLaunchKernelGGL((k_shard_expand<W, kMoveGeneral, true>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
@@ -1305,7 +1380,7 @@ template <typename W> static int shard_chunk_commit(ShardEngine<W>& E, int64_t m
     if (E.commit_wgs) gx = std::min(tiles, std::max(1u, E.commit_wgs / regions));
     if (tiles) hipLaunchKernelGGL(k_shard_commit<W>, dim3(gx, regions), dim3(256), 0, st, E.d, geo);
     const int64_t np_max = std::min<int64_t>((int64_t)geo.n_par, (int64_t)(E.lvl_hi_host - E.lvl_lo_host));  // this rank's share of the chunk's parents, at most
-    if (E.d.born && np_max > 0) {
+    if (np_max > 0) {
         const dim3 grid((unsigned)((np_max + kBornParents - 1) / kBornParents));
         if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_commit_born<W, kMoveNf>), grid, dim3(kBornParents), 0, st, E.d, geo);
         else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_commit_born<W, kMoveNfCyclical>), grid, dim3(kBornParents), 0, st, E.d, geo);
@@ -1460,6 +1535,32 @@ int acx_shard_fail(acx_shard* h, void* stream) {
         if (int rc = E.await_ready((hipStream_t)stream)) return rc;
         hipLaunchKernelGGL(k_shard_fail, dim3(1), dim3(1), 0, (hipStream_t)stream, E.d.ctl, (unsigned long long)FAIL_HOST);
         ACX_HIP_TRY(hipGetLastError());
+    });
+    return ACX_OK;
+}
+
+int acx_shard_owner(int L, const int64_t* h_key_words, int world) {
+    if (L < 1 || L > 61 || !h_key_words || world < 1) return fail(ACX_E_INVAL, "acx_shard_owner: bad argument");
+    if (L <= 29) {
+        uint64_t k0, k1;
+        recio<uint64_t>::get(h_key_words, k0, k1);
+        return (int)owner_of_key<uint64_t>(k0, k1, (uint32_t)world);
+    }
+    u128 k0, k1;
+    recio<u128>::get(h_key_words, k0, k1);
+    return (int)owner_of_key<u128>(k0, k1, (uint32_t)world);
+}
+
+int acx_shard_check_owners(acx_shard* h, int64_t* n_bad, void* stream) {
+    if (!h || !n_bad) return fail(ACX_E_INVAL, "acx_shard_check_owners: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, {
+        hipStream_t st = (hipStream_t)stream;
+        if (int rc = E.await_ready(st)) return rc;
+        ACX_HIP_TRY(hipMemsetAsync(E.d_find, 0, 8, st));
+        hipLaunchKernelGGL(k_shard_check_owners<W>, dim3(1024), dim3(256), 0, st, E.d, (unsigned long long*)E.d_find);
+        ACX_HIP_TRY(hipGetLastError());
+        ACX_HIP_TRY(hipMemcpyAsync(n_bad, E.d_find, 8, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipStreamSynchronize(st));
     });
     return ACX_OK;
 }

@@ -216,7 +216,9 @@ int acx_search_many(int kind, const int8_t *h_presentations, int64_t n, int L, i
                     int64_t *path_n, acx_search_stats *stats, int32_t *rc_out);
 
 /* ---- sharded BFS frontier (one engine per GPU) ---------------------------------------------------
- * The multi-GPU form of bfs (breadth_first.py:15-97): states are partitioned by hash(key) mod world.  A level is processed
+ * The multi-GPU form of bfs (breadth_first.py:15-97): states are partitioned over the ranks by acx_shard_owner -- a function of
+ * the conjugacy classes of the two relators, which the eight conjugation moves of ac_moves.py:192-229 leave alone, so that a rank
+ * owns most children of its own nodes (ac-solver_amd/csrc/acx_owner.h).  A level is processed
  * in chunks of consecutive global frontier positions [c0, c1); per chunk every rank calls
  *     acx_shard_chunk_expand  -> all-to-all of the send buffer into the receive area  (RCCL; nothing at world 1)
  *     acx_shard_chunk_insert  -> all-reduce (sum) of the child masks                   (RCCL; nothing at world 1)
@@ -243,10 +245,11 @@ int acx_search_many(int kind, const int8_t *h_presentations, int64_t n, int L, i
 typedef struct acx_shard acx_shard;
 int acx_shard_key_words(int L); /* 2 for L <= 29, 4 for L <= 61 */
 /* geometry of a chunk of n_parents global parents (pure host arithmetic, no device needed).  fill_q8: capacity of a region at
- * world > 1 in 1/256 of the even share of ALL children (+ two workgroups' worth); <= 0 or > 320: the default 320 = 1.25 x,
- * safe for any input.  The records really sent fill ~38 % of that, and the all-to-all moves whole regions: the orchestrator
- * passes 1.3 x the fullest region of the previous level (control word ACX_SHARD_CTL_LEVEL_FILL, max over the ranks) and reruns
- * the search with the default if a region ever overflows (failure code 1). */
+ * world > 1 in 1/256 of the even share of ALL children (+ two workgroups' worth); <= 0 or 321 .. 2^20 - 1: the default 320 =
+ * 1.25 x; >= 2^20: the hard bound (every workgroup sends a region all it has: safe for any input, world^2 x the even share).
+ * Only the children whose owner is another rank are sent (a few per cent, acx_owner.h), and the all-to-all moves whole regions:
+ * the orchestrator passes 1.3 x the fullest region of the previous level (control word ACX_SHARD_CTL_LEVEL_FILL, max over the
+ * ranks) and reruns the search with the default, then with the hard bound, if a region ever overflows (failure code 1). */
 int acx_shard_layout(int64_t n_parents, int world, int key_words, int fill_q8, int64_t *subregions, int64_t *subcap, int64_t *region_words);
 /* node_cap: local nodes; chunk_parents: the largest chunk (global parents) */
 acx_shard *acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t chunk_parents, int rank, int world);
@@ -255,6 +258,9 @@ int acx_shard_attach(acx_shard *h, int64_t *d_log, int64_t log_words, int64_t *d
 /* the root as a record (tag 0, parent_ref -1), host buffer of key_words + 2 int64; every rank calls it (it also selects
  * the move code of the search from the root's form) */
 int acx_shard_root_record(acx_shard *h, const int8_t *h_presentation, int64_t *h_record);
+/* rank that owns the state with these key words (the first key_words int64 of a record): pure host arithmetic, no device needed.
+ * Negative: an error code. */
+int acx_shard_owner(int L, const int64_t *h_key_words, int world);
 /* the owner of the root passes its record (local node 0, global position 0), every other rank NULL */
 int acx_shard_seed(acx_shard *h, const int64_t *h_record, void *stream);
 /* children of the local nodes of the running level whose global positions lie in [c0, c1), routed to their owners (children
@@ -291,6 +297,9 @@ int acx_shard_fail(acx_shard *h, void *stream);
 int acx_shard_find(acx_shard *h, int64_t gpos, int64_t *id, void *stream);
 /* h_info3 = (action, total_length, parent_ref = rank << 40 | local id) of a local node; the root has action -1, parent_ref -1 */
 int acx_shard_node_info(acx_shard *h, int64_t id, int64_t *h_info3);
+/* test hook: *n_bad = local nodes that do not live on the rank acx_shard_owner names for their key, or whose stored class hashes
+ * (inherited from the parent along conjugations) differ from the ones their key gives.  0 on a healthy engine. */
+int acx_shard_check_owners(acx_shard *h, int64_t *n_bad, void *stream);
 
 /* ---- PPO rollout: fused policy inference ---------------------------------------------------------------
  * The agent of ac_solver/agents/ppo_agent.py:11-109 -- actor and critic, each in_dim -> 256 -> 256 -> {n_actions, 1} with

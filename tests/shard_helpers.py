@@ -22,6 +22,7 @@ _INVERSE = {0: 2, 2: 0, 1: 3, 3: 1, 4: 8, 8: 4, 5: 9, 9: 5, 6: 10, 10: 6, 7: 11,
 
 
 FILL_DEFAULT = 320
+FILL_HARD = 1 << 20
 FILL_MIN_EVEN = 2048  # chunks with a smaller even share do not update the level's fill word (csrc/acx_shard.hip: k_shard_decide)
 
 
@@ -34,7 +35,7 @@ def layout(n_par, world, KW, fill_q8=0):
     n_blocks = -(-12 * n_par // TILE)
     hard = -(-n_blocks // SUB) * TILE
     cap = 0 if world == 1 else hard  # world 1: every child is born where it is owned (no record), a region is its header
-    if world > 1:
+    if world > 1 and fill_q8 < FILL_HARD:
         if fill_q8 <= 0 or fill_q8 > FILL_DEFAULT:
             fill_q8 = FILL_DEFAULT
         cap = min(hard, -(-even_share(n_par, world) * fill_q8 // 256) + 2 * TILE)

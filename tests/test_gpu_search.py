@@ -301,16 +301,18 @@ def test_sharded_bfs_hip_engine_matches_reference(search, golden_json, world):
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("world", [4, 8])
-def test_sharded_bfs_mid_size_thread_ranks_equal_the_fused_search(search, golden_json, world):
+def test_sharded_bfs_mid_size_thread_ranks_equal_the_fused_search(search, golden_json, world, monkeypatch):
     """Several ranks of the HIP engine on one GPU at sizes where every rank runs many full workgroups per chunk, several chunks per
     level and the two-stream pipeline: 3e6 nodes on AK(3) with 64-bit keys, 1e6 on a Miller-Schupp presentation with 128-bit keys
     (max_relator_length 36), 2e6 with cyclic reduction.  Every rank must return the fused search's node and expansion counts
     (itself checked against the oracle at 1e7, test_full_size_config3...) and the same (solved, path)."""
     from ac_solver import _acx
+    from ac_solver.search import sharded
     from ac_solver.search._common import run_search
     from ac_solver.search.sharded import bfs_sharded
     from tests.shard_helpers import run_threads
 
+    monkeypatch.setattr(sharded, "_CHECK_OWNERS", True)  # every node must live on the rank the owner function names (csrc/acx_owner.h)
     ak3 = np.zeros(50, np.int8)
     ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
     ak3[25:31] = [1, 2, 1, -2, -1, -2]
@@ -322,24 +324,40 @@ def test_sharded_bfs_mid_size_thread_ranks_equal_the_fused_search(search, golden
     def run(comm):
         return [bfs_sharded(p, b, cyclically_reduce_after_moves=c, comm=comm, batch_parents=bp, want_stats=True) for p, b, c, bp in cases]
 
-    for res in run_threads(world, run):
+    all_res = run_threads(world, run)
+    for res in all_res:
         for (ok, path, st), (wok, wpath, wst) in zip(res, want):
             assert (ok, path) == (wok, wpath)
             assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (world, st, wst)
+            assert st["owner_mismatches"] == 0, (world, st)
+    # the ranks' shares of the nodes: the owner function spreads them (1.03-1.10 x the mean at 8 ranks on these searches)
+    for k in range(len(cases)):
+        shares = [res[k][2]["local_nodes"] for res in all_res]
+        assert max(shares) * world <= 1.35 * sum(shares), (world, k, shares)
     assert want[3][0] and not want[0][0]
     if world == 4:
         # the regions of the exchange: adaptive capacity really in use (chunks of 2^16 parents: an even share of 3072 records per
-        # sub-region, about half of it sent), and a capacity that cannot hold (1/256 of the even share of 2^18-parent chunks + the
-        # two tiles of slack) overflows, fails every rank at the same chunk and is rerun with the default -- same counts
+        # sub-region), and a capacity that cannot hold overflows, fails every rank at the same chunk and is rerun with the
+        # default -- same counts
         fills = res[0][2]["region_fill_q8"]
         assert isinstance(fills, list) and fills and min(fills) < 320, fills
 
+        # (only the few per cent of the children that another rank owns are sent, csrc/acx_owner.h: it takes a level of ~2.7e6 parents in
+        # ONE chunk to push ~7e3 records at a sub-region of 3072 + 1/256 of the even share)
+        big = run_search(_acx.SEARCH_BFS, ak3, 10**7, False)
+
         def forced(comm):
-            return bfs_sharded(ak3, 3 * 10**6, comm=comm, batch_parents=1 << 18, want_stats=True, region_fill=1)
+            return bfs_sharded(ak3, 10**7, comm=comm, batch_parents=1 << 22, want_stats=True, region_fill=1)
 
         for ok, path, st in run_threads(world, forced):
-            assert (ok, path) == want[0][:2] and st["nodes"] == want[0][2]["nodes"] and st["expanded"] == want[0][2]["expanded"]
+            assert (ok, path) == big[:2] and st["nodes"] == big[2]["nodes"] and st["expanded"] == big[2]["expanded"]
             assert st.get("region_overflow_reruns") == 1, st
+        # ... and when the default capacity overflows as well (here: because the test shrinks it), the third attempt runs under the
+        # hard bound (every workgroup could send a region all it has) with small chunks
+        monkeypatch.setattr(sharded, "FILL_DEFAULT", 2)
+        for ok, path, st in run_threads(world, forced):
+            assert (ok, path) == big[:2] and st["nodes"] == big[2]["nodes"] and st["expanded"] == big[2]["expanded"]
+            assert st.get("region_overflow_reruns") == 2, st
 
 
 @pytest.mark.timeout(600)
@@ -418,38 +436,15 @@ def _key_words(state, L, KW):
 
 
 @pytest.mark.timeout(600)
-def test_sharded_bfs_with_every_child_as_a_record_still_matches(search):
-    """ACX_SHARD_BORN=0 (the A/B switch of DESIGN.md section 4: every child travels as a record, round 3's data path) is read once per
-    process, so a fresh interpreter runs it: world 1 and two thread ranks against the oracle, both key widths."""
-    import subprocess
-    import sys
-
-    code = """
-import sys, numpy as np
-sys.path[:0] = [%r, %r]
-from ac_solver.search.sharded import bfs_sharded
-from oracle import ac_oracle as O
-from tests.shard_helpers import run_threads
-ak3 = np.zeros(50, np.int8); ak3[:7] = [1, 1, 1, -2, -2, -2, -2]; ak3[25:31] = [1, 2, 1, -2, -1, -2]
-wide = np.zeros(72, np.int8); wide[:7] = [1, 1, 1, -2, -2, -2, -2]; wide[36:42] = [1, 2, 1, -2, -1, -2]
-for p, b, c in ((ak3, 300000, False), (ak3, 20000, True), (wide, 100000, False)):
-    want = O.bfs(p, b, cyclically_reduce_after_moves=c, stats=True)
-    got = bfs_sharded(p, b, cyclically_reduce_after_moves=c, batch_parents=1 << 12, want_stats=True)
-    assert got[:2] == want[:2] and got[2]["nodes"] == want[2]["nodes"] and got[2]["expanded"] == want[2]["expanded"], (b, c)
-    for r in run_threads(2, lambda comm: bfs_sharded(p, b, cyclically_reduce_after_moves=c, comm=comm, batch_parents=1 << 12, want_stats=True)):
-        assert r[:2] == want[:2] and r[2]["nodes"] == want[2]["nodes"], (b, c)
-print("ok")
-""" % (PKG, ROOT)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ACX_SHARD_BORN="0"), capture_output=True, text=True, timeout=500)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]
-
-
-@pytest.mark.parametrize("L", [25, 36])
-def test_device_routing_matches_owner_of(search, L):
-    """acx_shard_chunk_expand routes every child to the region of the rank the orchestrator's owner function names (owner_of),
-    both key widths, and sends exactly the children it should: not the unchanged ones, not the ones that undo their parent's
-    move (normal-form root, cyclical = False), and of the duplicates inside a workgroup tile (128 parents) only the smallest tag.
-    Fed back into the SAME engine (as if it owned every key) insert + commit reproduce a plain BFS level by level."""
+@pytest.mark.parametrize("L,cyclical", [(25, False), (36, False), (25, True)])
+def test_device_routing_matches_owner_of(search, L, cyclical):
+    """`world` engines on one GPU driven in lockstep by hand (the exchange is a copy per pair of ranks, the mask all-reduce a sum):
+    acx_shard_chunk_expand routes every child to the region of the rank the owner function names (sharded.owner_of = csrc/acx_owner.h:
+    a function of the conjugacy classes of the two relators and of the letter next to each one's cyclically reduced core), the
+    children a rank owns itself are BORN in the expansion kernel (no record) -- in a normal-form search the kernel inherits a
+    conjugation child's class hashes from its parent without computing them --, and exactly the children that should travel do: not the unchanged ones, not the ones that undo their
+    parent's move (normal-form root, cyclical = False), and of the duplicates inside a workgroup tile (128 consecutive LOCAL parents)
+    only the smallest tag.  Insert + commit on every rank reproduce a plain BFS level by level; every node lives on its owner."""
     import torch
 
     from ac_solver.search.sharded import CTL_NODES, CTL_NEXT_COUNT, HDR, HipShardEngine, owner_of
@@ -460,67 +455,99 @@ def test_device_routing_matches_owner_of(search, L):
     ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
     ak3[L:L + 6] = [1, 2, 1, -2, -1, -2]
     for world in (2, 3, 8):
-        eng = HipShardEngine(L, False, 100000, 1 << 15, 0, world, 50000)
-        KW, RW = eng.KW, eng.RW
-        eng.seed(eng.root_record(ak3))
-        level = [(ak3.copy(), 0xff)]  # host mirror of the frontier (oracle moves) with the action that made each node, global FIFO order
+        engs = [HipShardEngine(L, cyclical, 100000, 1 << 15, r, world, 50000) for r in range(world)]
+        KW, RW = engs[0].KW, engs[0].RW
+
+        def owner(st):
+            return int(owner_of(np.array([_key_words(st, L, KW)], np.int64), world)[0])
+
+        roots = [e.root_record(ak3) for e in engs]  # (every rank calls it: it selects the move code)
+        o_root = engs[0].root_owner(roots[0])
+        assert o_root == owner(ak3) == int(owner_of(roots[0][None, :KW], world)[0])
+        for r, e in enumerate(engs):
+            e.seed(roots[r] if r == o_root else None)
+        level = [(ak3.copy(), 0xff, o_root, 0)]  # host mirror of the frontier in global FIFO order: state, action that made it, owner, local id there
         visited = {tuple(ak3.tolist())}
-        first_id = 0                  # local id of the level's first node (this engine commits everything: ids are FIFO order)
-        nodes = 1
-        n_born = 0
-        for lvl in range(5):          # a few levels: 12, then up to 144, ... children
+        n_local = [1 if r == o_root else 0 for r in range(world)]
+        n_born = n_sent = 0
+        for lvl in range(5 if not cyclical else 6):  # a few levels: 12, then up to 144, ... children
             F = len(level)
-            send, recv = eng.chunk_expand(0, F, True)
-            S, cap, rw = eng.layout(F, 0)
-            regs = send.view(S * world, rw).cpu()
-            # expected records: tag -> state, tile by tile
-            want, tile_keys = {}, {}
-            for gp, (st, made_by) in enumerate(level):
-                out, lens, err = O.move_batch(np.repeat(st[None], 12, axis=0), np.arange(12, dtype=np.uint8), L, cyclical=False)
+            bufs = [e.chunk_expand(0, F, True) for e in engs]
+            S, cap, rw = engs[0].layout(F, 0)
+            # what every rank should have sent where, and what it should have kept: tile by tile of its LOCAL parents
+            want = {}                                    # tag -> (state, owner)
+            want_sent = [dict() for _ in range(world)]   # per sender: tag -> (destination, parent's local id)
+            local_idx = [0] * world
+            tile_keys = {}
+            for gp, (st, made_by, po, pid) in enumerate(level):
+                out, lens, err = O.move_batch(np.repeat(st[None], 12, axis=0), np.arange(12, dtype=np.uint8), L, cyclical=cyclical)
+                tile = (po, local_idx[po] // 128)
+                local_idx[po] += 1
                 for a in range(12):
-                    if np.array_equal(out[a], st) or (made_by < 12 and a == inverse[made_by]):
+                    if np.array_equal(out[a], st) or (not cyclical and made_by < 12 and a == inverse[made_by]):
                         continue
-                    key, tile = tuple(out[a].tolist()), gp // 128  # a workgroup = 128 consecutive local parents x 12 actions
+                    key = tuple(out[a].tolist())
                     if key in tile_keys.setdefault(tile, set()):
                         continue
                     tile_keys[tile].add(key)
-                    want[12 * gp + a] = out[a]
-            got = {}
-            for r in range(S * world):
-                n = int(regs[r, 0])
-                assert n <= cap and int(regs[r, 1]) == 1 << 62 and int(regs[r, 2]) == 1 << 62 and int(regs[r, 3]) == 0
-                rows = regs[r, HDR:HDR + n * RW].view(n, RW)
-                if n:
-                    assert (owner_of(rows[:, :KW], world) == r // S).all(), (L, world, r)
-                for row in rows.tolist():
-                    tag, pid = row[KW] >> 32, row[KW] & 0xFFFFFFFF
-                    assert pid == first_id + tag // 12  # the parent's local id
-                    got[tag] = row[:KW]
-            # the children this engine (rank 0) owns itself are BORN in the expansion kernel: no record, their slots are claimed there
-            own = {t for t, st in want.items() if int(owner_of(torch.tensor([[int(v) for v in _key_words(st, L, KW)]], dtype=torch.int64), world)[0]) == 0}
-            assert sorted(got) == sorted(set(want) - own), (L, world, lvl)
-            n_born += len(own)
-            recv.copy_(send)  # as if every region came back to this engine: records and born children of one chunk fold together
-            packed = eng.chunk_insert(F).clone().to(torch.int64)  # two parents per word
-            lmask = torch.stack([packed & 0xFFF, (packed >> 16) & 0xFFF], dim=1).reshape(-1)[:F]
-            eng.chunk_commit(1 << 40)
-            eng.ctl_snapshot(0)
-            ctl = eng.ctl_wait(0)
+                    co = owner(out[a])
+                    want[12 * gp + a] = (out[a], co)
+                    if co != po:
+                        want_sent[po][12 * gp + a] = (co, pid)
+                    else:
+                        n_born += 1
+            for r, (send, recv) in enumerate(bufs):
+                regs = send.view(S * world, rw).cpu()
+                got = {}
+                for q in range(S * world):
+                    n = int(regs[q, 0])
+                    assert n <= cap and int(regs[q, 1]) == 1 << 62 and int(regs[q, 2]) == 1 << 62 and int(regs[q, 3]) == 0
+                    rows = regs[q, HDR:HDR + n * RW].view(n, RW)
+                    if n:
+                        assert (owner_of(rows[:, :KW], world) == q // S).all(), (L, world, r, q)
+                    for row in rows.tolist():
+                        got[row[KW] >> 32] = (q // S, row[KW] & 0xFFFFFFFF)
+                assert got == want_sent[r], (L, world, lvl, r)
+                n_sent += len(got)
+            # the exchange: region block d of rank r's send buffer -> block r of rank d's receive area
+            blk = S * rw
+            for d in range(world):
+                for r in range(world):
+                    bufs[d][1].view(world, blk)[r].copy_(bufs[r][0].view(world, blk)[d])
+            masks = [e.chunk_insert(F).clone() for e in engs]
+            total = torch.stack(masks).sum(0).to(torch.int32)  # the all-reduce (sum == or: a child has one owner)
+            lmasks = []
+            for e, m in zip(engs, masks):
+                packed = m.to(torch.int64)
+                lmasks.append(torch.stack([packed & 0xFFF, (packed >> 16) & 0xFFF], dim=1).reshape(-1)[:F].cpu())
+                e.gmask_view(F).copy_(total)
+                e.chunk_commit(1 << 40)
             nxt = []
+            new_local = [0] * world
             for tag in sorted(want):
-                key = tuple(want[tag].tolist())
-                if key not in visited:
-                    visited.add(key)
-                    nxt.append((want[tag], tag % 12))
-                    assert (int(lmask[tag // 12]) >> (tag % 12)) & 1, tag
-            nodes += len(nxt)
-            assert int(ctl[CTL_NEXT_COUNT]) == len(nxt) and int(ctl[CTL_NODES]) == nodes
-            for k in (0, len(nxt) // 2, len(nxt) - 1):  # committed in tag order: node ids are the FIFO order
-                a, tl, pref = eng.node_info(first_id + F + k)
-                assert a == nxt[k][1] and tl == int(np.count_nonzero(nxt[k][0]))
-            first_id += F
+                st, co = want[tag]
+                key = tuple(st.tolist())
+                if key in visited:
+                    continue
+                visited.add(key)
+                nxt.append((st, tag % 12, co, n_local[co] + new_local[co]))
+                new_local[co] += 1
+                for r in range(world):  # the bit is set on the owner and nowhere else
+                    assert ((int(lmasks[r][tag // 12]) >> (tag % 12)) & 1) == (1 if r == co else 0), (tag, r, co)
+            for r, e in enumerate(engs):
+                e.ctl_snapshot(0)
+                ctl = e.ctl_wait(0)
+                assert int(ctl[CTL_NEXT_COUNT]) == len(nxt) and int(ctl[CTL_NODES]) == n_local[r] + new_local[r], (L, world, lvl, r)
+                assert e.check_owners() == 0
+            for k in (0, len(nxt) // 2, len(nxt) - 1):  # committed in tag order: a rank's node ids follow the global FIFO order
+                st, a, co, lid = nxt[k]
+                got_a, tl, pref = engs[co].node_info(lid)
+                assert got_a == a and tl == int(np.count_nonzero(st))
+            n_local = [n_local[r] + new_local[r] for r in range(world)]
             level = nxt
-        assert n_born > 0  # some children were born on this rank (no record) and still came out as nodes in the right places
+        assert n_sent > 0 and n_born > 0  # (a few levels deep the conjugators are short and about half of the children still travel; at depth a quarter)
+        for e in engs:
+            e.close()
 
 
 def test_many_searches_overlapped_equal_single(search, golden_json):

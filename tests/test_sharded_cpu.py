@@ -23,7 +23,7 @@ SMALL = [(AK2, 4000, False), (AK2, 10, False), (AK2, 500, False), (AK2, 1, False
 
 def _strip(results):
     """(ok, path, stats without the wall-clock fields)"""
-    return [(ok, path, {k: v for k, v in st.items() if not k.endswith("_seconds")}) for ok, path, st in results]
+    return [(ok, path, {k: v for k, v in st.items() if not k.endswith("_seconds") and k != "local_nodes"}) for ok, path, st in results]
 
 
 def _run(comm, batch, cases=None):
@@ -202,9 +202,93 @@ def test_layout_mirror_matches_the_library():
     for world in (1, 2, 3, 8, 64):
         for n_par in (1, 7, 85, 86, 1000, 1365, 1366, 1 << 18, (1 << 21) + 5):
             for kw in (2, 4):
-                for fill in (0, 64, 121, 320, 999):
+                for fill in (0, 24, 64, 121, 320, 999, 1 << 20, (1 << 20) + 5):
                     _acx.check(_acx.lib.acx_shard_layout(n_par, world, kw, fill, C.byref(s), C.byref(cap), C.byref(rw)))
                     assert (s.value, cap.value, rw.value) == layout(n_par, world, kw, fill), (world, n_par, kw, fill)
+
+
+def _random_reduced(rng, n):
+    w = []
+    while len(w) < n:
+        c = int(rng.integers(0, 4))
+        if not w or w[-1] != c ^ 3:
+            w.append(c)
+    return w
+
+
+def test_owner_function_python_mirror_matches_the_library():
+    """sharded.owner_of (what the NumPy engine and the orchestrator's root placement use) == acx_shard_owner (csrc/acx_owner.h
+    compiled for the host: the arithmetic the kernels run), both key widths, reduced and unreduced words"""
+    import ctypes as C
+
+    from ac_solver import _acx
+    from ac_solver.search.sharded import owner_of
+
+    rng = np.random.default_rng(5)
+    for L, half in ((7, 1), (25, 1), (29, 1), (36, 2), (61, 2)):
+        bits = 64 * half
+        for _ in range(400):
+            row = []
+            for _r in range(2):
+                n = int(rng.integers(1, L + 1))
+                w = _random_reduced(rng, n) if rng.random() < 0.8 else [int(c) for c in rng.integers(0, 4, n)]
+                k = sum(c << (2 * i) for i, c in enumerate(w)) | (n << (bits - 6))
+                for j in range(half):
+                    v = (k >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+                    row.append(v - (1 << 64) if v >= (1 << 63) else v)
+            row = np.array(row, np.int64)
+            for world in (1, 2, 3, 8, 64):
+                assert _acx.lib.acx_shard_owner(L, _acx.ptr(row, C.c_int64), world) == int(owner_of(row[None], world)[0]), (L, row, world)
+
+
+@pytest.mark.parametrize("cyclical", [False, True])
+def test_conjugation_moves_keep_the_class_hashes(cyclical):
+    """What the HIP engine relies on (csrc/acx_owner.h): in a normal-form search the eight conjugation children of a node (actions
+    4 .. 11) have the node's own class hashes, a move leaves the class hash AND the inner letter of the relator it does not rewrite
+    alone, and a conjugation only changes the inner letter of its relator while the conjugator u (r = u c u^-1) has at most one
+    letter -- so most children have their parent's owner.  Checked with the oracle's ACMove on every node of a few searches' trees,
+    tight max_relator_length included (where conjugations stop fitting and children come back unchanged)."""
+    from ac_solver.search.sharded import class_hash, conj_prefix, inner_letter, owner_of
+    from tests.shard_helpers import _CODE, key_of_state
+
+    def classes(state, L):
+        return [class_hash([_CODE[int(a)] for a in state[h * L:(h + 1) * L] if a != 0]) for h in (0, 1)]
+
+    def inners(state, L):
+        words = [[_CODE[int(a)] for a in state[h * L:(h + 1) * L] if a != 0] for h in (0, 1)]
+        return [inner_letter(w) for w in words], [conj_prefix(w) for w in words]
+
+    concat_moved = conj_total = conj_stayed = 0
+    for p, budget in ((AK2, 400), (MS, 400), ([1, 1, 1, -2, -2, -2, -2, 0, 0, 0, 1, 2, 1, -2, -1, -2, 0, 0, 0, 0], 300)):
+        p = np.array(p, np.int8)
+        L = len(p) // 2
+        seen, queue = {tuple(p.tolist())}, [p]
+        while queue and len(seen) < budget:
+            st = queue.pop(0)
+            pc = classes(st, L)
+            pin, pp = inners(st, L)
+            po = int(owner_of(np.array([key_of_state(st, L)], np.int64), 8)[0])
+            out, lens, errs = O.move_batch(np.repeat(st[None], 12, axis=0), np.arange(12, dtype=np.uint8), L, cyclical=cyclical)
+            for a in range(12):
+                cc = classes(out[a], L)
+                untouched = 0 if a % 2 == 0 else 1  # even action ids rewrite r_1 (ac_moves.py:192-206)
+                cin, _ = inners(out[a], L)
+                assert cc[untouched] == pc[untouched] and cin[untouched] == pin[untouched], (st, a)
+                if a >= 4:
+                    assert cc == pc, (st, a, out[a])
+                    if pp[1 - untouched] >= 2:  # a conjugator of two letters or more keeps its last letter
+                        assert cin == pin, (st, a, out[a])
+                    if not np.array_equal(out[a], st):
+                        conj_total += 1
+                        conj_stayed += int(owner_of(np.array([key_of_state(out[a], L)], np.int64), 8)[0]) == po
+                elif cc != pc:
+                    concat_moved += 1
+                key = tuple(out[a].tolist())
+                if key not in seen:
+                    seen.add(key)
+                    queue.append(out[a])
+    assert concat_moved > 100  # (the concatenations DO change the class: the function is not constant)
+    assert conj_stayed > 0.6 * conj_total, (conj_stayed, conj_total)  # most conjugation children stay on their parent's rank (of 8)
 
 
 def test_undo_children_are_visited_states():

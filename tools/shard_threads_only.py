@@ -30,10 +30,12 @@ def work(comm):
         t0 = time.perf_counter()
         ok, path, st = bfs_sharded(ak3, budget, comm=comm, batch_parents=bp, want_stats=True)
         torch.cuda.synchronize()
-        out.append((time.perf_counter() - t0, st["nodes"], st["expanded"]))
+        out.append((time.perf_counter() - t0, st["nodes"], st["expanded"], st["local_nodes"], st.get("region_fill_all"), st["chunks"]))
     return out
 
 
 res = run_threads(world, work) if world > 1 else [work(None)]
 for k in range(reps):
-    print(f"world {world} search {k}: {max(r[k][0] for r in res) * 1e3:.1f} ms wall (thread ranks on one GPU), nodes {res[0][k][1]} expanded {res[0][k][2]}", flush=True)
+    local = [r[k][3] for r in res]
+    print(f"world {world} search {k}: {max(r[k][0] for r in res) * 1e3:.1f} ms wall (thread ranks on one GPU), nodes {res[0][k][1]} expanded {res[0][k][2]}, "
+          f"chunks {res[0][k][5]}, local nodes max/mean {max(local) * len(local) / sum(local):.3f}, region fill per level (1/256 of the even share) {res[0][k][4]}", flush=True)
