@@ -78,6 +78,7 @@ SIGNATURES = {
     "acx_move_batch_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "acx_move_batch": (C.c_int, [_i8p, _u8p, C.c_int64, C.c_int, C.c_int, _i8p, _i32p, _u8p, _i32p]),
     "acx_simplify_relators": (C.c_int, [_i8p, C.c_int64, C.c_int, C.c_int, _i8p, _i32p, _u8p]),
+    "acx_replay_paths": (C.c_int, [_i8p, C.c_int64, C.c_int, C.c_int, _i32p, _i64p, _i32p, _u8p, _i8p]),
     "acx_env_create": (_vp, [C.c_int64, C.c_int, C.c_int64, C.c_int]),
     "acx_env_destroy": (None, [_vp]),
     "acx_env_set_initial": (C.c_int, [_vp, _i8p, _i64p, C.c_int64, _vp]),

@@ -271,28 +271,35 @@ class _MinibatchOrder:
 
         if seed in self.jobs:
             return
-        busy = {k for _, k in self.jobs.values()}
+        busy = {job[1] for job in self.jobs.values()}
         k = 0 if 0 not in busy else 1
         assert k not in busy, "more than two updates' permutations in flight"
         if self.copied[k] is not None:
             self.copied[k].synchronize()  # the permutations this buffer held have left it
+
+        failed = []  # an exception on the worker thread would die with it and leave the never-written buffer as "permutations"
 
         def work(out=self.host[k].numpy()):
             import ctypes as C
 
             from ac_solver import _acx
 
-            _acx.check(_acx.lib.acx_np_shuffle_epochs(int(seed) & 0xFFFFFFFF, self.batch_size, self.epochs, _acx.ptr(out, C.c_int64)), "acx_np_shuffle_epochs")
+            try:
+                _acx.check(_acx.lib.acx_np_shuffle_epochs(int(seed) & 0xFFFFFFFF, self.batch_size, self.epochs, _acx.ptr(out, C.c_int64)), "acx_np_shuffle_epochs")
+            except BaseException as e:  # noqa: BLE001 -- re-raised by get() on the training thread
+                failed.append(e)
 
         th = threading.Thread(target=work)
         th.start()
-        self.jobs[seed] = (th, k)
+        self.jobs[seed] = (th, k, failed)
 
     def get(self, seed):
         """-> [epochs, batch_size] int64 on the training device: the permutations of the update seeded with `seed`"""
         self.prefetch(seed)
-        th, k = self.jobs.pop(seed)
+        th, k, failed = self.jobs.pop(seed)
         th.join()
+        if failed:
+            raise failed[0]
         if not self.on_gpu:
             return self.host[k]
         self.dev.copy_(self.host[k], non_blocking=True)
@@ -460,78 +467,80 @@ def ppo_training_loop(envs, args, device, optimizer, agent, curr_states, success
         events = []  # (step, env, next curriculum state) of this rollout
         reset_err_any = None
         curriculum.begin_borrow()  # the rollout's curriculum draws advance the generator's state inside libacx; back in `random` after the rollout
-        if fused is not None:
-            fused.refresh()  # the weights of the last update
-
-        # ---------------------------------------------------------------- rollout (device resident) ----
-        for step in range(T):
-            global_step += N * world
+        try:  # (whatever the rollout raises, the generator state goes back into `random`: a caller that catches and continues must not find it stale)
             if fused is not None:
-                fused.sample(obs[step], actions[step], logprobs[step], values[step])
-                action = actions[step]
-                if stats_stream is not None:  # rows up to `step` are final: their f32 behaviour statistics start on the second stream
-                    stats_stream.rows_final(step + 1, obs, actions, logprobs, values, last=step == T - 1)
-            else:
-                with torch.no_grad():
-                    action, logprob, _, value = agent.get_action_and_value(obs[step])
-                actions[step] = action
-                logprobs[step] = logprob
-                values[step] = value.flatten()
-            envs.step(action, out=(obs[step + 1], rewards[step], term[step + 1], trunc), check_errors=False)
-            ph.lap("policy+env")
-            if normalizer is not None:  # NormalizeReward, then TransformReward(clip) as make_env stacks them
-                rewards[step] = normalizer(rewards[step], term[step + 1])
-                if args.clip_rewards:
-                    rewards[step].clamp_(args.min_rew, args.max_rew)
-            ep_return += rewards[step]
-            ep_length += 1
-            fin = term[step + 1] | trunc
-            # ---- episodes ended: bookkeeping of the reference (training.py:167-224) on the finished envs only ----
-            # two read-backs per step: how many (the size of `idx`), then index, done flag, return and length of each in one block
-            idx = torch.nonzero(fin).flatten()
-            if idx.numel() == 0:
+                fused.refresh()  # the weights of the last update
+
+            # ---------------------------------------------------------------- rollout (device resident) ----
+            for step in range(T):
+                global_step += N * world
+                if fused is not None:
+                    fused.sample(obs[step], actions[step], logprobs[step], values[step])
+                    action = actions[step]
+                    if stats_stream is not None:  # rows up to `step` are final: their f32 behaviour statistics start on the second stream
+                        stats_stream.rows_final(step + 1, obs, actions, logprobs, values, last=step == T - 1)
+                else:
+                    with torch.no_grad():
+                        action, logprob, _, value = agent.get_action_and_value(obs[step])
+                    actions[step] = action
+                    logprobs[step] = logprob
+                    values[step] = value.flatten()
+                envs.step(action, out=(obs[step + 1], rewards[step], term[step + 1], trunc), check_errors=False)
+                ph.lap("policy+env")
+                if normalizer is not None:  # NormalizeReward, then TransformReward(clip) as make_env stacks them
+                    rewards[step] = normalizer(rewards[step], term[step + 1])
+                    if args.clip_rewards:
+                        rewards[step].clamp_(args.min_rew, args.max_rew)
+                ep_return += rewards[step]
+                ep_length += 1
+                fin = term[step + 1] | trunc
+                # ---- episodes ended: bookkeeping of the reference (training.py:167-224) on the finished envs only ----
+                # two read-backs per step: how many (the size of `idx`), then index, done flag, return and length of each in one block
+                idx = torch.nonzero(fin).flatten()
+                if idx.numel() == 0:
+                    ph.lap("episode bookkeeping")
+                    continue
+                packed = torch.stack((idx.double(), term[step + 1][idx].double(), ep_return[idx].double(), ep_length[idx].double())).cpu().numpy()
+                idx_h = packed[0].astype(np.int64).tolist()
+                done_np = packed[1] != 0
+                ret_h, len_h = packed[2].tolist(), packed[3].tolist()  # (float32 values, exact in float64: what .tolist() of the tensors gives)
+                current = [curr_states[i] for i in idx_h]
+
+                def on_done(k, s):  # the shortest action sequence seen for state s (strictly shorter replaces; the first of a length stays)
+                    # an episode's action list is as long as the episode: only a record-setting one is read back from the device
+                    if s not in ACMoves_hist or int(len_h[k]) < len(ACMoves_hist[s]):
+                        moves = envs.get_actions(idx_h[k], finished=True)
+                        if len(moves) != int(len_h[k]):
+                            raise RuntimeError(f"env {idx_h[k]}: an episode of {int(len_h[k])} steps with {len(moves)} recorded actions")
+                        if s not in ACMoves_hist or len(moves) < len(ACMoves_hist[s]):
+                            ACMoves_hist[s] = moves
+
+                new_states = curriculum.finish_episodes(current, done_np, on_done)
+                for i, nxt in zip(idx_h, new_states):
+                    curr_states[i] = nxt
+                if rollout_log is not None:
+                    events.extend((step, i, nxt) for i, nxt in zip(idx_h, new_states))
+                returns_queue.extend(ret_h)
+                lengths_queue.extend(len_h)
+                episode += len(idx_h)
+                round1_complete = curriculum.round1_complete
+                ep_return[idx] = 0
+                ep_length[idx] = 0
+                # the finished envs restart from their next curriculum state (envs.envs[i].reset(options={"starting_state": ...})): one
+                # upload (the states' numbers, through a pinned buffer), rows gathered and environments reset on the device
+                if device.type == "cuda":
+                    k = len(new_states)
+                    ns_pin[:k].copy_(torch.from_numpy(np.asarray(new_states, np.int64)))
+                    ns_dev = ns_pin[:k].to(device, non_blocking=True)
+                    reset_err = envs.reset_envs_device(idx, init_rows_dev.index_select(0, ns_dev))
+                    reset_err_any = reset_err.any() if reset_err_any is None else reset_err_any | reset_err.any()
+                else:
+                    ns_dev = torch.as_tensor(new_states, device=device)
+                    envs.reset_envs(idx_h, init_rows[new_states])
+                obs[step + 1].index_copy_(0, idx, init_table.index_select(0, ns_dev))
                 ph.lap("episode bookkeeping")
-                continue
-            packed = torch.stack((idx.double(), term[step + 1][idx].double(), ep_return[idx].double(), ep_length[idx].double())).cpu().numpy()
-            idx_h = packed[0].astype(np.int64).tolist()
-            done_np = packed[1] != 0
-            ret_h, len_h = packed[2].tolist(), packed[3].tolist()  # (float32 values, exact in float64: what .tolist() of the tensors gives)
-            current = [curr_states[i] for i in idx_h]
-
-            def on_done(k, s):  # the shortest action sequence seen for state s (strictly shorter replaces; the first of a length stays)
-                # an episode's action list is as long as the episode: only a record-setting one is read back from the device
-                if s not in ACMoves_hist or int(len_h[k]) < len(ACMoves_hist[s]):
-                    moves = envs.get_actions(idx_h[k], finished=True)
-                    if len(moves) != int(len_h[k]):
-                        raise RuntimeError(f"env {idx_h[k]}: an episode of {int(len_h[k])} steps with {len(moves)} recorded actions")
-                    if s not in ACMoves_hist or len(moves) < len(ACMoves_hist[s]):
-                        ACMoves_hist[s] = moves
-
-            new_states = curriculum.finish_episodes(current, done_np, on_done)
-            for i, nxt in zip(idx_h, new_states):
-                curr_states[i] = nxt
-            if rollout_log is not None:
-                events.extend((step, i, nxt) for i, nxt in zip(idx_h, new_states))
-            returns_queue.extend(ret_h)
-            lengths_queue.extend(len_h)
-            episode += len(idx_h)
-            round1_complete = curriculum.round1_complete
-            ep_return[idx] = 0
-            ep_length[idx] = 0
-            # the finished envs restart from their next curriculum state (envs.envs[i].reset(options={"starting_state": ...})): one
-            # upload (the states' numbers, through a pinned buffer), rows gathered and environments reset on the device
-            if device.type == "cuda":
-                k = len(new_states)
-                ns_pin[:k].copy_(torch.from_numpy(np.asarray(new_states, np.int64)))
-                ns_dev = ns_pin[:k].to(device, non_blocking=True)
-                reset_err = envs.reset_envs_device(idx, init_rows_dev.index_select(0, ns_dev))
-                reset_err_any = reset_err.any() if reset_err_any is None else reset_err_any | reset_err.any()
-            else:
-                ns_dev = torch.as_tensor(new_states, device=device)
-                envs.reset_envs(idx_h, init_rows[new_states])
-            obs[step + 1].index_copy_(0, idx, init_table.index_select(0, ns_dev))
-            ph.lap("episode bookkeeping")
-        curriculum.end_borrow()
+        finally:
+            curriculum.end_borrow()
         if reset_err_any is not None and bool(reset_err_any):  # (cannot happen: the rows are the validated initial states)
             raise ValueError("a curriculum state is not a valid presentation (ACEnv.reset)")
         envs._raise_on_errors()

@@ -79,6 +79,8 @@ class _Handle:
     """Owns one acx_env; frees it with the Python object."""
 
     def __init__(self, n, L, horizon, flags):
+        if L > 64:  # (the reference takes any length; here a relator is one 128-bit device word)
+            raise ValueError(f"max_relator_length = {L} is not supported: the device environment keeps a relator in one 128-bit word (max_relator_length <= 64)")
         _acx.require_device()
         self.ptr = _acx.lib.acx_env_create(n, L, int(horizon), flags)
         if not self.ptr:
@@ -110,7 +112,7 @@ class ACEnv(Env):
             self.supermoves = normalise_supermoves(config.use_supermoves)
         L = self.max_relator_length
         if L > 64:
-            raise ValueError("ACEnv supports max_relator_length <= 64 on the device")
+            raise ValueError(f"max_relator_length = {L} is not supported: the device environment keeps a relator in one 128-bit word (max_relator_length <= 64)")
         if np.any(np.abs(self.initial_state) > self.n_gen):
             raise ValueError("ACEnv is a two-generator environment: letters must be in {+-1, +-2}")
 
@@ -151,7 +153,9 @@ class ACEnv(Env):
         self.lengths = [int(np.count_nonzero(obs[0, :L])), int(np.count_nonzero(obs[0, L:]))]
         self.count_steps += 1
         is_done = bool(done[0])
-        reward = int(rew[0])
+        # the reference's own expression on exact Python ints (ac_env.py:101-102); the kernel's float32 reward is what the rollout
+        # tensors carry and is only exact below 2^24 (max_reward = horizon_length * max_relator_length * 2 can be larger)
+        reward = self.max_reward * is_done - sum(self.lengths) * (1 - is_done)
         return self.state, reward, is_done, bool(trunc[0]), ({"actions": self.actions.copy()} if is_done else {})
 
     def reset(self, *, seed=None, options=None):

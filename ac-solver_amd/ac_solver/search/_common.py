@@ -7,6 +7,16 @@ import numpy as np
 from ac_solver import _acx
 
 
+MAX_SEARCH_RELATOR_LENGTH = 61  # a relator and its length share one 128-bit key word (csrc/acx_frontier.h: keyops)
+
+
+def _check_width(L):
+    """The reference takes any max_relator_length; the device frontier packs a relator and its length into one 128-bit key."""
+    if L > MAX_SEARCH_RELATOR_LENGTH:
+        raise ValueError(f"max_relator_length = {L} is not supported by the device search: at most {MAX_SEARCH_RELATOR_LENGTH} "
+                         "(a relator and its length share one 128-bit key word)")
+
+
 def run_search(kind, presentation, max_nodes_to_explore, cyclical, want_stats=False, verbose=False):
     """`verbose`: print "New minimal length found: l" for every child that is shorter than everything generated before it, as
     the reference does while it searches (breadth_first.py:79-82, greedy.py:85-89); here the lines come out when the
@@ -26,6 +36,7 @@ def run_search(kind, presentation, max_nodes_to_explore, cyclical, want_stats=Fa
             _acx.check(_acx.lib.acx_search_minima_enable(0))
     p = _acx.as_i8_rows(np.array(presentation))
     L = p.size // 2
+    _check_width(L)
     cap = 1 << 12
     while True:
         pa = np.empty(cap, np.int32)
@@ -52,6 +63,7 @@ def run_search_many(kind, presentations, max_nodes_to_explore, cyclical, n_threa
     rows = _acx.as_i8_rows(np.asarray(presentations))
     n, width = rows.shape
     L = width // 2
+    _check_width(L)
     solved = np.zeros(n, np.int32)
     pa = np.empty((n, path_cap), np.int32)
     pl = np.empty((n, path_cap), np.int32)
@@ -99,6 +111,7 @@ def run_search_groups(kind, groups, max_nodes_to_explore, cyclical, n_threads=16
         return []
     counts = np.array([r.shape[0] for r in rows], np.int64)
     widths = np.array([r.shape[1] // 2 for r in rows], np.int32)
+    _check_width(int(widths.max()))
     n = int(counts.sum())
     ptrs = (C.POINTER(C.c_int8) * ng)(*[_acx.ptr(r, C.c_int8) for r in rows])
     solved = np.zeros(n, np.int32)

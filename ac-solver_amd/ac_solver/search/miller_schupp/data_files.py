@@ -41,19 +41,39 @@ def read_literals(filepath):
         return [literal_eval(line.strip()) for line in f if line.strip()]
 
 
+def replay_paths(presentations, paths, cyclical=False, want_final=False):
+    """Apply the actions of many search paths to their presentations in ONE launch (acx_replay_paths: a lane per path); returns,
+    per path, the list of total lengths after each move -- and the presentations the paths end at with `want_final`.
+    `presentations`: rows of one max_relator_length; `paths`: search paths [(-1, l0), (a, l), ...] (the root entry is skipped).
+    A path is valid when its list equals its recorded lengths and ends at 2 (breadth_first.py:113-126).  A move on which the
+    reference's ACMove raises does so here as well (AssertionError / IndexError, as envs.ac_moves.ACMove)."""
+    import ctypes as C
+
+    from ac_solver import _acx
+
+    _acx.require_device()
+    rows = _acx.as_i8_rows(np.asarray(presentations, dtype=np.int8).reshape(len(paths), -1))
+    n, L = rows.shape[0], rows.shape[1] // 2
+    acts = [np.array([int(a) for a, _ in p[1:]], np.int32) for p in paths]
+    offsets = np.zeros(n + 1, np.int64)
+    offsets[1:] = np.cumsum([len(a) for a in acts])
+    flat = np.ascontiguousarray(np.concatenate(acts) if n and offsets[-1] else np.zeros(0, np.int32), np.int32)
+    out = np.zeros(max(int(offsets[-1]), 1), np.int32)
+    err = np.zeros(max(n, 1), np.uint8)
+    final = np.zeros_like(rows) if want_final else None
+    _acx.check(_acx.lib.acx_replay_paths(_acx.ptr(rows, C.c_int8), n, L, int(bool(cyclical)), _acx.ptr(flat, C.c_int32) if len(flat) else None,
+                                         _acx.ptr(offsets, C.c_int64), _acx.ptr(out, C.c_int32), _acx.ptr(err, C.c_uint8),
+                                         None if final is None else _acx.ptr(final, C.c_int8)), "acx_replay_paths")
+    for i in np.flatnonzero(err[:n]):
+        raise (IndexError if err[i] == _acx.ERR_INDEX else AssertionError)(f"path {i}: a move of the path is not valid on {rows[i].tolist()} (code {int(err[i])})")
+    lens = [out[offsets[i]:offsets[i + 1]].tolist() for i in range(n)]
+    return (lens, final) if want_final else lens
+
+
 def replay_path(presentation, path, cyclical=False):
     """Apply the actions of a search path to `presentation` on the GPU; returns the list of total lengths after each
     move.  A path is valid when this equals its recorded lengths and ends at 2 (breadth_first.py:113-126)."""
-    from ac_solver.envs.ac_moves import ACMove
-
-    state = np.array(presentation, dtype=np.int8)
-    L = len(state) // 2
-    lengths = [int(np.count_nonzero(state[:L])), int(np.count_nonzero(state[L:]))]
-    out = []
-    for action, _ in path[1:]:
-        state, lengths = ACMove(int(action), state, L, lengths, cyclical=cyclical)
-        out.append(int(sum(lengths)))
-    return out
+    return replay_paths([presentation], [path], cyclical)[0]
 
 
 def make_data_files(max_nodes_to_explore=10**6, out_dir=None, verbose=True):

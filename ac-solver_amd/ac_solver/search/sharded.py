@@ -408,6 +408,9 @@ def _bfs_sharded_once(presentation, max_nodes_to_explore=10000, verbose=False, c
     assert is_array_valid_presentation(presentation), f"{presentation} is not a valid presentation"
     p = np.array(presentation, dtype=np.int8)
     L = len(p) // 2
+    from ac_solver.search._common import _check_width
+
+    _check_width(L)
     max_nodes = int(max_nodes_to_explore)
     comm = SingleComm() if comm is None else comm
     world, rank = comm.world, comm.rank
@@ -582,6 +585,30 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
     #     blocks this rank reads for chunks before the first dead one are as valid as every other rank's.
     #   * The level's closing all-reduce carries the failure code: a failure in the last chunk of a level, or one that no header
     #     carried, ends every rank there, whatever status each of them read.
+    #   * The control-block calls of a failed rank may raise as well (a sticky HIP error): they are guarded, the rank keeps the last
+    #     block it read (or a synthetic "running" one) and leaves the loop by the fail_hdr_chunk + lag rule and the closing all-reduce
+    #     alone.  (engine.layout is host arithmetic on (parents, world, key words): it cannot fail with the device.)
+    def ctl_snapshot(slot):
+        try:
+            engine.ctl_snapshot(slot)
+        except Exception as e:  # noqa: BLE001
+            if not exchange:
+                raise
+            set_failed(e)
+
+    def ctl_wait(slot):
+        try:
+            return engine.ctl_wait(slot)
+        except Exception as e:  # noqa: BLE001
+            if not exchange:
+                raise
+            set_failed(e)
+            if ctl is not None:
+                return ctl
+            blank = np.zeros(CTL_WORDS, np.int64)  # "running", nothing known: the loop goes on until the failure rule ends it
+            blank[CTL_MIN_LEN], blank[CTL_NODES_GLOBAL] = INF, nodes_seen
+            return blank
+
     def produce(c0, c1, idx):
         """expansion + exchange of one chunk on the side stream -> (n_par, event after which its receive area is complete, dead, stamps)"""
         nonlocal tight_used, fail_hdr_chunk
@@ -703,18 +730,18 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
                 done.append(ev_done)
             if tl_rows is not None:
                 tl_rows.append((n_par, e0, e1, ev, m0, m1, m2, m3, levels))
-            engine.ctl_snapshot(k % (lag + 2))
+            ctl_snapshot(k % (lag + 2))
             pending.append(k % (lag + 2))
             chunks += 1
             if len(pending) > lag:
-                ctl = engine.ctl_wait(pending.pop(0))
+                ctl = ctl_wait(pending.pop(0))
                 n_read += 1
                 new_read, nodes_seen = int(ctl[CTL_NEXT_COUNT]), int(ctl[CTL_NODES_GLOBAL])
             k += 1
         if on_gpu:
             main.wait_stream(side)  # (a chunk that was produced but never consumed: the search ended)
         while pending and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING):  # end of the level: the one synchronisation
-            ctl = engine.ctl_wait(pending.pop(0))
+            ctl = ctl_wait(pending.pop(0))
         status = int(ctl[CTL_STATUS])
         # closing all-reduce of the level (max): [failure code, -(smallest total length generated), fullest region received].
         # Every rank does it here, whatever status it read, so a failure that no header carried (the last chunk of a level; a

@@ -150,6 +150,34 @@ __global__ void __launch_bounds__(64) k_simplify_rows(const int8_t* __restrict__
     err[r] = nn < 0 ? (uint8_t)(-nn) : 0;
 }
 
+// ---------------------------------------------------------------- path replay ------------------
+// One lane per search path: the moves of the path applied to its presentation one after the other (what the reference's search
+// scripts do with the path they return, breadth_first.py:113-126 / greedy.py:130-143), the total length after every move.  A move
+// on which the reference's ACMove raises ends the path: its entry and every later one read -1, err[i] says why.
+constexpr int kReplayBadAction = 251;
+template <typename W>
+__global__ void __launch_bounds__(64) k_replay_paths(const int8_t* __restrict__ rows, int64_t n, int L, int cyclical, const int32_t* __restrict__ actions,
+                                                     const int64_t* __restrict__ offsets, int32_t* __restrict__ tlen, uint8_t* __restrict__ err,
+                                                     int8_t* __restrict__ final_rows) {
+    ACX_VGPR_PAD_W(W, "v47", "v79");
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Pres<W> s;
+    bool ok = pack_relator<W>(rows + i * 2 * L, L, s.w0, s.n0);
+    ok = pack_relator<W>(rows + i * 2 * L + L, L, s.w1, s.n1) && ok;
+    int e = ok ? ACX_ERR_NONE : ACX_ERR_UNPACKABLE;
+    for (int64_t k = offsets[i]; k < offsets[i + 1]; k++) {
+        const int a = actions[k];
+        if (!e) e = (a < 0 || a > 11) ? kReplayBadAction : apply_move<W, true>(s, a, L, cyclical != 0);
+        tlen[k] = e ? -1 : s.n0 + s.n1;
+    }
+    err[i] = (uint8_t)e;
+    if (final_rows && ok) {
+        unpack_relator<W>(s.w0, s.n0, L, final_rows + i * 2 * L);
+        unpack_relator<W>(s.w1, s.n1, L, final_rows + i * 2 * L + L);
+    }
+}
+
 // ---------------------------------------------------------------- packed stateless kernel -----
 // One wave = 64 rows = one contiguous 128*L byte tile, moved global <-> LDS with 16-B lanes; each
 // lane then packs / unpacks its own row inside LDS.
@@ -860,6 +888,45 @@ int acx_simplify_relators(const int8_t* h_in, int64_t n, int width, int cyclical
     memcpy(h_out, h + o_out, (size_t)n * width);
     memcpy(h_len, h + o_len, (size_t)n * 8);
     memcpy(h_err, h + o_err, (size_t)n);
+    return ACX_OK;
+}
+
+int acx_replay_paths(const int8_t* h_presentations, int64_t n, int L, int cyclical, const int32_t* h_actions, const int64_t* h_offsets,
+                     int32_t* h_total_len, uint8_t* h_err, int8_t* h_final) {
+    if (!have_device()) return ACX_E_NODEVICE;
+    if (n < 0 || L < 1 || L > 64 || !h_presentations || !h_offsets || !h_err) return fail(ACX_E_INVAL, "acx_replay_paths: bad argument (1 <= L <= 64)");
+    if (n == 0) return ACX_OK;
+    const int64_t m = h_offsets[n];
+    if (h_offsets[0] != 0 || m < 0 || (m > 0 && (!h_actions || !h_total_len))) return fail(ACX_E_INVAL, "acx_replay_paths: bad offsets");
+    for (int64_t i = 0; i < n; i++)
+        if (h_offsets[i + 1] < h_offsets[i]) return fail(ACX_E_INVAL, "acx_replay_paths: offsets must not decrease");
+    const size_t row = (size_t)2 * L, a16 = 256;
+    auto up = [&](size_t b) { return (b + a16 - 1) / a16 * a16; };
+    const size_t o_in = 0, o_off = up(n * row), o_act = o_off + up((n + 1) * 8), o_len = o_act + up(m * 4), o_err = o_len + up(m * 4), o_fin = o_err + up(n),
+                 total = o_fin + up(n * row);
+    Scratch& s = scratch(0);
+    int rc = s.ensure(total);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)s.p;
+    uint8_t* h = step_staging(total);  // pinned mirror: one upload, ONE launch for all paths, one read-back, one synchronisation
+    if (!h) return fail(ACX_E_NOMEM, "acx_replay_paths: hipHostMalloc(%zu) failed", total);
+    memcpy(h + o_in, h_presentations, (size_t)n * row);
+    memcpy(h + o_off, h_offsets, (size_t)(n + 1) * 8);
+    if (m) memcpy(h + o_act, h_actions, (size_t)m * 4);
+    ACX_HIP_TRY(hipMemcpyAsync(b, h, o_len, hipMemcpyHostToDevice, nullptr));
+    const unsigned grid = (unsigned)ceil_div<int64_t>(n, 64);
+    if (L <= 32)
+        hipLaunchKernelGGL(k_replay_paths<uint64_t>, dim3(grid), dim3(64), 0, nullptr, (const int8_t*)(b + o_in), n, L, cyclical, (const int32_t*)(b + o_act),
+                           (const int64_t*)(b + o_off), (int32_t*)(b + o_len), b + o_err, h_final ? (int8_t*)(b + o_fin) : nullptr);
+    else
+        hipLaunchKernelGGL(k_replay_paths<u128>, dim3(grid), dim3(64), 0, nullptr, (const int8_t*)(b + o_in), n, L, cyclical, (const int32_t*)(b + o_act),
+                           (const int64_t*)(b + o_off), (int32_t*)(b + o_len), b + o_err, h_final ? (int8_t*)(b + o_fin) : nullptr);
+    ACX_HIP_TRY(hipGetLastError());
+    ACX_HIP_TRY(hipMemcpyAsync(h + o_len, b + o_len, (h_final ? total : o_fin) - o_len, hipMemcpyDeviceToHost, nullptr));
+    ACX_HIP_TRY(hipStreamSynchronize(nullptr));
+    if (m) memcpy(h_total_len, h + o_len, (size_t)m * 4);
+    memcpy(h_err, h + o_err, (size_t)n);
+    if (h_final) memcpy(h_final, h + o_fin, (size_t)n * row);
     return ACX_OK;
 }
 

@@ -44,6 +44,9 @@ ALGO_BYTES_PER_STEP = 4 * L + 7  # state in + out (2 x 2L), action 1, reward f32
 SEARCH_TIMEOUT_S = int(os.environ.get("ACX_BENCH_SEARCH_TIMEOUT", "240"))  # multi-rank runs: how long the RCCL-backed secondary measurements may take
 HBM_PEAK_GBS = 8000.0            # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 MIN_TIMED_STEPS = 16384          # the K steps are repeated ceil(MIN_TIMED_STEPS / K) times: a window of >= 50 ms
+MIN_ROLLOUT_ROWS = 128           # rows of the rollout buffers the timed steps rotate over, whatever --steps is: 128 x 3.7 MB = 470 MB at 65 536
+                                 # envs, beyond the 256 MiB Infinity Cache -- the observation / reward / flag streams of a launch HAVE to reach HBM
+                                 # (a PPO rollout buffer of horizon 1000 is larger still); --steps 20 alone kept the whole working set cache resident
 GRAPH_NODES_MAX = 1024           # passes of the same K steps captured into ONE hipGraph (K = 20: 51 passes): consecutive graph
                                  # launches leave a ~6 us bubble on the GPU, which a 20-node graph pays every 20 steps
 
@@ -777,11 +780,12 @@ def main():
     dev = env.device
     T = K + W
     tape = torch.as_tensor(np.random.default_rng(rank).integers(0, 12, size=(T, N), dtype=np.uint8), device=dev)
-    # PPO-style rollout buffers, resident in HBM before the timed region
-    obs = torch.empty((K, N, 2 * L), dtype=torch.int8, device=dev)
-    rew = torch.empty((K, N), dtype=torch.float32, device=dev)
-    done = torch.empty((K, N), dtype=torch.bool, device=dev)
-    trunc = torch.empty((K, N), dtype=torch.bool, device=dev)
+    # PPO-style rollout buffers, resident in HBM before the timed region: ROWS rows, step k of pass p writes row (p K + k) mod ROWS
+    ROWS = max(K, MIN_ROLLOUT_ROWS)
+    obs = torch.empty((ROWS, N, 2 * L), dtype=torch.int8, device=dev)
+    rew = torch.zeros((ROWS, N), dtype=torch.float32, device=dev)
+    done = torch.empty((ROWS, N), dtype=torch.bool, device=dev)
+    trunc = torch.empty((ROWS, N), dtype=torch.bool, device=dev)
 
     def launch(t, slot):
         _acx.check(_acx.lib.acx_env_step(env._h.ptr, tape[t].data_ptr(), _acx.U8, obs[slot].data_ptr(), _acx.I8, rew[slot].data_ptr(), 0.0, 0.0,
@@ -789,7 +793,7 @@ def main():
 
     env.reset()
     for t in range(W):  # untimed warm-up steps
-        launch(t, t % K)
+        launch(t, t % ROWS)
     torch.cuda.synchronize()
 
     R = max(1, -(-MIN_TIMED_STEPS // K))  # passes over the K steps in the timed window; same on every rank (depends on K only)
@@ -802,9 +806,9 @@ def main():
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):  # capturing does not execute: the env stays in its post-warm-up state
-                for _ in range(P):
+                for p_ in range(P):
                     for k in range(K):
-                        launch(W + k, k)
+                        launch(W + k, (p_ * K + k) % ROWS)
         except Exception as e:  # pragma: no cover
             print(f"[bench] graph capture failed ({e}); falling back to eager launches", file=sys.stderr)
             graph, mode = None, "eager"
@@ -839,9 +843,9 @@ def main():
         if graph is not None:
             graph.replay()
         else:
-            for _ in range(P):
+            for p_ in range(P):
                 for k in range(K):
-                    launch(W + k, k)
+                    launch(W + k, (p_ * K + k) % ROWS)
 
     # one isolated graph launch (P passes; round 1 timed one pass): carries the fixed cost of one graph replay + synchronize
     if use_dist:
@@ -873,7 +877,8 @@ def main():
     wall, dev_ms, single_wall = float(tmax[0]), float(tmax[1]), float(tmax[2])
 
     # sanity: the timed steps really ran (count_steps advanced, rewards written)
-    assert int(env.get_counts().max()) > 0 and bool(torch.isfinite(rew).all()) and bool((rew != 0).all())
+    written = min(ROWS, P * K)
+    assert int(env.get_counts().max()) > 0 and bool(torch.isfinite(rew[:written]).all()) and bool((rew[:written] != 0).all())
 
     def headline(extras, search):
         total_steps = N * K * R * world
@@ -916,22 +921,36 @@ def main():
         # nothing of a launch HAS to reach HBM before the next one starts -- the launch is bound by latency (kernel boundary + one
         # dependent memory round trip + instruction issue), and `frac` says how far that is from the HBM roofline, not which
         # resource is saturated.
-        working_set = K * (2 * L + 6) * N + 24 * N
+        rows_used = min(ROWS, P * K)
+        working_set = rows_used * (2 * L + 6) * N + 24 * N
         out["roofline"]["hbm_bytes_beyond_mall"] = 0 if working_set < (256 << 20) else (ALGO_BYTES_PER_STEP - 50) * N
         out["roofline"]["working_set_bytes"] = working_set
-        ev = os.path.join(ROOT, "profiles", "r3_env_step_roofline.json")
+        out["roofline"]["rollout_rows"] = rows_used
+        ev = os.path.join(ROOT, "profiles", "r5_env_step_roofline.json")
         if os.path.exists(ev) and N == N_ENVS:
             with open(ev) as f:
-                r3 = json.load(f)
-            kt, stp = r3.get(str(N), {}).get("rocprof_kernel_trace"), r3.get("stamps_65536")
-            if kt:  # isolated dispatches (eager launches ~10 us apart): the kernel's begin-to-end LATENCY, not the back-to-back period timed here
-                out["roofline"]["rocprof"] = {"avg_kernel_us": kt["avg_us"], "min_kernel_us": kt["min_us"], "calls": kt["calls"],
-                                              "source": "profiles/r3_env_step_65536_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 tools/env_roofline.py 65536 400)",
-                                              "frac_by_kernel_duration": ALGO_BYTES_PER_STEP * N / (kt["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                r5 = json.load(f)
+            kt, stp = r5.get(str(N), {}).get("rocprof_kernel_trace"), r5.get("stamps_65536")
+            if kt:
+                # the same command under rocprofv3 --kernel-trace: begin-to-end of every dispatch of the replayed graph.  A dispatch that
+                # is longer than the launch PERIOD measured here cannot be the same thing (an isolated dispatch's latency): no fraction then.
+                rp = {"avg_kernel_us": kt["avg_us"], "min_kernel_us": kt["min_us"], "calls": kt["calls"], "period_us_under_rocprof": kt.get("period_us_under_rocprof"),
+                      "source": "profiles/r5_env_step_65536_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-search --no-extras "
+                                "--no-cpu-baseline: tools/profile_env_r5.sh)"}
+                if kt["avg_us"] <= launch_s * 1e6:
+                    rp["frac_by_kernel_duration"] = ALGO_BYTES_PER_STEP * N / (kt["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                else:
+                    rp["note"] = "the traced dispatches are longer than the launch period timed in this run: not comparable, no fraction derived"
+                out["roofline"]["rocprof"] = rp
             if stp:  # in-kernel stamps of the diagnostic build under the same graph replay: where the period goes
                 out["roofline"]["stamps"] = {"active_us": stp["active_us_median"], "launch_boundary_us": stp["gap_us_median"], "one_wave_us": stp["one_wave_us_median"],
                                              "wave_start_spread_us": stp["wave_start_spread_us_median"], "frac_by_active_time": stp["frac_of_8TBps_by_active_time"],
-                                             "source": "profiles/r3_env_step_roofline.json: tools/step_stamps.py on the -DACX_STEP_STAMP build (s_memrealtime per wave)"}
+                                             "source": "profiles/r5_env_step_roofline.json: tools/step_stamps.py on the -DACX_STEP_STAMP build of this round's kernel (s_memrealtime per wave)"}
+            tr = r5.get(str(N), {}).get("traffic_bytes_per_launch")
+            if tr:
+                out["roofline"]["traffic"] = tr
+                out["roofline"]["traffic_source"] = ("profiles/r5_env_step_roofline.json (rocprofv3 --pmc FETCH_SIZE and, in a pass of its own, --pmc WRITE_SIZE over the same bench.py "
+                                                     "command; 2 x FETCH_SIZE + WRITE_SIZE: gfx950 counts 128-B read requests at 64 B)")
         r4f = os.path.join(ROOT, "profiles", "r4_env_step_roofline.json")
         if os.path.exists(r4f) and N == N_ENVS:
             # where trace and HIP events agree (launch overhead < 5 %): the same kernel at 2^20 envs (state resident in the Infinity

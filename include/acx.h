@@ -74,6 +74,16 @@ int acx_move_batch(const int8_t *h_in, const uint8_t *h_action, int64_t n, int L
 int acx_simplify_relators(const int8_t *h_in, int64_t n, int width, int cyclical, int8_t *h_out, int32_t *h_len,
                           uint8_t *h_err);
 
+/* ---- path replay -------------------------------------------------------------------
+ * What the reference's search scripts do with a path they found (breadth_first.py:113-126, greedy.py:130-143): apply its moves
+ * to the presentation one after the other -- for n paths in ONE launch, a lane per path.  Path i has the actions
+ * h_actions[h_offsets[i] .. h_offsets[i + 1]) (0..11, WITHOUT the root entry of a search path; h_offsets[0] = 0, n + 1 entries);
+ * h_total_len (same layout) receives the total length after every move; a move on which the reference's ACMove raises ends its
+ * path: h_err[i] = that error code (251: an action outside 0..11; 250: the row is not a presentation over {+-1,+-2}), its entry
+ * and the later ones read -1.  h_final (nullable) [n, 2L]: the presentations the paths end at.  L <= 64. */
+int acx_replay_paths(const int8_t *h_presentations, int64_t n, int L, int cyclical, const int32_t *h_actions,
+                     const int64_t *h_offsets, int32_t *h_total_len, uint8_t *h_err, int8_t *h_final);
+
 /* ---- vectorised environment ---------------------------------------------------------------
  * n independent ACEnv instances (ac_env.py:56-134) resident on one device in packed form.
  * A handle is bound to the device current at creation and is not thread safe. */

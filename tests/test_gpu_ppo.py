@@ -107,9 +107,23 @@ def test_data_files_reproduce_the_published_results(tmp_path, golden_json):
     want = {r["pool_index"]: [tuple(x) for x in r["path"]] for r in gp["rows"]}
     for k, p in zip(gs_order, paths):
         assert p[0][0] == 0 and from_legacy_path(p) == want[k], k
-    for k in (0, 100, 532):  # a path file line really trivialises its presentation
-        path = from_legacy_path(paths[k])
-        assert replay_path(solved[k], path) == [l for _, l in path[1:]] and path[-1][1] == 2
+    # every path file line really trivialises its presentation: all 533 paths replayed, one launch per max_relator_length
+    # (acx_replay_paths: a lane per path), lengths after every move = the recorded ones, final presentation trivial
+    from ac_solver.envs.utils import is_presentation_trivial
+    from ac_solver.search.miller_schupp.data_files import replay_paths
+
+    by_width = {}
+    for k, p in enumerate(solved):
+        by_width.setdefault(len(p), []).append(k)
+    for width, ks in by_width.items():
+        plain = [from_legacy_path(paths[k]) for k in ks]
+        lens, final = replay_paths([solved[k] for k in ks], plain, want_final=True)
+        for k, path, got, end in zip(ks, plain, lens, final):
+            assert got == [l for _, l in path[1:]] and path[-1][1] == 2 and is_presentation_trivial(end), k
+    path = from_legacy_path(paths[100])
+    assert replay_path(solved[100], path) == [l for _, l in path[1:]]
+    with pytest.raises(AssertionError):  # an action list that empties a relator raises like the reference's ACMove
+        replay_paths([[1, 0, 0, -1, 0, 0]], [[(-1, 2), (0, 0)]])
 
 
 @pytest.mark.timeout(600)

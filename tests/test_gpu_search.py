@@ -416,6 +416,22 @@ def test_a_host_side_failure_of_the_hip_engine_ends_every_thread_rank_together(s
     assert all(r == O.bfs(ak3, 200000) for r in run_threads(2, clean))
 
 
+def test_search_beyond_the_key_width_says_so(search):
+    """the reference searches at any max_relator_length; the device frontier stops at 61 and says that (a ValueError naming the
+    limit, not a generic library error) -- the Miller-Schupp generator reaches L = 64 at n = 14 (miller_schupp.py:43)"""
+    from ac_solver import bfs, greedy_search
+    from ac_solver.search.sharded import bfs_sharded
+
+    p = np.zeros(124, np.int8)
+    p[:2], p[62:64] = [1, 2], [2, 1]
+    for fn in (bfs, greedy_search, bfs_sharded):
+        with pytest.raises(ValueError, match="max_relator_length = 62"):
+            fn(p, 100)
+    ok = np.zeros(122, np.int8)
+    ok[:2], ok[61:63] = [1, 2], [2, 1]
+    assert bfs(ok, 1000)[0] is not None and greedy_search(ok, 1000)[0] is not None  # 61 still runs
+
+
 def _key_words(state, L, KW):
     """the packed key of a state as the engine's int64 words (2-bit letters, length in the top six bits of each relator's word)"""
     code = {-2: 0, -1: 1, 1: 2, 2: 3}

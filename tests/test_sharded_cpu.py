@@ -169,6 +169,80 @@ def test_a_host_side_failure_in_any_engine_call_ends_every_rank_at_the_same_coll
         assert out[0][1] == out[1][1] == out[2][1], (fail_at, [st for _, st in out])  # the same number of each collective on every rank
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("lag", [0, 2])
+@pytest.mark.parametrize("where", ["chunk_expand", "chunk_insert", "chunk_commit"])
+def test_a_sticky_engine_failure_ends_every_rank_at_the_same_collective(where, lag):
+    """What a HIP fault looks like: from the first failing call on EVERY call of that rank's engine raises -- the control-block
+    snapshot and wait included, which the failing rank still makes in order to leave the chunk loop in step with the others.  The
+    orchestrator must keep pairing the collectives (dead chunks, guarded control-block calls) and every rank must raise."""
+    from ac_solver.search import sharded
+    from ac_solver.search.sharded import bfs_sharded
+
+    for fail_at in (3, 10, 17):
+        calls = {}
+        broken = []
+
+        class Sticky(OracleShardEngine):
+            def _maybe(self, name):
+                if self.rank != 1:
+                    return
+                if name == where:
+                    calls[name] = calls.get(name, 0) + 1
+                    if calls[name] == fail_at:
+                        broken.append(name)
+                if broken:
+                    raise RuntimeError("device lost (simulated)")
+
+            def chunk_expand(self, *a, **k):
+                self._maybe("chunk_expand")
+                return super().chunk_expand(*a, **k)
+
+            def chunk_insert(self, n_par):
+                self._maybe("chunk_insert")
+                return super().chunk_insert(n_par)
+
+            def chunk_insert_dead(self, n_par):
+                self._maybe("chunk_insert_dead")
+                return super().chunk_insert_dead(n_par)
+
+            def chunk_commit(self, max_nodes):
+                self._maybe("chunk_commit")
+                return super().chunk_commit(max_nodes)
+
+            def ctl_snapshot(self, slot):
+                self._maybe("ctl_snapshot")
+                return super().ctl_snapshot(slot)
+
+            def ctl_wait(self, slot):
+                self._maybe("ctl_wait")
+                return super().ctl_wait(slot)
+
+            def fail_local(self):
+                self._maybe("fail_local")
+                return super().fail_local()
+
+        def run(comm):
+            try:
+                bfs_sharded(AK2, 600, comm=comm, engine_factory=Sticky, batch_parents=8)
+            except RuntimeError as e:
+                return str(e), dict(comm.stats)
+            return "no error", dict(comm.stats)
+
+        sharded._FORCE_LAG = lag
+        try:
+            out = run_threads(3, run)
+        finally:
+            sharded._FORCE_LAG = None
+        msgs = [m for m, _ in out]
+        if not broken:
+            assert all(m == "no error" for m in msgs), (fail_at, msgs)
+            continue
+        assert all("sharded bfs failed" in m for m in msgs), (fail_at, msgs)
+        assert "simulated" in msgs[1], (fail_at, msgs)
+        assert out[0][1] == out[1][1] == out[2][1], (fail_at, [st for _, st in out])
+
+
 def test_a_device_side_capacity_failure_reaches_every_rank():
     """node capacity exhausted on one rank: refused on that rank before anything is written, carried to the others by the next
     chunk's headers (or by the closing all-reduce when the search ends first)"""
