@@ -21,6 +21,8 @@ U8, I32, I64, I8, F32 = 0, 1, 2, 3, 4
 ENV_RECORD_ACTIONS = 1
 SEARCH_BFS, SEARCH_GREEDY = 0, 1
 ERR_ASSERT, ERR_INDEX, ERR_VALUE, ERR_UNPACKABLE = 1, 2, 3, 250
+# acx_set_option: tuning / test knobs of the search entry points (process wide; nothing on a call path reads the environment)
+OPT_BFS_NO_RUNAHEAD, OPT_GREEDY_HOST, OPT_GREEDY_HAND_MIN, OPT_MEGA_RANK_MAX, OPT_BFS_MANY_BMAX, OPT_GREEDY_SLOTS, OPT_GENERAL_MOVE = range(7)
 
 
 class AcxError(RuntimeError):
@@ -116,6 +118,8 @@ SIGNATURES = {
     "acx_shard_find": (C.c_int, [_vp, C.c_int64, _i64p, _vp]),
     "acx_shard_node_info": (C.c_int, [_vp, C.c_int64, _i64p]),
     "acx_release_cached_memory": (C.c_int, []),
+    "acx_set_option": (C.c_int, [C.c_int, C.c_int64]),
+    "acx_get_option": (C.c_int64, [C.c_int]),
     "acx_policy_sample": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _vp, _vp, C.c_int, C.c_uint64, _vp, _vp, _vp, _vp]),
     "acx_policy_packed_bytes": (C.c_int64, [C.c_int]),
     "acx_search_minima_enable": (C.c_int, [C.c_int]),
@@ -189,3 +193,22 @@ def simplify_rows(rows, cyclical):
     check(lib.acx_simplify_relators(ptr(rows, C.c_int8), n, width, int(bool(cyclical)), ptr(out, C.c_int8), ptr(lens, C.c_int32),
                                     ptr(err, C.c_uint8)), "acx_simplify_relators")
     return out, lens, err
+
+
+class options:
+    """`with _acx.options(OPT_GREEDY_HAND_MIN=16, ...):` -- library options (include/acx.h: ACX_OPT_*) for the duration of a block, the
+    previous values restored on the way out.  Process wide: meant for tests and tuning runs, not for concurrent callers."""
+
+    def __init__(self, **values):
+        self.values = {globals()[k]: int(v) for k, v in values.items()}
+
+    def __enter__(self):
+        self.saved = {k: lib.acx_get_option(k) for k in self.values}
+        for k, v in self.values.items():
+            check(lib.acx_set_option(k, v), "acx_set_option")
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            lib.acx_set_option(k, v)
+        return False

@@ -1,6 +1,5 @@
 """Shared driver for bfs / greedy_search: hands the presentation to libacx's device frontier."""
 import ctypes as C
-import os
 
 import numpy as np
 
@@ -94,16 +93,7 @@ def run_search_groups(kind, groups, max_nodes_to_explore, cyclical, n_threads=16
     key width, taken by a fixed set of workgroups one after the other.  bfs: one batch after the other -- a batch fills the GPU on
     its own (acx_bfs_many.h: a tile of every search's frontier per workgroup), and batches in flight together only evict each
     other's tables from the caches (measured: the seven widths one after another 144 ms, all at once 190-250 ms).
-    ACX_SWEEP_WORKERS=k: the earlier form, k host threads with one acx_search_many call per batch (A/B runs).
     -> list (per batch) of lists of (solved, path, stats), each identical to what run_search returns."""
-    workers = int(os.environ.get("ACX_SWEEP_WORKERS", "0"))
-    if workers > 0 and len(groups) > 1:
-        from concurrent.futures import ThreadPoolExecutor
-
-        order = sorted(range(len(groups)), key=lambda k: -np.asarray(groups[k]).shape[-1])  # widest first
-        with ThreadPoolExecutor(max_workers=workers) as ex:
-            futs = {k: ex.submit(run_search_many, kind, groups[k], max_nodes_to_explore, cyclical, n_threads, path_cap) for k in order}
-            return [futs[k].result() for k in range(len(groups))]
     _acx.require_device()
     rows = [_acx.as_i8_rows(np.asarray(g)) for g in groups]
     ng = len(rows)

@@ -38,7 +38,6 @@ backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests; an in-process thread co
 ranks in the GPU tests).
 """
 import ctypes as C
-import os
 import sys
 
 import numpy as np
@@ -538,8 +537,6 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
     # The kernels are bound by vector issue (expansion) or by the memory system (the rest); what shortens the search is
     # shortening them.  So without an exchange everything runs in stream order; with one, expansion + all-to-all start at once
     # on the side stream ("insert"): the per-rank kernels shrink with the world size and the collectives are what has to be hidden.
-    if overlap is None and os.environ.get("ACX_SHARD_OVERLAP"):  # (A/B runs: insert | commit | off)
-        overlap = {"insert": "insert", "commit": "commit", "off": False}[os.environ["ACX_SHARD_OVERLAP"]]
     if overlap is None or overlap is True:
         overlap = "insert" if exchange else False
     assert overlap in (False, "insert", "commit"), overlap

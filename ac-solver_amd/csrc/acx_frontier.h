@@ -5,7 +5,6 @@
 #include <array>
 #include <string.h>
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 #include <stdlib.h>
 #include <algorithm>
 #include <map>
@@ -40,27 +39,8 @@ ACX_HD uint64_t fold(uint64_t k) { return k; }
 ACX_HD uint64_t fold(u128 k) { return (uint64_t)k ^ ((uint64_t)(k >> 64) * 0x9e3779b97f4a7c15ull); }
 template <typename W> ACX_HD uint64_t hash_key(W k0, W k1) { return mix64(fold(k0) * 0x9e3779b97f4a7c15ull + mix64(fold(k1))); }
 
-// Visited set of the BFS frontiers: open addressing with the FULL key inline, one entry per 32-byte (u64 keys) /
-// 64-byte (u128 keys) sector, so a probe is ONE random memory access whether the slot is empty, holds another key
-// or holds this key.  `stamp` = epoch << 32 | tag of the candidate that claimed the entry; an entry whose epoch is not
-// the running batch's is a committed state, an entry of the running epoch is provisional and folds to the minimum tag
-// among equal keys (64-bit atomicMin).  The table never stores node ids: BFS only asks "seen before?".
-template <typename W> struct TabEntry;
-template <> struct alignas(32) TabEntry<uint64_t> {
-    uint64_t k0, k1;
-    unsigned long long stamp;
-    uint64_t pad;
-};
-template <> struct alignas(64) TabEntry<u128> {
-    u128 k0, k1;
-    unsigned long long stamp;
-    uint64_t pad[3];
-};
-constexpr unsigned long long kStampEmpty = ~0ull;
 
 template <typename W> struct SearchDev {
-    TabEntry<W>* tab;  // sharded BFS visited table (inline keys); tmask = entries - 1
-    uint32_t tmask;
     unsigned long long* stab;  // fused single-GPU BFS: stamp table (acx_bfs.h); stmask = slots - 1
     uint32_t stmask;
     // node arena (committed nodes, id order == the reference's insertion order)
@@ -84,8 +64,8 @@ template <typename W> struct SearchDev {
     uint32_t* cflag;  // 1 = winner / new
     uint32_t* cpos;   // exclusive scan of cflag
     uint8_t* cknown;  // greedy: already in the visited table
-    uint8_t* btook;   // fused BFS: byte-wide "took the entry" / "was replaced" flags of k_insert_tab (instead of cflag / cslot;
-    uint8_t* brepl;   // null on the other paths): a quarter of the flag traffic of the three kernels that touch them
+    uint8_t* btook;   // fused BFS (acx_bfs.h): byte-wide "took the slot" / "was replaced" flags per tag of the running batch
+    uint8_t* brepl;   // (null on the greedy batch-per-launch path, which numbers its winners through cflag / cpos)
     // device scalars
     unsigned long long* solved_tag;   // min tag with total length 2
     unsigned long long* shorter_tag;  // greedy: min tag of a NEW child shorter than the bucket
@@ -235,85 +215,6 @@ __global__ void __launch_bounds__(256) k_mark(SearchDev<W> d, const uint32_t* __
     if (win && bucket_len >= 0 && (int)d.clen[t] < bucket_len) atomicMin(d.shorter_tag, (unsigned long long)t);
 }
 
-// BFS: insert candidate t into the inline-key table (see TabEntry).  Winner bookkeeping without a second pass over the
-// table: cflag[t] = 1 when t took the entry (claimed it empty, or replaced a larger tag of the same key), and a candidate
-// that is replaced later gets cslot[its tag] = 1 from the one that replaced it (cslot must be zero on entry); the
-// winners are then cflag & !cslot (k_mark_tab, a streaming pass).
-template <typename W>
-__global__ void __launch_bounds__(256) k_insert_tab(SearchDev<W> d, uint32_t m, uint32_t epoch, int skip_known) {
-    ACX_VGPR_PAD_W(W, "v39", "v47");
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m) return;
-    if (skip_known && d.cknown[t]) {
-        if (d.btook) d.btook[t] = 0;
-        else d.cflag[t] = 0;
-        return;
-    }
-    const W k0 = d.ck0[t], k1 = d.ck1[t];
-    const unsigned long long me = ((unsigned long long)epoch << 32) | t;
-    uint32_t h = (uint32_t)hash_key<W>(k0, k1) & d.tmask, probes = 0;
-    uint32_t took = 0;
-    for (;;) {
-        TabEntry<W>* e = d.tab + h;
-        const W e0 = e->k0, e1 = e->k1;  // one sector together with the stamp
-        unsigned long long st = e->stamp;
-        if (st == kStampEmpty) {
-            st = atomicCAS(&e->stamp, kStampEmpty, me);
-            if (st == kStampEmpty) {  // claimed: the key moves in (readers of this batch compare through the candidate arena)
-                e->k0 = k0;
-                e->k1 = k1;
-                took = 1;
-                break;
-            }
-            // lost the race: `st` is a stamp of the running epoch now
-        }
-        if ((uint32_t)(st >> 32) == epoch) {
-            const uint32_t o = (uint32_t)st;
-            if (d.ck0[o] == k0 && d.ck1[o] == k1) {
-                if (st > me) {
-                    const unsigned long long prev = atomicMin(&e->stamp, me);  // the holder I actually replaced (if any)
-                    if (prev > me) {
-                        took = 1;
-                        if (d.brepl) d.brepl[(uint32_t)prev] = 1;  // that candidate is no longer the first discoverer
-                        else d.cslot[(uint32_t)prev] = 1;
-                    }
-                }
-                break;
-            }
-        } else if (e0 == k0 && e1 == k1) {
-            break;  // a committed state
-        }
-        h = (h + 1) & d.tmask;
-        if (++probes > d.tmask) {
-            atomicOr(d.err, kErrTableFull);
-            break;
-        }
-    }
-    if (d.btook) d.btook[t] = (uint8_t)took;
-    else d.cflag[t] = took;
-}
-
-template <typename W> __global__ void __launch_bounds__(256) k_mark_tab(SearchDev<W> d, uint32_t m) {
-    ACX_VGPR_PAD("v15");
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m) return;
-    d.cflag[t] = (d.cflag[t] && !d.cslot[t]) ? 1u : 0u;
-}
-
-template <typename W> __global__ void k_root_tab(SearchDev<W> d, W k0, W k1, uint32_t tl) {
-    ACX_VGPR_PAD("v23");
-    d.k0[0] = k0;
-    d.k1[0] = k1;
-    d.parent[0] = kEmpty;
-    d.act[0] = 0xff;
-    d.tlen[0] = (uint8_t)tl;
-    d.depth[0] = 0;
-    TabEntry<W>* e = d.tab + ((uint32_t)hash_key<W>(k0, k1) & d.tmask);
-    e->k0 = k0;
-    e->k1 = k1;
-    e->stamp = 0;  // epoch 0 is never a running batch
-}
-
 // What the reference does with this batch, decided on the device so that the host needs ONE read-back per batch.
 struct Decision {
     uint32_t p_end;       // last parent of the batch that the reference pops
@@ -419,99 +320,6 @@ __global__ void __launch_bounds__(256) k_commit(SearchDev<W> d, const uint32_t* 
 #endif
 constexpr uint32_t kCompactItems = ACX_COMPACT_ITEMS;  // a multiple of 8, at most 32 (one flag bit each in a 32-bit word)
 constexpr uint32_t kCompactTile = 256 * kCompactItems;
-constexpr unsigned long long kTileAgg = 1ull, kTileIncl = 2ull;
-
-template <typename W>
-__global__ void __launch_bounds__(256) k_compact_tab(SearchDev<W> d, uint32_t pbegin, uint32_t m, uint32_t base, uint32_t cap_nodes, uint32_t epoch,
-                                                     unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t* __restrict__ total_out) {
-    __shared__ uint32_t s_tile, s_prefix, s_wsum[4];
-    __shared__ uint16_t s_list[kCompactTile];
-    ACX_VGPR_PAD("v47");
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint32_t tile = s_tile, ntiles = (m + kCompactTile - 1) / kCompactTile;
-    const uint32_t t0 = tile * kCompactTile + tid * kCompactItems;
-    uint32_t fl = 0;  // bit i: candidate t0 + i is a winner (took its entry and was not replaced)
-    if (t0 + kCompactItems <= m) {
-#pragma unroll
-        for (uint32_t q = 0; q < kCompactItems / 8; q++) {
-            const unsigned long long tb = *(const unsigned long long*)(d.btook + t0 + 8 * q), rb = *(const unsigned long long*)(d.brepl + t0 + 8 * q);
-            const unsigned long long w = tb & ~rb;  // bytes are 0 / 1
-#pragma unroll
-            for (uint32_t i = 0; i < 8; i++) fl |= (uint32_t)((w >> (8u * i)) & 1ull) << (8 * q + i);
-        }
-    } else {
-        for (uint32_t i = 0; i < kCompactItems; i++)
-            if (t0 + i < m && d.btook[t0 + i] && !d.brepl[t0 + i]) fl |= 1u << i;
-    }
-    const uint32_t cnt = (uint32_t)__popc(fl);
-    uint32_t incl = cnt;  // inclusive scan over the wave
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
-        if (lane >= (uint32_t)o) incl += v;
-    }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (uint32_t w = 0; w < wave; w++) wbase += s_wsum[w];
-    const uint32_t block_total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    // local winner list (offsets inside the tile), in tag order
-    {
-        uint32_t pos = wbase + incl - cnt, f = fl;
-        while (f) {
-            const uint32_t i = (uint32_t)__builtin_ctz(f);
-            f &= f - 1;
-            s_list[pos++] = (uint16_t)(tid * kCompactItems + i);
-        }
-    }
-    if (wave == 0) {
-        const unsigned long long tagged = (unsigned long long)epoch << 34;
-        if (lane == 0)
-            __hip_atomic_store(&status[tile], tagged | ((tile == 0 ? kTileIncl : kTileAgg) << 32) | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t excl = 0;
-        long long j0 = (long long)tile - 1;
-        while (j0 >= 0) {  // 64 predecessors per round, nearest first
-            const long long j = j0 - (long long)lane;
-            unsigned long long w = tagged | (kTileIncl << 32);  // before the first tile: inclusive 0
-            for (;;) {
-                if (j >= 0) w = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool ready = (w >> 34) == (unsigned long long)epoch && ((w >> 32) & 3ull) != 0;
-                if (__all(ready)) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            const unsigned long long inc = __ballot(((w >> 32) & 3ull) == kTileIncl);
-            const uint32_t first = inc ? (uint32_t)__builtin_ctzll(inc) : 63u;  // nearest predecessor that knows its inclusive count
-            uint32_t v = lane <= first ? (uint32_t)w : 0u;
-            for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-            excl += v;
-            if (inc) break;
-            j0 -= 64;
-        }
-        if (lane == 0) {
-            if (tile != 0) __hip_atomic_store(&status[tile], tagged | (kTileIncl << 32) | (excl + block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_prefix = excl;
-            if (tile == ntiles - 1) {
-                *total_out = excl + block_total;
-                *ticket = 0;  // every ticket of this launch has been taken
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t first_id = base + s_prefix, tbase = tile * kCompactTile;
-    for (uint32_t j = tid; j < block_total; j += 256) {
-        const uint32_t id = first_id + j;
-        if (id >= cap_nodes) break;  // beyond the budget: never read
-        const uint32_t t = tbase + s_list[j];
-        const uint32_t p = t / 12u, pid = pbegin + p;
-        d.k0[id] = d.ck0[t];
-        d.k1[id] = d.ck1[t];
-        d.parent[id] = pid;
-        d.act[id] = (uint8_t)(t - 12u * p);
-        d.tlen[id] = d.clen[t];
-        d.depth[id] = d.depth[pid] + 1;
-    }
-}
 
 // k_decide for the one-pass BFS commit: the winners of the batch are nodes base .. base + total - 1 in tag order, so
 // "winners before tag T" is a binary search over their (parent, action) and the budget-crossing candidate is winner need - 1.
@@ -691,6 +499,10 @@ __global__ void __launch_bounds__(256) k_rank_sort(SearchDev<W> d, const uint32_
     if (i < n) out[rank] = mine;
 }
 
+
+// exclusive prefix sum of n 32-bit flags (the batch-per-launch paths: greedy fallback, simplex graph).  tmp == nullptr: only the size
+// of the temporary storage is returned in *tmp_bytes.  Defined once, in acx_search.hip (the only unit that includes rocprim).
+int scan_u32_exclusive(void* tmp, size_t* tmp_bytes, const uint32_t* in, uint32_t* out, size_t n, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------- host ---
 // Device blocks of finished searches are kept in one process-wide pool and handed to the next search: hipMalloc / hipFree

@@ -1102,21 +1102,11 @@ __global__ void __launch_bounds__(kGT) k_greedy_persistent(GreedyDev<W> g, Greed
     greedy_run<W, kSingleSortCap<W>, (uint32_t)kGT, NF>(g, out, nullptr, nullptr, 0);
 }
 
-// One search per workgroup: acx_search_many runs a whole group of independent greedy searches in ONE launch (a
-// stream per search is limited by the few hardware queues a process gets; here every CU can carry a search).
-template <typename W, bool NF>
-__global__ void __launch_bounds__(kGreedyMultiThreads) k_greedy_multi(const GreedyDev<W>* __restrict__ gs, GreedyOut* __restrict__ outs, int32_t* __restrict__ path_act,
-                                                      int32_t* __restrict__ path_len, long long path_cap) {
-    const GreedyDev<W> g = gs[blockIdx.x];
-    greedy_run<W, greedy_cfg<W>::kSortCap, kGreedyMultiThreads, NF>(g, outs + blockIdx.x, path_act + (size_t)blockIdx.x * path_cap, path_len + (size_t)blockIdx.x * path_cap, path_cap);
-}
-
 // ---- many searches on a FIXED number of workgroups (round 4) -----------------------------------------------------------------------
-// k_greedy_multi gives every search of a launch its own workgroup and its own memory, so a launch is as many searches as fit the
-// memory budget (46 at 1e6 nodes), a batch of 170 is four launches one after the other, and every launch waits for its slowest
-// search while the compute units of the finished ones stand idle -- with the seven batches of a Miller-Schupp sweep on seven
-// streams (which share four hardware queues by default) the chip ran at a quarter of the workgroup time it was given
-// (5.5e10 workgroup cycles = 103 ms x 256 compute units in a 400 ms sweep).  Here a launch is a fixed set of SLOTS -- a workgroup
+// Rounds 2-3 gave every search of a launch its own workgroup and its own memory (k_greedy_multi): a launch was as many searches as fit
+// the memory budget (46 at 1e6 nodes), a batch of 170 four launches one after the other, and every launch waited for its slowest
+// search while the compute units of the finished ones stood idle (5.5e10 workgroup cycles = 103 ms x 256 compute units in a 400 ms
+// sweep).  Here a launch is a fixed set of SLOTS -- a workgroup
 // with the memory of one search -- and the searches are JOBS the workgroups take from a counter, one after the other: a slot is
 // cleaned between two jobs by the workgroup itself (the visited table, the rows of the bucket table the last job can have
 // touched).  Searches of different max_relator_length share a launch (a job carries its L), so a whole sweep is one launch per

@@ -8,7 +8,7 @@
 // runs that bucket here, in MEGA-BATCHES of up to kMegaParents parents spread over the whole chip, and relaunches the
 // persistent kernel afterwards.  A mega-batch is the batch of acx_greedy.h step for step -- same tags, same decisions:
 //
-//   k_gm_runsort / k_gm_merge   order the bucket by the signed state tuple (runs sorted in LDS, merged by rank)
+//   k_gm_rank      order the bucket by the signed state tuple: an all-pairs counting sort over the whole chip
 //   k_gm_begin     scalars of the batch, empty in-batch table
 //   k_gm_expand    one lane per tag t = 12 * parent + action: move, success / raising-move test, read-only probe of the
 //                  visited table, in-batch dedup to the minimum tag (the key of a table occupant is REBUILT from its
@@ -59,10 +59,8 @@ template <typename W> struct MegaDev {
 };
 
 // ---- ordering a bucket ----------------------------------------------------------------------------------------------------
-// Runs of kMegaRun entries are sorted in LDS, one workgroup each (the bitonic network of acx_greedy.h); the final position of
-// an entry is its index in its own run plus, for every other run, the number of that run's keys that precede it (a binary
-// search: the keys of a bucket are pairwise distinct).
-// Buckets of at most kMegaRankMax entries (round 4) are ordered by COUNTING instead: the keys of a bucket are pairwise distinct, so the
+// A handed-off bucket of at most kMegaRankMax entries is ordered by COUNTING (round 4; a larger one the frontier kernel orders
+// itself before it hands it off): the keys of a bucket are pairwise distinct, so the
 // final position of an entry is the number of entries that precede it.  k_gm_rank spreads the n x n comparisons over the whole chip --
 // a work item is 256 entries against a tile of 32, an LDS broadcast per comparison -- and k_gm_begin, the first kernel of the
 // mega-batch behind it, writes the ids to their places: ~15 us for the average handed-off bucket (3 200 entries) where the sorted runs + rank merge took 41 + 15 us with three or
@@ -112,78 +110,6 @@ template <typename W> __global__ void __launch_bounds__(256) k_gm_rank(MegaDev<W
             if (jt == 0) g.gid[i] = id;
         }
         __syncthreads();
-    }
-}
-
-constexpr uint32_t kMegaRun = 1024;  // short runs: the bitonic network's depth grows with log^2 of the run, the merge only with the number of runs
-template <typename W> __global__ void __launch_bounds__(kGT) k_gm_runsort(MegaDev<W> md, uint32_t n, uint32_t chained) {
-    constexpr uint32_t SC = kMegaRun;
-    __shared__ W sk0[SC];
-    __shared__ W sk1[SC];
-    __shared__ uint32_t sid[SC];
-    ACX_VGPR_PAD_W(W, "v47", "v63");
-    const GreedyDev<W>& g = md.g;
-    if (chained) {  // (the grid is a fixed one: runs are dealt round-robin to its workgroups)
-        if (!md.sc->h_pending || !md.sc->h_sort) return;
-        n = md.sc->h_live;
-    }
-    const GreedyState* ps = g.state;
-    const BucketRec r = g.bk[(size_t)ps->cur_len * kDepthCap + ps->cur_depth];
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t i0 = blockIdx.x * SC; i0 < n; i0 += gridDim.x * SC) {
-        const uint32_t cnt = min(SC, n - i0);
-        for (uint32_t i = tid; i < cnt; i += kGT) {
-            const uint32_t id = g.arena[r.off + r.head + i0 + i];
-            const NodeKey<W> nk = g.nkeys[id];
-            sid[i] = id;
-            sk0[i] = nk.k0;
-            sk1[i] = nk.k1;
-        }
-        __syncthreads();
-        lds_sort<W, (uint32_t)kGT>(sk0, sk1, sid, cnt, tid);
-        for (uint32_t i = tid; i < cnt; i += kGT) {
-            g.gid[i0 + i] = sid[i];
-            g.gk0[i0 + i] = sk0[i];
-            g.gk1[i0 + i] = sk1[i];
-        }
-        __syncthreads();
-    }
-}
-
-template <typename W> __global__ void __launch_bounds__(256) k_gm_merge(MegaDev<W> md, uint32_t n, uint32_t chained) {
-    constexpr uint32_t SC = kMegaRun;
-    ACX_VGPR_PAD_W(W, "v47", "v63");
-    const GreedyDev<W>& g = md.g;
-    if (chained) {
-        if (!md.sc->h_pending || !md.sc->h_sort) return;
-        n = md.sc->h_live;
-    }
-    GreedyState* ps = g.state;
-    BucketRec* rp = g.bk + (size_t)ps->cur_len * kDepthCap + ps->cur_depth;
-    const BucketRec r = *rp;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const W m0 = g.gk0[i], m1 = g.gk1[i];
-        const uint32_t mine = i / SC;
-        uint32_t rank = i - mine * SC;
-        for (uint32_t q0 = 0, q = 0; q0 < n; q0 += SC, q++) {
-            if (q == mine) continue;
-            uint32_t lo = q0, hi = min(n, q0 + SC);  // first entry of run q that does not precede my key
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (key_less<W>(g.gk0[mid], g.gk1[mid], m0, m1)) lo = mid + 1;
-                else hi = mid;
-            }
-            rank += lo - q0;
-        }
-        g.arena[r.off + r.head + rank] = g.gid[i];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // (sorted_end is read above by every workgroup through the copy `r` only for off / head: writing it here races with nothing)
-        rp->sorted_end = r.cnt;
-        ps->sorts++;
-        if (n > greedy_cfg<W>::kSortCap) ps->big_sorts++;
-        ps->hist[min(15, 31 - __builtin_clz(n))]++;
-        if (n > ps->max_bucket) ps->max_bucket = n;
     }
 }
 

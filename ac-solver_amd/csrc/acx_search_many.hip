@@ -1,0 +1,657 @@
+// acx_search_many.hip -- many independent searches per call (acx_search_many, acx_search_groups): what the reference's Miller-Schupp
+// driver does one search after the other (search/miller_schupp/miller_schupp.py:140-158).
+//   greedy_search  the searches are JOBS that a fixed set of persistent workgroups takes from a counter (acx_greedy.h: k_greedy_sched),
+//                  one launch per key width
+//   bfs            the searches of a batch share the launches of the fused single search, a tile of every search's frontier per
+//                  workgroup (acx_bfs_many.h)
+// A single search (n == 1), verbose searches and searches under the digest hook go through acx_search, one after the other on a few
+// host threads.
+#include "acx_searcher.h"
+#include "acx_bfs.h"
+#include "acx_bfs_many.h"
+#include "acx_greedy.h"
+
+namespace acx {
+
+// Greedy searches as JOBS on a fixed set of workgroup slots (acx_greedy.h: k_greedy_sched).  `groups`: batches of presentations, each
+// with its own max_relator_length (all of one key width W); out0 = index of a batch's first search in the output arrays.
+struct SearchGroupIn {
+    const int8_t* rows;
+    int64_t n;
+    int L;
+    int64_t out0;
+};
+static uint32_t greedy_slots_wanted() {
+    // one workgroup of this kernel per compute unit (its 1024 lanes take the whole register file); ACX_OPT_GREEDY_SLOTS: the tests run
+    // many jobs on a few slots
+    return (uint32_t)std::min<int64_t>(std::max<int64_t>(option(ACX_OPT_GREEDY_SLOTS, 256), 1), 4096);
+}
+template <typename W>
+static int run_greedy_sched(const std::vector<SearchGroupIn>& groups, int64_t max_nodes, int cyclical, int32_t* solved, int32_t* path_action, int32_t* path_len,
+                            int64_t path_cap, int64_t* path_n, acx_search_stats* stats, int32_t* rc_out, uint8_t* need_rerun, uint32_t slots_cap) {
+    int64_t n_all = 0;
+    int L_max = 1;
+    for (const auto& gr : groups) n_all += gr.n, L_max = std::max(L_max, gr.L);
+    if (n_all == 0) return ACX_OK;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    // a slot: the node arrays, the id table, the bucket table / bitmap / arena and the sort scratch of ONE search (as run_greedy_group lays them out)
+    const uint64_t cap_nodes = (uint64_t)max_nodes + 64 + 12 * 1024;
+    uint64_t n_slots = 1024;
+    while (n_slots < 2 * (cap_nodes + 12288)) n_slots <<= 1;
+    if (n_slots > (1ull << 31)) return fail(ACX_E_INVAL, "acx_search_many: budget too large for 32-bit node ids");
+    const uint32_t nlen_max = (uint32_t)(2 * L_max + 1);
+    const uint64_t arena_entries = std::min<uint64_t>(8ull * (uint64_t)std::max<int64_t>(max_nodes, 1) + (1ull << 20), 1ull << 31);
+    const uint64_t sort_cap = 2 * ((uint64_t)std::max<int64_t>(max_nodes, 1) + 64) + 4096;
+    auto up = [](uint64_t b) { return (b + 255) / 256 * 256; };
+    const uint64_t b_slots = up(n_slots * 8), b_bk = up((uint64_t)nlen_max * kDepthCap * sizeof(BucketRec)), b_bm = up((uint64_t)nlen_max * (kDepthCap / 32) * 4);
+    const uint64_t b_arena = up(arena_entries * 4), b_key = up(cap_nodes * sizeof(NodeKey<W>)), b_u32 = up(cap_nodes * 4), b_u8 = up(cap_nodes);
+    const uint64_t b_gk = up(sort_cap * sizeof(W)), b_gid = up(sort_cap * 4);
+    const uint64_t per_rest = b_arena + b_key + 2 * b_u32 + 2 * b_u8 + 2 * b_gk + b_gid;
+    const uint64_t per_slot = b_slots + b_bk + b_bm + per_rest;
+    size_t free_b = 0, total_b = 0;
+    double avail = 64e9;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) avail = (double)free_b + (double)block_pool().cached_on(BlockPool::current_device());
+    const double budget = std::max(2.0 * (double)per_slot, std::min(64e9, avail / 5.0));
+    // the jobs, by move code: a root in normal form keeps its search in normal form (the shorter move code); one launch per code
+    std::vector<GreedyJob<W>> jobs[2];
+    std::vector<int64_t> where[2];  // job -> index in the output arrays
+    for (const auto& gr : groups)
+        for (int64_t k = 0; k < gr.n; k++) need_rerun[gr.out0 + k] = 0, rc_out[gr.out0 + k] = ACX_OK, solved[gr.out0 + k] = 0, path_n[gr.out0 + k] = 0;
+    for (const auto& gr : groups)
+        for (int64_t k = 0; k < gr.n; k++) {
+            const int64_t o = gr.out0 + k;
+            Pres<W> root;
+            bool ok = pack_relator<W>(gr.rows + k * 2 * gr.L, gr.L, root.w0, root.n0);
+            ok = pack_relator<W>(gr.rows + k * 2 * gr.L + gr.L, gr.L, root.w1, root.n1) && ok;
+            if (!ok) {
+                rc_out[o] = ACX_E_ROWERR;
+                return fail(ACX_E_ROWERR, "acx_search_many: presentation %lld is not a zero-padded word pair over {+-1,+-2}", (long long)o);
+            }
+            GreedyJob<W> jb;
+            memset(&jb, 0, sizeof(jb));
+            jb.root_k0 = keyops<W>::make(root.w0, root.n0);
+            jb.root_k1 = keyops<W>::make(root.w1, root.n1);
+            jb.root_len = (uint32_t)(root.n0 + root.n1);
+            jb.nlen = (uint32_t)(2 * gr.L + 1);
+            jb.L = gr.L;
+            const int code = is_normal_form<W>(root, cyclical != 0) ? 1 : 0;
+            jobs[code].push_back(jb);
+            where[code].push_back(o);
+        }
+    // longest first, as far as one can tell beforehand: a search that is still running when the others are done has the chip to itself
+    // (measured on the Miller-Schupp sweep at 1e6 nodes: an UNSOLVED search costs 1.33e8 workgroup cycles at max_relator_length 18, 1.20e8
+    // at 20, 8.2e7 at 24, 6.9e7 at 28 -- the tighter the length bound, the more batches a node costs -- and a solved one a tenth of that;
+    // which searches stay unsolved is not known beforehand, so: the smaller max_relator_length first, the longer relators first)
+    for (int code = 0; code < 2; code++) {
+        std::vector<size_t> order(jobs[code].size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+            const GreedyJob<W>&x = jobs[code][a], &y = jobs[code][b];
+            return x.L != y.L ? x.L < y.L : x.root_len > y.root_len;
+        });
+        std::vector<GreedyJob<W>> js(order.size());
+        std::vector<int64_t> ws(order.size());
+        for (size_t i = 0; i < order.size(); i++) js[i] = jobs[code][order[i]], ws[i] = where[code][order[i]];
+        jobs[code].swap(js);
+        where[code].swap(ws);
+    }
+    const uint32_t n_most = (uint32_t)std::max(jobs[0].size(), jobs[1].size());
+    uint32_t R = (uint32_t)std::max<double>(1.0, std::min<double>(std::min<uint32_t>(n_most, std::max<uint32_t>(slots_cap, 1u)), budget / (double)per_slot));
+    DevBuf big, dslots, djobs, dcounter, douts, dpa, dpl;
+    while (big.alloc((uint64_t)R * per_slot)) {  // (the estimate of the free memory was too good: fewer slots -- the jobs just take longer)
+        if (R == 1) return ACX_E_NOMEM;
+        (void)hipGetLastError();  // (the failed hipMalloc's error must not meet the launch check below)
+        R = (R + 1) / 2;
+    }
+    uint8_t* p_slots = (uint8_t*)big.p;
+    uint8_t* p_bk = p_slots + (uint64_t)R * b_slots;
+    uint8_t* p_bm = p_bk + (uint64_t)R * b_bk;
+    uint8_t* p_rest = p_bm + (uint64_t)R * b_bm;
+    std::vector<GreedyDev<W>> hslots((size_t)R);
+    for (uint32_t r = 0; r < R; r++) {
+        GreedyDev<W>& g = hslots[r];
+        memset(&g, 0, sizeof(g));
+        uint8_t* q = p_rest + (uint64_t)r * per_rest;
+        auto take = [&](uint64_t bytes) {
+            uint8_t* x = q;
+            q += bytes;
+            return x;
+        };
+        g.tab = (unsigned long long*)(p_slots + (uint64_t)r * b_slots);
+        g.tmask = (uint32_t)(n_slots - 1);
+        g.bk = (BucketRec*)(p_bk + (uint64_t)r * b_bk);
+        g.bitmap = (uint32_t*)(p_bm + (uint64_t)r * b_bm);
+        g.arena = (uint32_t*)take(b_arena);
+        g.nkeys = (NodeKey<W>*)take(b_key);
+        g.d.parent = (uint32_t*)take(b_u32);
+        g.d.depth = (uint32_t*)take(b_u32);
+        g.d.act = take(b_u8);
+        g.d.tlen = take(b_u8);
+        g.gk0 = (W*)take(b_gk);
+        g.gk1 = (W*)take(b_gk);
+        g.gid = (uint32_t*)take(b_gid);
+        g.d.cyclical = cyclical;
+        g.arena_cap = (uint32_t)arena_entries;
+        g.nlen = nlen_max;  // (rows of the slot's bucket table; a job runs with its own 2 L + 1)
+        g.max_nodes = (long long)max_nodes;
+    }
+    hipStream_t st = nullptr;
+    {  // the 128-bit searches are the longer ones: when both widths are in flight their workgroups get a free compute unit first
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        ACX_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, sizeof(W) > 8 ? hi : lo));
+    }
+    struct StreamGuard {
+        hipStream_t s;
+        ~StreamGuard() {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+    } guard{st};
+    const int64_t pc = std::max<int64_t>(path_cap, 1);
+    if (dslots.alloc((size_t)R * sizeof(GreedyDev<W>)) || djobs.alloc((size_t)n_most * sizeof(GreedyJob<W>)) || dcounter.alloc(256) ||
+        douts.alloc((size_t)n_most * sizeof(GreedyOut)) || dpa.alloc((size_t)n_most * pc * 4) || dpl.alloc((size_t)n_most * pc * 4))
+        return ACX_E_NOMEM;
+    EventPair evs;
+    ACX_HIP_TRY(evs.create());
+    for (int code = 1; code >= 0; code--) {
+        const size_t nj = jobs[code].size();
+        if (!nj) continue;
+        for (uint32_t r = 0; r < R; r++) hslots[r].nf = (uint32_t)code;
+        // the slots as a search expects them: table free, bucket records and bitmaps zero (between two jobs the workgroup does it itself)
+        ACX_HIP_TRY(hipMemsetAsync(p_slots, 0xff, (uint64_t)R * b_slots, st));
+        ACX_HIP_TRY(hipMemsetAsync(p_bk, 0, (uint64_t)R * (b_bk + b_bm), st));
+        ACX_HIP_TRY(hipMemcpyAsync(dslots.p, hslots.data(), (size_t)R * sizeof(GreedyDev<W>), hipMemcpyHostToDevice, st));
+        ACX_HIP_TRY(hipMemcpyAsync(djobs.p, jobs[code].data(), nj * sizeof(GreedyJob<W>), hipMemcpyHostToDevice, st));
+        ACX_HIP_TRY(hipMemsetAsync(dcounter.p, 0, 256, st));
+        ACX_HIP_TRY(hipMemsetAsync(douts.p, 0, nj * sizeof(GreedyOut), st));
+        ACX_HIP_TRY(hipEventRecord(evs.a, st));
+        const unsigned grid = (unsigned)std::min<size_t>(R, nj);
+        if (code)
+            hipLaunchKernelGGL((k_greedy_sched<W, true>), dim3(grid), dim3(kGreedyMultiThreads), 0, st, (const GreedyDev<W>*)dslots.p, (const GreedyJob<W>*)djobs.p, (uint32_t)nj,
+                               (uint32_t*)dcounter.p, (GreedyOut*)douts.p, (int32_t*)dpa.p, (int32_t*)dpl.p, (long long)pc);
+        else
+            hipLaunchKernelGGL((k_greedy_sched<W, false>), dim3(grid), dim3(kGreedyMultiThreads), 0, st, (const GreedyDev<W>*)dslots.p, (const GreedyJob<W>*)djobs.p, (uint32_t)nj,
+                               (uint32_t*)dcounter.p, (GreedyOut*)douts.p, (int32_t*)dpa.p, (int32_t*)dpl.p, (long long)pc);
+        ACX_HIP_TRY(hipGetLastError());
+        ACX_HIP_TRY(hipEventRecord(evs.b, st));
+        const double t_launched = since();
+        std::vector<GreedyOut> o(nj);
+        std::vector<int32_t> pa(nj * (size_t)pc), pl(nj * (size_t)pc);
+        ACX_HIP_TRY(hipMemcpyAsync(o.data(), douts.p, nj * sizeof(GreedyOut), hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipMemcpyAsync(pa.data(), dpa.p, nj * (size_t)pc * 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipMemcpyAsync(pl.data(), dpl.p, nj * (size_t)pc * 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipStreamSynchronize(st));
+        float ms = 0;
+        ACX_HIP_TRY(hipEventElapsedTime(&ms, evs.a, evs.b));
+        if (g_debug) {  // -DACX_GREEDY_PROFILE=1 builds: where the workgroups' cycles go, summed over the launch's searches
+            unsigned long long tp[12] = {}, tot = 0, batches = 0, sorts = 0, bigs = 0;
+            for (size_t j = 0; j < nj; j++) {
+                for (int q = 0; q < 12; q++) tp[q] += o[j].t_phase[q];
+                batches += o[j].batches;
+                sorts += o[j].sorts;
+                bigs += o[j].big_sorts;
+            }
+            for (int q = 0; q < 8; q++) tot += tp[q];
+            {  // the longest searches of the launch (their share of the launch's cycles decides how well any order can pack them)
+                std::vector<unsigned long long> cyc(nj, 0);
+                for (size_t j = 0; j < nj; j++)
+                    for (int q = 0; q < 8; q++) cyc[j] += o[j].t_phase[q];
+                std::vector<unsigned long long> sorted_c(cyc);
+                std::sort(sorted_c.begin(), sorted_c.end());
+                size_t first_long = nj;  // position (in job order) of the first search longer than half the longest
+                for (size_t j = 0; j < nj && first_long == nj; j++)
+                    if (2 * cyc[j] > sorted_c[nj - 1]) first_long = j;
+                size_t last_long = 0;
+                for (size_t j = 0; j < nj; j++)
+                    if (2 * cyc[j] > sorted_c[nj - 1]) last_long = j;
+                if (tot) {
+                    std::vector<size_t> idx(nj);
+                    for (size_t j = 0; j < nj; j++) idx[j] = j;
+                    std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return cyc[a] > cyc[b]; });
+                    for (size_t q = 0; q < std::min<size_t>(nj, 12); q++)
+                        fprintf(stderr, "[acx_greedy_sched]   job %zu: L %d, root length %u, %.3e cycles, %u nodes, %llu batches, status %u\n", idx[q], jobs[code][idx[q]].L,
+                                jobs[code][idx[q]].root_len, (double)cyc[idx[q]], o[idx[q]].nodes, (unsigned long long)o[idx[q]].batches, o[idx[q]].status);
+                    // mean cycles by max_relator_length and outcome
+                    for (int L0 = 1; L0 <= 61; L0++) {
+                        double c[2] = {0, 0};
+                        size_t cnt[2] = {0, 0};
+                        for (size_t j = 0; j < nj; j++)
+                            if (jobs[code][j].L == L0) c[o[j].status == GREEDY_SOLVED] += (double)cyc[j], cnt[o[j].status == GREEDY_SOLVED]++;
+                        if (cnt[0] + cnt[1]) fprintf(stderr, "[acx_greedy_sched]   L %d: %zu unsolved, mean %.3e cycles; %zu solved, mean %.3e\n", L0, cnt[0], cnt[0] ? c[0] / cnt[0] : 0.0, cnt[1], cnt[1] ? c[1] / cnt[1] : 0.0);
+                    }
+                }
+                if (tot)
+                    fprintf(stderr, "[acx_greedy_sched] job cycles: longest %.3e, median %.3e, p90 %.3e; searches longer than half the longest: first at job %zu, last at job %zu of %zu\n",
+                            (double)sorted_c[nj - 1], (double)sorted_c[nj / 2], (double)sorted_c[nj * 9 / 10], first_long, last_long, nj);
+            }
+            fprintf(stderr, "[acx_greedy_sched] %zu searches on %u slots (%s move code), %llu batches, %llu sorts (%llu of buckets larger than the LDS), launch %.2f ms; host: launched at %.1f ms, results at %.1f ms\n", nj, grid,
+                    code ? "normal-form" : "general", batches, sorts, bigs, ms, t_launched, since());
+            if (tot)
+                fprintf(stderr, "[acx_greedy_sched] %.3e workgroup cycles; cycles%%: select %.1f sort %.1f expand %.1f probe %.1f scan %.1f commit %.1f file %.1f tail %.1f; %.1f%% in sorts of buckets > LDS, %.1f%% in 256 < n <= LDS\n",
+                        (double)tot, 100.0 * tp[0] / tot, 100.0 * tp[1] / tot, 100.0 * tp[2] / tot, 100.0 * tp[3] / tot, 100.0 * tp[4] / tot, 100.0 * tp[5] / tot, 100.0 * tp[6] / tot,
+                        100.0 * tp[7] / tot, 100.0 * tp[10] / tot, 100.0 * tp[11] / tot);
+        }
+        for (size_t j = 0; j < nj; j++) {
+            const int64_t k = where[code][j];
+            const GreedyOut& r = o[j];
+            if (r.status == GREEDY_FALLBACK) {
+                need_rerun[k] = 1;
+                continue;
+            }
+            if (r.status == GREEDY_MOVE_ERROR) {
+                rc_out[k] = err_to_rc(r.err);
+                continue;
+            }
+            if (r.status != GREEDY_SOLVED && r.status != GREEDY_BUDGET && r.status != GREEDY_EXHAUSTED) {
+                rc_out[k] = fail(ACX_E_NODEVICE, "greedy frontier kernel ended in state %u", r.status);
+                continue;
+            }
+            solved[k] = r.status == GREEDY_SOLVED ? 1 : 0;
+            path_n[k] = r.path_n;
+            if ((int64_t)r.path_n > path_cap) {
+                rc_out[k] = fail(ACX_E_CAPACITY, "path has %u entries, buffer holds %lld", r.path_n, (long long)path_cap);
+            } else if (path_action && path_len) {
+                memcpy(path_action + k * path_cap, pa.data() + j * (size_t)pc, (size_t)r.path_n * 4);
+                memcpy(path_len + k * path_cap, pl.data() + j * (size_t)pc, (size_t)r.path_n * 4);
+            }
+            if (stats) {
+                stats[k].nodes = (int64_t)r.nodes;
+                stats[k].expanded = (int64_t)r.expanded;
+                stats[k].children = (int64_t)r.expanded * 12;
+                stats[k].levels = (int64_t)r.batches;
+                stats[k].min_len = (int32_t)r.min_len;
+                stats[k].seconds = ms * 1e-3;  // of the whole launch
+            }
+        }
+    }
+    return ACX_OK;
+}
+
+// A group of independent breadth-first searches, level-synchronous on the kernels of the fused single search (acx_bfs_many.h): one
+// round of launches advances every running search by one batch of at most `bmax` parents.  rc_out[k] = ACX_OK / ACX_E_CAPACITY (path
+// buffer, or a probe sequence that ran through the whole table) / ACX_E_ROWERR (the reference raises).
+static uint32_t bfs_many_bmax() {
+    const int64_t v = option(ACX_OPT_BFS_MANY_BMAX, 1 << 15);  // (the tests shrink it: more rounds, every tile edge)
+    return (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 128), 1 << 22);
+}
+template <typename W>
+static int run_bfs_group_fused(const int8_t* rows, int64_t n, int L, int64_t max_nodes, int cyclical, int32_t* solved, int32_t* path_action, int32_t* path_len,
+                               int64_t path_cap, int64_t* path_n, acx_search_stats* stats, int32_t* rc_out) {
+    if (n <= 0) return ACX_OK;
+    const uint32_t bmax = (uint32_t)std::min<int64_t>(std::max<int64_t>(max_nodes / 4, 1024), bfs_many_bmax());
+    const uint64_t cap_nodes = (uint64_t)std::max<int64_t>(max_nodes, 0) + 64, cap_cand = 12ull * bmax;
+    uint64_t n_slots = 1024;
+    while (n_slots < 2 * (cap_nodes + cap_cand)) n_slots <<= 1;  // two slots per stamp the table may ever hold
+    if (n_slots > (1ull << 31)) return fail(ACX_E_INVAL, "acx_search_many: budget too large for 32-bit node ids");
+    auto up = [](uint64_t b) { return (b + 255) / 256 * 256; };
+    const uint64_t tiles = cap_cand / kCompactTile + 2;
+    const uint64_t b_tab = up(n_slots * 8), b_key = up(cap_nodes * sizeof(W)), b_u32 = up(cap_nodes * 4), b_u8 = up(cap_nodes), b_flag = up(cap_cand + 8);
+    const uint64_t b_counts = up(tiles * 4), b_masks = up(tiles * 1024), b_scal = 256;
+    const uint64_t per_rest = 2 * b_key + 2 * b_u32 + 2 * b_u8 + b_flag + b_counts + b_masks + b_scal;
+    // [tables of all searches][replaced-flags of all searches] (one memset each), then the rest search by search
+    // (every device block is declared before the stream guard below: an error return first waits for the streams, then frees)
+    DevBuf big, dcur, dq, droots, dstatus, dwant, dpa, dpl, dpn;
+    if (big.alloc((uint64_t)n * (b_tab + b_flag + per_rest))) return ACX_E_NOMEM;
+    uint8_t* p_tab = (uint8_t*)big.p;
+    uint8_t* p_repl = p_tab + (uint64_t)n * b_tab;
+    uint8_t* p_rest = p_repl + (uint64_t)n * b_flag;
+    SearchHandles H;
+    if (int rc = search_handles_take(H)) return rc;
+    struct Give {
+        SearchHandles& h;
+        ~Give() { search_handles_give(h); }
+    } give{H};
+    hipStream_t st = H.st;
+    ACX_HIP_TRY(hipMemsetAsync(p_tab, 0xff, (uint64_t)n * b_tab, st));
+    ACX_HIP_TRY(hipMemsetAsync(p_repl, 0, (uint64_t)n * b_flag, st));  // once: k_bfs_count zeroes what a batch sets
+    std::vector<int64_t> order[2];  // [0] general move code, [1] normal form (a root in normal form keeps its whole search there)
+    std::vector<Pres<W>> roots((size_t)n);
+    for (int64_t k = 0; k < n; k++) rc_out[k] = ACX_OK, solved[k] = 0, path_n[k] = 0;
+    const bool general = option(ACX_OPT_GENERAL_MOVE, 0) != 0;
+    for (int64_t k = 0; k < n; k++) {
+        Pres<W>& root = roots[(size_t)k];
+        bool ok = pack_relator<W>(rows + k * 2 * L, L, root.w0, root.n0);
+        ok = pack_relator<W>(rows + k * 2 * L + L, L, root.w1, root.n1) && ok;
+        if (!ok) {
+            rc_out[k] = ACX_E_ROWERR;
+            return fail(ACX_E_ROWERR, "acx_search_many: presentation %lld is not a zero-padded word pair over {+-1,+-2}", (long long)k);
+        }
+        order[is_normal_form<W>(root, cyclical != 0) && !general ? 1 : 0].push_back(k);
+    }
+    if (dcur.alloc((size_t)n * sizeof(BfsCursor))) return ACX_E_NOMEM;  // the searches' cursors, contiguous: one copy brings them all back
+    std::vector<BfsMany<W>> hq;
+    std::vector<W> hroots;
+    std::vector<int64_t> slot_of;  // launch slot -> search index: [general ...][normal form ...]
+    for (int mode = 0; mode < 2; mode++)
+        for (int64_t k : order[mode]) {
+            const size_t j = slot_of.size();
+            slot_of.push_back(k);
+            BfsMany<W> e;
+            memset(&e, 0, sizeof(e));
+            uint8_t* q = p_rest + (uint64_t)j * per_rest;
+            auto take = [&](uint64_t bytes) {
+                uint8_t* r = q;
+                q += bytes;
+                return r;
+            };
+            SearchDev<W>& d = e.d;
+            d.L = L;
+            d.cyclical = cyclical;
+            d.stab = (unsigned long long*)(p_tab + (uint64_t)j * b_tab);
+            d.stmask = (uint32_t)(n_slots - 1);
+            d.brepl = p_repl + (uint64_t)j * b_flag;
+            d.k0 = (W*)take(b_key);
+            d.k1 = (W*)take(b_key);
+            d.parent = (uint32_t*)take(b_u32);
+            d.depth = (uint32_t*)take(b_u32);
+            d.act = take(b_u8);
+            d.tlen = take(b_u8);
+            d.btook = take(b_flag);
+            e.counts = (uint32_t*)take(b_counts);
+            e.masks = (uint32_t*)take(b_masks);
+            uint8_t* sc = take(b_scal);
+            d.solved_tag = (unsigned long long*)(sc + 0);
+            d.shorter_tag = (unsigned long long*)(sc + 8);
+            d.err_tag = (unsigned long long*)(sc + 16);
+            d.err = (uint32_t*)(sc + 24);
+            d.min_len = (uint32_t*)(sc + 28);
+            e.dec = (Decision*)(sc + 64);
+            e.total = (uint32_t*)(sc + 132);
+            e.cur = (BfsCursor*)dcur.p + j;
+            hq.push_back(e);
+            hroots.push_back(keyops<W>::make(roots[(size_t)k].w0, roots[(size_t)k].n0));
+            hroots.push_back(keyops<W>::make(roots[(size_t)k].w1, roots[(size_t)k].n1));
+        }
+    const int64_t pc = std::max<int64_t>(path_cap, 1);
+    const uint32_t un = (uint32_t)n;
+    if (dq.alloc((size_t)n * sizeof(BfsMany<W>)) || droots.alloc((size_t)n * 2 * sizeof(W)) || dstatus.alloc((size_t)n * 4 * kRunAheadSlots) || dwant.alloc((size_t)n * 4) ||
+        dpa.alloc((size_t)n * pc * 4) || dpl.alloc((size_t)n * pc * 4) || dpn.alloc((size_t)n * 4))
+        return ACX_E_NOMEM;
+    const size_t cur_off = up((size_t)n * 4 * kRunAheadSlots);
+    uint8_t* pin = pinned_staging(cur_off + (size_t)n * sizeof(BfsCursor));
+    if (!pin) return fail(ACX_E_NOMEM, "hipHostMalloc failed");
+    uint32_t* h_status = (uint32_t*)pin;
+    ACX_HIP_TRY(hipMemcpyAsync(dq.p, hq.data(), (size_t)n * sizeof(BfsMany<W>), hipMemcpyHostToDevice, st));
+    ACX_HIP_TRY(hipMemcpyAsync(droots.p, hroots.data(), (size_t)n * 2 * sizeof(W), hipMemcpyHostToDevice, st));
+    EventPair evs;
+    ACX_HIP_TRY(evs.create());
+    ACX_HIP_TRY(hipEventRecord(evs.a, st));
+    const BfsMany<W>* q = (const BfsMany<W>*)dq.p;
+    const uint32_t n_gen = (uint32_t)order[0].size(), n_nf = (uint32_t)order[1].size();
+    const dim3 sgrid((un + 63) / 64), sblock(64);
+    hipLaunchKernelGGL(k_bfs_root_many<W>, sgrid, sblock, 0, st, q, (const W*)droots.p, un);
+    const uint32_t mcap = 12u * bmax;
+    uint64_t bound = 1;  // no search has more than `bound` parents queued in this round (a batch multiplies the nodes by at most 13)
+    uint64_t rounds = 0;
+    for (uint64_t k = 0;; k++) {
+        if (k + 1 >= (1ull << 30)) return fail(ACX_E_CAPACITY, "acx_search_many: more than 2^30 batches");
+        const uint32_t bp = (uint32_t)std::min<uint64_t>(bound, bmax);
+        const unsigned ex = (bp + kBfsParents - 1) / kBfsParents, cx = (12u * bp + kCompactTile - 1) / kCompactTile;
+        if (n_gen) hipLaunchKernelGGL((k_bfs_expand_insert_many<W, kMoveGeneral>), dim3(ex, n_gen), dim3(kBfsThreads), 0, st, q, bmax);
+        if (n_nf) {
+            if (cyclical) hipLaunchKernelGGL((k_bfs_expand_insert_many<W, kMoveNfCyclical>), dim3(ex, n_nf), dim3(kBfsThreads), 0, st, q + n_gen, bmax);
+            else hipLaunchKernelGGL((k_bfs_expand_insert_many<W, kMoveNf>), dim3(ex, n_nf), dim3(kBfsThreads), 0, st, q + n_gen, bmax);
+        }
+        hipLaunchKernelGGL(k_bfs_count_many<W>, dim3(cx, un), dim3(256), 0, st, q, mcap);
+        if (n_gen) hipLaunchKernelGGL((k_bfs_compact_many<W, kMoveGeneral>), dim3(cx, n_gen), dim3(256), 0, st, q, mcap, (uint32_t)cap_nodes);
+        if (n_nf) {
+            if (cyclical) hipLaunchKernelGGL((k_bfs_compact_many<W, kMoveNfCyclical>), dim3(cx, n_nf), dim3(256), 0, st, q + n_gen, mcap, (uint32_t)cap_nodes);
+            else hipLaunchKernelGGL((k_bfs_compact_many<W, kMoveNf>), dim3(cx, n_nf), dim3(256), 0, st, q + n_gen, mcap, (uint32_t)cap_nodes);
+        }
+        const int slot = (int)(k % kRunAheadSlots);
+        uint32_t* dst = (uint32_t*)dstatus.p + (size_t)slot * n;
+        hipLaunchKernelGGL(k_decide_tab_many<W>, sgrid, sblock, 0, st, q, un, mcap, bmax, (uint32_t)cap_nodes, (long long)max_nodes, dst);
+        ACX_HIP_TRY(hipGetLastError());
+        // the round's status words, copied on the side stream behind an event of the main one (the slot is reused four rounds later, which
+        // is only enqueued after the host has waited for this copy)
+        ACX_HIP_TRY(hipEventRecord(H.ev_batch[slot], st));
+        ACX_HIP_TRY(hipStreamWaitEvent(H.st_copy, H.ev_batch[slot], 0));
+        ACX_HIP_TRY(hipMemcpyAsync(h_status + (size_t)slot * n, dst, (size_t)n * 4, hipMemcpyDeviceToHost, H.st_copy));
+        ACX_HIP_TRY(hipEventRecord(H.ev_cursor[slot], H.st_copy));
+        bound = std::min<uint64_t>(bound * 13, 1ull << 40);
+        rounds = k + 1;
+        if (k >= kRunAheadLag) {
+            const int old = (int)((k - kRunAheadLag) % kRunAheadSlots);
+            ACX_HIP_TRY(hipEventSynchronize(H.ev_cursor[old]));
+            bool all = true;
+            for (int64_t j = 0; j < n && all; j++) all = h_status[(size_t)old * n + j] != 0;
+            if (all) break;  // (the rounds enqueued behind it found every cursor ended and left them alone)
+        }
+    }
+    // every search has ended: its cursor says how (status 3: the queue ran empty; 1: `term` is the batch that ended it, not applied)
+    BfsCursor* hc = (BfsCursor*)(pin + cur_off);
+    ACX_HIP_TRY(hipMemcpyAsync(hc, dcur.p, (size_t)n * sizeof(BfsCursor), hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
+    std::vector<uint32_t> want((size_t)n, kEmpty);
+    bool any_path = false;
+    for (int64_t j = 0; j < n; j++) {
+        const BfsCursor& c = hc[j];
+        if (c.status == 1 && c.term.solved && !c.term.err) {
+            want[(size_t)j] = c.term_pbegin + c.term.solved_tag / 12;
+            any_path = true;
+        }
+    }
+    std::vector<int32_t> pa, pl;
+    std::vector<uint32_t> pn((size_t)n, 0);
+    if (any_path) {
+        pa.resize((size_t)n * pc);
+        pl.resize((size_t)n * pc);
+        ACX_HIP_TRY(hipMemcpyAsync(dwant.p, want.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_paths_many<W>, sgrid, sblock, 0, st, q, un, (const uint32_t*)dwant.p, (int32_t*)dpa.p, (int32_t*)dpl.p, (uint32_t*)dpn.p, (long long)pc);
+        ACX_HIP_TRY(hipGetLastError());
+        ACX_HIP_TRY(hipMemcpyAsync(pn.data(), dpn.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipMemcpyAsync(pa.data(), dpa.p, (size_t)n * pc * 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipMemcpyAsync(pl.data(), dpl.p, (size_t)n * pc * 4, hipMemcpyDeviceToHost, st));
+    }
+    ACX_HIP_TRY(hipEventRecord(evs.b, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    ACX_HIP_TRY(hipEventElapsedTime(&ms, evs.a, evs.b));
+    if (g_debug) fprintf(stderr, "[acx_bfs_many] %lld searches (%u general), %llu rounds of <= %u parents, group %.2f ms\n", (long long)n, n_gen, (unsigned long long)rounds, bmax, ms);
+    for (int64_t j = 0; j < n; j++) {
+        const int64_t k = slot_of[(size_t)j];
+        const BfsCursor& c = hc[j];
+        uint64_t nodes = c.nodes, expanded = c.expanded;
+        uint32_t min_len = c.min_len;
+        if (c.status == 1) {
+            const Decision& dec = c.term;
+            if (dec.err == 0xFE) {
+                rc_out[k] = fail(ACX_E_CAPACITY, "acx_search_many: a probe sequence ran through the whole visited table of search %lld", (long long)k);
+                continue;
+            }
+            if (dec.err) {
+                rc_out[k] = err_to_rc(dec.err);
+                continue;
+            }
+            min_len = std::min<uint32_t>(min_len, dec.min_len);
+            nodes += dec.committed;
+            if (dec.solved) {  // success: path of the parent + (action, 2); checked before dedup and before the budget test
+                const uint32_t ps = dec.solved_tag / 12, as = dec.solved_tag % 12;
+                const int64_t len = (int64_t)pn[(size_t)j];
+                if (path_action && path_len) {
+                    const int64_t w = std::min<int64_t>(len, path_cap);
+                    if (w > 0) {
+                        memcpy(path_action + k * path_cap, pa.data() + j * pc, (size_t)w * 4);
+                        memcpy(path_len + k * path_cap, pl.data() + j * pc, (size_t)w * 4);
+                    }
+                    if (len < path_cap) {
+                        path_action[k * path_cap + len] = (int32_t)as;
+                        path_len[k * path_cap + len] = 2;
+                    }
+                }
+                path_n[k] = len + 1;
+                solved[k] = 1;
+                expanded += ps + 1;
+                min_len = 2;
+                if (path_n[k] > path_cap) rc_out[k] = fail(ACX_E_CAPACITY, "path has %lld entries, buffer holds %lld", (long long)path_n[k], (long long)path_cap);
+            } else {
+                expanded += (uint64_t)dec.p_end + 1;
+            }
+        } else if (c.status != 3) {
+            rc_out[k] = fail(ACX_E_NODEVICE, "bfs cursor of search %lld ended in state %u", (long long)k, c.status);
+            continue;
+        }
+        if (stats) {
+            stats[k].nodes = (int64_t)nodes;
+            stats[k].expanded = (int64_t)expanded;
+            stats[k].children = (int64_t)expanded * 12;
+            stats[k].levels = (int64_t)c.batches;
+            stats[k].min_len = (int32_t)min_len;
+            stats[k].seconds = ms * 1e-3;  // of the whole group
+        }
+    }
+    return ACX_OK;
+}
+
+}  // namespace acx
+
+using namespace acx;
+
+extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t n, int L, int64_t max_nodes, int cyclical, int n_threads,
+                               int32_t* solved, int32_t* path_action, int32_t* path_len, int64_t path_cap, int64_t* path_n,
+                               acx_search_stats* stats, int32_t* rc_out);
+
+extern "C" int acx_search_groups(int kind, int n_groups, const int8_t* const* h_presentations, const int64_t* n, const int32_t* L, int64_t max_nodes, int cyclical,
+                                 int32_t* solved, int32_t* path_action, int32_t* path_len, int64_t path_cap, int64_t* path_n, acx_search_stats* stats,
+                                 int32_t* rc_out) {
+    if (!have_device()) return ACX_E_NODEVICE;
+    if (n_groups < 0 || (n_groups && (!h_presentations || !n || !L)) || !solved || !path_n || !rc_out || path_cap < 0)
+        return fail(ACX_E_INVAL, "acx_search_groups: bad argument");
+    if (kind != ACX_SEARCH_BFS && kind != ACX_SEARCH_GREEDY) return fail(ACX_E_INVAL, "acx_search_groups: bad kind");
+    std::vector<int64_t> out0((size_t)n_groups + 1, 0);
+    for (int g = 0; g < n_groups; g++) {
+        if (n[g] < 0 || L[g] < 1 || (n[g] && !h_presentations[g])) return fail(ACX_E_INVAL, "acx_search_groups: bad group %d", g);
+        out0[(size_t)g + 1] = out0[(size_t)g] + n[g];
+    }
+    if (max_nodes < 0) max_nodes = 0;
+    bool sched = kind == ACX_SEARCH_GREEDY && !option(ACX_OPT_GREEDY_HOST, 0) && !t_minima_on && !g_digest_on.load();
+    for (int g = 0; g < n_groups; g++) sched = sched && L[g] <= 61;
+    if (!sched) {  // one batch after the other through acx_search_many (bfs: a batch fills the GPU by itself, acx_bfs_many.h)
+        for (int g = 0; g < n_groups; g++) {
+            const int64_t o = out0[(size_t)g];
+            const int rc = acx_search_many(kind, h_presentations[g], n[g], L[g], max_nodes, cyclical, 16, solved + o, path_action ? path_action + o * path_cap : nullptr,
+                                           path_len ? path_len + o * path_cap : nullptr, path_cap, path_n + o, stats ? stats + o : nullptr, rc_out + o);
+            if (rc != ACX_OK) return rc;
+        }
+        return ACX_OK;
+    }
+    // greedy_search: ALL batches as jobs of one launch per key width (64-bit keys up to max_relator_length 29, 128-bit above), the two
+    // launches side by side
+    std::vector<SearchGroupIn> narrow, wide;
+    for (int g = 0; g < n_groups; g++)
+        if (n[g]) (L[g] <= 29 ? narrow : wide).push_back(SearchGroupIn{h_presentations[g], n[g], L[g], out0[(size_t)g]});
+    const int64_t n_all = out0[(size_t)n_groups];
+    std::vector<uint8_t> rerun((size_t)n_all, 0);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int rc_wide = ACX_OK;
+    std::string err_wide;
+    struct Joined {  // (whatever leaves this function first -- an exception of a host allocation included -- the side thread is joined)
+        std::thread t;
+        ~Joined() {
+            if (t.joinable()) t.join();
+        }
+    } side_guard;
+    std::thread& side = side_guard.t;
+    // Both widths in flight: the slots are SHARED OUT -- a workgroup of this kernel fills a compute unit and stays until the launch's
+    // jobs are used up, so whatever is launched beyond the chip's 256 compute units (the fills of the other launch's tables included)
+    // waits for one of them to end.  In proportion to the expected work: a 128-bit search costs ~1.7 x a 64-bit one (measured on the
+    // Miller-Schupp sweep: 7.0e7 against 4.2e7 workgroup cycles).
+    const uint32_t total = greedy_slots_wanted();
+    int64_t n_narrow = 0, n_wide = 0;
+    for (const auto& gr : narrow) n_narrow += gr.n;
+    for (const auto& gr : wide) n_wide += gr.n;
+    uint32_t slots_wide = total, slots_narrow = total;
+    if (n_narrow && n_wide) {
+        const double share = 1.7 * (double)n_wide / (1.7 * (double)n_wide + (double)n_narrow);
+        slots_wide = (uint32_t)std::min<double>(std::max<double>(1.0, share * total + 0.5), (double)total - 1.0);
+        slots_narrow = total - slots_wide;
+    }
+    if (!wide.empty() && !narrow.empty())
+        side = std::thread([&]() {
+            (void)hipSetDevice(dev);
+            rc_wide = run_greedy_sched<u128>(wide, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), slots_wide);
+            if (rc_wide != ACX_OK) err_wide = acx_last_error();
+        });
+    int rc = ACX_OK;
+    if (!narrow.empty()) rc = run_greedy_sched<uint64_t>(narrow, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), slots_narrow);
+    if (side.joinable()) side.join();
+    else if (!wide.empty()) rc_wide = run_greedy_sched<u128>(wide, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), slots_wide);
+    if (rc != ACX_OK) return rc;
+    if (rc_wide != ACX_OK) return err_wide.empty() ? rc_wide : fail(rc_wide, "%s", err_wide.c_str());
+    for (int g = 0; g < n_groups; g++)
+        for (int64_t k = 0; k < n[g]; k++) {
+            const int64_t o = out0[(size_t)g] + k;
+            if (rerun[(size_t)o])  // a search that outgrew a capacity of its workgroup: alone through acx_search
+                rc_out[o] = acx_search(kind, h_presentations[g] + k * 2 * L[g], L[g], max_nodes, cyclical, solved + o, path_action ? path_action + o * path_cap : nullptr,
+                                       path_len ? path_len + o * path_cap : nullptr, path_cap, path_n + o, stats ? stats + o : nullptr);
+        }
+    for (int64_t k = 0; k < n_all; k++)
+        if (rc_out[k] != ACX_OK && rc_out[k] != ACX_E_CAPACITY) return fail(ACX_E_ROWERR, "acx_search_groups: search %lld failed with code %d", (long long)k, rc_out[k]);
+    return ACX_OK;
+}
+
+extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t n, int L, int64_t max_nodes, int cyclical, int n_threads,
+                               int32_t* solved, int32_t* path_action, int32_t* path_len, int64_t path_cap, int64_t* path_n,
+                               acx_search_stats* stats, int32_t* rc_out) {
+    if (!have_device()) return ACX_E_NODEVICE;
+    if (n < 0 || !h_presentations || !solved || !path_n || !rc_out || path_cap < 0) return fail(ACX_E_INVAL, "acx_search_many: bad argument");
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 64) n_threads = 64;
+    if (kind == ACX_SEARCH_GREEDY && n > 1 && L >= 1 && L <= 61 && !option(ACX_OPT_GREEDY_HOST, 0) && !t_minima_on && !g_digest_on.load()) {
+        // greedy: the searches as jobs on a fixed set of workgroup slots (k_greedy_sched)
+        if (max_nodes < 0) max_nodes = 0;
+        std::vector<uint8_t> rerun((size_t)n, 0);
+        const std::vector<SearchGroupIn> one{SearchGroupIn{h_presentations, n, L, 0}};
+        const int rc = L <= 29 ? run_greedy_sched<uint64_t>(one, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), greedy_slots_wanted())
+                               : run_greedy_sched<u128>(one, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), greedy_slots_wanted());
+        if (rc != ACX_OK) return rc;
+        for (int64_t k = 0; k < n; k++)
+            if (rerun[k])
+                rc_out[k] = acx_search(kind, h_presentations + k * 2 * L, L, max_nodes, cyclical, solved + k, path_action ? path_action + k * path_cap : nullptr,
+                                       path_len ? path_len + k * path_cap : nullptr, path_cap, path_n + k, stats ? stats + k : nullptr);
+        for (int64_t k = 0; k < n; k++)
+            if (rc_out[k] != ACX_OK && rc_out[k] != ACX_E_CAPACITY) return fail(ACX_E_ROWERR, "acx_search_many: search %lld failed with code %d", (long long)k, rc_out[k]);
+        return ACX_OK;
+    }
+    if (kind == ACX_SEARCH_BFS && n > 1 && L >= 1 && L <= 61 && !t_minima_on && !g_digest_on.load()) {
+        // bfs: groups of searches sharing the launches of the fused single search, a batch of every search per round (acx_bfs_many.h)
+        if (max_nodes < 0) max_nodes = 0;
+        const double nn = (double)std::max<int64_t>(max_nodes, 1);
+        const double per_search = (L <= 29 ? 26.0 : 42.0) * nn + 32.0 * (nn + 12.0 * bfs_many_bmax()) + 64.0 * bfs_many_bmax() + 1e6;
+        const int64_t group = (int64_t)std::max(1.0, std::min(4096.0, group_byte_budget(48e9) / per_search));
+        for (int64_t k0 = 0; k0 < n; k0 += group) {
+            const int64_t m = std::min<int64_t>(group, n - k0);
+            int32_t* pa = path_action ? path_action + k0 * path_cap : nullptr;
+            int32_t* pl = path_len ? path_len + k0 * path_cap : nullptr;
+            acx_search_stats* ps = stats ? stats + k0 : nullptr;
+            const int8_t* pr = h_presentations + k0 * 2 * L;
+            const int rc = L <= 29 ? run_bfs_group_fused<uint64_t>(pr, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0)
+                                   : run_bfs_group_fused<u128>(pr, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0);
+            if (rc != ACX_OK) return rc;
+        }
+        for (int64_t k = 0; k < n; k++)
+            if (rc_out[k] != ACX_OK && rc_out[k] != ACX_E_CAPACITY) return fail(ACX_E_ROWERR, "acx_search_many: search %lld failed with code %d", (long long)k, rc_out[k]);
+        return ACX_OK;
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<int64_t> next(0);
+    auto work = [&]() {
+        (void)hipSetDevice(dev);
+        for (;;) {
+            const int64_t k = next.fetch_add(1);
+            if (k >= n) break;
+            rc_out[k] = acx_search(kind, h_presentations + k * 2 * L, L, max_nodes, cyclical, solved + k, path_action ? path_action + k * path_cap : nullptr,
+                                   path_len ? path_len + k * path_cap : nullptr, path_cap, path_n + k, stats ? stats + k : nullptr);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; t++) pool.emplace_back(work);
+    for (auto& t : pool) t.join();
+    for (int64_t k = 0; k < n; k++)
+        if (rc_out[k] != ACX_OK && rc_out[k] != ACX_E_CAPACITY) return fail(ACX_E_ROWERR, "acx_search_many: search %lld failed with code %d", (long long)k, rc_out[k]);
+    return ACX_OK;
+}

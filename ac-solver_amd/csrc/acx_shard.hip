@@ -1165,8 +1165,6 @@ template <typename W> struct ShardEngine {
             insert_wgs = 4u * (unsigned)cus;
             commit_wgs = 8u * (unsigned)cus;
         }
-        if (const char* e = getenv("ACX_SHARD_INSERT_WGS")) insert_wgs = (unsigned)atoi(e);  // (tuning: tools/scratch/shard_env_sweep.py)
-        if (const char* e = getenv("ACX_SHARD_COMMIT_WGS")) commit_wgs = (unsigned)atoi(e);
         cap_nodes = (uint64_t)node_cap + 64;
         chunk_parents = (uint64_t)std::max<int64_t>(chunk_parents_, 1);
         int64_t subcap, region_words;

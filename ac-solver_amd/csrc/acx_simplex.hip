@@ -183,8 +183,7 @@ extern "C" int acx_simplex_graph(int n, int classic, int64_t cap_nodes, int64_t 
     uint32_t* d_edges = (uint32_t*)b_edges.p;
     uint8_t* d_efilt = (uint8_t*)b_edges.p + (size_t)std::max<int64_t>(cap_edges, 1) * 8;
     size_t tmp_bytes = 0;
-    if (rocprim::exclusive_scan(nullptr, tmp_bytes, d.cflag, d.cpos, 0u, cap_cand, rocprim::plus<uint32_t>(), (hipStream_t) nullptr) != hipSuccess)
-        return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan sizing failed");
+    if (int src = scan_u32_exclusive(nullptr, &tmp_bytes, d.cflag, d.cpos, cap_cand, (hipStream_t) nullptr)) return src;
     if (b_tmp.alloc(tmp_bytes + 256)) return ACX_E_NOMEM;
     hipStream_t st = nullptr;
     ACX_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -205,13 +204,11 @@ extern "C" int acx_simplex_graph(int n, int classic, int64_t cap_nodes, int64_t 
         hipLaunchKernelGGL(k_insert<W>, grid, block, 0, st, d, d.slots, d.smask, m, 1);
         hipLaunchKernelGGL(k_mark<W>, grid, block, 0, st, d, d.slots, m, -1);
         size_t tb = tmp_bytes;
-        if (rocprim::exclusive_scan(b_tmp.p, tb, d.cflag, d.cpos, 0u, (size_t)m, rocprim::plus<uint32_t>(), st) != hipSuccess)
-            return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan failed");
+        if (int src = scan_u32_exclusive(b_tmp.p, &tb, d.cflag, d.cpos, (size_t)m, st)) return src;
         hipLaunchKernelGGL(k_commit_pairs, grid, block, 0, st, d, m, (uint32_t)nodes, (uint32_t)cap_nodes);
         hipLaunchKernelGGL(k_edge_flags, grid, block, 0, st, d, m, (uint32_t)head, M, eflag);
         tb = tmp_bytes;
-        if (rocprim::exclusive_scan(b_tmp.p, tb, eflag, epos, 0u, (size_t)m, rocprim::plus<uint32_t>(), st) != hipSuccess)
-            return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan failed");
+        if (int src = scan_u32_exclusive(b_tmp.p, &tb, eflag, epos, (size_t)m, st)) return src;
         hipLaunchKernelGGL(k_edge_write, grid, block, 0, st, d, m, (uint32_t)head, M, eflag, epos, (unsigned long long)edges, (unsigned long long)cap_edges, d_edges,
                            d_efilt);
         ACX_HIP_TRY(hipGetLastError());

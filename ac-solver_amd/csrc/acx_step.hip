@@ -1125,7 +1125,7 @@ int acx_env_step(acx_env* e, const void* d_actions, int action_dtype, void* d_ob
     // 64 envs (k_env_step_team), when an observation but no terminal observation is written.  Measured: 2.66 vs 3.05 us at 16 384 envs,
     // no difference at 65 536 (every SIMD then carries a full chain either way), slower above.
     constexpr int64_t kTeamMaxEnvs = 32768;
-    const bool team = d_obs && !d_final_obs && e->n <= kTeamMaxEnvs && !getenv("ACX_ENV_NO_TEAM");
+    const bool team = d_obs && !d_final_obs && e->n <= kTeamMaxEnvs;
     const unsigned tgrid = (unsigned)ceil_div<int64_t>(e->n, 64);
     const size_t tlds = ((size_t)64 * 2 * e->L * (f32 ? 4 : 1) + 15) / 16 * 16 + 64 * (2 * (e->wide ? 16 : 8) + 4);
 #define ACX_STEP_TEAM(OBS, LC)                                                                                                               \

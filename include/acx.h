@@ -225,6 +225,21 @@ int acx_search_many(int kind, const int8_t *h_presentations, int64_t n, int L, i
                     int n_threads, int32_t *solved, int32_t *path_action, int32_t *path_len, int64_t path_cap,
                     int64_t *path_n, acx_search_stats *stats, int32_t *rc_out);
 
+/* ---- options ---------------------------------------------------------------------------------------------
+ * Tuning and test knobs of the search entry points, set through the ABI (process wide); nothing on a call path reads the
+ * environment.  value < 0 restores the built-in default; acx_get_option returns -1 for "default".
+ * The only environment variable libacx looks at is ACX_DEBUG (diagnostics on stderr), once, when it is loaded. */
+#define ACX_OPT_BFS_NO_RUNAHEAD 0  /* 1: acx_search(bfs) reads every batch's decision back (the path small frontiers and verbose searches take) */
+#define ACX_OPT_GREEDY_HOST 1      /* 1: greedy searches run batch per launch from the host (the path of verbose searches and of capacity fallbacks) */
+#define ACX_OPT_GREEDY_HAND_MIN 2  /* a bucket of at least this many queued parents of a single greedy search goes to the whole-GPU kernels (default 512; 0: never) */
+#define ACX_OPT_MEGA_RANK_MAX 3    /* handed-off buckets up to this size are ordered by the counting sort (default 16384, at least 256) */
+#define ACX_OPT_BFS_MANY_BMAX 4    /* parents per search and round of acx_search_many(bfs) (default 32768, 128 .. 2^22) */
+#define ACX_OPT_GREEDY_SLOTS 5     /* persistent workgroups of acx_search_many / acx_search_groups (greedy) (default 256 = one per compute unit) */
+#define ACX_OPT_GENERAL_MOVE 6     /* 1: the general move code also for roots in normal form (tests: both codes must build the same arena) */
+#define ACX_OPT_COUNT 8
+int acx_set_option(int option, int64_t value);
+int64_t acx_get_option(int option);
+
 /* ---- sharded BFS frontier (one engine per GPU) ---------------------------------------------------
  * The multi-GPU form of bfs (breadth_first.py:15-97): states are partitioned over the ranks by acx_shard_owner -- a function of
  * the conjugacy classes of the two relators, which the eight conjugation moves of ac_moves.py:192-229 leave alone, so that a rank

@@ -96,26 +96,13 @@ def test_bfs_at_the_bench_budget_repeats_and_agrees_with_the_sharded_engine(dige
 
 
 @pytest.mark.timeout(300)
-def test_general_and_normal_form_move_code_build_the_same_arena(digests, monkeypatch):
+def test_general_and_normal_form_move_code_build_the_same_arena(digests):
     """the two move codes of the BFS kernels (acx_bfs.h: apply_move / apply_move_nf) must give the same nodes"""
     from ac_solver import _acx
 
     a = _search_with_digest(_acx.SEARCH_BFS, _ak3(), 3 * 10**6, False)
-    monkeypatch.setenv("ACX_BFS_GENERAL_MOVE", "1")
-    b = _search_with_digest(_acx.SEARCH_BFS, _ak3(), 3 * 10**6, False)
-    assert a == b
-
-
-@pytest.mark.timeout(300)
-@pytest.mark.parametrize("switch", ["ACX_BFS_INLINE_TAB", "ACX_BFS_CLASSIC_COMMIT"])
-def test_round1_bfs_paths_build_the_same_arena(digests, monkeypatch, switch):
-    """acx_search keeps round 1's BFS for A/B measurements (inline-key visited table, k_insert_tab + one-pass k_compact_tab; and
-    with ACX_BFS_CLASSIC_COMMIT its mark / scan / commit launches): same nodes in the same order as the stamp-table kernels"""
-    from ac_solver import _acx
-
-    a = _search_with_digest(_acx.SEARCH_BFS, _ak3(), 2 * 10**6, False)
-    monkeypatch.setenv(switch, "1")
-    b = _search_with_digest(_acx.SEARCH_BFS, _ak3(), 2 * 10**6, False)
+    with _acx.options(OPT_GENERAL_MOVE=1):
+        b = _search_with_digest(_acx.SEARCH_BFS, _ak3(), 3 * 10**6, False)
     assert a == b
 
 

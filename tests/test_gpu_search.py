@@ -132,10 +132,10 @@ def test_full_size_config3_ak3_budget_1e7_against_oracle(search, algo):
 
 
 @pytest.mark.timeout(600)
-def test_bfs_run_ahead_batches_equal_read_back_batches_and_the_oracle(search, golden_json, monkeypatch):
+def test_bfs_run_ahead_batches_equal_read_back_batches_and_the_oracle(search, golden_json):
     """Round 3: once the frontier holds a full batch the fused bfs enqueues its batches back to back against a device-resident
-    cursor and reads it two batches late (acx_frontier.h: BfsCursor); ACX_BFS_NO_RUNAHEAD=1 reads every batch's decision back as
-    round 2 did.  Both must give the oracle's (solved, path) and counts: searches that END inside the run-ahead phase by success
+    cursor and reads it two batches late (acx_frontier.h: BfsCursor); the option ACX_OPT_BFS_NO_RUNAHEAD reads every batch's decision
+    back, as small frontiers and verbose searches do.  Both must give the oracle's (solved, path) and counts: searches that END inside the run-ahead phase by success
     (Miller-Schupp presentations bfs solves late), by budget (at several offsets inside a batch) and by exhaustion of nothing
     (budget far beyond the last saturated batch), both cyclical values, both key widths."""
     from ac_solver import _acx
@@ -154,11 +154,9 @@ def test_bfs_run_ahead_batches_equal_read_back_batches_and_the_oracle(search, go
     cases += [(ak3, b, False) for b in (2 * 10**6, 2 * 10**6 + 1, 2999999, 3 * 10**6, 4194304, 4194305)] + [(ak3, 3 * 10**6, True)]
     n_solved = 0
     for p, budget, cyc in cases:
-        monkeypatch.delenv("ACX_BFS_NO_RUNAHEAD", raising=False)
         ahead = run_search(_acx.SEARCH_BFS, p, budget, cyc)
-        monkeypatch.setenv("ACX_BFS_NO_RUNAHEAD", "1")
-        back = run_search(_acx.SEARCH_BFS, p, budget, cyc)
-        monkeypatch.delenv("ACX_BFS_NO_RUNAHEAD", raising=False)
+        with _acx.options(OPT_BFS_NO_RUNAHEAD=1):
+            back = run_search(_acx.SEARCH_BFS, p, budget, cyc)
         wok, wpath, wst = O.bfs(p, budget, cyclically_reduce_after_moves=cyc, stats=True)
         for ok, path, st in (ahead, back):
             assert (ok, path) == (wok, wpath), (budget, cyc)
@@ -168,9 +166,10 @@ def test_bfs_run_ahead_batches_equal_read_back_batches_and_the_oracle(search, go
     assert n_solved >= 10
 
 
-def test_greedy_batch_per_launch_path_equals_device_frontier(search, golden_json, monkeypatch):
+def test_greedy_batch_per_launch_path_equals_device_frontier(search, golden_json):
     """greedy_search runs on the persistent one-workgroup frontier (acx_greedy.h); the batch-per-launch path it falls
-    back to when a capacity is exceeded (ACX_GREEDY_HOST=1 forces it) must return the same thing."""
+    back to when a capacity is exceeded -- and that verbose searches take -- (the option ACX_OPT_GREEDY_HOST forces it) must
+    return the same thing."""
     from ac_solver import _acx
     from ac_solver.search._common import run_search
 
@@ -180,42 +179,40 @@ def test_greedy_batch_per_launch_path_equals_device_frontier(search, golden_json
     ak3[25:31] = [1, 2, 1, -2, -1, -2]
     cases = [(ak3, 1, False), (ak3, 2, False), (ak3, 13, True), (ak3, 30000, False), (pool[1100], 20000, False), (pool[77], 5000, True), (pool[600], 10**5, False)]
     for p, budget, cyc in cases:
-        monkeypatch.delenv("ACX_GREEDY_HOST", raising=False)
         a = run_search(_acx.SEARCH_GREEDY, p, budget, cyc)
-        monkeypatch.setenv("ACX_GREEDY_HOST", "1")
-        b = run_search(_acx.SEARCH_GREEDY, p, budget, cyc)
-        monkeypatch.delenv("ACX_GREEDY_HOST", raising=False)
+        with _acx.options(OPT_GREEDY_HOST=1):
+            b = run_search(_acx.SEARCH_GREEDY, p, budget, cyc)
         assert a[:2] == b[:2] and a[2]["nodes"] == b[2]["nodes"] and a[2]["expanded"] == b[2]["expanded"], (budget, cyc)
         assert a[2]["min_len"] >= b[2]["min_len"]  # the batch path also counts children of parents it speculated on
 
 
 @pytest.mark.parametrize("hand_min", [1, 6, 100])
-def test_greedy_whole_gpu_batches_equal_the_reference(search, golden_json, monkeypatch, hand_min):
-    """A single greedy_search hands buckets of >= 1024 parents to the whole-GPU kernels (acx_greedy_mega.h).  With the
-    threshold lowered (ACX_GREEDY_HAND_MIN) every bucket of the fixture searches takes that route: reference-generated
+def test_greedy_whole_gpu_batches_equal_the_reference(search, golden_json, hand_min):
+    """A single greedy_search hands buckets of >= 512 parents to the whole-GPU kernels (acx_greedy_mega.h).  With the
+    threshold lowered (ACX_OPT_GREEDY_HAND_MIN) every bucket of the fixture searches takes that route: reference-generated
     paths (all widths incl. 128-bit words, both `cyclical`, solved / budget / raising rows) and the oracle's node counts."""
     from ac_solver import _acx
     from ac_solver.search._common import run_search
     from oracle import ac_oracle as O
 
-    monkeypatch.setenv("ACX_GREEDY_HAND_MIN", str(hand_min))
     cap = 10**5 if hand_min == 1 else 10**6
     n = 0
-    for r in golden_json("search.json"):
-        if r["algo"] != "greedy" or r["budget"] > cap:
-            continue
-        ok, path = search.greedy_search(r["presentation"], r["budget"], cyclically_reduce_after_moves=r["cyclical"])
-        assert ok == r["solved"] and path == _as_tuples(r["path"]), (r["tag"], r["budget"], r["cyclical"])
-        n += 1
-    assert n > 100
-    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
-    rng = np.random.default_rng(hand_min)
-    for k in rng.choice(len(pool), size=6, replace=False):
-        for budget, cyc in ((40000, False), (7000, True)):
-            got = run_search(_acx.SEARCH_GREEDY, np.array(pool[k], dtype=np.int8), budget, cyc)
-            wok, wpath, wst = O.greedy_search(pool[k], budget, cyclically_reduce_after_moves=cyc, stats=True)
-            assert got[:2] == (wok, wpath), (int(k), budget, cyc)
-            assert got[2]["nodes"] == wst["nodes"] and got[2]["expanded"] == wst["expanded"], (int(k), budget, cyc)
+    with _acx.options(OPT_GREEDY_HAND_MIN=hand_min):
+        for r in golden_json("search.json"):
+            if r["algo"] != "greedy" or r["budget"] > cap:
+                continue
+            ok, path = search.greedy_search(r["presentation"], r["budget"], cyclically_reduce_after_moves=r["cyclical"])
+            assert ok == r["solved"] and path == _as_tuples(r["path"]), (r["tag"], r["budget"], r["cyclical"])
+            n += 1
+        assert n > 100
+        pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+        rng = np.random.default_rng(hand_min)
+        for k in rng.choice(len(pool), size=6, replace=False):
+            for budget, cyc in ((40000, False), (7000, True)):
+                got = run_search(_acx.SEARCH_GREEDY, np.array(pool[k], dtype=np.int8), budget, cyc)
+                wok, wpath, wst = O.greedy_search(pool[k], budget, cyclically_reduce_after_moves=cyc, stats=True)
+                assert got[:2] == (wok, wpath), (int(k), budget, cyc)
+                assert got[2]["nodes"] == wst["nodes"] and got[2]["expanded"] == wst["expanded"], (int(k), budget, cyc)
 
 
 @pytest.mark.timeout(600)
@@ -236,19 +233,17 @@ def test_greedy_buckets_larger_than_one_whole_gpu_batch(search):
         assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (budget, cyc, st, wst)
 
 
-@pytest.mark.parametrize("env", [{}, {"ACX_GREEDY_NO_CHAIN": "1"}, {"ACX_MEGA_RANK_MAX": "256"}, {"ACX_MEGA_RANK_MAX": "256", "ACX_GREEDY_HAND_MIN": "64"},
-                                 {"ACX_GREEDY_NO_CHAIN": "1", "ACX_MEGA_RANK_MAX": "700"}])
-def test_greedy_hand_off_protocols_agree_with_the_oracle(search, monkeypatch, env):
-    """The hand-off cycle of a single greedy_search: chained on the stream (default: every kernel reads its work from device scalars,
-    the host looks two cycles late) or with one synchronisation per hand-off (ACX_GREEDY_NO_CHAIN); the handed-off bucket ordered by the
-    whole-GPU counting sort, by sorted runs + rank merge (unchained, above ACX_MEGA_RANK_MAX) or by the frontier kernel itself before
-    the hand-off (chained, above ACX_MEGA_RANK_MAX).  AK(3), 64- and 128-bit keys: result, path and counts as the oracle's."""
+@pytest.mark.parametrize("env", [{}, {"OPT_MEGA_RANK_MAX": 256}, {"OPT_MEGA_RANK_MAX": 256, "OPT_GREEDY_HAND_MIN": 64}, {"OPT_GREEDY_HAND_MIN": 0},
+                                 {"OPT_MEGA_RANK_MAX": 700, "OPT_GREEDY_HAND_MIN": 2048}])
+def test_greedy_hand_off_protocols_agree_with_the_oracle(search, env):
+    """The hand-off cycle of a single greedy_search, chained on the stream (every kernel reads its work from device scalars, the host
+    looks two cycles late): the handed-off bucket ordered by the whole-GPU counting sort, or -- above ACX_OPT_MEGA_RANK_MAX -- by the
+    frontier kernel itself before the hand-off; hand-offs from 64 / 512 / 2048 queued parents, or never (the one-workgroup frontier
+    alone).  AK(3), 64- and 128-bit keys: result, path and counts as the oracle's."""
     from ac_solver import _acx
     from ac_solver.search._common import run_search
     from oracle import ac_oracle as O
 
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
     ak3 = np.zeros(50, np.int8)
     ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
     ak3[25:31] = [1, 2, 1, -2, -1, -2]
@@ -256,7 +251,8 @@ def test_greedy_hand_off_protocols_agree_with_the_oracle(search, monkeypatch, en
     wide[:7] = ak3[:7]
     wide[36:42] = ak3[25:31]
     for pres, budget, cyc in ((ak3, 10**6, False), (ak3, 3 * 10**5, True), (wide, 3 * 10**5, False)):
-        ok, path, st = run_search(_acx.SEARCH_GREEDY, pres, budget, cyc)
+        with _acx.options(**env):
+            ok, path, st = run_search(_acx.SEARCH_GREEDY, pres, budget, cyc)
         wok, wpath, wst = O.greedy_search(pres, budget, cyclically_reduce_after_moves=cyc, stats=True)
         assert (ok, path) == (wok, wpath), (env, budget, cyc)
         assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (env, budget, cyc, st, wst)
@@ -428,8 +424,8 @@ def test_search_beyond_the_key_width_says_so(search):
         with pytest.raises(ValueError, match="max_relator_length = 62"):
             fn(p, 100)
     ok = np.zeros(122, np.int8)
-    ok[:2], ok[61:63] = [1, 2], [2, 1]
-    assert bfs(ok, 1000)[0] is not None and greedy_search(ok, 1000)[0] is not None  # 61 still runs
+    ok[:5], ok[61:67] = [1, 1, -2, -2, -2], [1, 2, 1, -2, -1, -2]  # AK(2) at the widest supported length
+    assert greedy_search(ok, 10000)[1] is not None and bfs(ok, 1000) == (False, None)  # 61 still runs
 
 
 def _key_words(state, L, KW):
@@ -587,11 +583,11 @@ def _pad(rel0, rel1, L):
 
 
 @pytest.mark.parametrize("L", [9, 33])
-def test_many_bfs_searches_share_their_launches_and_equal_single_ones(search, L, monkeypatch):
+def test_many_bfs_searches_share_their_launches_and_equal_single_ones(search, L):
     """acx_search_many(bfs) = acx_bfs_many.h: one round of launches advances every search of the group by a batch.  Groups that mix
     roots in and out of normal form (two move codes), searches that end by success, by budget at every small budget and by an empty
     queue, batches of 128 / 1024 / 32768 parents: (solved, path, nodes, expanded) equal the single search's, which the other
-    tests hold against the oracle -- and round 3's one-workgroup-per-search kernel (ACX_BFS_MANY=multi) says the same."""
+    tests hold against the oracle."""
     from ac_solver import _acx
     from ac_solver.search._common import run_search, run_search_many
 
@@ -607,11 +603,11 @@ def test_many_bfs_searches_share_their_launches_and_equal_single_ones(search, L,
     for cyc in (False, True):
         single = {}
         for bmax in (128, 1024, 32768):
-            monkeypatch.setenv("ACX_BFS_MANY_BMAX", str(bmax))
             for budget in list(range(0, 30)) + [157, 1537, 1538, 20000, 120000]:
                 if bmax != 128 and budget < 30 and budget % 7:
                     continue
-                many = run_search_many(_acx.SEARCH_BFS, rows, budget, cyc)
+                with _acx.options(OPT_BFS_MANY_BMAX=bmax):
+                    many = run_search_many(_acx.SEARCH_BFS, rows, budget, cyc)
                 for k, (ok, path, st) in enumerate(many):
                     if (k, budget) not in single:
                         single[(k, budget)] = run_search(_acx.SEARCH_BFS, rows[k], budget, cyc)
@@ -620,17 +616,10 @@ def test_many_bfs_searches_share_their_launches_and_equal_single_ones(search, L,
                     # (min_len also counts the children of the last batch behind the one that ended the search: it depends on the batch size)
                     assert [st[f] for f in ("nodes", "expanded", "children")] == [wst[f] for f in ("nodes", "expanded", "children")], (cyc, bmax, budget, k, st, wst)
                     assert st["min_len"] == wst["min_len"] or not ok
-        monkeypatch.delenv("ACX_BFS_MANY_BMAX")
-        monkeypatch.setenv("ACX_BFS_MANY", "multi")
-        for budget in (13, 1537, 120000):
-            for k, (ok, path, st) in enumerate(run_search_many(_acx.SEARCH_BFS, rows, budget, cyc)):
-                wok, wpath, wst = single[(k, budget)]
-                assert (ok, path, st["nodes"], st["expanded"]) == (wok, wpath, wst["nodes"], wst["expanded"]), ("multi", cyc, budget, k)
-        monkeypatch.delenv("ACX_BFS_MANY")
     # a finite state space: the queue runs empty (breadth_first.py:61) in every search of the group, after different numbers of batches
     tiny = np.stack([_pad([1, 1], [2, 2], 3), _pad([1, 1], [2, 1], 3), _pad([1, 1], [2], 3), _pad([1, 2, 1], [2, 2], 3), _pad([2, 2], [1, -2], 3)])
-    monkeypatch.setenv("ACX_BFS_MANY_BMAX", "128")
-    got = run_search_many(_acx.SEARCH_BFS, tiny, 10**5, False)
+    with _acx.options(OPT_BFS_MANY_BMAX=128):
+        got = run_search_many(_acx.SEARCH_BFS, tiny, 10**5, False)
     assert [(ok, path, st["nodes"], st["expanded"]) for ok, path, st in got] == [(False, None, n, n) for n in (1, 48, 108, 60, 48)]  # (the C oracle's counts)
     for k, (ok, path, st) in enumerate(got):
         wok, wpath, wst = run_search(_acx.SEARCH_BFS, tiny[k], 10**5, False)
@@ -643,8 +632,16 @@ def test_many_bfs_searches_share_their_launches_and_equal_single_ones(search, L,
         run_search_many(_acx.SEARCH_BFS, bad, 100, False)
 
 
-@pytest.mark.parametrize("slots", ["2", "5", "256"])
-def test_greedy_searches_as_jobs_on_a_few_workgroup_slots(search, golden_json, monkeypatch, slots):
+@pytest.fixture
+def greedy_slots(request):
+    from ac_solver import _acx
+
+    with _acx.options(OPT_GREEDY_SLOTS=request.param):
+        yield request.param
+
+
+@pytest.mark.parametrize("greedy_slots", [2, 5, 256], indirect=True)
+def test_greedy_searches_as_jobs_on_a_few_workgroup_slots(search, golden_json, greedy_slots):
     """acx_search_groups / acx_search_many(greedy) = k_greedy_sched: a fixed set of workgroups, each with the memory of ONE search,
     takes the searches from a counter and cleans its slot (visited table, bucket rows, the vector L1) between two of them.  With 2 or 5
     slots every workgroup runs dozens of searches one after the other -- of different max_relator_length, solved after a handful
@@ -653,7 +650,7 @@ def test_greedy_searches_as_jobs_on_a_few_workgroup_slots(search, golden_json, m
     from ac_solver import _acx
     from ac_solver.search._common import run_search, run_search_groups, run_search_many
 
-    monkeypatch.setenv("ACX_GREEDY_SLOTS", slots)
+    slots = greedy_slots
     pool = ms_pool_generator_order(golden_json("ms_pool.json"))
     rng = np.random.default_rng(17)
     groups = []

@@ -61,9 +61,17 @@ def test_random_presentations_against_oracle(L):
     assert raised + solved >= 0
 
 
+@pytest.fixture
+def many_bmax():
+    from ac_solver import _acx
+
+    yield
+    _acx.lib.acx_set_option(_acx.OPT_BFS_MANY_BMAX, -1)
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("L", [6, 25, 33])
-def test_random_presentation_groups_through_search_many(L, monkeypatch):
+def test_random_presentation_groups_through_search_many(L, many_bmax):
     """acx_search_many on groups of random presentations (roots in and out of normal form in one group, so both move codes; small
     batches per round so that the searches of a group are many rounds apart): every search as the oracle's, for bfs (the searches
     share their launches, acx_bfs_many.h) and greedy_search (one workgroup per search); a group with a search in which the
@@ -74,7 +82,7 @@ def test_random_presentation_groups_through_search_many(L, monkeypatch):
 
     _acx.require_device()
     rng = np.random.default_rng(500 + L + 1000 * SEED)
-    monkeypatch.setenv("ACX_BFS_MANY_BMAX", str(int(rng.choice([128, 512, 32768]))))
+    _acx.check(_acx.lib.acx_set_option(_acx.OPT_BFS_MANY_BMAX, int(rng.choice([128, 512, 32768]))))  # (the fixture restores the default)
     for budget, cyc in ((int(rng.choice([1, 7, 60])), False), (500, True), (4000, False), (30000, True)):
         rows = []
         for _ in range(40):

@@ -43,7 +43,7 @@ for name in ("fetch", "write"):
     for f in glob.glob(f"{O}/{name}/**/*counter_collection.csv", recursive=True):
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_env_step" in r["Kernel_Name"]]
     if vals:
-        vals = vals[-2000:]
+        vals = vals[-400:]
         e[name.upper() + "_SIZE_KB_per_launch"] = sum(vals) / len(vals)
 if "FETCH_SIZE_KB_per_launch" in e and "WRITE_SIZE_KB_per_launch" in e:
     e["traffic_bytes_per_launch"] = (2 * e["FETCH_SIZE_KB_per_launch"] + e["WRITE_SIZE_KB_per_launch"]) * 1024
