@@ -30,7 +30,6 @@
 
 namespace acx {
 
-constexpr unsigned long long kSlotFree = ~0ull;
 constexpr uint32_t kSelfAction = 15u;  // slot names the node itself (the root)
 
 // hash of the stamp table: one multiply-xorshift round per key word (bucket = low bits, fingerprint = bits 36..63, LDS fold
@@ -45,7 +44,15 @@ ACX_HD uint64_t stamp_hash(u128 k0, u128 k1) {
     return stamp_mix(stamp_mix(h, (uint64_t)k1), (uint64_t)(k1 >> 64));
 }
 
-ACX_HD unsigned long long slot_make(uint64_t hk, uint32_t pid, uint32_t act) { return (hk & ~((1ull << 36) - 1)) | ((unsigned long long)pid << 4) | act; }
+// A stamp: epoch(8) | fingerprint(20, the top bits of the key's hash) | parent node id(32) | action(4).  The EPOCH is the search's
+// (SearchDev::epoch, 1 .. 254): a slot whose epoch field differs is FREE -- what an earlier search left in the table's memory
+// (acx_frontier.h: StampBuf hands a table of a finished search to the next one with the next epoch, no refill), or the 0xFF.. of a
+// fresh fill.  A free slot is claimed by a CAS on the value that was seen there; stamps of one search share their top eight bits, so
+// equal keys still fold to the smaller (parent, action) with a 64-bit atomicMin.
+ACX_HD unsigned long long slot_make(uint64_t hk, uint32_t pid, uint32_t act, uint32_t epoch) {
+    return ((unsigned long long)epoch << 56) | ((hk >> 44) << 36) | ((unsigned long long)pid << 4) | act;
+}
+ACX_HD bool slot_free(unsigned long long s, uint32_t epoch) { return (uint32_t)(s >> 56) != epoch; }
 ACX_HD uint32_t slot_parent(unsigned long long s) { return (uint32_t)(s >> 4); }
 ACX_HD uint32_t slot_action(unsigned long long s) { return (uint32_t)s & 15u; }
 
@@ -81,7 +88,7 @@ template <typename W> __global__ void k_bfs_root(SearchDev<W> d, W k0, W k1, uin
     d.tlen[0] = (uint8_t)tl;
     d.depth[0] = 0;
     const uint64_t hk = stamp_hash(k0, k1);
-    d.stab[(uint32_t)hk & d.stmask & ~3u] = slot_make(hk, 0u, kSelfAction);  // first slot of its bucket
+    d.stab[(uint32_t)hk & d.stmask & ~3u] = slot_make(hk, 0u, kSelfAction, d.epoch);  // first slot of its bucket
 }
 
 // ---- expand + dedup of a batch in ONE launch ------------------------------------------------------------------------------------
@@ -206,22 +213,23 @@ __device__ __forceinline__ void bfs_expand_insert_body(const SearchDev<W>& d, ui
     for (int it = 0; it < kBfsItems; it++) {
         if (!(probe[it] && s_slot[ls[it]] == me[it])) continue;
         const uint32_t a = w * kBfsItems + it;
-        const unsigned long long mine = slot_make(hk[it], pid, a);
+        const unsigned long long mine = slot_make(hk[it], pid, a, d.epoch);
         uint32_t base = (uint32_t)hk[it] & d.stmask & ~3u, probes = 0, took = 0;
         bool open = true;
         while (open) {
             const ulonglong2 lo = *(const ulonglong2*)(d.stab + base), hi = *(const ulonglong2*)(d.stab + base + 2);
             const unsigned long long v0 = lo.x, v1 = lo.y, v2 = hi.x, v3 = hi.y;
-            auto hot = [&](unsigned long long v) { return v == kSlotFree || (v >> 36) == (mine >> 36); };  // free, or my fingerprint
+            auto hot = [&](unsigned long long v) { return slot_free(v, d.epoch) || (v >> 36) == (mine >> 36); };  // free, or my epoch + fingerprint
             uint32_t cand = (hot(v0) ? 1u : 0u) | (hot(v1) ? 2u : 0u) | (hot(v2) ? 4u : 0u) | (hot(v3) ? 8u : 0u);
             while (cand) {
                 const uint32_t jj = (uint32_t)__builtin_ctz(cand);
                 cand &= cand - 1;
                 unsigned long long st = jj == 0 ? v0 : (jj == 1 ? v1 : (jj == 2 ? v2 : v3));
                 unsigned long long* slot = d.stab + base + jj;
-                if (st == kSlotFree) {
-                    st = atomicCAS(slot, kSlotFree, mine);
-                    if (st == kSlotFree) {
+                if (slot_free(st, d.epoch)) {  // claim it: whoever changes the slot first writes a stamp of THIS epoch, so a failed CAS returns one
+                    const unsigned long long seen = st;
+                    st = atomicCAS(slot, seen, mine);
+                    if (st == seen) {
                         took = 1;
                         open = false;
                         break;

@@ -37,7 +37,7 @@ template <typename W> __global__ void k_bfs_root_many(const BfsMany<W>* __restri
     d.tlen[0] = (uint8_t)tl;
     d.depth[0] = 0;
     const uint64_t hk = stamp_hash(k0, k1);
-    d.stab[(uint32_t)hk & d.stmask & ~3u] = slot_make(hk, 0u, kSelfAction);
+    d.stab[(uint32_t)hk & d.stmask & ~3u] = slot_make(hk, 0u, kSelfAction, d.epoch);
     *d.solved_tag = kNoTag;
     *d.shorter_tag = kNoTag;
     *d.err_tag = kNoTag;

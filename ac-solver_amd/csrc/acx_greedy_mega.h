@@ -71,6 +71,10 @@ template <typename W> struct MegaDev {
 #define ACX_RANK_TILE 32
 #endif
 constexpr uint32_t kRankTile = ACX_RANK_TILE;
+#ifndef ACX_RANK_GRID
+#define ACX_RANK_GRID 1024
+#endif
+constexpr uint32_t kRankGrid = ACX_RANK_GRID;  // workgroups of k_gm_rank (a work item = 256 entries x a tile; a bucket of 3 200 entries: 1 300 items)
 template <typename W> __global__ void __launch_bounds__(256) k_gm_rank(MegaDev<W> md, uint32_t n, uint32_t chained) {
     __shared__ W sj0[kRankTile];
     __shared__ W sj1[kRankTile];

@@ -139,7 +139,7 @@ int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int cyclica
     if (chain) {
         uint32_t* hst = (uint32_t*)S.h_pin;  // pinned: the frontier kernel's status word after every cycle, kRunAheadSlots entries
         for (uint64_t k = 0;; k++) {
-            hipLaunchKernelGGL(k_gm_rank<W>, dim3(1024), dim3(256), 0, st, md, 0u, 1u);
+            hipLaunchKernelGGL(k_gm_rank<W>, dim3(kRankGrid), dim3(256), 0, st, md, 0u, 1u);
             hipLaunchKernelGGL(k_gm_begin<W>, dim3(kMegaSlots / 1024), dim3(256), 0, st, md, 0u, 0u, 1u);
             hipLaunchKernelGGL(k_gm_expand<W>, dim3(kMegaTags / 256), dim3(256), 0, st, md, 0u, 0u, 1u);
             hipLaunchKernelGGL(k_gm_mark<W>, dim3(kMegaTiles), dim3(kMegaTile), 0, st, md, 0u, 1u);

@@ -290,12 +290,13 @@ static int run_bfs_group_fused(const int8_t* rows, int64_t n, int L, int64_t max
     const uint64_t b_tab = up(n_slots * 8), b_key = up(cap_nodes * sizeof(W)), b_u32 = up(cap_nodes * 4), b_u8 = up(cap_nodes), b_flag = up(cap_cand + 8);
     const uint64_t b_counts = up(tiles * 4), b_masks = up(tiles * 1024), b_scal = 256;
     const uint64_t per_rest = 2 * b_key + 2 * b_u32 + 2 * b_u8 + b_flag + b_counts + b_masks + b_scal;
-    // [tables of all searches][replaced-flags of all searches] (one memset each), then the rest search by search
+    // the stamp tables of all searches in ONE block of their own (StampBuf: the next group of the same size takes it over with a new
+    // epoch instead of refilling it); [replaced-flags of all searches] (one memset), then the rest search by search
     // (every device block is declared before the stream guard below: an error return first waits for the streams, then frees)
+    StampBuf tabs;
     DevBuf big, dcur, dq, droots, dstatus, dwant, dpa, dpl, dpn;
-    if (big.alloc((uint64_t)n * (b_tab + b_flag + per_rest))) return ACX_E_NOMEM;
-    uint8_t* p_tab = (uint8_t*)big.p;
-    uint8_t* p_repl = p_tab + (uint64_t)n * b_tab;
+    if (big.alloc((uint64_t)n * (b_flag + per_rest))) return ACX_E_NOMEM;
+    uint8_t* p_repl = (uint8_t*)big.p;
     uint8_t* p_rest = p_repl + (uint64_t)n * b_flag;
     SearchHandles H;
     if (int rc = search_handles_take(H)) return rc;
@@ -304,7 +305,8 @@ static int run_bfs_group_fused(const int8_t* rows, int64_t n, int L, int64_t max
         ~Give() { search_handles_give(h); }
     } give{H};
     hipStream_t st = H.st;
-    ACX_HIP_TRY(hipMemsetAsync(p_tab, 0xff, (uint64_t)n * b_tab, st));
+    if (int rc = tabs.alloc((uint64_t)n * b_tab, st)) return rc;
+    uint8_t* p_tab = (uint8_t*)tabs.p;
     ACX_HIP_TRY(hipMemsetAsync(p_repl, 0, (uint64_t)n * b_flag, st));  // once: k_bfs_count zeroes what a batch sets
     std::vector<int64_t> order[2];  // [0] general move code, [1] normal form (a root in normal form keeps its whole search there)
     std::vector<Pres<W>> roots((size_t)n);
@@ -341,6 +343,7 @@ static int run_bfs_group_fused(const int8_t* rows, int64_t n, int L, int64_t max
             d.cyclical = cyclical;
             d.stab = (unsigned long long*)(p_tab + (uint64_t)j * b_tab);
             d.stmask = (uint32_t)(n_slots - 1);
+            d.epoch = tabs.epoch;
             d.brepl = p_repl + (uint64_t)j * b_flag;
             d.k0 = (W*)take(b_key);
             d.k1 = (W*)take(b_key);

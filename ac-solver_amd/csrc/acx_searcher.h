@@ -82,6 +82,7 @@ void search_handles_give(SearchHandles& h);
 
 template <typename W> struct Searcher {
     SearchDev<W> d;
+    StampBuf stamp_tab_buf;  // the fused BFS's stamp table: handed from search to search with a new epoch, no refill (acx_frontier.h)
     DevBuf arena_nodes, arena_cand, arena_tab, arena_btab, arena_scal, arena_tmp, arena_list, arena_path, arena_status, arena_first, arena_cursor;
     uint8_t* h_cursor = nullptr;  // pinned: kRunAheadSlots x BfsCursor (behind the Decision staging)
     SearchHandles handles;
@@ -155,8 +156,9 @@ template <typename W> struct Searcher {
         if (lean) {
             d.slots = nullptr;
         } else if (stamp_tab) {
-            if (arena_tab.alloc(n_slots * 8)) return ACX_E_NOMEM;
-            d.stab = (unsigned long long*)arena_tab.p;
+            if (int rc = stamp_tab_buf.alloc(n_slots * 8, st)) return rc;
+            d.stab = (unsigned long long*)stamp_tab_buf.p;
+            d.epoch = stamp_tab_buf.epoch;
             d.stmask = (uint32_t)(n_slots - 1);
         } else {
             if (arena_tab.alloc(n_slots * 4)) return ACX_E_NOMEM;
@@ -196,7 +198,7 @@ template <typename W> struct Searcher {
             tmp_bytes = need + 256;
             if (arena_tmp.alloc(tmp_bytes)) return ACX_E_NOMEM;
         }
-        if (!lean) ACX_HIP_TRY(hipMemsetAsync(arena_tab.p, 0xff, n_slots * (stamp_tab ? 8 : 4), st));
+        if (!lean && !stamp_tab) ACX_HIP_TRY(hipMemsetAsync(arena_tab.p, 0xff, n_slots * 4, st));
         ACX_HIP_TRY(hipMemsetAsync(arena_scal.p, 0xff, 256, st));
         ACX_HIP_TRY(hipMemsetAsync(d.err, 0, 4, st));
         if (stamp_tab) ACX_HIP_TRY(hipMemsetAsync(d.brepl, 0, cap_cand + 8, st));  // once: k_bfs_compact zeroes what a batch sets
