@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACX_VERSION 400  /* history: INTEGRATION.md, "ACX_VERSION history" */
+#define ACX_VERSION 500  /* history: INTEGRATION.md, "ACX_VERSION history" */
 
 /* return codes */
 #define ACX_OK 0
@@ -202,13 +202,11 @@ int acx_release_cached_memory(void);
 /* n independent searches of the same kind / budget (the batch driver trivialize_miller_schupp_through_search,
  * miller_schupp.py:95-177, runs them one after another).  Both kinds run as GROUPS of searches, each search with its own visited
  * table and node arena.  bfs: the searches of a group share the launches of the fused single search (acx_bfs_many.h: a tile of one
- * search's batch per workgroup, a batch of every running search per round of four launches; ACX_BFS_MANY=multi selects the
- * earlier one-persistent-workgroup-per-search kernel k_bfs_multi for A/B runs).  greedy_search: ONE launch of up to 192 persistent
- * workgroups, each with the memory of one search, which take the searches from a counter one after the other (k_greedy_sched,
- * acx_greedy.h; ACX_GREEDY_MULTI_STATIC=1: round 3's one workgroup per search, as many searches per launch as fit the memory
- * budget).  A greedy search that outgrows a capacity of its workgroup is rerun alone through acx_search.  `n_threads` only matters on the fallback
- * path (n == 1, L > 61 never reaches it, the diagnostic switches ACX_GREEDY_HOST / ACX_BFS_MANY_STREAMS, `verbose` minima or the
- * digest hook on): there that many host threads run one acx_search each, every search on its own HIP stream; 1..64, clamped.
+ * search's batch per workgroup, a batch of every running search per round of four launches).  greedy_search: ONE launch of up to
+ * 256 persistent workgroups (ACX_OPT_GREEDY_SLOTS), each with the memory of one search, which take the searches from a counter one
+ * after the other (k_greedy_sched, acx_greedy.h).  A greedy search that outgrows a capacity of its workgroup is rerun alone through
+ * acx_search.  `n_threads` only matters on the fallback path (n == 1, the option ACX_OPT_GREEDY_HOST, `verbose` minima or the digest
+ * hook on): there that many host threads run one acx_search each, every search on its own HIP stream; 1..64, clamped.
  * Row k of every output belongs to presentation k ([n, path_cap] for the paths); rc_out[k] is that search's return code
  * (ACX_E_CAPACITY when its path needs more than path_cap entries: path_n[k] then holds the required size).  Results are
  * identical to n calls of acx_search. */
