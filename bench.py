@@ -193,7 +193,7 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
         """median of `reps` timed searches (MAX over the ranks each) behind a full-size warm-up call; no garbage collection while the clock runs
         (as timeit does: a full collection of this process's heap takes 25-30 ms and landed in one search out of four)"""
         t0 = time.perf_counter()
-        bfs_sharded(p, b, comm=comm, batch_parents=1 << 21)  # warm-up at full size: allocator (GBs of first-time hipMalloc), kernels, communicator
+        bfs_sharded(p, b, comm=comm)  # (chunks: bfs_sharded's default, 2^21 global parents, 2^22 from 8 ranks on) warm-up at full size: allocator (GBs of first-time hipMalloc), kernels, communicator
         torch.cuda.synchronize()
         first_call = time.perf_counter() - t0
         if use_dist:
@@ -203,7 +203,7 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
             gc.collect()
             gc.disable()
             t0 = time.perf_counter()
-            ok, path, st = bfs_sharded(p, b, comm=comm, batch_parents=1 << 21, want_stats=True)
+            ok, path, st = bfs_sharded(p, b, comm=comm, want_stats=True)
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
@@ -223,6 +223,7 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
                 "input": "AK(3) at max_relator_len=25, cyclical=False", "scaling": "strong",
                 "collectives": {k[5:]: v for k, v in st.items() if k.startswith("comm_")},
                 "exchange_bytes_per_chunk_per_rank": (st.get("comm_all_to_all_bytes", 0) / max(st.get("comm_all_to_all_calls", 1), 1)),
+                "local_nodes_of_rank0": st.get("local_nodes"), "owner": "class hashes + inner letters of both relators (csrc/acx_owner.h): ~3/4 of the children are owned by the rank that makes them",
                 "region_fill_q8": st.get("region_fill_q8"), "region_overflow_reruns": st.get("region_overflow_reruns", 0),
                 "roofline": {"bound": "hbm", "achieved": algo / secs / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
                              "frac": algo / secs / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
@@ -232,7 +233,7 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
     def timeline_of(comm, b):
         """one more search with HIP events around every stage of every chunk (not a timed sample: the events cost a little)"""
         try:
-            _, _, st = bfs_sharded(p, b, comm=comm, batch_parents=1 << 21, want_stats=True, timeline=True)
+            _, _, st = bfs_sharded(p, b, comm=comm, want_stats=True, timeline=True)
             return st.get("timeline")
         except Exception as e:  # noqa: BLE001
             return {"error": f"{type(e).__name__}: {e}"}

@@ -152,3 +152,57 @@ def test_random_presentations_sharded_bfs(world):
                 n_raise += 1
             assert got == want, (world, budget, cyc, bp, row.tolist())
     assert n_raise >= 0
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("L", [6, 25, 33])
+def test_random_presentations_through_the_sharded_engine(L, monkeypatch):
+    """bfs_sharded on 2 / 3 / 5 thread ranks of the HIP engine (one GPU plays all of them) on random presentations -- roots in and out
+    of normal form (the general move code computes every child's owner from scratch, the normal-form codes inherit it along
+    conjugations), searches in which a move empties a relator (every rank raises like the reference), tiny chunks so that records of
+    a chunk meet born children of the next: result, path and counts as the oracle's, and every node on the rank the owner function
+    names (csrc/acx_owner.h)."""
+    from ac_solver import _acx
+    from ac_solver.search import sharded
+    from ac_solver.search.sharded import bfs_sharded
+    from oracle import ac_oracle as O
+    from tests.shard_helpers import run_threads
+
+    _acx.require_device()
+    monkeypatch.setattr(sharded, "_CHECK_OWNERS", True)
+    rng = np.random.default_rng(900 + L + 1000 * SEED)
+    raised = crossed = 0
+    for case in range(10):
+        row = np.zeros(2 * L, np.int8)
+        for h in (0, 1):
+            w = _random_word(rng, int(rng.integers(1, min(L, 9) + 1)))
+            if rng.random() < 0.3 and len(w) + 2 <= L:  # not freely reduced: the general move code
+                w = w[:1] + [w[0], -w[0]] + w[1:]
+            row[h * L:h * L + len(w)] = w
+        budget = int(rng.choice([40, 700, 6000, 40000]))
+        cyc = bool(rng.integers(0, 2))
+        world = int(rng.choice([2, 3, 5]))
+        bp = int(rng.choice([64, 1024, 1 << 15]))
+        try:
+            want = O.bfs(row, budget, cyclically_reduce_after_moves=cyc, stats=True)
+        except (AssertionError, IndexError):
+            want = "raises"
+
+        def run(comm):
+            try:
+                return bfs_sharded(row, budget, cyclically_reduce_after_moves=cyc, comm=comm, batch_parents=bp, want_stats=True)
+            except (AssertionError, IndexError):
+                return "raises"
+
+        got = run_threads(world, run)
+        if want == "raises":
+            raised += 1
+            assert all(g == "raises" for g in got), (L, case, budget, cyc, world, row.tolist())
+            continue
+        wok, wpath, wst = want
+        for ok, path, st in got:
+            assert (ok, path) == (wok, wpath), (L, case, budget, cyc, world, bp, row.tolist())
+            assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (L, case, budget, cyc, world, bp, row.tolist(), st, wst)
+            assert st["owner_mismatches"] == 0
+        crossed += sum(st["local_nodes"] > 0 for _, _, st in got) > 1
+    assert crossed >= 3  # (the searches really were spread over several ranks)
