@@ -656,8 +656,10 @@ struct StampBuf {
             epoch = last + 1;
             return ACX_OK;
         }
+        // the WHOLE block, not only the `want` bytes in use: a later, larger table that gets this block with its epoch tag must not find
+        // bytes that were never filled (or stamps from before an epoch wrap) beyond this table's end
         epoch = 1;
-        ACX_HIP_TRY(hipMemsetAsync(p, 0xff, want, st));
+        ACX_HIP_TRY(hipMemsetAsync(p, 0xff, bytes, st));
         return ACX_OK;
     }
     ~StampBuf() {
