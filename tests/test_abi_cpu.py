@@ -42,6 +42,28 @@ def test_header_flags_match_binding():
     assert (int(consts["ACX_U8"]), int(consts["ACX_I32"]), int(consts["ACX_I64"]), int(consts["ACX_I8"]), int(consts["ACX_F32"])) == (0, 1, 2, 3, 4)
 
 
+def test_options_are_set_through_the_abi_and_mirror_the_header():
+    """acx_set_option / acx_get_option (process-wide knobs; the library reads no environment variable on a call path): round trip,
+    -1 = default, unknown options refused; the Python constants are the header's; csrc/ has exactly one getenv (ACX_DEBUG, at load)"""
+    from ac_solver import _acx
+
+    src = open(os.path.join(ROOT, "include", "acx.h")).read()
+    consts = {k: int(v) for k, v in re.findall(r"#define\s+(ACX_OPT_[A-Z0-9_]+)\s+(\d+)", src)}
+    n = consts.pop("ACX_OPT_COUNT")
+    assert consts and all(getattr(_acx, k[4:]) == v < n for k, v in consts.items()), consts
+    for k in consts.values():
+        assert _acx.lib.acx_get_option(k) == -1
+        assert _acx.lib.acx_set_option(k, 7) == 0 and _acx.lib.acx_get_option(k) == 7
+        assert _acx.lib.acx_set_option(k, -5) == 0 and _acx.lib.acx_get_option(k) == -1
+    assert _acx.lib.acx_set_option(n, 1) == _acx.E_INVAL and _acx.lib.acx_set_option(-1, 1) == _acx.E_INVAL and _acx.lib.acx_get_option(n + 3) == -1
+    with _acx.options(OPT_GREEDY_SLOTS=3, OPT_BFS_MANY_BMAX=128):
+        assert _acx.lib.acx_get_option(_acx.OPT_GREEDY_SLOTS) == 3 and _acx.lib.acx_get_option(_acx.OPT_BFS_MANY_BMAX) == 128
+    assert _acx.lib.acx_get_option(_acx.OPT_GREEDY_SLOTS) == -1 and _acx.lib.acx_get_option(_acx.OPT_BFS_MANY_BMAX) == -1
+    csrc = os.path.join(ROOT, "ac-solver_amd", "csrc")
+    hits = [(f, line.strip()) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h")) for line in open(os.path.join(csrc, f)) if "getenv(" in line]
+    assert len(hits) == 1 and "ACX_DEBUG" in hits[0][1], hits
+
+
 def test_no_cpu_fallback_without_gpu():
     from ac_solver import _acx
 
