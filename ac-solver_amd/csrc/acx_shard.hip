@@ -166,6 +166,7 @@ template <typename W> struct ShardDev {
     uint8_t* inn;        // world > 1: inner letters of the two relators, in0 | in1 << 4
     unsigned long long* stab;
     uint32_t stmask;
+    uint32_t epoch;      // of this engine's stamps (1 .. 254)
     int64_t* log;        // record log = receive areas of all chunks
     uint8_t* btook;      // one byte per tag of a chunk: took a slot / was pushed out again (both zero between chunks); TWO sets, `flag_stride`
     uint8_t* brepl;      // bytes apart, indexed by the chunk's parity (ChunkGeo::par): the expansion of chunk k + 1 claims beside the dedup of chunk k
@@ -287,17 +288,21 @@ __global__ void __launch_bounds__(256) k_shard_prep(ShardDev<W> d, ChunkGeo g, i
 }
 
 // ---- stamps -----------------------------------------------------------------------------------------------------------------
-// 8-byte slots, all ones = free, else fingerprint(27, bits 37..63 of the key's hash) | type(1) | payload(36):
+// 8-byte slots: epoch(8) | fingerprint(19, the top bits of the key's hash) | type(1) | payload(36); another epoch = free:
 //   type 0 (REC)   payload = word offset, in this rank's record log, of the record that claimed the slot
 //   type 1 (BORN)  payload = local id of the parent node << 4 | action: the state is that child of that node; its key is rebuilt
 //                  from the parent's key in the node arena (written by the commit of an earlier level) and one move
 // A slot only ever moves free -> first claimer of key K -> a claimer of K with a smaller (chunk, tag), so whatever a (possibly
 // stale) plain load shows, an occupant that beats me stays beaten, and every change goes through a device-scope CAS.
-constexpr unsigned long long kStampFree = ~0ull;
 constexpr unsigned long long kStampOff = (1ull << 36) - 1;   // payload
 constexpr unsigned long long kStampBorn = 1ull << 36;        // type bit
-constexpr unsigned long long kStampFpMask = ~((1ull << 37) - 1);
-__device__ __forceinline__ bool stamp_fp_eq(unsigned long long a, unsigned long long b) { return (a >> 37) == (b >> 37); }
+// the top 27 bits of a stamp: the engine's EPOCH (8 bits; ShardDev::epoch, 1 .. 254) over a 19-bit fingerprint of the key's hash.  A
+// slot whose epoch field differs is FREE: what an earlier search left in the table's memory, or the 0xFF.. of a fresh fill (the table
+// comes from the pool through StampBuf, acx_frontier.h, and is not refilled from search to search); a free slot is claimed by a CAS
+// on the value that was seen there.
+__device__ __forceinline__ unsigned long long stamp_top(uint64_t hk, uint32_t epoch) { return ((unsigned long long)epoch << 56) | ((hk >> 45) << 37); }
+__device__ __forceinline__ bool stamp_free(unsigned long long st, uint32_t epoch) { return (uint32_t)(st >> 56) != epoch; }
+__device__ __forceinline__ bool stamp_fp_eq(unsigned long long a, unsigned long long b) { return (a >> 37) == (b >> 37); }  // epoch and fingerprint
 __device__ __forceinline__ uint32_t born_parent(unsigned long long st) { return (uint32_t)((st & kStampOff) >> 4); }
 __device__ __forceinline__ uint32_t born_action(unsigned long long st) { return (uint32_t)st & 15u; }
 template <typename W, int MODE> __device__ __forceinline__ void stamp_key(const ShardDev<W>& d, unsigned long long st, W& q0, W& q1) {
@@ -347,7 +352,8 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
     __shared__ uint32_t s_cnt[64];
     __shared__ uint32_t s_base[64];
     extern __shared__ uint32_t s_bits[];  // [world][64]: bits 0..11 the surviving actions of lane l's parent that go to owner o; later | their prefix << 16
-    ACX_VGPR_PAD_W(W, "v55", "v87");  // the code needs 46-47 / 71-79 registers (tools/kernel_resources.py)
+    ACX_VGPR_PAD_W(W, "v55", "v111");  // the code needs 46-78 / 98-106 registers (tools/kernel_resources.py); the 128-bit general SOLO build had exactly
+                                       // 104 with a v_lshrrev_b64 amount in v103: the build's shift check refused it
     if (d.ctl[C_STATUS] != 0) return;
     const uint32_t tid = threadIdx.x, l = (tid & 63u) + 64u * (tid >> 8), w = (tid >> 6) & 3u;  // parent slot in the workgroup; wave inside its group of four
     const uint32_t s_lo = d.bounds[2 * g.par], s_hi = d.bounds[2 * g.par + 1];
@@ -523,13 +529,13 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
     for (int it = 0; it < kExpandItems; it++) {
         if (!born[it]) continue;
         const uint32_t a = expand_action(w, it);
-        const unsigned long long mine = (hk[it] & kStampFpMask) | kStampBorn | ((unsigned long long)id << 4) | a;
+        const unsigned long long mine = stamp_top(hk[it], d.epoch) | kStampBorn | ((unsigned long long)id << 4) | a;
         uint32_t base = (uint32_t)hk[it] & d.stmask & ~3u, probes = 0;
         bool open = true, took = false;
         while (open) {
             const ulonglong2 lo = *(const ulonglong2*)(d.stab + base), hi = *(const ulonglong2*)(d.stab + base + 2);
             const unsigned long long v0 = lo.x, v1 = lo.y, v2 = hi.x, v3 = hi.y;
-            auto hot = [&](unsigned long long v) { return v == kStampFree || stamp_fp_eq(v, mine); };
+            auto hot = [&](unsigned long long v) { return stamp_free(v, d.epoch) || stamp_fp_eq(v, mine); };
             uint32_t cand = (hot(v0) ? 1u : 0u) | (hot(v1) ? 2u : 0u) | (hot(v2) ? 4u : 0u) | (hot(v3) ? 8u : 0u);
             while (cand && open) {
                 const uint32_t jj = (uint32_t)__builtin_ctz(cand);
@@ -537,9 +543,9 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
                 unsigned long long st = jj == 0 ? v0 : (jj == 1 ? v1 : (jj == 2 ? v2 : v3));
                 unsigned long long* slot = d.stab + base + jj;
                 for (;;) {  // until this slot is decided for me (once it holds my key it only changes among holders of MY key)
-                    if (st == kStampFree) {
-                        const unsigned long long old = atomicCAS(slot, kStampFree, mine);
-                        if (old == kStampFree) {
+                    if (stamp_free(st, d.epoch)) {  // (whoever changes a free slot first writes a stamp of THIS epoch: a failed CAS returns one)
+                        const unsigned long long old = atomicCAS(slot, st, mine);
+                        if (old == st) {
                             took = true;
                             open = false;
                             break;
@@ -600,7 +606,7 @@ template <typename W, int MODE> __device__ __forceinline__ void shard_insert_til
     recio<W>::get(rec, c0, c1);
     const uint32_t tag = (uint32_t)((unsigned long long)rec[recio<W>::KW] >> 32);
     const uint64_t hk = shard_hash(c0, c1);
-    const unsigned long long me = (hk & kStampFpMask) | (unsigned long long)off;
+    const unsigned long long me = stamp_top(hk, d.epoch) | (unsigned long long)off;
     uint8_t* __restrict__ btook = d.btook + g.par * d.flag_stride;
     uint8_t* __restrict__ brepl = d.brepl + g.par * d.flag_stride;
     uint8_t* __restrict__ brepl_next = d.brepl + (g.par ^ 1u) * d.flag_stride;
@@ -610,7 +616,7 @@ template <typename W, int MODE> __device__ __forceinline__ void shard_insert_til
     while (open) {
         const ulonglong2 lo = *(const ulonglong2*)(d.stab + base), hi = *(const ulonglong2*)(d.stab + base + 2);
         const unsigned long long v0 = lo.x, v1 = lo.y, v2 = hi.x, v3 = hi.y;
-        auto hot = [&](unsigned long long v) { return v == kStampFree || stamp_fp_eq(v, me); };
+        auto hot = [&](unsigned long long v) { return stamp_free(v, d.epoch) || stamp_fp_eq(v, me); };
         uint32_t cand = (hot(v0) ? 1u : 0u) | (hot(v1) ? 2u : 0u) | (hot(v2) ? 4u : 0u) | (hot(v3) ? 8u : 0u);
         while (cand && open) {
             const uint32_t j = (uint32_t)__builtin_ctz(cand);
@@ -618,9 +624,9 @@ template <typename W, int MODE> __device__ __forceinline__ void shard_insert_til
             unsigned long long st = j == 0 ? v0 : (j == 1 ? v1 : (j == 2 ? v2 : v3));
             unsigned long long* slot = d.stab + base + j;
             for (;;) {  // until this slot is decided for me (once it holds my key it only changes among holders of MY key)
-                if (st == kStampFree) {
-                    const unsigned long long old = atomicCAS(slot, kStampFree, me);
-                    if (old == kStampFree) {
+                if (stamp_free(st, d.epoch)) {
+                    const unsigned long long old = atomicCAS(slot, st, me);
+                    if (old == st) {
                         took = 1;
                         open = false;
                         break;
@@ -1035,7 +1041,7 @@ template <typename W> __global__ void k_shard_seed(ShardDev<W> d, W k0, W k1) {
     recio<W>::put(d.log, k0, k1);
     d.log[recio<W>::KW] = 0;
     const uint64_t hk = shard_hash(k0, k1);
-    d.stab[(uint32_t)hk & d.stmask & ~3u] = hk & kStampFpMask;  // a record stamp with offset 0: first slot of its bucket
+    d.stab[(uint32_t)hk & d.stmask & ~3u] = stamp_top(hk, d.epoch);  // a record stamp with offset 0: first slot of its bucket
     d.ctl[C_NODES] = 1;
 }
 
@@ -1109,7 +1115,8 @@ static void ctl_host_give(CtlHost& c) {
 
 template <typename W> struct ShardEngine {
     ShardDev<W> d;
-    DevBuf nodes_buf, chunk_buf, tab_buf, scal_buf;
+    StampBuf tab_buf;  // the visited table: from the pool with a new epoch, no refill (acx_frontier.h)
+    DevBuf nodes_buf, chunk_buf, scal_buf;
     int64_t* d_find = nullptr;
     int64_t* d_send = nullptr;  // the caller's send buffer (null when world == 1: the chunk is expanded straight into the log)
     uint64_t cap_nodes = 0, n_slots = 0, chunk_parents = 0, log_words = 0, send_words = 0;
@@ -1214,8 +1221,9 @@ template <typename W> struct ShardEngine {
             d.gblk = (uint32_t*)take(b, 4 * n_tiles);
             if (pass == 0 && chunk_buf.alloc(o)) return ACX_E_NOMEM;
         }
-        if (tab_buf.alloc(n_slots * 8)) return ACX_E_NOMEM;
+        if (int rc = tab_buf.alloc(n_slots * 8, nullptr)) return rc;  // (a fill, when there is one, is queued on the null stream like the others)
         d.stab = (unsigned long long*)tab_buf.p;
+        d.epoch = tab_buf.epoch;
         d.stmask = (uint32_t)(n_slots - 1);
         if (scal_buf.alloc(1024)) return ACX_E_NOMEM;
         uint8_t* sc = (uint8_t*)scal_buf.p;
@@ -1225,7 +1233,6 @@ template <typename W> struct ShardEngine {
         d_find = (int64_t*)(sc + 384);
         d.cap_nodes = (uint32_t)cap_nodes;
         if (int rc = ctl_host_take(host)) return rc;
-        ACX_HIP_TRY(hipMemsetAsync(d.stab, 0xff, n_slots * 8, nullptr));
         ACX_HIP_TRY(hipMemsetAsync(chunk_buf.p, 0, flag_bytes, nullptr));
         ACX_HIP_TRY(hipMemsetAsync(scal_buf.p, 0, 1024, nullptr));
         hipLaunchKernelGGL(k_shard_ctl_init, dim3(1), dim3(1), 0, nullptr, d.ctl);  // smallest length = none yet; len(tree_nodes) counts the root, on every rank
