@@ -8,14 +8,16 @@
 // batch.  So the visited table is mostly written, and the three memory-side operations a new key used to cost (CAS of the
 // stamp + two key words stored into a 32-byte entry of an 8.6 GB table) are the thing to cut:
 //
-//   * one 8-byte slot per state:  fingerprint(28) | parent node id(32) | action(4), all ones = free.  A slot names the
+//   * one 8-byte slot per state:  epoch(8) | fingerprint(20) | parent node id(32) | action(4) (slot_make below; rounds 2-4: a
+//     28-bit fingerprint, all ones = free).  A slot names the
 //     state as "child `action` of node `parent`" (action 15: the node itself, used for the root), so the full key of an
 //     occupant is RECOMPUTED from the parent's key in the node arena (two 8-byte loads that hit in L2 / Infinity Cache
 //     far more often than a table entry does, plus one apply_move) -- and only when the fingerprint matches.  Exact set
 //     semantics are kept (full-key compare before "seen"); a new state costs ONE CAS and no store.
 //   * the batch is told apart by the parent id: parents of the running batch are the nodes >= pbegin, everything below
 //     is a committed state.  (parent, action) is also the reference's generation order, so the minimum-tag fold among
-//     equal keys is a 64-bit atomicMin on the slot, as before.  No epochs, no commit pass.
+//     equal keys is a 64-bit atomicMin on the slot, as before.  No per-batch epochs, no commit pass.  (The epoch of round 5 is per
+//     SEARCH: a slot that carries another search's epoch is free, so a table is handed from search to search without a refill.)
 //   * expand and insert are ONE kernel: the child never travels through a candidate arena (16 B written + 16 B read
 //     per child before); k_bfs_compact recomputes the winners' keys the same way.
 //   * children equal to their parent are dropped before any probe (visited by construction), and a workgroup first
@@ -277,7 +279,7 @@ __global__ void __launch_bounds__(kBfsThreads) k_bfs_expand_insert(SearchDev<W> 
 //                  kept in `masks`) and the tile's winner count; zeroes the replaced-flags it read
 //   k_bfs_compact  position of a tile's first winner = sum of the counts of ALL earlier tiles (256 at a time, independent loads),
 //                  then the nodes in tag order, the winners' keys recomputed from their parents.
-// Rounds 1-2 did this in one launch (k_compact_tab's scheme: a ticket per tile, decoupled look-back over status words).  Its
+// Rounds 1-2 did this in one launch (a ticket per tile, decoupled look-back over status words).  Its
 // own clock (-DACX_COMPACT_PROFILE) showed where the 58 us per 2^20-parent batch went: the ~1500 same-address returning
 // atomics of the tickets take 18 us, and every memory access of the kernel crawls while they last (a tile that had its ticket
 // after 1 us saw its 32 KB of flags after 20 us); then 8 us of look-back, then 22 us of node writes at ~3 TB/s.

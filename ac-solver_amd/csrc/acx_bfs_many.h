@@ -1,6 +1,6 @@
 // Many independent breadth-first searches, level-synchronous in ONE sequence of launches (round 4).
 //
-// acx_search_many(bfs) used to give every search one persistent workgroup (acx_bfs_multi.h): 170 searches of a Miller-Schupp batch
+// acx_search_many(bfs) used to give every search one persistent workgroup (rounds 2-3, k_bfs_multi): 170 searches of a Miller-Schupp batch
 // fill 170 of the 256 compute units with ONE workgroup each, and every search then runs at the latency of its own atomics.  Here the
 // searches of a group share the kernels of the fused single search (acx_bfs.h: expand + dedup, count, compact, decide), launched over a
 // 2-D grid: blockIdx.x = tile of the search's batch, blockIdx.y = search.  Every search has its own arenas and its own device-resident

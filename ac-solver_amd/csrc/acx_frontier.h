@@ -119,8 +119,7 @@ __global__ void __launch_bounds__(256) k_expand(SearchDev<W> d, const uint32_t* 
         d.ck0[t] = c0;
         d.ck1[t] = c1;
         d.cknown[t] = (c0 == pk0 && c1 == pk1) ? 1 : 0;  // an unchanged state is its (visited) parent: k_insert skips the probe
-        if (d.brepl) d.brepl[t] = 0;                       // BFS: "replaced by a smaller tag" flag of k_insert_tab
-        else d.cslot[t] = 0;
+        d.cslot[t] = 0;
         tl = (uint32_t)(s.n0 + s.n1);
         d.clen[t] = (uint8_t)tl;
         if (d.first_len && tl < d.min_len_start) atomicMin(&d.first_len[tl], (unsigned long long)t);  // a candidate for "New minimal length found"
@@ -303,19 +302,10 @@ __global__ void __launch_bounds__(256) k_commit(SearchDev<W> d, const uint32_t* 
             }
         }
     }
-    // BFS (insert_now == 0): the inline-key table already holds the key under this batch's epoch; nothing to rewrite
 }
 
-// ---- BFS: winners -> nodes in ONE pass (mark + scan + commit) -----------------------------------------------------------
-// A tile of kCompactTile consecutive candidates per workgroup.  The tile counts its winners (cflag & !cslot, see
-// k_insert_tab), gets the number of winners before it through a decoupled look-back over per-tile status words
-// (epoch << 34 | state << 32 | count; tiles are handed out by a ticket so that a tile only ever waits for tiles that
-// already run), and writes its winners as nodes base + rank, rank = position among the batch's winners in tag order.
-// Every winner of the batch is written (ids below cap_nodes): in a BFS a batch is cut short only when the search
-// ends, and k_decide_tab then derives the counts the reference would have from the tags of the written nodes.
-// 32 candidates per lane, 8192 per tile: every tile takes a ticket from ONE counter, and a single word serves only ~90
-// returning atomics per microsecond -- with 2048-candidate tiles the 162 000 tickets of a 1e8-node search were 1.8 of the
-// pass's 2.9 ms.
+// ---- BFS: winners -> nodes (acx_bfs.h: k_bfs_count + k_bfs_compact) work on tiles of kCompactTile consecutive candidates, 32 per lane
+// (one winner bit each in a 32-bit word) ---------------------------------------------------------------------------------------------
 #ifndef ACX_COMPACT_ITEMS
 #define ACX_COMPACT_ITEMS 32
 #endif

@@ -84,7 +84,7 @@ template <typename W> struct GreedyDev {
     uint32_t nf;         // 1: the root is in normal form (freely -- with `cyclical`, cyclically -- reduced, both relators non-empty), so every node is: the
                          // kernels instantiated for that run the shorter move code apply_move_nf (acx_word.h; what the BFS kernels call kMoveNf)
     uint32_t hand_min;   // 0: never; else a selected bucket with at least this many queued parents ends the kernel with GREEDY_HANDOFF
-    GreedyState* state;  // nullable (k_greedy_multi): where the frontier is parked / resumed from
+    GreedyState* state;  // nullable (k_greedy_sched): where the frontier is parked / resumed from
     const uint32_t* mega_status;  // nullable: {status, cut, remaining} of the whole-GPU kernels (acx_greedy_mega.h: MegaScalars).  The host
                                   // relaunches this kernel behind every mega-batch WITHOUT waiting for the batch's outcome (one
                                   // synchronisation per hand-off instead of two); when the bucket is not finished the launch is a no-op
@@ -108,13 +108,13 @@ struct GreedyOut {
 
 // Handed-off buckets of at most this many entries are ordered by the whole-GPU counting sort of acx_greedy_mega.h (k_gm_rank); in
 // chained mode a larger one is ordered by the frontier kernel itself (its bitonic network through HBM) BEFORE it is handed off.
-constexpr uint32_t kMegaRankMax = 16384;  // GreedyDev::rank_max unless ACX_MEGA_RANK_MAX says otherwise (tests: a small value sends AK(3) through the own-sort path)
+constexpr uint32_t kMegaRankMax = 16384;  // GreedyDev::rank_max unless the option ACX_OPT_MEGA_RANK_MAX says otherwise (tests: a small value sends AK(3) through the own-sort path)
 
 template <typename W> struct greedy_cfg;
-// k_greedy_multi (one search per workgroup, many searches per launch): lanes and candidates per batch.  Measured on the 1190
+// k_greedy_sched (many searches per launch, one per workgroup at a time): lanes and candidates per batch.  Measured on the 1190
 // Miller-Schupp searches of 1e6 nodes (tools/ms_sweep_warm.py greedy): 1024 lanes x 4 children 0.40 s, 1024 x 2 0.43 s;
 // 512-lane workgroups, two per compute unit (128 registers each): x 4 0.50 s, x 2 0.49 s, x 1 0.55 s -- unlike the BFS
-// kernel (acx_bfs_multi.h) this one gains nothing from a second search per compute unit, its batches need the lanes.
+// kernels this one gains nothing from a second search per compute unit, its batches need the lanes.
 #ifndef ACX_GREEDY_MULTI_THREADS
 #define ACX_GREEDY_MULTI_THREADS 1024
 #endif
