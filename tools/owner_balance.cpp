@@ -81,11 +81,12 @@ static uint64_t inner_letters(WW w, int n, int k) {
     return f;
 }
 
-enum { S_WHOLE = 0, S_R0, S_CLASS0, S_CHEAP0, S_CLASS01, S_CLASS0_R1LEN, S_BIGRAM01, S_CHEAP01, S_BIGRAM01_IN1, S_BIGRAM01_IN2, S_BIGRAM01_IN3, S_N };
+enum { S_WHOLE = 0, S_R0, S_CLASS0, S_CHEAP0, S_CLASS01, S_CLASS0_R1LEN, S_BIGRAM01, S_CHEAP01, S_BIGRAM01_IN1, S_BIGRAM01_IN2, S_BIGRAM01_IN3, S_BIGRAM01_IN1_R0, S_BIGRAM01_IN1_R1, S_N };
 static const char* kNames[S_N] = {"hash(r0, r1)           [round 4]", "hash(r0)", "hash(class(r0))", "hash(cheap invariant(r0))",
                                   "hash(class(r0)) + hash(class(r1))", "hash(class(r0), |r1| >> 2)",
                                   "hash(bigrams(r0)) + hash(bigrams(r1))", "hash(cheap(r0)) + hash(cheap(r1))",
-                                  "bigrams + 1 innermost conjugator letter per relator", "bigrams + 2 innermost conjugator letters", "bigrams + 3 innermost conjugator letters"};
+                                  "bigrams + 1 innermost conjugator letter per relator", "bigrams + 2 innermost conjugator letters", "bigrams + 3 innermost conjugator letters",
+                                  "bigrams + the innermost conjugator letter of r0 only", "bigrams + the innermost conjugator letter of r1 only"};
 static uint64_t owner_hash(int scheme, const Key& k) {
     const WW w0 = k.a & (((WW)1 << kLenShift) - 1), w1 = k.b & (((WW)1 << kLenShift) - 1);
     const int n0 = (int)(k.a >> kLenShift), n1 = (int)(k.b >> kLenShift);
@@ -102,6 +103,8 @@ static uint64_t owner_hash(int scheme, const Key& k) {
             const int k = scheme - S_BIGRAM01_IN1 + 1;
             return mix(0, (uint32_t)(conj_bigram(w0, n0) + conj_bigram(w1, n1) + inner_letters(w0, n0, k) * 0x9E3779B1u + inner_letters(w1, n1, k) * 0x85EBCA77u));
         }
+        case S_BIGRAM01_IN1_R0: return mix(0, (uint32_t)(conj_bigram(w0, n0) + conj_bigram(w1, n1) + inner_letters(w0, n0, 1) * 0x9E3779B1u));
+        case S_BIGRAM01_IN1_R1: return mix(0, (uint32_t)(conj_bigram(w0, n0) + conj_bigram(w1, n1) + inner_letters(w1, n1, 1) * 0x85EBCA77u));
         case S_CHEAP01: return mix(0, conj_cheap(w0, n0)) + mix(1, conj_cheap(w1, n1));
         default: return mix(mix(0, conj_class(w0, n0)), (uint64_t)(n1 >> 2));
     }
