@@ -126,6 +126,20 @@ def test_data_files_reproduce_the_published_results(tmp_path, golden_json):
         replay_paths([[1, 0, 0, -1, 0, 0]], [[(-1, 2), (0, 0)]])
 
 
+def test_data_package_is_importable_as_in_the_reference(golden_json):
+    """the reference's own check (tests/search/miller_schupp/data/test_do_files_exist.py) and the way its trainer opens the files
+    (agents/utils.py:28, importlib.resources): the package exists, and importing it on a GPU box leaves the files there"""
+    from importlib import resources
+
+    import ac_solver.search.miller_schupp.data as data
+
+    for file_type in ["greedy_solved", "all"]:
+        file_name = f"{file_type}_presentations.txt"
+        assert (resources.files(data) / file_name).is_file(), f"File {file_name} does not exist in the package"
+    with resources.files(data).joinpath("all_presentations.txt").open() as f:
+        assert len([line for line in f if line.strip()]) == 1190
+
+
 @pytest.mark.timeout(600)
 def test_train_ppo_runs_baseline_config5_shape(tmp_path, monkeypatch):
     """BASELINE config 5 per GPU: `python -m ac_solver.agents.ppo --num-envs 131072` -- more environments than the 1190 initial
