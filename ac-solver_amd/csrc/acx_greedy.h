@@ -1116,8 +1116,13 @@ template <typename W> struct GreedyJob {
     uint32_t root_len, nlen;
     int32_t L, pad_;
 };
+#ifndef ACX_GREEDY_MULTI_WAVES_PER_EU
+#define ACX_GREEDY_MULTI_WAVES_PER_EU 1  // the second launch bound: waves per SIMD the register allocation must leave room for.  Round 5 measured
+// the sweep with TWO searches per compute unit (-DACX_GREEDY_MULTI_THREADS=512 -DACX_GREEDY_MULTI_R=2 -DACX_GREEDY_MULTI_WAVES_PER_EU=4, 512 slots):
+// 0.152-0.158 s against 0.172-0.176 s -- and twice the slots' memory (106 GB; a cold call 3.5 s instead of 0.9 s), so not the default
+#endif
 template <typename W, bool NF>
-__global__ void __launch_bounds__(kGreedyMultiThreads) k_greedy_sched(const GreedyDev<W>* __restrict__ slots, const GreedyJob<W>* __restrict__ jobs, uint32_t n_jobs,
+__global__ void __launch_bounds__(kGreedyMultiThreads, ACX_GREEDY_MULTI_WAVES_PER_EU) k_greedy_sched(const GreedyDev<W>* __restrict__ slots, const GreedyJob<W>* __restrict__ jobs, uint32_t n_jobs,
                                                       uint32_t* __restrict__ counter, GreedyOut* __restrict__ outs, int32_t* __restrict__ path_act,
                                                       int32_t* __restrict__ path_len, long long path_cap) {
     __shared__ uint32_t s_job;

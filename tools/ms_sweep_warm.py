@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """bfs / greedy over the 1190 Miller-Schupp presentations, all seven widths in flight, timed on the second run (device pools warm).
-python tools/ms_sweep_warm.py [bfs|greedy] [budget]"""
+python tools/ms_sweep_warm.py [bfs|greedy] [budget] [greedy slots]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "ac-solver_amd"), ROOT]
@@ -10,6 +10,8 @@ from ac_solver.search._common import run_search_groups
 g = json.load(open(os.path.join(ROOT, "tests/golden/ms_pool.json")))
 algo = sys.argv[1] if len(sys.argv) > 1 else "bfs"
 budget = int(float(sys.argv[2])) if len(sys.argv) > 2 else 10**6
+slots = int(sys.argv[3]) if len(sys.argv) > 3 else -1  # ACX_OPT_GREEDY_SLOTS (-1: the library's default)
+_acx.check(_acx.lib.acx_set_option(_acx.OPT_GREEDY_SLOTS, slots))
 kind, cyc = (_acx.SEARCH_BFS, True) if algo == "bfs" else (_acx.SEARCH_GREEDY, False)
 groups = [np.array([p for w in range(1, 8) for p in g["by_n"][str(n)][str(w)]], dtype=np.int8) for n in range(1, 8)]
 for rep in range(3):
