@@ -528,7 +528,7 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
     # Inside a level chunk k + 1 needs nothing from chunk k: its parents were committed during the previous level and it has its
     # own slice of the record log; only the send buffer is shared, and that is reused in `side`'s own order.  The CPU engines of
     # the tests run everything in program order.  What running two of the engine's kernels side by side is worth on ONE GPU
-    # (measured, tools/scratch/trace_timeline.py on rocprofv3 kernel traces of 1e8-node searches):
+    # (measured in round 3 on rocprofv3 kernel traces of 1e8-node searches):
     #   * expansion beside k_shard_insert: the dedup keeps ~2.6e5 table atomics queued at the memory side, the expansion's
     #     region reservations (one returning atomic per workgroup) wait ~14 us each behind them and it loses its share of the
     #     compute units: 0.21 -> 0.75-0.9 ms per 2^21-parent chunk, the dedup slows by a third, the chunk period stays;

@@ -1134,7 +1134,7 @@ template <typename W> struct ShardEngine {
     // workgroup per 256 record slots).  Regions are sized for the worst case and are usually less than half full, so two
     // thirds of the per-slot workgroups found nothing to do, and the dedup gains nothing from more than ~4 workgroups per
     // compute unit in flight: the memory-side atomic units are saturated by then and a deeper queue is only more latency.
-    // Measured at 1e8 nodes (tools/scratch/shard_env_sweep.py): insert 545 -> 528 us per 2^21-parent chunk, commit 158 -> ~125.
+    // Measured at 1e8 nodes (round 4, a sweep over the workgroup counts): insert 545 -> 528 us per 2^21-parent chunk, commit 158 -> ~125.
     unsigned insert_wgs = 0, commit_wgs = 0;
     int move_mode = kMoveGeneral;  // acx_bfs.h: set from the root (acx_shard_root_record, which every rank calls)
     CtlHost host;  // pinned snapshot slots + events
