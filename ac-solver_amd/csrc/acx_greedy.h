@@ -194,9 +194,10 @@ template <typename W, uint32_t kGT> __device__ __forceinline__ void lds_merge(W*
     }
 }
 
-// Workgroup barrier that orders LDS traffic only: outstanding global stores / atomics stay in flight (the
-// s_waitcnt vmcnt(0) that __syncthreads() carries is what exposes their latency).  Global data written before
-// it is NOT guaranteed visible to the other waves afterwards.
+// Workgroup barrier that orders LDS traffic only: outstanding global stores / atomics stay in flight.  Global data written
+// before it is NOT guaranteed visible to the other waves afterwards.  (With ROCm 7.2's compiler __syncthreads() on gfx950 is
+// the same two instructions -- no barrier of this file's kernels is preceded by a vmcnt wait: the waves of a workgroup share
+// a compute unit and its L1 -- so this spelling only pins down what the commit phase relies on; round 5 checked the assembly.)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // exclusive prefix of up to 64 wave counts by one wave; returns the grand total (valid in every lane)
