@@ -512,6 +512,7 @@ struct BlockPool {
         size_t bytes;
         int dev;  // the device the block was allocated on: a block is only ever handed to a caller whose current device is that one
         uint32_t stamp_epoch;  // != 0: the block was the stamp table of a finished BFS whose stamps carry epochs <= this (StampBuf)
+        uint64_t clean_tag;    // != 0: the block holds greedy slots in the layout this names, every one of them as a search expects it (GreedySlots)
     };
     std::mutex mu;
     std::vector<Block> blocks;
@@ -525,27 +526,37 @@ struct BlockPool {
     }
     // `stamp_epoch` (StampBuf): a former stamp table is preferred and its epoch returned; every other caller gets an untagged block
     // if there is one (a tagged block it takes loses its tag: its content becomes the caller's)
-    void* take(size_t bytes, size_t* got, int dev, uint32_t* stamp_epoch = nullptr) {
+    // `clean_tag` (GreedySlots): in: the layout wanted, out: that tag if the block carries it (its content is then valid), else 0.
+    void* take(size_t bytes, size_t* got, int dev, uint32_t* stamp_epoch = nullptr, uint64_t* clean_tag = nullptr) {
         std::lock_guard<std::mutex> lock(mu);
         size_t best = blocks.size();
+        const uint64_t want_clean = clean_tag ? *clean_tag : 0;
+        auto wanted = [&](size_t k) {  // a block whose content this caller can use
+            return stamp_epoch ? blocks[k].stamp_epoch != 0 : (want_clean ? blocks[k].clean_tag == want_clean : false);
+        };
+        auto tagged = [&](size_t k) { return blocks[k].stamp_epoch != 0 || blocks[k].clean_tag != 0; };
         auto better = [&](size_t k) {
             if (best == blocks.size()) return true;
-            const bool tk = blocks[k].stamp_epoch != 0, tb = blocks[best].stamp_epoch != 0;
-            if (tk != tb) return stamp_epoch ? tk : !tk;
+            if (wanted(k) != wanted(best)) return wanted(k);
+            if (!wanted(k) && tagged(k) != tagged(best)) return !tagged(k);  // (somebody else's content is the last thing to overwrite)
             return blocks[k].bytes < blocks[best].bytes;
         };
         for (size_t k = 0; k < blocks.size(); k++)
             if (blocks[k].dev == dev && blocks[k].bytes >= bytes && blocks[k].bytes <= bytes + bytes / 2 + 4096 && better(k)) best = k;
-        if (best == blocks.size()) return nullptr;
+        if (best == blocks.size()) {
+            if (clean_tag) *clean_tag = 0;
+            return nullptr;
+        }
         void* p = blocks[best].p;
         *got = blocks[best].bytes;
         if (stamp_epoch) *stamp_epoch = blocks[best].stamp_epoch;
+        if (clean_tag) *clean_tag = blocks[best].clean_tag == want_clean ? want_clean : 0;
         cached[dev] -= blocks[best].bytes;
         blocks[best] = blocks.back();
         blocks.pop_back();
         return p;
     }
-    void give(void* p, size_t bytes, int dev, uint32_t stamp_epoch = 0) {
+    void give(void* p, size_t bytes, int dev, uint32_t stamp_epoch = 0, uint64_t clean_tag = 0) {
         {
             std::lock_guard<std::mutex> lock(mu);
             size_t free_b = 0, total_b = 0;
@@ -556,7 +567,7 @@ struct BlockPool {
             // than an eighth of the device is free, blocks go back to the driver instead of into the pool
             const bool roomy = !info || !mine || free_b > total_b / 8;
             if (roomy && bytes <= kMaxCachedBlock && cached[dev] + bytes <= max_cached[dev] && blocks.size() < kMaxBlocks) {
-                blocks.push_back({p, bytes, dev, stamp_epoch});
+                blocks.push_back({p, bytes, dev, stamp_epoch, clean_tag});
                 cached[dev] += bytes;
                 return;
             }
@@ -598,10 +609,12 @@ struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
     int dev = 0;
-    int alloc(size_t b) {
+    uint64_t clean_tag = 0;  // what the block goes back to the pool as (GreedySlots: set once every slot in it is clean again)
+    // `want_clean`: in: a content tag; out: that tag if the block already carries it, else 0
+    int alloc(size_t b, uint64_t* want_clean = nullptr) {
         const size_t want = b ? b : 1;
         dev = BlockPool::current_device();
-        p = block_pool().take(want, &bytes, dev);
+        p = block_pool().take(want, &bytes, dev, nullptr, want_clean);
         if (p) return ACX_OK;
         bytes = want;
         if (hipMalloc(&p, bytes) != hipSuccess) {
@@ -614,7 +627,7 @@ struct DevBuf {
         return ACX_OK;
     }
     ~DevBuf() {
-        if (p) block_pool().give(p, bytes, dev);
+        if (p) block_pool().give(p, bytes, dev, 0, clean_tag);
     }
 };
 

@@ -91,6 +91,14 @@ template <typename W> struct GreedyDev {
     uint32_t rank_max;   // chained mode: a handed-off bucket of more entries is ordered by the frontier kernel itself first (kMegaRankMax)
     uint32_t* hand_ctl;  // nullable: {pending, queued parents, 1 = unsorted tail} of MegaScalars -- chained mode (acx_greedy_mega.h): the hand-off
                          // is read by the whole-GPU kernels the host has ALREADY enqueued behind this one, not by the host
+    // k_greedy_sched: gk0 / gk1 / gid of a slot hold `scratch_cap` entries, enough for the usual bucket that outgrows the LDS; a sort that
+    // needs more borrows one of `big_n` full-size regions ([gk0 | gk1 | gid], `big_key_bytes` per key array, `big_stride` bytes apart)
+    // shared by all slots of the call: big_lock[r] = 1 while a workgroup sorts in region r.  big_lock == nullptr: gk0 / gk1 / gid are full size.
+    uint32_t scratch_cap;
+    uint32_t big_n;
+    uint32_t* big_lock;
+    uint8_t* big_base;
+    unsigned long long big_key_bytes, big_stride;
 };
 
 struct GreedyOut {
@@ -98,7 +106,7 @@ struct GreedyOut {
     uint32_t solved_parent, solved_action, last_parent, last_child_len;
     unsigned long long expanded, batches;
     uint32_t fallback_reason, max_bucket;
-    uint32_t path_n, pad_;
+    uint32_t path_n, arena_top;  // arena_top: entries of the bucket arena the search used
     uint32_t hand_len, hand_depth, hand_live, hand_sort;  // GREEDY_HANDOFF: the bucket, its queued parents, 1 = it has an unsorted tail
     unsigned long long sorts, big_sorts;
     uint32_t hist_sort[16];  // sorts by log2(bucket size)
@@ -112,16 +120,20 @@ constexpr uint32_t kMegaRankMax = 16384;  // GreedyDev::rank_max unless the opti
 
 template <typename W> struct greedy_cfg;
 // k_greedy_sched (many searches per launch, one per workgroup at a time): lanes and candidates per batch.  Measured on the 1190
-// Miller-Schupp searches of 1e6 nodes (tools/ms_sweep_warm.py greedy): 1024 lanes x 4 children 0.40 s, 1024 x 2 0.43 s;
-// 512-lane workgroups, two per compute unit (128 registers each): x 4 0.50 s, x 2 0.49 s, x 1 0.55 s -- unlike the BFS
-// kernels this one gains nothing from a second search per compute unit, its batches need the lanes.
+// Miller-Schupp searches of 1e6 nodes (tools/ms_sweep_warm.py greedy).  Rounds 2-3, one workgroup per search in static launches:
+// 1024 lanes x 4 children 0.40 s, 512-lane workgroups two per compute unit 0.49-0.55 s (a launch waited for its slowest search: latency
+// counted).  Round 4, searches as jobs on persistent workgroups: 1024 x 4 0.172-0.176 s.  Round 5, the same with 512 lanes, TWO
+// workgroups per compute unit (128 registers each, waves-per-SIMD bound 4) and 512 slots: 0.152-0.158 s with 1, 2 or 4 children per
+// lane -- 2 has the fewest spills (35 registers against 73-88) and the smallest LDS (40 / 72 KB); 512 lanes alone on a compute unit, no
+// spills: 0.177 s; 256 lanes: 0.178 s.  A search does not need the lanes, the chip needs the searches in flight.
 #ifndef ACX_GREEDY_MULTI_THREADS
-#define ACX_GREEDY_MULTI_THREADS 1024
+#define ACX_GREEDY_MULTI_THREADS 512
 #endif
 constexpr uint32_t kGreedyMultiThreads = ACX_GREEDY_MULTI_THREADS;
 #ifndef ACX_GREEDY_MULTI_R
-#define ACX_GREEDY_MULTI_R 4
+#define ACX_GREEDY_MULTI_R 2
 #endif
+constexpr uint32_t kGreedyResident = 512;  // workgroups of k_greedy_sched the chip holds: two on each of the 256 compute units
 template <> struct greedy_cfg<uint64_t> { static constexpr uint32_t kSortCap = ACX_GREEDY_MULTI_R * kGreedyMultiThreads; };
 template <> struct greedy_cfg<u128> { static constexpr uint32_t kSortCap = 2 * kGreedyMultiThreads; };
 
@@ -255,6 +267,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
     __shared__ uint32_t s_hist[32];
     __shared__ unsigned long long s_tph[24], s_tc;  // phase clock, kept by thread 0
     __shared__ uint32_t s_small;  // (profile) the running bucket holds <= 21 parents
+    __shared__ uint32_t s_big;    // the region of the shared sort scratch this workgroup holds
     (void)s_small;
 #if ACX_GREEDY_PROFILE
 #define ACX_TICK(k) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); s_tph[k] += now__ - s_tc; if ((k) < 8 && s_small) s_tph[16 + (k)] += now__ - s_tc; s_tc = now__; } } while (0)
@@ -535,6 +548,26 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                     // through the scratch arrays in HBM (coalesced, a few hundred KB per stage).
                     uint32_t P = SC;
                     while (P < n) P <<= 1;
+                    W* q0 = g.gk0;
+                    W* q1 = g.gk1;
+                    uint32_t* qi = g.gid;
+                    const bool borrow = g.big_lock != nullptr && P > g.scratch_cap;  // (uniform)
+                    if (borrow) {  // a full-size region of the call's shared pool: held for this one sort
+                        if (tid == 0) {
+                            uint32_t r = blockIdx.x % g.big_n;
+                            while (atomicCAS(&g.big_lock[r], 0u, 1u) != 0u) {
+                                r = r + 1 == g.big_n ? 0u : r + 1;
+                                __builtin_amdgcn_s_sleep(32);
+                            }
+                            s_big = r;
+                        }
+                        __syncthreads();
+                        __threadfence();  // (acquire: nothing of the region's last holder in this compute unit's L1)
+                        uint8_t* b = g.big_base + (size_t)s_big * g.big_stride;
+                        q0 = (W*)b;
+                        q1 = (W*)(b + g.big_key_bytes);
+                        qi = (uint32_t*)(b + 2 * g.big_key_bytes);
+                    }
                     for (uint32_t c0 = 0; c0 < P; c0 += SC) {
                         for (uint32_t i = tid; i < SC; i += kGT) {
                             const uint32_t gi = c0 + i;
@@ -550,9 +583,9 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                         }
                         lds_sort<W, kGT>(sk0, sk1, sid, SC, tid, ((c0 / SC) & 1u) != 0);
                         for (uint32_t i = tid; i < SC; i += kGT) {
-                            g.gid[c0 + i] = sid[i];
-                            g.gk0[c0 + i] = sk0[i];
-                            g.gk1[c0 + i] = sk1[i];
+                            qi[c0 + i] = sid[i];
+                            q0[c0 + i] = sk0[i];
+                            q1[c0 + i] = sk1[i];
                         }
                         __syncthreads();
                     }
@@ -561,40 +594,45 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                             for (uint32_t q = tid; q < P / 2; q += kGT) {
                                 const uint32_t i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), x = i | j;
                                 const bool asc = (i & k) == 0;
-                                const uint32_t ia = g.gid[i], ib = g.gid[x];
-                                const W a0 = g.gk0[i], a1 = g.gk1[i], b0 = g.gk0[x], b1 = g.gk1[x];
+                                const uint32_t ia = qi[i], ib = qi[x];
+                                const W a0 = q0[i], a1 = q1[i], b0 = q0[x], b1 = q1[x];
                                 bool a_after_b;
                                 if (ia == 0xFFFFFFFFu) a_after_b = ib != 0xFFFFFFFFu;
                                 else if (ib == 0xFFFFFFFFu) a_after_b = false;
                                 else a_after_b = key_less<W>(b0, b1, a0, a1);
                                 if (a_after_b == asc) {
-                                    g.gid[i] = ib;
-                                    g.gk0[i] = b0;
-                                    g.gk1[i] = b1;
-                                    g.gid[x] = ia;
-                                    g.gk0[x] = a0;
-                                    g.gk1[x] = a1;
+                                    qi[i] = ib;
+                                    q0[i] = b0;
+                                    q1[i] = b1;
+                                    qi[x] = ia;
+                                    q0[x] = a0;
+                                    q1[x] = a1;
                                 }
                             }
                             __syncthreads();
                         }
                         for (uint32_t c0 = 0; c0 < P; c0 += SC) {  // the remaining strides stay inside a chunk: in LDS
                             for (uint32_t i = tid; i < SC; i += kGT) {
-                                sid[i] = g.gid[c0 + i];
-                                sk0[i] = g.gk0[c0 + i];
-                                sk1[i] = g.gk1[c0 + i];
+                                sid[i] = qi[c0 + i];
+                                sk0[i] = q0[c0 + i];
+                                sk1[i] = q1[c0 + i];
                             }
                             __syncthreads();
                             lds_merge<W, kGT>(sk0, sk1, sid, SC, tid, (c0 & k) == 0);
                             for (uint32_t i = tid; i < SC; i += kGT) {
-                                g.gid[c0 + i] = sid[i];
-                                g.gk0[c0 + i] = sk0[i];
-                                g.gk1[c0 + i] = sk1[i];
+                                qi[c0 + i] = sid[i];
+                                q0[c0 + i] = sk0[i];
+                                q1[c0 + i] = sk1[i];
                             }
                             __syncthreads();
                         }
                     }
-                    for (uint32_t i = tid; i < n; i += kGT) g.arena[base + i] = g.gid[i];
+                    for (uint32_t i = tid; i < n; i += kGT) g.arena[base + i] = qi[i];
+                    if (borrow) {  // every access to the region is through before it is another workgroup's
+                        __threadfence();
+                        __syncthreads();
+                        if (tid == 0) atomicExch(&g.big_lock[s_big], 0u);
+                    }
                 }
                 __syncthreads();
             }
@@ -1063,6 +1101,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
         for (int k = 0; k < 24; k++) out->t_phase[k] = s_tph[k];
         for (int k = 0; k < 16; k++) out->hist_sort[k] = s_hist[k], out->hist_np[k] = s_hist[16 + k];
         out->path_n = 0;
+        out->arena_top = s_arena_top;
         if (path_act && (s_status == GREEDY_SOLVED || s_status == GREEDY_BUDGET || s_status == GREEDY_EXHAUSTED)) {
             // greedy.py:93 (success) / :121 (failure): path of a popped node + one more (action, length) entry
             const bool ok = s_status == GREEDY_SOLVED;
@@ -1103,13 +1142,12 @@ __global__ void __launch_bounds__(kGT) k_greedy_persistent(GreedyDev<W> g, Greed
     greedy_run<W, kSingleSortCap<W>, (uint32_t)kGT, NF>(g, out, nullptr, nullptr, 0);
 }
 
-// ---- many searches on a FIXED number of workgroups (round 4) -----------------------------------------------------------------------
-// Rounds 2-3 gave every search of a launch its own workgroup and its own memory (k_greedy_multi): a launch was as many searches as fit
-// the memory budget (46 at 1e6 nodes), a batch of 170 four launches one after the other, and every launch waited for its slowest
-// search while the compute units of the finished ones stood idle (5.5e10 workgroup cycles = 103 ms x 256 compute units in a 400 ms
-// sweep).  Here a launch is a fixed set of SLOTS -- a workgroup
-// with the memory of one search -- and the searches are JOBS the workgroups take from a counter, one after the other: a slot is
-// cleaned between two jobs by the workgroup itself (the visited table, the rows of the bucket table the last job can have
+// ---- many searches as jobs on persistent workgroups (round 4; the slots a pool since round 5) ------------------------------------------
+// Rounds 2-3 gave every search of a launch its own workgroup and its own memory: a launch was as many searches as fit the memory
+// budget (46 at 1e6 nodes), a batch of 170 four launches one after the other, and every launch waited for its slowest search while
+// the compute units of the finished ones stood idle (5.5e10 workgroup cycles = 103 ms x 256 compute units in a 400 ms sweep).  Here
+// the searches are JOBS that persistent workgroups take from a counter, one after the other, and a SLOT is the memory of one search:
+// it is cleaned between two jobs by the workgroup itself (the visited table, the rows of the bucket table the last job can have
 // touched).  Searches of different max_relator_length share a launch (a job carries its L), so a whole sweep is one launch per
 // key width and move code.
 template <typename W> struct GreedyJob {
@@ -1118,39 +1156,68 @@ template <typename W> struct GreedyJob {
     int32_t L, pad_;
 };
 #ifndef ACX_GREEDY_MULTI_WAVES_PER_EU
-#define ACX_GREEDY_MULTI_WAVES_PER_EU 1  // the second launch bound: waves per SIMD the register allocation must leave room for.  Round 5 measured
-// the sweep with TWO searches per compute unit (-DACX_GREEDY_MULTI_THREADS=512 -DACX_GREEDY_MULTI_R=2 -DACX_GREEDY_MULTI_WAVES_PER_EU=4, 512 slots):
-// 0.152-0.158 s against 0.172-0.176 s -- and twice the slots' memory (106 GB; a cold call 3.5 s instead of 0.9 s), so not the default
+#define ACX_GREEDY_MULTI_WAVES_PER_EU 4  // the second launch bound: waves per SIMD the register allocation leaves room for -- two 512-lane workgroups per compute unit
 #endif
+
+// A slot as the host set it up: visited table free, bucket records and bitmap zero.  Only rows 0 .. hi + 2 of the first `nlen` lengths
+// can be anything else after a search whose deepest node was at depth hi.
+template <typename W> __device__ __forceinline__ void greedy_slot_clean(const GreedyDev<W>& g, uint32_t hi, uint32_t nlen, uint32_t tid) {
+    ulonglong2* t2 = (ulonglong2*)g.tab;
+    const uint32_t n2 = (g.tmask + 1u) / 2u;
+    for (uint32_t i = tid; i < n2; i += kGreedyMultiThreads) t2[i] = make_ulonglong2(kTabEmpty, kTabEmpty);
+    const uint32_t rows = min(hi + 3u, kDepthCap), words = (rows + 31u) / 32u;
+    for (uint32_t l = 0; l < nlen; l++) {
+        uint4* r4 = (uint4*)(g.bk + (size_t)l * kDepthCap);  // a record is two uint4
+        for (uint32_t i = tid; i < 2u * rows; i += kGreedyMultiThreads) r4[i] = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = tid; i < words; i += kGreedyMultiThreads) g.bitmap[(size_t)l * (kDepthCap / 32) + i] = 0;
+    }
+}
+
+// `slot_free`: one bit per slot of the call, set = free.  The slots are a POOL (round 5): a workgroup takes one when it gets its first
+// job, keeps it for the jobs that follow (cleaning it in between) and hands it back CLEAN when the jobs are used up -- so the launches
+// of the two key widths (their GreedyDev arrays describe the same memory) need no shares fixed beforehand: both are launched with as
+// many workgroups as they have jobs, the chip holds 512 of them, and whichever launch runs out of jobs first leaves its compute units
+// -- and its slots -- to the waiting workgroups of the other.
 template <typename W, bool NF>
-__global__ void __launch_bounds__(kGreedyMultiThreads, ACX_GREEDY_MULTI_WAVES_PER_EU) k_greedy_sched(const GreedyDev<W>* __restrict__ slots, const GreedyJob<W>* __restrict__ jobs, uint32_t n_jobs,
+__global__ void __launch_bounds__(kGreedyMultiThreads, ACX_GREEDY_MULTI_WAVES_PER_EU) k_greedy_sched(const GreedyDev<W>* __restrict__ slots, uint32_t* __restrict__ slot_free, uint32_t slot_words,
+                                                      const GreedyJob<W>* __restrict__ jobs, uint32_t n_jobs,
                                                       uint32_t* __restrict__ counter, GreedyOut* __restrict__ outs, int32_t* __restrict__ path_act,
                                                       int32_t* __restrict__ path_len, long long path_cap) {
-    __shared__ uint32_t s_job;
+    __shared__ uint32_t s_job, s_slot;
     const uint32_t tid = threadIdx.x;
-    uint32_t used = 0, prev_hi = 0, prev_nlen = 0;
+    uint32_t slot = 0xFFFFFFFFu, used = 0, prev_hi = 0, prev_nlen = 0;
     for (;;) {
         __syncthreads();
         if (tid == 0) s_job = atomicAdd(counter, 1u);
         __syncthreads();
         const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_job);  // (uniform: the slot and the job arrive through scalar loads)
         if (j >= n_jobs) break;
-        GreedyDev<W> g = slots[blockIdx.x];
+        if (slot == 0xFFFFFFFFu) {  // the first job of this workgroup: a slot of the pool
+            if (tid == 0) {
+                uint32_t w = blockIdx.x % slot_words;
+                for (;;) {
+                    const uint32_t bits = atomicOr(&slot_free[w], 0u);
+                    if (bits) {
+                        const uint32_t b = 1u << (uint32_t)__builtin_ctz(bits);
+                        if (atomicAnd(&slot_free[w], ~b) & b) {
+                            s_slot = w * 32u + (uint32_t)__builtin_ctz(bits);
+                            break;
+                        }
+                    } else {
+                        w = w + 1 == slot_words ? 0u : w + 1;
+                        if (w == blockIdx.x % slot_words) __builtin_amdgcn_s_sleep(64);  // (once around without a free slot: more workgroups resident than slots)
+                    }
+                }
+            }
+            __syncthreads();
+            slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot);
+        }
+        GreedyDev<W> g = slots[slot];
         const uint32_t nlen_cap = g.nlen;  // the slot's bucket table has rows for this many total lengths
         const GreedyJob<W> jb = jobs[j];
-        if (used) {  // the slot as the host set it up: table free, bucket records and bitmap zero (only rows 0 .. depth_hi + 2 can be anything else)
-            ulonglong2* t2 = (ulonglong2*)g.tab;
-            const uint32_t n2 = (g.tmask + 1u) / 2u;
-            for (uint32_t i = tid; i < n2; i += kGreedyMultiThreads) t2[i] = make_ulonglong2(kTabEmpty, kTabEmpty);
-            const uint32_t rows = min(prev_hi + 3u, kDepthCap), words = (rows + 31u) / 32u;
-            for (uint32_t l = 0; l < prev_nlen; l++) {
-                uint4* r4 = (uint4*)(g.bk + (size_t)l * kDepthCap);  // a record is two uint4
-                for (uint32_t i = tid; i < 2u * rows; i += kGreedyMultiThreads) r4[i] = make_uint4(0, 0, 0, 0);
-                for (uint32_t i = tid; i < words; i += kGreedyMultiThreads) g.bitmap[(size_t)l * (kDepthCap / 32) + i] = 0;
-            }
-        }
-        // the vector L1 may hold lines of the slot as the LAST job left them (a kernel starts with an empty L1, a job does not): an
-        // agent-scope fence writes the clean-up through and invalidates them
+        if (used) greedy_slot_clean<W>(g, prev_hi, prev_nlen, tid);
+        // the vector L1 may hold lines of the slot as its LAST job left them (a kernel starts with an empty L1, a job does not -- and the slot's
+        // last user may have been a workgroup on another compute unit): an agent-scope fence writes the clean-up through and invalidates them
         __threadfence();
         g.root_k0 = jb.root_k0;
         g.root_k1 = jb.root_k1;
@@ -1162,6 +1229,13 @@ __global__ void __launch_bounds__(kGreedyMultiThreads, ACX_GREEDY_MULTI_WAVES_PE
         used = 1;
         prev_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
         prev_nlen = g.nlen;
+    }
+    if (slot != 0xFFFFFFFFu) {  // back into the pool, clean
+        const GreedyDev<W> g = slots[slot];
+        if (used) greedy_slot_clean<W>(g, prev_hi, prev_nlen, tid);
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) atomicOr(&slot_free[slot >> 5], 1u << (slot & 31u));
     }
 }
 

@@ -22,37 +22,162 @@ struct SearchGroupIn {
     int64_t out0;
 };
 static uint32_t greedy_slots_wanted() {
-    // one workgroup of this kernel per compute unit (its 1024 lanes take the whole register file); ACX_OPT_GREEDY_SLOTS: the tests run
-    // many jobs on a few slots
-    return (uint32_t)std::min<int64_t>(std::max<int64_t>(option(ACX_OPT_GREEDY_SLOTS, 256), 1), 4096);
+    // two workgroups of this kernel per compute unit (512 lanes, 128 registers each); ACX_OPT_GREEDY_SLOTS: the tests run many jobs on a few slots
+    return (uint32_t)std::min<int64_t>(std::max<int64_t>(option(ACX_OPT_GREEDY_SLOTS, kGreedyResident), 1), 4096);
 }
+
+// The SLOTS of a call -- the memory of one greedy search each (visited table, bucket table / bitmap / arena, node arrays, a small sort
+// scratch) -- in ONE layout for every key width of the call (the arrays of 64-bit keys use the front of what 128-bit keys would), a
+// free bitmap on the device (k_greedy_sched: a workgroup takes a slot with its first job and hands it back clean), and a few
+// full-size sort scratch regions shared by all slots (acx_greedy.h: GreedyDev::big_lock).  Blocks of <= 6 GB: the block pool keeps them.
+struct GreedySlots {
+    uint32_t S = 0, per_group = 0, nlen_max = 0, big_n = 0, words = 0;
+    uint64_t n_tab = 0, cap_nodes = 0, arena_entries = 0, scratch_cap = 0, sort_cap = 0, key_bytes = 0;
+    uint64_t b_tab = 0, b_bk = 0, b_bm = 0, b_arena = 0, b_key = 0, b_u32 = 0, b_u8 = 0, b_gk = 0, b_gid = 0, per_rest = 0, per_slot = 0;
+    uint64_t big_key_bytes = 0, big_stride = 0;
+    std::vector<DevBuf> groups;
+    std::vector<uint8_t> was_clean;  // per group: the block came from the pool with this layout's tag (no fills needed)
+    DevBuf free_bits, big, big_lock;
+    static uint64_t up(uint64_t b) { return (b + 255) / 256 * 256; }
+    // names the layout of a group of m slots: a block that carries it holds m slots of exactly these arrays, all clean
+    uint64_t layout_tag(uint64_t m) const {
+        uint64_t h = 0x9E3779B97F4A7C15ull;
+        for (uint64_t v : {m, b_tab, b_bk, b_bm, per_rest, (uint64_t)nlen_max}) h = (h ^ v) * 0xD6E8FEB86659FD93ull, h ^= h >> 32;
+        return h | 1;
+    }
+    // every kernel of the call has ended well: every workgroup has handed its slot back clean, the blocks may say so in the pool
+    void mark_clean() {
+        for (uint32_t q = 0; q < groups.size(); q++) groups[q].clean_tag = layout_tag(std::min<uint32_t>(per_group, S - q * per_group));
+    }
+
+    // `n_jobs` searches of at most `max_nodes` nodes, max_relator_length <= L_max, `wide`: some of them with 128-bit keys.  Everything is
+    // set up on `st` (tables free, bucket tables zero, every slot free); the caller synchronises `st` before it launches.
+    int setup(int64_t n_jobs, int64_t max_nodes, int L_max, bool wide, uint32_t slots_wanted, hipStream_t st) {
+        key_bytes = wide ? 16 : 8;
+        cap_nodes = (uint64_t)max_nodes + 64 + 12 * 1024;
+        n_tab = 1024;
+        while (n_tab < 2 * (cap_nodes + 12288)) n_tab <<= 1;
+        if (n_tab > (1ull << 31)) return fail(ACX_E_INVAL, "acx_search_many: budget too large for 32-bit node ids");
+        nlen_max = (uint32_t)(2 * L_max + 1);
+        arena_entries = std::min<uint64_t>(8ull * (uint64_t)std::max<int64_t>(max_nodes, 1) + (1ull << 20), 1ull << 31);
+        sort_cap = 2 * ((uint64_t)std::max<int64_t>(max_nodes, 1) + 64) + 4096;
+        scratch_cap = std::min<uint64_t>(sort_cap, (uint64_t)std::max<int64_t>(option(ACX_OPT_GREEDY_SCRATCH, 1 << 16), 2048));
+        b_tab = up(n_tab * 8), b_bk = up((uint64_t)nlen_max * kDepthCap * sizeof(BucketRec)), b_bm = up((uint64_t)nlen_max * (kDepthCap / 32) * 4);
+        b_arena = up(arena_entries * 4), b_key = up(cap_nodes * 2 * key_bytes), b_u32 = up(cap_nodes * 4), b_u8 = up(cap_nodes);
+        b_gk = up(scratch_cap * key_bytes), b_gid = up(scratch_cap * 4);
+        per_rest = b_arena + b_key + 2 * b_u32 + 2 * b_u8 + 2 * b_gk + b_gid;
+        per_slot = b_tab + b_bk + b_bm + per_rest;
+        size_t free_b = 0, total_b = 0;
+        double avail = 64e9;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) avail = (double)free_b + (double)block_pool().cached_on(BlockPool::current_device());
+        const double budget = std::max(2.0 * (double)per_slot, std::min(112e9, avail * 0.4));
+        S = (uint32_t)std::max<double>(1.0, std::min<double>(std::min<double>((double)std::max<int64_t>(n_jobs, 1), (double)std::max<uint32_t>(slots_wanted, 1u)), budget / (double)per_slot));
+        for (;;) {
+            per_group = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(S, (6ull << 30) / per_slot));
+            const uint32_t n_groups = (S + per_group - 1) / per_group;
+            groups.clear();
+            groups.resize(n_groups);
+            bool ok = true;
+            was_clean.assign(n_groups, 0);
+            for (uint32_t q = 0; q < n_groups && ok; q++) {
+                uint64_t tag = layout_tag(std::min<uint32_t>(per_group, S - q * per_group));
+                ok = groups[q].alloc((uint64_t)std::min<uint32_t>(per_group, S - q * per_group) * per_slot, &tag) == ACX_OK;
+                was_clean[q] = tag != 0;
+            }
+            if (ok) break;
+            (void)hipGetLastError();  // (the estimate of the free memory was too good: fewer slots -- the jobs just take longer)
+            groups.clear();
+            if (S == 1) return ACX_E_NOMEM;
+            S = (S + 1) / 2;
+        }
+        for (uint32_t q = 0; q * per_group < S; q++) {
+            const uint64_t m = std::min<uint32_t>(per_group, S - q * per_group);
+            uint8_t* base = (uint8_t*)groups[q].p;
+            if (was_clean[q]) continue;  // the block comes back from the pool as the last call's workgroups left it: every slot clean
+            ACX_HIP_TRY(hipMemsetAsync(base, 0xff, m * b_tab, st));
+            ACX_HIP_TRY(hipMemsetAsync(base + m * b_tab, 0, m * (b_bk + b_bm), st));
+        }
+        words = (S + 31) / 32;
+        std::vector<uint32_t> bits(words, 0);
+        for (uint32_t r = 0; r < S; r++) bits[r >> 5] |= 1u << (r & 31);
+        if (free_bits.alloc((size_t)words * 4)) return ACX_E_NOMEM;
+        ACX_HIP_TRY(hipMemcpyAsync(free_bits.p, bits.data(), (size_t)words * 4, hipMemcpyHostToDevice, st));
+        ACX_HIP_TRY(hipStreamSynchronize(st));  // (`bits` is a pageable host buffer of this scope)
+        big_n = 0;
+        if (sort_cap > scratch_cap) {  // buckets of more than half the slot's scratch: a few full-size regions for all slots
+            big_key_bytes = up(sort_cap * key_bytes);
+            big_stride = 2 * big_key_bytes + up(sort_cap * 4);
+            big_n = std::min<uint32_t>(std::max<uint32_t>(S / 16, 2), 16);
+            while (big_n > 1 && big.alloc((uint64_t)big_n * big_stride)) {
+                (void)hipGetLastError();
+                big_n /= 2;
+            }
+            if (!big.p && big.alloc((uint64_t)big_n * big_stride)) return ACX_E_NOMEM;
+            if (big_lock.alloc(256)) return ACX_E_NOMEM;
+            ACX_HIP_TRY(hipMemsetAsync(big_lock.p, 0, 256, st));
+        }
+        return ACX_OK;
+    }
+    template <typename W> void describe(std::vector<GreedyDev<W>>& out, int cyclical, int64_t max_nodes) const {
+        out.resize(S);
+        for (uint32_t r = 0; r < S; r++) {
+            GreedyDev<W>& g = out[r];
+            memset(&g, 0, sizeof(g));
+            const uint32_t q = r / per_group, k = r % per_group;
+            const uint64_t m = std::min<uint32_t>(per_group, S - q * per_group);
+            uint8_t* base = (uint8_t*)groups[q].p;
+            g.tab = (unsigned long long*)(base + k * b_tab);
+            g.tmask = (uint32_t)(n_tab - 1);
+            g.bk = (BucketRec*)(base + m * b_tab + k * b_bk);
+            g.bitmap = (uint32_t*)(base + m * (b_tab + b_bk) + k * b_bm);
+            uint8_t* x = base + m * (b_tab + b_bk + b_bm) + k * per_rest;
+            auto take = [&](uint64_t bytes) {
+                uint8_t* y = x;
+                x += bytes;
+                return y;
+            };
+            g.arena = (uint32_t*)take(b_arena);
+            g.nkeys = (NodeKey<W>*)take(b_key);
+            g.d.parent = (uint32_t*)take(b_u32);
+            g.d.depth = (uint32_t*)take(b_u32);
+            g.d.act = take(b_u8);
+            g.d.tlen = take(b_u8);
+            g.gk0 = (W*)take(b_gk);
+            g.gk1 = (W*)take(b_gk);
+            g.gid = (uint32_t*)take(b_gid);
+            g.d.cyclical = cyclical;
+            g.arena_cap = (uint32_t)arena_entries;
+            g.nlen = nlen_max;  // (rows of the slot's bucket table; a job runs with its own 2 L + 1)
+            g.max_nodes = (long long)max_nodes;
+            g.scratch_cap = (uint32_t)scratch_cap;
+            if (big_n) {
+                g.big_n = big_n;
+                g.big_lock = (uint32_t*)big_lock.p;
+                g.big_base = (uint8_t*)big.p;
+                g.big_key_bytes = big_key_bytes;
+                g.big_stride = big_stride;
+            }
+        }
+    }
+};
+
+// The jobs of one key width on `n_wgs` workgroups over the call's slots.
 template <typename W>
-static int run_greedy_sched(const std::vector<SearchGroupIn>& groups, int64_t max_nodes, int cyclical, int32_t* solved, int32_t* path_action, int32_t* path_len,
-                            int64_t path_cap, int64_t* path_n, acx_search_stats* stats, int32_t* rc_out, uint8_t* need_rerun, uint32_t slots_cap) {
+static int run_greedy_sched(const GreedySlots& pool, const std::vector<SearchGroupIn>& groups, int64_t max_nodes, int cyclical, int32_t* solved, int32_t* path_action,
+                            int32_t* path_len, int64_t path_cap, int64_t* path_n, acx_search_stats* stats, int32_t* rc_out, uint8_t* need_rerun, uint32_t n_wgs,
+                            std::atomic<int>* launched = nullptr, std::atomic<int>* wait_for = nullptr) {
+    // `launched` is set once this width's first kernel is in its queue (or the function returns), `wait_for`: that flag of the other width
+    struct Signal {
+        std::atomic<int>* f;
+        ~Signal() {
+            if (f) f->store(1);
+        }
+    } signal{launched};
     int64_t n_all = 0;
-    int L_max = 1;
-    for (const auto& gr : groups) n_all += gr.n, L_max = std::max(L_max, gr.L);
+    for (const auto& gr : groups) n_all += gr.n;
     if (n_all == 0) return ACX_OK;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-    // a slot: the node arrays, the id table, the bucket table / bitmap / arena and the sort scratch of ONE search (as run_greedy_group lays them out)
-    const uint64_t cap_nodes = (uint64_t)max_nodes + 64 + 12 * 1024;
-    uint64_t n_slots = 1024;
-    while (n_slots < 2 * (cap_nodes + 12288)) n_slots <<= 1;
-    if (n_slots > (1ull << 31)) return fail(ACX_E_INVAL, "acx_search_many: budget too large for 32-bit node ids");
-    const uint32_t nlen_max = (uint32_t)(2 * L_max + 1);
-    const uint64_t arena_entries = std::min<uint64_t>(8ull * (uint64_t)std::max<int64_t>(max_nodes, 1) + (1ull << 20), 1ull << 31);
-    const uint64_t sort_cap = 2 * ((uint64_t)std::max<int64_t>(max_nodes, 1) + 64) + 4096;
-    auto up = [](uint64_t b) { return (b + 255) / 256 * 256; };
-    const uint64_t b_slots = up(n_slots * 8), b_bk = up((uint64_t)nlen_max * kDepthCap * sizeof(BucketRec)), b_bm = up((uint64_t)nlen_max * (kDepthCap / 32) * 4);
-    const uint64_t b_arena = up(arena_entries * 4), b_key = up(cap_nodes * sizeof(NodeKey<W>)), b_u32 = up(cap_nodes * 4), b_u8 = up(cap_nodes);
-    const uint64_t b_gk = up(sort_cap * sizeof(W)), b_gid = up(sort_cap * 4);
-    const uint64_t per_rest = b_arena + b_key + 2 * b_u32 + 2 * b_u8 + 2 * b_gk + b_gid;
-    const uint64_t per_slot = b_slots + b_bk + b_bm + per_rest;
-    size_t free_b = 0, total_b = 0;
-    double avail = 64e9;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) avail = (double)free_b + (double)block_pool().cached_on(BlockPool::current_device());
-    const double budget = std::max(2.0 * (double)per_slot, std::min(64e9, avail / 5.0));
     // the jobs, by move code: a root in normal form keeps its search in normal form (the shorter move code); one launch per code
     std::vector<GreedyJob<W>> jobs[2];
     std::vector<int64_t> where[2];  // job -> index in the output arrays
@@ -97,45 +222,10 @@ static int run_greedy_sched(const std::vector<SearchGroupIn>& groups, int64_t ma
         where[code].swap(ws);
     }
     const uint32_t n_most = (uint32_t)std::max(jobs[0].size(), jobs[1].size());
-    uint32_t R = (uint32_t)std::max<double>(1.0, std::min<double>(std::min<uint32_t>(n_most, std::max<uint32_t>(slots_cap, 1u)), budget / (double)per_slot));
-    DevBuf big, dslots, djobs, dcounter, douts, dpa, dpl;
-    while (big.alloc((uint64_t)R * per_slot)) {  // (the estimate of the free memory was too good: fewer slots -- the jobs just take longer)
-        if (R == 1) return ACX_E_NOMEM;
-        (void)hipGetLastError();  // (the failed hipMalloc's error must not meet the launch check below)
-        R = (R + 1) / 2;
-    }
-    uint8_t* p_slots = (uint8_t*)big.p;
-    uint8_t* p_bk = p_slots + (uint64_t)R * b_slots;
-    uint8_t* p_bm = p_bk + (uint64_t)R * b_bk;
-    uint8_t* p_rest = p_bm + (uint64_t)R * b_bm;
-    std::vector<GreedyDev<W>> hslots((size_t)R);
-    for (uint32_t r = 0; r < R; r++) {
-        GreedyDev<W>& g = hslots[r];
-        memset(&g, 0, sizeof(g));
-        uint8_t* q = p_rest + (uint64_t)r * per_rest;
-        auto take = [&](uint64_t bytes) {
-            uint8_t* x = q;
-            q += bytes;
-            return x;
-        };
-        g.tab = (unsigned long long*)(p_slots + (uint64_t)r * b_slots);
-        g.tmask = (uint32_t)(n_slots - 1);
-        g.bk = (BucketRec*)(p_bk + (uint64_t)r * b_bk);
-        g.bitmap = (uint32_t*)(p_bm + (uint64_t)r * b_bm);
-        g.arena = (uint32_t*)take(b_arena);
-        g.nkeys = (NodeKey<W>*)take(b_key);
-        g.d.parent = (uint32_t*)take(b_u32);
-        g.d.depth = (uint32_t*)take(b_u32);
-        g.d.act = take(b_u8);
-        g.d.tlen = take(b_u8);
-        g.gk0 = (W*)take(b_gk);
-        g.gk1 = (W*)take(b_gk);
-        g.gid = (uint32_t*)take(b_gid);
-        g.d.cyclical = cyclical;
-        g.arena_cap = (uint32_t)arena_entries;
-        g.nlen = nlen_max;  // (rows of the slot's bucket table; a job runs with its own 2 L + 1)
-        g.max_nodes = (long long)max_nodes;
-    }
+    const uint32_t R = pool.S;
+    std::vector<GreedyDev<W>> hslots;
+    pool.describe<W>(hslots, cyclical, max_nodes);
+    DevBuf dslots, djobs, dcounter, douts, dpa, dpl;
     hipStream_t st = nullptr;
     {  // the 128-bit searches are the longer ones: when both widths are in flight their workgroups get a free compute unit first
         int lo = 0, hi = 0;
@@ -159,22 +249,26 @@ static int run_greedy_sched(const std::vector<SearchGroupIn>& groups, int64_t ma
         const size_t nj = jobs[code].size();
         if (!nj) continue;
         for (uint32_t r = 0; r < R; r++) hslots[r].nf = (uint32_t)code;
-        // the slots as a search expects them: table free, bucket records and bitmaps zero (between two jobs the workgroup does it itself)
-        ACX_HIP_TRY(hipMemsetAsync(p_slots, 0xff, (uint64_t)R * b_slots, st));
-        ACX_HIP_TRY(hipMemsetAsync(p_bk, 0, (uint64_t)R * (b_bk + b_bm), st));
+        // (the slots are as a search expects them -- table free, bucket records and bitmaps zero: GreedySlots::setup, and every workgroup
+        // hands its slot back that way)
         ACX_HIP_TRY(hipMemcpyAsync(dslots.p, hslots.data(), (size_t)R * sizeof(GreedyDev<W>), hipMemcpyHostToDevice, st));
         ACX_HIP_TRY(hipMemcpyAsync(djobs.p, jobs[code].data(), nj * sizeof(GreedyJob<W>), hipMemcpyHostToDevice, st));
         ACX_HIP_TRY(hipMemsetAsync(dcounter.p, 0, 256, st));
         ACX_HIP_TRY(hipMemsetAsync(douts.p, 0, nj * sizeof(GreedyOut), st));
         ACX_HIP_TRY(hipEventRecord(evs.a, st));
-        const unsigned grid = (unsigned)std::min<size_t>(R, nj);
+        const unsigned grid = (unsigned)std::min<size_t>(std::max<uint32_t>(n_wgs, 1u), nj);
+        if (wait_for) {
+            while (!wait_for->load()) std::this_thread::yield();
+            wait_for = nullptr;
+        }
         if (code)
-            hipLaunchKernelGGL((k_greedy_sched<W, true>), dim3(grid), dim3(kGreedyMultiThreads), 0, st, (const GreedyDev<W>*)dslots.p, (const GreedyJob<W>*)djobs.p, (uint32_t)nj,
-                               (uint32_t*)dcounter.p, (GreedyOut*)douts.p, (int32_t*)dpa.p, (int32_t*)dpl.p, (long long)pc);
+            hipLaunchKernelGGL((k_greedy_sched<W, true>), dim3(grid), dim3(kGreedyMultiThreads), 0, st, (const GreedyDev<W>*)dslots.p, (uint32_t*)pool.free_bits.p, pool.words,
+                               (const GreedyJob<W>*)djobs.p, (uint32_t)nj, (uint32_t*)dcounter.p, (GreedyOut*)douts.p, (int32_t*)dpa.p, (int32_t*)dpl.p, (long long)pc);
         else
-            hipLaunchKernelGGL((k_greedy_sched<W, false>), dim3(grid), dim3(kGreedyMultiThreads), 0, st, (const GreedyDev<W>*)dslots.p, (const GreedyJob<W>*)djobs.p, (uint32_t)nj,
-                               (uint32_t*)dcounter.p, (GreedyOut*)douts.p, (int32_t*)dpa.p, (int32_t*)dpl.p, (long long)pc);
+            hipLaunchKernelGGL((k_greedy_sched<W, false>), dim3(grid), dim3(kGreedyMultiThreads), 0, st, (const GreedyDev<W>*)dslots.p, (uint32_t*)pool.free_bits.p, pool.words,
+                               (const GreedyJob<W>*)djobs.p, (uint32_t)nj, (uint32_t*)dcounter.p, (GreedyOut*)douts.p, (int32_t*)dpa.p, (int32_t*)dpl.p, (long long)pc);
         ACX_HIP_TRY(hipGetLastError());
+        if (launched) launched->store(1);
         ACX_HIP_TRY(hipEventRecord(evs.b, st));
         const double t_launched = since();
         std::vector<GreedyOut> o(nj);
@@ -194,6 +288,17 @@ static int run_greedy_sched(const std::vector<SearchGroupIn>& groups, int64_t ma
                 bigs += o[j].big_sorts;
             }
             for (int q = 0; q < 8; q++) tot += tp[q];
+            {
+                unsigned long long hs[16] = {}, top = 0;
+                for (size_t j = 0; j < nj; j++) {
+                    for (int q = 0; q < 16; q++) hs[q] += o[j].hist_sort[q];
+                    top = std::max<unsigned long long>(top, o[j].arena_top);
+                }
+                fprintf(stderr, "[acx_greedy_sched] sorts by log2(n):");
+                for (int q = 0; q < 16; q++) fprintf(stderr, " %llu", hs[q]);
+                fprintf(stderr, "; a slot's own scratch holds %llu entries, %u shared regions; largest bucket arena in use %llu of %llu entries\n", (unsigned long long)pool.scratch_cap, pool.big_n, top,
+                        (unsigned long long)pool.arena_entries);
+            }
             {  // the longest searches of the launch (their share of the launch's cycles decides how well any order can pack them)
                 std::vector<unsigned long long> cyc(nj, 0);
                 for (size_t j = 0; j < nj; j++)
@@ -226,7 +331,7 @@ static int run_greedy_sched(const std::vector<SearchGroupIn>& groups, int64_t ma
                     fprintf(stderr, "[acx_greedy_sched] job cycles: longest %.3e, median %.3e, p90 %.3e; searches longer than half the longest: first at job %zu, last at job %zu of %zu\n",
                             (double)sorted_c[nj - 1], (double)sorted_c[nj / 2], (double)sorted_c[nj * 9 / 10], first_long, last_long, nj);
             }
-            fprintf(stderr, "[acx_greedy_sched] %zu searches on %u slots (%s move code), %llu batches, %llu sorts (%llu of buckets larger than the LDS), launch %.2f ms; host: launched at %.1f ms, results at %.1f ms\n", nj, grid,
+            fprintf(stderr, "[acx_greedy_sched] %zu searches on %u workgroups (%s move code), %llu batches, %llu sorts (%llu of buckets larger than the LDS), launch %.2f ms; host: launched at %.1f ms, results at %.1f ms\n", nj, grid,
                     code ? "normal-form" : "general", batches, sorts, bigs, ms, t_launched, since());
             if (tot)
                 fprintf(stderr, "[acx_greedy_sched] %.3e workgroup cycles; cycles%%: select %.1f sort %.1f expand %.1f probe %.1f scan %.1f commit %.1f file %.1f tail %.1f; %.1f%% in sorts of buckets > LDS, %.1f%% in 256 < n <= LDS\n",
@@ -541,14 +646,43 @@ extern "C" int acx_search_groups(int kind, int n_groups, const int8_t* const* h_
         return ACX_OK;
     }
     // greedy_search: ALL batches as jobs of one launch per key width (64-bit keys up to max_relator_length 29, 128-bit above), the two
-    // launches side by side
+    // launches side by side over ONE pool of slots
     std::vector<SearchGroupIn> narrow, wide;
+    int L_max = 1;
     for (int g = 0; g < n_groups; g++)
-        if (n[g]) (L[g] <= 29 ? narrow : wide).push_back(SearchGroupIn{h_presentations[g], n[g], L[g], out0[(size_t)g]});
+        if (n[g]) (L[g] <= 29 ? narrow : wide).push_back(SearchGroupIn{h_presentations[g], n[g], L[g], out0[(size_t)g]}), L_max = std::max(L_max, (int)L[g]);
     const int64_t n_all = out0[(size_t)n_groups];
+    if (n_all == 0) return ACX_OK;
     std::vector<uint8_t> rerun((size_t)n_all, 0);
     int dev = 0;
     (void)hipGetDevice(&dev);
+    int64_t n_narrow = 0, n_wide = 0;
+    for (const auto& gr : narrow) n_narrow += gr.n;
+    for (const auto& gr : wide) n_wide += gr.n;
+    GreedySlots pool;
+    {
+        hipStream_t st0 = nullptr;
+        ACX_HIP_TRY(hipStreamCreateWithFlags(&st0, hipStreamNonBlocking));
+        int rc0 = pool.setup(n_all, max_nodes, L_max, !wide.empty(), greedy_slots_wanted(), st0);
+        if (rc0 == ACX_OK && hipStreamSynchronize(st0) != hipSuccess) rc0 = fail(ACX_E_NODEVICE, "acx_search_groups: setting up the slots failed");
+        (void)hipStreamDestroy(st0);
+        if (rc0 != ACX_OK) return rc0;
+    }
+    // Workgroups per launch.  With a slot for every workgroup the chip can hold (two per compute unit) both launches get as many
+    // workgroups as they have jobs: those beyond the chip's capacity wait in the dispatcher, and whichever launch runs out of jobs first
+    // leaves its compute units (and slots) to the other -- no shares to guess.  With fewer slots (the tests' option, little free
+    // memory) a waiting workgroup would hold a compute unit while it spins for a slot, so the slots are shared out in proportion to
+    // the expected work: a 128-bit search costs ~1.7 x a 64-bit one (measured on the Miller-Schupp sweep).
+    uint32_t wgs_wide = pool.S, wgs_narrow = pool.S;
+    if (n_narrow && n_wide && pool.S < kGreedyResident) {
+        const double share = 1.7 * (double)n_wide / (1.7 * (double)n_wide + (double)n_narrow);
+        wgs_wide = (uint32_t)std::min<double>(std::max<double>(1.0, share * pool.S + 0.5), std::max<double>(1.0, (double)pool.S - 1.0));
+        wgs_narrow = std::max<uint32_t>(1u, pool.S - wgs_wide);
+    }
+    // The 128-bit launch goes first (and its stream has the higher priority): its searches are the uniformly long ones (nine in ten of the
+    // Miller-Schupp sweep's stay unsolved), so they should all be on the chip from the start; the 64-bit launch, with its many short
+    // searches, fills in as compute units come free.  Measured: 0.149 s this way round, 0.158-0.161 s the other.
+    std::atomic<int> wide_launched{0};
     int rc_wide = ACX_OK;
     std::string err_wide;
     struct Joined {  // (whatever leaves this function first -- an exception of a host allocation included -- the side thread is joined)
@@ -558,30 +692,19 @@ extern "C" int acx_search_groups(int kind, int n_groups, const int8_t* const* h_
         }
     } side_guard;
     std::thread& side = side_guard.t;
-    // Both widths in flight: the slots are SHARED OUT -- a workgroup of this kernel fills a compute unit and stays until the launch's
-    // jobs are used up, so whatever is launched beyond the chip's 256 compute units (the fills of the other launch's tables included)
-    // waits for one of them to end.  In proportion to the expected work: a 128-bit search costs ~1.7 x a 64-bit one (measured on the
-    // Miller-Schupp sweep: 7.0e7 against 4.2e7 workgroup cycles).
-    const uint32_t total = greedy_slots_wanted();
-    int64_t n_narrow = 0, n_wide = 0;
-    for (const auto& gr : narrow) n_narrow += gr.n;
-    for (const auto& gr : wide) n_wide += gr.n;
-    uint32_t slots_wide = total, slots_narrow = total;
-    if (n_narrow && n_wide) {
-        const double share = 1.7 * (double)n_wide / (1.7 * (double)n_wide + (double)n_narrow);
-        slots_wide = (uint32_t)std::min<double>(std::max<double>(1.0, share * total + 0.5), (double)total - 1.0);
-        slots_narrow = total - slots_wide;
-    }
     if (!wide.empty() && !narrow.empty())
         side = std::thread([&]() {
             (void)hipSetDevice(dev);
-            rc_wide = run_greedy_sched<u128>(wide, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), slots_wide);
+            rc_wide = run_greedy_sched<u128>(pool, wide, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), wgs_wide, &wide_launched);
             if (rc_wide != ACX_OK) err_wide = acx_last_error();
         });
     int rc = ACX_OK;
-    if (!narrow.empty()) rc = run_greedy_sched<uint64_t>(narrow, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), slots_narrow);
+    if (!narrow.empty())
+        rc = run_greedy_sched<uint64_t>(pool, narrow, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), wgs_narrow, nullptr,
+                                        side.joinable() ? &wide_launched : nullptr);
     if (side.joinable()) side.join();
-    else if (!wide.empty()) rc_wide = run_greedy_sched<u128>(wide, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), slots_wide);
+    else if (!wide.empty()) rc_wide = run_greedy_sched<u128>(pool, wide, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), wgs_wide);
+    if (rc == ACX_OK && rc_wide == ACX_OK) pool.mark_clean();
     if (rc != ACX_OK) return rc;
     if (rc_wide != ACX_OK) return err_wide.empty() ? rc_wide : fail(rc_wide, "%s", err_wide.c_str());
     for (int g = 0; g < n_groups; g++)
@@ -608,9 +731,19 @@ extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t 
         if (max_nodes < 0) max_nodes = 0;
         std::vector<uint8_t> rerun((size_t)n, 0);
         const std::vector<SearchGroupIn> one{SearchGroupIn{h_presentations, n, L, 0}};
-        const int rc = L <= 29 ? run_greedy_sched<uint64_t>(one, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), greedy_slots_wanted())
-                               : run_greedy_sched<u128>(one, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), greedy_slots_wanted());
+        GreedySlots pool;
+        {
+            hipStream_t st0 = nullptr;
+            ACX_HIP_TRY(hipStreamCreateWithFlags(&st0, hipStreamNonBlocking));
+            int rc0 = pool.setup(n, max_nodes, L, L > 29, greedy_slots_wanted(), st0);
+            if (rc0 == ACX_OK && hipStreamSynchronize(st0) != hipSuccess) rc0 = fail(ACX_E_NODEVICE, "acx_search_many: setting up the slots failed");
+            (void)hipStreamDestroy(st0);
+            if (rc0 != ACX_OK) return rc0;
+        }
+        const int rc = L <= 29 ? run_greedy_sched<uint64_t>(pool, one, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), pool.S)
+                               : run_greedy_sched<u128>(pool, one, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), pool.S);
         if (rc != ACX_OK) return rc;
+        pool.mark_clean();
         for (int64_t k = 0; k < n; k++)
             if (rerun[k])
                 rc_out[k] = acx_search(kind, h_presentations + k * 2 * L, L, max_nodes, cyclical, solved + k, path_action ? path_action + k * path_cap : nullptr,

@@ -232,8 +232,9 @@ int acx_search_many(int kind, const int8_t *h_presentations, int64_t n, int L, i
 #define ACX_OPT_GREEDY_HAND_MIN 2  /* a bucket of at least this many queued parents of a single greedy search goes to the whole-GPU kernels (default 512; 0: never) */
 #define ACX_OPT_MEGA_RANK_MAX 3    /* handed-off buckets up to this size are ordered by the counting sort (default 16384, at least 256) */
 #define ACX_OPT_BFS_MANY_BMAX 4    /* parents per search and round of acx_search_many(bfs) (default 32768, 128 .. 2^22) */
-#define ACX_OPT_GREEDY_SLOTS 5     /* persistent workgroups of acx_search_many / acx_search_groups (greedy) (default 256 = one per compute unit) */
+#define ACX_OPT_GREEDY_SLOTS 5     /* persistent workgroups of acx_search_many / acx_search_groups (greedy) (default 512 = two per compute unit; slots of the call = min(this, jobs, what the memory holds)) */
 #define ACX_OPT_GENERAL_MOVE 6     /* 1: the general move code also for roots in normal form (tests: both codes must build the same arena) */
+#define ACX_OPT_GREEDY_SCRATCH 7   /* acx_search_many / acx_search_groups, greedy: entries of a slot's own sort scratch (default 65536; a bucket that needs more borrows a shared full-size region; tests: small) */
 #define ACX_OPT_COUNT 8
 int acx_set_option(int option, int64_t value);
 int64_t acx_get_option(int option);

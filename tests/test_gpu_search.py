@@ -640,7 +640,7 @@ def greedy_slots(request):
         yield request.param
 
 
-@pytest.mark.parametrize("greedy_slots", [2, 5, 256], indirect=True)
+@pytest.mark.parametrize("greedy_slots", [2, 5, 512], indirect=True)
 def test_greedy_searches_as_jobs_on_a_few_workgroup_slots(search, golden_json, greedy_slots):
     """acx_search_groups / acx_search_many(greedy) = k_greedy_sched: a fixed set of workgroups, each with the memory of ONE search,
     takes the searches from a counter and cleans its slot (visited table, bucket rows, the vector L1) between two of them.  With 2 or 5
@@ -679,6 +679,28 @@ def test_greedy_searches_as_jobs_on_a_few_workgroup_slots(search, golden_json, g
     bad = np.stack([_pad([1, 1], [2, 2], 2), _pad([1, 2], [2, 1], 2)])
     with pytest.raises(AssertionError):
         run_search_groups(_acx.SEARCH_GREEDY, [groups[0], bad], 100, False)
+
+
+def test_greedy_jobs_borrow_the_shared_sort_scratch(search, golden_json):
+    """k_greedy_sched: a slot's own sort scratch is small, a bucket that outgrows it is ordered in one of a few full-size regions that all
+    slots of the call share (GreedyDev::big_lock).  With the smallest scratch (2048 entries) and 24 searches on 12 slots whose buckets
+    reach thousands of entries the regions are contended: every search as the single search's."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search, run_search_many
+
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    rows = [np.asarray(pool[k], dtype=np.int8) for k in range(170, 170 + 340, 15)]  # max_relator_length 18 / 20: the tightest bounds, the largest buckets
+    budget = 150000
+    with _acx.options(OPT_GREEDY_SLOTS=12, OPT_GREEDY_SCRATCH=2048):
+        got = {}
+        for L in sorted({len(r) // 2 for r in rows}):
+            grp = np.stack([r for r in rows if len(r) // 2 == L])
+            for row, res in zip(grp, run_search_many(_acx.SEARCH_GREEDY, grp, budget, False)):
+                got[row.tobytes()] = res
+    for row in rows:
+        ok, path, st = got[row.tobytes()]
+        wok, wpath, wst = run_search(_acx.SEARCH_GREEDY, row, budget, False)
+        assert (ok, path, st["nodes"], st["expanded"]) == (wok, wpath, wst["nodes"], wst["expanded"]), row.tolist()
 
 
 def test_miller_schupp_driver_matches_reference_test_ranges(search, golden_json):
