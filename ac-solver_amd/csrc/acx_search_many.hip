@@ -207,7 +207,9 @@ static int run_greedy_sched(const GreedySlots& pool, const std::vector<SearchGro
     // longest first, as far as one can tell beforehand: a search that is still running when the others are done has the chip to itself
     // (measured on the Miller-Schupp sweep at 1e6 nodes: an UNSOLVED search costs 1.33e8 workgroup cycles at max_relator_length 18, 1.20e8
     // at 20, 8.2e7 at 24, 6.9e7 at 28 -- the tighter the length bound, the more batches a node costs -- and a solved one a tenth of that;
-    // which searches stay unsolved is not known beforehand, so: the smaller max_relator_length first, the longer relators first)
+    // which searches stay unsolved is not known beforehand, so: the smaller max_relator_length first, the longer relators first.
+    // Round 5, on the slot pool: this order 0.147-0.153 s; longest roots first whatever the bound 0.168; the wider bounds first 0.167;
+    // by 2 L - root length 0.145-0.150; the 128-bit launch held to 300 / 256 workgroups 0.148 / 0.153-0.163)
     for (int code = 0; code < 2; code++) {
         std::vector<size_t> order(jobs[code].size());
         for (size_t i = 0; i < order.size(); i++) order[i] = i;
