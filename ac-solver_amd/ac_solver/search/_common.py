@@ -50,7 +50,7 @@ def run_search(kind, presentation, max_nodes_to_explore, cyclical, want_stats=Fa
             raise AssertionError(_acx.last_error())
         _acx.check(rc, "acx_search")
         break
-    path = [(int(a), int(l)) for a, l in zip(pa[: n.value], pl[: n.value])] if n.value else None
+    path = list(zip(pa[: n.value].tolist(), pl[: n.value].tolist())) if n.value else None  # (tolist: Python ints, as the reference's tuples hold)
     stats = dict(nodes=st.nodes, expanded=st.expanded, children=st.children, levels=st.levels, min_len=st.min_len, seconds=st.seconds)
     return bool(solved.value), path, stats
 
@@ -75,15 +75,28 @@ def run_search_many(kind, presentations, max_nodes_to_explore, cyclical, n_threa
     if rc == _acx.E_ROWERR and (rcs == _acx.E_ROWERR).any():
         raise AssertionError(_acx.last_error())
     _acx.check(rc, "acx_search_many")
+    return _collect(n, solved, pa, pl, pn, rcs, stats, lambda k: run_search(kind, rows[k], max_nodes_to_explore, cyclical))
+
+
+_STATS_DTYPE = np.dtype([("nodes", np.int64), ("expanded", np.int64), ("children", np.int64), ("levels", np.int64), ("min_len", np.int32), ("seconds", np.float64)],
+                        align=True)  # = _acx.SearchStats (include/acx.h: acx_search_stats)
+
+
+def _collect(n, solved, pa, pl, pn, rcs, stats, redo):
+    """the output arrays of acx_search_many / acx_search_groups -> [(solved, path, stats)] (plain Python ints, as the reference's tuples hold); a search
+    whose path outgrew the buffer (rare) is redone alone by `redo(k)`.  Whole-array conversions: a sweep is 1190 paths."""
+    assert _STATS_DTYPE.itemsize == C.sizeof(_acx.SearchStats)
+    st = np.frombuffer(stats, dtype=_STATS_DTYPE, count=n) if n else np.zeros(0, _STATS_DTYPE)
+    cols = [st[f].tolist() for f in ("nodes", "expanded", "children", "levels", "min_len", "seconds")]
+    ok, cnt, codes = solved.tolist(), pn.tolist(), rcs.tolist()
     out = []
     for k in range(n):
-        if rcs[k] == _acx.E_CAPACITY:  # rare: a path longer than path_cap -> redo that search alone
-            out.append(run_search(kind, rows[k], max_nodes_to_explore, cyclical))
+        if codes[k] == _acx.E_CAPACITY:
+            out.append(redo(k))
             continue
-        st = stats[k]
-        path = [(int(a), int(l)) for a, l in zip(pa[k, : pn[k]], pl[k, : pn[k]])] if pn[k] else None
-        out.append((bool(solved[k]), path, dict(nodes=st.nodes, expanded=st.expanded, children=st.children, levels=st.levels, min_len=st.min_len,
-                                                seconds=st.seconds)))
+        m = cnt[k]
+        path = list(zip(pa[k, :m].tolist(), pl[k, :m].tolist())) if m else None
+        out.append((bool(ok[k]), path, dict(nodes=cols[0][k], expanded=cols[1][k], children=cols[2][k], levels=cols[3][k], min_len=cols[4][k], seconds=cols[5][k])))
     return out
 
 
@@ -116,20 +129,14 @@ def run_search_groups(kind, groups, max_nodes_to_explore, cyclical, n_threads=16
     if rc == _acx.E_ROWERR and (rcs == _acx.E_ROWERR).any():
         raise AssertionError(_acx.last_error())
     _acx.check(rc, "acx_search_groups")
-    out, k = [], 0
-    for g in range(ng):
-        res = []
-        for i in range(int(counts[g])):
-            if rcs[k] == _acx.E_CAPACITY:  # rare: a path longer than path_cap -> redo that search alone
-                res.append(run_search(kind, rows[g][i], max_nodes_to_explore, cyclical))
-            else:
-                st = stats[k]
-                path = [(int(a), int(l)) for a, l in zip(pa[k, : pn[k]], pl[k, : pn[k]])] if pn[k] else None
-                res.append((bool(solved[k]), path, dict(nodes=st.nodes, expanded=st.expanded, children=st.children, levels=st.levels, min_len=st.min_len,
-                                                        seconds=st.seconds)))
-            k += 1
-        out.append(res)
-    return out
+    first = np.concatenate([[0], np.cumsum(counts)]).tolist()
+
+    def redo(k):
+        g = int(np.searchsorted(first, k, side="right")) - 1
+        return run_search(kind, rows[g][k - first[g]], max_nodes_to_explore, cyclical)
+
+    flat = _collect(n, solved, pa, pl, pn, rcs, stats, redo)
+    return [flat[first[g]:first[g + 1]] for g in range(ng)]
 
 
 def self_check(search_fn, budget=10**6):

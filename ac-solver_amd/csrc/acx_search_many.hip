@@ -661,6 +661,8 @@ extern "C" int acx_search_groups(int kind, int n_groups, const int8_t* const* h_
     int64_t n_narrow = 0, n_wide = 0;
     for (const auto& gr : narrow) n_narrow += gr.n;
     for (const auto& gr : wide) n_wide += gr.n;
+    const auto t_call = std::chrono::steady_clock::now();
+    auto since_call = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
     GreedySlots pool;
     {
         hipStream_t st0 = nullptr;
@@ -670,6 +672,7 @@ extern "C" int acx_search_groups(int kind, int n_groups, const int8_t* const* h_
         (void)hipStreamDestroy(st0);
         if (rc0 != ACX_OK) return rc0;
     }
+    const double t_setup = since_call();
     // Workgroups per launch.  With a slot for every workgroup the chip can hold (two per compute unit) both launches get as many
     // workgroups as they have jobs: those beyond the chip's capacity wait in the dispatcher, and whichever launch runs out of jobs first
     // leaves its compute units (and slots) to the other -- no shares to guess.  With fewer slots (the tests' option, little free
@@ -706,6 +709,7 @@ extern "C" int acx_search_groups(int kind, int n_groups, const int8_t* const* h_
                                         side.joinable() ? &wide_launched : nullptr);
     if (side.joinable()) side.join();
     else if (!wide.empty()) rc_wide = run_greedy_sched<u128>(pool, wide, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), wgs_wide);
+    if (g_debug) fprintf(stderr, "[acx_search_groups] %u slots of %.0f MB set up in %.1f ms; both launches done at %.1f ms\n", pool.S, pool.per_slot / 1e6, t_setup, since_call());
     if (rc == ACX_OK && rc_wide == ACX_OK) pool.mark_clean();
     if (rc != ACX_OK) return rc;
     if (rc_wide != ACX_OK) return err_wide.empty() ? rc_wide : fail(rc_wide, "%s", err_wide.c_str());
