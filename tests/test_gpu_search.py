@@ -681,6 +681,34 @@ def test_greedy_searches_as_jobs_on_a_few_workgroup_slots(search, golden_json, g
         run_search_groups(_acx.SEARCH_GREEDY, [groups[0], bad], 100, False)
 
 
+def test_greedy_slot_blocks_come_back_clean(search, golden_json):
+    """The blocks that hold the slots of a call go back to the library's block pool tagged "every slot clean" (every workgroup hands its
+    slot back that way), and the next call with the same layout fills nothing: the same groups three times over, another budget (another
+    layout: the tag must not match) in between -- the same results every time, and as the single search's."""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search, run_search_groups
+
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    rng = np.random.default_rng(23)
+    groups = []
+    for n0 in (1, 3, 6):  # max_relator_length 18, 24 (64-bit keys), 36 (128-bit keys)
+        pick = np.sort(rng.choice(170, size=24, replace=False)) + 170 * n0
+        groups.append(np.array([pool[int(k)] for k in pick], dtype=np.int8))
+
+    def key(res):
+        return [[(ok, path, st["nodes"], st["expanded"]) for ok, path, st in r] for r in res]
+
+    first = key(run_search_groups(_acx.SEARCH_GREEDY, groups, 20000, False))
+    other = key(run_search_groups(_acx.SEARCH_GREEDY, groups, 5000, False))
+    assert key(run_search_groups(_acx.SEARCH_GREEDY, groups, 20000, False)) == first
+    assert key(run_search_groups(_acx.SEARCH_GREEDY, groups[::-1], 20000, False)) == first[::-1]
+    assert key(run_search_groups(_acx.SEARCH_GREEDY, groups, 5000, False)) == other
+    for g, res in zip(groups, first):
+        for row, got in zip(g[::5], res[::5]):
+            wok, wpath, wst = run_search(_acx.SEARCH_GREEDY, row, 20000, False)
+            assert got == (wok, wpath, wst["nodes"], wst["expanded"])
+
+
 def test_greedy_jobs_borrow_the_shared_sort_scratch(search, golden_json):
     """k_greedy_sched: a slot's own sort scratch is small, a bucket that outgrows it is ordered in one of a few full-size regions that all
     slots of the call share (GreedyDev::big_lock).  With the smallest scratch (2048 entries) and 24 searches on 12 slots whose buckets
