@@ -10,9 +10,15 @@ One Python literal per line:
   bfs_solved_presentations.txt     the 278 presentations bfs trivialises with a 1e6-node budget (cyclic reduction on)
 
 The files are not shipped: `ensure_data_file` produces them with this build's own searches on the GPU
-(about half a minute) the first time one is asked for, into ac_solver/search/miller_schupp/data/.
+(well under a second of device time) the first time one is asked for, into ac_solver/search/miller_schupp/data/.
+First use under N ranks (torchrun starts N trainers on a fresh box): ONE process generates, holding an exclusive
+`flock` on `<dir>/.lock`; the others block on the lock and find the files when they get it.  Every file is written
+under a temporary name and renamed into place (`os.replace`), so a reader never sees a half-written file.
 """
+import contextlib
+import fcntl
 import os
+import tempfile
 from ast import literal_eval
 
 import numpy as np
@@ -31,9 +37,36 @@ def from_legacy_path(path):
 
 
 def write_literals(rows, filepath):
-    with open(filepath, "w") as f:
-        for row in rows:
-            f.write(f"{row}\n")
+    """One literal per line, atomically: the text goes to a temporary file of the same directory which is then renamed over
+    `filepath` -- a concurrent reader sees the old file or the whole new one."""
+    d = os.path.dirname(os.path.abspath(filepath))
+    fd, tmp = tempfile.mkstemp(prefix="." + os.path.basename(filepath) + ".", suffix=".tmp", dir=d)
+    try:
+        with os.fdopen(fd, "w") as f:
+            for row in rows:
+                f.write(f"{row}\n")
+            f.flush()
+            os.fsync(f.fileno())
+        os.chmod(tmp, 0o644)
+        os.replace(tmp, filepath)
+    except BaseException:
+        with contextlib.suppress(OSError):
+            os.unlink(tmp)
+        raise
+
+
+@contextlib.contextmanager
+def _dir_lock(d):
+    """Exclusive advisory lock on `<d>/.lock` (flock: released by the kernel when the holder dies)."""
+    os.makedirs(d, exist_ok=True)
+    fd = os.open(os.path.join(d, ".lock"), os.O_RDWR | os.O_CREAT, 0o644)
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX)
+        yield
+    finally:
+        with contextlib.suppress(OSError):
+            fcntl.flock(fd, fcntl.LOCK_UN)
+        os.close(fd)
 
 
 def read_literals(filepath):
@@ -113,13 +146,27 @@ def make_data_files(max_nodes_to_explore=10**6, out_dir=None, verbose=True):
     return out_dir
 
 
-def ensure_data_file(name):
+def _have_all(d):
+    return all(os.path.exists(os.path.join(d, name)) for name in FILES)
+
+
+def ensure_data_files(data_dir=None, generate=None):
+    """All four files present in `data_dir` (default: the package's data directory), produced at most ONCE however many
+    processes ask at the same time: whoever gets the directory lock first generates (files appear by rename), the others wait
+    on the lock and then find them.  `generate(out_dir)` defaults to `make_data_files` (this build's searches on the GPU)."""
+    d = data_dir or DATA_DIR
+    if _have_all(d):
+        return d
+    with _dir_lock(d):
+        if not _have_all(d):
+            print(f"Miller-Schupp data files not found: running the searches once to produce {d} ...", flush=True)
+            (generate or (lambda out: make_data_files(out_dir=out)))(d)
+    return d
+
+
+def ensure_data_file(name, data_dir=None, generate=None):
     assert name in FILES, f"unknown data file {name}"
-    path = os.path.join(DATA_DIR, name)
-    if not os.path.exists(path):
-        print(f"{name} not found: running the Miller-Schupp searches once to produce ac_solver/search/miller_schupp/data/ ...", flush=True)
-        make_data_files()
-    return path
+    return os.path.join(ensure_data_files(data_dir, generate), name)
 
 
 if __name__ == "__main__":

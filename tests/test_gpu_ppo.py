@@ -128,10 +128,12 @@ def test_data_files_reproduce_the_published_results(tmp_path, golden_json):
 
 def test_data_package_is_importable_as_in_the_reference(golden_json):
     """the reference's own check (tests/search/miller_schupp/data/test_do_files_exist.py) and the way its trainer opens the files
-    (agents/utils.py:28, importlib.resources): the package exists, and importing it on a GPU box leaves the files there"""
+    (agents/utils.py:28, importlib.resources): the package exists (its import does no GPU work), and after the first use the files are there"""
     from importlib import resources
 
     import ac_solver.search.miller_schupp.data as data
+
+    data.ensure()
 
     for file_type in ["greedy_solved", "all"]:
         file_name = f"{file_type}_presentations.txt"
