@@ -117,6 +117,9 @@ SIGNATURES = {
     "acx_shard_fail": (C.c_int, [_vp, _vp]),
     "acx_shard_find": (C.c_int, [_vp, C.c_int64, _i64p, _vp]),
     "acx_shard_node_info": (C.c_int, [_vp, C.c_int64, _i64p]),
+    "acx_shard_set_replicated": (C.c_int, [_vp, C.c_int]),
+    "acx_shard_partition": (C.c_int, [_vp, _vp]),
+    "acx_shard_walk": (C.c_int, [_vp, C.c_int64, C.c_int64, _i64p, _vp]),
     "acx_release_cached_memory": (C.c_int, []),
     "acx_set_option": (C.c_int, [C.c_int, C.c_int64]),
     "acx_get_option": (C.c_int64, [C.c_int]),

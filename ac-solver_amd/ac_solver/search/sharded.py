@@ -55,6 +55,11 @@ CTL_STATUS, CTL_NODES_GLOBAL, CTL_NEXT_COUNT, CTL_EXPANDED, CTL_SOLVED_TAG, CTL_
 CTL_FAIL_LOCAL, CTL_MIN_LEN, CTL_FAIL_SEEN, CTL_LEVEL_FILL = 8, 9, 10, 12
 FILL_DEFAULT = 320  # region capacity in 1/256 of the even share of all children: 1.25 x (acx_shard_layout)
 FILL_HARD = 1 << 20  # the hard bound: every workgroup sends a region all it has -- cannot overflow, world^2 x the even share
+# Levels of fewer parents than this are expanded by EVERY rank (no collectives); the first level at least this large is partitioned by
+# owner.  What a level costs a rank: replicated F parents x ~0.2 ns (the world-1 kernels: 9.3 ms per 4.5e7 parents) + six launches; sharded
+# F / world x that + ONE all-to-all + TWO all-reduces (>= 120-210 us at any size, tools/shard_host_cost.py) + eight launches: at 8 ranks the
+# two meet near 2^19-2^20 parents; 2^18 keeps the replicated share of a 1e8-node search below 1 % of its expansions.
+REPLICATE_BELOW = 1 << 18
 ST_RUNNING, ST_SOLVED, ST_BUDGET, ST_MOVE_ERROR, ST_FAILED = 0, 1, 2, 3, 4
 _FAIL_TEXT = {1: "a send region or the record log overflowed", 2: "node capacity exceeded", 3: "visited table full", 4: "engine call failed"}
 
@@ -145,12 +150,13 @@ class HipShardEngine:
         self.RW = self.KW + 1
         self.rank, self.world, self.L = rank, world, int(L)
         self.B = int(chunk_parents)
+        self.replicated = False  # set_replicated / partition: whole levels on every rank with the world-1 kernels, no exchange
         with torch.cuda.device(self.device):
             self.h = _acx.lib.acx_shard_create(L, int(bool(cyclical)), int(node_cap), self.B, rank, world)
             if not self.h:
                 raise _acx.AcxError(f"acx_shard_create failed: {_acx.last_error()}")
             full = self.layout_words(self.B)
-            words = 8 + int(full * (est_parents / self.B + 2))
+            words = 8 + int(full * (est_parents / self.B + 2)) + 64 * 40  # (+ the header-only regions of the replicated levels' chunks)
             self.log = torch.empty(words, dtype=torch.int64, device=self.device)
             self.send = torch.empty(full, dtype=torch.int64, device=self.device) if world > 1 else None
             self.gmask = torch.empty((self.B + 1) // 2, dtype=torch.int32, device=self.device)  # two parents' 12-bit masks per word
@@ -183,12 +189,36 @@ class HipShardEngine:
 
     def layout(self, n_par, fill_q8=0):
         s, cap, rw = C.c_int64(), C.c_int64(), C.c_int64()
-        self._acx.check(self._acx.lib.acx_shard_layout(int(n_par), self.world, self.KW, int(fill_q8), C.byref(s), C.byref(cap), C.byref(rw)), "acx_shard_layout")
+        self._acx.check(self._acx.lib.acx_shard_layout(int(n_par), self.world_eff, self.KW, int(fill_q8), C.byref(s), C.byref(cap), C.byref(rw)), "acx_shard_layout")
         return s.value, cap.value, rw.value
 
     def layout_words(self, n_par, fill_q8=0):
         s, _, rw = self.layout(n_par, fill_q8)
-        return s * self.world * rw
+        return s * self.world_eff * rw
+
+    @property
+    def world_eff(self):
+        """the world size the chunk geometry is computed for: 1 during the replicated phase"""
+        return 1 if self.replicated else self.world
+
+    def set_replicated(self):
+        """before the root is seeded, on every rank: the levels that follow are processed whole by every rank (acx_shard_set_replicated)"""
+        self._acx.check(self._acx.lib.acx_shard_set_replicated(self.h, 1), "acx_shard_set_replicated")
+        self.replicated = True
+
+    def partition(self):
+        """end of the replicated phase, between two levels: this rank's share of the newest level becomes its frontier slice"""
+        try:
+            self._acx.check(self._acx.lib.acx_shard_partition(self.h, self._stream()), "acx_shard_partition")
+        finally:
+            self.replicated = False
+
+    def walk(self, node_id, cap=256):
+        """-> (next parent reference that is not local, or -1 at the root; [(action, total length), ...] from node_id upwards)"""
+        out = np.zeros(2 + 2 * cap, np.int64)
+        self._acx.check(self._acx.lib.acx_shard_walk(self.h, int(node_id), int(cap), self._acx.ptr(out, C.c_int64), self._stream()), "acx_shard_walk")
+        n = int(out[1])
+        return int(out[0]), [(int(out[2 + 2 * k]), int(out[3 + 2 * k])) for k in range(n)]
 
     def root_record(self, presentation):
         rec = np.zeros(self.KW + 2, np.int64)
@@ -228,7 +258,7 @@ class HipShardEngine:
                 self.log = bigger
                 self._attach()
             torch.cuda.synchronize(self.device)  # the copy ran on the calling stream; the other stream's next kernels read the new block
-        if self.send is not None and need > self.send.numel():  # (only under a capacity above the default: the hard bound of the last resort)
+        if self.send is not None and not self.replicated and need > self.send.numel():  # (only under a capacity above the default: the hard bound of the last resort)
             torch.cuda.synchronize(self.device)
             with torch.cuda.device(self.device):
                 self.send = torch.empty(need, dtype=torch.int64, device=self.device)
@@ -239,7 +269,7 @@ class HipShardEngine:
         assert off.value == self._cursor and words.value == need, (off.value, self._cursor, words.value, need)
         recv = self.log[off.value: off.value + need]
         self._cursor += need
-        return (recv if self.send is None else self.send[:need]), recv
+        return (recv if (self.send is None or self.replicated) else self.send[:need]), recv
 
     def chunk_insert(self, n_par):
         """-> the chunk's child masks, two parents per int32 word (parent p: bits 16 (p & 1) .. + 11 of word p >> 1), to be summed over the ranks"""
@@ -366,11 +396,12 @@ class _RegionOverflow(RuntimeError):
 
 
 def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False, comm=None,
-                engine_factory=None, batch_parents=None, want_stats=False, log_fraction=0.5, overlap=None, region_fill=None, timeline=False):
+                engine_factory=None, batch_parents=None, want_stats=False, log_fraction=0.5, overlap=None, region_fill=None, timeline=False,
+                replicate_below=None):
     """`bfs` with the frontier sharded over the ranks of `comm`: see _bfs_sharded_once.  A search whose adaptive (or given) region
     capacity turns out too tight fails on every rank at the same chunk and is rerun from scratch with the safe default."""
     kw = dict(verbose=verbose, cyclically_reduce_after_moves=cyclically_reduce_after_moves, comm=comm, engine_factory=engine_factory,
-              want_stats=want_stats, log_fraction=log_fraction, overlap=overlap, timeline=timeline)
+              want_stats=want_stats, log_fraction=log_fraction, overlap=overlap, timeline=timeline, replicate_below=replicate_below)
     # (the owner function keeps families of states on one rank -- csrc/acx_owner.h --, so no capacity below the hard bound is safe
     # for EVERY input: the third attempt uses it, with small chunks, since a region then has room for every child of its senders)
     if batch_parents is None:
@@ -391,13 +422,18 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
 
 
 def _bfs_sharded_once(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False, comm=None,
-                      engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None, region_fill=None, timeline=False):
+                      engine_factory=None, batch_parents=1 << 21, want_stats=False, log_fraction=0.5, overlap=None, region_fill=None, timeline=False,
+                      replicate_below=None):
     """Same contract as `bfs`: returns (is_search_successful, path or None) [+ stats dict], identical on every rank.
     `batch_parents`: global frontier positions per chunk.  `log_fraction`: expected expanded parents / max_nodes, sizes the
     record log (it grows by doubling if the estimate is short).  `overlap`: expansion + exchange of chunk k + 1 on a side stream, started beside the dedup of chunk k ("insert": the default when there is an exchange, i.e. world > 1) or beside its commit ("commit"); False: one stream, the default without an exchange.  `region_fill`: capacity of the exchanged regions in 1/256 of the even share of all children -- None: adaptive (1.25 x the fullest region of the previous level, at most the default), an int: that value for every chunk, FILL_DEFAULT: 1.25 x the even share of all children, FILL_HARD: the bound that cannot overflow; a search whose regions overflow is rerun with the default, then with the hard bound.  `timeline` (GPU, with want_stats): HIP events around every stage of every chunk -- stats["timeline"] gives the median device time of
     expansion, all-to-all, dedup, mask all-reduce and commit per full-size chunk, the chunk period and `overlap_effective` = their
     sum / the period (1 = the stages run one after the other, > 1 = the side stream hides work).  A diagnostic: the events cost a
-    little, so timed runs leave it off."""
+    little, so timed runs leave it off.  `replicate_below` (world > 1): levels of fewer parents than this are processed WHOLE by every
+    rank with the world-1 kernels -- no all-to-all, no mask all-reduce, no closing all-reduce: a small level costs a rank a few
+    microseconds of expansion against >= 100 us of collectives --; at the first level that is at least this large the frontier is
+    partitioned by owner (engine.partition) and the chunks are exchanged.  One all-reduce closes the replicated phase (failure code:
+    a rank whose engine raised ends every rank there).  None: REPLICATE_BELOW; 0 or 1: every level is exchanged (rounds 3-5)."""
     from ac_solver.envs.utils import is_array_valid_presentation
 
     import time
@@ -414,7 +450,12 @@ def _bfs_sharded_once(presentation, max_nodes_to_explore=10000, verbose=False, c
     comm = SingleComm() if comm is None else comm
     world, rank = comm.world, comm.rank
     B = int(max(1, min(batch_parents, max(max_nodes, 64))))  # global parents per chunk
-    node_cap = (max_nodes + 64 if world == 1 else int(2.0 * max_nodes / world)) + 4096
+    replicate_below = REPLICATE_BELOW if replicate_below is None else int(replicate_below)
+    if world == 1:
+        replicate_below = 0
+    # (the nodes of the replicated levels live on every rank, and so does a copy of a rank's share of the level the partition happens at:
+    # the levels below `replicate_below` parents hold < 2 x that many nodes unless the search hardly grows, the level after them < 12 x)
+    node_cap = (max_nodes + 64 if world == 1 else int(2.0 * max_nodes / world) + min(max_nodes, 16 * max(replicate_below, 0))) + 4096
     engine = (engine_factory or _default_engine)(L, cyclically_reduce_after_moves, node_cap, B, rank, world, max(1.0, log_fraction * max_nodes))
     # The orchestrator allocates a few small Python objects per chunk; in a process with a large heap (bench.py) that now and then
     # triggers a full garbage collection (25-30 ms there) in the middle of a 13 ms search.  No collections while the search runs
@@ -424,7 +465,7 @@ def _bfs_sharded_once(presentation, max_nodes_to_explore=10000, verbose=False, c
     gc_was_on = gc.isenabled()
     gc.disable()
     try:
-        return _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, want_stats, overlap, region_fill, t_begin, timeline)
+        return _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, want_stats, overlap, region_fill, t_begin, timeline, replicate_below)
     finally:
         if hasattr(engine, "close"):
             engine.close()
@@ -455,13 +496,15 @@ def _timeline_summary(torch, rows, B):
     return out
 
 
-def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, want_stats, overlap, region_fill, t_begin, timeline=False):
+def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, want_stats, overlap, region_fill, t_begin, timeline=False, replicate_below=0):
     import time
 
     torch = _torch()
     dev = getattr(engine, "device", torch.device("cpu"))
     KW = engine.KW
-    exchange = world > 1 or _FORCE_EXCHANGE
+    # the replicated phase (small levels whole on every rank): from the root until the first level of >= replicate_below parents
+    replicating = world > 1 and replicate_below > 1 and hasattr(engine, "set_replicated")
+    exchange = (world > 1 or _FORCE_EXCHANGE) and not replicating  # flips to True at the partition
     lag = LAG if dev.type == "cuda" else 0
     if _FORCE_LAG is not None:
         lag = int(_FORCE_LAG)
@@ -472,9 +515,14 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
 
     # root: node 0 of its owner, global frontier position 0
     root = engine.root_record(p)
-    owner_root = int(engine.root_owner(root) if hasattr(engine, "root_owner") else owner_of(root[None, :KW], world)[0])
-    engine.seed(root if rank == owner_root else None)
+    if replicating:
+        engine.set_replicated()
+        engine.seed(root)  # every rank holds the replicated levels
+    else:
+        owner_root = int(engine.root_owner(root) if hasattr(engine, "root_owner") else owner_of(root[None, :KW], world)[0])
+        engine.seed(root if rank == owner_root else None)
     F = 1
+    repl_levels = 0
     levels = chunks = 0
     failure = None         # the first exception on this rank's host side
     fail_hdr_chunk = None  # index (inside the running level) of the first chunk this rank sent with "failed" headers
@@ -496,15 +544,35 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
         raise RuntimeError(f"sharded bfs failed on rank {rank}: {failure or _FAIL_TEXT.get(int(ctl[CTL_FAIL_LOCAL]) if ctl is not None else 4, 'engine failure')}"
                            if mine else f"sharded bfs failed on another rank: {_FAIL_TEXT.get(code, 'engine failure')}")
 
-    def walk(pref, tail):
-        """path of the node `pref` (rank << 40 | id) from the root + tail"""
+    WALK_CAP = 256
+
+    def walk(pref, tail, collective=True):
+        """path of the node `pref` (rank << 40 | id) from the root + tail.  The owner of a node walks up for as long as the parents are
+        its own (ONE launch and one copy per segment, engine.walk) and shares the segment with ONE all-reduce; the owner function keeps
+        three quarters of the children on their parent's rank, and the nodes of the replicated levels name the rank that holds them, so a
+        path is a handful of segments.  `collective` False (the search ended in its replicated phase): every rank walks its own copy."""
         rev = []
         while pref >= 0:
             r, nid = pref >> 40, pref & _ID_MASK
-            info = i64(list(engine.node_info(nid)) if rank == r else [0, 0, 0])
-            if rank != r:
-                info[2] = 0
-            comm.all_reduce(info, "sum")
+            if hasattr(engine, "walk"):
+                buf = np.zeros(2 + 2 * WALK_CAP, np.int64)
+                if rank == r or not collective:
+                    nxt, pairs = engine.walk(nid, WALK_CAP)
+                    buf[0], buf[1] = nxt, len(pairs)
+                    buf[2:2 + 2 * len(pairs)] = np.asarray(pairs, np.int64).reshape(-1)
+                if collective:
+                    t = i64(buf.tolist())
+                    comm.all_reduce(t, "sum")
+                    buf = np.asarray(t.tolist(), np.int64)
+                n = int(buf[1])
+                rev.extend((int(buf[2 + 2 * k]), int(buf[3 + 2 * k])) for k in range(n))
+                pref = int(buf[0])
+                continue
+            info = i64(list(engine.node_info(nid)) if (rank == r or not collective) else [0, 0, 0])
+            if collective:
+                if rank != r:
+                    info[2] = 0
+                comm.all_reduce(info, "sum")
             a, tl, pref = (int(v) for v in info.tolist())
             rev.append((a, tl))
         return rev[::-1] + tail
@@ -519,6 +587,7 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
             if tl_rows:
                 st["timeline"] = _timeline_summary(torch, tl_rows, B)
             st["local_nodes"] = int(ctl[CTL_NODES])
+            st["replicated_levels"] = repl_levels
             if _CHECK_OWNERS and hasattr(engine, "check_owners"):
                 st["owner_mismatches"] = engine.check_owners()
             return ok, path, st
@@ -538,7 +607,7 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
     # shortening them.  So without an exchange everything runs in stream order; with one, expansion + all-to-all start at once
     # on the side stream ("insert"): the per-rank kernels shrink with the world size and the collectives are what has to be hidden.
     if overlap is None or overlap is True:
-        overlap = "insert" if exchange else False
+        overlap = "insert" if (world > 1 or _FORCE_EXCHANGE) else False
     assert overlap in (False, "insert", "commit"), overlap
     on_gpu = dev.type == "cuda"
     main = torch.cuda.current_stream(dev) if on_gpu else None
@@ -669,111 +738,143 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
         return min(n, want)
 
     min_len = INF
-    while F > 0:
-        levels += 1
-        pending = []  # snapshot slots of the chunks whose control block has not been read yet
-        k = 0
-        ctl = None
-        if on_gpu:
-            side.wait_stream(main)  # the level's parents are the nodes the main stream committed during the previous level
-        sizes, n_read, new_read, c_next = [], 0, 0, 0
-        done = []  # per consumed chunk of this level: event behind its commit on the main stream
+    phase_closed = not replicating  # the replicated phase ends with ONE all-reduce (failure code), whichever way it ends
+    try:
+        while F > 0:
+            levels += 1
+            pending = []  # snapshot slots of the chunks whose control block has not been read yet
+            k = 0
+            ctl = None
+            if on_gpu:
+                side.wait_stream(main)  # the level's parents are the nodes the main stream committed during the previous level
+            sizes, n_read, new_read, c_next = [], 0, 0, 0
+            done = []  # per consumed chunk of this level: event behind its commit on the main stream
 
-        def produce_next():
-            nonlocal c_next
-            n = next_size(c_next, sizes, n_read, new_read)
-            sizes.append(n)
-            c_next += n
-            return produce(c_next - n, c_next, len(sizes) - 1)
+            def produce_next():
+                nonlocal c_next
+                n = next_size(c_next, sizes, n_read, new_read)
+                sizes.append(n)
+                c_next += n
+                return produce(c_next - n, c_next, len(sizes) - 1)
 
-        ready = produce_next()
-        while ready is not None and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING) and (fail_hdr_chunk is None or k <= fail_hdr_chunk + lag):
-            n_par, ev, dead, (e0, e1) = ready
-            ready = None
-            if c_next < F and overlap != "commit":
-                ready = produce_next()  # runs beside this chunk's dedup and commit
-            if ev is not None:
-                main.wait_event(ev)
-            m0 = stamp(main)
-            if dead:  # never went through the engine: nothing to dedup, nothing to commit; the collectives still pair up
-                gmask = torch.zeros((n_par + 1) // 2, dtype=torch.int32, device=dev)
-            else:
-                try:
-                    gmask = engine.chunk_insert(n_par)
-                except Exception as e:  # noqa: BLE001
-                    set_failed(e)
-                    try:  # masks only: the chunk stays in the engine's ring, so its commit (and the decide kernel in it) still runs
-                        gmask = engine.chunk_insert_dead(n_par)
-                    except Exception:  # noqa: BLE001
-                        gmask = engine.gmask_view(n_par)  # the engine's own buffer: its commit reads the all-reduced masks from there
-                        gmask.zero_()
-            m1 = stamp(main)
-            if c_next < F and overlap == "commit":
-                if on_gpu:
-                    side.wait_stream(main)  # not before this chunk's dedup is through
-                ready = produce_next()  # runs beside this chunk's mask all-reduce and commit
-            if exchange:
-                reduce_masks(gmask)  # every (parent, action) child has exactly one owner, so SUM == OR
-            m2 = stamp(main)
-            if not dead:
-                try:
-                    engine.chunk_commit(max_nodes)
-                except Exception as e:  # noqa: BLE001
-                    set_failed(e)
-            m3 = stamp(main)
-            if on_gpu and side is not main:
-                ev_done = torch.cuda.Event()
-                ev_done.record(main)
-                done.append(ev_done)
-            if tl_rows is not None:
-                tl_rows.append((n_par, e0, e1, ev, m0, m1, m2, m3, levels))
-            ctl_snapshot(k % (lag + 2))
-            pending.append(k % (lag + 2))
-            chunks += 1
-            if len(pending) > lag:
+            ready = produce_next()
+            while ready is not None and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING) and (fail_hdr_chunk is None or k <= fail_hdr_chunk + lag):
+                n_par, ev, dead, (e0, e1) = ready
+                ready = None
+                if c_next < F and overlap != "commit":
+                    ready = produce_next()  # runs beside this chunk's dedup and commit
+                if ev is not None:
+                    main.wait_event(ev)
+                m0 = stamp(main)
+                if dead:  # never went through the engine: nothing to dedup, nothing to commit; the collectives still pair up
+                    gmask = torch.zeros((n_par + 1) // 2, dtype=torch.int32, device=dev)
+                else:
+                    try:
+                        gmask = engine.chunk_insert(n_par)
+                    except Exception as e:  # noqa: BLE001
+                        set_failed(e)
+                        try:  # masks only: the chunk stays in the engine's ring, so its commit (and the decide kernel in it) still runs
+                            gmask = engine.chunk_insert_dead(n_par)
+                        except Exception:  # noqa: BLE001
+                            gmask = engine.gmask_view(n_par)  # the engine's own buffer: its commit reads the all-reduced masks from there
+                            gmask.zero_()
+                m1 = stamp(main)
+                if c_next < F and overlap == "commit":
+                    if on_gpu:
+                        side.wait_stream(main)  # not before this chunk's dedup is through
+                    ready = produce_next()  # runs beside this chunk's mask all-reduce and commit
+                if exchange:
+                    reduce_masks(gmask)  # every (parent, action) child has exactly one owner, so SUM == OR
+                m2 = stamp(main)
+                if not dead:
+                    try:
+                        engine.chunk_commit(max_nodes)
+                    except Exception as e:  # noqa: BLE001
+                        set_failed(e)
+                m3 = stamp(main)
+                if on_gpu and side is not main:
+                    ev_done = torch.cuda.Event()
+                    ev_done.record(main)
+                    done.append(ev_done)
+                if tl_rows is not None:
+                    tl_rows.append((n_par, e0, e1, ev, m0, m1, m2, m3, levels))
+                ctl_snapshot(k % (lag + 2))
+                pending.append(k % (lag + 2))
+                chunks += 1
+                if len(pending) > lag:
+                    ctl = ctl_wait(pending.pop(0))
+                    n_read += 1
+                    new_read, nodes_seen = int(ctl[CTL_NEXT_COUNT]), int(ctl[CTL_NODES_GLOBAL])
+                k += 1
+            if on_gpu:
+                main.wait_stream(side)  # (a chunk that was produced but never consumed: the search ended)
+            while pending and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING):  # end of the level: the one synchronisation
                 ctl = ctl_wait(pending.pop(0))
-                n_read += 1
-                new_read, nodes_seen = int(ctl[CTL_NEXT_COUNT]), int(ctl[CTL_NODES_GLOBAL])
-            k += 1
-        if on_gpu:
-            main.wait_stream(side)  # (a chunk that was produced but never consumed: the search ended)
-        while pending and (ctl is None or ctl[CTL_STATUS] == ST_RUNNING):  # end of the level: the one synchronisation
-            ctl = ctl_wait(pending.pop(0))
-        status = int(ctl[CTL_STATUS])
-        # closing all-reduce of the level (max): [failure code, -(smallest total length generated), fullest region received].
-        # Every rank does it here, whatever status it read, so a failure that no header carried (the last chunk of a level; a
-        # region overflow noticed after the search ended; an exception on one rank's host side) ends every rank at the same point.
-        code = int(ctl[CTL_FAIL_LOCAL])
-        if status == ST_FAILED:
-            code = max(code, int(ctl[CTL_FAIL_SEEN]))
-        if failure is not None:
-            code = max(code, 4)
-        closing = [code, -int(ctl[CTL_MIN_LEN]), int(ctl[CTL_LEVEL_FILL])]
-        if exchange:
-            e = i64(closing)
-            comm.all_reduce(e, "max")
-            closing = [int(v) for v in e.tolist()]
-        min_len = min(min_len, -closing[1])
-        if closing[0]:
-            raise_failed(closing[0])
-        if status == ST_MOVE_ERROR:
-            # the reference executes this move before it stops: its ACMove raises (every rank sees the same words)
-            raise AssertionError("a move emptied a relator during the search: the reference's ACMove raises here")
-        if status == ST_SOLVED:
-            tag = int(ctl[CTL_SOLVED_TAG])
-            mine = engine.find(tag // 12)
-            pref = i64([(rank << 40) | mine if mine >= 0 else -1])
-            comm.all_reduce(pref, "max")
-            return finish(True, walk(int(pref[0]), [(tag % 12, 2)]), min_len)
-        if status == ST_BUDGET:
-            return finish(False, None, min_len)
-        F_prev, F, nodes_seen = F, int(ctl[CTL_NEXT_COUNT]), int(ctl[CTL_NODES_GLOBAL])
-        if adaptive:  # the fullest region any rank received in this level (0: no chunk large enough to tell) sizes the next level's regions
-            lf = closing[2]
-            # (round 3, owner = hash of the whole key, measured level by level on five searches: the fullest region falls by up to 25 % from
-            # one level to the next and rises by at most 7 %.  Round 5's owner function sends a quarter of the children: on AK(3) the
-            # fullest region of a level is 0.58 / 0.44 / 0.36 / 0.34 of the even share of ALL children at 8 ranks, falling as the
-            # conjugators grow.  An overflow only costs a rerun.)
-            fill = FILL_DEFAULT if lf == 0 else min(FILL_DEFAULT, max(24, lf * 5 // 4 + 12))
-            fills.append(fill)
+            status = int(ctl[CTL_STATUS])
+            # closing all-reduce of the level (max): [failure code, -(smallest total length generated), fullest region received].
+            # Every rank does it here, whatever status it read, so a failure that no header carried (the last chunk of a level; a
+            # region overflow noticed after the search ended; an exception on one rank's host side) ends every rank at the same point.
+            code = int(ctl[CTL_FAIL_LOCAL])
+            if status == ST_FAILED:
+                code = max(code, int(ctl[CTL_FAIL_SEEN]))
+            if failure is not None:
+                code = max(code, 4)
+            closing = [code, -int(ctl[CTL_MIN_LEN]), int(ctl[CTL_LEVEL_FILL])]
+            # the replicated phase: no closing all-reduce per level (every rank computes the same level) -- ONE when the phase ends, i.e. the
+            # search has ended or the next level is large enough to be partitioned: a rank whose engine raised joins it from the handler below
+            phase_end = replicating and (status != ST_RUNNING or int(ctl[CTL_NEXT_COUNT]) >= replicate_below or int(ctl[CTL_NEXT_COUNT]) == 0)
+            if replicating:
+                repl_levels += 1
+            if phase_end:
+                phase_closed = True
+            if exchange or phase_end:
+                e = i64(closing)
+                comm.all_reduce(e, "max")
+                closing = [int(v) for v in e.tolist()]
+            min_len = min(min_len, -closing[1])
+            if closing[0]:
+                raise_failed(closing[0])
+            if status == ST_MOVE_ERROR:
+                # the reference executes this move before it stops: its ACMove raises (every rank sees the same words)
+                raise AssertionError("a move emptied a relator during the search: the reference's ACMove raises here")
+            if status == ST_SOLVED:
+                tag = int(ctl[CTL_SOLVED_TAG])
+                mine = engine.find(tag // 12)
+                if replicating:  # every rank holds the whole tree: no collective
+                    return finish(True, walk((rank << 40) | mine, [(tag % 12, 2)], collective=False), min_len)
+                pref = i64([(rank << 40) | mine if mine >= 0 else -1])
+                comm.all_reduce(pref, "max")
+                return finish(True, walk(int(pref[0]), [(tag % 12, 2)]), min_len)
+            if status == ST_BUDGET:
+                return finish(False, None, min_len)
+            F_prev, F, nodes_seen = F, int(ctl[CTL_NEXT_COUNT]), int(ctl[CTL_NODES_GLOBAL])
+            if replicating:
+                if phase_end and F > 0:
+                    # the first large level: every rank keeps its own share of it (copies, in frontier order) and the chunks are exchanged
+                    # from here on.  A rank whose partition raises goes on as a failed rank (dead chunks: the others learn it from the headers).
+                    replicating, exchange = False, True
+                    adaptive = region_fill is None
+                    try:
+                        engine.partition()
+                    except Exception as e:  # noqa: BLE001
+                        set_failed(e)
+                        engine.replicated = False  # (the dead chunks this rank now sends are laid out for the real world size)
+            if adaptive:  # the fullest region any rank received in this level (0: no chunk large enough to tell) sizes the next level's regions
+                lf = closing[2]
+                # (round 3, owner = hash of the whole key, measured level by level on five searches: the fullest region falls by up to 25 % from
+                # one level to the next and rises by at most 7 %.  Round 5's owner function sends a quarter of the children: on AK(3) the
+                # fullest region of a level is 0.58 / 0.44 / 0.36 / 0.34 of the even share of ALL children at 8 ranks, falling as the
+                # conjugators grow.  An overflow only costs a rerun.)
+                fill = FILL_DEFAULT if lf == 0 else min(FILL_DEFAULT, max(24, lf * 5 // 4 + 12))
+                fills.append(fill)
+    except _RegionOverflow:
+        raise
+    except Exception as e:  # noqa: BLE001
+        if phase_closed or world == 1:  # (the reference's AssertionError for a move that empties a relator is raised behind the closing all-reduce)
+            raise
+        # an engine call of the replicated phase raised on THIS rank: the healthy ranks meet at the phase's closing all-reduce -- join it
+        # with a failure code, so that every rank ends there
+        phase_closed = True
+        comm.all_reduce(i64([4, 0, 0]), "max")
+        raise RuntimeError(f"sharded bfs failed on rank {rank}: {e}") from e
     return finish(False, None, min_len)

@@ -1047,14 +1047,124 @@ template <typename W> __global__ void k_shard_seed(ShardDev<W> d, W k0, W k1) {
 
 // test hook (acx_shard_check_owners): every local node must live on the rank that owns its key, and the class hashes it carries
 // (inherited along conjugations) must be the ones its key gives
-template <typename W> __global__ void __launch_bounds__(256) k_shard_check_owners(ShardDev<W> d, unsigned long long* __restrict__ bad) {
+template <typename W> __global__ void __launch_bounds__(256) k_shard_check_owners(ShardDev<W> d, uint32_t own_from, unsigned long long* __restrict__ bad) {
     ACX_VGPR_PAD_W(W, "v63", "v95");
     const uint32_t n = (uint32_t)d.ctl[C_NODES];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const OwnerParts o = owner_parts_of_key<W>(d.k0[i], d.k1[i]);
-        const bool ok = owner_of_sum(o.sum(), d.world) == d.rank && (!d.cls || (d.cls[i].x == o.c0 && d.cls[i].y == o.c1 && d.inn[i] == (uint8_t)(o.in0 | (o.in1 << 4))));
+        // (the nodes of the replicated levels, below own_from, live on EVERY rank: only what they carry is checked)
+        const bool ok = (i < own_from || owner_of_sum(o.sum(), d.world) == d.rank) && (!d.cls || (d.cls[i].x == o.c0 && d.cls[i].y == o.c1 && d.inn[i] == (uint8_t)(o.in0 | (o.in1 << 4))));
         if (!ok) atomicAdd(bad, 1ull);
     }
+}
+
+
+// ---- replicated small levels -> owner-partitioned frontier (round 6) -----------------------------------------------------------
+// While the levels are small every rank processes the WHOLE frontier with the world-1 kernels (no exchange, no collective: a level
+// of a few thousand parents costs a rank a few microseconds of expansion against >= 100 us of collectives): all ranks hold the same
+// nodes, in the same order, with every state stamped in their own table.  At the first large level the frontier is PARTITIONED: of
+// the newest level's nodes [base, base + n) a rank keeps a COPY of those it owns (acx_owner.h: from the class hashes and inner letters
+// every node carries), appended to its arena in the same (gpos) order -- its slice of the running level from then on.  The copy's
+// parent reference is the original's (a replicated node, named with this rank's own number: every rank holds it at the same id), so a
+// path walks from the sharded part into the replicated prefix without another exchange.  The table needs nothing: every state of the
+// replicated levels already has its stamp on every rank.
+constexpr int kPartTile = 1024;
+template <typename W> __device__ __forceinline__ bool part_owned(const ShardDev<W>& d, uint32_t i) {
+    const uint2 c = d.cls[i];
+    const uint32_t in = d.inn[i];
+    return owner_of_sum(owner_sum(c.x, c.y, in & 15u, in >> 4), d.world) == d.rank;
+}
+template <typename W> __global__ void __launch_bounds__(kPartTile) k_shard_part_count(ShardDev<W> d, uint32_t base, uint32_t n, uint32_t* __restrict__ cnt) {
+    __shared__ uint32_t s_c;
+    ACX_VGPR_PAD("v31");
+    if (threadIdx.x == 0) s_c = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * kPartTile + threadIdx.x;
+    const bool own = i < n && part_owned<W>(d, base + i);
+    const unsigned long long b = __ballot(own);
+    if ((threadIdx.x & 63u) == 0 && b) atomicAdd(&s_c, (uint32_t)__popcll(b));
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = s_c;
+}
+// one workgroup: the tiles' counts -> exclusive prefixes in place; the level switch that the next chunk's k_shard_prep performs then
+// finds the copies [old nodes, old nodes + total) as the new level
+template <typename W> __global__ void __launch_bounds__(1024) k_shard_part_scan(ShardDev<W> d, uint32_t tiles, uint32_t* __restrict__ cnt, uint32_t nodes_old) {
+    __shared__ uint32_t s_p[1024];
+    ACX_VGPR_PAD("v31");
+    const uint32_t tid = threadIdx.x, per = (tiles + 1023u) / 1024u;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t t = tid * per + k;
+        if (t < tiles) sum += cnt[t];
+    }
+    s_p[tid] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint32_t a = tid >= o ? s_p[tid - o] : 0u;
+        __syncthreads();
+        s_p[tid] += a;
+        __syncthreads();
+    }
+    uint32_t ex = s_p[tid] - sum;
+    const uint32_t total = s_p[1023];
+    const bool fits = (unsigned long long)nodes_old + total <= (unsigned long long)d.cap_nodes;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t t = tid * per + k;
+        if (t < tiles) {
+            const uint32_t c = cnt[t];
+            cnt[t] = fits ? ex : 0xFFFFFFFFu;  // (no room: nothing is copied, the search fails with FAIL_NODES on every path that looks)
+            ex += c;
+        }
+    }
+    if (tid == 0) {
+        d.ctl[C_LVL_HI] = nodes_old;
+        if (fits) d.ctl[C_NODES] = (unsigned long long)nodes_old + total;
+        else atomicMax(d.ctl + C_FAIL_LOCAL, (unsigned long long)FAIL_NODES);
+    }
+}
+template <typename W> __global__ void __launch_bounds__(kPartTile) k_shard_part_write(ShardDev<W> d, uint32_t base, uint32_t n, const uint32_t* __restrict__ cnt, uint32_t nodes_old) {
+    __shared__ uint32_t s_w[kPartTile / 64];
+    ACX_VGPR_PAD_W(W, "v31", "v39");
+    const uint32_t off = cnt[blockIdx.x];
+    if (off == 0xFFFFFFFFu) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t i = blockIdx.x * kPartTile + tid;
+    const bool own = i < n && part_owned<W>(d, base + i);
+    const unsigned long long b = __ballot(own);
+    if (lane == 0) s_w[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    uint32_t before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    for (uint32_t w2 = 0; w2 < wave; w2++) before += s_w[w2];
+    if (!own) return;
+    const uint32_t src = base + i, dst = nodes_old + off + before;
+    d.k0[dst] = d.k0[src];
+    d.k1[dst] = d.k1[src];
+    d.pref[dst] = d.pref[src];
+    d.gpos[dst] = d.gpos[src];
+    d.act[dst] = d.act[src];
+    d.tlen[dst] = d.tlen[src];
+    d.cls[dst] = d.cls[src];
+    d.inn[dst] = d.inn[src];
+}
+
+// The path of local node `id` towards the root for as long as the parents are local (one lane: a chain of dependent loads, run once per
+// search): out[0] = the first parent reference that is NOT local (-1: the root was reached), out[1] = n, then n pairs (action, total
+// length), node `id` first; the root's action is -1.
+template <typename W> __global__ void k_shard_walk(ShardDev<W> d, uint32_t id, uint32_t cap, int64_t* __restrict__ out) {
+    ACX_VGPR_PAD("v23");
+    uint32_t cur = id, n = 0;
+    int64_t next = -1;
+    for (;;) {
+        const int64_t pr = d.pref[cur];
+        out[2 + 2 * n] = pr < 0 ? -1 : (int64_t)d.act[cur];
+        out[3 + 2 * n] = (int64_t)d.tlen[cur];
+        n++;
+        next = pr;
+        if (pr < 0 || (uint32_t)((unsigned long long)pr >> 40) != d.rank || n == cap) break;
+        cur = (uint32_t)((unsigned long long)pr & 0xFFFFFFFFull);
+    }
+    out[0] = next;
+    out[1] = (int64_t)n;
 }
 
 template <typename W> __global__ void k_shard_find(ShardDev<W> d, uint32_t gpos, int64_t* __restrict__ out) {
@@ -1138,6 +1248,19 @@ template <typename W> struct ShardEngine {
     unsigned insert_wgs = 0, commit_wgs = 0;
     int move_mode = kMoveGeneral;  // acx_bfs.h: set from the root (acx_shard_root_record, which every rank calls)
     CtlHost host;  // pinned snapshot slots + events
+    // Round 6: while `replicated` is set the engine processes whole levels with the world-1 kernels (every rank the same nodes, no
+    // exchange); acx_shard_partition ends that phase.  The nodes below own_from are the replicated ones.
+    bool replicated = false;
+    uint64_t own_from = 0;
+    uint32_t* part_cnt = nullptr;  // per tile of kPartTile nodes: owned nodes (k_shard_part_*)
+    int64_t* d_walk = nullptr;     // k_shard_walk's output
+    static constexpr int kWalkCap = 1024;
+    int world_eff() const { return replicated ? 1 : world; }
+    ShardDev<W> dev() const {
+        ShardDev<W> x = d;
+        if (replicated) x.world = 1;  // (the rank stays: parent references name this rank)
+        return x;
+    }
 
     ~ShardEngine() {
         for (auto& e : host.ev)
@@ -1219,6 +1342,8 @@ template <typename W> struct ShardEngine {
             d.gpre = (uint32_t*)take(b, 4 * chunk_parents + 16);
             d.lblk = (uint32_t*)take(b, 4 * n_tiles);
             d.gblk = (uint32_t*)take(b, 4 * n_tiles);
+            part_cnt = (uint32_t*)take(b, 4 * (cap_nodes / kPartTile + 2));
+            d_walk = (int64_t*)take(b, 8 * (2 + 2 * kWalkCap));
             if (pass == 0 && chunk_buf.alloc(o)) return ACX_E_NOMEM;
         }
         if (int rc = tab_buf.alloc(n_slots * 8, nullptr)) return rc;  // (a fill, when there is one, is queued on the null stream like the others)
@@ -1311,8 +1436,8 @@ static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int lev
     if (n_par < 1 || (uint64_t)n_par > E.chunk_parents) return fail(ACX_E_CAPACITY, "acx_shard_chunk_expand: a chunk of %lld parents exceeds the engine's %llu", (long long)n_par, (unsigned long long)E.chunk_parents);
     if (c1 > (int64_t)0xFFFFFFFFll) return fail(ACX_E_INVAL, "acx_shard_chunk_expand: a level is limited to 2^32 - 1 positions");
     int64_t subcap, region_words, even;
-    shard_layout(n_par, E.world, recio<W>::RW, fill_q8, &subcap, &region_words, &even);
-    const int64_t total = region_words * kShardSub * E.world;
+    shard_layout(n_par, E.world_eff(), recio<W>::RW, fill_q8, &subcap, &region_words, &even);
+    const int64_t total = region_words * kShardSub * E.world_eff();
     if (E.geo_count == ShardEngine<W>::kGeoRing) return fail(ACX_E_INVAL, "acx_shard_chunk_expand: too many chunks in flight (commit the oldest first)");
     ChunkGeo geo{};
     geo.c0 = c0;
@@ -1322,8 +1447,8 @@ static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int lev
     geo.even = (uint32_t)even;
     geo.par = E.chunk_seq++ & 1u;
     geo.log_off = E.log_off;
-    int64_t* send = E.d_send ? E.d_send : E.d.log + E.log_off;
-    if ((uint64_t)(E.log_off + total) > E.log_words || (E.d_send && (uint64_t)total > E.send_words))
+    int64_t* send = (E.d_send && !E.replicated) ? E.d_send : E.d.log + E.log_off;  // (replicated levels: as world 1, the regions are their headers, in the log)
+    if ((uint64_t)(E.log_off + total) > E.log_words || (E.d_send && !E.replicated && (uint64_t)total > E.send_words))
         return fail(ACX_E_CAPACITY, "acx_shard_chunk_expand: the record log (%llu words, %lld used) cannot take a chunk of %lld words: attach a larger one",
                     (unsigned long long)E.log_words, (long long)E.log_off, (long long)total);
     if (level_first) {  // the nodes committed since the previous switch are this rank's slice of the new level (host mirror; the device switches in k_shard_prep)
@@ -1335,18 +1460,18 @@ static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int lev
     E.log_off += total;
     E.geos[(E.geo_head + E.geo_count) % ShardEngine<W>::kGeoRing] = geo;
     E.geo_count++;
-    hipLaunchKernelGGL(k_shard_prep<W>, dim3(1), dim3(256), 0, st, E.d, geo, level_first, send);
+    hipLaunchKernelGGL(k_shard_prep<W>, dim3(1), dim3(256), 0, st, E.dev(), geo, level_first, send);
     const int64_t np_max = std::min<int64_t>(n_par, (int64_t)(E.lvl_hi_host - E.lvl_lo_host));
     if (np_max > 0) {
         const dim3 grid((unsigned)((np_max + kExpandParents - 1) / kExpandParents));
-        const size_t lds = (size_t)E.world * kExpandParents * 4;  // s_bits
-        if (E.world == 1) {
-            if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_expand<W, kMoveNf, true>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
-            else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_expand<W, kMoveNfCyclical, true>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
-            else hipLaunchKernelGGL((k_shard_expand<W, kMoveGeneral, true>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
-        } else if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_expand<W, kMoveNf, false>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
-        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_expand<W, kMoveNfCyclical, false>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
-        else hipLaunchKernelGGL((k_shard_expand<W, kMoveGeneral, false>), grid, dim3(kExpandThreads), lds, st, E.d, geo, send);
+        const size_t lds = (size_t)E.world_eff() * kExpandParents * 4;  // s_bits
+        if (E.world_eff() == 1) {
+            if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_expand<W, kMoveNf, true>), grid, dim3(kExpandThreads), lds, st, E.dev(), geo, send);
+            else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_expand<W, kMoveNfCyclical, true>), grid, dim3(kExpandThreads), lds, st, E.dev(), geo, send);
+            else hipLaunchKernelGGL((k_shard_expand<W, kMoveGeneral, true>), grid, dim3(kExpandThreads), lds, st, E.dev(), geo, send);
+        } else if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_expand<W, kMoveNf, false>), grid, dim3(kExpandThreads), lds, st, E.dev(), geo, send);
+        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_expand<W, kMoveNfCyclical, false>), grid, dim3(kExpandThreads), lds, st, E.dev(), geo, send);
+        else hipLaunchKernelGGL((k_shard_expand<W, kMoveGeneral, false>), grid, dim3(kExpandThreads), lds, st, E.dev(), geo, send);
     }
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
@@ -1358,15 +1483,15 @@ template <typename W> static int shard_chunk_insert(ShardEngine<W>& E, hipStream
     if (E.geo_inserted >= E.geo_count) return fail(ACX_E_INVAL, "acx_shard_chunk_insert: no expanded chunk is waiting");
     const ChunkGeo& geo = E.geos[(E.geo_head + E.geo_inserted) % ShardEngine<W>::kGeoRing];
     E.geo_inserted++;
-    const unsigned tiles = (unsigned)((geo.subcap + 255) / 256), regions = (unsigned)(kShardSub * E.world);
+    const unsigned tiles = (unsigned)((geo.subcap + 255) / 256), regions = (unsigned)(kShardSub * E.world_eff());
     unsigned gx = tiles;
     if (E.insert_wgs) gx = std::min(tiles, std::max(1u, E.insert_wgs / regions));
     if (dedup && tiles) {  // (no tiles: world 1 with born stamps -- no record ever arrives)
-        if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_insert<W, kMoveNf>), dim3(gx, regions), dim3(256), 0, st, E.d, geo, tiles);
-        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_insert<W, kMoveNfCyclical>), dim3(gx, regions), dim3(256), 0, st, E.d, geo, tiles);
-        else hipLaunchKernelGGL((k_shard_insert<W, kMoveGeneral>), dim3(gx, regions), dim3(256), 0, st, E.d, geo, tiles);
+        if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_insert<W, kMoveNf>), dim3(gx, regions), dim3(256), 0, st, E.dev(), geo, tiles);
+        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_insert<W, kMoveNfCyclical>), dim3(gx, regions), dim3(256), 0, st, E.dev(), geo, tiles);
+        else hipLaunchKernelGGL((k_shard_insert<W, kMoveGeneral>), dim3(gx, regions), dim3(256), 0, st, E.dev(), geo, tiles);
     }
-    hipLaunchKernelGGL(k_shard_pack<W>, dim3((geo.n_par + kPackParents - 1) / kPackParents), dim3(256), 0, st, E.d, geo.n_par, geo.par);
+    hipLaunchKernelGGL(k_shard_pack<W>, dim3((geo.n_par + kPackParents - 1) / kPackParents), dim3(256), 0, st, E.dev(), geo.n_par, geo.par);
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
@@ -1378,18 +1503,18 @@ template <typename W> static int shard_chunk_commit(ShardEngine<W>& E, int64_t m
     E.geo_head = (E.geo_head + 1) % ShardEngine<W>::kGeoRing;
     E.geo_count--;
     E.geo_inserted--;
-    hipLaunchKernelGGL(k_shard_scan<W>, dim3((geo.n_par + kScanTile - 1) / kScanTile), dim3(1024), 0, st, E.d, geo.n_par);
-    hipLaunchKernelGGL(k_shard_decide<W>, dim3(1), dim3(1024), 0, st, E.d, geo, max_nodes);
-    const unsigned tiles = (unsigned)((geo.subcap + 255) / 256), regions = (unsigned)(kShardSub * E.world);
+    hipLaunchKernelGGL(k_shard_scan<W>, dim3((geo.n_par + kScanTile - 1) / kScanTile), dim3(1024), 0, st, E.dev(), geo.n_par);
+    hipLaunchKernelGGL(k_shard_decide<W>, dim3(1), dim3(1024), 0, st, E.dev(), geo, max_nodes);
+    const unsigned tiles = (unsigned)((geo.subcap + 255) / 256), regions = (unsigned)(kShardSub * E.world_eff());
     unsigned gx = tiles;
     if (E.commit_wgs) gx = std::min(tiles, std::max(1u, E.commit_wgs / regions));
-    if (tiles) hipLaunchKernelGGL(k_shard_commit<W>, dim3(gx, regions), dim3(256), 0, st, E.d, geo);
+    if (tiles) hipLaunchKernelGGL(k_shard_commit<W>, dim3(gx, regions), dim3(256), 0, st, E.dev(), geo);
     const int64_t np_max = std::min<int64_t>((int64_t)geo.n_par, (int64_t)(E.lvl_hi_host - E.lvl_lo_host));  // this rank's share of the chunk's parents, at most
     if (np_max > 0) {
         const dim3 grid((unsigned)((np_max + kBornParents - 1) / kBornParents));
-        if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_commit_born<W, kMoveNf>), grid, dim3(kBornParents), 0, st, E.d, geo);
-        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_commit_born<W, kMoveNfCyclical>), grid, dim3(kBornParents), 0, st, E.d, geo);
-        else hipLaunchKernelGGL((k_shard_commit_born<W, kMoveGeneral>), grid, dim3(kBornParents), 0, st, E.d, geo);
+        if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_commit_born<W, kMoveNf>), grid, dim3(kBornParents), 0, st, E.dev(), geo);
+        else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_commit_born<W, kMoveNfCyclical>), grid, dim3(kBornParents), 0, st, E.dev(), geo);
+        else hipLaunchKernelGGL((k_shard_commit_born<W, kMoveGeneral>), grid, dim3(kBornParents), 0, st, E.dev(), geo);
     }
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
@@ -1417,6 +1542,45 @@ template <typename W> static int shard_find(ShardEngine<W>& E, int64_t gpos, int
     hipLaunchKernelGGL(k_shard_find<W>, dim3(1), dim3(1), 0, st, E.d, (uint32_t)gpos, E.d_find);
     ACX_HIP_TRY(hipMemcpyAsync(id, E.d_find, 8, hipMemcpyDeviceToHost, st));
     ACX_HIP_TRY(hipStreamSynchronize(st));
+    return ACX_OK;
+}
+
+
+// end of the replicated phase: this rank's share of the newest level becomes its frontier slice (k_shard_part_*).  Called between two
+// levels, by every rank, after the level's last control block has been read (acx_shard_ctl_wait): the host mirror then knows the
+// nodes [lvl_hi_host, nodes_host) of the newest level.  Synchronises once (the number of copies comes back).
+template <typename W> static int shard_partition(ShardEngine<W>& E, hipStream_t st) {
+    if (int rc = E.await_ready(st)) return rc;
+    if (!E.replicated) return fail(ACX_E_INVAL, "acx_shard_partition: the engine is not in its replicated phase");
+    if (E.geo_count) return fail(ACX_E_INVAL, "acx_shard_partition: chunks are in flight (commit them first)");
+    E.replicated = false;
+    const uint64_t nodes_old = E.nodes_host, base = E.lvl_hi_host, n = nodes_old - base;
+    E.own_from = nodes_old;
+    E.lvl_hi_host = nodes_old;  // the next chunk's level switch: [nodes_old, nodes_old + copies)
+    if (E.world == 1) return ACX_OK;  // (a one-rank engine owns everything: the level is its slice as it stands)
+    if (n) {
+        const unsigned tiles = (unsigned)((n + kPartTile - 1) / kPartTile);
+        hipLaunchKernelGGL(k_shard_part_count<W>, dim3(tiles), dim3(kPartTile), 0, st, E.d, (uint32_t)base, (uint32_t)n, E.part_cnt);
+        hipLaunchKernelGGL(k_shard_part_scan<W>, dim3(1), dim3(1024), 0, st, E.d, tiles, E.part_cnt, (uint32_t)nodes_old);
+        hipLaunchKernelGGL(k_shard_part_write<W>, dim3(tiles), dim3(kPartTile), 0, st, E.d, (uint32_t)base, (uint32_t)n, E.part_cnt, (uint32_t)nodes_old);
+        ACX_HIP_TRY(hipGetLastError());
+    }
+    unsigned long long now = 0;
+    ACX_HIP_TRY(hipMemcpyAsync(&now, E.d.ctl + C_NODES, 8, hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
+    E.nodes_host = now;
+    return ACX_OK;
+}
+
+template <typename W> static int shard_walk(ShardEngine<W>& E, int64_t id, int64_t cap, int64_t* out, hipStream_t st) {
+    if (int rc = E.await_ready(st)) return rc;
+    if (id < 0 || (uint64_t)id >= E.cap_nodes || cap < 1) return fail(ACX_E_INVAL, "acx_shard_walk: bad argument");
+    const uint32_t c = (uint32_t)std::min<int64_t>(cap, ShardEngine<W>::kWalkCap);
+    hipLaunchKernelGGL(k_shard_walk<W>, dim3(1), dim3(1), 0, st, E.d, (uint32_t)id, c, E.d_walk);
+    ACX_HIP_TRY(hipGetLastError());
+    ACX_HIP_TRY(hipMemcpyAsync(out, E.d_walk, 16, hipMemcpyDeviceToHost, st));
+    ACX_HIP_TRY(hipStreamSynchronize(st));
+    if (out[1] > 0) ACX_HIP_TRY(hipMemcpy(out + 2, E.d_walk + 2, (size_t)out[1] * 16, hipMemcpyDeviceToHost));
     return ACX_OK;
 }
 
@@ -1562,12 +1726,33 @@ int acx_shard_check_owners(acx_shard* h, int64_t* n_bad, void* stream) {
         hipStream_t st = (hipStream_t)stream;
         if (int rc = E.await_ready(st)) return rc;
         ACX_HIP_TRY(hipMemsetAsync(E.d_find, 0, 8, st));
-        hipLaunchKernelGGL(k_shard_check_owners<W>, dim3(1024), dim3(256), 0, st, E.d, (unsigned long long*)E.d_find);
+        hipLaunchKernelGGL(k_shard_check_owners<W>, dim3(1024), dim3(256), 0, st, E.d, (uint32_t)E.own_from, (unsigned long long*)E.d_find);
         ACX_HIP_TRY(hipGetLastError());
         ACX_HIP_TRY(hipMemcpyAsync(n_bad, E.d_find, 8, hipMemcpyDeviceToHost, st));
         ACX_HIP_TRY(hipStreamSynchronize(st));
     });
     return ACX_OK;
+}
+
+
+int acx_shard_set_replicated(acx_shard* h, int on) {
+    if (!h) return fail(ACX_E_INVAL, "acx_shard_set_replicated: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, {
+        if (on && (E.nodes_host || E.chunk_seq)) return fail(ACX_E_INVAL, "acx_shard_set_replicated: only before the root is seeded");
+        if (!on && E.replicated) return fail(ACX_E_INVAL, "acx_shard_set_replicated: a replicated phase ends with acx_shard_partition");
+        E.replicated = on != 0;
+    });
+    return ACX_OK;
+}
+
+int acx_shard_partition(acx_shard* h, void* stream) {
+    if (!h) return fail(ACX_E_INVAL, "acx_shard_partition: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, return shard_partition<W>(E, (hipStream_t)stream));
+}
+
+int acx_shard_walk(acx_shard* h, int64_t id, int64_t cap, int64_t* h_out, void* stream) {
+    if (!h || !h_out) return fail(ACX_E_INVAL, "acx_shard_walk: bad argument");
+    ACX_SHARD_DISPATCH(&h->any, return shard_walk<W>(E, id, cap, h_out, (hipStream_t)stream));
 }
 
 int acx_shard_find(acx_shard* h, int64_t gpos, int64_t* id, void* stream) {

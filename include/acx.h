@@ -317,6 +317,20 @@ int acx_shard_ctl_snapshot(acx_shard *h, int slot, void *stream);
 int acx_shard_ctl_wait(acx_shard *h, int slot, int64_t *h_ctl);
 /* mark this rank as failed (an exception on the caller's side): travels to every rank with the next chunk's headers */
 int acx_shard_fail(acx_shard *h, void *stream);
+/* Replicated small levels (round 6).  acx_shard_set_replicated(h, 1), before the root is seeded and on EVERY rank (each of which then
+ * seeds the root): the levels that follow are processed WHOLE by every rank with the world-1 kernels -- acx_shard_layout with world 1,
+ * no all-to-all, no mask all-reduce; every rank commits the same nodes in the same order, each parent reference naming the rank itself.
+ * acx_shard_partition ends the phase between two levels (after the level's last acx_shard_ctl_wait, no chunk in flight): of the newest
+ * level a rank keeps copies of the nodes it owns (acx_shard_owner) as its slice of the next level; from then on the chunks are exchanged
+ * as described above.  A search that ends inside the replicated phase has needed no collective at all.  Reference semantics unchanged
+ * (breadth_first.py:61-95): the partition only changes WHO expands a frontier node. */
+int acx_shard_set_replicated(acx_shard *h, int on);
+int acx_shard_partition(acx_shard *h, void *stream);
+/* the path of local node `id` towards the root while the parents are local: h_out[0] = the first parent reference that is not local
+ * (rank << 40 | id on that rank; -1: the root was reached), h_out[1] = n <= cap (<= 1024), then n pairs (action, total length), node
+ * `id` first, the root's action -1.  h_out: 2 + 2 * cap words.  (One launch + one copy per SEGMENT of a path instead of
+ * acx_shard_node_info's synchronisation per node.) */
+int acx_shard_walk(acx_shard *h, int64_t id, int64_t cap, int64_t *h_out, void *stream);
 /* local id of the node of the running level at global position gpos, -1 when another rank owns it */
 int acx_shard_find(acx_shard *h, int64_t gpos, int64_t *id, void *stream);
 /* h_info3 = (action, total_length, parent_ref = rank << 40 | local id) of a local node; the root has action -1, parent_ref -1 */

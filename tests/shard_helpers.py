@@ -100,13 +100,52 @@ class OracleShardEngine:
         self.inverse_dropped = 0
         self.open, self.inserted = [], 0
         self.fill_min_even = FILL_MIN_EVEN
+        self.replicated = False
+        self.own_from = 0
+
+    @property
+    def world_eff(self):
+        return 1 if self.replicated else self.world
 
     def layout(self, n_par, fill_q8=0):
-        return layout(n_par, self.world, self.KW, fill_q8)
+        return layout(n_par, self.world_eff, self.KW, fill_q8)
 
     def layout_words(self, n_par, fill_q8=0):
         s, _, rw = self.layout(n_par, fill_q8)
-        return s * self.world * rw
+        return s * self.world_eff * rw
+
+    def set_replicated(self):
+        """csrc/acx_shard.hip acx_shard_set_replicated: whole levels on every rank, as world 1, until partition()"""
+        assert not self.states
+        self.replicated = True
+
+    def partition(self):
+        """acx_shard_partition: copies of the newest level's nodes this rank owns become its slice of the next level"""
+        from ac_solver.search.sharded import owner_of
+
+        assert self.replicated and not self.open
+        self.replicated = False
+        base, n_old = self.lvl_hi, len(self.states)
+        self.own_from = n_old
+        for nid in range(base, n_old):
+            k0, k1 = key_of_state(self.states[nid], self.L)
+            if int(owner_of(torch.tensor([[k0, k1]], dtype=torch.int64), self.world)[0]) == self.rank:
+                self.states.append(self.states[nid])
+                self.prefs.append(self.prefs[nid])
+                self.acts.append(self.acts[nid])
+                self.tlens.append(self.tlens[nid])
+                self.gpos.append(self.gpos[nid])
+        self.lvl_hi = n_old  # the next level switch makes [n_old, len(states)) the running level
+        self.ctl[5] = len(self.states)
+
+    def walk(self, nid, cap=256):
+        pairs = []
+        while True:
+            pref = self.prefs[nid]
+            pairs.append((-1 if pref < 0 else self.acts[nid], self.tlens[nid]))
+            if pref < 0 or (pref >> 40) != self.rank or len(pairs) == cap:
+                return pref, pairs
+            nid = pref & ((1 << 40) - 1)
 
     def root_record(self, p):
         p = np.asarray(p)
@@ -133,17 +172,18 @@ class OracleShardEngine:
 
         n_par = c1 - c0
         S, cap, rw = self.layout(n_par, fill_q8)
-        send = torch.zeros(S * self.world * rw, dtype=torch.int64)
-        recv = torch.zeros_like(send) if self.world > 1 else send
+        we = self.world_eff
+        send = torch.zeros(S * we * rw, dtype=torch.int64)
+        recv = torch.zeros_like(send) if we > 1 else send
         born = []  # children of local parents that this rank owns itself: they never travel (the HIP engine: BORN stamps)
-        self.open.append(((c0, n_par, S, cap, rw), recv, born))  # the orchestrator expands chunk k + 1 before it inserts chunk k
+        self.open.append(((c0, n_par, S, cap, rw, we), recv, born))  # the orchestrator expands chunk k + 1 before it inserts chunk k
         if self.ctl[0] != 0:
             return send, recv
         if level_first:
             self.lvl_lo, self.lvl_hi = self.lvl_hi, len(self.states)
             self.ctl[2] = 0
             self.ctl[12] = 0
-        regs = send.view(S * self.world, rw)
+        regs = send.view(S * we, rw)
         regs[:, 1] = INF
         regs[:, 2] = INF
         regs[:, 3] = int(self.ctl[8])
@@ -169,7 +209,7 @@ class OracleShardEngine:
                     self.inverse_dropped += 1
                     continue
                 k0, k1 = key_of_state(out[a], self.L)
-                o = int(owner_of(torch.tensor([[k0, k1]], dtype=torch.int64), self.world)[0])
+                o = self.rank if we == 1 else int(owner_of(torch.tensor([[k0, k1]], dtype=torch.int64), self.world)[0])
                 if o == self.rank:
                     born.append((tag - 12 * c0, k0, k1, (self.rank << 40) | nid))
                     continue
@@ -203,13 +243,13 @@ class OracleShardEngine:
     def chunk_insert(self, n_par):
         self.geo, self.recv, born = self.open[self.inserted]
         self.inserted += 1
-        c0, n_par, S, cap, rw = self.geo
+        c0, n_par, S, cap, rw, we = self.geo
         self.gmask_view(n_par)
         if self.ctl[0] != 0:
             return self.packed
-        regs = self.recv.view(S * self.world, rw)
+        regs = self.recv.view(S * we, rw)
         recs = list(born)
-        for r in range(S * self.world):
+        for r in range(S * we):
             n = int(regs[r, 0])
             if n > cap:
                 self.ctl[8] = max(int(self.ctl[8]), 1)
@@ -241,9 +281,9 @@ class OracleShardEngine:
         self.inserted = max(self.inserted - 1, 0)
         if self.ctl[0] != 0:
             return
-        c0, n_par, S, cap, rw = self.geo
-        regs = self.recv.view(S * self.world, rw)
-        even = even_share(n_par, self.world)
+        c0, n_par, S, cap, rw, we = self.geo
+        regs = self.recv.view(S * we, rw)
+        even = even_share(n_par, we)
         if even >= self.fill_min_even:  # the fullest region of the level, in 1/256 of the even share
             self.ctl[12] = max(int(self.ctl[12]), -(-int(regs[:, 0].max()) * 256 // even))
         fail = int(regs[:, 3].max())

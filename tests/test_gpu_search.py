@@ -284,15 +284,25 @@ def test_sharded_bfs_hip_engine_matches_reference(search, golden_json, world):
 
     def run(comm):
         # (the three schedules of the side stream in turn: whatever the world size defaults to, every rank count sees all of them)
-        return [bfs_sharded(p, b, cyclically_reduce_after_moves=c, comm=comm, batch_parents=bp, want_stats=True, overlap=("insert", "commit", False, None)[k % 4])
-                for k, (p, b, c, bp) in enumerate(cases)]
+        # replicate_below (round 6): every level exchanged (0), the frontier partitioned by owner after a few small levels (20, 700),
+        # the default (2^18: these searches stay replicated to their end -- no collective but the closing all-reduce)
+        out = []
+        for repl in (0, 20, 700, None):
+            out.append([bfs_sharded(p, b, cyclically_reduce_after_moves=c, comm=comm, batch_parents=bp, want_stats=True, overlap=("insert", "commit", False, None)[k % 4],
+                                    replicate_below=repl) for k, (p, b, c, bp) in enumerate(cases)])
+        return out
 
     results = [run(SingleComm())] if world == 1 else run_threads(world, run)
-    for res in results:
-        for (p, b, c, bp), (ok, path, st) in zip(cases, res):
-            wok, wpath, wst = O.bfs(p, b, cyclically_reduce_after_moves=c, stats=True)
-            assert (ok, path) == (wok, wpath), (world, b, c)
-            assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (world, b, c, st, wst)
+    want = [O.bfs(p, b, cyclically_reduce_after_moves=c, stats=True) for p, b, c, bp in cases]
+    for per_repl in results:
+        for repl, res in zip((0, 20, 700, None), per_repl):
+            for (p, b, c, bp), (ok, path, st), (wok, wpath, wst) in zip(cases, res, want):
+                assert (ok, path) == (wok, wpath), (world, b, c, repl)
+                assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (world, b, c, repl, st, wst)
+                if world > 1 and repl is None:
+                    assert st["replicated_levels"] == st["levels"] and st.get("comm_all_to_all_calls", 0) == 0, (world, repl, st)
+            if world > 1 and repl in (20, 700):  # some search was partitioned in mid-flight
+                assert any(0 < st["replicated_levels"] < st["levels"] for _, _, st in res), (world, repl)
 
 
 @pytest.mark.timeout(600)
@@ -318,14 +328,21 @@ def test_sharded_bfs_mid_size_thread_ranks_equal_the_fused_search(search, golden
     want = [run_search(_acx.SEARCH_BFS, p, b, c) for p, b, c, _ in cases]
 
     def run(comm):
-        return [bfs_sharded(p, b, cyclically_reduce_after_moves=c, comm=comm, batch_parents=bp, want_stats=True) for p, b, c, bp in cases]
+        # every level exchanged, then the small levels replicated (partition at the first level of >= 2^12 / the default 2^18 parents)
+        return [[bfs_sharded(p, b, cyclically_reduce_after_moves=c, comm=comm, batch_parents=bp, want_stats=True, replicate_below=repl) for p, b, c, bp in cases]
+                for repl in (0, 1 << 12, None)]
 
     all_res = run_threads(world, run)
-    for res in all_res:
-        for (ok, path, st), (wok, wpath, wst) in zip(res, want):
-            assert (ok, path) == (wok, wpath)
-            assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (world, st, wst)
-            assert st["owner_mismatches"] == 0, (world, st)
+    for per_repl in all_res:
+        for repl, res in zip((0, 1 << 12, None), per_repl):
+            for (ok, path, st), (wok, wpath, wst) in zip(res, want):
+                assert (ok, path) == (wok, wpath), (world, repl)
+                assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (world, repl, st, wst)
+                assert st["owner_mismatches"] == 0, (world, repl, st)
+                if repl:
+                    assert 0 < st["replicated_levels"] < st["levels"], (world, repl, st)
+    all_res = [per_repl[0] for per_repl in all_res]  # (what follows looks at the searches with every level exchanged)
+    res = all_res[-1]
     # the ranks' shares of the nodes: the owner function spreads them (1.03-1.10 x the mean at 8 ranks on these searches)
     for k in range(len(cases)):
         shares = [res[k][2]["local_nodes"] for res in all_res]

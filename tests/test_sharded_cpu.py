@@ -26,13 +26,22 @@ def _strip(results):
     return [(ok, path, {k: v for k, v in st.items() if not k.endswith("_seconds") and k != "local_nodes"}) for ok, path, st in results]
 
 
-def _run(comm, batch, cases=None):
+@pytest.fixture(autouse=True)
+def _every_level_exchanged_unless_asked(monkeypatch):
+    """The tests of this module that do not say otherwise run the exchange from the root on (rounds 3-5: `replicate_below` 0); the
+    replicated phase of round 6 is what the tests that pass `replicate_below` themselves exercise."""
+    from ac_solver.search import sharded
+
+    monkeypatch.setattr(sharded, "REPLICATE_BELOW", 0)
+
+
+def _run(comm, batch, cases=None, repl=0):
     from ac_solver.search.sharded import bfs_sharded
 
     res = []
     for p, budget, cyc in cases or CASES:
         res.append(bfs_sharded(p, budget, cyclically_reduce_after_moves=cyc, comm=comm, engine_factory=OracleShardEngine,
-                               batch_parents=batch, want_stats=True))
+                               batch_parents=batch, want_stats=True, replicate_below=repl))
     return res
 
 
@@ -43,16 +52,88 @@ def _check(results, cases=None):
         assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (budget, cyc, st, wst)
 
 
-@pytest.mark.parametrize("world,batch", [(1, 1 << 18), (2, 1 << 18), (3, 7), (4, 64)])
-def test_thread_ranks_match_reference(world, batch):
+@pytest.mark.parametrize("world,batch,repl", [(1, 1 << 18, 0), (2, 1 << 18, 0), (3, 7, 0), (4, 64, 0), (2, 1 << 18, 1 << 18), (2, 64, 6), (3, 7, 40), (4, 64, 150)])
+def test_thread_ranks_match_reference(world, batch, repl):
+    """`repl` = replicate_below: 0 exchanges every level; 2^18 keeps these searches replicated to their end (ONE all-reduce per search);
+    6 / 40 / 150 partition the frontier after a few levels, in the middle of the search"""
     from ac_solver.search.sharded import SingleComm
 
     if world == 1:
         _check(_run(SingleComm(), batch))
         return
     cases = CASES if batch > 1000 else SMALL  # (the NumPy engine is slow: tiny chunks get smaller budgets)
-    for res in run_threads(world, lambda comm: _run(comm, batch, cases)):
+    for res in run_threads(world, lambda comm: _run(comm, batch, cases, repl)):
         _check(res, cases)
+        for k, ((p, budget, cyc), (ok, path, st)) in enumerate(zip(cases, res)):
+            if repl >= 1 << 18:  # (the communicator's counters run on from search to search)
+                assert st["comm_all_to_all_calls"] == 0 and st["comm_all_reduce_calls"] == k + 1 and st["replicated_levels"] == st["levels"], st
+            elif repl and st["levels"] > st["replicated_levels"]:
+                assert st["replicated_levels"] >= 1 and st["comm_all_to_all_calls"] > 0, st
+
+
+def test_replicated_phase_saves_the_small_levels_collectives():
+    """the same search with every level exchanged and with the levels below 40 parents replicated: identical result, fewer collectives"""
+    def work(comm):
+        a = _run(comm, 64, SMALL[:1], 0)[0]
+        b = _run(comm, 64, SMALL[:1], 40)[0]
+        return a, b
+
+    for a, b in run_threads(3, work):
+        assert a[:2] == b[:2] and a[2]["nodes"] == b[2]["nodes"] and a[2]["expanded"] == b[2]["expanded"]
+        assert b[2]["replicated_levels"] >= 3
+        # (the communicator's counters run on from search to search: b's are a's + its own)
+        assert b[2]["comm_all_reduce_calls"] - a[2]["comm_all_reduce_calls"] < a[2]["comm_all_reduce_calls"]
+        assert b[2]["comm_all_to_all_calls"] - a[2]["comm_all_to_all_calls"] < a[2]["comm_all_to_all_calls"]
+
+
+@pytest.mark.parametrize("where", ["chunk_expand", "chunk_insert", "chunk_commit", "partition"])
+def test_a_failure_in_the_replicated_phase_ends_every_rank(where):
+    """An engine call of ONE rank raises while the levels are still replicated (no per-level collective pairs the ranks there), or in
+    the partition itself: every rank must raise, with the same collectives issued -- the healthy ranks at the phase's closing all-reduce
+    or, for the partition, at the first exchanged chunk's headers."""
+    from ac_solver.search.sharded import bfs_sharded
+
+    for fail_at in (1, 2, 5):
+        calls = {}
+
+        class Flaky(OracleShardEngine):
+            def _maybe(self, name):
+                if name == where and self.rank == 1:
+                    calls[name] = calls.get(name, 0) + 1
+                    if calls[name] == fail_at:
+                        raise RuntimeError("engine call failed (simulated)")
+
+            def chunk_expand(self, *a, **k):
+                self._maybe("chunk_expand")
+                return super().chunk_expand(*a, **k)
+
+            def chunk_insert(self, n_par):
+                self._maybe("chunk_insert")
+                return super().chunk_insert(n_par)
+
+            def chunk_commit(self, max_nodes):
+                self._maybe("chunk_commit")
+                return super().chunk_commit(max_nodes)
+
+            def partition(self):
+                self._maybe("partition")
+                return super().partition()
+
+        def run(comm):
+            try:
+                bfs_sharded(AK2, 4000, comm=comm, engine_factory=Flaky, batch_parents=32, replicate_below=60)
+            except RuntimeError as e:
+                return str(e), dict(comm.stats)
+            return "no error", dict(comm.stats)
+
+        out = run_threads(3, run)
+        msgs = [m for m, _ in out]
+        if calls.get(where, 0) < fail_at:  # (one partition per search)
+            assert all(m == "no error" for m in msgs), (fail_at, msgs)
+            continue
+        assert all("sharded bfs failed" in m for m in msgs), (where, fail_at, msgs)
+        assert "simulated" in msgs[1], (where, fail_at, msgs)
+        assert out[0][1] == out[1][1] == out[2][1], (where, fail_at, [st for _, st in out])
 
 
 def _gloo_worker(rank, world, port, q):
@@ -62,11 +143,12 @@ def _gloo_worker(rank, world, port, q):
         from ac_solver.search.sharded import TorchDistComm
 
         res = _run(TorchDistComm(torch.device("cpu")), 50)
+        res_repl = _run(TorchDistComm(torch.device("cpu")), 50, SMALL, 25)  # small levels replicated, the frontier partitioned at 25 parents
         # the mask all-reduce on a communicator of its own (dist.new_group): what bench.py times next to the shared one on N > 1 GPUs
         own = TorchDistComm(torch.device("cpu"), mask_group="own")
         res_own = _run(own, 50, SMALL)
         assert own.stats["mask_all_reduce_calls"] > 0 and own.mask_group is not own.group
-        q.put((rank, res, res_own))
+        q.put((rank, res, res_own, res_repl))
     finally:
         dist.destroy_process_group()
 
@@ -80,13 +162,17 @@ def test_gloo_world2_matches_reference():
     procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in procs]
     rows = [q.get(timeout=400) for _ in range(2)]
-    got = {r: a for r, a, _ in rows}
-    got_own = {r: b for r, _, b in rows}
+    got = {r: a for r, a, _, _ in rows}
+    got_own = {r: b for r, _, b, _ in rows}
+    got_repl = {r: c for r, _, _, c in rows}
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     _check(got[0])
     assert _strip(got[0]) == _strip(got[1])  # every rank returns the same answer
     _check(got_own[0], SMALL)
+    _check(got_repl[0], SMALL)
+    assert _strip(got_repl[0]) == _strip(got_repl[1])
+    assert any(0 < st["replicated_levels"] < st["levels"] for _, _, st in got_repl[0])  # some search was partitioned in mid-flight
     strip_comm = lambda res: [(ok, path, {k: v for k, v in st.items() if not k.startswith("comm_")}) for ok, path, st in _strip(res)]  # noqa: E731
     assert strip_comm(got_own[0]) == strip_comm(got_own[1])
 
