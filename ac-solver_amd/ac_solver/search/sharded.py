@@ -159,7 +159,7 @@ class HipShardEngine:
             words = 8 + int(full * (est_parents / self.B + 2)) + 64 * 40  # (+ the header-only regions of the replicated levels' chunks)
             self.log = torch.empty(words, dtype=torch.int64, device=self.device)
             self.send = torch.empty(full, dtype=torch.int64, device=self.device) if world > 1 else None
-            self.gmask = torch.empty((self.B + 1) // 2, dtype=torch.int32, device=self.device)  # two parents' 12-bit masks per word
+            self.gmask = torch.empty((self.B + 3) // 4 * 2, dtype=torch.int32, device=self.device)  # two parents' 12-bit masks per word; whole quads of parents (the kernels move four at a time)
             self._attach()
         self._cursor = 8  # host mirror of the engine's log cursor (deterministic: it advances by the chunk's words)
         self._ctl = np.zeros(CTL_WORDS, np.int64)

@@ -168,14 +168,14 @@ template <typename W> struct ShardDev {
     uint32_t stmask;
     uint32_t epoch;      // of this engine's stamps (1 .. 254)
     int64_t* log;        // record log = receive areas of all chunks
-    uint8_t* btook;      // one byte per tag of a chunk: took a slot / was pushed out again (both zero between chunks); TWO sets, `flag_stride`
-    uint8_t* brepl;      // bytes apart, indexed by the chunk's parity (ChunkGeo::par): the expansion of chunk k + 1 claims beside the dedup of chunk k
-    size_t flag_stride;
-    int32_t* lmask;      // [chunk parents] 12-bit masks: new states of this rank
+    uint32_t* tk;        // one word per PARENT of a chunk, bit a: child (parent, a) took a slot / was pushed out again (all zero between chunks).
+    uint32_t* rp;        // Round 6: bits instead of one byte per tag (k_shard_pack read 24 bytes per parent on every rank, now 8).  TWO sets,
+    size_t flag_stride;  // `flag_stride` words apart, indexed by the chunk's parity (ChunkGeo::par): the expansion of chunk k + 1 claims beside the dedup of chunk k
+    uint32_t* lmp;       // [chunk parents] bits 0..11: new states of this rank among the parent's children; bits 12..27: their exclusive count over the
+                         // earlier parents of the parent's kScanTile tile (k_shard_pack writes both)
+    uint32_t* gmp;       // the same from the all-reduced masks (k_shard_scan)
     int32_t* gmask;      // the same for all ranks after the caller's all-reduce, TWO parents per word (parent p: bits 16 (p & 1) .. + 11 of word
                          // p >> 1): every (parent, action) child has one owner, so the sum of the ranks' words is their union and no field carries
-    uint32_t* lpre;      // exclusive popcount prefix inside a kScanTile tile
-    uint32_t* gpre;
     uint32_t* lblk;      // per tile: total, turned into the exclusive prefix over the tiles by k_shard_decide
     uint32_t* gblk;
     unsigned long long* ctl;
@@ -345,7 +345,7 @@ __device__ __forceinline__ uint32_t inverse_action(uint32_t a) { return a < 4 ? 
 // are 1536 consecutive bytes), as in the fused search.
 template <typename W, int MODE, bool SOLO>
 __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, ChunkGeo g, int64_t* __restrict__ send) {
-    __shared__ uint32_t s_took[SOLO ? kExpandTile / 4 : 1];  // one byte per tag of the tile
+    __shared__ uint32_t s_tk[kExpandParents];  // bit a of word l: child a of the tile's parent l took a slot
     __shared__ W s_k0[kExpandTile];
     __shared__ W s_k1[kExpandTile];
     __shared__ uint32_t s_slot[kFoldSlots];
@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
     for (uint32_t i = tid; i < (uint32_t)kFoldSlots; i += kExpandThreads) s_slot[i] = kEmpty;
     if (!SOLO)
         for (uint32_t i = tid; i < d.world * (uint32_t)kExpandParents; i += kExpandThreads) s_bits[i] = 0;
-    if (SOLO && tid < (uint32_t)kExpandTile / 4) s_took[tid] = 0;
+    if (tid < (uint32_t)kExpandParents) s_tk[tid] = 0;
     // this lane's parent (the same for its three actions)
     const uint32_t p = blockIdx.x * kExpandParents + l, id = s_lo + p;
     const bool live = p < np;
@@ -523,8 +523,8 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
     // was dedup'ed before this kernel started, or -- on the main stream, beside this kernel -- the chunk before mine: smaller tags
     // either way) or a born child; a born child of MY chunk (its parent is one of this chunk's local parents: id >= s_lo) folds
     // with me by (parent, action), which IS the tag order; every other occupant with my key has been seen before me.
-    uint8_t* __restrict__ btook = d.btook + g.par * d.flag_stride;
-    uint8_t* __restrict__ brepl = d.brepl + g.par * d.flag_stride;
+    uint32_t* __restrict__ tk = d.tk + g.par * d.flag_stride;
+    uint32_t* __restrict__ rp = d.rp + g.par * d.flag_stride;
 #pragma unroll
     for (int it = 0; it < kExpandItems; it++) {
         if (!born[it]) continue;
@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
                     const unsigned long long old = atomicCAS(slot, st, mine);  // push the larger tag of my chunk out
                     if (old == st) {
                         took = true;
-                        brepl[12u * (d.gpos[born_parent(st)] - (uint32_t)g.c0) + born_action(st)] = 1;  // no longer the first discoverer
+                        atomicOr(rp + (d.gpos[born_parent(st)] - (uint32_t)g.c0), 1u << born_action(st));  // no longer the first discoverer
                         break;
                     }
                     st = old;  // somebody else replaced it meanwhile: look again
@@ -574,16 +574,13 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
                 open = false;
             }
         }
-        if (took) {
-            if (SOLO) ((uint8_t*)s_took)[12u * l + a] = 1;
-            else btook[12u * (gp - (uint32_t)g.c0) + a] = 1;
-        }
+        if (took) atomicOr(&s_tk[l], 1u << a);
     }
-    if (SOLO) {  // btook of the tile's tags, coalesced (zero = did not take a slot)
-        __syncthreads();
-        const uint32_t t0 = 12u * (s_lo - d.bounds[2 * g.par] + blockIdx.x * (uint32_t)kExpandParents);  // the tile's first parent is local parent blockIdx.x * 128 = position c0 + that
-        if (tid < (uint32_t)kExpandTile / 4 && t0 + 4u * tid < 12u * np) ((uint32_t*)(btook + t0))[tid] = s_took[tid];
-    }
+    // the took-bits of the tile's parents: ONE plain store per parent -- a chunk's word of a LOCAL parent is written by nobody else (a
+    // record this rank receives is the child of another rank's parent).  SOLO: the chunk's local parents are ALL its parents, the tile's
+    // words are 128 consecutive ones (coalesced); else the parent's position in the chunk is its gpos.
+    __syncthreads();
+    if (w == 0 && live && s_tk[l]) tk[SOLO ? p : gp - (uint32_t)g.c0] = s_tk[l];
 }
 
 // ---- dedup of the received records ------------------------------------------------------------------------------------------
@@ -607,9 +604,9 @@ template <typename W, int MODE> __device__ __forceinline__ void shard_insert_til
     const uint32_t tag = (uint32_t)((unsigned long long)rec[recio<W>::KW] >> 32);
     const uint64_t hk = shard_hash(c0, c1);
     const unsigned long long me = stamp_top(hk, d.epoch) | (unsigned long long)off;
-    uint8_t* __restrict__ btook = d.btook + g.par * d.flag_stride;
-    uint8_t* __restrict__ brepl = d.brepl + g.par * d.flag_stride;
-    uint8_t* __restrict__ brepl_next = d.brepl + (g.par ^ 1u) * d.flag_stride;
+    uint32_t* __restrict__ tk = d.tk + g.par * d.flag_stride;
+    uint32_t* __restrict__ rp = d.rp + g.par * d.flag_stride;
+    uint32_t* __restrict__ rp_next = d.rp + (g.par ^ 1u) * d.flag_stride;
     const uint32_t b0 = d.bounds[2 * g.par], b1 = d.bounds[2 * g.par + 1];  // this chunk's local parents
     uint32_t base = (uint32_t)hk & d.stmask & ~3u, probes = 0, took = 0;
     bool open = true;
@@ -638,7 +635,8 @@ template <typename W, int MODE> __device__ __forceinline__ void shard_insert_til
                 stamp_key<W, MODE>(d, st, q0, q1);
                 if (q0 != c0 || q1 != c1) break;  // same fingerprint, other key: next slot
                 open = false;
-                uint8_t* flag;  // where the holder is flagged when I push it out
+                uint32_t* flag;  // where the holder is flagged when I push it out: word of its parent, bit of its action
+                uint32_t fbit;
                 if (st & kStampBorn) {
                     const uint32_t hp = born_parent(st);
                     if (hp < b0) break;  // a child of an earlier chunk or level: seen before
@@ -646,21 +644,23 @@ template <typename W, int MODE> __device__ __forceinline__ void shard_insert_til
                     if (hp < b1) {  // a born child of THIS chunk
                         const uint32_t otag = 12u * (ogp - (uint32_t)g.c0) + born_action(st);
                         if (otag < tag) break;
-                        flag = brepl + otag;
+                        flag = rp + (ogp - (uint32_t)g.c0);
                     } else {  // of the NEXT chunk (its expansion runs beside me on the side stream): every tag of mine is smaller
-                        flag = brepl_next + 12u * (ogp - (uint32_t)g.c0 - g.n_par) + born_action(st);
+                        flag = rp_next + (ogp - (uint32_t)g.c0 - g.n_par);
                     }
+                    fbit = 1u << born_action(st);
                 } else {
                     const int64_t qoff = (int64_t)(st & kStampOff);
                     if (qoff < g.log_off) break;  // a record of an earlier chunk: seen before
                     const uint32_t qtag = (uint32_t)((unsigned long long)d.log[qoff + recio<W>::KW] >> 32);
                     if (qtag < tag) break;  // a record of this chunk with a smaller tag holds it
-                    flag = brepl + qtag;
+                    flag = rp + qtag / 12u;
+                    fbit = 1u << (qtag % 12u);
                 }
                 const unsigned long long old = atomicCAS(slot, st, me);  // push the larger tag out
                 if (old == st) {
                     took = 1;
-                    *flag = 1;  // no longer the first discoverer
+                    atomicOr(flag, fbit);  // no longer the first discoverer
                     break;
                 }
                 st = old;  // somebody else replaced it meanwhile: look again
@@ -673,7 +673,7 @@ template <typename W, int MODE> __device__ __forceinline__ void shard_insert_til
             open = false;
         }
     }
-    if (took) btook[tag] = 1;
+    if (took) atomicOr(tk + tag / 12u, 1u << (tag % 12u));
 }
 
 // grid (x, regions): x = tiles per region, or FEWER -- then a workgroup walks the tiles of its region x, x + gridDim.x, ...: a
@@ -685,89 +685,96 @@ __global__ void __launch_bounds__(256) k_shard_insert(ShardDev<W> d, ChunkGeo g,
     for (uint32_t bx = blockIdx.x; bx < tiles; bx += gridDim.x) shard_insert_tile<W, MODE>(d, g, blockIdx.y, bx);
 }
 
-// one 12-bit mask per parent of the chunk: bit a set when child (parent, a) is a new state of this rank; the flags it read are
-// zeroed again for the next chunk (no memset launches).  Two parents share a word of gmask.  A workgroup serves kPackParents
-// parents = 3072 flag bytes of each array, read as 192 coalesced 16-byte vectors, squeezed to one bit per flag in LDS, from
-// where every lane takes the 12 bits of its parent (a lane per parent reading its own 12 bytes as three dwords at a 12-byte
-// stride: 42 us per 2^21-parent chunk instead of 26).
-constexpr int kPackParents = 256;
-template <typename W> __global__ void __launch_bounds__(256) k_shard_pack(ShardDev<W> d, uint32_t n_par, uint32_t par) {
-    __shared__ uint16_t s_flag[kPackParents * 12 / 16 + 2];
-    ACX_VGPR_PAD("v31");
+// One word per parent of the chunk: bits 0..11 = the children (parent, a) that are new states of this rank (took a slot and were not
+// pushed out again), bits 12..27 = how many such children the earlier parents of the same kScanTile tile have; the tile's total goes
+// to lblk.  The flag words it read are zeroed again for the next chunk of the same parity (no memset launches).  Two parents share a
+// word of gmask (the all-reduce's buffer).  Round 6: the flags are one word per parent (8 bytes read per parent instead of 24) and the
+// local prefix is computed here (k_shard_scan only has the all-reduced masks left): a workgroup = one tile, four parents per lane.
+template <typename W> __global__ void __launch_bounds__(1024) k_shard_pack(ShardDev<W> d, uint32_t n_par, uint32_t par) {
+    __shared__ uint32_t s_w[16];
+    ACX_VGPR_PAD("v39");
     if (d.ctl[C_STATUS] != 0) return;
-    const uint32_t tid = threadIdx.x, p0 = blockIdx.x * kPackParents;
-    if (p0 >= n_par) return;
-    constexpr uint32_t kVecs = kPackParents * 12 / 16;
-    if (tid < kVecs) {  // (the arrays are padded by a tile: flags behind the chunk's last parent are zero and stay zero)
-        uint4* t = (uint4*)(d.btook + par * d.flag_stride + 12 * (size_t)p0) + tid;
-        uint4* r = (uint4*)(d.brepl + par * d.flag_stride + 12 * (size_t)p0) + tid;
-        const uint4 tv = *t, rv = *r;
-        if (tv.x | tv.y | tv.z | tv.w) *t = make_uint4(0, 0, 0, 0);
-        if (rv.x | rv.y | rv.z | rv.w) *r = make_uint4(0, 0, 0, 0);
-        auto squeeze = [](uint32_t v) { return (v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u); };  // bytes are 0 / 1
-        s_flag[tid] = (uint16_t)(squeeze(tv.x & ~rv.x) | (squeeze(tv.y & ~rv.y) << 4) | (squeeze(tv.z & ~rv.z) << 8) | (squeeze(tv.w & ~rv.w) << 12));
-    } else if (tid < kVecs + 2) {
-        s_flag[tid] = 0;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t p0 = blockIdx.x * kScanTile + tid * 4;  // (the arrays are padded by a tile: words behind the chunk's last parent are zero and stay zero)
+    uint4* t = (uint4*)(d.tk + par * d.flag_stride + p0);
+    uint4* r = (uint4*)(d.rp + par * d.flag_stride + p0);
+    const uint4 tv = *t, rv = *r;
+    if (tv.x | tv.y | tv.z | tv.w) *t = make_uint4(0, 0, 0, 0);
+    if (rv.x | rv.y | rv.z | rv.w) *r = make_uint4(0, 0, 0, 0);
+    uint32_t m[4] = {tv.x & ~rv.x & 0xFFFu, tv.y & ~rv.y & 0xFFFu, tv.z & ~rv.z & 0xFFFu, tv.w & ~rv.w & 0xFFFu};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (p0 + k >= n_par) m[k] = 0;
+    const uint32_t sum = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
+    uint32_t incl = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= (uint32_t)o) incl += v;
     }
+    if (lane == 63) s_w[wave] = incl;
     __syncthreads();
-    const uint32_t p = p0 + tid, bit = 12u * tid;
-    uint32_t m = 0;
-    if (p < n_par) {
-        m = (((uint32_t)s_flag[bit >> 4] | ((uint32_t)s_flag[(bit >> 4) + 1] << 16)) >> (bit & 15u)) & 0xFFFu;
-        d.lmask[p] = (int32_t)m;
+    uint32_t before = incl - sum, total = 0;
+#pragma unroll
+    for (uint32_t w2 = 0; w2 < 16; w2++) {
+        if (w2 < wave) before += s_w[w2];
+        total += s_w[w2];
     }
-    const uint32_t other = (uint32_t)__shfl_xor((int)m, 1);
-    if (!(tid & 1u) && p < n_par) d.gmask[p >> 1] = (int32_t)(m | (other << 16));
+    if (p0 < n_par) {
+        uint4 o;
+        o.x = m[0] | (before << 12);
+        before += (uint32_t)__popc(m[0]);
+        o.y = m[1] | (before << 12);
+        before += (uint32_t)__popc(m[1]);
+        o.z = m[2] | (before << 12);
+        before += (uint32_t)__popc(m[2]);
+        o.w = m[3] | (before << 12);
+        *(uint4*)(d.lmp + p0) = o;  // (lmp is padded to whole quads)
+        *(int2*)(d.gmask + (p0 >> 1)) = make_int2((int)(m[0] | (m[1] << 16)), (int)(m[2] | (m[3] << 16)));
+    }
+    if (tid == 0) d.lblk[blockIdx.x] = total;
 }
 
-// exclusive popcount prefixes of the local and the all-reduced masks inside tiles of kScanTile parents + the tiles' totals
+// exclusive popcount prefixes of the all-reduced masks inside tiles of kScanTile parents (gmp: mask | prefix << 12) + the tiles' totals
 template <typename W> __global__ void __launch_bounds__(1024) k_shard_scan(ShardDev<W> d, uint32_t n_par) {
-    __shared__ uint32_t s_l[16], s_g[16];
-    ACX_VGPR_PAD("v63");
+    __shared__ uint32_t s_g[16];
+    ACX_VGPR_PAD("v39");
     if (d.ctl[C_STATUS] != 0) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t p0 = blockIdx.x * kScanTile + tid * 4;
-    uint32_t lm[4], gm[4], lsum = 0, gsum = 0;
-    if (p0 + 4 <= n_par) {
-        const int4 a = *(const int4*)(d.lmask + p0);
+    uint32_t gm[4] = {0u, 0u, 0u, 0u};
+    if (p0 < n_par) {  // (gmask is padded to whole quads; the masks behind the chunk's last parent are dropped here)
         const int2 b = *(const int2*)(d.gmask + (p0 >> 1));  // four parents = two words
-        lm[0] = a.x, lm[1] = a.y, lm[2] = a.z, lm[3] = a.w;
         gm[0] = (uint32_t)b.x & 0xFFFu, gm[1] = ((uint32_t)b.x >> 16) & 0xFFFu, gm[2] = (uint32_t)b.y & 0xFFFu, gm[3] = ((uint32_t)b.y >> 16) & 0xFFFu;
-    } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            lm[k] = p0 + k < n_par ? (uint32_t)d.lmask[p0 + k] : 0u;
-            gm[k] = p0 + k < n_par ? gmask_of(d.gmask, p0 + k) : 0u;
-        }
+        for (int k = 1; k < 4; k++)
+            if (p0 + k >= n_par) gm[k] = 0;
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        lsum += (uint32_t)__popc(lm[k]);
-        gsum += (uint32_t)__popc(gm[k]);
-    }
-    uint32_t li = lsum, gi = gsum;
+    const uint32_t gsum = (uint32_t)(__popc(gm[0]) + __popc(gm[1]) + __popc(gm[2]) + __popc(gm[3]));
+    uint32_t gi = gsum;
     for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t a = (uint32_t)__shfl_up((int)li, o), b = (uint32_t)__shfl_up((int)gi, o);
-        if (lane >= (uint32_t)o) li += a, gi += b;
+        const uint32_t b = (uint32_t)__shfl_up((int)gi, o);
+        if (lane >= (uint32_t)o) gi += b;
     }
-    if (lane == 63) s_l[wave] = li, s_g[wave] = gi;
+    if (lane == 63) s_g[wave] = gi;
     __syncthreads();
-    uint32_t lb = 0, gb = 0, lt = 0, gt = 0;
+    uint32_t ge = gi - gsum, gt = 0;
 #pragma unroll
     for (uint32_t w = 0; w < 16; w++) {
-        if (w < wave) lb += s_l[w], gb += s_g[w];
-        lt += s_l[w], gt += s_g[w];
+        if (w < wave) ge += s_g[w];
+        gt += s_g[w];
     }
-    uint32_t le = lb + li - lsum, ge = gb + gi - gsum;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        if (p0 + k < n_par) {
-            d.lpre[p0 + k] = le;
-            d.gpre[p0 + k] = ge;
-            le += (uint32_t)__popc(lm[k]);
-            ge += (uint32_t)__popc(gm[k]);
-        }
-    if (tid == 0) d.lblk[blockIdx.x] = lt, d.gblk[blockIdx.x] = gt;
+    if (p0 < n_par) {
+        uint4 o;
+        o.x = gm[0] | (ge << 12);
+        ge += (uint32_t)__popc(gm[0]);
+        o.y = gm[1] | (ge << 12);
+        ge += (uint32_t)__popc(gm[1]);
+        o.z = gm[2] | (ge << 12);
+        ge += (uint32_t)__popc(gm[2]);
+        o.w = gm[3] | (ge << 12);
+        *(uint4*)(d.gmp + p0) = o;
+    }
+    if (tid == 0) d.gblk[blockIdx.x] = gt;
 }
 
 // The reference's decisions for the chunk, from the all-reduced masks and the received headers -- the same numbers on every rank:
@@ -838,7 +845,8 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(Sha
         for (uint32_t k = tid; k < (uint32_t)kScanTile; k += 1024) {
             const uint32_t p = t * kScanTile + k;
             if (p < g.n_par) {
-                const unsigned long long ex = (unsigned long long)d.gblk[t] + d.gpre[p], in = ex + (unsigned long long)__popc(gmask_of(d.gmask, p));
+                const uint32_t gm = d.gmp[p];
+                const unsigned long long ex = (unsigned long long)d.gblk[t] + (gm >> 12), in = ex + (unsigned long long)__popc(gm & 0xFFFu);
                 if (ex < need && in >= need) s_pb = p;
             }
         }
@@ -862,14 +870,15 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(Sha
     if (need < 1) {  // only the very first parent can see this (budget <= 1)
         p_end = 0;
         budget_hit = true;
-        commit_global = (unsigned long long)__popc(gmask_of(d.gmask, 0));
-        commit_local = (unsigned long long)__popc((uint32_t)d.lmask[0]);
+        commit_global = (unsigned long long)__popc(d.gmp[0] & 0xFFFu);
+        commit_local = (unsigned long long)__popc(d.lmp[0] & 0xFFFu);
     } else if (over) {
         p_end = s_pb;
         budget_hit = true;
         const uint32_t t = p_end / kScanTile;
-        commit_global = (unsigned long long)d.gblk[t] + d.gpre[p_end] + (unsigned long long)__popc(gmask_of(d.gmask, p_end));
-        commit_local = (unsigned long long)d.lblk[t] + d.lpre[p_end] + (unsigned long long)__popc((uint32_t)d.lmask[p_end]);
+        const uint32_t gm = d.gmp[p_end], lm = d.lmp[p_end];
+        commit_global = (unsigned long long)d.gblk[t] + (gm >> 12) + (unsigned long long)__popc(gm & 0xFFFu);
+        commit_local = (unsigned long long)d.lblk[t] + (lm >> 12) + (unsigned long long)__popc(lm & 0xFFFu);
     }
     const unsigned long long end_pos = (unsigned long long)g.c0 + p_end;
     const unsigned long long stag = s_solved, eword = s_err;
@@ -882,7 +891,8 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(Sha
     }
     if (is_solved) {
         const uint32_t q = (uint32_t)(stag / 12ull - (unsigned long long)g.c0), a = (uint32_t)(stag % 12ull);
-        const unsigned long long before = (unsigned long long)d.gblk[q / kScanTile] + d.gpre[q] + (unsigned long long)__popc(gmask_of(d.gmask, q) & ((1u << a) - 1u));
+        const uint32_t gq = d.gmp[q];
+        const unsigned long long before = (unsigned long long)d.gblk[q / kScanTile] + (gq >> 12) + (unsigned long long)__popc(gq & ((1u << a) - 1u));
         d.ctl[C_EXPANDED] += (unsigned long long)q + 1;
         d.ctl[C_NODES_GLOBAL] = nodes_global + before;  // new states with a smaller tag
         d.ctl[C_SOLVED_TAG] = stag;
@@ -928,10 +938,10 @@ template <typename W> __global__ void __launch_bounds__(256) k_shard_commit(Shar
         const uint32_t tag = (uint32_t)(x >> 32);
         if (tag >= dec.cutoff) continue;
         const uint32_t par = tag / 12u, a = tag - 12u * par;
-        const uint32_t lm = (uint32_t)d.lmask[par];
+        const uint32_t lm = d.lmp[par];
         if (!((lm >> a) & 1u)) continue;
-        const uint32_t below = (1u << a) - 1u, tile = par / kScanTile;
-        const uint32_t id = dec.node_base + d.lblk[tile] + d.lpre[par] + (uint32_t)__popc(lm & below);
+        const uint32_t below = (1u << a) - 1u, tile = par / kScanTile, gm = d.gmp[par];
+        const uint32_t id = dec.node_base + d.lblk[tile] + (lm >> 12) + (uint32_t)__popc(lm & below);
         if (id >= d.cap_nodes) continue;  // k_shard_decide has refused such a commit already: never reached
         W k0, k1;
         recio<W>::get(rec, k0, k1);
@@ -939,7 +949,7 @@ template <typename W> __global__ void __launch_bounds__(256) k_shard_commit(Shar
         d.k1[id] = k1;
         d.act[id] = (uint8_t)a;
         d.tlen[id] = (uint8_t)(keyops<W>::len(k0) + keyops<W>::len(k1));
-        d.gpos[id] = dec.gpos_base + d.gblk[tile] + d.gpre[par] + (uint32_t)__popc(gmask_of(d.gmask, par) & below);
+        d.gpos[id] = dec.gpos_base + d.gblk[tile] + (gm >> 12) + (uint32_t)__popc(gm & below);
         d.pref[id] = (int64_t)(((unsigned long long)(r / kShardSub) << 40) | (x & 0xFFFFFFFFull));
         const OwnerParts o = owner_parts_of_key<W>(k0, k1);  // (a record only exists at world > 1, and most children never become one: acx_owner.h)
         d.cls[id] = make_uint2(o.c0, o.c1);
@@ -973,14 +983,14 @@ template <typename W, int MODE> __global__ void __launch_bounds__(kBornParents) 
     uint32_t lm = 0;
     if (i < b1) {
         const uint32_t q = d.gpos[i] - (uint32_t)g.c0, tile = q / kScanTile;
-        const uint32_t full = (uint32_t)d.lmask[q];
+        const uint32_t lw = d.lmp[q], gw = d.gmp[q], full = lw & 0xFFFu;
         const uint32_t t0 = 12u * q;  // bits a with t0 + a < cutoff
         lm = t0 + 12u <= dec.cutoff ? full : (t0 >= dec.cutoff ? 0u : full & ((1u << (dec.cutoff - t0)) - 1u));
         s_q[tid] = q;
         s_lm[tid] = full;
-        s_gm[tid] = gmask_of(d.gmask, q);
-        s_idb[tid] = dec.node_base + d.lblk[tile] + d.lpre[q];
-        s_gpb[tid] = dec.gpos_base + d.gblk[tile] + d.gpre[q];
+        s_gm[tid] = gw & 0xFFFu;
+        s_idb[tid] = dec.node_base + d.lblk[tile] + (lw >> 12);
+        s_gpb[tid] = dec.gpos_base + d.gblk[tile] + (gw >> 12);
         s_pk0[tid] = d.k0[i];
         s_pk1[tid] = d.k1[i];
         if (d.cls) {
@@ -1332,14 +1342,13 @@ template <typename W> struct ShardEngine {
         for (int pass = 0; pass < 2; pass++) {
             uint8_t* b = (uint8_t*)chunk_buf.p;
             o = 0;
-            const size_t one_set = (12 * chunk_parents + 12 * kPackParents + 16 + 255) / 256 * 256;  // (+ a tile of k_shard_pack)
-            d.btook = take(b, 2 * one_set);  // two sets, by chunk parity
-            d.brepl = take(b, 2 * one_set);
+            const size_t one_set = (chunk_parents + kScanTile + 63) / 64 * 64;  // words (+ a tile of k_shard_pack)
+            d.tk = (uint32_t*)take(b, 2 * one_set * 4);  // two sets, by chunk parity
+            d.rp = (uint32_t*)take(b, 2 * one_set * 4);
             d.flag_stride = one_set;
             flag_bytes = o;
-            d.lmask = (int32_t*)take(b, 4 * chunk_parents + 16);
-            d.lpre = (uint32_t*)take(b, 4 * chunk_parents + 16);
-            d.gpre = (uint32_t*)take(b, 4 * chunk_parents + 16);
+            d.lmp = (uint32_t*)take(b, 4 * chunk_parents + 64);
+            d.gmp = (uint32_t*)take(b, 4 * chunk_parents + 64);
             d.lblk = (uint32_t*)take(b, 4 * n_tiles);
             d.gblk = (uint32_t*)take(b, 4 * n_tiles);
             part_cnt = (uint32_t*)take(b, 4 * (cap_nodes / kPartTile + 2));
@@ -1491,7 +1500,7 @@ template <typename W> static int shard_chunk_insert(ShardEngine<W>& E, hipStream
         else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_insert<W, kMoveNfCyclical>), dim3(gx, regions), dim3(256), 0, st, E.dev(), geo, tiles);
         else hipLaunchKernelGGL((k_shard_insert<W, kMoveGeneral>), dim3(gx, regions), dim3(256), 0, st, E.dev(), geo, tiles);
     }
-    hipLaunchKernelGGL(k_shard_pack<W>, dim3((geo.n_par + kPackParents - 1) / kPackParents), dim3(256), 0, st, E.dev(), geo.n_par, geo.par);
+    hipLaunchKernelGGL(k_shard_pack<W>, dim3((geo.n_par + kScanTile - 1) / kScanTile), dim3(1024), 0, st, E.dev(), geo.n_par, geo.par);
     ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }

@@ -257,7 +257,7 @@ int64_t acx_get_option(int option);
  *          acx_shard_chunk_expand returns; it is never recycled (a visited-table slot names its state by the offset of the
  *          record that claimed it).  At world 1 the chunk is expanded straight into it.
  *   send   int64[send_words] (world > 1): the chunk's send buffer, `words` long, same layout.
- *   gmask  int32[(chunk_parents + 1) / 2]: one 12-bit mask per parent of the chunk -- bit a set when child (parent, a) is a new
+ *   gmask  int32[(chunk_parents + 3) / 4 * 2] (whole quads of parents; the all-reduce covers the first (n + 1) / 2 words of a chunk of n parents): one 12-bit mask per parent of the chunk -- bit a set when child (parent, a) is a new
  *          state owned by this rank --, two parents per word (parent p: bits 16 (p & 1) .. + 11 of word p >> 1); the caller
  *          all-reduces (sum == or: a child has one owner, no field carries) its first (c1 - c0 + 1) / 2 words between insert and
  *          commit.
