@@ -171,9 +171,9 @@ template <typename W> struct ShardDev {
     uint32_t* tk;        // one word per PARENT of a chunk, bit a: child (parent, a) took a slot / was pushed out again (all zero between chunks).
     uint32_t* rp;        // Round 6: bits instead of one byte per tag (k_shard_pack read 24 bytes per parent on every rank, now 8).  TWO sets,
     size_t flag_stride;  // `flag_stride` words apart, indexed by the chunk's parity (ChunkGeo::par): the expansion of chunk k + 1 claims beside the dedup of chunk k
-    uint32_t* lmp;       // [chunk parents] bits 0..11: new states of this rank among the parent's children; bits 12..27: their exclusive count over the
-                         // earlier parents of the parent's kScanTile tile (k_shard_pack writes both)
-    uint32_t* gmp;       // the same from the all-reduced masks (k_shard_scan)
+    uint2* pm;           // [chunk parents] .x: bits 0..11 = new states of this rank among the parent's children, bits 12..27 = their exclusive count over
+                         // the earlier parents of the parent's kScanTile tile (k_shard_pack writes it); .y: the same from the all-reduced masks
+                         // (k_shard_scan).  ONE 8-byte entry: a commit kernel gathers a parent's numbering from one 32-byte sector, not from two or four
     int32_t* gmask;      // the same for all ranks after the caller's all-reduce, TWO parents per word (parent p: bits 16 (p & 1) .. + 11 of word
                          // p >> 1): every (parent, action) child has one owner, so the sum of the ranks' words is their union and no field carries
     uint32_t* lblk;      // per tile: total, turned into the exclusive prefix over the tiles by k_shard_decide
@@ -383,7 +383,6 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
     }
     W c0[kExpandItems], c1[kExpandItems];
     bool send_it[kExpandItems];
-    uint32_t csum[kExpandItems];  // owner_sum of the child: names its owner
     uint32_t tl_min = 0xFFFFFFFFu;
     const uint32_t hsub = blockIdx.x % kShardSub;
 #pragma unroll
@@ -393,7 +392,6 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
         const uint32_t j = a * (uint32_t)kExpandParents + l;  // the child's slot in the tile (action major: conflict-free LDS rows)
         send_it[it] = false;
         c0[it] = c1[it] = 0;
-        csum[it] = 0;
         if (live) {
             Pres<W> s;
             key_to_pres<W>(pk0, pk1, s);
@@ -411,13 +409,6 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
                     atomicMin((unsigned long long*)(send + (int64_t)(o * kShardSub + hsub) * g.region_words + 1), tag);
             send_it[it] = !(c0[it] == pk0 && c1[it] == pk1);
             if (MODE == kMoveNf && pa < 12u && a == inverse_action(pa)) send_it[it] = false;
-            if (!SOLO && send_it[it]) {
-                // what names the child's owner.  In a normal-form search a move leaves the other relator alone and a conjugation (a >= 4)
-                // keeps the class of the one it rewrites: only a concatenation (it == 0) has a class hash to compute, the others look
-                // up one inner letter.  A search whose root is not in normal form (its first level simplifies BOTH relators) computes
-                // everything, for every child.
-                csum[it] = (MODE == kMoveGeneral ? owner_parts_of_pres<W>(s) : owner_parts_of_child<W>(po, a, s)).sum();
-            }
         }
         s_k0[j] = c0[it];
         s_k1[j] = c1[it];
@@ -470,7 +461,16 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
         if (SOLO) {
             born[it] = send_it[it] && s_slot[ls[it]] == me[it];
         } else if (send_it[it] && s_slot[ls[it]] == me[it]) {
-            owner[it] = owner_of_sum(csum[it], d.world);
+            // what names the child's owner -- computed for the survivors of the tile's fold only (round 6; before: for every child that
+            // differed from its parent).  In a normal-form search a move leaves the other relator alone and a conjugation (a >= 4) keeps
+            // the class of the one it rewrites: only a concatenation (it == 0) has a class hash to compute, the others look up one inner
+            // letter.  A search whose root is not in normal form (its first level simplifies BOTH relators) computes everything.
+            const uint32_t a = expand_action(w, it);
+            __builtin_assume(it == 0 ? a < 4u : a >= 4u);
+            Pres<W> s;
+            key_to_pres<W>(c0[it], c1[it], s);
+            const uint32_t csum = (MODE == kMoveGeneral ? owner_parts_of_pres<W>(s) : owner_parts_of_child<W>(po, a, s)).sum();
+            owner[it] = owner_of_sum(csum, d.world);
             if (owner[it] == d.rank) {  // stays home: claims its slot below, no record
                 born[it] = true;
                 owner[it] = 0xFFFFFFFFu;
@@ -728,13 +728,14 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_pack(Shard
         o.z = m[2] | (before << 12);
         before += (uint32_t)__popc(m[2]);
         o.w = m[3] | (before << 12);
-        *(uint4*)(d.lmp + p0) = o;  // (lmp is padded to whole quads)
+        uint2* e = d.pm + p0;  // (pm is padded to whole quads; .y is k_shard_scan's)
+        e[0].x = o.x, e[1].x = o.y, e[2].x = o.z, e[3].x = o.w;
         *(int2*)(d.gmask + (p0 >> 1)) = make_int2((int)(m[0] | (m[1] << 16)), (int)(m[2] | (m[3] << 16)));
     }
     if (tid == 0) d.lblk[blockIdx.x] = total;
 }
 
-// exclusive popcount prefixes of the all-reduced masks inside tiles of kScanTile parents (gmp: mask | prefix << 12) + the tiles' totals
+// exclusive popcount prefixes of the all-reduced masks inside tiles of kScanTile parents (pm[].y: mask | prefix << 12) + the tiles' totals
 template <typename W> __global__ void __launch_bounds__(1024) k_shard_scan(ShardDev<W> d, uint32_t n_par) {
     __shared__ uint32_t s_g[16];
     ACX_VGPR_PAD("v39");
@@ -772,7 +773,8 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_scan(Shard
         o.z = gm[2] | (ge << 12);
         ge += (uint32_t)__popc(gm[2]);
         o.w = gm[3] | (ge << 12);
-        *(uint4*)(d.gmp + p0) = o;
+        uint2* e = d.pm + p0;
+        e[0].y = o.x, e[1].y = o.y, e[2].y = o.z, e[3].y = o.w;
     }
     if (tid == 0) d.gblk[blockIdx.x] = gt;
 }
@@ -845,7 +847,7 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(Sha
         for (uint32_t k = tid; k < (uint32_t)kScanTile; k += 1024) {
             const uint32_t p = t * kScanTile + k;
             if (p < g.n_par) {
-                const uint32_t gm = d.gmp[p];
+                const uint32_t gm = d.pm[p].y;
                 const unsigned long long ex = (unsigned long long)d.gblk[t] + (gm >> 12), in = ex + (unsigned long long)__popc(gm & 0xFFFu);
                 if (ex < need && in >= need) s_pb = p;
             }
@@ -870,13 +872,13 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(Sha
     if (need < 1) {  // only the very first parent can see this (budget <= 1)
         p_end = 0;
         budget_hit = true;
-        commit_global = (unsigned long long)__popc(d.gmp[0] & 0xFFFu);
-        commit_local = (unsigned long long)__popc(d.lmp[0] & 0xFFFu);
+        commit_global = (unsigned long long)__popc(d.pm[0].y & 0xFFFu);
+        commit_local = (unsigned long long)__popc(d.pm[0].x & 0xFFFu);
     } else if (over) {
         p_end = s_pb;
         budget_hit = true;
         const uint32_t t = p_end / kScanTile;
-        const uint32_t gm = d.gmp[p_end], lm = d.lmp[p_end];
+        const uint32_t gm = d.pm[p_end].y, lm = d.pm[p_end].x;
         commit_global = (unsigned long long)d.gblk[t] + (gm >> 12) + (unsigned long long)__popc(gm & 0xFFFu);
         commit_local = (unsigned long long)d.lblk[t] + (lm >> 12) + (unsigned long long)__popc(lm & 0xFFFu);
     }
@@ -891,7 +893,7 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_decide(Sha
     }
     if (is_solved) {
         const uint32_t q = (uint32_t)(stag / 12ull - (unsigned long long)g.c0), a = (uint32_t)(stag % 12ull);
-        const uint32_t gq = d.gmp[q];
+        const uint32_t gq = d.pm[q].y;
         const unsigned long long before = (unsigned long long)d.gblk[q / kScanTile] + (gq >> 12) + (unsigned long long)__popc(gq & ((1u << a) - 1u));
         d.ctl[C_EXPANDED] += (unsigned long long)q + 1;
         d.ctl[C_NODES_GLOBAL] = nodes_global + before;  // new states with a smaller tag
@@ -938,9 +940,10 @@ template <typename W> __global__ void __launch_bounds__(256) k_shard_commit(Shar
         const uint32_t tag = (uint32_t)(x >> 32);
         if (tag >= dec.cutoff) continue;
         const uint32_t par = tag / 12u, a = tag - 12u * par;
-        const uint32_t lm = d.lmp[par];
+        const uint2 pmv = d.pm[par];
+        const uint32_t lm = pmv.x;
         if (!((lm >> a) & 1u)) continue;
-        const uint32_t below = (1u << a) - 1u, tile = par / kScanTile, gm = d.gmp[par];
+        const uint32_t below = (1u << a) - 1u, tile = par / kScanTile, gm = pmv.y;
         const uint32_t id = dec.node_base + d.lblk[tile] + (lm >> 12) + (uint32_t)__popc(lm & below);
         if (id >= d.cap_nodes) continue;  // k_shard_decide has refused such a commit already: never reached
         W k0, k1;
@@ -983,7 +986,8 @@ template <typename W, int MODE> __global__ void __launch_bounds__(kBornParents) 
     uint32_t lm = 0;
     if (i < b1) {
         const uint32_t q = d.gpos[i] - (uint32_t)g.c0, tile = q / kScanTile;
-        const uint32_t lw = d.lmp[q], gw = d.gmp[q], full = lw & 0xFFFu;
+        const uint2 pmv = d.pm[q];
+        const uint32_t lw = pmv.x, gw = pmv.y, full = lw & 0xFFFu;
         const uint32_t t0 = 12u * q;  // bits a with t0 + a < cutoff
         lm = t0 + 12u <= dec.cutoff ? full : (t0 >= dec.cutoff ? 0u : full & ((1u << (dec.cutoff - t0)) - 1u));
         s_q[tid] = q;
@@ -1347,8 +1351,7 @@ template <typename W> struct ShardEngine {
             d.rp = (uint32_t*)take(b, 2 * one_set * 4);
             d.flag_stride = one_set;
             flag_bytes = o;
-            d.lmp = (uint32_t*)take(b, 4 * chunk_parents + 64);
-            d.gmp = (uint32_t*)take(b, 4 * chunk_parents + 64);
+            d.pm = (uint2*)take(b, 8 * chunk_parents + 64);
             d.lblk = (uint32_t*)take(b, 4 * n_tiles);
             d.gblk = (uint32_t*)take(b, 4 * n_tiles);
             part_cnt = (uint32_t*)take(b, 4 * (cap_nodes / kPartTile + 2));
@@ -1735,7 +1738,7 @@ int acx_shard_check_owners(acx_shard* h, int64_t* n_bad, void* stream) {
         hipStream_t st = (hipStream_t)stream;
         if (int rc = E.await_ready(st)) return rc;
         ACX_HIP_TRY(hipMemsetAsync(E.d_find, 0, 8, st));
-        hipLaunchKernelGGL(k_shard_check_owners<W>, dim3(1024), dim3(256), 0, st, E.d, (uint32_t)E.own_from, (unsigned long long*)E.d_find);
+        hipLaunchKernelGGL(k_shard_check_owners<W>, dim3(1024), dim3(256), 0, st, E.d, E.replicated ? 0xFFFFFFFFu : (uint32_t)E.own_from, (unsigned long long*)E.d_find);  // (still replicated: every node lives on every rank)
         ACX_HIP_TRY(hipGetLastError());
         ACX_HIP_TRY(hipMemcpyAsync(n_bad, E.d_find, 8, hipMemcpyDeviceToHost, st));
         ACX_HIP_TRY(hipStreamSynchronize(st));

@@ -190,7 +190,8 @@ def test_random_presentations_through_the_sharded_engine(L, monkeypatch):
 
         def run(comm):
             try:
-                return bfs_sharded(row, budget, cyclically_reduce_after_moves=cyc, comm=comm, batch_parents=bp, want_stats=True)
+                # (round 6: every level exchanged / the frontier partitioned by owner at the first level of >= 30 or 400 parents / the default)
+                return bfs_sharded(row, budget, cyclically_reduce_after_moves=cyc, comm=comm, batch_parents=bp, want_stats=True, replicate_below=(0, 30, 400, None)[case % 4])
             except (AssertionError, IndexError):
                 return "raises"
 
