@@ -34,6 +34,27 @@ class SearchStats(C.Structure):
                 ("min_len", C.c_int32), ("seconds", C.c_double)]
 
 
+# the communicator of acx_bfs_sharded (include/acx.h: acx_comm): two collectives as plain function pointers
+ALL_TO_ALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p)
+RED_SUM, RED_MAX = 0, 1
+
+
+class Comm(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("ctx", C.c_void_p), ("all_to_all", ALL_TO_ALL_FN), ("all_reduce", ALL_REDUCE_FN)]
+
+
+class ShardOpts(C.Structure):
+    _fields_ = [("batch_parents", C.c_int64), ("replicate_below", C.c_int64), ("region_fill", C.c_int32), ("overlap", C.c_int32),
+                ("mask_comm", C.POINTER(Comm)), ("fail_at_call", C.c_int32), ("fail_rank", C.c_int32)]
+
+
+class ShardRunStats(C.Structure):
+    _fields_ = [("nodes", C.c_int64), ("expanded", C.c_int64), ("levels", C.c_int64), ("chunks", C.c_int64), ("replicated_levels", C.c_int64),
+                ("local_nodes", C.c_int64), ("all_to_all_calls", C.c_int64), ("all_to_all_bytes", C.c_int64), ("all_reduce_calls", C.c_int64),
+                ("all_reduce_bytes", C.c_int64), ("min_len", C.c_int32), ("reruns", C.c_int32), ("setup_seconds", C.c_double), ("loop_seconds", C.c_double)]
+
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} not found: build the HIP extension first (python __graft_entry__.py, or "
@@ -120,6 +141,13 @@ SIGNATURES = {
     "acx_shard_set_replicated": (C.c_int, [_vp, C.c_int]),
     "acx_shard_partition": (C.c_int, [_vp, _vp]),
     "acx_shard_walk": (C.c_int, [_vp, C.c_int64, C.c_int64, _i64p, _vp]),
+    "acx_rccl_available": (C.c_int, []),
+    "acx_comm_rccl": (C.c_int, [_vp, C.POINTER(Comm)]),
+    "acx_rccl_unique_id": (C.c_int, [_vp]),
+    "acx_rccl_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "acx_rccl_comm_destroy": (C.c_int, [_vp]),
+    "acx_bfs_sharded": (C.c_int, [_i8p, C.c_int, C.c_int64, C.c_int, C.POINTER(Comm), C.POINTER(ShardOpts), _i32p, _i32p, _i32p, C.c_int64, _i64p,
+                               C.POINTER(ShardRunStats), _vp]),
     "acx_release_cached_memory": (C.c_int, []),
     "acx_set_option": (C.c_int, [C.c_int, C.c_int64]),
     "acx_get_option": (C.c_int64, [C.c_int]),

@@ -878,3 +878,152 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
         comm.all_reduce(i64([4, 0, 0]), "max")
         raise RuntimeError(f"sharded bfs failed on rank {rank}: {e}") from e
     return finish(False, None, min_len)
+
+
+# ------------------------------------------------------------------ the whole search as ONE C call (round 6) ---
+class NativeComm:
+    """An `acx_comm` (include/acx.h) for acx_bfs_sharded: the two collectives of the sharded search as C function pointers.
+
+    * `NativeComm.from_process_group(group=None)`: RCCL itself -- the ncclComm_t of a torch.distributed process group (backend "nccl"
+      == RCCL on ROCm; `ProcessGroupNCCL._comm_ptr()`), driven from C through the librccl the process already runs.  No Python between
+      the chunks of a search.
+    * `NativeComm.create_rccl(rank, world, broadcast)`: a communicator of the library's own (ncclCommInitRank): rank 0 makes the 128-byte
+      id, `broadcast(bytes_or_None) -> bytes` hands it to every rank (any transport: a torch.distributed store, MPI, a file).
+    * `NativeComm.from_python(comm, device)`: any communicator object of this module (ThreadComm of the tests, TorchDistComm over gloo)
+      behind ctypes callbacks -- the GPU tests run thread ranks of one GPU through it."""
+
+    def __init__(self, struct, keep=(), owned=None):
+        self.c, self._keep, self._owned = struct, keep, owned
+        self.rank, self.world = int(struct.rank), int(struct.world)
+
+    @classmethod
+    def from_comm_ptr(cls, ptr):
+        from ac_solver import _acx
+
+        c = _acx.Comm()
+        _acx.check(_acx.lib.acx_comm_rccl(C.c_void_p(int(ptr)), C.byref(c)), "acx_comm_rccl")
+        return cls(c)
+
+    @classmethod
+    def from_process_group(cls, group=None, device=None):
+        torch = _torch()
+        import torch.distributed as dist
+
+        pg = group if group is not None else dist.distributed_c10d._get_default_group()
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        backend = pg._get_backend(dev)
+        if not hasattr(backend, "_comm_ptr"):
+            raise RuntimeError("the process group's backend for CUDA tensors is not NCCL / RCCL: no communicator to hand to libacx")
+        # the communicator exists once the group has run a collective on this device
+        dist.all_reduce(torch.zeros(1, device=dev), group=group)
+        torch.cuda.synchronize(dev)
+        return cls.from_comm_ptr(backend._comm_ptr())
+
+    @classmethod
+    def create_rccl(cls, rank, world, broadcast):
+        from ac_solver import _acx
+
+        _acx.require_device()
+        uid = (C.c_char * 128)()
+        if rank == 0:
+            _acx.check(_acx.lib.acx_rccl_unique_id(uid), "acx_rccl_unique_id")
+        data = broadcast(bytes(uid.raw) if rank == 0 else None)
+        uid.raw = bytes(data)
+        handle = C.c_void_p()
+        _acx.check(_acx.lib.acx_rccl_comm_create(uid, int(rank), int(world), C.byref(handle)), "acx_rccl_comm_create")
+        out = cls.from_comm_ptr(handle.value)
+        out._owned = handle
+        return out
+
+    def close(self):
+        if self._owned is not None:
+            from ac_solver import _acx
+
+            _acx.lib.acx_rccl_comm_destroy(self._owned)
+            self._owned = None
+
+    @classmethod
+    def from_python(cls, comm, device=None):
+        from ac_solver import _acx
+
+        torch = _torch()
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+        class _Span:  # a device pointer as a torch tensor (the __cuda_array_interface__ protocol)
+            def __init__(self, ptr, n, typestr):
+                self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+        def tensor(ptr, n, typestr):
+            return torch.as_tensor(_Span(ptr, n, typestr), device=dev)
+
+        def on(stream):
+            return torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev) if stream else torch.cuda.default_stream(dev))
+
+        errors = []
+
+        def a2a(ctx, send, recv, words, stream):
+            try:
+                with on(stream):
+                    comm.all_to_all_single(tensor(recv, words, "<i8"), tensor(send, words, "<i8"))
+                return 0
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+                return -1
+
+        def red(ctx, buf, n, dtype, op, stream):
+            try:
+                with on(stream):
+                    comm.all_reduce(tensor(buf, n, "<i4" if dtype == _acx.I32 else "<i8"), "sum" if op == _acx.RED_SUM else "max")
+                return 0
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+                return -1
+
+        fa, fr = _acx.ALL_TO_ALL_FN(a2a), _acx.ALL_REDUCE_FN(red)
+        out = cls(_acx.Comm(int(comm.rank), int(comm.world), None, fa, fr), keep=(fa, fr, comm))
+        out.errors = errors
+        return out
+
+
+def bfs_sharded_native(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False, comm=None, batch_parents=None,
+                       want_stats=False, overlap=None, region_fill=None, replicate_below=None, mask_comm=None, _fail_at_call=0, _fail_rank=0):
+    """`bfs` over the ranks of `comm` (a NativeComm; None = one rank) as ONE C call per rank: acx_bfs_sharded (csrc/acx_shard_run.hip) runs
+    what bfs_sharded above orchestrates from Python -- same engine, same chunk loop, same result.  Same contract as `bfs`
+    (breadth_first.py:15-97): (is_search_successful, path or None) [+ stats], identical on every rank."""
+    from ac_solver import _acx
+    from ac_solver.envs.utils import is_array_valid_presentation
+    from ac_solver.search._common import _check_width
+
+    assert is_array_valid_presentation(presentation), f"{presentation} is not a valid presentation"
+    p = _acx.as_i8_rows(np.array(presentation))
+    L = p.size // 2
+    _check_width(L)
+    _acx.require_device()
+    torch = _torch()
+    opts = _acx.ShardOpts()
+    opts.batch_parents = int(batch_parents or 0)
+    opts.replicate_below = 0 if replicate_below is None else (-1 if int(replicate_below) <= 1 else int(replicate_below))
+    opts.region_fill = int(region_fill or 0)
+    opts.overlap = {None: 0, True: 0, "insert": 2, False: 1}[overlap]
+    if mask_comm is not None:
+        opts.mask_comm = C.pointer(mask_comm.c)
+    opts.fail_at_call, opts.fail_rank = int(_fail_at_call), int(_fail_rank)
+    cap = 1 << 12
+    while True:
+        pa, pl = np.empty(cap, np.int32), np.empty(cap, np.int32)
+        solved, n, st = C.c_int32(), C.c_int64(), _acx.ShardRunStats()
+        rc = _acx.lib.acx_bfs_sharded(_acx.ptr(p, C.c_int8), L, int(max_nodes_to_explore), int(bool(cyclically_reduce_after_moves)),
+                                      None if comm is None else C.byref(comm.c), C.byref(opts), C.byref(solved), _acx.ptr(pa, C.c_int32), _acx.ptr(pl, C.c_int32),
+                                      cap, C.byref(n), C.byref(st), torch.cuda.current_stream().cuda_stream)
+        if rc == _acx.E_CAPACITY and n.value > cap:
+            cap = int(n.value)
+            continue
+        if rc == _acx.E_ROWERR:
+            raise AssertionError(_acx.last_error())
+        if rc != _acx.OK:
+            raise RuntimeError(_acx.last_error() or f"acx_bfs_sharded failed (code {rc})")
+        break
+    path = list(zip(pa[: n.value].tolist(), pl[: n.value].tolist())) if solved.value else None
+    if want_stats:
+        return bool(solved.value), path, {k: getattr(st, k) for k, _ in _acx.ShardRunStats._fields_} | {"world": 1 if comm is None else comm.world}
+    return bool(solved.value), path

@@ -171,9 +171,10 @@ template <typename W> struct ShardDev {
     uint32_t* tk;        // one word per PARENT of a chunk, bit a: child (parent, a) took a slot / was pushed out again (all zero between chunks).
     uint32_t* rp;        // Round 6: bits instead of one byte per tag (k_shard_pack read 24 bytes per parent on every rank, now 8).  TWO sets,
     size_t flag_stride;  // `flag_stride` words apart, indexed by the chunk's parity (ChunkGeo::par): the expansion of chunk k + 1 claims beside the dedup of chunk k
-    uint2* pm;           // [chunk parents] .x: bits 0..11 = new states of this rank among the parent's children, bits 12..27 = their exclusive count over
-                         // the earlier parents of the parent's kScanTile tile (k_shard_pack writes it); .y: the same from the all-reduced masks
-                         // (k_shard_scan).  ONE 8-byte entry: a commit kernel gathers a parent's numbering from one 32-byte sector, not from two or four
+    uint32_t* lmp;       // [chunk parents] bits 0..11 = new states of this rank among the parent's children, bits 12..27 = their exclusive count over the
+                         // earlier parents of the parent's kScanTile tile (k_shard_pack)
+    uint2* pm;           // .x = lmp, .y = the same from the all-reduced masks (k_shard_scan writes both halves: whole, coalesced entries).  ONE
+                         // 8-byte entry: a commit kernel gathers a parent's numbering from one 32-byte sector, not from two or four
     int32_t* gmask;      // the same for all ranks after the caller's all-reduce, TWO parents per word (parent p: bits 16 (p & 1) .. + 11 of word
                          // p >> 1): every (parent, action) child has one owner, so the sum of the ranks' words is their union and no field carries
     uint32_t* lblk;      // per tile: total, turned into the exclusive prefix over the tiles by k_shard_decide
@@ -728,8 +729,7 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_pack(Shard
         o.z = m[2] | (before << 12);
         before += (uint32_t)__popc(m[2]);
         o.w = m[3] | (before << 12);
-        uint2* e = d.pm + p0;  // (pm is padded to whole quads; .y is k_shard_scan's)
-        e[0].x = o.x, e[1].x = o.y, e[2].x = o.z, e[3].x = o.w;
+        *(uint4*)(d.lmp + p0) = o;  // (padded to whole quads)
         *(int2*)(d.gmask + (p0 >> 1)) = make_int2((int)(m[0] | (m[1] << 16)), (int)(m[2] | (m[3] << 16)));
     }
     if (tid == 0) d.lblk[blockIdx.x] = total;
@@ -773,8 +773,10 @@ template <typename W> __global__ void __launch_bounds__(1024) k_shard_scan(Shard
         o.z = gm[2] | (ge << 12);
         ge += (uint32_t)__popc(gm[2]);
         o.w = gm[3] | (ge << 12);
-        uint2* e = d.pm + p0;
-        e[0].y = o.x, e[1].y = o.y, e[2].y = o.z, e[3].y = o.w;
+        const uint4 l = *(const uint4*)(d.lmp + p0);
+        uint4* e = (uint4*)(d.pm + p0);
+        e[0] = make_uint4(l.x, o.x, l.y, o.y);
+        e[1] = make_uint4(l.z, o.z, l.w, o.w);
     }
     if (tid == 0) d.gblk[blockIdx.x] = gt;
 }
@@ -1351,6 +1353,7 @@ template <typename W> struct ShardEngine {
             d.rp = (uint32_t*)take(b, 2 * one_set * 4);
             d.flag_stride = one_set;
             flag_bytes = o;
+            d.lmp = (uint32_t*)take(b, 4 * chunk_parents + 64);
             d.pm = (uint2*)take(b, 8 * chunk_parents + 64);
             d.lblk = (uint32_t*)take(b, 4 * n_tiles);
             d.gblk = (uint32_t*)take(b, 4 * n_tiles);

@@ -370,6 +370,56 @@ int acx_ball_sizes(const int8_t *h_presentations, int64_t n, int L, int radius, 
 int acx_simplex_graph(int n, int classic, int64_t cap_nodes, int64_t cap_edges, int64_t *n_nodes, uint8_t *h_node_size,
                       int64_t *n_edges, uint32_t *h_edges, uint8_t *h_edge_filt);
 
+/* ---- a whole sharded bfs in ONE call (round 6) -----------------------------------------------------------------------------
+ * bfs(presentation, max_nodes_to_explore, verbose, cyclically_reduce_after_moves) of breadth_first.py:15-97 over the ranks of a
+ * communicator: what ac_solver/search/sharded.py drives chunk by chunk through acx_shard_* (five or six calls and two collectives per
+ * chunk, from Python), as one C call per rank -- the same chunk loop, two-stream pipeline, lagged control block, replicated small
+ * levels, adaptive region capacity and failure protocol, on the same engine (csrc/acx_shard_run.hip).  Every rank calls it with the
+ * same arguments and gets the same (solved, path); identical to acx_search(ACX_SEARCH_BFS, ...) on one GPU for every world size.
+ *
+ * acx_comm: the two collectives the search needs, as plain function pointers (the library links no collective library); both are
+ * enqueued on `stream` and return 0 on success.  all_to_all: equal splits of int64 words -- rank d receives words [d k, (d + 1) k) of
+ * every rank's d_send, k = words / world, rank r's block at [r k, (r + 1) k) of d_recv.  all_reduce: in place, dtype ACX_I32 / ACX_I64,
+ * op ACX_RED_SUM / ACX_RED_MAX.  acx_comm_rccl fills one in for an ncclComm_t of the caller (RCCL over xGMI): librccl is resolved at run
+ * time -- the copy the process already runs (torch's), else librccl.so -- e.g. torch.distributed's own communicator,
+ * dist.distributed_c10d._get_default_group()._get_backend(torch.device("cuda"))._comm_ptr(), or one made with acx_rccl_comm_create from
+ * an id that rank 0 got from acx_rccl_unique_id and broadcast (128 bytes). */
+#define ACX_RED_SUM 0
+#define ACX_RED_MAX 1
+typedef struct acx_comm {
+    int32_t rank, world;
+    void *ctx;
+    int (*all_to_all)(void *ctx, const int64_t *d_send, int64_t *d_recv, int64_t words, void *stream);
+    int (*all_reduce)(void *ctx, void *d_buf, int64_t n, int dtype, int op, void *stream);
+} acx_comm;
+int acx_rccl_available(void); /* 1 when librccl could be resolved */
+int acx_comm_rccl(void *nccl_comm, acx_comm *out);
+int acx_rccl_unique_id(void *id128);
+int acx_rccl_comm_create(const void *id128, int rank, int world, void **nccl_comm); /* ncclCommInitRank on the current device */
+int acx_rccl_comm_destroy(void *nccl_comm);
+
+typedef struct acx_shard_opts { /* all zero = the defaults of sharded.py:bfs_sharded */
+    int64_t batch_parents;      /* global parents per chunk (default 2^21, 2^22 from 8 ranks on) */
+    int64_t replicate_below;    /* levels of fewer parents are processed whole by every rank, no collectives (default 2^18; < 0: every level exchanged) */
+    int32_t region_fill;        /* capacity of the exchanged regions in 1/256 of the even share (default: adaptive; ACX 320 = 1.25 x) */
+    int32_t overlap;            /* 0: expansion + all-to-all of chunk k + 1 on a side stream beside the dedup of chunk k when world > 1; 1: one stream; 2: side stream always */
+    const acx_comm *mask_comm;  /* a second communicator for the per-chunk mask all-reduce (runs beside the all-to-all of the next chunk); NULL: the same */
+    int32_t fail_at_call;       /* test hook: the n-th engine call of rank `fail_rank` fails (every rank must then return an error, none may hang) */
+    int32_t fail_rank;
+} acx_shard_opts;
+typedef struct acx_shard_run_stats {
+    int64_t nodes, expanded, levels, chunks, replicated_levels, local_nodes;
+    int64_t all_to_all_calls, all_to_all_bytes, all_reduce_calls, all_reduce_bytes;
+    int32_t min_len, reruns;
+    double setup_seconds, loop_seconds;
+} acx_shard_run_stats;
+/* returns ACX_OK (solved / path as acx_search), ACX_E_ROWERR where the reference raises AssertionError (an invalid presentation, a move
+ * that empties a relator), ACX_E_CAPACITY when the path needs more than path_cap entries (*path_n says how many), another negative code
+ * when a rank failed (every rank returns one).  comm NULL = one rank. */
+int acx_bfs_sharded(const int8_t *h_presentation, int L, int64_t max_nodes, int cyclical, const acx_comm *comm, const acx_shard_opts *opts,
+                    int32_t *solved, int32_t *path_action, int32_t *path_len, int64_t path_cap, int64_t *path_n, acx_shard_run_stats *stats,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -181,3 +181,44 @@ _Zgood:
 """
     bad, _, _ = K.risky_sites(sample)
     assert [(b[0], b[2]) for b in bad] == [("_Zbad", "v31")]
+
+
+def test_bfs_dispatches_to_the_collective_form_only_when_switched_on(monkeypatch):
+    """ac_solver.search.breadth_first.shard_over_process_group: `bfs` keeps the reference's signature (breadth_first.py:15) and hands the
+    search to acx_bfs_sharded -- same arguments -- once a communicator of more than one rank has been switched on, for budgets of at
+    least `min_nodes`, and never for verbose searches (host logic: no GPU needed, the two backends are stand-ins)."""
+    from ac_solver.search import breadth_first as B
+    from ac_solver.search import sharded as S
+
+    calls = []
+
+    def fake_native(presentation, max_nodes, verbose, cyclical, comm=None, want_stats=False, **kw):
+        calls.append(("native", list(presentation), max_nodes, cyclical, comm.world))
+        return True, [(-1, 4), (3, 2)], {"nodes": 7}
+
+    def fake_single(kind, presentation, max_nodes, cyclical, verbose=False):
+        calls.append(("single", presentation.tolist(), max_nodes, cyclical, verbose))
+        return False, None, {"nodes": max_nodes}
+
+    monkeypatch.setattr(S, "bfs_sharded_native", fake_native)
+    monkeypatch.setattr(B, "run_search", fake_single)
+
+    class FakeComm(S.NativeComm):
+        def __init__(self, world):
+            self.rank, self.world = 0, world
+
+    p = [1, 2, 0, -2, 1, 0]
+    assert B.bfs(p, 50) == (False, None) and calls[-1][0] == "single"
+    old = B.shard_over_process_group(FakeComm(4), min_nodes=100)
+    try:
+        assert old is None
+        assert B.bfs(p, 50) == (False, None) and calls[-1][0] == "single"             # below min_nodes
+        assert B.bfs(p, 500, cyclically_reduce_after_moves=True) == (True, [(-1, 4), (3, 2)])
+        assert calls[-1] == ("native", p, 500, True, 4)
+        assert B.bfs(p, 500, verbose=True) == (False, None) and calls[-1][0] == "single" and calls[-1][4] is True
+        B.shard_over_process_group(FakeComm(1), min_nodes=0)
+        assert B.bfs(p, 500) == (False, None) and calls[-1][0] == "single"            # one rank: nothing to shard over
+    finally:
+        B.shard_over_process_group(None)
+    assert B.bfs(p, 500) == (False, None) and calls[-1][0] == "single"
+    assert B.bfs.__name__ == "bfs"  # miller_schupp.py:130-133 asserts on it

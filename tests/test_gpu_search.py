@@ -771,6 +771,114 @@ def test_miller_schupp_driver_matches_reference_test_ranges(search, golden_json)
         assert [list(x) for x in s] == ws and [list(x) for x in u] == wu and p == wp
 
 
+# ---- the whole sharded search as ONE C call per rank (acx_bfs_sharded, csrc/acx_shard_run.hip) ----
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_native_sharded_bfs_equals_the_reference_and_the_python_orchestrator(search, golden_json, world):
+    """acx_bfs_sharded on thread ranks of one GPU (the collectives through ctypes callbacks into the tests' ThreadComm): result, path
+    and counts of the oracle (breadth_first.py:61-95), and the same levels / chunks / replicated levels as sharded.py's orchestration of
+    the same engine -- every level exchanged, the frontier partitioned after a few small levels, the default."""
+    from ac_solver.search.sharded import NativeComm, SingleComm, bfs_sharded, bfs_sharded_native
+    from oracle import ac_oracle as O
+    from tests.shard_helpers import run_threads
+
+    ak2 = [1, 1, -2, -2, -2, 0, 0, 1, 2, 1, -2, -1, -2, 0]
+    ak3 = np.zeros(50, np.int8)
+    ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+    ak3[25:31] = [1, 2, 1, -2, -1, -2]
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    cases = [(ak2, 10**6, False, 1 << 18), (ak2, 10, False, 1 << 18), (ak2, 1, False, 4), (ak2, 3000, True, 100),
+             (ak3, 10**5, False, 1 << 14), (ak3, 5000, True, 333), (pool[1100], 20000, False, 1 << 12), (pool[600], 3000, False, 50)]
+    repls = (0, 20, 700, None)
+
+    def run(comm):
+        nat = None if world == 1 else NativeComm.from_python(comm)
+        out = []
+        for repl in repls:
+            for p, b, c, bp in cases:
+                a = bfs_sharded_native(p, b, cyclically_reduce_after_moves=c, comm=nat, batch_parents=bp, want_stats=True, replicate_below=repl)
+                ref = bfs_sharded(p, b, cyclically_reduce_after_moves=c, comm=comm, batch_parents=bp, want_stats=True, replicate_below=repl)
+                out.append((a, ref))
+        assert nat is None or not nat.errors, nat.errors
+        return out
+
+    results = [run(SingleComm())] if world == 1 else run_threads(world, run)
+    want = [O.bfs(p, b, cyclically_reduce_after_moves=c, stats=True) for p, b, c, bp in cases]
+    for res in results:
+        for k, ((ok, path, st), (rok, rpath, rst)) in enumerate(res):
+            wok, wpath, wst = want[k % len(cases)]
+            assert (ok, path) == (wok, wpath) == (rok, rpath), (world, k)
+            assert st["nodes"] == wst["nodes"] and st["expanded"] == wst["expanded"], (world, k, st, wst)
+            assert (st["levels"], st["chunks"], st["replicated_levels"]) == (rst["levels"], rst["chunks"], rst["replicated_levels"]), (world, k, st, rst)
+            assert st["min_len"] == rst["min_len"], (world, k, st, rst)
+
+
+@pytest.mark.timeout(600)
+def test_native_sharded_bfs_a_failing_rank_ends_every_rank(search):
+    """acx_shard_opts.fail_at_call: the n-th engine call of rank 1 fails instead of being made -- in the replicated phase, at the
+    partition, in the middle of exchanged levels.  Every rank must come back with an error (thread ranks meet at barriers: a rank left
+    alone in a collective would hang this test), and the next search on the same communicator must run."""
+    from ac_solver.search.sharded import NativeComm, bfs_sharded_native
+    from oracle import ac_oracle as O
+    from tests.shard_helpers import run_threads
+
+    ak3 = np.zeros(50, np.int8)
+    ak3[:7] = [1, 1, 1, -2, -2, -2, -2]
+    ak3[25:31] = [1, 2, 1, -2, -1, -2]
+    want = O.bfs(ak3, 30000)
+
+    def run(comm):
+        nat = NativeComm.from_python(comm)
+        out = []
+        for fail_at in (2, 7, 15, 16, 17, 25, 40, 61, 90):
+            try:
+                bfs_sharded_native(ak3, 30000, comm=nat, batch_parents=256, replicate_below=40, _fail_at_call=fail_at, _fail_rank=1)
+                out.append("no error")
+            except RuntimeError as e:
+                out.append(str(e))
+        out.append(bfs_sharded_native(ak3, 30000, comm=nat, batch_parents=256, replicate_below=40))
+        assert not nat.errors, nat.errors
+        return out
+
+    got = run_threads(3, run)
+    for r, res in enumerate(got):
+        assert all("sharded bfs failed" in m for m in res[:-1]), (r, res[:-1])
+        assert res[-1] == want
+    assert all("simulated" in m for m in got[1][:-1]), got[1][:-1]
+
+
+def test_rccl_communicator_of_the_library(search):
+    """acx_comm_rccl: librccl resolved at run time, a communicator of the library's own (acx_rccl_unique_id / acx_rccl_comm_create, world 1 on
+    the one GPU of a box) -- its two collectives called through the acx_comm function pointers on device buffers, then a search on it."""
+    import ctypes as C
+
+    import torch
+
+    from ac_solver import _acx
+    from ac_solver.search.sharded import NativeComm, bfs_sharded_native
+    from oracle import ac_oracle as O
+
+    assert _acx.lib.acx_rccl_available() == 1
+    comm = NativeComm.create_rccl(0, 1, lambda b: b)
+    try:
+        assert (comm.rank, comm.world) == (0, 1)
+        st = torch.cuda.current_stream().cuda_stream
+        a = torch.arange(1000, dtype=torch.int64, device="cuda")
+        b = torch.zeros_like(a)
+        assert comm.c.all_to_all(comm.c.ctx, a.data_ptr(), b.data_ptr(), a.numel(), st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        m = torch.arange(77, dtype=torch.int32, device="cuda")
+        assert comm.c.all_reduce(comm.c.ctx, m.data_ptr(), m.numel(), _acx.I32, _acx.RED_SUM, st) == 0
+        assert comm.c.all_reduce(comm.c.ctx, a.data_ptr(), a.numel(), _acx.I64, _acx.RED_MAX, st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(m.cpu(), torch.arange(77, dtype=torch.int32)) and torch.equal(a.cpu(), torch.arange(1000))
+        ak2 = [1, 1, -2, -2, -2, 0, 0, 1, 2, 1, -2, -1, -2, 0]
+        assert bfs_sharded_native(ak2, 10**6, comm=comm) == O.bfs(ak2, 10**6)
+    finally:
+        comm.close()
+
+
 def test_sharded_bfs_over_rccl_process_group(search):
     """The production communicator (torch.distributed, backend nccl == RCCL) with device tensors, world size 1:
     exercises the equal-split all_to_all_single and the all_reduce on the HIP engine's buffers."""
@@ -796,6 +904,18 @@ def test_sharded_bfs_over_rccl_process_group(search):
                 got = _bfs_through_comm(bfs_sharded, ak2, budget, comm)
                 assert got == O.bfs(ak2, budget)
             assert comm.stats["mask_all_reduce_calls"] > 0 and comm.stats["all_to_all_calls"] > 0
+        # the process group's own ncclComm_t handed to the library (ProcessGroupNCCL._comm_ptr) and `bfs` switched to the collective form
+        from ac_solver.search.breadth_first import bfs, shard_over_process_group
+        from ac_solver.search.sharded import NativeComm, bfs_sharded_native
+
+        nat = NativeComm.from_process_group()
+        assert (nat.rank, nat.world) == (0, 1)
+        assert bfs_sharded_native(ak2, 10**6, comm=nat) == O.bfs(ak2, 10**6)
+        old = shard_over_process_group(True, min_nodes=0)
+        try:
+            assert bfs(ak2, 10**6) == O.bfs(ak2, 10**6)
+        finally:
+            shard_over_process_group(old)
         import ac_solver.search.sharded as sh
 
         sh._FORCE_EXCHANGE = True
