@@ -654,16 +654,22 @@ def _bfs_sharded_run(engine, p, L, max_nodes, B, comm, world, rank, verbose, wan
     #   * The control-block calls of a failed rank may raise as well (a sticky HIP error): they are guarded, the rank keeps the last
     #     block it read (or a synthetic "running" one) and leaves the loop by the fail_hdr_chunk + lag rule and the closing all-reduce
     #     alone.  (engine.layout is host arithmetic on (parents, world, key words): it cannot fail with the device.)
+    bad_slots = set()  # a snapshot that was never taken leaves WHATEVER an earlier chunk (or search: the pinned slots are pooled) wrote in its slot
+
     def ctl_snapshot(slot):
+        bad_slots.discard(slot)
         try:
             engine.ctl_snapshot(slot)
         except Exception as e:  # noqa: BLE001
             if not exchange:
                 raise
             set_failed(e)
+            bad_slots.add(slot)
 
     def ctl_wait(slot):
         try:
+            if slot in bad_slots:
+                raise RuntimeError(f"no snapshot in slot {slot}")
             return engine.ctl_wait(slot)
         except Exception as e:  # noqa: BLE001
             if not exchange:

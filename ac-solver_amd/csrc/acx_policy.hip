@@ -70,7 +70,10 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 constexpr int kWaves = 8;          // waves per workgroup: 256 environments share every staged fragment
 constexpr int kSlotFrags = 17;     // fragments per ring slot (one output block of a 256-wide layer)
 constexpr int kSlotBytes = kSlotFrags * 1024;
-constexpr int kRing = 6;           // slots
+#ifndef ACX_POLICY_RING
+#define ACX_POLICY_RING 6
+#endif
+constexpr int kRing = ACX_POLICY_RING;  // slots
 constexpr int kAhead = kRing - 1;  // chunks in flight ahead of the one being consumed
 #ifndef ACX_POLICY_FRAG_AHEAD
 #define ACX_POLICY_FRAG_AHEAD 5
@@ -208,6 +211,14 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __
                 // instruction (that costs an s_nop each time), and the pair shares one v_cvt_pk_bf16_f32
 #pragma unroll
                 for (int q = 8 * u / UT; q < 8 * (u + 1) / UT; q++) {
+#ifdef ACX_POLICY_NO_TANH  // timing experiment only (wrong numbers): what the kernel costs without the tanh's vector instructions
+                    const uint32_t pk0 = pack_bf16(pend[2 * q], pend[2 * q + 1]);
+                    if (q < 4) lo[q] = pk0;
+                    else hi[q - 4] = pk0;
+                    if (q == 3) out_lo = __builtin_bit_cast(frag_ab, lo);
+                    if (q == 7) out_hi = __builtin_bit_cast(frag_ab, hi);
+                    continue;
+#endif
                     const float ea = __builtin_amdgcn_exp2f(pend[2 * q]), eb = __builtin_amdgcn_exp2f(pend[2 * q + 1]);
                     const float da = ea + 1.0f, db = eb + 1.0f;
                     const float ra = __builtin_amdgcn_rcpf(da), rb = __builtin_amdgcn_rcpf(db);
@@ -238,7 +249,11 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __
         // chunk c + 1 has landed for this wave's own loads ... and, behind the barrier, for everyone's (the running block reads its
         // first fragments before it ends); chunk c - 1 is consumed, so its slot takes chunk c + kAhead
         static_assert(P::issued_at_top(c) - P::pending_at_top(c) / 3 >= (c + 2 < P::C ? c + 2 : P::C), "chunk c + 1 must have landed behind this wait");
+#ifdef ACX_POLICY_NO_BARRIER  // timing experiment only (races on the ring): what the per-chunk workgroup barrier costs
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P::pending_at_top(c)) : "memory");
+#else
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(P::pending_at_top(c)) : "memory");
+#endif
 #ifdef ACX_POLICY_STAMP  // diagnostic build: shader-clock stamp per chunk into the (over-allocated) logprob buffer
         logprob[n_env + (blockIdx.x & 1) * 512 + wave * 64 + c] = (float)(long long)(__builtin_amdgcn_s_memtime() - t_start);  // (no branch: all lanes store the same word)
 #endif

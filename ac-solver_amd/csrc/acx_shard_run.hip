@@ -128,7 +128,7 @@ struct ShardRun {
         calls++;
         return fail_at_call > 0 && rank == fail_rank && calls == fail_at_call;
     }
-#define ECALL(expr) (hook() ? fail(ACX_E_NODEVICE, "engine call failed (simulated)") : (expr))
+#define ECALL(expr) (hook() ? fail(ACX_E_NODEVICE, "engine call failed (simulated): call %d, level %lld, %.40s", calls, (long long)levels, #expr) : (expr))
     void set_failed() {
         if (!failed) fail_msg = last_error_buf();
         failed = true;
@@ -261,16 +261,20 @@ struct ShardRun {
         return ACX_OK;
     }
 
+    bool slot_ok[4] = {false, false, false, false};  // a snapshot that was never taken leaves WHATEVER an earlier chunk (or search: the pinned
+                                                       // slots are pooled) wrote in its slot: such a slot is not read
     int ctl_snapshot(int slot) {
+        slot_ok[slot] = true;
         if (int rc = ECALL(acx_shard_ctl_snapshot(h, slot, main_st))) {
             if (!exchange) return rc;
             set_failed();
+            slot_ok[slot] = false;
         }
         return ACX_OK;
     }
     int ctl_wait(int slot) {
         int64_t got[ACX_SHARD_CTL_WORDS];
-        if (int rc = ECALL(acx_shard_ctl_wait(h, slot, got))) {
+        if (int rc = slot_ok[slot] ? ECALL(acx_shard_ctl_wait(h, slot, got)) : fail(ACX_E_NODEVICE, "no snapshot in slot %d", slot)) {
             if (!exchange) return rc;
             set_failed();
             if (!have_ctl) {  // "running", nothing known: the loop goes on until the failure rule ends it
