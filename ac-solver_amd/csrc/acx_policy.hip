@@ -284,24 +284,26 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __
     });
     const frag_cd& logit = head[0];
     const frag_cd& val = head[1];
-    // outputs 0..3 and 8..11 sit in lane half 0 (registers 0..3, 4..7), outputs 4..7 and 12..15 in half 1: both halves gather all 16
-    float lg[16];
-#pragma unroll
-    for (int v = 0; v < 8; v++) {
-        const float other = __shfl_xor(logit[v], 32);
-        lg[(v & 3) + 8 * (v >> 2)] = h ? other : logit[v];
-        lg[(v & 3) + 8 * (v >> 2) + 4] = h ? logit[v] : other;
-    }
     {
-        // Both lanes of an environment (l and l + 32) hold all 16 head outputs: each draws for eight of the actions (lane half h:
-        // actions 8 h .. 8 h + 7), one shuffle picks the better of the two candidates.  (Loops run over all 16 outputs with a test
-        // against n_actions: a runtime trip count would index lg[] dynamically.)
+        // Head output a of an environment sits in lane half (a >> 2) & 1, register (a & 3) + 4 (a >> 3).  Lane half h draws for the eight
+        // actions 8 h .. 8 h + 7: four of them are its own registers, four its partner's (lane ^ 32) -- one shuffle each; the soft-max's
+        // maximum and sum are taken over the lane's eight and combined with the partner's (round 6: the sixteen outputs used to be gathered
+        // into an array that both halves indexed by h, which the compiler kept in scratch memory).
+        float mine[8];  // logit of action 8 h + k
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float other_lo = __shfl_xor(logit[k], 32), other_hi = __shfl_xor(logit[4 + k], 32);
+            mine[k] = h ? other_hi : logit[k];          // action 8 h + k lives in half 0: registers k (h = 0: my own) and 4 + k (h = 1: the partner's)
+            mine[4 + k] = h ? logit[4 + k] : other_lo;  // action 8 h + 4 + k lives in half 1
+        }
         float mx = -3.0e38f;
 #pragma unroll
-        for (int a = 0; a < 16; a++) mx = a < n_actions ? fmaxf(mx, lg[a]) : mx;
+        for (int k = 0; k < 8; k++) mx = 8 * (int)h + k < n_actions ? fmaxf(mx, mine[k]) : mx;
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.0f;
 #pragma unroll
-        for (int a = 0; a < 16; a++) sum += a < n_actions ? __expf(lg[a] - mx) : 0.0f;
+        for (int k = 0; k < 8; k++) sum += 8 * (int)h + k < n_actions ? __expf(mine[k] - mx) : 0.0f;
+        sum += __shfl_xor(sum, 32);
         const float lse = mx + __logf(sum);
         int best = 0;
         float best_score = -3.0e38f, best_lp = 0.0f;
@@ -311,7 +313,7 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int a = 8 * (int)h + k;
-            const float lga = h ? lg[8 + k] : lg[k];
+            const float lga = mine[k];
             const uint32_t bits = fmix32(fmix32(((uint32_t)env * 16u + (uint32_t)a) ^ s_lo) + s_hi + (uint32_t)(env >> 28));
             // 23 random bits: (k + 0.5) * 2^-23 is exact in f32 for every k < 2^23, so u stays strictly inside (0, 1)
             // (with 24 bits k + 0.5 rounds to 2^24 for the largest k: u = 1, an infinite Gumbel score, once per 2^24 draws)
