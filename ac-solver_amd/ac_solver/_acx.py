@@ -96,8 +96,6 @@ SIGNATURES = {
     "acx_version": (C.c_int, []),
     "acx_last_error": (C.c_char_p, []),
     "acx_device_count": (C.c_int, []),
-    "acx_np_shuffle_epochs": (C.c_int, [C.c_uint32, C.c_int64, C.c_int, _i64p]),
-    "acx_py_curriculum_draws": (C.c_int, [C.POINTER(C.c_uint32), _i32p, C.c_int64, C.c_int64, C.c_int64, C.c_double, _u8p, _i64p]),
     "acx_move_batch_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "acx_move_batch": (C.c_int, [_i8p, _u8p, C.c_int64, C.c_int, C.c_int, _i8p, _i32p, _u8p, _i32p]),
     "acx_simplify_relators": (C.c_int, [_i8p, C.c_int64, C.c_int, C.c_int, _i8p, _i32p, _u8p]),

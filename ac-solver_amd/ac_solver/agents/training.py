@@ -105,10 +105,10 @@ class Curriculum:
         return nxt
 
     # ---- a rollout step's finished episodes at once ------------------------------------------------------------------------------
-    _C_MIN = 48  # below this many draws Python's own generator is cheaper than moving its state to libacx and back
+    _C_MIN = 48  # below this many draws Python's own generator is cheaper than moving its state to libacx_trainer and back
 
-    # The state of Python's global generator while libacx draws from it: taken out once (begin_borrow: 625 words, ~60 us with the
-    # conversions), advanced in place by every acx_py_curriculum_draws call, put back by end_borrow -- the training loop borrows it
+    # The state of Python's global generator while libacx_trainer draws from it: taken out once (begin_borrow: 625 words, ~60 us with the
+    # conversions), advanced in place by every acxt_py_curriculum_draws call, put back by end_borrow -- the training loop borrows it
     # for a whole rollout (nothing else draws from `random` in there); on its own, finish_episodes borrows per call.
     _borrowed = None
 
@@ -125,13 +125,14 @@ class Curriculum:
             random.setstate((ver, tuple(mt.tolist()) + (pos.value,), gauss))
 
     def _draws(self, n):
-        """next_state() n times after the first round, with both lists fixed: the same draws from `random`, taken in libacx
-        (acx_py_curriculum_draws restates CPython's Random.random / choice) on the state of the global generator.  -> states [n]"""
+        """next_state() n times after the first round, with both lists fixed: the same draws from `random`, taken in libacx_trainer
+        (acxt_py_curriculum_draws restates CPython's Random.random / choice) on the state of the global generator.  -> states [n]"""
         if n < self._C_MIN and self._borrowed is None:
             return [self.next_state() for _ in range(n)]
         import ctypes as C
 
         from ac_solver import _acx
+        from ac_solver.agents import _host
 
         mine = self._borrowed is None
         if mine:
@@ -139,8 +140,8 @@ class Curriculum:
         _, _, mt, pos = self._borrowed
         which, index = np.empty(n, np.uint8), np.empty(n, np.int64)
         solved, unsolved = self._list("solved"), self._list("unsolved")
-        _acx.check(_acx.lib.acx_py_curriculum_draws(mt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), n, len(solved), len(unsolved), float(self.p),
-                                                    _acx.ptr(which, C.c_uint8), _acx.ptr(index, C.c_int64)), "acx_py_curriculum_draws")
+        _host.check(_host.lib.acxt_py_curriculum_draws(mt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), n, len(solved), len(unsolved), float(self.p),
+                                                       _acx.ptr(which, C.c_uint8), _acx.ptr(index, C.c_int64)), "acxt_py_curriculum_draws")
         if mine:
             self.end_borrow()
         key = ("arrays", len(solved), len(unsolved))
@@ -253,7 +254,7 @@ class _MinibatchOrder:
     np.random.shuffle(b_inds)); nothing draws from that generator in between, so the permutations are a function of the seed alone.
     At BASELINE config 5's shape a shuffle of 4 Mi indices takes ~100 ms of host time, and each minibatch's slice went to the device
     through a synchronous copy -- with the GPU idle meanwhile (60 of an update's 123 ms).  Here a thread computes them through libacx
-    (acx_np_shuffle_epochs: NumPy's legacy algorithm restated, pinned against numpy in tests/test_agents_cpu.py, and -- unlike
+    (acxt_np_shuffle_epochs: NumPy's legacy algorithm restated, pinned against numpy in tests/test_agents_cpu.py, and -- unlike
     np.random.shuffle, which holds the GIL for all of its run -- off the interpreter lock), ONE UPDATE AHEAD: the permutations of
     update u + 1 are started at the top of update u (two pinned buffers take turns), go to the device in one copy, and a minibatch
     is a slice of that."""
@@ -283,9 +284,10 @@ class _MinibatchOrder:
             import ctypes as C
 
             from ac_solver import _acx
+            from ac_solver.agents import _host
 
             try:
-                _acx.check(_acx.lib.acx_np_shuffle_epochs(int(seed) & 0xFFFFFFFF, self.batch_size, self.epochs, _acx.ptr(out, C.c_int64)), "acx_np_shuffle_epochs")
+                _host.check(_host.lib.acxt_np_shuffle_epochs(int(seed) & 0xFFFFFFFF, self.batch_size, self.epochs, _acx.ptr(out, C.c_int64)), "acxt_np_shuffle_epochs")
             except BaseException as e:  # noqa: BLE001 -- re-raised by get() on the training thread
                 failed.append(e)
 

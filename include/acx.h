@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACX_VERSION 500  /* history: INTEGRATION.md, "ACX_VERSION history" */
+#define ACX_VERSION 600  /* history: INTEGRATION.md, "ACX_VERSION history" */
 
 /* return codes */
 #define ACX_OK 0
@@ -173,20 +173,6 @@ int acx_search(int kind, const int8_t *h_presentation, int L, int64_t max_nodes,
  * sequence (*n = its length, the first min(*n, cap) entries are written).  greedy_search then runs batch by batch on the
  * host-driven path (same result, slower). */
 int acx_search_minima_enable(int on);
-/* Host utility of the PPO driver (no device work): the permutations np.random.seed(seed); for e in range(epochs): np.random.shuffle(b_inds)
- * leaves in b_inds = np.arange(n) -- what the update loop of agents/training.py:121, 273-275 draws its minibatches from -- written to
- * h_out [epochs, n].  NumPy's legacy MT19937 / shuffle algorithm restated (a third-party dependency of the reference); runs without
- * the interpreter lock, so the driver computes it on a thread beside the rollout.  n < 2^32. */
-int acx_np_shuffle_epochs(uint32_t seed, int64_t n, int epochs, int64_t *h_out);
-/* Host utility of the PPO driver (no device work): the draws of n consecutive curriculum decisions (training.py:199-221 of the
- * reference, after its first round: `len(solved) == 0 or (unsolved and random.uniform(0, 1) > repeat_solved_prob)` ->
- * random.choice(list(unsolved)), else random.choice(list(solved))) for FIXED sizes of the two lists.  mt_state [624] / *mt_pos: the
- * state of Python's global `random` generator as random.getstate()[1] holds it, advanced in place exactly as n calls of the
- * Python code advance it (CPython's Random restated: a third-party dependency of the reference).  which[i] = 0: element index[i] of
- * the unsolved list, 1: of the solved list.  The caller splits a rollout step's finished episodes where a list changes. */
-int acx_py_curriculum_draws(uint32_t *mt_state, int32_t *mt_pos, int64_t n, int64_t n_solved, int64_t n_unsolved,
-                            double repeat_solved_prob, uint8_t *which, int64_t *index);
-
 int acx_search_last_minima(int32_t *lengths, int64_t cap, int64_t *n);
 
 /* Test hook (repeat-determinism tests): with the switch on, every acx_search of the process ends with one extra pass that

@@ -31,6 +31,16 @@ def test_library_exports_every_declared_symbol():
     assert isinstance(_acx.device_count(), int)
 
 
+def test_trainer_library_exports_what_its_header_declares():
+    """include/acx_trainer.h / libacx_trainer.so: the host utilities of the PPO trainer, kept out of libacx.so's public header"""
+    from ac_solver.agents import _host
+
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "acx_trainer.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(acxt_[a-z0-9_]+)\s*\(", src)))
+    assert names == sorted(_host.SIGNATURES) and all(hasattr(_host.lib, n) for n in names)
+    assert not [n for n in declared_functions() if "shuffle" in n or "curriculum" in n]  # gone from acx.h
+
+
 def test_header_flags_match_binding():
     from ac_solver import _acx
 

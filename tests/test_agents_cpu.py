@@ -205,12 +205,13 @@ def test_curriculum_object_equals_per_episode_choose_next_state():
 
 
 def test_py_curriculum_draws_are_pythons_own():
-    """acx_py_curriculum_draws (csrc/acx_step.hip, host only): CPython's random.uniform / random.choice restated on the state of the
+    """acxt_py_curriculum_draws (csrc/trainer/acx_trainer.cpp -> libacx_trainer.so, host only): CPython's random.uniform / random.choice restated on the state of the
     global generator -- the same decisions as the Python expression of choose_next_state, and the same generator state afterwards."""
     import ctypes as C
     import random
 
     from ac_solver import _acx
+    from ac_solver.agents import _host
 
     for seed, n_solved, n_unsolved, p, n in ((1, 0, 17, 0.25, 300), (2, 5, 0, 0.25, 300), (3, 1, 1, 0.5, 500), (4, 640, 550, 0.25, 4000),
                                              (5, 3, 1190, 0.0, 1000), (6, 1189, 1, 1.0, 1000), (7, 2 ** 20 + 1, 2 ** 31, 0.3, 2000)):
@@ -228,15 +229,15 @@ def test_py_curriculum_draws_are_pythons_own():
         mt = np.array(internal[:624], dtype=np.uint32)
         pos = C.c_int32(internal[624])
         which, index = np.empty(n, np.uint8), np.empty(n, np.int64)
-        assert _acx.lib.acx_py_curriculum_draws(mt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), n, n_solved, n_unsolved, p,
+        assert _host.lib.acxt_py_curriculum_draws(mt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), n, n_solved, n_unsolved, p,
                                                 _acx.ptr(which, C.c_uint8), _acx.ptr(index, C.c_int64)) == 0
         assert list(zip(which.tolist(), index.tolist())) == want
         assert (ver, tuple(mt.tolist()) + (pos.value,), gauss) == after
     mt = np.zeros(624, np.uint32)
     pos = C.c_int32(624)
     one = np.empty(1, np.uint8), np.empty(1, np.int64)
-    assert _acx.lib.acx_py_curriculum_draws(mt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), 1, 0, 0, 0.5, _acx.ptr(one[0], C.c_uint8),
-                                            _acx.ptr(one[1], C.c_int64)) == _acx.E_INVAL
+    assert _host.lib.acxt_py_curriculum_draws(mt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), 1, 0, 0, 0.5, _acx.ptr(one[0], C.c_uint8),
+                                            _acx.ptr(one[1], C.c_int64)) == _host.E_INVAL
 
 
 def test_finished_episodes_of_a_step_at_once_equal_one_by_one():
@@ -338,7 +339,7 @@ def test_minibatch_order_is_the_references_shuffle_sequence():
 
 
 def test_libacx_shuffle_is_numpys_legacy_shuffle():
-    """acx_np_shuffle_epochs (csrc/acx_step.hip, a host utility without device work): np.random.seed(s) followed by one
+    """acxt_np_shuffle_epochs (csrc/trainer/acx_trainer.cpp -> libacx_trainer.so, a host utility without device work): np.random.seed(s) followed by one
     np.random.shuffle of the same array per epoch, bit for bit -- MT19937 seeded by an integer, Fisher-Yates from the top with
     masked rejection sampling.  Pinned against numpy itself, including seeds above 2^31 and sizes around powers of two."""
     import ctypes as C
@@ -346,13 +347,14 @@ def test_libacx_shuffle_is_numpys_legacy_shuffle():
     import numpy as np
 
     from ac_solver import _acx
+    from ac_solver.agents import _host
 
     for seed, n, epochs in ((1, 10, 1), (7, 1000, 3), (123456, 100003, 2), (2**31 + 5, 4096, 1), (3, 1, 2), (42, 2, 4), (0, 65537, 1), (2**32 - 1, 65535, 2)):
         out = np.empty((epochs, n), np.int64)
-        assert _acx.lib.acx_np_shuffle_epochs(seed, n, epochs, _acx.ptr(out, C.c_int64)) == 0
+        assert _host.lib.acxt_np_shuffle_epochs(seed, n, epochs, _acx.ptr(out, C.c_int64)) == 0
         np.random.seed(seed)
         a = np.arange(n)
         for e in range(epochs):
             np.random.shuffle(a)
             assert np.array_equal(out[e], a), (seed, n, e)
-    assert _acx.lib.acx_np_shuffle_epochs(1, 0, 1, _acx.ptr(np.empty(1, np.int64), C.c_int64)) == _acx.E_INVAL
+    assert _host.lib.acxt_np_shuffle_epochs(1, 0, 1, _acx.ptr(np.empty(1, np.int64), C.c_int64)) == _host.E_INVAL

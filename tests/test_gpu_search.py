@@ -980,6 +980,41 @@ def test_config4_all_1190_ms_presentations_bfs_1e4_vs_oracle(search, golden_json
     assert not bad, bad[:10]
 
 
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("cyclical", [False, True])
+def test_config4_all_1190_ms_presentations_through_the_sharded_engine(search, golden_json, world, cyclical):
+    """BASELINE config 4 as it is worded -- bfs over the Miller-Schupp presentations with the frontier SHARDED: all 1190 presentations
+    (both key widths), budget 1e4, through acx_bfs_sharded on 2 and 8 thread ranks of the one GPU, the frontier partitioned by owner at
+    the first level of >= 64 parents and exchanged in chunks of 1024 parents from there on; (solved, path) and the node / expansion
+    counts of every search on every rank against the same oracle rows as the single-GPU test above (breadth_first.py:61-95)."""
+    from ac_solver.search.sharded import NativeComm, bfs_sharded_native
+    from oracle import ac_oracle as O
+    from tests.shard_helpers import run_threads
+
+    pool = ms_pool_generator_order(golden_json("ms_pool.json"))
+    assert len(pool) == 1190
+    rows = [np.array(p, dtype=np.int8) for p in pool]
+    want = [O.bfs(r, 10**4, cyclically_reduce_after_moves=cyclical, stats=True) for r in rows]
+
+    def run(comm):
+        nat = NativeComm.from_python(comm)
+        out = [bfs_sharded_native(r, 10**4, cyclically_reduce_after_moves=cyclical, comm=nat, batch_parents=1024, replicate_below=64, want_stats=True) for r in rows]
+        assert not nat.errors, nat.errors[:1]
+        return out
+
+    got = run_threads(world, run)
+    bad = []
+    exchanged = 0
+    for r, res in enumerate(got):
+        for k, ((ok, path, st), (wok, wpath, wst)) in enumerate(zip(res, want)):
+            if (ok, path) != (wok, wpath) or st["nodes"] != wst["nodes"] or st["expanded"] != wst["expanded"]:
+                bad.append((r, k, ok, wok, st["nodes"], wst["nodes"], st["expanded"], wst["expanded"]))
+            exchanged += r == 0 and st["levels"] > st["replicated_levels"]
+    assert not bad, bad[:10]
+    assert exchanged > 1000, exchanged  # (nearly every search reaches a level of 64 parents within its 1e4 nodes: the exchange really ran)
+
+
 def _two_process_worker(rank, world, port, q):
     """child process of test_sharded_bfs_two_processes_share_one_gpu: its own HIP context on cuda:0, gloo between the processes"""
     import os
