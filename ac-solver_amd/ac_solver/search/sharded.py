@@ -61,7 +61,7 @@ FILL_HARD = 1 << 20  # the hard bound: every workgroup sends a region all it has
 # two meet near 2^19-2^20 parents; 2^18 keeps the replicated share of a 1e8-node search below 1 % of its expansions.
 REPLICATE_BELOW = 1 << 18
 ST_RUNNING, ST_SOLVED, ST_BUDGET, ST_MOVE_ERROR, ST_FAILED = 0, 1, 2, 3, 4
-_FAIL_TEXT = {1: "a send region or the record log overflowed", 2: "node capacity exceeded", 3: "visited table full", 4: "engine call failed"}
+_FAIL_TEXT = {1: "a send region overflowed (the record log never does: the host grows it before a chunk is expanded)", 2: "node capacity exceeded", 3: "visited table full", 4: "engine call failed"}
 
 
 def _torch():
@@ -409,7 +409,11 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
         # on, where a rank's share of a chunk is small (profiles/r5_shard_thread_ranks_device_work.txt: 3.7 -> 3.4 ms per rank at 8)
         batch_parents = 1 << (22 if (comm is not None and comm.world >= 8) else 21)
     reruns = 0
+    tried = []
     for fill, bp in ((region_fill, batch_parents), (FILL_DEFAULT, batch_parents), (FILL_HARD, min(batch_parents, 1 << 17))):
+        if (fill, bp) in tried:  # (a caller who asked for the default itself: the identical attempt would overflow again)
+            continue
+        tried.append((fill, bp))
         try:
             out = _bfs_sharded_once(presentation, max_nodes_to_explore, region_fill=fill, **dict(kw, batch_parents=bp))
         except _RegionOverflow:

@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(256) k_rank_sort(SearchDev<W> d, const uint32_
 
 
 // exclusive prefix sum of n 32-bit flags (the batch-per-launch paths: greedy fallback, simplex graph).  tmp == nullptr: only the size
-// of the temporary storage is returned in *tmp_bytes.  Defined once, in acx_search.hip (the only unit that includes rocprim).
+// of the temporary storage is returned in *tmp_bytes.  Defined once, in acx_search.hip (three small kernels of the library's own).
 int scan_u32_exclusive(void* tmp, size_t* tmp_bytes, const uint32_t* in, uint32_t* out, size_t n, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------- host ---
@@ -661,12 +661,20 @@ struct StampBuf {
         }
         // the WHOLE block, not only the `want` bytes in use: a later, larger table that gets this block with its epoch tag must not find
         // bytes that were never filled (or stamps from before an epoch wrap) beyond this table's end
-        epoch = 1;
+        // (the tag only once the fill is QUEUED: a block whose fill failed goes back untagged -- epoch 0 -- and is filled by whoever takes it next)
         ACX_HIP_TRY(hipMemsetAsync(p, 0xff, bytes, st));
+        epoch = 1;
+        filled_on = st;
+        fresh = true;
         return ACX_OK;
     }
+    hipStream_t filled_on = nullptr;
+    bool fresh = false;  // this owner queued the fill: a give-back before that stream has drained (an error return right behind alloc) must not
+                         // hand the block to another stream as "clean"
     ~StampBuf() {
-        if (p) block_pool().give(p, bytes, dev, epoch);
+        if (!p) return;
+        if (fresh && hipStreamQuery(filled_on) != hipSuccess) (void)hipStreamSynchronize(filled_on);
+        block_pool().give(p, bytes, dev, epoch);
     }
 };
 

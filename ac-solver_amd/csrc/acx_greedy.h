@@ -133,7 +133,7 @@ constexpr uint32_t kGreedyMultiThreads = ACX_GREEDY_MULTI_THREADS;
 #ifndef ACX_GREEDY_MULTI_R
 #define ACX_GREEDY_MULTI_R 2
 #endif
-constexpr uint32_t kGreedyResident = 512;  // workgroups of k_greedy_sched the chip holds: two on each of the 256 compute units
+constexpr uint32_t kGreedyPerCu = 2;  // workgroups of k_greedy_sched a compute unit holds (512 lanes, 128 registers each)
 template <> struct greedy_cfg<uint64_t> { static constexpr uint32_t kSortCap = ACX_GREEDY_MULTI_R * kGreedyMultiThreads; };
 template <> struct greedy_cfg<u128> { static constexpr uint32_t kSortCap = 2 * kGreedyMultiThreads; };
 
@@ -1187,31 +1187,40 @@ __global__ void __launch_bounds__(kGreedyMultiThreads, ACX_GREEDY_MULTI_WAVES_PE
     const uint32_t tid = threadIdx.x;
     uint32_t slot = 0xFFFFFFFFu, used = 0, prev_hi = 0, prev_nlen = 0;
     for (;;) {
-        __syncthreads();
-        if (tid == 0) s_job = atomicAdd(counter, 1u);
-        __syncthreads();
-        const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_job);  // (uniform: the slot and the job arrive through scalar loads)
-        if (j >= n_jobs) break;
-        if (slot == 0xFFFFFFFFu) {  // the first job of this workgroup: a slot of the pool
+        // A workgroup takes its SLOT first and a job only once it holds one (round 6: it used to take the job first and then spin for a
+        // slot -- a workgroup without a slot sat on a compute unit holding a search that could not start).  With fewer slots than resident
+        // workgroups (ACX_OPT_GREEDY_SLOTS, little free memory) the ones that find no slot leave as soon as the job counter is exhausted.
+        if (slot == 0xFFFFFFFFu) {
+            __syncthreads();
             if (tid == 0) {
-                uint32_t w = blockIdx.x % slot_words;
+                uint32_t w = blockIdx.x % slot_words, found = 0xFFFFFFFFu;
                 for (;;) {
                     const uint32_t bits = atomicOr(&slot_free[w], 0u);
                     if (bits) {
                         const uint32_t b = 1u << (uint32_t)__builtin_ctz(bits);
                         if (atomicAnd(&slot_free[w], ~b) & b) {
-                            s_slot = w * 32u + (uint32_t)__builtin_ctz(bits);
+                            found = w * 32u + (uint32_t)__builtin_ctz(bits);
                             break;
                         }
                     } else {
                         w = w + 1 == slot_words ? 0u : w + 1;
-                        if (w == blockIdx.x % slot_words) __builtin_amdgcn_s_sleep(64);  // (once around without a free slot: more workgroups resident than slots)
+                        if (w == blockIdx.x % slot_words) {  // once around without a free slot: more workgroups resident than slots
+                            if (atomicOr(counter, 0u) >= n_jobs) break;  // nothing left to start: do not wait for a slot
+                            __builtin_amdgcn_s_sleep(64);
+                        }
                     }
                 }
+                s_slot = found;
             }
             __syncthreads();
             slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot);
+            if (slot == 0xFFFFFFFFu) break;
         }
+        __syncthreads();
+        if (tid == 0) s_job = atomicAdd(counter, 1u);
+        __syncthreads();
+        const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_job);  // (uniform: the slot and the job arrive through scalar loads)
+        if (j >= n_jobs) break;
         GreedyDev<W> g = slots[slot];
         const uint32_t nlen_cap = g.nlen;  // the slot's bucket table has rows for this many total lengths
         const GreedyJob<W> jb = jobs[j];

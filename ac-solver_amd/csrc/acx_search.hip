@@ -16,7 +16,7 @@
 //     of acx_bfs.h; greedy: an id table
 //   * winners are numbered by an exclusive scan in tag order, which reproduces the reference's insertion
 //     order (BFS: k_bfs_count + k_bfs_compact, which also writes the nodes; the greedy batch-per-launch path: flag pass +
-//     rocprim scan + k_commit); the per-parent budget test (breadth_first.py:91-95) becomes "first parent whose cumulative
+//     exclusive scan + k_commit); the per-parent budget test (breadth_first.py:91-95) becomes "first parent whose cumulative
 //     winner count reaches the budget"; the solved test (:84-85) "minimum tag with total length 2"
 //   * greedy additionally stops a batch right after the first parent that inserts a NEW child shorter than
 //     the bucket (that child is the heap's next minimum); later parents stay queued
@@ -25,16 +25,94 @@
 // W = u64 for L <= 29, u128 for L <= 61.  Roofline: HBM (random table probes); see DESIGN.md.
 #include <string.h>
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include "acx_searcher.h"
 #include "acx_bfs.h"
 
 namespace acx {
 
+// ---- exclusive prefix sum of 32-bit flags (the batch-per-launch paths: greedy fallback, simplex graph) -------------------------------
+// Round 6: three small kernels of the library's own instead of rocprim::exclusive_scan (the one rocprim call left; its include cost this
+// unit several seconds of compile time).  Tiles of 4096 elements: scan inside the tile + the tile's total; one workgroup scans the
+// totals; the tiles add their offset.  Not a throughput path.
+constexpr int kScanU32Tile = 4096;
+__global__ void __launch_bounds__(1024) k_scan_u32_tiles(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t* __restrict__ totals, size_t n) {
+    __shared__ uint32_t s_w[16];
+    ACX_VGPR_PAD("v31");
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const size_t p0 = (size_t)blockIdx.x * kScanU32Tile + (size_t)tid * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = p0 + k < n ? in[p0 + k] : 0u;
+    const uint32_t sum = v[0] + v[1] + v[2] + v[3];
+    uint32_t incl = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= (uint32_t)o) incl += a;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - sum, total = 0;
+#pragma unroll
+    for (uint32_t w2 = 0; w2 < 16; w2++) {
+        if (w2 < wave) before += s_w[w2];
+        total += s_w[w2];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (p0 + k < n) out[p0 + k] = before;
+        before += v[k];
+    }
+    if (tid == 0) totals[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(1024) k_scan_u32_totals(uint32_t* __restrict__ totals, uint32_t tiles) {
+    __shared__ uint32_t s_p[1024];
+    ACX_VGPR_PAD("v31");
+    const uint32_t tid = threadIdx.x, per = (tiles + 1023u) / 1024u;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < per; k++) sum += tid * per + k < tiles ? totals[tid * per + k] : 0u;
+    s_p[tid] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint32_t a = tid >= o ? s_p[tid - o] : 0u;
+        __syncthreads();
+        s_p[tid] += a;
+        __syncthreads();
+    }
+    uint32_t ex = s_p[tid] - sum;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t t = tid * per + k;
+        if (t < tiles) {
+            const uint32_t c = totals[t];
+            totals[t] = ex;
+            ex += c;
+        }
+    }
+}
+__global__ void __launch_bounds__(1024) k_scan_u32_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ totals, size_t n) {
+    ACX_VGPR_PAD("v31");
+    const uint32_t off = totals[blockIdx.x];
+    const size_t p0 = (size_t)blockIdx.x * kScanU32Tile + (size_t)threadIdx.x * 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (p0 + k < n) out[p0 + k] += off;
+}
+
 int scan_u32_exclusive(void* tmp, size_t* tmp_bytes, const uint32_t* in, uint32_t* out, size_t n, hipStream_t st) {
-    if (rocprim::exclusive_scan(tmp, *tmp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), st) != hipSuccess)
-        return fail(ACX_E_NODEVICE, "rocprim::exclusive_scan failed");
+    const size_t tiles = (n + kScanU32Tile - 1) / kScanU32Tile, need = (tiles + 1) * 4;
+    if (!tmp) {
+        *tmp_bytes = need;
+        return ACX_OK;
+    }
+    if (*tmp_bytes < need) return fail(ACX_E_INVAL, "scan_u32_exclusive: %zu bytes of temporary storage, %zu needed", *tmp_bytes, need);
+    if (n == 0) return ACX_OK;
+    uint32_t* totals = (uint32_t*)tmp;
+    hipLaunchKernelGGL(k_scan_u32_tiles, dim3((unsigned)tiles), dim3(1024), 0, st, in, out, totals, n);
+    if (tiles > 1) {
+        hipLaunchKernelGGL(k_scan_u32_totals, dim3(1), dim3(1024), 0, st, totals, (uint32_t)tiles);
+        hipLaunchKernelGGL(k_scan_u32_add, dim3((unsigned)tiles), dim3(1024), 0, st, out, totals, n);
+    }
+    ACX_HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
 

@@ -21,9 +21,15 @@ struct SearchGroupIn {
     int L;
     int64_t out0;
 };
+// workgroups of k_greedy_sched the device holds at once: kGreedyPerCu per compute unit (512 on an MI355X: 256 compute units)
+static uint32_t greedy_resident() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return kGreedyPerCu * (uint32_t)std::max(cus, 1);
+}
 static uint32_t greedy_slots_wanted() {
-    // two workgroups of this kernel per compute unit (512 lanes, 128 registers each); ACX_OPT_GREEDY_SLOTS: the tests run many jobs on a few slots
-    return (uint32_t)std::min<int64_t>(std::max<int64_t>(option(ACX_OPT_GREEDY_SLOTS, kGreedyResident), 1), 4096);
+    // a slot per resident workgroup; ACX_OPT_GREEDY_SLOTS: the tests run many jobs on a few slots
+    return (uint32_t)std::min<int64_t>(std::max<int64_t>(option(ACX_OPT_GREEDY_SLOTS, greedy_resident()), 1), 4096);
 }
 
 // The SLOTS of a call -- the memory of one greedy search each (visited table, bucket table / bitmap / arena, node arrays, a small sort
@@ -679,7 +685,7 @@ extern "C" int acx_search_groups(int kind, int n_groups, const int8_t* const* h_
     // memory) a waiting workgroup would hold a compute unit while it spins for a slot, so the slots are shared out in proportion to
     // the expected work: a 128-bit search costs ~1.7 x a 64-bit one (measured on the Miller-Schupp sweep).
     uint32_t wgs_wide = pool.S, wgs_narrow = pool.S;
-    if (n_narrow && n_wide && pool.S < kGreedyResident) {
+    if (n_narrow && n_wide && pool.S < greedy_resident()) {
         const double share = 1.7 * (double)n_wide / (1.7 * (double)n_wide + (double)n_narrow);
         wgs_wide = (uint32_t)std::min<double>(std::max<double>(1.0, share * pool.S + 0.5), std::max<double>(1.0, (double)pool.S - 1.0));
         wgs_narrow = std::max<uint32_t>(1u, pool.S - wgs_wide);

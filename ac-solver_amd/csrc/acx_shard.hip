@@ -204,7 +204,7 @@ __device__ __forceinline__ uint32_t gmask_of(const int32_t* __restrict__ gmask, 
 // Region capacity at world > 1: `fill_q8` / 256 x the even share of ALL children + two workgroups' worth (never more than the
 // hard bound).  The default (fill_q8 <= 0) is 1.25 x: safe whatever the presentation does, but the records that are really
 // sent (the unchanged children, the undo children and the in-tile duplicates stay home) fill ~38 % of that, and the all-to-all
-// moves the whole region.  The orchestrator therefore passes the fullest region of the previous level x 1.3
+// moves the whole region.  The orchestrator therefore passes the fullest region of the previous level x 1.25 + 12 / 256 of the even share
 // (ctl[C_LEVEL_FILL]); an overflow fails the search (FAIL_REGION) and the orchestrator reruns it with the default.
 constexpr int kShardFillDefault = 320;
 constexpr int kShardFillHard = 1 << 20;  // fill_q8 at or above this: the hard bound itself (the orchestrator's last resort after two overflows)

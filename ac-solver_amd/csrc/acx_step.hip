@@ -175,6 +175,8 @@ __global__ void __launch_bounds__(64) k_replay_paths(const int8_t* __restrict__ 
     if (final_rows && ok) {
         unpack_relator<W>(s.w0, s.n0, L, final_rows + i * 2 * L);
         unpack_relator<W>(s.w1, s.n1, L, final_rows + i * 2 * L + L);
+    } else if (final_rows) {  // a row that does not unpack (err ACX_ERR_UNPACKABLE) ends as zeros, not as whatever the scratch held
+        for (int k = 0; k < 2 * L; k++) final_rows[i * 2 * L + k] = 0;
     }
 }
 

@@ -189,7 +189,7 @@ int acx_release_cached_memory(void);
  * miller_schupp.py:95-177, runs them one after another).  Both kinds run as GROUPS of searches, each search with its own visited
  * table and node arena.  bfs: the searches of a group share the launches of the fused single search (acx_bfs_many.h: a tile of one
  * search's batch per workgroup, a batch of every running search per round of four launches).  greedy_search: ONE launch of up to
- * 256 persistent workgroups (ACX_OPT_GREEDY_SLOTS), each with the memory of one search, which take the searches from a counter one
+ * two persistent workgroups per compute unit (512 on an MI355X; ACX_OPT_GREEDY_SLOTS), each with the memory of one search, which take the searches from a counter one
  * after the other (k_greedy_sched, acx_greedy.h).  A greedy search that outgrows a capacity of its workgroup is rerun alone through
  * acx_search.  `n_threads` only matters on the fallback path (n == 1, the option ACX_OPT_GREEDY_HOST, `verbose` minima or the digest
  * hook on): there that many host threads run one acx_search each, every search on its own HIP stream; 1..64, clamped.
@@ -258,7 +258,7 @@ int acx_shard_key_words(int L); /* 2 for L <= 29, 4 for L <= 61 */
  * world > 1 in 1/256 of the even share of ALL children (+ two workgroups' worth); <= 0 or 321 .. 2^20 - 1: the default 320 =
  * 1.25 x; >= 2^20: the hard bound (every workgroup sends a region all it has: safe for any input, world^2 x the even share).
  * Only the children whose owner is another rank are sent (a few per cent, acx_owner.h), and the all-to-all moves whole regions:
- * the orchestrator passes 1.3 x the fullest region of the previous level (control word ACX_SHARD_CTL_LEVEL_FILL, max over the
+ * the orchestrator passes 1.25 x the fullest region of the previous level + 12 / 256 (control word ACX_SHARD_CTL_LEVEL_FILL, max over the
  * ranks) and reruns the search with the default, then with the hard bound, if a region ever overflows (failure code 1). */
 int acx_shard_layout(int64_t n_parents, int world, int key_words, int fill_q8, int64_t *subregions, int64_t *subcap, int64_t *region_words);
 /* node_cap: local nodes; chunk_parents: the largest chunk (global parents) */
