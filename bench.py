@@ -255,6 +255,36 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
     # where a chunk period goes: device time of the expansion, the all-to-all, the dedup, the mask all-reduce and the commit per
     # full-size chunk, and how much of their sum the side stream hides (overlap_effective > 1)
     one["timeline"] = timeline_of(comms["shared"], budget)
+    # the same search as ONE C call per rank (acx_bfs_sharded, csrc/acx_shard_run.hip): the chunk loop in C++ on the process group's own RCCL
+    # communicator (ProcessGroupNCCL._comm_ptr -> acx_comm_rccl); the numbers above are the Python orchestration of the same engine
+    def timed_native(b, reps=3):
+        from ac_solver.search.sharded import NativeComm, bfs_sharded_native
+
+        nat = NativeComm.from_process_group(device=dev) if (use_dist and world > 1) else None
+        bfs_sharded_native(p, b, comm=nat)
+        torch.cuda.synchronize()
+        samples, st = [], None
+        for _ in range(reps):
+            if use_dist:
+                dist.barrier()
+            t0 = time.perf_counter()
+            ok, path, st = bfs_sharded_native(p, b, comm=nat, want_stats=True)
+            torch.cuda.synchronize()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            samples.append(float(dt[0]))
+        secs = sorted(samples)[len(samples) // 2]
+        return {"nodes_per_s": st["nodes"] / secs, "nodes": st["nodes"], "seconds": secs, "samples_seconds": samples, "levels": st["levels"], "chunks": st["chunks"],
+                "replicated_levels": st["replicated_levels"], "expanded": st["expanded"], "n_gpus": world, "budget": b, "setup_seconds": st["setup_seconds"],
+                "loop_seconds": st["loop_seconds"], "collectives": {k: st[k] for k in ("all_to_all_calls", "all_to_all_bytes", "all_reduce_calls", "all_reduce_bytes")},
+                "entry": "acx_bfs_sharded: one C call per rank" + (", collectives on the process group's RCCL communicator (acx_comm_rccl)" if nat is not None else " (one rank: no collective)")}
+
+    try:
+        out["bfs_sharded_native"] = timed_native(budget)
+        out["bfs_sharded_native_strong"] = timed_native(STRONG_BUDGET, reps=2)
+    except Exception as e:  # noqa: BLE001
+        out["bfs_sharded_native"] = dict(out.get("bfs_sharded_native", {}), error=f"{type(e).__name__}: {e}")
     # the strong-scaling point of the 1 -> 8 GPU curve: the SAME 4e8-node search at every N
     try:
         out["bfs_sharded_strong"] = timed_sharded(comms["shared"], STRONG_BUDGET, reps=3)
@@ -483,7 +513,7 @@ def extra_env_numbers(dev, pool):
         # Blocks of 40 launches back to back for >= 0.3 s of device time: the FIRST block is a burst right after lighter work (what
         # rounds 1-3 reported: 67-69 us per 4 Mi-env launch), the LAST ones are the sustained rate of a kernel that keeps HBM
         # saturated (78-79 us: the same figure tools/env_roofline.py measures in a process of its own, by HIP events and by
-        # rocprofv3 --kernel-trace -- profiles/r4_env_step_roofline.json).  `us_per_step_launch` is the sustained median.
+        # rocprofv3 --kernel-trace -- profiles/r6_env_step_roofline.json: 74 us by HIP events, 69 us traced on this round's kernel).  `us_per_step_launch` is the sustained median.
         k = 0
         for _ in range(4):
             step(k)
@@ -512,14 +542,14 @@ def extra_env_numbers(dev, pool):
                                "frac_of_hbm_peak_algorithmic": ALGO_BYTES_PER_STEP * n_big / us / 1e3 / HBM_PEAK_GBS,
                                "hbm_bytes_beyond_mall_per_launch": beyond, "frac_of_hbm_peak_beyond_mall": beyond / us / 1e3 / HBM_PEAK_GBS,
                                "state_stays_in_infinity_cache": state_resident}
-        tracked = os.path.join(ROOT, "profiles", "r4_env_step_roofline.json")
-        if os.path.exists(tracked):  # the same kernel and batch in a process of its own (tools/profile_env_r4.sh): HIP events and the kernel trace of the same command
+        tracked = os.path.join(ROOT, "profiles", "r6_env_step_roofline.json")
+        if os.path.exists(tracked):  # the same kernel and batch in a process of its own (tools/profile_env_r6.sh): HIP events and the kernel trace of the same command
             with open(tracked) as fh:
                 t = json.load(fh).get(str(n_big), {})
             if t.get("rocprof_kernel_trace"):
                 regimes[str(n_big)]["tracked"] = {"hip_event_us": t["hip_event"]["hip_event_us_per_launch"], "rocprof_avg_us": t["rocprof_kernel_trace"]["avg_us"],
                                                   "rocprof_median_us": t["rocprof_kernel_trace"]["median_us"], "traffic_bytes_per_launch": t.get("traffic_bytes_per_launch"),
-                                                  "source": f"profiles/r4_env_step_roofline.json + r4_env_step_{n_big}_kernel_stats.csv"}
+                                                  "source": f"profiles/r6_env_step_roofline.json + r6_env_step_{n_big}_int8_kernel_stats.csv"}
         del env, obs, tape, rew, done, trunc
     out["throughput_regime"] = regimes["4194304"]
     out["throughput_regime"]["hbm_honest"] = True   # THE size to read the env kernel's HBM fraction from
@@ -927,49 +957,61 @@ def main():
         out["roofline"]["hbm_bytes_beyond_mall"] = 0 if working_set < (256 << 20) else (ALGO_BYTES_PER_STEP - 50) * N
         out["roofline"]["working_set_bytes"] = working_set
         out["roofline"]["rollout_rows"] = rows_used
-        ev = os.path.join(ROOT, "profiles", "r5_env_step_roofline.json")
+        # the fractions by name: by the launch PERIOD timed in this run (= `frac`), and counting only the bytes that HAVE to
+        # reach HBM at this batch size (the packed state, 24 B per environment, stays in the 256 MiB Infinity Cache from launch to launch)
+        out["roofline"]["frac_by_period"] = achieved / HBM_PEAK_GBS
+        out["roofline"]["frac_hbm_beyond_mall"] = out["roofline"]["hbm_bytes_beyond_mall"] / launch_s / 1e9 / HBM_PEAK_GBS
+        ev = os.path.join(ROOT, "profiles", "r6_env_step_roofline.json")
         if os.path.exists(ev) and N == N_ENVS:
             with open(ev) as f:
-                r5 = json.load(f)
-            kt, stp = r5.get(str(N), {}).get("rocprof_kernel_trace"), r5.get("stamps_65536")
+                r6 = json.load(f)
+            here = r6.get(str(N), {})
+            kt, stp = here.get("rocprof_kernel_trace"), r6.get("stamps_65536")
             if kt:
                 # the same command under rocprofv3 --kernel-trace: begin-to-end of every dispatch of the replayed graph.  A dispatch that
                 # is longer than the launch PERIOD measured here cannot be the same thing (an isolated dispatch's latency): no fraction then.
                 rp = {"avg_kernel_us": kt["avg_us"], "min_kernel_us": kt["min_us"], "calls": kt["calls"], "period_us_under_rocprof": kt.get("period_us_under_rocprof"),
-                      "source": "profiles/r5_env_step_65536_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-search --no-extras "
-                                "--no-cpu-baseline: tools/profile_env_r5.sh)"}
+                      "source": "profiles/r6_env_step_65536_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-search --no-extras "
+                                "--no-cpu-baseline: tools/profile_env_r6.sh)"}
                 if kt["avg_us"] <= launch_s * 1e6:
                     rp["frac_by_kernel_duration"] = ALGO_BYTES_PER_STEP * N / (kt["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
                 else:
-                    rp["note"] = "the traced dispatches are longer than the launch period timed in this run: not comparable, no fraction derived"
+                    rp["note"] = ("the traced dispatches are longer than the launch period timed in this run (the profiler serialises the graph's nodes): not comparable, no "
+                                  "fraction derived; the traces that DO agree with their HIP events are at_1Mi_envs / at_4Mi_envs / f32_obs_131072_envs below")
                 out["roofline"]["rocprof"] = rp
+            busy = here.get("sq_busy")
+            if busy:  # profiler-side busy time per launch: SQ_BUSY_CYCLES calibrated on the 4 Mi-env launch, whose duration trace and events agree on
+                out["roofline"]["profiler_busy"] = dict(busy, source="profiles/r6_env_step_roofline.json (rocprofv3 --pmc SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over tools/env_roofline.py)")
+            elif here.get("GRBM_GUI_ACTIVE_per_launch"):
+                out["roofline"]["profiler_busy"] = {"GRBM_GUI_ACTIVE_per_launch": here["GRBM_GUI_ACTIVE_per_launch"], "busy_us_at_2p4GHz": here["grbm_busy_us_per_launch_at_2p4GHz"],
+                                                    "note": "under --pmc every dispatch runs alone (51 us apart): GRBM_GUI_ACTIVE then spans the profiler's own per-dispatch work, not "
+                                                            "the kernel (the guide: reads high below ~0.3 ms); at 4 Mi envs it gives 75.8 us against 68.8-74.4 us traced / timed",
+                                                    "source": "profiles/r6_env_step_roofline.json"}
             if stp:  # in-kernel stamps of the diagnostic build under the same graph replay: where the period goes
                 out["roofline"]["stamps"] = {"active_us": stp["active_us_median"], "launch_boundary_us": stp["gap_us_median"], "one_wave_us": stp["one_wave_us_median"],
                                              "wave_start_spread_us": stp["wave_start_spread_us_median"], "frac_by_active_time": stp["frac_of_8TBps_by_active_time"],
-                                             "source": "profiles/r5_env_step_roofline.json: tools/step_stamps.py on the -DACX_STEP_STAMP build of this round's kernel (s_memrealtime per wave)"}
-            tr = r5.get(str(N), {}).get("traffic_bytes_per_launch")
+                                             "source": "profiles/r6_env_step_roofline.json: tools/step_stamps.py on the -DACX_STEP_STAMP build of this round's kernel (s_memrealtime per wave)"}
+            tr = here.get("traffic_bytes_per_launch")
             if tr:
                 out["roofline"]["traffic"] = tr
-                out["roofline"]["traffic_source"] = ("profiles/r5_env_step_roofline.json (rocprofv3 --pmc FETCH_SIZE and, in a pass of its own, --pmc WRITE_SIZE over the same bench.py "
-                                                     "command; 2 x FETCH_SIZE + WRITE_SIZE: gfx950 counts 128-B read requests at 64 B)")
-        r4f = os.path.join(ROOT, "profiles", "r4_env_step_roofline.json")
-        if os.path.exists(r4f) and N == N_ENVS:
-            # where trace and HIP events agree (launch overhead < 5 %): the same kernel at 2^20 envs (state resident in the Infinity
-            # Cache: read the beyond-MALL fraction) and at 4 Mi envs -- the HBM-honest size, sustained (0.3 s warm-up, 5 x 40 launches)
-            with open(r4f) as f:
-                r4 = json.load(f)
-            for key, n_big in (("at_1Mi_envs", 1 << 20), ("at_4Mi_envs", 1 << 22)):
-                big = r4.get(str(n_big), {})
+                out["roofline"]["traffic_source"] = ("profiles/r6_env_step_roofline.json (rocprofv3 --pmc FETCH_SIZE and, in a pass of its own, --pmc WRITE_SIZE over tools/env_roofline.py "
+                                                     "65536 400 int8 128 1: same kernel, batch and row ring; 2 x FETCH_SIZE + WRITE_SIZE: gfx950 counts 128-B read requests at 64 B)")
+            # where trace and HIP events agree (launch overhead < 5 %): the same kernel at 2^20 envs (state resident in the Infinity Cache: read the
+            # beyond-MALL fraction), at 4 Mi envs -- the HBM-honest size, sustained (0.3 s warm-up, 5 x 40 launches) -- and with f32 observation
+            # rows at BASELINE config 5's per-GPU shape; all re-taken on this round's acx_step.hip
+            for key, tag, n_big, per_env, beyond in (("at_1Mi_envs", str(1 << 20), 1 << 20, ALGO_BYTES_PER_STEP, 57), ("at_4Mi_envs", str(1 << 22), 1 << 22, ALGO_BYTES_PER_STEP, 105),
+                                                     ("f32_obs_131072_envs", "131072_float32", 1 << 17, 12 * L + 10, 12 * L + 10 - 50)):
+                big = r6.get(tag, {})
                 if not big.get("rocprof_kernel_trace"):
                     continue
                 us_ev, us_tr = big["hip_event"]["hip_event_us_per_launch"], big["rocprof_kernel_trace"]["avg_us"]
-                resident = 105 * n_big < (256 << 20)
-                out["roofline"][key] = {"hip_event_us": us_ev, "rocprof_avg_us": us_tr, "frac_by_hip_events": ALGO_BYTES_PER_STEP * n_big / us_ev / 1e3 / HBM_PEAK_GBS,
-                                        "frac_by_rocprof_avg": ALGO_BYTES_PER_STEP * n_big / us_tr / 1e3 / HBM_PEAK_GBS,
-                                        "frac_of_hbm_peak_beyond_mall": (57 if resident else 105) * n_big / us_tr / 1e3 / HBM_PEAK_GBS, "state_stays_in_infinity_cache": resident,
+                resident = key != "at_4Mi_envs"
+                out["roofline"][key] = {"hip_event_us": us_ev, "rocprof_avg_us": us_tr, "frac_by_hip_events": per_env * n_big / us_ev / 1e3 / HBM_PEAK_GBS,
+                                        "frac_by_rocprof_avg": per_env * n_big / us_tr / 1e3 / HBM_PEAK_GBS,
+                                        "frac_of_hbm_peak_beyond_mall": beyond * n_big / us_tr / 1e3 / HBM_PEAK_GBS, "state_stays_in_infinity_cache": resident,
                                         "hbm_honest": not resident, "traffic_bytes_per_launch": big.get("traffic_bytes_per_launch"),
                                         "algorithmic_bytes_per_launch": big["algorithmic_bytes_per_launch"],
-                                        "source": f"profiles/r4_env_step_{n_big}_kernel_stats.csv + r4_env_step_roofline.json (tools/profile_env_r4.sh)"}
+                                        "source": f"profiles/r6_env_step_{tag if '_' in tag else tag + '_int8'}_kernel_stats.csv + r6_env_step_roofline.json (tools/profile_env_r6.sh)"}
         if extras is not None:
             out["env_context"] = extras
         if search is not None:
