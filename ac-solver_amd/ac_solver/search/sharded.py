@@ -405,9 +405,11 @@ def bfs_sharded(presentation, max_nodes_to_explore=10000, verbose=False, cyclica
     # (the owner function keeps families of states on one rank -- csrc/acx_owner.h --, so no capacity below the hard bound is safe
     # for EVERY input: the third attempt uses it, with small chunks, since a region then has room for every child of its senders)
     if batch_parents is None:
-        # a chunk's fixed costs (eight launches per rank) against the memory of its flag arrays: 2^21 global parents, 2^22 from 8 ranks
-        # on, where a rank's share of a chunk is small (profiles/r5_shard_thread_ranks_device_work.txt: 3.7 -> 3.4 ms per rank at 8)
-        batch_parents = 1 << (22 if (comm is not None and comm.world >= 8) else 21)
+        # a chunk's fixed costs (eight launches per rank) against the memory of its flag arrays: 2^21 global parents, more from 8 ranks
+        # on, where a rank's share of a chunk is small (profiles/r5_shard_thread_ranks_device_work.txt: 3.7 -> 3.4 ms per rank at 8 with 2^22)
+        # (round 6: the flags of a chunk are one word per parent instead of a byte per child -- 16 B of zeroed memory per parent, not 48 -- so a larger
+        # chunk no longer pays for itself in fills: 2^23 from 8 ranks on, profiles/r6_shard_thread_ranks_device_work.txt)
+        batch_parents = 1 << (23 if (comm is not None and comm.world >= 8) else 21)
     reruns = 0
     tried = []
     for fill, bp in ((region_fill, batch_parents), (FILL_DEFAULT, batch_parents), (FILL_HARD, min(batch_parents, 1 << 17))):

@@ -692,7 +692,7 @@ int acx_bfs_sharded(const int8_t* h_presentation, int L, int64_t max_nodes, int 
     const int world = comm->world;
     acx_shard_opts o = {};
     if (opts) o = *opts;
-    int64_t batch = o.batch_parents > 0 ? o.batch_parents : (1ll << (world >= 8 ? 22 : 21));
+    int64_t batch = o.batch_parents > 0 ? o.batch_parents : (1ll << (world >= 8 ? 23 : 21));
     int64_t repl = o.replicate_below == 0 ? kReplicateBelow : (o.replicate_below < 0 ? 0 : o.replicate_below);
     if (world == 1) repl = 0;
     int dev = 0;

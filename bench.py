@@ -193,7 +193,7 @@ def search_numbers(world, rank, dev, budget, use_dist=False, out=None):
         """median of `reps` timed searches (MAX over the ranks each) behind a full-size warm-up call; no garbage collection while the clock runs
         (as timeit does: a full collection of this process's heap takes 25-30 ms and landed in one search out of four)"""
         t0 = time.perf_counter()
-        bfs_sharded(p, b, comm=comm)  # (chunks: bfs_sharded's default, 2^21 global parents, 2^22 from 8 ranks on) warm-up at full size: allocator (GBs of first-time hipMalloc), kernels, communicator
+        bfs_sharded(p, b, comm=comm)  # (chunks: bfs_sharded's default, 2^21 global parents, 2^23 from 8 ranks on) warm-up at full size: allocator (GBs of first-time hipMalloc), kernels, communicator
         torch.cuda.synchronize()
         first_call = time.perf_counter() - t0
         if use_dist:

@@ -385,7 +385,7 @@ int acx_rccl_comm_create(const void *id128, int rank, int world, void **nccl_com
 int acx_rccl_comm_destroy(void *nccl_comm);
 
 typedef struct acx_shard_opts { /* all zero = the defaults of sharded.py:bfs_sharded */
-    int64_t batch_parents;      /* global parents per chunk (default 2^21, 2^22 from 8 ranks on) */
+    int64_t batch_parents;      /* global parents per chunk (default 2^21, 2^23 from 8 ranks on) */
     int64_t replicate_below;    /* levels of fewer parents are processed whole by every rank, no collectives (default 2^18; < 0: every level exchanged) */
     int32_t region_fill;        /* capacity of the exchanged regions in 1/256 of the even share (default: adaptive; ACX 320 = 1.25 x) */
     int32_t overlap;            /* 0: expansion + all-to-all of chunk k + 1 on a side stream beside the dedup of chunk k when world > 1; 1: one stream; 2: side stream always */

@@ -2,14 +2,15 @@
 """profiles/<tag>_*_pmc_summary.txt (tools/pmc_sum.py) -> profiles/search_traffic.json: HBM bytes of each search workload by the
 counters, per search / per sweep.  fetch = max(FETCH_SIZE, TCC_MISS_sum x 64 B) per kernel (FETCH_SIZE counts 128-B read requests
 at 64 B on gfx950; random 32-B probes show up in the miss count), + WRITE_SIZE; table fills (fillBufferAligned) listed apart.
-    python3 tools/search_traffic.py [tag]       (children counts: the bench's own, see KEYS)"""
+    python3 tools/search_traffic.py [tag[,older tag ...]]       (children counts: the bench's own, see KEYS; a workload without a summary of
+the first tag takes the next one's -- round 6 re-profiled the kernels it changed: `r6,r5`)"""
 import json
 import os
 import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
+tags = (sys.argv[1] if len(sys.argv) > 1 else "r6,r5").split(",")
 # key in search_traffic.json -> (summary file, kernel-name filter, searches the profiled command ran, children per search / sweep, what it was)
 KEYS = {
     "bfs_ak3_1e8": ("bfs_1e8", ("k_bfs_", "k_decide_tab"), 1, 332140812, "tools/bfs_only.py 1e8 (a 2e4-node warm-up + ONE 1e8-node search)"),
@@ -20,9 +21,10 @@ KEYS = {
 }
 out = {}
 for key, (name, pats, runs, children, what) in KEYS.items():
-    path = os.path.join(ROOT, "profiles", f"{tag}_{name}_pmc_summary.txt")
-    if not os.path.exists(path):
+    tag = next((t for t in tags if os.path.exists(os.path.join(ROOT, "profiles", f"{t}_{name}_pmc_summary.txt"))), None)
+    if tag is None:
         continue
+    path = os.path.join(ROOT, "profiles", f"{tag}_{name}_pmc_summary.txt")
     kernels, cur = {}, None
     for line in open(path):
         m = re.match(r"^(\S.*?)\s+dispatches=(\d+)", line)
