@@ -202,7 +202,11 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __
             constexpr int u = decltype(uu)::value;
             static_for<2 * u, (2 * u + 2 < NM ? 2 * u + 2 : NM)>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
+#ifdef ACX_POLICY_NO_LDS_READ  // timing experiment only (wrong numbers): every MFMA reuses the block's first fragments -- what the LDS reads cost
+                if constexpr (i + kFragAhead < NM) a[i + kFragAhead] = a[i % kFragAhead];
+#else
                 if constexpr (i + kFragAhead < NM) a[i + kFragAhead] = S[(i + kFragAhead) * 64];
+#endif
                 if constexpr (i == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], ones, zero, 0, 0, 0);
                 else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bfrag(std::integral_constant<int, i - 1>{}), acc, 0, 0, 0);
             });
@@ -257,7 +261,9 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __
 #ifdef ACX_POLICY_STAMP  // diagnostic build: shader-clock stamp per chunk into the (over-allocated) logprob buffer
         logprob[n_env + (blockIdx.x & 1) * 512 + wave * 64 + c] = (float)(long long)(__builtin_amdgcn_s_memtime() - t_start);  // (no branch: all lanes store the same word)
 #endif
+#ifndef ACX_POLICY_NO_STREAM  // (timing experiment only when defined: the weights are not streamed beyond the ring's first fill)
         if constexpr (c + kAhead < P::C) issue(std::integral_constant<int, c + kAhead>{});
+#endif
         const frag_ab* S = (const frag_ab*)(s_mem + slot * kSlotBytes) + lane;
         const frag_ab* Sn = (const frag_ab*)(s_mem + ((c + 1) % kRing) * kSlotBytes) + lane;  // first block of the next chunk
         if constexpr (cc < P::C1) {  // ---- layer 1: a few output blocks per chunk
