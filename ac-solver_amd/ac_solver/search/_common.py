@@ -6,14 +6,24 @@ import numpy as np
 from ac_solver import _acx
 
 
-MAX_SEARCH_RELATOR_LENGTH = 61  # a relator and its length share one 128-bit key word (csrc/acx_frontier.h: keyops)
+MAX_SEARCH_RELATOR_LENGTH = 64  # one 128-bit key word per relator (csrc/acx_keys.h: 2 bits per letter; up to 61 the length rides in the word,
+#                                 62 .. 64 use a key that only FREELY REDUCED words have -- which every state of a search is)
 
 
-def _check_width(L):
-    """The reference takes any max_relator_length; the device frontier packs a relator and its length into one 128-bit key."""
+def _check_width(L, presentation=None):
+    """The reference takes any max_relator_length; the device frontier names a relator by one 128-bit key: 64 letters at most, and from 62
+    letters on the root has to be freely reduced (its own Miller-Schupp presentations are: miller_schupp.py:43 reaches 64 at n = 14)."""
     if L > MAX_SEARCH_RELATOR_LENGTH:
         raise ValueError(f"max_relator_length = {L} is not supported by the device search: at most {MAX_SEARCH_RELATOR_LENGTH} "
-                         "(a relator and its length share one 128-bit key word)")
+                         "(a relator is named by one 128-bit key word: 64 letters of 2 bits)")
+    if L > 61 and presentation is not None:
+        p = np.asarray(presentation)
+        for h in (0, 1):
+            w = p[h * L:(h + 1) * L]
+            w = w[w != 0]
+            if len(w) > 1 and bool((w[:-1] == -w[1:]).any()):
+                raise ValueError(f"max_relator_length = {L} (> 61): the presentation must be freely reduced (csrc/acx_keys.h: the 128-bit key of these "
+                                 "lengths names reduced words only)")
 
 
 def run_search(kind, presentation, max_nodes_to_explore, cyclical, want_stats=False, verbose=False):
@@ -35,7 +45,7 @@ def run_search(kind, presentation, max_nodes_to_explore, cyclical, want_stats=Fa
             _acx.check(_acx.lib.acx_search_minima_enable(0))
     p = _acx.as_i8_rows(np.array(presentation))
     L = p.size // 2
-    _check_width(L)
+    _check_width(L, p)
     cap = 1 << 12
     while True:
         pa = np.empty(cap, np.int32)

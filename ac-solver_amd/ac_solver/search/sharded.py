@@ -451,7 +451,7 @@ def _bfs_sharded_once(presentation, max_nodes_to_explore=10000, verbose=False, c
     L = len(p) // 2
     from ac_solver.search._common import _check_width
 
-    _check_width(L)
+    _check_width(L, p)
     max_nodes = int(max_nodes_to_explore)
     comm = SingleComm() if comm is None else comm
     world, rank = comm.world, comm.rank
@@ -1009,7 +1009,7 @@ def bfs_sharded_native(presentation, max_nodes_to_explore=10000, verbose=False, 
     assert is_array_valid_presentation(presentation), f"{presentation} is not a valid presentation"
     p = _acx.as_i8_rows(np.array(presentation))
     L = p.size // 2
-    _check_width(L)
+    _check_width(L, p)
     _acx.require_device()
     torch = _torch()
     opts = _acx.ShardOpts()

@@ -63,9 +63,9 @@ ACX_HD uint32_t slot_action(unsigned long long s) { return (uint32_t)s & 15u; }
 // of the search is, and the kernels run the shorter apply_move_nf: MODE 1 for cyclical = False, MODE 2 for cyclical = True.
 enum : int { kMoveGeneral = 0, kMoveNf = 1, kMoveNfCyclical = 2 };
 template <typename W, int MODE> __device__ __forceinline__ int search_move(Pres<W>& s, int a, int L, bool cyclical) {
-    if (MODE == kMoveNf) return apply_move_nf<W, kSearchSafe>(s, a, L, false);
-    if (MODE == kMoveNfCyclical) return apply_move_nf<W, kSearchSafe>(s, a, L, true);
-    return apply_move<W, kSearchSafe>(s, a, L, cyclical);
+    if (MODE == kMoveNf) return apply_move_nf<W, kSearchSafeOf<W>>(s, a, L, false);
+    if (MODE == kMoveNfCyclical) return apply_move_nf<W, kSearchSafeOf<W>>(s, a, L, true);
+    return apply_move<W, kSearchSafeOf<W>>(s, a, L, cyclical);
 }
 
 // key of the state a slot names: child `act` of node `pid` (or the node itself)
@@ -445,7 +445,7 @@ __device__ __forceinline__ void bfs_compact_body(const SearchDev<W>& d, uint32_t
             {
                 Pres<W> g;
                 key_to_pres<W>(pk0[u], pk1[u], g);
-                (void)apply_move<W, kSearchSafe>(g, (int)act[u], d.L, d.cyclical != 0);
+                (void)apply_move<W, kSearchSafeOf<W>>(g, (int)act[u], d.L, d.cyclical != 0);
                 if (g.w0 != s.w0 || g.w1 != s.w1 || g.n0 != s.n0 || g.n1 != s.n1 || !is_normal_form<W>(s, d.cyclical != 0))
                     printf("COMPACT: node %u = move(%u, %u): parent %llx %llx nf %llx %llx general %llx %llx\n", id, pid[u], act[u], (unsigned long long)pk0[u],
                            (unsigned long long)pk1[u], (unsigned long long)keyops<W>::make(s.w0, s.n0), (unsigned long long)keyops<W>::make(s.w1, s.n1),

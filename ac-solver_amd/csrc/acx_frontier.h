@@ -13,6 +13,7 @@
 #include <vector>
 #include "acx_common.h"
 #include "acx_word.h"
+#include "acx_keys.h"  // keyops: (word, length) <-> key; u128x: the key type of max_relator_length 62 .. 64
 
 namespace acx {
 
@@ -20,12 +21,6 @@ constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kProv = 0x80000000u;  // provisional id = kProv | tag (candidate of the running batch)
 constexpr uint64_t kNoTag = ~0ull;
 
-template <typename W> struct keyops {
-    static constexpr int kShift = wtraits<W>::kBits - 6;
-    static ACX_HD W make(W w, int n) { return w | ((W)n << kShift); }
-    static ACX_HD int len(W k) { return (int)(uint32_t)(k >> kShift); }
-    static ACX_HD W word(W k) { return k & (((W)1 << kShift) - 1); }
-};
 
 ACX_HD uint64_t mix64(uint64_t x) {
     x ^= x >> 32;
@@ -90,13 +85,12 @@ template <typename W> struct SearchDev {
 #ifndef ACX_SEARCH_SAFE
 #define ACX_SEARCH_SAFE 0
 #endif
-constexpr bool kSearchSafe = ACX_SEARCH_SAFE != 0;
+// (u128x, max_relator_length 62 .. 64: a shift by 64 letters IS the word width -- those searches run the range-checked flavour)
+template <typename W> constexpr bool kSearchSafeOf = ACX_SEARCH_SAFE != 0 || is_long_key<W>::value;
 
 template <typename W> __device__ __forceinline__ void key_to_pres(W k0, W k1, Pres<W>& s) {
-    s.w0 = keyops<W>::word(k0);
-    s.n0 = keyops<W>::len(k0);
-    s.w1 = keyops<W>::word(k1);
-    s.n1 = keyops<W>::len(k1);
+    keyops<W>::split(k0, s.w0, s.n0);
+    keyops<W>::split(k1, s.w1, s.n1);
 }
 
 // one lane per (parent, action): tag t = 12 * p + a
@@ -111,7 +105,7 @@ __global__ void __launch_bounds__(256) k_expand(SearchDev<W> d, const uint32_t* 
         Pres<W> s;
         const W pk0 = d.k0[pid], pk1 = d.k1[pid];
         key_to_pres<W>(pk0, pk1, s);
-        const int e = apply_move<W, kSearchSafe>(s, (int)a, d.L, d.cyclical != 0);
+        const int e = apply_move<W, kSearchSafeOf<W>>(s, (int)a, d.L, d.cyclical != 0);
         // the reference's ACMove raises here -- but only if it gets this far: the search raises when this move precedes its
         // termination (k_decide), so the FIRST such move of the batch is what matters
         if (e) atomicMin(d.err_tag, ((unsigned long long)t << 8) | (unsigned long long)e);

@@ -716,7 +716,7 @@ __device__ __forceinline__ void greedy_run(const GreedyDev<W>& g, GreedyOut* __r
                 const uint32_t p = t / 12u;
                 Pres<W> s;
                 key_to_pres<W>(sp_k0[p], sp_k1[p], s);
-                const int e = NF ? apply_move_nf<W, kSearchSafe>(s, (int)(t - 12u * p), d.L, d.cyclical != 0) : apply_move<W, kSearchSafe>(s, (int)(t - 12u * p), d.L, d.cyclical != 0);
+                const int e = NF ? apply_move_nf<W, kSearchSafeOf<W>>(s, (int)(t - 12u * p), d.L, d.cyclical != 0) : apply_move<W, kSearchSafeOf<W>>(s, (int)(t - 12u * p), d.L, d.cyclical != 0);
                 if (e) atomicMin(&s_err_tag, ((unsigned long long)t << 8) | (unsigned long long)e);  // counts only if the reference gets this far
                 const W c0 = keyops<W>::make(s.w0, s.n0), c1 = keyops<W>::make(s.w1, s.n1);
                 const uint32_t tl = (uint32_t)(s.n0 + s.n1);

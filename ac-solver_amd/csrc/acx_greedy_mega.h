@@ -182,7 +182,7 @@ template <typename W> __device__ __forceinline__ void gm_child(const MegaDev<W>&
     p1 = nk.k1;
     Pres<W> s;
     key_to_pres<W>(p0, p1, s);
-    e = g.nf ? apply_move_nf<W, kSearchSafe>(s, (int)(t - 12u * p), g.d.L, g.d.cyclical != 0) : apply_move<W, kSearchSafe>(s, (int)(t - 12u * p), g.d.L, g.d.cyclical != 0);
+    e = g.nf ? apply_move_nf<W, kSearchSafeOf<W>>(s, (int)(t - 12u * p), g.d.L, g.d.cyclical != 0) : apply_move<W, kSearchSafeOf<W>>(s, (int)(t - 12u * p), g.d.L, g.d.cyclical != 0);
     c0 = keyops<W>::make(s.w0, s.n0);
     c1 = keyops<W>::make(s.w1, s.n1);
     tl = (uint32_t)(s.n0 + s.n1);

@@ -22,7 +22,7 @@
 //     the bucket (that child is the heap's next minimum); later parents stay queued
 //
 // Keys: a relator word and its length share one machine word (length in the top 6 bits):
-// W = u64 for L <= 29, u128 for L <= 61.  Roofline: HBM (random table probes); see DESIGN.md.
+// W = u64 for L <= 29, u128 for L <= 61, u128x (acx_keys.h: the same 128 bits, a key that needs no length field) for L <= 64.  Roofline: HBM (random table probes); see DESIGN.md.
 #include <string.h>
 #include <cstring>
 
@@ -169,9 +169,17 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
     // The batch-per-launch greedy path below stays for two callers: verbose searches (the per-improvement lengths need each batch's
     // decision on the host) and searches that outgrow a capacity of the persistent kernel (depth >= 16 384, bucket arena); the tests
     // select it with ACX_OPT_GREEDY_HOST to hold it against the oracle.
-    if (greedy && !option(ACX_OPT_GREEDY_HOST, 0) && !t_minima_on) {  // device-resident priority frontier; falls through when it hits a capacity
+    if constexpr (is_long_key<W>::value) {
+        // max_relator_length 62 .. 64 (acx_keys.h): the key names a FREELY REDUCED word, which every state ACMove produces is -- the root has to be
+        if (has_inverse_pair<W, true>(root.w0, root.n0) || has_inverse_pair<W, true>(root.w1, root.n1))
+            return fail(ACX_E_INVAL, "acx_search: at max_relator_length %d (> 61) the presentation must be freely reduced", L);
+    }
+    // (the persistent frontier and its whole-GPU kernels are not instantiated for the 62 .. 64-letter key type: those searches -- the reference's
+    // Miller-Schupp presentations from n = 14 on -- take the batch-per-launch path, same result)
+    if (greedy && !option(ACX_OPT_GREEDY_HOST, 0) && !t_minima_on && !is_long_key<W>::value) {  // device-resident priority frontier; falls through when it hits a capacity
         bool handled = false;
-        const int grc = run_greedy_device<W>(root, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, &handled);
+        int grc = ACX_OK;
+        if constexpr (!is_long_key<W>::value) grc = run_greedy_device<W>(root, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, &handled);
         if (grc != ACX_OK || handled) return grc;
         *solved = 0;
         *path_n = 0;
@@ -478,10 +486,11 @@ extern "C" int acx_search(int kind, const int8_t* h_presentation, int L, int64_t
     if ((kind != ACX_SEARCH_BFS && kind != ACX_SEARCH_GREEDY) || !h_presentation || L < 1 || !solved || !path_n || path_cap < 0 ||
         (path_cap > 0 && (!path_action || !path_len)))
         return fail(ACX_E_INVAL, "acx_search: bad argument");
-    if (L > 61) return fail(ACX_E_INVAL, "acx_search handles max_relator_length <= 61, got %d", L);
+    if (L > 64) return fail(ACX_E_INVAL, "acx_search handles max_relator_length <= 64, got %d", L);
     if (max_nodes < 0) max_nodes = 0;
     if (L <= 29) return run_search<uint64_t>(kind, h_presentation, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats);
-    return run_search<u128>(kind, h_presentation, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats);
+    if (L <= 61) return run_search<u128>(kind, h_presentation, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats);
+    return run_search<u128x>(kind, h_presentation, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats);
 }
 
 extern "C" int acx_search_minima_enable(int on) {

@@ -86,6 +86,17 @@ template <> struct recio<u128> {
     }
 };
 
+template <> struct recio<u128x> {  // max_relator_length 62 .. 64 (acx_keys.h): the same four words
+    static constexpr int KW = 4, RW = 5;
+    static ACX_HD void put(int64_t* r, u128x k0, u128x k1) { recio<u128>::put(r, (u128)k0, (u128)k1); }
+    static ACX_HD void get(const int64_t* r, u128x& k0, u128x& k1) {
+        u128 a, b;
+        recio<u128>::get(r, a, b);
+        k0 = u128x(a);
+        k1 = u128x(b);
+    }
+};
+
 // The key hash of the sharded engine: ONE value per key serves the LDS fold slot of the expansion, the stamp-table bucket and the
 // 27-bit fingerprint.  k_shard_expand is bound by vector issue, and the hash of the fused search (hash_key: five 64-bit
 // multiplies, i.e. fifteen quarter-rate 32-bit multiplies per child) was ~30 % of its vector cycles; this one is one
@@ -105,10 +116,10 @@ struct OwnerParts {
 };
 template <typename W> ACX_HD OwnerParts owner_parts_of_key(W k0, W k1) {
     OwnerParts o;
-    o.c0 = class_hash<W, kSearchSafe>(keyops<W>::word(k0), keyops<W>::len(k0));
-    o.c1 = class_hash<W, kSearchSafe>(keyops<W>::word(k1), keyops<W>::len(k1));
-    o.in0 = inner_letter<W, kSearchSafe>(keyops<W>::word(k0), keyops<W>::len(k0));
-    o.in1 = inner_letter<W, kSearchSafe>(keyops<W>::word(k1), keyops<W>::len(k1));
+    o.c0 = class_hash<W, kSearchSafeOf<W>>(keyops<W>::word(k0), keyops<W>::len(k0));
+    o.c1 = class_hash<W, kSearchSafeOf<W>>(keyops<W>::word(k1), keyops<W>::len(k1));
+    o.in0 = inner_letter<W, kSearchSafeOf<W>>(keyops<W>::word(k0), keyops<W>::len(k0));
+    o.in1 = inner_letter<W, kSearchSafeOf<W>>(keyops<W>::word(k1), keyops<W>::len(k1));
     return o;
 }
 template <typename W> ACX_HD uint32_t owner_of_key(W k0, W k1, uint32_t world) { return owner_of_sum(owner_parts_of_key<W>(k0, k1).sum(), world); }
@@ -116,11 +127,11 @@ template <typename W> ACX_HD uint32_t owner_of_key(W k0, W k1, uint32_t world) {
 // action ids r_1, ac_moves.py:192-206), a conjugation (a >= 4) kept its class, and only its inner letter has to be looked up again
 template <typename W> ACX_HD OwnerParts owner_parts_of_child(OwnerParts o, uint32_t a, const Pres<W>& s) {
     if (a & 1u) {
-        if (a < 4u) o.c0 = class_hash<W, kSearchSafe>(s.w0, s.n0);
-        o.in0 = inner_letter<W, kSearchSafe>(s.w0, s.n0);
+        if (a < 4u) o.c0 = class_hash<W, kSearchSafeOf<W>>(s.w0, s.n0);
+        o.in0 = inner_letter<W, kSearchSafeOf<W>>(s.w0, s.n0);
     } else {
-        if (a < 4u) o.c1 = class_hash<W, kSearchSafe>(s.w1, s.n1);
-        o.in1 = inner_letter<W, kSearchSafe>(s.w1, s.n1);
+        if (a < 4u) o.c1 = class_hash<W, kSearchSafeOf<W>>(s.w1, s.n1);
+        o.in1 = inner_letter<W, kSearchSafeOf<W>>(s.w1, s.n1);
     }
     return o;
 }
@@ -1383,14 +1394,20 @@ template <typename W> struct ShardEngine {
 };
 
 struct ShardAny {
-    bool wide;
+    int width;  // 0: uint64_t keys (max_relator_length <= 29), 1: unsigned __int128 (<= 61), 2: u128x (<= 64, acx_keys.h)
     ShardEngine<uint64_t>* e64 = nullptr;
     ShardEngine<u128>* e128 = nullptr;
+    ShardEngine<u128x>* e128x = nullptr;
 };
 
 #define ACX_SHARD_DISPATCH(h, ...)                   \
     do {                                             \
-        if ((h)->wide) {                             \
+        if ((h)->width == 2) {                       \
+            typedef u128x W;                         \
+            auto& E = *(h)->e128x;                   \
+            (void)sizeof(W);                         \
+            __VA_ARGS__;                             \
+        } else if ((h)->width == 1) {                \
             typedef u128 W;                          \
             auto& E = *(h)->e128;                    \
             (void)sizeof(W);                         \
@@ -1408,6 +1425,8 @@ template <typename W> static int shard_root(ShardEngine<W>& E, const int8_t* pre
     bool ok = pack_relator<W>(pres, E.d.L, root.w0, root.n0);
     ok = pack_relator<W>(pres + E.d.L, E.d.L, root.w1, root.n1) && ok;
     if (!ok) return fail(ACX_E_ROWERR, "acx_shard: the presentation is not a zero-padded word pair over {+-1,+-2}");
+    if (is_long_key<W>::value && (has_inverse_pair<W, true>(root.w0, root.n0) || has_inverse_pair<W, true>(root.w1, root.n1)))
+        return fail(ACX_E_INVAL, "acx_shard: at max_relator_length %d (> 61) the presentation must be freely reduced (acx_keys.h)", (int)E.d.L);
     // a root in normal form keeps the whole search in normal form (acx_bfs.h)
     E.move_mode = !is_normal_form<W>(root, E.d.cyclical != 0) ? kMoveGeneral : (E.d.cyclical ? kMoveNfCyclical : kMoveNf);
     recio<W>::put(rec, keyops<W>::make(root.w0, root.n0), keyops<W>::make(root.w1, root.n1));
@@ -1626,7 +1645,7 @@ struct acx_shard {
 
 extern "C" {
 
-int acx_shard_key_words(int L) { return L <= 29 ? 2 : 4; }
+int acx_shard_key_words(int L) { return L <= 29 ? 2 : 4; }  // (62 .. 64: four words as well, in the encoding of acx_keys.h)
 
 int acx_shard_layout(int64_t n_parents, int world, int key_words, int fill_q8, int64_t* subregions, int64_t* subcap, int64_t* region_words) {
     if (n_parents < 1 || world < 1 || (key_words != 2 && key_words != 4) || !subregions || !subcap || !region_words) return fail(ACX_E_INVAL, "acx_shard_layout: bad argument");
@@ -1637,15 +1656,18 @@ int acx_shard_layout(int64_t n_parents, int world, int key_words, int fill_q8, i
 
 acx_shard* acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t chunk_parents, int rank, int world) {
     if (!have_device()) return nullptr;
-    if (L < 1 || L > 61 || node_cap < 1 || chunk_parents < 1 || chunk_parents > (1ll << 27) || world < 1 || world > 64 || rank < 0 || rank >= world) {
-        fail(ACX_E_INVAL, "acx_shard_create: bad argument (1 <= L <= 61, world <= 64, chunk_parents <= 2^27)");
+    if (L < 1 || L > 64 || node_cap < 1 || chunk_parents < 1 || chunk_parents > (1ll << 27) || world < 1 || world > 64 || rank < 0 || rank >= world) {
+        fail(ACX_E_INVAL, "acx_shard_create: bad argument (1 <= L <= 64, world <= 64, chunk_parents <= 2^27)");
         return nullptr;
     }
     acx_shard* h = new (std::nothrow) acx_shard();
     if (!h) return nullptr;
-    h->any.wide = L > 29;
+    h->any.width = L <= 29 ? 0 : (L <= 61 ? 1 : 2);
     int rc;
-    if (h->any.wide) {
+    if (h->any.width == 2) {
+        h->any.e128x = new ShardEngine<u128x>();
+        rc = h->any.e128x->init(L, cyclical, node_cap, chunk_parents, rank, world);
+    } else if (h->any.width == 1) {
         h->any.e128 = new ShardEngine<u128>();
         rc = h->any.e128->init(L, cyclical, node_cap, chunk_parents, rank, world);
     } else {
@@ -1655,6 +1677,7 @@ acx_shard* acx_shard_create(int L, int cyclical, int64_t node_cap, int64_t chunk
     if (rc != ACX_OK) {
         delete h->any.e64;
         delete h->any.e128;
+        delete h->any.e128x;
         delete h;
         return nullptr;
     }
@@ -1665,6 +1688,7 @@ void acx_shard_destroy(acx_shard* h) {
     if (!h) return;
     delete h->any.e64;
     delete h->any.e128;
+    delete h->any.e128x;
     delete h;
 }
 
@@ -1724,7 +1748,12 @@ int acx_shard_fail(acx_shard* h, void* stream) {
 }
 
 int acx_shard_owner(int L, const int64_t* h_key_words, int world) {
-    if (L < 1 || L > 61 || !h_key_words || world < 1) return fail(ACX_E_INVAL, "acx_shard_owner: bad argument");
+    if (L < 1 || L > 64 || !h_key_words || world < 1) return fail(ACX_E_INVAL, "acx_shard_owner: bad argument");
+    if (L > 61) {
+        u128x k0, k1;
+        recio<u128x>::get(h_key_words, k0, k1);
+        return (int)owner_of_key<u128x>(k0, k1, (uint32_t)world);
+    }
     if (L <= 29) {
         uint64_t k0, k1;
         recio<uint64_t>::get(h_key_words, k0, k1);

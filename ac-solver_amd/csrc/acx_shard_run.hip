@@ -682,7 +682,7 @@ int acx_bfs_sharded(const int8_t* h_presentation, int L, int64_t max_nodes, int 
                     int32_t* path_action, int32_t* path_len, int64_t path_cap, int64_t* path_n, acx_shard_run_stats* stats, void* stream) {
     if (!h_presentation || !solved || !path_n || max_nodes < 0 || (path_cap > 0 && (!path_action || !path_len)))
         return fail(ACX_E_INVAL, "acx_bfs_sharded: bad argument");
-    if (L < 1 || L > 61) return fail(ACX_E_INVAL, "acx_bfs_sharded: max_relator_length 1 .. 61");
+    if (L < 1 || L > 64) return fail(ACX_E_INVAL, "acx_bfs_sharded: max_relator_length 1 .. 64");
     if (!have_device()) return ACX_E_NODEVICE;
     if (!valid_presentation(h_presentation, L)) return fail(ACX_E_ROWERR, "acx_bfs_sharded: not a valid presentation (breadth_first.py:36)");
     acx_comm one = {0, 1, nullptr, nullptr, nullptr};

@@ -6,8 +6,11 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../ac-solver_amd/csrc/acx_bytes.h"
 #include "../../ac-solver_amd/csrc/acx_word.h"
+#include "../../ac-solver_amd/csrc/acx_keys.h"
 
 using namespace acx;
 
@@ -101,6 +104,28 @@ template <typename W> static void move_nf_rows(const int8_t* in, const uint8_t* 
 }
 
 extern "C" {
+
+// keyops<u128x> (csrc/acx_keys.h: the 128-bit key of a freely reduced word of up to 64 letters): key of the word `letters`, and the word /
+// length it decodes back to.  Also a move through Pres<u128x> (the word functions take the type unchanged): shim_move_long.
+void shim_long_key(const int8_t* letters, int n, uint64_t* key2, int32_t* n_back, int8_t* letters_back) {
+    u128x w;
+    int len = 0;
+    std::vector<int8_t> row(64, 0);
+    for (int k = 0; k < n; k++) row[k] = letters[k];
+    (void)pack_relator<u128x>(row.data(), 64, w, len);
+    const u128x key = keyops<u128x>::make(w, len);
+    key2[0] = (uint64_t)(u128)key;
+    key2[1] = (uint64_t)((u128)key >> 64);
+    u128x wb;
+    int nb;
+    keyops<u128x>::split(key, wb, nb);
+    *n_back = nb;
+    unpack_relator<u128x>(wb, nb, 64, letters_back);
+}
+
+void shim_move_long(const int8_t* in, const uint8_t* act, int64_t n, int L, int cyclical, int8_t* out, int32_t* len, uint8_t* err) {
+    move_packed_rows<u128x>(in, act, n, L, cyclical, out, len, err);
+}
 
 void shim_move_nf(const int8_t* in, const uint8_t* act, int64_t n, int L, int cyclical, int wide, int8_t* out, int32_t* len, uint8_t* err) {
     if (wide) move_nf_rows<u128>(in, act, n, L, cyclical, out, len, err);

@@ -10,7 +10,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
 def build():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("acx_word.h", "acx_bytes.h")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("acx_word.h", "acx_bytes.h", "acx_keys.h")]
     if os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
         return SO
     subprocess.check_call([CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-o", SO, SRC])

@@ -430,19 +430,88 @@ def test_a_host_side_failure_of_the_hip_engine_ends_every_thread_rank_together(s
 
 
 def test_search_beyond_the_key_width_says_so(search):
-    """the reference searches at any max_relator_length; the device frontier stops at 61 and says that (a ValueError naming the
-    limit, not a generic library error) -- the Miller-Schupp generator reaches L = 64 at n = 14 (miller_schupp.py:43)"""
+    """the reference searches at any max_relator_length; the device frontier names a relator by one 128-bit key: 64 letters at most, and says so
+    beyond (a ValueError naming the limit, not a generic library error); from 62 letters on the root has to be freely reduced"""
     from ac_solver import bfs, greedy_search
-    from ac_solver.search.sharded import bfs_sharded
+    from ac_solver.search.sharded import bfs_sharded, bfs_sharded_native
 
-    p = np.zeros(124, np.int8)
-    p[:2], p[62:64] = [1, 2], [2, 1]
-    for fn in (bfs, greedy_search, bfs_sharded):
-        with pytest.raises(ValueError, match="max_relator_length = 62"):
+    p = np.zeros(130, np.int8)
+    p[:2], p[65:67] = [1, 2], [2, 1]
+    for fn in (bfs, greedy_search, bfs_sharded, bfs_sharded_native):
+        with pytest.raises(ValueError, match="max_relator_length = 65"):
             fn(p, 100)
+    q = np.zeros(124, np.int8)
+    q[:3], q[62:64] = [1, -1, 2], [2, 1]  # x x^-1 y: not freely reduced
+    for fn in (bfs, greedy_search, bfs_sharded, bfs_sharded_native):
+        with pytest.raises(ValueError, match="freely reduced"):
+            fn(q, 100)
     ok = np.zeros(122, np.int8)
-    ok[:5], ok[61:67] = [1, 1, -2, -2, -2], [1, 2, 1, -2, -1, -2]  # AK(2) at the widest supported length
-    assert greedy_search(ok, 10000)[1] is not None and bfs(ok, 1000) == (False, None)  # 61 still runs
+    ok[:5], ok[61:67] = [1, 1, -2, -2, -2], [1, 2, 1, -2, -1, -2]  # AK(2) at the widest length of the plain 128-bit key
+    assert greedy_search(ok, 10000)[1] is not None and bfs(ok, 1000) == (False, None)
+
+
+def _ms_presentation(n, w, L):
+    """<x, y | x^-1 y^n x = y^(n + 1), x = w> as the reference's generator writes it (miller_schupp.py:20-83) at max_relator_length L"""
+    r1 = [-1] + [2] * n + [1] + [-2] * (n + 1)
+    r2 = [-1] + list(w)
+    p = np.zeros(2 * L, np.int8)
+    p[:len(r1)], p[L:L + len(r2)] = r1, r2
+    return p
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("L", [62, 63, 64])
+def test_searches_at_max_relator_length_62_to_64_match_the_oracle(search, L):
+    """The reference takes any max_relator_length (breadth_first.py:42-45) and its own Miller-Schupp generator reaches 64 at n = 14
+    (miller_schupp.py:43).  Keys of these lengths (csrc/acx_keys.h): bfs, greedy_search, the sharded bfs (Python orchestration and
+    acx_bfs_sharded, 1 and 3 thread ranks) and a batch through acx_search_many against the C oracle -- result, path, node and expansion
+    counts -- on Miller-Schupp presentations at n = 14 / 13, on AK(3), and on a presentation whose relators reach the full 64 letters."""
+    from ac_solver import _acx, bfs, greedy_search
+    from ac_solver.search._common import run_search, run_search_many
+    from ac_solver.search.sharded import NativeComm, bfs_sharded, bfs_sharded_native
+    from oracle import ac_oracle as O
+    from tests.shard_helpers import run_threads
+
+    rng = np.random.default_rng(L)
+    ak3 = np.zeros(2 * L, np.int8)
+    ak3[:7], ak3[L:L + 6] = [1, 1, 1, -2, -2, -2, -2], [1, 2, 1, -2, -1, -2]
+    long_rows = np.zeros(2 * L, np.int8)  # two long reduced relators: moves run into the length bound from the start
+    for h in (0, 1):
+        w = []
+        while len(w) < L - 3 * h:
+            c = int(rng.choice([-2, -1, 1, 2]))
+            if not w or w[-1] != -c:
+                w.append(c)
+        long_rows[h * L:h * L + len(w)] = w
+    cases = [(_ms_presentation(14 if L == 64 else 13, [2, 1, -2], L), 20000, False), (_ms_presentation(14 if L == 64 else 13, [1, 2, -1, 2], L), 6000, True),
+             (ak3, 30000, False), (ak3, 5000, True), (long_rows, 3000, False), (long_rows, 2000, True)]
+    for p, budget, cyc in cases:
+        wb = O.bfs(p, budget, cyclically_reduce_after_moves=cyc, stats=True)
+        wg = O.greedy_search(p, budget, cyclically_reduce_after_moves=cyc, stats=True)
+        ok, path, st = run_search(_acx.SEARCH_BFS, p, budget, cyc)
+        assert (ok, path) == wb[:2] and st["nodes"] == wb[2]["nodes"] and st["expanded"] == wb[2]["expanded"], (L, budget, cyc)
+        ok, path, st = run_search(_acx.SEARCH_GREEDY, p, budget, cyc)
+        assert (ok, path) == wg[:2] and st["nodes"] == wg[2]["nodes"] and st["expanded"] == wg[2]["expanded"], (L, budget, cyc)
+        assert bfs(p, budget, cyclically_reduce_after_moves=cyc) == (wb[0], wb[1] if wb[0] else None)
+        assert greedy_search(p, budget, cyclically_reduce_after_moves=cyc) == wg[:2]
+        ok, path, st = bfs_sharded(p, budget, cyclically_reduce_after_moves=cyc, want_stats=True)
+        assert (ok, path) == wb[:2] and st["nodes"] == wb[2]["nodes"], (L, budget, cyc)
+
+        def run(comm):
+            nat = NativeComm.from_python(comm)
+            a = bfs_sharded_native(p, budget, cyclically_reduce_after_moves=cyc, comm=nat, batch_parents=512, replicate_below=40, want_stats=True)
+            b = bfs_sharded(p, budget, cyclically_reduce_after_moves=cyc, comm=comm, batch_parents=512, replicate_below=0, want_stats=True)
+            assert not nat.errors, nat.errors[:1]
+            return a, b
+
+        for a, b in run_threads(3, run):
+            for ok, path, st in (a, b):
+                assert (ok, path) == wb[:2] and st["nodes"] == wb[2]["nodes"] and st["expanded"] == wb[2]["expanded"], (L, budget, cyc)
+    rows = np.stack([c[0] for c in cases[:3]])
+    for kind, fn in ((_acx.SEARCH_BFS, O.bfs), (_acx.SEARCH_GREEDY, O.greedy_search)):
+        got = run_search_many(kind, rows, 4000, False)
+        for r, (ok, path, st) in zip(rows, got):
+            assert (ok, path) == fn(r, 4000)[:2], (L, kind)
 
 
 def _key_words(state, L, KW):

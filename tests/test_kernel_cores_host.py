@@ -236,3 +236,69 @@ def test_normal_form_search_path_matches_oracle(shim, L, cyc):
         ok = we == 0
         cur = np.ascontiguousarray(want[ok])
         mv = np.roll(mv[ok], 1)
+
+
+# ---- keys of max_relator_length 62 .. 64 (csrc/acx_keys.h: keyops<u128x>) ----------------------------------------------------
+_CODE = {-2: 0, -1: 1, 1: 2, 2: 3}
+
+
+def _long_key_python(word):
+    """the 128-bit key of a freely reduced word of 1 .. 64 letters, restated: the plain first letter, code[k] ^ code[k - 1] for the
+    others, the field 3 as a terminator behind the last letter (none at 64 letters)"""
+    n = len(word)
+    codes = [_CODE[int(a)] for a in word]
+    fields = [codes[0]] + [codes[k] ^ codes[k - 1] for k in range(1, n)] + ([3] if n < 64 else [])
+    return sum(f << (2 * k) for k, f in enumerate(fields))
+
+
+def _reduced_word(rng, n):
+    w = []
+    while len(w) < n:
+        c = int(rng.choice([-2, -1, 1, 2]))
+        if not w or w[-1] != -c:
+            w.append(c)
+    return w
+
+
+def test_long_keys_name_reduced_words_of_up_to_64_letters(shim):
+    """keyops<u128x>::make / split on the CPU: the key is the restated one, decodes to the word it was made of, and distinct words get
+    distinct keys -- lengths 1 .. 64, prefixes of one another included (a word and the same word with letters appended differ only in
+    where the terminator sits)"""
+    rng = np.random.default_rng(64)
+    seen = {}
+    for trial in range(3000):
+        n = int(rng.integers(1, 65)) if trial % 7 else 64 - trial % 3
+        w = _reduced_word(rng, n)
+        for m in {n, max(1, n - 1), max(1, n // 2)}:  # the word and two of its prefixes
+            word = np.array(w[:m], np.int8)
+            key2 = np.zeros(2, np.uint64)
+            back_n = C.c_int32(-1)
+            back = np.zeros(64, np.int8)
+            shim.shim_long_key(_p(word, C.c_int8), m, _p(key2, C.c_uint64), C.byref(back_n), _p(back, C.c_int8))
+            key = int(key2[0]) | (int(key2[1]) << 64)
+            assert key == _long_key_python(word), (m, word.tolist())
+            assert back_n.value == m and back[:m].tolist() == word.tolist() and not back[m:].any(), (m, word.tolist(), back.tolist())
+            assert seen.setdefault(key, tuple(word.tolist())) == tuple(word.tolist())
+
+
+@pytest.mark.parametrize("L", [62, 63, 64])
+def test_moves_on_the_long_word_type_match_the_oracle(shim, L):
+    """ACMove through Pres<u128x> (the word functions take the type unchanged, range-checked shifts: a shift by 64 letters is the word's
+    width) against the oracle's ACMove (ac_moves.py:159-231), relators up to the full 64 letters"""
+    rng = np.random.default_rng(L)
+    n = 1500
+    st = np.zeros((n, 2 * L), np.int8)
+    for i in range(n):
+        for h in (0, 1):
+            m = int(rng.integers(1, L + 1)) if i % 5 else L - int(rng.integers(0, 3))
+            st[i, h * L:h * L + m] = _reduced_word(rng, m)
+    mv = rng.integers(0, 12, n).astype(np.uint8)
+    for cyc in (False, True):
+        out = np.empty_like(st)
+        lens = np.empty((n, 2), np.int32)
+        err = np.empty(n, np.uint8)
+        shim.shim_move_long(_p(st, C.c_int8), _p(mv, C.c_uint8), C.c_int64(n), L, int(cyc), _p(out, C.c_int8), _p(lens, C.c_int32), _p(err, C.c_uint8))
+        want, wlens, werr = O.move_batch(st, mv, L, cyclical=cyc)
+        assert np.array_equal(err, werr)
+        ok = werr == 0
+        assert np.array_equal(out[ok], want[ok]) and np.array_equal(lens[ok], wlens[ok])
