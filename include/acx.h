@@ -163,6 +163,10 @@ typedef struct {
 #define ACX_SEARCH_BFS 0
 #define ACX_SEARCH_GREEDY 1
 
+/* max_relator_length L <= 64 (the reference takes any, breadth_first.py:42-45; its Miller-Schupp generator reaches 64 at n = 14): one
+ * 128-bit key word per relator.  L <= 29: 64-bit keys; <= 61: word | length in one unsigned __int128; 62 .. 64: a key that names FREELY
+ * REDUCED words (csrc/acx_keys.h) -- every state ACMove produces is one, the presentation handed in has to be (ACX_E_INVAL otherwise);
+ * those searches run the fused bfs / the batch-per-launch greedy frontier, and acx_search_many runs them one by one. */
 int acx_search(int kind, const int8_t *h_presentation, int L, int64_t max_nodes, int cyclical, int32_t *solved,
                int32_t *path_action, int32_t *path_len, int64_t path_cap, int64_t *path_n, acx_search_stats *stats);
 
@@ -253,7 +257,7 @@ int64_t acx_get_option(int option);
  * parent's local id | (12 * (global parent position - c0) + action) << 32.  An all-to-all with equal splits of
  * S * region_words int64 per rank delivers it. */
 typedef struct acx_shard acx_shard;
-int acx_shard_key_words(int L); /* 2 for L <= 29, 4 for L <= 61 */
+int acx_shard_key_words(int L); /* 2 for L <= 29, 4 for L <= 64 (62 .. 64: the reduced-word key of csrc/acx_keys.h) */
 /* geometry of a chunk of n_parents global parents (pure host arithmetic, no device needed).  fill_q8: capacity of a region at
  * world > 1 in 1/256 of the even share of ALL children (+ two workgroups' worth); <= 0 or 321 .. 2^20 - 1: the default 320 =
  * 1.25 x; >= 2^20: the hard bound (every workgroup sends a region all it has: safe for any input, world^2 x the even share).

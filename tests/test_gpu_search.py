@@ -483,7 +483,7 @@ def test_searches_at_max_relator_length_62_to_64_match_the_oracle(search, L):
             if not w or w[-1] != -c:
                 w.append(c)
         long_rows[h * L:h * L + len(w)] = w
-    cases = [(_ms_presentation(14 if L == 64 else 13, [2, 1, -2], L), 20000, False), (_ms_presentation(14 if L == 64 else 13, [1, 2, -1, 2], L), 6000, True),
+    cases = [(_ms_presentation(14 if L == 64 else 13, [2, 1, -2], L), 20000, False), (_ms_presentation(14 if L == 64 else 13, [2, 1, 2, -1], L), 6000, True),
              (ak3, 30000, False), (ak3, 5000, True), (long_rows, 3000, False), (long_rows, 2000, True)]
     for p, budget, cyc in cases:
         wb = O.bfs(p, budget, cyclically_reduce_after_moves=cyc, stats=True)
@@ -507,6 +507,14 @@ def test_searches_at_max_relator_length_62_to_64_match_the_oracle(search, L):
         for a, b in run_threads(3, run):
             for ok, path, st in (a, b):
                 assert (ok, path) == wb[:2] and st["nodes"] == wb[2]["nodes"] and st["expanded"] == wb[2]["expanded"], (L, budget, cyc)
+    if L == 64:  # the package's own generator at n = 14 (the reference's reaches max_relator_length 64 there) through the batch driver's searches
+        from ac_solver.search.miller_schupp.miller_schupp import generate_miller_schupp_presentations
+
+        gen = generate_miller_schupp_presentations(14, 3)
+        sample = [np.array(p, np.int8) for lenw in sorted(gen) for p in gen[lenw]][:8]
+        assert sample and all(len(p) == 128 for p in sample)
+        for p in sample:
+            assert greedy_search(p, 3000) == O.greedy_search(p, 3000) and bfs(p, 3000) == (lambda r: (r[0], r[1] if r[0] else None))(O.bfs(p, 3000))
     rows = np.stack([c[0] for c in cases[:3]])
     for kind, fn in ((_acx.SEARCH_BFS, O.bfs), (_acx.SEARCH_GREEDY, O.greedy_search)):
         got = run_search_many(kind, rows, 4000, False)
