@@ -136,6 +136,7 @@ constexpr uint32_t kGreedyMultiThreads = ACX_GREEDY_MULTI_THREADS;
 constexpr uint32_t kGreedyPerCu = 2;  // workgroups of k_greedy_sched a compute unit holds (512 lanes, 128 registers each)
 template <> struct greedy_cfg<uint64_t> { static constexpr uint32_t kSortCap = ACX_GREEDY_MULTI_R * kGreedyMultiThreads; };
 template <> struct greedy_cfg<u128> { static constexpr uint32_t kSortCap = 2 * kGreedyMultiThreads; };
+template <> struct greedy_cfg<u128x> : greedy_cfg<u128> {};  // (max_relator_length 62 .. 64, acx_keys.h: the same 16-byte keys)
 
 // The hash of the greedy frontier's tables (visited table: slot = low bits, 32-bit fingerprint = high half; in-batch tables: low bits /
 // bits 40..): one multiply-xorshift round per key word, as the BFS stamp tables use (acx_bfs.h: stamp_hash).  Rounds 1-3 used

@@ -174,12 +174,9 @@ static int run_search(int kind, const int8_t* pres, int L, int64_t max_nodes, in
         if (has_inverse_pair<W, true>(root.w0, root.n0) || has_inverse_pair<W, true>(root.w1, root.n1))
             return fail(ACX_E_INVAL, "acx_search: at max_relator_length %d (> 61) the presentation must be freely reduced", L);
     }
-    // (the persistent frontier and its whole-GPU kernels are not instantiated for the 62 .. 64-letter key type: those searches -- the reference's
-    // Miller-Schupp presentations from n = 14 on -- take the batch-per-launch path, same result)
-    if (greedy && !option(ACX_OPT_GREEDY_HOST, 0) && !t_minima_on && !is_long_key<W>::value) {  // device-resident priority frontier; falls through when it hits a capacity
+    if (greedy && !option(ACX_OPT_GREEDY_HOST, 0) && !t_minima_on) {  // device-resident priority frontier; falls through when it hits a capacity
         bool handled = false;
-        int grc = ACX_OK;
-        if constexpr (!is_long_key<W>::value) grc = run_greedy_device<W>(root, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, &handled);
+        const int grc = run_greedy_device<W>(root, L, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, &handled);
         if (grc != ACX_OK || handled) return grc;
         *solved = 0;
         *path_n = 0;

@@ -236,5 +236,6 @@ int run_greedy_device(const Pres<W>& root, int L, int64_t max_nodes, int cyclica
 
 template int run_greedy_device<uint64_t>(const Pres<uint64_t>&, int, int64_t, int, int32_t*, int32_t*, int32_t*, int64_t, int64_t*, acx_search_stats*, bool*);
 template int run_greedy_device<u128>(const Pres<u128>&, int, int64_t, int, int32_t*, int32_t*, int32_t*, int64_t, int64_t*, acx_search_stats*, bool*);
+template int run_greedy_device<u128x>(const Pres<u128x>&, int, int64_t, int, int32_t*, int32_t*, int32_t*, int64_t, int64_t*, acx_search_stats*, bool*);
 
 }  // namespace acx

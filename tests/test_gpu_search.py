@@ -492,6 +492,9 @@ def test_searches_at_max_relator_length_62_to_64_match_the_oracle(search, L):
         assert (ok, path) == wb[:2] and st["nodes"] == wb[2]["nodes"] and st["expanded"] == wb[2]["expanded"], (L, budget, cyc)
         ok, path, st = run_search(_acx.SEARCH_GREEDY, p, budget, cyc)
         assert (ok, path) == wg[:2] and st["nodes"] == wg[2]["nodes"] and st["expanded"] == wg[2]["expanded"], (L, budget, cyc)
+        with _acx.options(OPT_GREEDY_HOST=1):  # the batch-per-launch greedy frontier on the same key type
+            ok, path, st = run_search(_acx.SEARCH_GREEDY, p, budget, cyc)
+        assert (ok, path) == wg[:2] and st["nodes"] == wg[2]["nodes"] and st["expanded"] == wg[2]["expanded"], (L, budget, cyc)
         assert bfs(p, budget, cyclically_reduce_after_moves=cyc) == (wb[0], wb[1] if wb[0] else None)
         assert greedy_search(p, budget, cyclically_reduce_after_moves=cyc) == wg[:2]
         ok, path, st = bfs_sharded(p, budget, cyclically_reduce_after_moves=cyc, want_stats=True)
