@@ -46,7 +46,7 @@ class Comm(C.Structure):
 
 class ShardOpts(C.Structure):
     _fields_ = [("batch_parents", C.c_int64), ("replicate_below", C.c_int64), ("region_fill", C.c_int32), ("overlap", C.c_int32),
-                ("mask_comm", C.POINTER(Comm)), ("fail_at_call", C.c_int32), ("fail_rank", C.c_int32)]
+                ("mask_comm", C.POINTER(Comm)), ("fail_at_call", C.c_int32), ("fail_rank", C.c_int32), ("log_fraction_q8", C.c_int32)]
 
 
 class ShardRunStats(C.Structure):

@@ -998,7 +998,7 @@ class NativeComm:
 
 
 def bfs_sharded_native(presentation, max_nodes_to_explore=10000, verbose=False, cyclically_reduce_after_moves=False, comm=None, batch_parents=None,
-                       want_stats=False, overlap=None, region_fill=None, replicate_below=None, mask_comm=None, _fail_at_call=0, _fail_rank=0):
+                       want_stats=False, overlap=None, region_fill=None, replicate_below=None, mask_comm=None, log_fraction=None, _fail_at_call=0, _fail_rank=0):
     """`bfs` over the ranks of `comm` (a NativeComm; None = one rank) as ONE C call per rank: acx_bfs_sharded (csrc/acx_shard_run.hip) runs
     what bfs_sharded above orchestrates from Python -- same engine, same chunk loop, same result.  Same contract as `bfs`
     (breadth_first.py:15-97): (is_search_successful, path or None) [+ stats], identical on every rank."""
@@ -1020,6 +1020,7 @@ def bfs_sharded_native(presentation, max_nodes_to_explore=10000, verbose=False, 
     if mask_comm is not None:
         opts.mask_comm = C.pointer(mask_comm.c)
     opts.fail_at_call, opts.fail_rank = int(_fail_at_call), int(_fail_rank)
+    opts.log_fraction_q8 = 0 if log_fraction is None else max(1, int(log_fraction * 256))
     cap = 1 << 12
     while True:
         pa, pl = np.empty(cap, np.int32), np.empty(cap, np.int32)

@@ -620,9 +620,26 @@ struct DevBuf {
         }
         return ACX_OK;
     }
-    ~DevBuf() {
-        if (p) block_pool().give(p, bytes, dev, 0, clean_tag);
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;  // (an owner: a copy would hand the block back twice)
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), dev(o.dev), clean_tag(o.clean_tag) { o.p = nullptr; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p, bytes = o.bytes, dev = o.dev, clean_tag = o.clean_tag;
+            o.p = nullptr;
+        }
+        return *this;
     }
+    // back to the pool now (the buffer can be allocated again)
+    void release() {
+        if (p) block_pool().give(p, bytes, dev, 0, clean_tag);
+        p = nullptr;
+        bytes = 0;
+        clean_tag = 0;
+    }
+    ~DevBuf() { release(); }
 };
 
 // The stamp table(s) of a BFS (acx_bfs.h).  A stamp carries its search's EPOCH, and a slot with another epoch is free: the table of

@@ -191,9 +191,7 @@ struct ShardRun {
             const int64_t nw = std::max<int64_t>(2 * log_words, cursor + 2 * need);
             if (bigger.alloc((size_t)nw * 8)) return ACX_E_NOMEM;
             ACX_HIP_TRY(hipMemcpy(bigger.p, log.p, (size_t)cursor * 8, hipMemcpyDeviceToDevice));
-            std::swap(log.p, bigger.p);
-            std::swap(log.bytes, bigger.bytes);
-            std::swap(log.dev, bigger.dev);
+            std::swap(log, bigger);  // (the old block goes back to the pool when `bigger` leaves the scope)
             log_words = nw;
             if (int rc = attach()) return rc;
             ACX_HIP_TRY(hipDeviceSynchronize());
@@ -202,9 +200,7 @@ struct ShardRun {
             ACX_HIP_TRY(hipDeviceSynchronize());
             DevBuf bigger;
             if (bigger.alloc((size_t)need * 8)) return ACX_E_NOMEM;
-            std::swap(send.p, bigger.p);
-            std::swap(send.bytes, bigger.bytes);
-            std::swap(send.dev, bigger.dev);
+            std::swap(send, bigger);
             send_words = need;
             if (int rc = attach()) return rc;
         }
@@ -238,10 +234,8 @@ struct ShardRun {
             words = S * world * rw;
             if ((size_t)words * 8 > dead_send.bytes || !dead_send.p) {
                 ACX_HIP_TRY(hipDeviceSynchronize());
-                dead_send.~DevBuf();
-                new (&dead_send) DevBuf();
-                dead_recv.~DevBuf();
-                new (&dead_recv) DevBuf();
+                dead_send.release();
+                dead_recv.release();
                 if (dead_send.alloc((size_t)words * 8) || dead_recv.alloc((size_t)words * 8)) return ACX_E_NOMEM;
             }
             sp = (int64_t*)dead_send.p;
@@ -395,8 +389,7 @@ struct ShardRun {
                 const int64_t mask_words = (cur.n_par + 1) / 2;
                 if (cur.dead) {  // never went through the engine: nothing to dedup, nothing to commit; the collectives still pair up
                     if ((size_t)mask_words * 4 > dead_mask.bytes || !dead_mask.p) {
-                        dead_mask.~DevBuf();
-                        new (&dead_mask) DevBuf();
+                        dead_mask.release();
                         if (dead_mask.alloc((size_t)((B + 3) / 4 * 2) * 4)) return ACX_E_NOMEM;
                     }
                     masks = (int32_t*)dead_mask.p;
@@ -722,7 +715,7 @@ int acx_bfs_sharded(const int8_t* h_presentation, int L, int64_t max_nodes, int 
         R.fail_at_call = o.fail_at_call;
         R.fail_rank = o.fail_rank;
         const int64_t node_cap = (world == 1 ? max_nodes + 64 : (int64_t)(2.0 * (double)max_nodes / world) + std::min<int64_t>(max_nodes, 16 * std::max<int64_t>(repl, 0))) + 4096;
-        if (int rc = R.setup(node_cap, std::max(1.0, 0.5 * (double)max_nodes))) return rc;
+        if (int rc = R.setup(node_cap, std::max(1.0, (o.log_fraction_q8 > 0 ? o.log_fraction_q8 / 256.0 : 0.5) * (double)max_nodes))) return rc;
         const auto t_ready = std::chrono::steady_clock::now();
         const int rc = R.run();
         if (rc == RC_OVERFLOW) {

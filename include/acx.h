@@ -396,6 +396,7 @@ typedef struct acx_shard_opts { /* all zero = the defaults of sharded.py:bfs_sha
     const acx_comm *mask_comm;  /* a second communicator for the per-chunk mask all-reduce (runs beside the all-to-all of the next chunk); NULL: the same */
     int32_t fail_at_call;       /* test hook: the n-th engine call of rank `fail_rank` fails (every rank must then return an error, none may hang) */
     int32_t fail_rank;
+    int32_t log_fraction_q8;    /* expected expanded parents / max_nodes in 1/256, sizes the record log (default 128 = 0.5; the log grows by doubling when the estimate is short) */
 } acx_shard_opts;
 typedef struct acx_shard_run_stats {
     int64_t nodes, expanded, levels, chunks, replicated_levels, local_nodes;

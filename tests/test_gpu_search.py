@@ -917,6 +917,8 @@ def test_native_sharded_bfs_a_failing_rank_ends_every_rank(search):
             except RuntimeError as e:
                 out.append(str(e))
         out.append(bfs_sharded_native(ak3, 30000, comm=nat, batch_parents=256, replicate_below=40))
+        # a record log sized for 1/256 of the budget: it has to grow (by doubling) several times in mid-search
+        assert bfs_sharded_native(ak3, 30000, comm=nat, batch_parents=256, replicate_below=40, log_fraction=1 / 256) == out[-1]
         assert not nat.errors, nat.errors
         return out
 
