@@ -644,13 +644,46 @@ extern "C" int acx_search_groups(int kind, int n_groups, const int8_t* const* h_
     if (max_nodes < 0) max_nodes = 0;
     bool sched = kind == ACX_SEARCH_GREEDY && !option(ACX_OPT_GREEDY_HOST, 0) && !t_minima_on && !g_digest_on.load();
     for (int g = 0; g < n_groups; g++) sched = sched && L[g] <= 61;
-    if (!sched) {  // one batch after the other through acx_search_many (bfs: a batch fills the GPU by itself, acx_bfs_many.h)
-        for (int g = 0; g < n_groups; g++) {
-            const int64_t o = out0[(size_t)g];
-            const int rc = acx_search_many(kind, h_presentations[g], n[g], L[g], max_nodes, cyclical, 16, solved + o, path_action ? path_action + o * path_cap : nullptr,
-                                           path_len ? path_len + o * path_cap : nullptr, path_cap, path_n + o, stats ? stats + o : nullptr, rc_out + o);
-            if (rc != ACX_OK) return rc;
+    if (!sched) {
+        // The batches through acx_search_many.  bfs: a batch fills the GPU by itself (acx_bfs_many.h) -- until its last searches are left: TWO
+        // batches in flight (two host threads, each with its own stream) let the next one's rounds fill the chip while the running one's tail
+        // drains.  Measured on the 1190-presentation sweep (tools/scratch/bfs_sweep_overlap.py): 0.137 s one after the other, 0.129 with two in
+        // flight, 0.130 with three, 0.19-0.25 with all seven (round 4: their tables evict each other from the caches).
+        const int in_flight = kind == ACX_SEARCH_BFS && n_groups > 1 && !t_minima_on && !g_digest_on.load() ? 2 : 1;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<int> next(0), first_rc(ACX_OK);
+        std::mutex err_mu;
+        std::string first_err;
+        auto work = [&](bool own_thread) {
+            if (own_thread) (void)hipSetDevice(dev);
+            for (;;) {
+                const int g = next.fetch_add(1);
+                if (g >= n_groups || first_rc.load() != ACX_OK) return;
+                const int64_t o = out0[(size_t)g];
+                const int rc = acx_search_many(kind, h_presentations[g], n[g], L[g], max_nodes, cyclical, 16, solved + o, path_action ? path_action + o * path_cap : nullptr,
+                                               path_len ? path_len + o * path_cap : nullptr, path_cap, path_n + o, stats ? stats + o : nullptr, rc_out + o);
+                if (rc != ACX_OK) {
+                    std::lock_guard<std::mutex> lock(err_mu);
+                    if (first_rc.load() == ACX_OK) {
+                        first_rc.store(rc);
+                        first_err = acx_last_error();  // (the message is thread-local: carried to the caller's thread below)
+                    }
+                }
+            }
+        };
+        {
+            struct Joined {
+                std::vector<std::thread> t;
+                ~Joined() {
+                    for (auto& x : t)
+                        if (x.joinable()) x.join();
+                }
+            } others;
+            for (int k = 1; k < in_flight; k++) others.t.emplace_back(work, true);
+            work(false);
         }
+        if (first_rc.load() != ACX_OK) return fail(first_rc.load(), "%s", first_err.c_str());
         return ACX_OK;
     }
     // greedy_search: ALL batches as jobs of one launch per key width (64-bit keys up to max_relator_length 29, 128-bit above), the two
