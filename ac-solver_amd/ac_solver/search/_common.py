@@ -99,16 +99,13 @@ def _collect(n, solved, pa, pl, pn, rcs, stats, redo):
     st = np.frombuffer(stats, dtype=_STATS_DTYPE, count=n) if n else np.zeros(0, _STATS_DTYPE)
     cols = [st[f].tolist() for f in ("nodes", "expanded", "children", "levels", "min_len", "seconds")]
     ok, cnt, codes = solved.tolist(), pn.tolist(), rcs.tolist()
-    # (the paths in TWO conversions for the whole call instead of two per search: a sweep's 533 paths cost 3.5-7 ms one by one)
-    width = min(int(max((c for c, rc in zip(cnt, codes) if rc != _acx.E_CAPACITY), default=0)), pa.shape[1]) if n else 0
-    acts, lens = (pa[:, :width].tolist(), pl[:, :width].tolist()) if width else ([], [])
     out = []
     for k in range(n):
         if codes[k] == _acx.E_CAPACITY:
             out.append(redo(k))
             continue
         m = cnt[k]
-        path = list(zip(acts[k][:m], lens[k][:m])) if m else None
+        path = list(zip(pa[k, :m].tolist(), pl[k, :m].tolist())) if m else None
         out.append((bool(ok[k]), path, dict(nodes=cols[0][k], expanded=cols[1][k], children=cols[2][k], levels=cols[3][k], min_len=cols[4][k], seconds=cols[5][k])))
     return out
 
