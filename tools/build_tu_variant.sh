@@ -11,8 +11,8 @@ B=/tmp/acx_var/${tu}_$name
 mkdir -p $B
 make -s BUILD=$B EXTRA="$*" SHIFT64_CHECK=${SHIFT64_CHECK:-1} $B/acx_$tu.o
 objs=""
-for f in step search search_greedy search_many shard ball simplex policy; do
+for f in step search search_greedy search_many shard shard_run ball simplex policy; do
   if [ $f = $tu ]; then objs="$objs $B/acx_$f.o"; else objs="$objs _build/acx_$f.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../lib/var_$name.so $objs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../lib/var_$name.so $objs -ldl
 echo built ../lib/var_$name.so
