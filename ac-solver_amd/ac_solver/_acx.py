@@ -22,7 +22,7 @@ ENV_RECORD_ACTIONS = 1
 SEARCH_BFS, SEARCH_GREEDY = 0, 1
 ERR_ASSERT, ERR_INDEX, ERR_VALUE, ERR_UNPACKABLE = 1, 2, 3, 250
 # acx_set_option: tuning / test knobs of the search entry points (process wide; nothing on a call path reads the environment)
-OPT_BFS_NO_RUNAHEAD, OPT_GREEDY_HOST, OPT_GREEDY_HAND_MIN, OPT_MEGA_RANK_MAX, OPT_BFS_MANY_BMAX, OPT_GREEDY_SLOTS, OPT_GENERAL_MOVE, OPT_GREEDY_SCRATCH = range(8)
+OPT_BFS_NO_RUNAHEAD, OPT_GREEDY_HOST, OPT_GREEDY_HAND_MIN, OPT_MEGA_RANK_MAX, OPT_BFS_MANY_BMAX, OPT_GREEDY_SLOTS, OPT_GENERAL_MOVE, OPT_GREEDY_SCRATCH, OPT_GREEDY_KEEP_ORDER = range(9)
 
 
 class AcxError(RuntimeError):

@@ -116,7 +116,7 @@ int scan_u32_exclusive(void* tmp, size_t* tmp_bytes, const uint32_t* in, uint32_
     return ACX_OK;
 }
 
-std::atomic<int64_t> g_options[ACX_OPT_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+std::atomic<int64_t> g_options[ACX_OPT_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 const bool g_debug = getenv("ACX_DEBUG") != nullptr;  // the one look at the environment, when the library is loaded
 std::atomic<int> g_digest_on{0};
 thread_local uint64_t t_last_digest = 0;

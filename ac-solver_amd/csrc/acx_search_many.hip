@@ -216,7 +216,7 @@ static int run_greedy_sched(const GreedySlots& pool, const std::vector<SearchGro
     // which searches stay unsolved is not known beforehand, so: the smaller max_relator_length first, the longer relators first.
     // Round 5, on the slot pool: this order 0.147-0.153 s; longest roots first whatever the bound 0.168; the wider bounds first 0.167;
     // by 2 L - root length 0.145-0.150; the 128-bit launch held to 300 / 256 workgroups 0.148 / 0.153-0.163)
-    for (int code = 0; code < 2; code++) {
+    for (int code = 0; code < 2 && !option(ACX_OPT_GREEDY_KEEP_ORDER, 0); code++) {
         std::vector<size_t> order(jobs[code].size());
         for (size_t i = 0; i < order.size(); i++) order[i] = i;
         std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {

@@ -225,7 +225,8 @@ int acx_search_many(int kind, const int8_t *h_presentations, int64_t n, int L, i
 #define ACX_OPT_GREEDY_SLOTS 5     /* persistent workgroups of acx_search_many / acx_search_groups (greedy) (default 512 = two per compute unit; slots of the call = min(this, jobs, what the memory holds)) */
 #define ACX_OPT_GENERAL_MOVE 6     /* 1: the general move code also for roots in normal form (tests: both codes must build the same arena) */
 #define ACX_OPT_GREEDY_SCRATCH 7   /* acx_search_many / acx_search_groups, greedy: entries of a slot's own sort scratch (default 65536; a bucket that needs more borrows a shared full-size region; tests: small) */
-#define ACX_OPT_COUNT 8
+#define ACX_OPT_GREEDY_KEEP_ORDER 8 /* 1: acx_search_many / acx_search_groups (greedy) take the jobs in the caller's order (default: smaller max_relator_length first, longer relators first) */
+#define ACX_OPT_COUNT 9
 int acx_set_option(int option, int64_t value);
 int64_t acx_get_option(int option);
 
