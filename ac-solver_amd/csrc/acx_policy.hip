@@ -200,9 +200,6 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __
         constexpr int UT = (NM & 1) && U > 1 ? U - 1 : U;  // the units that carry tanh work (an odd block's last MFMA may consume out_hi)
         static_for<0, U>([&](auto uu) {
             constexpr int u = decltype(uu)::value;
-#ifdef ACX_POLICY_SETPRIO
-            __builtin_amdgcn_s_setprio(ACX_POLICY_SETPRIO);
-#endif
             static_for<2 * u, (2 * u + 2 < NM ? 2 * u + 2 : NM)>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
 #ifdef ACX_POLICY_NO_LDS_READ  // timing experiment only (wrong numbers): every MFMA reuses the block's first fragments -- what the LDS reads cost
@@ -213,9 +210,6 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __
                 if constexpr (i == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], ones, zero, 0, 0, 0);
                 else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bfrag(std::integral_constant<int, i - 1>{}), acc, 0, 0, 0);
             });
-#ifdef ACX_POLICY_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
             if (have_pend && u < UT) {
                 // two values at a time, their instruction chains interleaved: a transcendental's result is not consumed by the next
                 // instruction (that costs an s_nop each time), and the pair shares one v_cvt_pk_bf16_f32
