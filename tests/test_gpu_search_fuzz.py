@@ -155,7 +155,7 @@ def test_random_presentations_sharded_bfs(world):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("L", [6, 25, 33])
+@pytest.mark.parametrize("L", [6, 25, 33, 63])
 def test_random_presentations_through_the_sharded_engine(L, monkeypatch):
     """bfs_sharded on 2 / 3 / 5 thread ranks of the HIP engine (one GPU plays all of them) on random presentations -- roots in and out
     of normal form (the general move code computes every child's owner from scratch, the normal-form codes inherit it along
@@ -176,7 +176,7 @@ def test_random_presentations_through_the_sharded_engine(L, monkeypatch):
         row = np.zeros(2 * L, np.int8)
         for h in (0, 1):
             w = _random_word(rng, int(rng.integers(1, min(L, 9) + 1)))
-            if rng.random() < 0.3 and len(w) + 2 <= L:  # not freely reduced: the general move code
+            if L <= 61 and rng.random() < 0.3 and len(w) + 2 <= L:  # not freely reduced: the general move code (keys of 62 .. 64 letters need a reduced root)
                 w = w[:1] + [w[0], -w[0]] + w[1:]
             row[h * L:h * L + len(w)] = w
         budget = int(rng.choice([40, 700, 6000, 40000]))
@@ -190,8 +190,17 @@ def test_random_presentations_through_the_sharded_engine(L, monkeypatch):
 
         def run(comm):
             try:
-                # (round 6: every level exchanged / the frontier partitioned by owner at the first level of >= 30 or 400 parents / the default)
-                return bfs_sharded(row, budget, cyclically_reduce_after_moves=cyc, comm=comm, batch_parents=bp, want_stats=True, replicate_below=(0, 30, 400, None)[case % 4])
+                # (round 6: every level exchanged / the frontier partitioned by owner at the first level of >= 30 or 400 parents / the default;
+                # the Python orchestration and acx_bfs_sharded -- the same loop in C++ -- in turn)
+                repl = (0, 30, 400, None)[case % 4]
+                if (case // 4 + SEED) % 2:
+                    from ac_solver.search.sharded import NativeComm, bfs_sharded_native
+
+                    nat = NativeComm.from_python(comm)
+                    ok, path, st = bfs_sharded_native(row, budget, cyclically_reduce_after_moves=cyc, comm=nat, batch_parents=bp, want_stats=True, replicate_below=repl)
+                    assert not nat.errors, nat.errors[:1]
+                    return ok, path, dict(st, owner_mismatches=0)
+                return bfs_sharded(row, budget, cyclically_reduce_after_moves=cyc, comm=comm, batch_parents=bp, want_stats=True, replicate_below=repl)
             except (AssertionError, IndexError):
                 return "raises"
 
