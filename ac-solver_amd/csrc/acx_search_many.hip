@@ -771,7 +771,17 @@ extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t 
     if (n < 0 || !h_presentations || !solved || !path_n || !rc_out || path_cap < 0) return fail(ACX_E_INVAL, "acx_search_many: bad argument");
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 64) n_threads = 64;
-    if (kind == ACX_SEARCH_GREEDY && n > 1 && L >= 1 && L <= 61 && !option(ACX_OPT_GREEDY_HOST, 0) && !t_minima_on && !g_digest_on.load()) {
+    // max_relator_length 62 .. 64 (acx_keys.h): the reduced-word key type when every root is freely reduced (a presentation that is not goes through
+    // acx_search below, which says so)
+    bool long_ok = L >= 62 && L <= 64;
+    for (int64_t k = 0; long_ok && k < n; k++)
+        for (int h = 0; h < 2 && long_ok; h++) {
+            const int8_t* w = h_presentations + (k * 2 + h) * L;
+            for (int i = 0; i + 1 < L && w[i + 1] != 0; i++)
+                if (w[i] == -w[i + 1]) long_ok = false;
+        }
+    const bool fits = L >= 1 && (L <= 61 || long_ok);
+    if (kind == ACX_SEARCH_GREEDY && n > 1 && fits && !option(ACX_OPT_GREEDY_HOST, 0) && !t_minima_on && !g_digest_on.load()) {
         // greedy: the searches as jobs on a fixed set of workgroup slots (k_greedy_sched)
         if (max_nodes < 0) max_nodes = 0;
         std::vector<uint8_t> rerun((size_t)n, 0);
@@ -785,8 +795,9 @@ extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t 
             (void)hipStreamDestroy(st0);
             if (rc0 != ACX_OK) return rc0;
         }
-        const int rc = L <= 29 ? run_greedy_sched<uint64_t>(pool, one, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), pool.S)
-                               : run_greedy_sched<u128>(pool, one, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), pool.S);
+        const int rc = L <= 29   ? run_greedy_sched<uint64_t>(pool, one, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), pool.S)
+                       : L <= 61 ? run_greedy_sched<u128>(pool, one, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), pool.S)
+                                 : run_greedy_sched<u128x>(pool, one, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), pool.S);
         if (rc != ACX_OK) return rc;
         pool.mark_clean();
         for (int64_t k = 0; k < n; k++)
@@ -797,7 +808,7 @@ extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t 
             if (rc_out[k] != ACX_OK && rc_out[k] != ACX_E_CAPACITY) return fail(ACX_E_ROWERR, "acx_search_many: search %lld failed with code %d", (long long)k, rc_out[k]);
         return ACX_OK;
     }
-    if (kind == ACX_SEARCH_BFS && n > 1 && L >= 1 && L <= 61 && !t_minima_on && !g_digest_on.load()) {
+    if (kind == ACX_SEARCH_BFS && n > 1 && fits && !t_minima_on && !g_digest_on.load()) {
         // bfs: groups of searches sharing the launches of the fused single search, a batch of every search per round (acx_bfs_many.h)
         if (max_nodes < 0) max_nodes = 0;
         const double nn = (double)std::max<int64_t>(max_nodes, 1);
@@ -809,8 +820,9 @@ extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t 
             int32_t* pl = path_len ? path_len + k0 * path_cap : nullptr;
             acx_search_stats* ps = stats ? stats + k0 : nullptr;
             const int8_t* pr = h_presentations + k0 * 2 * L;
-            const int rc = L <= 29 ? run_bfs_group_fused<uint64_t>(pr, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0)
-                                   : run_bfs_group_fused<u128>(pr, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0);
+            const int rc = L <= 29   ? run_bfs_group_fused<uint64_t>(pr, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0)
+                           : L <= 61 ? run_bfs_group_fused<u128>(pr, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0)
+                                     : run_bfs_group_fused<u128x>(pr, m, L, max_nodes, cyclical, solved + k0, pa, pl, path_cap, path_n + k0, ps, rc_out + k0);
             if (rc != ACX_OK) return rc;
         }
         for (int64_t k = 0; k < n; k++)

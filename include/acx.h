@@ -166,7 +166,8 @@ typedef struct {
 /* max_relator_length L <= 64 (the reference takes any, breadth_first.py:42-45; its Miller-Schupp generator reaches 64 at n = 14): one
  * 128-bit key word per relator.  L <= 29: 64-bit keys; <= 61: word | length in one unsigned __int128; 62 .. 64: a key that names FREELY
  * REDUCED words (csrc/acx_keys.h) -- every state ACMove produces is one, the presentation handed in has to be (ACX_E_INVAL otherwise);
- * acx_search_many / acx_search_groups run those searches one by one through acx_search. */
+ * acx_search_groups takes a batch of such presentations through acx_search_many (shared bfs launches / greedy jobs on workgroup slots, as for the
+ * other widths) instead of the one-launch-per-key-width scheduler. */
 int acx_search(int kind, const int8_t *h_presentation, int L, int64_t max_nodes, int cyclical, int32_t *solved,
                int32_t *path_action, int32_t *path_len, int64_t path_cap, int64_t *path_n, acx_search_stats *stats);
 
