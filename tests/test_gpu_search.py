@@ -510,7 +510,18 @@ def test_searches_at_max_relator_length_62_to_64_match_the_oracle(search, L):
         for a, b in run_threads(3, run):
             for ok, path, st in (a, b):
                 assert (ok, path) == wb[:2] and st["nodes"] == wb[2]["nodes"] and st["expanded"] == wb[2]["expanded"], (L, budget, cyc)
-    if L == 64:  # the package's own generator at n = 14 (the reference's reaches max_relator_length 64 there) through the batch driver's searches
+    if L == 64:  # the batch driver itself at n = 14 (miller_schupp.py:95-177: max_relator_length 64 there) against the oracle, search by search
+        from ac_solver.search.miller_schupp.miller_schupp import generate_miller_schupp_presentations, trivialize_miller_schupp_through_search
+
+        for fn, ofn in ((greedy_search, O.greedy_search), (bfs, O.bfs)):
+            s_rels, u_rels, s_paths = trivialize_miller_schupp_through_search(min_n=14, max_n=14, min_w_len=1, max_w_len=3, max_nodes_to_explore=2000, search_fn=fn)
+            gen14 = generate_miller_schupp_presentations(14, 3)
+            todo = [p for lenw in range(1, 4) for p in gen14.get(lenw, [])]
+            assert len(s_rels) + len(u_rels) == len(todo) > 0 and all(len(p) == 128 for p in todo)
+            want = [ofn(np.array(p, np.int8), 2000) for p in todo]
+            assert [list(p) for p in s_rels] == [list(p) for p, w in zip(todo, want) if w[0]]
+            assert s_paths == [w[1] for w in want if w[0]]
+    if L == 64:  # the package's own generator at n = 14 (the reference's reaches max_relator_length 64 there) through the single searches
         from ac_solver.search.miller_schupp.miller_schupp import generate_miller_schupp_presentations
 
         gen = generate_miller_schupp_presentations(14, 3)
