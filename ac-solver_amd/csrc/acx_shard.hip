@@ -370,18 +370,14 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
     const uint32_t tid = threadIdx.x, l = (tid & 63u) + 64u * (tid >> 8), w = (tid >> 6) & 3u;  // parent slot in the workgroup; wave inside its group of four
     const uint32_t s_lo = d.bounds[2 * g.par], s_hi = d.bounds[2 * g.par + 1];
     const uint32_t np = s_hi - s_lo;
-    // A workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... of the rank's share of the chunk (round 6): the host does not know
-    // the share (the bounds are found on the device), and a grid sized for the largest possible one started ~28 000 workgroups per launch at
-    // 8 ranks that found nothing to do (~20 us of a 100 us launch).
-    for (uint32_t tile = blockIdx.x; tile * kExpandParents < np; tile += gridDim.x) {
-    if (tile != blockIdx.x) __syncthreads();  // (the tile before is through with the LDS arrays)
+    if (blockIdx.x * kExpandParents >= np) return;
     if (tid < 64) s_cnt[tid] = 0;
     for (uint32_t i = tid; i < (uint32_t)kFoldSlots; i += kExpandThreads) s_slot[i] = kEmpty;
     if (!SOLO)
         for (uint32_t i = tid; i < d.world * (uint32_t)kExpandParents; i += kExpandThreads) s_bits[i] = 0;
     if (tid < (uint32_t)kExpandParents) s_tk[tid] = 0;
     // this lane's parent (the same for its three actions)
-    const uint32_t p = tile * kExpandParents + l, id = s_lo + p;
+    const uint32_t p = blockIdx.x * kExpandParents + l, id = s_lo + p;
     const bool live = p < np;
     W pk0 = 0, pk1 = 0;
     uint32_t gp = 0, pa = 0xffu;
@@ -400,7 +396,7 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
     W c0[kExpandItems], c1[kExpandItems];
     bool send_it[kExpandItems];
     uint32_t tl_min = 0xFFFFFFFFu;
-    const uint32_t hsub = tile % kShardSub;
+    const uint32_t hsub = blockIdx.x % kShardSub;
 #pragma unroll
     for (int it = 0; it < kExpandItems; it++) {
         const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)expand_action(w, it));  // uniform across the wave
@@ -597,7 +593,6 @@ __global__ void __launch_bounds__(kExpandThreads) k_shard_expand(ShardDev<W> d, 
     // words are 128 consecutive ones (coalesced); else the parent's position in the chunk is its gpos.
     __syncthreads();
     if (w == 0 && live && s_tk[l]) tk[SOLO ? p : gp - (uint32_t)g.c0] = s_tk[l];
-    }  // tiles
 }
 
 // ---- dedup of the received records ------------------------------------------------------------------------------------------
@@ -998,8 +993,8 @@ template <typename W, int MODE> __global__ void __launch_bounds__(kBornParents) 
     if (!dec.commit) return;
     const uint32_t b0 = d.bounds[2 * g.par], b1 = d.bounds[2 * g.par + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t first = b0 + blockIdx.x * (uint32_t)kBornParents; first < b1; first += gridDim.x * (uint32_t)kBornParents) {  // (as k_shard_expand: the host does not know b1 - b0)
-    if (first != b0 + blockIdx.x * (uint32_t)kBornParents) __syncthreads();
+    const uint32_t first = b0 + blockIdx.x * (uint32_t)kBornParents;
+    if (first >= b1) return;
     const uint32_t i = first + tid;
     uint32_t lm = 0;
     if (i < b1) {
@@ -1054,7 +1049,6 @@ template <typename W, int MODE> __global__ void __launch_bounds__(kBornParents) 
             d.inn[id] = (uint8_t)(o.in0 | (o.in1 << 4));
         }
     }
-    }  // blocks of kBornParents local parents
 }
 
 // root: local node 0 of its owner (global position 0 of level 0); its record sits at the start of the log
@@ -1278,7 +1272,7 @@ template <typename W> struct ShardEngine {
     // thirds of the per-slot workgroups found nothing to do, and the dedup gains nothing from more than ~4 workgroups per
     // compute unit in flight: the memory-side atomic units are saturated by then and a deeper queue is only more latency.
     // Measured at 1e8 nodes (round 4, a sweep over the workgroup counts): insert 545 -> 528 us per 2^21-parent chunk, commit 158 -> ~125.
-    unsigned insert_wgs = 0, commit_wgs = 0, expand_wgs = 4096, born_wgs = 8192;
+    unsigned insert_wgs = 0, commit_wgs = 0;
     int move_mode = kMoveGeneral;  // acx_bfs.h: set from the root (acx_shard_root_record, which every rank calls)
     CtlHost host;  // pinned snapshot slots + events
     // Round 6: while `replicated` is set the engine processes whole levels with the world-1 kernels (every rank the same nodes, no
@@ -1327,8 +1321,6 @@ template <typename W> struct ShardEngine {
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             insert_wgs = 4u * (unsigned)cus;
             commit_wgs = 8u * (unsigned)cus;
-            expand_wgs = 16u * (unsigned)cus;  // 512-lane workgroups, three resident per compute unit: five rounds of them, then they walk
-            born_wgs = 32u * (unsigned)cus;
         }
         cap_nodes = (uint64_t)node_cap + 64;
         chunk_parents = (uint64_t)std::max<int64_t>(chunk_parents_, 1);
@@ -1505,8 +1497,7 @@ static int shard_chunk_expand(ShardEngine<W>& E, int64_t c0, int64_t c1, int lev
     hipLaunchKernelGGL(k_shard_prep<W>, dim3(1), dim3(256), 0, st, E.dev(), geo, level_first, send);
     const int64_t np_max = std::min<int64_t>(n_par, (int64_t)(E.lvl_hi_host - E.lvl_lo_host));
     if (np_max > 0) {
-        // (a bounded grid: the workgroups walk the tiles of the rank's share, which only the device knows -- k_shard_expand)
-        const dim3 grid((unsigned)std::min<int64_t>((np_max + kExpandParents - 1) / kExpandParents, (int64_t)E.expand_wgs));
+        const dim3 grid((unsigned)((np_max + kExpandParents - 1) / kExpandParents));
         const size_t lds = (size_t)E.world_eff() * kExpandParents * 4;  // s_bits
         if (E.world_eff() == 1) {
             if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_expand<W, kMoveNf, true>), grid, dim3(kExpandThreads), lds, st, E.dev(), geo, send);
@@ -1554,7 +1545,7 @@ template <typename W> static int shard_chunk_commit(ShardEngine<W>& E, int64_t m
     if (tiles) hipLaunchKernelGGL(k_shard_commit<W>, dim3(gx, regions), dim3(256), 0, st, E.dev(), geo);
     const int64_t np_max = std::min<int64_t>((int64_t)geo.n_par, (int64_t)(E.lvl_hi_host - E.lvl_lo_host));  // this rank's share of the chunk's parents, at most
     if (np_max > 0) {
-        const dim3 grid((unsigned)std::min<int64_t>((np_max + kBornParents - 1) / kBornParents, (int64_t)E.born_wgs));
+        const dim3 grid((unsigned)((np_max + kBornParents - 1) / kBornParents));
         if (E.move_mode == kMoveNf) hipLaunchKernelGGL((k_shard_commit_born<W, kMoveNf>), grid, dim3(kBornParents), 0, st, E.dev(), geo);
         else if (E.move_mode == kMoveNfCyclical) hipLaunchKernelGGL((k_shard_commit_born<W, kMoveNfCyclical>), grid, dim3(kBornParents), 0, st, E.dev(), geo);
         else hipLaunchKernelGGL((k_shard_commit_born<W, kMoveGeneral>), grid, dim3(kBornParents), 0, st, E.dev(), geo);
