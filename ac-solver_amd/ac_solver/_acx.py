@@ -8,6 +8,7 @@ through the accelerator.
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -210,6 +211,29 @@ def move_rows(rows, actions, L, flags):
     check(lib.acx_move_batch(ptr(rows, C.c_int8), None if act is None else ptr(act, C.c_uint8), n, L, flags, ptr(out, C.c_int8),
                              ptr(lens, C.c_int32), ptr(err, C.c_uint8), ptr(fit, C.c_int32) if flags & F_BYTES else None), "acx_move_batch")
     return out, lens, err, fit
+
+
+_one_row_io = threading.local()
+
+
+def move_one_row(arr, move_id, L, flags):
+    """ACMove on ONE presentation through the packed kernel: the host arrays and their ctypes pointers are made once per thread and
+    width (`ndarray.ctypes.data_as` costs more than the device call's own host work).  -> (out row, len0, len1, err)"""
+    io = getattr(_one_row_io, "by_width", None)
+    if io is None:
+        require_device()
+        io = _one_row_io.by_width = {}
+    slot = io.get(L)
+    if slot is None:
+        rows, act, out = np.zeros((1, 2 * L), np.int8), np.zeros(1, np.uint8), np.zeros((1, 2 * L), np.int8)
+        lens, err = np.zeros((1, 2), np.int32), np.zeros(1, np.uint8)
+        slot = io[L] = (rows, act, out, lens, err, ptr(rows, C.c_int8), ptr(act, C.c_uint8), ptr(out, C.c_int8), ptr(lens, C.c_int32),
+                        ptr(err, C.c_uint8))
+    rows, act, out, lens, err, p_rows, p_act, p_out, p_lens, p_err = slot
+    rows[0] = arr if arr.dtype == np.int8 else as_i8_rows(arr)
+    act[0] = move_id
+    check(lib.acx_move_batch(p_rows, p_act, 1, L, flags, p_out, p_lens, p_err, None), "acx_move_batch")
+    return out[0], int(lens[0, 0]), int(lens[0, 1]), int(err[0])
 
 
 def simplify_rows(rows, cyclical):

@@ -122,6 +122,13 @@ class ACEnv(Env):
 
         self._dtype = self.initial_state.dtype
         self._h = _Handle(1, L, self.horizon_length, 0)
+        # host side of step(): the arrays acx_env_step_host reads and fills and their ctypes pointers, made once
+        act, obs, rew = np.zeros(1, np.int64), np.zeros((1, 2 * L), np.int8), np.zeros(1, np.float32)
+        done, trunc, err = np.zeros(1, np.uint8), np.zeros(1, np.uint8), np.zeros(1, np.uint8)
+        self._io = (act, obs, done, trunc, err)
+        self._io_keep = rew
+        self._io_ptrs = (_acx.ptr(act, C.c_int64), _acx.ptr(obs, C.c_int8), _acx.ptr(rew, C.c_float), _acx.ptr(done, C.c_uint8),
+                         _acx.ptr(trunc, C.c_uint8), None, 0, _acx.ptr(err, C.c_uint8), None)
         if self.supermoves:
             upload_supermoves(self._h.ptr, self.supermoves)
         row = _acx.as_i8_rows(self.initial_state.reshape(1, -1))
@@ -135,15 +142,9 @@ class ACEnv(Env):
         self.actions += [action]
         L = self.max_relator_length
         assert action in range(0, self.action_space.n), f"Expect n to be in range 0-{self.action_space.n - 1} (both inclusive); got {action}"
-        act = np.array([int(action)], dtype=np.int64)
-        obs = np.empty((1, 2 * L), np.int8)
-        rew = np.empty(1, np.float32)
-        done = np.empty(1, np.uint8)
-        trunc = np.empty(1, np.uint8)
-        err = np.empty(1, np.uint8)
-        _acx.check(_acx.lib.acx_env_step_host(self._h.ptr, _acx.ptr(act, C.c_int64), _acx.ptr(obs, C.c_int8), _acx.ptr(rew, C.c_float),
-                                              _acx.ptr(done, C.c_uint8), _acx.ptr(trunc, C.c_uint8), None, 0, _acx.ptr(err, C.c_uint8), None),
-                   "acx_env_step_host")  # one launch, one read-back, one synchronisation
+        act, obs, done, trunc, err = self._io
+        act[0] = int(action)
+        _acx.check(_acx.lib.acx_env_step_host(self._h.ptr, *self._io_ptrs), "acx_env_step_host")  # one launch, one synchronisation
         if err[0]:
             # the reference's ACMove raised before state/lengths/count_steps were touched (ac_env.py:97);
             # the kernel left the device state and counter untouched as well

@@ -64,10 +64,10 @@ def ACMove(move_id, presentation, max_relator_length, lengths, cyclical=True):
         # a two-generator presentation goes through the packed kernel (the one the environments use): a third of the byte-exact
         # kernel's time per call; rows it cannot pack (other letters, zeros that are not right padding) report 250 and take the
         # byte-exact route below, which reproduces the reference on ANY int8 array
-        out, lens, err, _ = _acx.move_rows(arr.reshape(1, -1), [int(move_id)], max_relator_length, flags)
-        if err[0] == 0:
-            return out[0].astype(arr.dtype), [int(lens[0, 0]), int(lens[0, 1])]
-        if err[0] != _acx.ERR_UNPACKABLE:
-            raise _RAISES[int(err[0])](f"move {move_id} on {arr}: the reference raises here (empty relator / zeros not padded to the right)")
+        out, len0, len1, err = _acx.move_one_row(arr.reshape(-1), int(move_id), max_relator_length, flags)
+        if err == 0:
+            return out.astype(arr.dtype), [len0, len1]
+        if err != _acx.ERR_UNPACKABLE:
+            raise _RAISES[err](f"move {move_id} on {arr}: the reference raises here (empty relator / zeros not padded to the right)")
     out, lens, _ = _one_row(presentation, int(move_id), max_relator_length, flags)
     return out, lens

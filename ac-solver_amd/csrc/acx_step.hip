@@ -645,6 +645,9 @@ __global__ void k_env_gather(EnvDev<W> e, const int64_t* __restrict__ idx, int64
 // =================================================================== C ABI ======================
 using namespace acx;
 
+// host-buffer entry points with at most this many rows / environments hand the pinned staging block itself to the kernels (zero copy)
+constexpr int64_t kDirectRows = 64;
+
 // pinned host staging of the host-buffer step, one grow-only buffer per host thread
 static uint8_t* step_staging(size_t bytes) {
     static thread_local uint8_t* buf = nullptr;
@@ -735,11 +738,15 @@ int acx_move_batch(const int8_t* h_in, const uint8_t* h_action, int64_t n, int L
     if (!h) return fail(ACX_E_NOMEM, "acx_move_batch: hipHostMalloc(%zu) failed", total);
     memcpy(h + o_in, h_in, (size_t)n * row);
     if (h_action) memcpy(h + o_act, h_action, (size_t)n);
-    ACX_HIP_TRY(hipMemcpyAsync(b + o_in, h + o_in, h_action ? o_act + (size_t)n : (size_t)n * row, hipMemcpyHostToDevice, nullptr));
+    // A handful of rows (the reference's single-call surface: ACMove on ONE presentation): the kernel reads and writes the pinned block itself
+    // (hipHostMalloc memory is mapped into the device's address space) -- one launch and one synchronisation, no copy engine round trips.
+    const bool direct = n <= kDirectRows;
+    if (direct) b = h;
+    else ACX_HIP_TRY(hipMemcpyAsync(b + o_in, h + o_in, h_action ? o_act + (size_t)n : (size_t)n * row, hipMemcpyHostToDevice, nullptr));
     rc = acx_move_batch_device((const int8_t*)(b + o_in), h_action ? b + o_act : nullptr, ACX_U8, n, L, flags, (int8_t*)(b + o_out),
                                (int32_t*)(b + o_len), b + o_err, h_fit ? (int32_t*)(b + o_fit) : nullptr, nullptr);
     if (rc) return rc;
-    ACX_HIP_TRY(hipMemcpyAsync(h + o_out, b + o_out, (h_fit ? total : o_fit) - o_out, hipMemcpyDeviceToHost, nullptr));
+    if (!direct) ACX_HIP_TRY(hipMemcpyAsync(h + o_out, b + o_out, (h_fit ? total : o_fit) - o_out, hipMemcpyDeviceToHost, nullptr));
     ACX_HIP_TRY(hipStreamSynchronize(nullptr));
     memcpy(h_out, h + o_out, (size_t)n * row);
     memcpy(h_len, h + o_len, (size_t)n * 8);
@@ -1074,7 +1081,9 @@ int acx_env_step_host(acx_env* e, const int64_t* h_actions, int8_t* h_obs, float
     uint8_t* h = step_staging(total);
     if (!h) return fail(ACX_E_NOMEM, "acx_env_step_host: hipHostMalloc(%zu) failed", total);
     memcpy(h + o_act, h_actions, (size_t)n * 8);
-    ACX_HIP_TRY(hipMemcpyAsync(b + o_act, h + o_act, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    const bool direct = n <= kDirectRows;  // (a few environments -- ACEnv.step on ONE: the kernels work on the pinned block, as acx_move_batch)
+    if (direct) b = h;
+    else ACX_HIP_TRY(hipMemcpyAsync(b + o_act, h + o_act, (size_t)n * 8, hipMemcpyHostToDevice, st));
     rc = acx_env_step(e, b + o_act, ACX_I64, b + o_obs, ACX_I8, (float*)(b + o_rew), 0.f, 0.f, b + o_done, b + o_trunc,
                       h_final_obs ? b + o_fin : nullptr, autoreset, st);
     if (rc) return rc;
@@ -1085,7 +1094,7 @@ int acx_env_step_host(acx_env* e, const int64_t* h_actions, int8_t* h_obs, float
         ACX_HIP_TRY(hipGetLastError());
     }
     const size_t first = h_obs || h_final_obs ? o_obs : o_rew;
-    ACX_HIP_TRY(hipMemcpyAsync(h + first, b + first, total - first, hipMemcpyDeviceToHost, st));
+    if (!direct) ACX_HIP_TRY(hipMemcpyAsync(h + first, b + first, total - first, hipMemcpyDeviceToHost, st));
     ACX_HIP_TRY(hipStreamSynchronize(st));
     if (h_obs) memcpy(h_obs, h + o_obs, (size_t)n * row);
     if (h_final_obs) memcpy(h_final_obs, h + o_fin, (size_t)n * row);

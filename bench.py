@@ -486,7 +486,7 @@ def extra_env_numbers(dev, pool):
             st, ln = ACMove(int(a), st, L, ln)
         move_us = (time.perf_counter() - t0) / 350 * 1e6
         out["single_call_surface"] = {"single_env_step_us": step_us, "acmove_call_us": move_us, "reference_step_us": 105.0, "reference_acmove_us": 34.0,
-                                      "note": "one environment per call: an upload, one launch, one read-back, one synchronisation (acx_env_step_host / "
+                                      "note": "one environment per call: one launch on the pinned staging block and one synchronisation (acx_env_step_host / "
                                               "acx_move_batch); reference figures measured in the build container (BASELINE.md)"}
         del e1
     except Exception as e:  # noqa: BLE001
