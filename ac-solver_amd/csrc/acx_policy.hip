@@ -14,9 +14,10 @@
 //   Weights: the whole fragment sequence of both networks (2 x 185 KB at 50 inputs) streams once per workgroup through a ring
 //   of six 17 KB LDS slots, filled by global_load_lds_dwordx4 five chunks ahead of the MFMAs that read them (counted vmcnt,
 //   raw s_barrier per chunk), shared by the eight waves.
-//   The heads leave the 12 logits / the value of an environment in two lanes (l and l + 32); one shuffle gathers them and
-//   lane l < 32 finishes: log-softmax, a Gumbel-max draw (counter-based hash of (seed, env, action): an exact sample of
-//   Categorical(softmax(logits))), log-probability, value.
+//   The heads leave the 12 logits / the value of an environment in two lanes (l and l + 32); each lane draws among the actions it holds
+//   (an exponential race on a counter-based hash of (seed, env, action): an exact sample of Categorical(softmax(logits))), the two
+//   combine their soft-max sums and winners with a few shuffles, and lane l < 32 stores action, log-probability and value.
+//   A workgroup walks tiles of 256 environments (one workgroup per compute unit); the weight stream carries on across tiles.
 // Arithmetic: bf16 inputs, weights and activations, f32 accumulation (the reference's policy is f32 torch: the test compares
 // with a torch f32 forward at bf16 tolerance and with a bf16-rounded emulation tightly).  Only inference: the PPO update
 // keeps torch autograd on the f32 master weights; FusedPolicy.refresh() re-packs them after every optimizer step.
@@ -89,17 +90,15 @@ template <int KS1> struct plan {
     static constexpr int first(int cc) { return cc < C1 ? cc * OPC * F1 : (cc < C1 + 8 ? 8 * F1 + (cc - C1) * 17 : 8 * F1 + 8 * 17); }
     static constexpr int obs_in(int cc) { return (cc + 1) * OPC < 8 ? OPC : 8 - cc * OPC; }
     static constexpr int count(int cc) { return cc < C1 ? obs_in(cc) * F1 : 17; }
-    // vmcnt that retires chunk c: every wave issues three loads per chunk (fragments w and w + 8, an eighth of fragment 16)
-    static constexpr int pending_after(int c) {
-        int n = 0;
-        for (int k = c + 1; k < C && k < c + kAhead; k++) n += 3;  // (c >= C - 1: nothing)
-        return n;
-    }
-    // Top of loop iteration c: chunks 0 .. min(c + kAhead, C) - 1 have been issued (chunk c + kAhead only goes out AFTER this wait
-    // and its barrier, into the slot chunk c - 1 leaves).  The running block reads the first fragments of chunk c + 1 before it
-    // ends, so chunk c + 1 must have landed: at most the loads of the chunks issued behind it may stay in flight.
-    static constexpr int issued_at_top(int c) { return c + kAhead < C ? c + kAhead : C; }
-    static constexpr int pending_at_top(int c) { return issued_at_top(c) > c + 2 ? 3 * (issued_at_top(c) - (c + 2)) : 0; }
+    // The weight stream is endless: behind a tile's last chunk comes chunk 0 of the workgroup's next tile (the same weights again; behind
+    // the last tile the loads are issued all the same and nobody reads them).  Every wave issues three loads per chunk (fragments w and
+    // w + 8, an eighth of fragment 16).  Top of loop iteration c: chunks .. c + kAhead - 1 have been issued (chunk c + kAhead only goes out
+    // AFTER this wait and its barrier, into the slot chunk c - 1 leaves).  The running block reads the first fragments of chunk c + 1
+    // before it ends, so chunk c + 1 must have landed: at most the loads of the kAhead - 2 chunks issued behind it may stay in flight.
+    // (A tile boundary waits for vmcnt(0): the epilogue's stores and the next tile's observation loads are not part of this count.)
+    static constexpr int pending_at_top = 3 * (kAhead - 2);
+    static constexpr int pending_first = 3 * (kAhead - 1);  // before the first tile: chunk 0 has landed
+    static_assert(kAhead >= 2, "the ring holds the running chunk, the next one and at least one in flight");
 };
 
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
@@ -140,43 +139,157 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];  // the fragment ring
     ACX_VGPR_PAD("v255");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, r = lane & 31u, h = lane >> 5;
-    const int64_t env = ((int64_t)blockIdx.x * kWaves + wave) * 32 + r;
+#ifdef ACX_POLICY_STAMP  // (the 100 MHz counter all compute units share: where a workgroup's life sits inside the launch)
+#define ACX_POLICY_WALL(k) do { if (wave == 0) logprob[n_env + 1024 + (size_t)blockIdx.x * 4 + (k)] = (float)(uint32_t)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFull); } while (0)
+#else
+#define ACX_POLICY_WALL(k) do { } while (0)
+#endif
+    ACX_POLICY_WALL(0);
+    // A workgroup walks the tiles of 256 environments blockIdx.x, blockIdx.x + gridDim.x, ... (the launch has one workgroup per compute
+    // unit): the weight stream runs on across the tile boundary, and the next tile's observations are loaded behind the sampling of the
+    // running one -- a second round of workgroups paid the wave launches, the ring's first fill and the observation loads again (5 us
+    // before its first MFMA; round 6 measured it with the chip's 100 MHz counter, tools/policy_stamps.py).
+    const int64_t tiles = (n_env + 32 * kWaves - 1) / (32 * kWaves);
+    int64_t env = ((int64_t)blockIdx.x * kWaves + wave) * 32 + r;
     const uint32_t ring = (uint32_t)(uintptr_t)s_mem;  // LDS byte address (low half of the flat address)
-    // B operand of layer 1: the lane's environment, inputs 16 ks + 8 h .. + 7 (zero beyond in_dim / n_env)
-    frag_ab x[KS1];
+    // The observations of a tile are one contiguous block of the observation matrix (256 rows): it is loaded as such -- every lane four
+    // consecutive elements per step, a wave 1 KB (f32) or 256 B (int8 rows, what acx_env_step writes with ACX_I8) per instruction --
+    // rounded to bf16 and kept behind the ring as a plain copy [256][in_dim]; the B operand of layer 1 (the lane's environment, inputs
+    // 16 ks + 8 h .. + 7, zero beyond in_dim) is read from there behind the barrier of the tile's first chunk.  Rounds 2-6 had every lane
+    // load its own 8 KS1 elements: 32-40 instructions of 64 different cache lines each, 3.3 us per tile in the address path (measured with
+    // the chip's 100 MHz counter, tools/policy_stamps.py).  Load and conversion are two steps: the loads of the next tile stay in flight
+    // across the sampling epilogue.
+    constexpr int NI = 2 * KS1;  // steps: 256 rows x in_dim <= 256 x 16 KS1 elements = 2048 per step x 2 KS1
+    unsigned short* s_obs = (unsigned short*)(s_mem + kRing * kSlotBytes);
+    constexpr uint32_t kObsZero = 256u * 16u * (uint32_t)KS1;  // a bf16 zero behind the copy: what the inputs beyond in_dim read
+    if (tid == 0) *(uint32_t*)(s_obs + kObsZero) = 0;
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4a;
+    uint32_t raw[4 * NI];
+    auto load_obs = [&](int64_t tile_, bool live) {
+        int width = in_dim;
+        asm volatile("" : "+s"(width));  // (made here, not once for all tiles: what hangs on it would be hoisted out of the tile loop)
+        const int64_t g0 = tile_ * (32 * kWaves) * width, total = n_env * (int64_t)width;
+        const bool vec = obs_i8 ? ((uintptr_t)obs_any & 3u) == 0 : ((uintptr_t)obs_any & 15u) == 0;  // (uniform)
 #pragma unroll
-    for (int ks = 0; ks < KS1; ks++)
+        for (int i = 0; i < NI; i++) {
+            const uint32_t idx = 4u * tid + 2048u * (uint32_t)i;
+            const int64_t g = g0 + idx;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int k = 16 * ks + 8 * (int)h + j;
-            float o = 0.0f;  // (int8 observations -- what acx_env_step writes with ACX_I8 -- are a quarter of the bytes of the f32 rows)
-            if (env < n_env && k < in_dim) o = obs_i8 ? (float)((const int8_t*)obs_any)[env * in_dim + k] : ((const float*)obs_any)[env * in_dim + k];
-            x[ks][j] = (short)bf16_of(o);
+            for (int e = 0; e < 4; e++) raw[4 * i + e] = 0;
+            if (!live || idx >= (uint32_t)(32 * kWaves * width)) continue;
+            if (obs_i8) {  // four int8 elements in raw[4 i]
+                const int8_t* p8 = (const int8_t*)obs_any + g;
+                if (vec && g + 3 < total) raw[4 * i] = *(const uint32_t*)p8;
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (g + e < total) raw[4 * i] |= (uint32_t)(uint8_t)p8[e] << (8 * e);
+            } else {
+                const float* pf = (const float*)obs_any + g;
+                if (vec && g + 3 < total) {
+                    const u32x4a v = *(const u32x4a*)pf;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) raw[4 * i + e] = v[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (g + e < total) raw[4 * i + e] = __float_as_uint(pf[e]);
+                }
+            }
         }
+    };
+    auto stage_obs = [&]() {  // raw -> bf16 -> the copy in LDS (rows beyond n_env: zeros)
+        int width = in_dim;
+        asm volatile("" : "+s"(width));
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const uint32_t idx = 4u * tid + 2048u * (uint32_t)i;
+            if (idx >= (uint32_t)(32 * kWaves * width)) continue;
+            float f[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) f[e] = obs_i8 ? (float)(int32_t)(int8_t)(raw[4 * i] >> (8 * e)) : __uint_as_float(raw[4 * i + e]);
+            uint2 pk;
+            pk.x = pack_bf16(f[0], f[1]);
+            pk.y = pack_bf16(f[2], f[3]);
+            *(uint2*)(s_obs + idx) = pk;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the hand-written barriers of this kernel wait for nothing themselves)
+    };
+    frag_ab x[KS1];
+    auto read_obs = [&]() {  // behind a barrier that follows stage_obs
+        int width = in_dim;
+        asm volatile("" : "+s"(width));
+        const uint32_t row = (wave * 32u + r) * (uint32_t)width;
+        if ((width & 1) == 0) {  // (uniform; 2 x max_relator_length is even) two inputs per 32-bit read: a pair lies inside the row or beyond it
+            const uint32_t* s_obs2 = (const uint32_t*)s_obs;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++) {
+                u32x4a v;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t k = 16u * (uint32_t)ks + 8u * h + 2u * (uint32_t)q;
+                    v[q] = s_obs2[k < (uint32_t)width ? (row + k) >> 1 : kObsZero >> 1];
+                }
+                x[ks] = __builtin_bit_cast(frag_ab, v);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t k = 16u * (uint32_t)ks + 8u * h + (uint32_t)j;
+                    x[ks][j] = (short)s_obs[k < (uint32_t)width ? row + k : kObsZero];
+                }
+        }
+    };
+    load_obs(blockIdx.x, true);
+    stage_obs();
     frag_ab ones;
 #pragma unroll
     for (int j = 0; j < 8; j++) ones[j] = (h == 0 && j < 2) ? (short)0x3F80 : (short)0;
 
-    const frag_ab* src_w[2] = {actor + wave * 64 + lane, critic + wave * 64 + lane};  // fragment `wave` of a chunk, this lane's 16 bytes
-    const frag_ab* src_l[2] = {actor + lane, critic + lane};                              // fragment 0 of a chunk, this lane's 16 bytes
+    // Every second workgroup of an XCD (workgroups go to the eight XCDs in turn) runs the critic first: the compute units of an XCD stay
+    // in step with each other, and all of them pulling the same 17 KB of weights through the same L2 channels at the same moment is what
+    // the streaming costs -- with two orders, two address streams are in flight at any time.
+    const bool critic_first = ((blockIdx.x >> 3) & 1u) != 0;  // (uniform)
+    const frag_ab* net0 = critic_first ? critic : actor;
+    const frag_ab* net1 = critic_first ? actor : critic;
+    const frag_ab* src_w[2] = {net0 + wave * 64 + lane, net1 + wave * 64 + lane};  // fragment `wave` of a chunk, this lane's 16 bytes
+    const frag_ab* src_l[2] = {net0 + lane, net1 + lane};                            // fragment 0 of a chunk, this lane's 16 bytes
     const uint32_t ring_w = __builtin_amdgcn_readfirstlane(ring + wave * 1024u);
     auto uniform64 = [](unsigned long long v) {  // (the EXEC masks must live in scalar registers)
         return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)v);
     };
     const unsigned long long all = uniform64(~0ull), none = uniform64(0ull);
     const unsigned long long eighth = uniform64(0xFFull << (8u * wave));
-    auto issue = [&](auto ic) {  // chunk c of the stream -> ring slot c % kRing
+    // Ring slot of the running tile's chunk 0 (uniform).  A tile's chunks take consecutive slots and the next tile carries on behind them,
+    // so chunk c of the stream (c >= P::C: chunk c - P::C of the NEXT tile, the same weights again) sits in slot (slot0 + c) % kRing.
+    uint32_t slot0 = 0;
+    auto slot_bytes = [&](int c) -> uint32_t {  // (c is a compile-time constant at every call: one scalar add and compare)
+        uint32_t s0 = slot0;
+        asm volatile("" : "+s"(s0));  // (recomputed at every use: hoisted to the top of a tile the slot addresses of all chunks would spill)
+        const uint32_t sl = s0 + (uint32_t)(c % kRing);
+        return __builtin_amdgcn_readfirstlane((sl >= (uint32_t)kRing ? sl - (uint32_t)kRing : sl) * (uint32_t)kSlotBytes);
+    };
+    auto issue = [&](auto ic) {  // chunk c of the stream -> its ring slot
         constexpr int c = decltype(ic)::value;
-        constexpr int cc = c % P::CN, cnt = P::count(cc), slot = c % kRing, net = c < P::CN ? 0 : 1;
+        constexpr int cc = (c % P::C) % P::CN, cnt = P::count(cc), net = (c % P::C) < P::CN ? 0 : 1;
         constexpr size_t first = (size_t)P::first(cc) * 64;
-        glds16(src_w[net] + first, ring_w + slot * kSlotBytes, all);
-        glds16(src_w[net] + first + 8 * 64, ring_w + slot * kSlotBytes + 8 * 1024, cnt >= 16 ? all : uniform64(wave + 8 < (uint32_t)cnt ? ~0ull : 0ull));
-        glds16(src_l[net] + first + 16 * 64, __builtin_amdgcn_readfirstlane(ring + slot * kSlotBytes + 16 * 1024), cnt == 17 ? eighth : none);
+        const uint32_t sb = slot_bytes(c);
+        // (the source addresses are made HERE, from pointers the optimiser cannot see through: inside the tile loop they are loop
+        // invariants, and hoisted out of it -- fifty 64-bit values -- they would live in scratch memory)
+        const frag_ab* pw = src_w[net];
+        const frag_ab* pl = src_l[net];
+        asm volatile("" : "+v"(pw), "+v"(pl));
+        glds16(pw + first, ring_w + sb, all);
+        glds16(pw + first + 8 * 64, ring_w + sb + 8 * 1024, cnt >= 16 ? all : uniform64(wave + 8 < (uint32_t)cnt ? ~0ull : 0ull));
+        glds16(pl + first + 16 * 64, __builtin_amdgcn_readfirstlane(ring + sb + 16 * 1024), cnt == 17 ? eighth : none);
     };
     static_for<0, kAhead>(issue);
 
 #ifdef ACX_POLICY_STAMP
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    ACX_POLICY_WALL(1);
 #endif
     frag_ab hb1[16], hb2[16];  // tanh outputs of layers 1 and 2 as B operands (k-step 2 ob + half <- accumulator registers 8 half ..)
     frag_cd pend;              // accumulator of the previous output block: its tanh is spread among this block's MFMAs
@@ -200,6 +313,10 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __
         constexpr int UT = (NM & 1) && U > 1 ? U - 1 : U;  // the units that carry tanh work (an odd block's last MFMA may consume out_hi)
         static_for<0, U>([&](auto uu) {
             constexpr int u = decltype(uu)::value;
+            if constexpr (u == U - 1) {  // the next block's first fragments: on their way before the block's last MFMAs, not behind them
+#pragma unroll
+                for (int i = 0; i < kFragAhead && i < NMN; i++) apre[i] = Snext[i * 64];
+            }
             static_for<2 * u, (2 * u + 2 < NM ? 2 * u + 2 : NM)>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
 #ifdef ACX_POLICY_NO_LDS_READ  // timing experiment only (wrong numbers): every MFMA reuses the block's first fragments -- what the LDS reads cost
@@ -233,39 +350,36 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __
                     if (q == 7) out_hi = __builtin_bit_cast(frag_ab, hi);
                 }
             }
-            if constexpr (u == U - 1) {
-#pragma unroll
-                for (int i = 0; i < kFragAhead && i < NMN; i++) apre[i] = Snext[i * 64];
-            }
             __builtin_amdgcn_sched_barrier(0);
         });
         return acc;
     };
     frag_ab unused_lo, unused_hi;
     // chunk 0 has landed (for everyone: barrier) -> its first fragments
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(P::pending_after(0)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(P::pending_first) : "memory");
 #pragma unroll
     for (int i = 0; i < kFragAhead && i < P::F1; i++) apre[i] = ((const frag_ab*)s_mem + lane)[i * 64];
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     static_for<0, P::C>([&](auto ic) {
         constexpr int c = decltype(ic)::value;
-        constexpr int net = c / P::CN, cc = c % P::CN, slot = c % kRing;
-        constexpr int ccn = (c + 1) % P::CN, nm_of_next_chunk = c + 1 >= P::C ? 0 : (ccn < P::C1 ? P::F1 : 17);
+        constexpr int net = c / P::CN, cc = c % P::CN;
+        constexpr int ccn = (c + 1) % P::CN, nm_of_next_chunk = ccn < P::C1 ? P::F1 : 17;  // (behind the tile's last chunk: the next tile's first block)
         // chunk c + 1 has landed for this wave's own loads ... and, behind the barrier, for everyone's (the running block reads its
         // first fragments before it ends); chunk c - 1 is consumed, so its slot takes chunk c + kAhead
-        static_assert(P::issued_at_top(c) - P::pending_at_top(c) / 3 >= (c + 2 < P::C ? c + 2 : P::C), "chunk c + 1 must have landed behind this wait");
 #ifdef ACX_POLICY_NO_BARRIER  // timing experiment only (races on the ring): what the per-chunk workgroup barrier costs
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P::pending_at_top(c)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P::pending_at_top) : "memory");
 #else
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(P::pending_at_top(c)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(P::pending_at_top) : "memory");
 #endif
 #ifdef ACX_POLICY_STAMP  // diagnostic build: shader-clock stamp per chunk into the (over-allocated) logprob buffer
-        logprob[n_env + (blockIdx.x & 1) * 512 + wave * 64 + c] = (float)(long long)(__builtin_amdgcn_s_memtime() - t_start);  // (no branch: all lanes store the same word)
+        logprob[n_env + (blockIdx.x & 1) * 512 + wave * 64 + (tile >= (int64_t)gridDim.x ? 30 : 0) + c] = (float)(long long)(__builtin_amdgcn_s_memtime() - t_start);  // (no branch: all lanes store the same word)
 #endif
 #ifndef ACX_POLICY_NO_STREAM  // (timing experiment only when defined: the weights are not streamed beyond the ring's first fill)
-        if constexpr (c + kAhead < P::C) issue(std::integral_constant<int, c + kAhead>{});
+        issue(std::integral_constant<int, c + kAhead>{});
 #endif
-        const frag_ab* S = (const frag_ab*)(s_mem + slot * kSlotBytes) + lane;
-        const frag_ab* Sn = (const frag_ab*)(s_mem + ((c + 1) % kRing) * kSlotBytes) + lane;  // first block of the next chunk
+        if constexpr (c == 0) read_obs();  // (the tile's observations: staged before this chunk's barrier)
+        const frag_ab* S = (const frag_ab*)(s_mem + slot_bytes(c)) + lane;
+        const frag_ab* Sn = (const frag_ab*)(s_mem + slot_bytes(c + 1)) + lane;  // first block of the next chunk
         if constexpr (cc < P::C1) {  // ---- layer 1: a few output blocks per chunk
             static_for<0, P::obs_in(cc)>([&](auto kk) {
                 constexpr int k = decltype(kk)::value, ob = cc * P::OPC + k;
@@ -288,65 +402,83 @@ __global__ void __launch_bounds__(64 * kWaves, 2) k_policy_sample(const void* __
                               [&](auto ks) { return hb2[decltype(ks)::value]; }, true, hb2[14], hb2[15]);
         }
     });
-    const frag_cd& logit = head[0];
-    const frag_cd& val = head[1];
-    {
-        // Head output a of an environment sits in lane half (a >> 2) & 1, register (a & 3) + 4 (a >> 3).  Lane half h draws for the eight
-        // actions 8 h .. 8 h + 7: four of them are its own registers, four its partner's (lane ^ 32) -- one shuffle each; the soft-max's
-        // maximum and sum are taken over the lane's eight and combined with the partner's (round 6: the sixteen outputs used to be gathered
-        // into an array that both halves indexed by h, which the compiler kept in scratch memory).
-        float mine[8];  // logit of action 8 h + k
+    float logit[8];  // (the actor's head: the network that ran first or second)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float other_lo = __shfl_xor(logit[k], 32), other_hi = __shfl_xor(logit[4 + k], 32);
-            mine[k] = h ? other_hi : logit[k];          // action 8 h + k lives in half 0: registers k (h = 0: my own) and 4 + k (h = 1: the partner's)
-            mine[4 + k] = h ? logit[4 + k] : other_lo;  // action 8 h + 4 + k lives in half 1
-        }
+    for (int k = 0; k < 8; k++) logit[k] = critic_first ? head[1][k] : head[0][k];
+    const float val0 = critic_first ? head[0][0] : head[1][0];
+    ACX_POLICY_WALL(2);
+    // the next tile's observations start their trip now and are looked at behind the sampling (no tile left: no load goes out)
+    const int64_t env_next = env + (int64_t)gridDim.x * (32 * kWaves);
+    load_obs(tile + gridDim.x, tile + gridDim.x < tiles);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        // Head output a of an environment sits in lane half (a >> 2) & 1, register (a & 3) + 4 (a >> 3): a lane draws for the eight actions
+        // its own registers hold -- no shuffle per logit (rounds 2-6 gave half h the actions 8 h .. 8 h + 7 and fetched half of them from
+        // the partner lane) -- and the halves combine the soft-max's maximum and sum and, at the end, their winners.
+        // The draw is an exponential race: argmin over a of E_a / w_a with E_a = -ln u_a i.i.d. Exp(1) and w_a = exp(logit_a - max) is an
+        // exact sample of Categorical(softmax(logits)) (the same law as the Gumbel-max of rounds 2-6 without its two logarithms per action:
+        // w_a is the soft-max's own term).  Transcendentals as the bare instructions (v_exp_f32 / v_log_f32 are base 2; every argument
+        // here is a normal number, so none of the denormal handling of expf / logf is needed).
+        constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+        bool valid[8];
         float mx = -3.0e38f;
 #pragma unroll
-        for (int k = 0; k < 8; k++) mx = 8 * (int)h + k < n_actions ? fmaxf(mx, mine[k]) : mx;
+        for (int k = 0; k < 8; k++) {
+            valid[k] = (k & 3) + 4 * (int)h + 8 * (k >> 2) < n_actions;
+            mx = valid[k] ? fmaxf(mx, logit[k]) : mx;
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; k++) sum += 8 * (int)h + k < n_actions ? __expf(mine[k] - mx) : 0.0f;
-        sum += __shfl_xor(sum, 32);
-        const float lse = mx + __logf(sum);
-        int best = 0;
-        float best_score = -3.0e38f, best_lp = 0.0f;
-        // Gumbel-max with a counter-based 32-bit hash (two rounds of the murmur3 finaliser over (env, action), keyed by both seed
-        // halves): cheap next to the 64-bit multiplies of mix64, which were a tenth of the kernel
-        const uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
+        float w[8], sum = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int a = 8 * (int)h + k;
-            const float lga = mine[k];
-            const uint32_t bits = fmix32(fmix32(((uint32_t)env * 16u + (uint32_t)a) ^ s_lo) + s_hi + (uint32_t)(env >> 28));
+            w[k] = valid[k] ? __builtin_amdgcn_exp2f((logit[k] - mx) * kLog2e) : 0.0f;
+            sum += w[k];
+        }
+        sum += __shfl_xor(sum, 32);
+        const float ln_sum = __builtin_amdgcn_logf(sum) * kLn2;
+        // counter-based uniforms: one hash of (seed, environment) -- two rounds of the murmur3 finaliser, keyed by both seed halves -- and
+        // one more round per action (32-bit multiplies are quarter rate: rounds 2-6 spent four per action)
+        const uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
+        const uint32_t base = fmix32(fmix32((uint32_t)env ^ s_lo) + s_hi + (uint32_t)(env >> 32));
+        int best = 0;
+        float best_t = 3.0e38f, best_lp = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int a = (k & 3) + 4 * (int)h + 8 * (k >> 2);
+            const uint32_t bits = fmix32(base + (uint32_t)(a + 1) * 0x9E3779B9u);
             // 23 random bits: (k + 0.5) * 2^-23 is exact in f32 for every k < 2^23, so u stays strictly inside (0, 1)
-            // (with 24 bits k + 0.5 rounds to 2^24 for the largest k: u = 1, an infinite Gumbel score, once per 2^24 draws)
             const float u = ((float)(bits >> 9) + 0.5f) * (1.0f / 8388608.0f);
-            const float lp = lga - lse;
-            const float score = lp - __logf(-__logf(u));
-            if (a < n_actions && score > best_score) {
-                best_score = score;
+            const float t = -__builtin_amdgcn_logf(u) * __builtin_amdgcn_rcpf(w[k]);  // (w = 0: an action of probability < 1e-38, or none: infinite)
+            if (valid[k] && t < best_t) {  // (the lane's own actions in rising order: a tie keeps the lower one)
+                best_t = t;
                 best = a;
-                best_lp = lp;
+                best_lp = (logit[k] - mx) - ln_sum;
             }
         }
-        const float o_score = __shfl_xor(best_score, 32), o_lp = __shfl_xor(best_lp, 32);
+        const float o_t = __shfl_xor(best_t, 32), o_lp = __shfl_xor(best_lp, 32);
         const int o_best = __shfl_xor(best, 32);
-        if (o_score > best_score || (o_score == best_score && o_best < best)) {  // (ties: the lower action, as a scan in action order would)
+        if (o_t < best_t || (o_t == best_t && o_best < best)) {  // (ties: the lower action, as a scan in action order would)
             best = o_best;
             best_lp = o_lp;
         }
         if (h == 0 && env < n_env) {
             action[env] = best;
             logprob[env] = best_lp;
-            value[env] = val[0];
+            value[env] = val0;
         }
 #ifdef ACX_POLICY_STAMP
-        logprob[n_env + (blockIdx.x & 1) * 512 + wave * 64 + 63] = (float)(long long)(__builtin_amdgcn_s_memtime() - t_start);
+        ACX_POLICY_WALL(3);
+        logprob[n_env + (blockIdx.x & 1) * 512 + wave * 64 + (tile >= (int64_t)gridDim.x ? 63 : 29)] = (float)(long long)(__builtin_amdgcn_s_memtime() - t_start);
 #endif
     }
+    __builtin_amdgcn_sched_barrier(0);
+    env = env_next;
+    stage_obs();  // (every wave read the running tile's copy behind the barrier of chunk 0, twenty barriers ago)
+    slot0 = __builtin_amdgcn_readfirstlane((slot0 + (uint32_t)(P::C % kRing)) % (uint32_t)kRing);
+    // everything this wave has in flight -- the stores above and the ring's next chunks, issued up to kAhead ago -- is through before the
+    // counted waits of the next tile start from zero
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }  // tiles
 }
 
 }  // namespace policy
@@ -365,8 +497,15 @@ extern "C" int acx_policy_sample(const void* d_obs, int obs_dtype, int64_t n_env
     const int ks1 = (in_dim + 15) / 16;
     const policy::frag_ab* a = (const policy::frag_ab*)d_actor;
     const policy::frag_ab* c = (const policy::frag_ab*)d_critic;
-    const dim3 grid((unsigned)((n_env + 32 * policy::kWaves - 1) / (32 * policy::kWaves))), block(64 * policy::kWaves);
-    const size_t lds = (size_t)policy::kRing * policy::kSlotBytes;
+    const int64_t tiles = (n_env + 32 * policy::kWaves - 1) / (32 * policy::kWaves);
+    static int cus = 0;  // (a workgroup fills a compute unit: 255 registers per lane, 102 KB of LDS)
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        cus = n > 0 ? n : 256;
+    }
+    const dim3 grid((unsigned)(tiles < cus ? tiles : cus)), block(64 * policy::kWaves);
+    const size_t lds = (size_t)policy::kRing * policy::kSlotBytes + (size_t)256 * 16 * ks1 * 2 + 16;  // the fragment ring, the tile's observations as bf16
     hipStream_t st = (hipStream_t)stream;
 #define ACX_POLICY_LAUNCH(KS)                                                                                                                        \
     ACX_HIP_TRY(hipFuncSetAttribute((const void*)policy::k_policy_sample<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \

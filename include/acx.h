@@ -334,7 +334,7 @@ int acx_shard_check_owners(acx_shard *h, int64_t *n_bad, void *stream);
 /* ---- PPO rollout: fused policy inference ---------------------------------------------------------------
  * The agent of ac_solver/agents/ppo_agent.py:11-109 -- actor and critic, each in_dim -> 256 -> 256 -> {n_actions, 1} with
  * tanh -- evaluated on n_env observations and sampled, in ONE kernel on the matrix cores (bf16 operands, f32 accumulation):
- * d_action[e] ~ Categorical(softmax(actor(obs[e]))) (Gumbel-max with a counter-based hash of (seed, e, action): pass a
+ * d_action[e] ~ Categorical(softmax(actor(obs[e]))) (an exponential race on a counter-based hash of (seed, e, action): pass a
  * fresh seed per call), d_logprob[e] its log-probability, d_value[e] = critic(obs[e]).  d_obs [n_env, in_dim] row-major, obs_dtype
  * ACX_F32 or ACX_I8 (what acx_env_step writes with either; the int8 rows are a quarter of the bytes).  d_actor / d_critic: the networks packed by
  * ac_solver/agents/fused_policy.py:pack_network (acx_policy_packed_bytes(in_dim) bytes each).  in_dim <= 80,

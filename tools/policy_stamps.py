@@ -13,14 +13,28 @@ agent = Agent(SimpleNamespace(single_observation_space=SimpleNamespace(shape=(in
 fp = FusedPolicy(agent, in_dim)
 obs = torch.randint(-2, 3, (n, in_dim), device=dev).float()
 act = torch.zeros(n, dtype=torch.int64, device=dev)
-logp, val = torch.zeros(n + 1024, device=dev), torch.zeros(n, device=dev)
+logp, val = torch.zeros(n + 1024 + 4 * 512, device=dev), torch.zeros(n, device=dev)
 for _ in range(20):
     fp.sample(obs, act, logp, val)
 torch.cuda.synchronize()
 st = logp[n + 512:n + 512 + 8 * 64].view(8, 64).cpu()  # a block with odd index
-for w in (0, 1, 4, 7):
+for w in (0, 4, 7):
     row = st[w]
-    print("wave", w, "stamps:", [int(x) for x in row[:22]], "end", int(row[63]))
-    d = [int(row[i + 1] - row[i]) for i in range(21)]
-    print("   deltas:", d)
+    for t, (lo, end) in enumerate(((0, 29), (30, 63))):  # a workgroup's first and second tile of 256 environments
+        print("wave", w, "tile", t, "stamps:", [int(x) for x in row[lo:lo + 26]], "end", int(row[end]))
+        print("   deltas:", [int(row[lo + i + 1] - row[lo + i]) for i in range(25)])
 
+
+# where the workgroups sit inside the launch (100 MHz counter shared by the chip): entry, observations loaded, heads done, end
+wall = logp[n + 1024:n + 1024 + 4 * (n // 256)].view(-1, 4).cpu().double()
+t0 = wall[:, 0].min()
+wall = (wall - t0) * 0.01  # microseconds
+import numpy as np
+w = wall.numpy()
+order = np.argsort(w[:, 0])
+print("workgroups by entry time (us): entry / obs loaded / heads done / end")
+for i in list(order[:4]) + list(order[254:260]) + list(order[-3:]):
+    print(f"  wg {i:4d}: " + " ".join(f"{v:7.2f}" for v in w[i]))
+print("first round (256 earliest): entry", w[order[:256], 0].min(), "..", w[order[:256], 0].max(), " end", w[order[:256], 3].min(), "..", w[order[:256], 3].max())
+print("second round: entry", w[order[256:], 0].min(), "..", w[order[256:], 0].max(), " end", w[order[256:], 3].min(), "..", w[order[256:], 3].max())
+print("obs load (entry -> loaded) median", np.median(w[:, 1] - w[:, 0]), " epilogue median", np.median(w[:, 3] - w[:, 2]), " body median", np.median(w[:, 2] - w[:, 1]))
