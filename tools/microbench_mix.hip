@@ -11,7 +11,7 @@ typedef __attribute__((ext_vector_type(16))) float frag_cd;
 #define EXP(r) asm volatile("v_exp_f32 %0, %0" : "+v"(r))
 #define RCP(r) asm volatile("v_rcp_f32 %0, %0" : "+v"(r))
 
-template <int K, int KIND, int CH> __global__ void __launch_bounds__(512) k_mix(int n, unsigned long long* out, float* sink) {
+template <int K, int KIND, int CH, int AG> __global__ void __launch_bounds__(512) k_mix(int n, unsigned long long* out, float* sink) {
     frag_ab a, b;
     for (int j = 0; j < 8; j++) {
         a[j] = (short)(threadIdx.x + j);
@@ -28,7 +28,8 @@ template <int K, int KIND, int CH> __global__ void __launch_bounds__(512) k_mix(
     for (int i = 0; i < n; i++) {
 #pragma unroll
         for (int c = 0; c < CH; c++) {
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[c], 0, 0, 0);
+            if (AG) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[c]) : "v"(a), "v"(b));  // accumulator in the AccVGPR half
+            else acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[c], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < K; j++) {
@@ -51,17 +52,17 @@ template <int K, int KIND, int CH> __global__ void __launch_bounds__(512) k_mix(
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
 
-template <int K, int KIND, int CH> void run(int waves_per_simd) {
+template <int K, int KIND, int CH, int AG = 0> void run(int waves_per_simd) {
     const int n = 1000;
     unsigned long long* d;
     float* sink;
     hipMalloc(&d, 256 * 16 * 8);
     hipMalloc(&sink, 4);
-    for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL((k_mix<K, KIND, CH>), dim3(256), dim3(256 * waves_per_simd), 0, 0, n, d, sink);
+    for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL((k_mix<K, KIND, CH, AG>), dim3(256), dim3(256 * waves_per_simd), 0, 0, n, d, sink);
     hipDeviceSynchronize();
     unsigned long long h[8];
     hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-    printf("chains %d, waves/SIMD %d, %2d %s per MFMA: %6.1f ticks per MFMA and SIMD\n", CH, waves_per_simd, K, KIND ? "tanh-mix instructions" : "v_fma_f32            ",
+    printf("%schains %d, waves/SIMD %d, %2d %s per MFMA: %6.1f ticks per MFMA and SIMD\n", AG ? "AccVGPR accumulators, " : "", CH, waves_per_simd, K, KIND ? "tanh-mix instructions" : "v_fma_f32            ",
            (double)h[0] / ((double)n * CH * waves_per_simd));
     hipFree(d);
     hipFree(sink);
@@ -84,5 +85,11 @@ int main() {
     }
     sweep<0, 2>(1);
     sweep<1, 2>(1);
+    run<0, 1, 1, 1>(2);
+    run<4, 1, 1, 1>(2);
+    run<8, 1, 1, 1>(2);
+    run<12, 1, 1, 1>(2);
+    run<8, 0, 1, 1>(2);
+    run<16, 0, 1, 1>(2);
     return 0;
 }

@@ -25,16 +25,14 @@ for w in (0, 4, 7):
         print("   deltas:", [int(row[lo + i + 1] - row[lo + i]) for i in range(25)])
 
 
-# where the workgroups sit inside the launch (100 MHz counter shared by the chip): entry, observations loaded, heads done, end
-wall = logp[n + 1024:n + 1024 + 4 * (n // 256)].view(-1, 4).cpu().double()
-t0 = wall[:, 0].min()
-wall = (wall - t0) * 0.01  # microseconds
+# where the workgroups sit inside the launch (100 MHz counter shared by the chip): entry, first tile staged, heads of the last tile done, end
 import numpy as np
-w = wall.numpy()
+n_wg = min(n // 256, torch.cuda.get_device_properties(0).multi_processor_count)
+w = logp[n + 1024:n + 1024 + 4 * n_wg].view(-1, 4).cpu().double().numpy()
+w = (w - w[:, 0].min()) * 0.01  # microseconds
 order = np.argsort(w[:, 0])
-print("workgroups by entry time (us): entry / obs loaded / heads done / end")
-for i in list(order[:4]) + list(order[254:260]) + list(order[-3:]):
+print("workgroups by entry time (us): entry / first tile staged / last heads done / end")
+for i in list(order[:3]) + list(order[-3:]):
     print(f"  wg {i:4d}: " + " ".join(f"{v:7.2f}" for v in w[i]))
-print("first round (256 earliest): entry", w[order[:256], 0].min(), "..", w[order[:256], 0].max(), " end", w[order[:256], 3].min(), "..", w[order[:256], 3].max())
-print("second round: entry", w[order[256:], 0].min(), "..", w[order[256:], 0].max(), " end", w[order[256:], 3].min(), "..", w[order[256:], 3].max())
-print("obs load (entry -> loaded) median", np.median(w[:, 1] - w[:, 0]), " epilogue median", np.median(w[:, 3] - w[:, 2]), " body median", np.median(w[:, 2] - w[:, 1]))
+print(f"{n_wg} workgroups: entry {w[:, 0].min():.2f} .. {w[:, 0].max():.2f}, end {w[:, 3].min():.2f} .. {w[:, 3].max():.2f};"
+      f" entry -> staged median {np.median(w[:, 1] - w[:, 0]):.2f}, sampling epilogue median {np.median(w[:, 3] - w[:, 2]):.2f}")
