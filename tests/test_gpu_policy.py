@@ -44,7 +44,8 @@ def _emulate(seq, x):
     return h
 
 
-@pytest.mark.parametrize("in_dim,n_act,n", [(50, 12, 4099), (72, 12, 1000), (14, 12, 33), (80, 16, 257), (3, 2, 64)])
+# (more than 65 536 environments: a workgroup walks several tiles of 256, the last one ragged; odd widths read the staged rows 16 bits at a time)
+@pytest.mark.parametrize("in_dim,n_act,n", [(50, 12, 4099), (72, 12, 1000), (14, 12, 33), (80, 16, 257), (3, 2, 64), (72, 12, 70001), (51, 12, 131333)])
 def test_fused_policy_matches_torch(in_dim, n_act, n):
     import torch
 
@@ -115,6 +116,32 @@ def test_int8_observations_give_the_same_outputs():
         a = torch.zeros(n, dtype=torch.int64, device="cuda")
         lp, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
         fp.sample(o.contiguous(), a, lp, v)
+        outs.append((a.clone(), lp.clone(), v.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "int8"])
+def test_observation_rows_at_any_address(dtype):
+    """the kernel loads a tile's observations four elements at a time when the matrix starts on a 16-byte (int8: 4-byte) boundary and
+    element by element otherwise: the same outputs from a copy that starts one element off"""
+    import torch
+
+    from ac_solver.agents.fused_policy import FusedPolicy
+
+    n, in_dim = 66001, 50
+    agent = _agent(in_dim, 12, 33)
+    dt = getattr(torch, dtype)
+    obs = torch.randint(-2, 3, (n, in_dim), device="cuda").to(dt)
+    shifted = torch.zeros(n * in_dim + 1, dtype=dt, device="cuda")[1:].view(n, in_dim)
+    shifted.copy_(obs)
+    assert shifted.data_ptr() % 4 != 0 if dtype == "int8" else shifted.data_ptr() % 16 != 0
+    outs = []
+    for o in (obs, shifted):
+        fp = FusedPolicy(agent, in_dim, seed=4)
+        a = torch.zeros(n, dtype=torch.int64, device="cuda")
+        lp, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        fp.sample(o, a, lp, v)
         outs.append((a.clone(), lp.clone(), v.clone()))
     for x, y in zip(*outs):
         assert torch.equal(x, y)
