@@ -1,5 +1,7 @@
 """Shared driver for bfs / greedy_search: hands the presentation to libacx's device frontier."""
 import ctypes as C
+import gc
+import threading
 
 import numpy as np
 
@@ -65,6 +67,18 @@ def run_search(kind, presentation, max_nodes_to_explore, cyclical, want_stats=Fa
     return bool(solved.value), path, stats
 
 
+_path_io = threading.local()
+
+
+def _path_buffers(n, path_cap):
+    """the (n, path_cap) int32 arrays the library writes the paths into, kept per thread between calls of the same shape: a search writes a
+    few hundred entries at the start of its 16 KB row, so fresh arrays cost a page fault per row and array (2 400 for a sweep: 3-4 ms)"""
+    held = getattr(_path_io, "held", None)
+    if held is None or held[0] != (n, path_cap):
+        held = _path_io.held = ((n, path_cap), np.empty((n, path_cap), np.int32), np.empty((n, path_cap), np.int32))
+    return held[1], held[2]
+
+
 def run_search_many(kind, presentations, max_nodes_to_explore, cyclical, n_threads=16, path_cap=4096):
     """Independent searches on one GPU, overlapped (acx_search_many).  `presentations` [n, 2L].
     -> list of (solved, path, stats) in input order, each identical to what run_search returns."""
@@ -74,8 +88,7 @@ def run_search_many(kind, presentations, max_nodes_to_explore, cyclical, n_threa
     L = width // 2
     _check_width(L)
     solved = np.zeros(n, np.int32)
-    pa = np.empty((n, path_cap), np.int32)
-    pl = np.empty((n, path_cap), np.int32)
+    pa, pl = _path_buffers(n, path_cap)
     pn = np.zeros(n, np.int64)
     rcs = np.zeros(n, np.int32)
     stats = (_acx.SearchStats * n)()
@@ -100,6 +113,19 @@ def _collect(n, solved, pa, pl, pn, rcs, stats, redo):
     cols = [st[f].tolist() for f in ("nodes", "expanded", "children", "levels", "min_len", "seconds")]
     ok, cnt, codes = solved.tolist(), pn.tolist(), rcs.tolist()
     out = []
+    # (tens of thousands of tuples and a dict per search, none of them part of a cycle: the collector's generation counts would trigger
+    # several full passes over the caller's heap in the middle of this loop -- 3 ms of conversion became 8)
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        _collect_rows(n, ok, cnt, codes, pa, pl, cols, redo, out)
+    finally:
+        if gc_was_on:
+            gc.enable()
+    return out
+
+
+def _collect_rows(n, ok, cnt, codes, pa, pl, cols, redo, out):
     for k in range(n):
         if codes[k] == _acx.E_CAPACITY:
             out.append(redo(k))
@@ -107,7 +133,6 @@ def _collect(n, solved, pa, pl, pn, rcs, stats, redo):
         m = cnt[k]
         path = list(zip(pa[k, :m].tolist(), pl[k, :m].tolist())) if m else None
         out.append((bool(ok[k]), path, dict(nodes=cols[0][k], expanded=cols[1][k], children=cols[2][k], levels=cols[3][k], min_len=cols[4][k], seconds=cols[5][k])))
-    return out
 
 
 def run_search_groups(kind, groups, max_nodes_to_explore, cyclical, n_threads=16, path_cap=4096):
@@ -128,8 +153,7 @@ def run_search_groups(kind, groups, max_nodes_to_explore, cyclical, n_threads=16
     n = int(counts.sum())
     ptrs = (C.POINTER(C.c_int8) * ng)(*[_acx.ptr(r, C.c_int8) for r in rows])
     solved = np.zeros(n, np.int32)
-    pa = np.empty((n, path_cap), np.int32)
-    pl = np.empty((n, path_cap), np.int32)
+    pa, pl = _path_buffers(n, path_cap)
     pn = np.zeros(n, np.int64)
     rcs = np.zeros(n, np.int32)
     stats = (_acx.SearchStats * n)()

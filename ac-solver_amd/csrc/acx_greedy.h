@@ -1235,7 +1235,13 @@ __global__ void __launch_bounds__(kGreedyMultiThreads, ACX_GREEDY_MULTI_WAVES_PE
         g.nlen = min(jb.nlen, nlen_cap);
         g.d.L = jb.L;
         uint32_t hi = 0;
+        const unsigned long long wall0 = __builtin_amdgcn_s_memrealtime();  // (the chip's 100 MHz counter: where the job sits in the launch, for ACX_DEBUG's timeline)
         greedy_run<W, greedy_cfg<W>::kSortCap, kGreedyMultiThreads, NF>(g, outs + j, path_act + (size_t)j * path_cap, path_len + (size_t)j * path_cap, path_cap, &hi);
+        if (tid == 0) {
+            outs[j].t_phase[21] = blockIdx.x;
+            outs[j].t_phase[22] = wall0;
+            outs[j].t_phase[23] = __builtin_amdgcn_s_memrealtime();
+        }
         used = 1;
         prev_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
         prev_nlen = g.nlen;

@@ -21,6 +21,57 @@ struct SearchGroupIn {
     int L;
     int64_t out0;
 };
+// The streams of a call come from a pool and go back to it (synchronised), as the stream pairs of acx_search do: a call used to create
+// and destroy three -- one for the set-up, a high- and a low-priority one for the two launches.  Classes: 0 default priority, 1 highest,
+// 2 lowest.  (What the pool does NOT cure, measured in round 6: from the third sweep of a process on, the first device operation of a
+// call -- two fills of a few bytes -- completes 10-25 ms after it was enqueued, whatever stream it is on and however the host waits;
+// rocprofv3 shows the device idle until then.  The second sweep of a process does not have it, a sweep behind a 0.2 s pause has it less.)
+struct StreamLease {
+    hipStream_t s = nullptr;
+    int cls = 0, dev = 0;
+    struct Pooled {
+        hipStream_t s;
+        int cls, dev;
+    };
+    static std::mutex& mu() {
+        static std::mutex m;
+        return m;
+    }
+    static std::vector<Pooled>& pool() {
+        static std::vector<Pooled> p;
+        return p;
+    }
+    int take(int cls_) {
+        cls = cls_;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lock(mu());
+            auto& p = pool();
+            for (size_t i = 0; i < p.size(); i++)
+                if (p[i].cls == cls && p[i].dev == dev) {
+                    s = p[i].s;
+                    p[i] = p.back();
+                    p.pop_back();
+                    return ACX_OK;
+                }
+        }
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (cls == 0) ACX_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        else ACX_HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, cls == 1 ? hi : lo));
+        return ACX_OK;
+    }
+    StreamLease() = default;
+    StreamLease(const StreamLease&) = delete;
+    StreamLease& operator=(const StreamLease&) = delete;
+    ~StreamLease() {
+        if (!s) return;
+        (void)hipStreamSynchronize(s);
+        std::lock_guard<std::mutex> lock(mu());
+        pool().push_back({s, cls, dev});
+    }
+};
+
 // workgroups of k_greedy_sched the device holds at once: kGreedyPerCu per compute unit (512 on an MI355X: 256 compute units)
 static uint32_t greedy_resident() {
     int dev = 0, cus = 256;
@@ -103,12 +154,11 @@ struct GreedySlots {
             ACX_HIP_TRY(hipMemsetAsync(base, 0xff, m * b_tab, st));
             ACX_HIP_TRY(hipMemsetAsync(base + m * b_tab, 0, m * (b_bk + b_bm), st));
         }
+        // every slot free: all-ones words, the last one cut to the slots that exist (device fills: no host buffer, no synchronisation here)
         words = (S + 31) / 32;
-        std::vector<uint32_t> bits(words, 0);
-        for (uint32_t r = 0; r < S; r++) bits[r >> 5] |= 1u << (r & 31);
         if (free_bits.alloc((size_t)words * 4)) return ACX_E_NOMEM;
-        ACX_HIP_TRY(hipMemcpyAsync(free_bits.p, bits.data(), (size_t)words * 4, hipMemcpyHostToDevice, st));
-        ACX_HIP_TRY(hipStreamSynchronize(st));  // (`bits` is a pageable host buffer of this scope)
+        ACX_HIP_TRY(hipMemsetAsync(free_bits.p, 0xff, (size_t)words * 4, st));
+        if (S & 31u) ACX_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)((uint32_t*)free_bits.p + (words - 1)), (int)((1u << (S & 31u)) - 1u), 1, st));
         big_n = 0;
         if (sort_cap > scratch_cap) {  // buckets of more than half the slot's scratch: a few full-size regions for all slots
             big_key_bytes = up(sort_cap * key_bytes);
@@ -234,19 +284,10 @@ static int run_greedy_sched(const GreedySlots& pool, const std::vector<SearchGro
     std::vector<GreedyDev<W>> hslots;
     pool.describe<W>(hslots, cyclical, max_nodes);
     DevBuf dslots, djobs, dcounter, douts, dpa, dpl;
-    hipStream_t st = nullptr;
-    {  // the 128-bit searches are the longer ones: when both widths are in flight their workgroups get a free compute unit first
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        ACX_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, sizeof(W) > 8 ? hi : lo));
-    }
-    struct StreamGuard {
-        hipStream_t s;
-        ~StreamGuard() {
-            (void)hipStreamSynchronize(s);
-            (void)hipStreamDestroy(s);
-        }
-    } guard{st};
+    // the 128-bit searches are the longer ones: when both widths are in flight their workgroups get a free compute unit first
+    StreamLease lease;  // (declared behind the device buffers: synchronised before they go back to the pool)
+    if (lease.take(sizeof(W) > 8 ? 1 : 2) != ACX_OK) return ACX_E_NODEVICE;
+    hipStream_t st = lease.s;
     const int64_t pc = std::max<int64_t>(path_cap, 1);
     if (dslots.alloc((size_t)R * sizeof(GreedyDev<W>)) || djobs.alloc((size_t)n_most * sizeof(GreedyJob<W>)) || dcounter.alloc(256) ||
         douts.alloc((size_t)n_most * sizeof(GreedyOut)) || dpa.alloc((size_t)n_most * pc * 4) || dpl.alloc((size_t)n_most * pc * 4))
@@ -338,6 +379,30 @@ static int run_greedy_sched(const GreedySlots& pool, const std::vector<SearchGro
                 if (tot)
                     fprintf(stderr, "[acx_greedy_sched] job cycles: longest %.3e, median %.3e, p90 %.3e; searches longer than half the longest: first at job %zu, last at job %zu of %zu\n",
                             (double)sorted_c[nj - 1], (double)sorted_c[nj / 2], (double)sorted_c[nj * 9 / 10], first_long, last_long, nj);
+            }
+            {  // the launch's timeline from the jobs' own stamps (100 MHz counter): how long the jobs are, when the long ones started, how busy the workgroups were
+                unsigned long long t_first = ~0ull, t_last = 0;
+                for (size_t j = 0; j < nj; j++) t_first = std::min(t_first, o[j].t_phase[22]), t_last = std::max(t_last, o[j].t_phase[23]);
+                std::vector<size_t> idx(nj);
+                for (size_t j = 0; j < nj; j++) idx[j] = j;
+                std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return o[a].t_phase[23] - o[a].t_phase[22] > o[b].t_phase[23] - o[b].t_phase[22]; });
+                double busy = 0;
+                for (size_t j = 0; j < nj; j++) busy += (double)(o[j].t_phase[23] - o[j].t_phase[22]) * 1e-5;
+                fprintf(stderr, "[acx_greedy_sched] timeline: first job starts at raw %.2f ms, last job ends %.2f ms later; jobs' own time %.1f ms in all = %.2f ms on each of %u workgroups\n",
+                        (double)(t_first % 100000000ull) * 1e-5, (double)(t_last - t_first) * 1e-5, busy, busy / grid, grid);
+                for (size_t q = 0; q < std::min<size_t>(nj, 10); q++) {
+                    const GreedyOut& x = o[idx[q]];
+                    fprintf(stderr, "[acx_greedy_sched]   job %zu (L %d, root length %u, %s, %llu batches): %.2f ms, started at %.2f, workgroup %llu\n", idx[q], jobs[code][idx[q]].L, jobs[code][idx[q]].root_len,
+                            x.status == GREEDY_SOLVED ? "solved" : "unsolved", (unsigned long long)x.batches, (double)(x.t_phase[23] - x.t_phase[22]) * 1e-5, (double)(x.t_phase[22] - t_first) * 1e-5, x.t_phase[21]);
+                }
+                size_t late = 0;  // jobs of at least half the longest that started in the launch's second half
+                const unsigned long long longest = o[idx[0]].t_phase[23] - o[idx[0]].t_phase[22];
+                for (size_t j = 0; j < nj; j++)
+                    if (2 * (o[j].t_phase[23] - o[j].t_phase[22]) >= longest && 2 * (o[j].t_phase[22] - t_first) >= t_last - t_first) late++;
+                double dur[5];
+                for (int q = 0; q < 5; q++) dur[q] = (double)(o[idx[std::min(nj - 1, nj * (size_t)q / 4)]].t_phase[23] - o[idx[std::min(nj - 1, nj * (size_t)q / 4)]].t_phase[22]) * 1e-5;
+                fprintf(stderr, "[acx_greedy_sched]   job ms: max %.2f, upper quartile %.2f, median %.2f, lower quartile %.2f, min %.2f; %zu jobs of at least half the longest started in the second half\n", dur[0], dur[1],
+                        dur[2], dur[3], dur[4], late);
             }
             fprintf(stderr, "[acx_greedy_sched] %zu searches on %u workgroups (%s move code), %llu batches, %llu sorts (%llu of buckets larger than the LDS), launch %.2f ms; host: launched at %.1f ms, results at %.1f ms\n", nj, grid,
                     code ? "normal-form" : "general", batches, sorts, bigs, ms, t_launched, since());
@@ -704,11 +769,11 @@ extern "C" int acx_search_groups(int kind, int n_groups, const int8_t* const* h_
     auto since_call = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
     GreedySlots pool;
     {
-        hipStream_t st0 = nullptr;
-        ACX_HIP_TRY(hipStreamCreateWithFlags(&st0, hipStreamNonBlocking));
+        StreamLease l0;
+        if (l0.take(0) != ACX_OK) return ACX_E_NODEVICE;
+        hipStream_t st0 = l0.s;
         int rc0 = pool.setup(n_all, max_nodes, L_max, !wide.empty(), greedy_slots_wanted(), st0);
         if (rc0 == ACX_OK && hipStreamSynchronize(st0) != hipSuccess) rc0 = fail(ACX_E_NODEVICE, "acx_search_groups: setting up the slots failed");
-        (void)hipStreamDestroy(st0);
         if (rc0 != ACX_OK) return rc0;
     }
     const double t_setup = since_call();
@@ -748,7 +813,12 @@ extern "C" int acx_search_groups(int kind, int n_groups, const int8_t* const* h_
                                         side.joinable() ? &wide_launched : nullptr);
     if (side.joinable()) side.join();
     else if (!wide.empty()) rc_wide = run_greedy_sched<u128>(pool, wide, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), wgs_wide);
-    if (g_debug) fprintf(stderr, "[acx_search_groups] %u slots of %.0f MB set up in %.1f ms; both launches done at %.1f ms\n", pool.S, pool.per_slot / 1e6, t_setup, since_call());
+    if (g_debug) {
+        size_t clean = 0;
+        for (uint8_t c : pool.was_clean) clean += c;
+        fprintf(stderr, "[acx_search_groups] %u slots of %.0f MB in %zu blocks (%zu of them came back clean from the pool) set up in %.1f ms; both launches done at %.1f ms\n", pool.S, pool.per_slot / 1e6,
+                pool.groups.size(), clean, t_setup, since_call());
+    }
     if (rc == ACX_OK && rc_wide == ACX_OK) pool.mark_clean();
     if (rc != ACX_OK) return rc;
     if (rc_wide != ACX_OK) return err_wide.empty() ? rc_wide : fail(rc_wide, "%s", err_wide.c_str());
@@ -788,11 +858,11 @@ extern "C" int acx_search_many(int kind, const int8_t* h_presentations, int64_t 
         const std::vector<SearchGroupIn> one{SearchGroupIn{h_presentations, n, L, 0}};
         GreedySlots pool;
         {
-            hipStream_t st0 = nullptr;
-            ACX_HIP_TRY(hipStreamCreateWithFlags(&st0, hipStreamNonBlocking));
+            StreamLease l0;
+            if (l0.take(0) != ACX_OK) return ACX_E_NODEVICE;
+            hipStream_t st0 = l0.s;
             int rc0 = pool.setup(n, max_nodes, L, L > 29, greedy_slots_wanted(), st0);
             if (rc0 == ACX_OK && hipStreamSynchronize(st0) != hipSuccess) rc0 = fail(ACX_E_NODEVICE, "acx_search_many: setting up the slots failed");
-            (void)hipStreamDestroy(st0);
             if (rc0 != ACX_OK) return rc0;
         }
         const int rc = L <= 29   ? run_greedy_sched<uint64_t>(pool, one, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), pool.S)

@@ -14,7 +14,7 @@ slots = int(sys.argv[3]) if len(sys.argv) > 3 else -1  # ACX_OPT_GREEDY_SLOTS (-
 _acx.check(_acx.lib.acx_set_option(_acx.OPT_GREEDY_SLOTS, slots))
 kind, cyc = (_acx.SEARCH_BFS, True) if algo == "bfs" else (_acx.SEARCH_GREEDY, False)
 groups = [np.array([p for w in range(1, 8) for p in g["by_n"][str(n)][str(w)]], dtype=np.int8) for n in range(1, 8)]
-for rep in range(3):
+for rep in range(int(os.environ.get("REPS", "3"))):
     t0 = time.perf_counter()
     res = run_search_groups(kind, groups, budget, cyc)
     dt = time.perf_counter() - t0

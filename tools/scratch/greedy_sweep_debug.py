@@ -11,7 +11,7 @@ groups = []
 for n in range(1, 8):
     d = generate_miller_schupp_presentations(n, 7)
     groups.append(np.array([q for w in range(1, 8) for q in d[w]], dtype=np.int8))
-for rep in range(3):
+for rep in range(int(os.environ.get("REPS", "3"))):
     print(f"---- call {rep}", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     run_search_groups(_acx.SEARCH_GREEDY, groups, 10**6, False)
