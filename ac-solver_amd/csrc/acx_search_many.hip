@@ -808,9 +808,10 @@ extern "C" int acx_search_groups(int kind, int n_groups, const int8_t* const* h_
             if (rc_wide != ACX_OK) err_wide = acx_last_error();
         });
     int rc = ACX_OK;
-    if (!narrow.empty())
+    if (!narrow.empty()) {
         rc = run_greedy_sched<uint64_t>(pool, narrow, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), wgs_narrow, nullptr,
                                         side.joinable() ? &wide_launched : nullptr);
+    }
     if (side.joinable()) side.join();
     else if (!wide.empty()) rc_wide = run_greedy_sched<u128>(pool, wide, max_nodes, cyclical, solved, path_action, path_len, path_cap, path_n, stats, rc_out, rerun.data(), wgs_wide);
     if (g_debug) {
