@@ -21,11 +21,61 @@ struct SearchGroupIn {
     int L;
     int64_t out0;
 };
+// Pinned host memory for the results of a launch, from a pool (never freed: no HIP calls at process exit).  The launches of a greedy sweep
+// read 40 MB of path buffers back.  Into pageable vectors the runtime pins those pages for the copy and unpins them afterwards, and the
+// device's NEXT operation -- the first fill of the next call, on any stream -- then completed 10-25 ms after it was enqueued (round 6:
+// from the third sweep of a process on, rocprofv3 showing the device idle until a point on a 10 ms grid; the sweep's later repetitions
+// took 0.15-0.16 s against the second's 0.135).
+struct HostBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    struct Pooled {
+        void* p;
+        size_t bytes;
+    };
+    static std::mutex& mu() {
+        static std::mutex m;
+        return m;
+    }
+    static std::vector<Pooled>& pool() {
+        static std::vector<Pooled>* v = new std::vector<Pooled>();
+        return *v;
+    }
+    int alloc(size_t want) {
+        want = want ? want : 1;
+        {
+            std::lock_guard<std::mutex> lock(mu());
+            auto& v = pool();
+            size_t best = v.size();
+            for (size_t i = 0; i < v.size(); i++)
+                if (v[i].bytes >= want && v[i].bytes <= 2 * want + 4096 && (best == v.size() || v[i].bytes < v[best].bytes)) best = i;
+            if (best != v.size()) {
+                p = v[best].p, bytes = v[best].bytes;
+                v[best] = v.back();
+                v.pop_back();
+                return ACX_OK;
+            }
+        }
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+            p = nullptr;
+            return fail(ACX_E_NOMEM, "hipHostMalloc(%zu) failed", want);
+        }
+        bytes = want;
+        return ACX_OK;
+    }
+    HostBuf() = default;
+    HostBuf(const HostBuf&) = delete;
+    HostBuf& operator=(const HostBuf&) = delete;
+    ~HostBuf() {
+        if (!p) return;
+        std::lock_guard<std::mutex> lock(mu());
+        pool().push_back({p, bytes});
+    }
+};
+
 // The streams of a call come from a pool and go back to it (synchronised), as the stream pairs of acx_search do: a call used to create
 // and destroy three -- one for the set-up, a high- and a low-priority one for the two launches.  Classes: 0 default priority, 1 highest,
-// 2 lowest.  (What the pool does NOT cure, measured in round 6: from the third sweep of a process on, the first device operation of a
-// call -- two fills of a few bytes -- completes 10-25 ms after it was enqueued, whatever stream it is on and however the host waits;
-// rocprofv3 shows the device idle until then.  The second sweep of a process does not have it, a sweep behind a 0.2 s pause has it less.)
+// 2 lowest.
 struct StreamLease {
     hipStream_t s = nullptr;
     int cls = 0, dev = 0;
@@ -320,11 +370,17 @@ static int run_greedy_sched(const GreedySlots& pool, const std::vector<SearchGro
         if (launched) launched->store(1);
         ACX_HIP_TRY(hipEventRecord(evs.b, st));
         const double t_launched = since();
-        std::vector<GreedyOut> o(nj);
-        std::vector<int32_t> pa(nj * (size_t)pc), pl(nj * (size_t)pc);
-        ACX_HIP_TRY(hipMemcpyAsync(o.data(), douts.p, nj * sizeof(GreedyOut), hipMemcpyDeviceToHost, st));
-        ACX_HIP_TRY(hipMemcpyAsync(pa.data(), dpa.p, nj * (size_t)pc * 4, hipMemcpyDeviceToHost, st));
-        ACX_HIP_TRY(hipMemcpyAsync(pl.data(), dpl.p, nj * (size_t)pc * 4, hipMemcpyDeviceToHost, st));
+        HostBuf ho, hpa, hpl;
+        if (ho.alloc(nj * sizeof(GreedyOut)) || hpa.alloc(nj * (size_t)pc * 4) || hpl.alloc(nj * (size_t)pc * 4)) return ACX_E_NOMEM;
+        struct View {  // (what the code below indexes)
+            int32_t* q;
+            int32_t* data() const { return q; }
+        };
+        const GreedyOut* o = (const GreedyOut*)ho.p;
+        const View pa{(int32_t*)hpa.p}, pl{(int32_t*)hpl.p};
+        ACX_HIP_TRY(hipMemcpyAsync(ho.p, douts.p, nj * sizeof(GreedyOut), hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipMemcpyAsync(hpa.p, dpa.p, nj * (size_t)pc * 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipMemcpyAsync(hpl.p, dpl.p, nj * (size_t)pc * 4, hipMemcpyDeviceToHost, st));
         ACX_HIP_TRY(hipStreamSynchronize(st));
         float ms = 0;
         ACX_HIP_TRY(hipEventElapsedTime(&ms, evs.a, evs.b));
@@ -614,15 +670,24 @@ static int run_bfs_group_fused(const int8_t* rows, int64_t n, int L, int64_t max
             any_path = true;
         }
     }
-    std::vector<int32_t> pa, pl;
-    std::vector<uint32_t> pn((size_t)n, 0);
+    // (pinned, pooled host buffers: the runtime pins and unpins the pages of a pageable target around every copy, and the device's next
+    // operation then waits for the unmapping -- 10-25 ms behind the greedy sweep's 40 MB, round 6)
+    HostBuf hpa, hpl, hpn;
+    struct View {
+        int32_t* q;
+        int32_t* data() const { return q; }
+    };
+    View pa{nullptr}, pl{nullptr};
+    if (hpn.alloc((size_t)n * 4)) return ACX_E_NOMEM;
+    uint32_t* pn = (uint32_t*)hpn.p;
+    memset(pn, 0, (size_t)n * 4);
     if (any_path) {
-        pa.resize((size_t)n * pc);
-        pl.resize((size_t)n * pc);
+        if (hpa.alloc((size_t)n * pc * 4) || hpl.alloc((size_t)n * pc * 4)) return ACX_E_NOMEM;
+        pa.q = (int32_t*)hpa.p, pl.q = (int32_t*)hpl.p;
         ACX_HIP_TRY(hipMemcpyAsync(dwant.p, want.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_paths_many<W>, sgrid, sblock, 0, st, q, un, (const uint32_t*)dwant.p, (int32_t*)dpa.p, (int32_t*)dpl.p, (uint32_t*)dpn.p, (long long)pc);
         ACX_HIP_TRY(hipGetLastError());
-        ACX_HIP_TRY(hipMemcpyAsync(pn.data(), dpn.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        ACX_HIP_TRY(hipMemcpyAsync(pn, dpn.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
         ACX_HIP_TRY(hipMemcpyAsync(pa.data(), dpa.p, (size_t)n * pc * 4, hipMemcpyDeviceToHost, st));
         ACX_HIP_TRY(hipMemcpyAsync(pl.data(), dpl.p, (size_t)n * pc * 4, hipMemcpyDeviceToHost, st));
     }
