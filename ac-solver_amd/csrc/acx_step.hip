@@ -657,7 +657,8 @@ static uint8_t* step_staging(size_t bytes) {
     buf = nullptr;
     cap = 0;
     const size_t want = bytes + bytes / 2 + 4096;
-    if (hipHostMalloc((void**)&buf, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    // (portable + mapped: the kernels of a small call read and write this block themselves, on whichever device the thread has current)
+    if (hipHostMalloc((void**)&buf, want, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return nullptr;
     cap = want;
     return buf;
 }
