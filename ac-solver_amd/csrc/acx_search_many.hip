@@ -68,8 +68,16 @@ struct HostBuf {
     HostBuf& operator=(const HostBuf&) = delete;
     ~HostBuf() {
         if (!p) return;
-        std::lock_guard<std::mutex> lock(mu());
-        pool().push_back({p, bytes});
+        {
+            std::lock_guard<std::mutex> lock(mu());
+            size_t held = 0;
+            for (const Pooled& q : pool()) held += q.bytes;
+            if (held + bytes <= (512ull << 20)) {  // (a sweep's buffers are 40 MB; beyond half a gigabyte of idle pinned memory a buffer goes back to the driver)
+                pool().push_back({p, bytes});
+                return;
+            }
+        }
+        (void)hipHostFree(p);
     }
 };
 
