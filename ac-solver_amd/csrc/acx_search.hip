@@ -513,8 +513,12 @@ extern "C" int acx_search_last_digest(uint64_t* digest) {
     return ACX_OK;
 }
 
+namespace acx {
+void host_buffers_trim();  // acx_search_many.hip: the pinned result buffers of the sweeps
+}
 extern "C" int acx_release_cached_memory(void) {
     block_pool().trim();
+    acx::host_buffers_trim();
     return ACX_OK;
 }
 

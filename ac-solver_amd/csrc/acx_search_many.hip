@@ -81,6 +81,15 @@ struct HostBuf {
     }
 };
 
+void host_buffers_trim() {  // acx_release_cached_memory: the idle pinned buffers go back to the driver too
+    std::vector<HostBuf::Pooled> old;
+    {
+        std::lock_guard<std::mutex> lock(HostBuf::mu());
+        old.swap(HostBuf::pool());
+    }
+    for (const HostBuf::Pooled& q : old) (void)hipHostFree(q.p);
+}
+
 // The streams of a call come from a pool and go back to it (synchronised), as the stream pairs of acx_search do: a call used to create
 // and destroy three -- one for the set-up, a high- and a low-priority one for the two launches.  Classes: 0 default priority, 1 highest,
 // 2 lowest.

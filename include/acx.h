@@ -187,7 +187,8 @@ int acx_search_digest_enable(int on);
 int acx_search_last_digest(uint64_t *digest);
 
 /* acx_search keeps the device blocks of a finished search for the next search of the same host thread (hipMalloc /
- * hipFree are slow and hipFree synchronises the device); this returns the calling thread's cached blocks to the driver */
+ * hipFree are slow and hipFree synchronises the device); this returns the cached blocks -- and the idle pinned host buffers the
+ * sweeps read their results into -- to the driver */
 int acx_release_cached_memory(void);
 
 /* n independent searches of the same kind / budget (the batch driver trivialize_miller_schupp_through_search,
