@@ -232,3 +232,54 @@ def test_bfs_dispatches_to_the_collective_form_only_when_switched_on(monkeypatch
         B.shard_over_process_group(None)
     assert B.bfs(p, 500) == (False, None) and calls[-1][0] == "single"
     assert B.bfs.__name__ == "bfs"  # miller_schupp.py:130-133 asserts on it
+
+
+def test_result_conversion_of_the_batch_drivers():
+    """_common._collect / _path_buffers (host side of run_search_many / run_search_groups): the (n, path_cap) arrays are kept per thread
+    and shape, the tuples come out as the reference's (plain ints, None for a search without a path), and the collector is left as it was"""
+    import gc
+    import threading
+
+    from ac_solver import _acx
+    from ac_solver.search import _common
+
+    pa, pl = _common._path_buffers(5, 16)
+    assert pa.shape == pl.shape == (5, 16) and pa is not pl
+    again = _common._path_buffers(5, 16)
+    assert again[0] is pa and again[1] is pl  # same shape, same thread: the same arrays (their pages are mapped already)
+    other = _common._path_buffers(6, 16)
+    assert other[0] is not pa and other[0].shape == (6, 16)
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(_common._path_buffers(6, 16)[0]))
+    t.start()
+    t.join()
+    assert seen[0] is not other[0]  # another thread, another pair
+
+    n = 3
+    solved = np.array([1, 0, 0], np.int32)
+    pa, pl = _common._path_buffers(n, 8)
+    pa[:] = 99
+    pl[:] = 99
+    pa[0, :3] = [-1, 4, 7]
+    pl[0, :3] = [9, 6, 2]
+    pa[1, :2] = [-1, 11]
+    pl[1, :2] = [9, 10]
+    pn = np.array([3, 2, 0], np.int64)
+    rcs = np.zeros(n, np.int32)
+    stats = (_acx.SearchStats * n)()
+    stats[0].nodes, stats[1].nodes, stats[2].min_len = 17, 1000, 5
+    for was_on in (True, False):
+        (gc.enable if was_on else gc.disable)()
+        try:
+            out = _common._collect(n, solved, pa, pl, pn, rcs, stats, lambda k: pytest.fail("no search outgrew its buffer"))
+            assert gc.isenabled() == was_on
+        finally:
+            gc.enable()
+        assert out[0][0] is True and out[0][1] == [(-1, 9), (4, 6), (7, 2)] and out[0][2]["nodes"] == 17
+        assert out[1][0] is False and out[1][1] == [(-1, 9), (11, 10)] and out[1][2]["nodes"] == 1000
+        assert out[2][1] is None and out[2][2]["min_len"] == 5
+        assert all(type(v) is int for pair in out[0][1] for v in pair)
+    # a search whose path outgrew the buffer is redone alone
+    rcs[2] = _acx.E_CAPACITY
+    out = _common._collect(n, solved, pa, pl, pn, rcs, stats, lambda k: ("redone", k))
+    assert out[2] == ("redone", 2)
