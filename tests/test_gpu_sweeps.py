@@ -48,3 +48,22 @@ def test_bfs_sweep_reproduces_published_278(golden_json):
     g = golden_json("ms_pool.json")
     paths = _sweep(_acx.SEARCH_BFS, ms_pool_generator_order(g), 10**6, True)
     assert sorted(paths) == sorted(g["bfs_solved_order"]) and len(paths) == 278
+
+
+def test_sweeps_repeat_and_survive_a_release_of_the_cached_memory(golden_json):
+    """the batch drivers keep device blocks, streams, pinned result buffers and (Python side) their path arrays between calls: a second
+    call, a call behind acx_release_cached_memory and a call with another shape give the first call's results"""
+    from ac_solver import _acx
+    from ac_solver.search._common import run_search_groups
+
+    g = golden_json("ms_pool.json")
+    groups = [np.array([p for w in range(5, 8) for p in g["by_n"][str(n)][str(w)]], dtype=np.int8) for n in range(1, 6)]
+    flat = lambda res: [(ok, path, st["nodes"]) for r in res for ok, path, st in r]  # noqa: E731
+    for kind, cyc in ((_acx.SEARCH_GREEDY, False), (_acx.SEARCH_BFS, True)):
+        first = flat(run_search_groups(kind, groups, 20000, cyc))
+        assert any(ok for ok, _, _ in first) and not all(ok for ok, _, _ in first)
+        assert flat(run_search_groups(kind, groups, 20000, cyc)) == first
+        _acx.check(_acx.lib.acx_release_cached_memory(), "acx_release_cached_memory")
+        assert flat(run_search_groups(kind, groups, 20000, cyc)) == first
+        fewer = flat(run_search_groups(kind, groups[:2], 20000, cyc, path_cap=512))  # other (n, path_cap): other host arrays
+        assert fewer == first[:len(fewer)]
